@@ -1,0 +1,196 @@
+/*
+ * gdmix_re.h — C ABI of libgdmix_re.so, the MI355X-native random-effect (RE) trainer hot path.
+ *
+ * The reference (linkedin/gdmix, Python/TF/scipy, CPU only) has no FFI; the boundary this library
+ * replaces is the body of three Python call sites (paths relative to the reference checkout):
+ *
+ *   prepare_jobs            gdmix-trainer/src/gdmix/models/custom/scipy/job_consumers.py:161-296
+ *        -> gdmix_re_pack       (per-entity np.unique / local indexing / COO build, :243-250)
+ *   BinaryLogisticRegressionTrainer.fit
+ *                           gdmix-trainer/src/gdmix/models/custom/binary_logistic_regression.py:191-239
+ *        -> gdmix_re_solve      (_loss :84-110, _gradient :121-131, scipy fmin_l_bfgs_b :223-231,
+ *                                _compute_variance :144-189, threshold model_utils.py:4-12)
+ *   BinaryLogisticRegressionTrainer.predict_proba(return_logits=True)
+ *                           binary_logistic_regression.py:241-262, job_consumers.py:138-152
+ *        -> gdmix_re_score
+ *   Math.abs(id.toString.hashCode) % numPartitions
+ *                           gdmix-data/src/main/scala/com/linkedin/gdmix/utils/PartitionUtils.scala:31-37
+ *        -> gdmix_java_partition_id / gdmix_java_string_hash
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative GDMIX_RE_E* code; nothing throws or aborts;
+ *     gdmix_re_last_error() returns a thread-local NUL-terminated message for the last failure.
+ *   - the caller owns every buffer. Device buffers may come from any allocator bound to the context's
+ *     HIP device (the Python host passes torch tensor data_ptr()s). The library never frees or
+ *     retains caller memory after the work enqueued on `stream` has completed.
+ *   - all device work is enqueued on the caller's `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and is asynchronous with respect to the host unless stated otherwise.
+ *   - a context is bound to one HIP device; calls on one context must be serialised by the caller.
+ *   - all arithmetic of the solver is IEEE fp64 on fp32-valued inputs, as in the reference.
+ */
+#ifndef GDMIX_RE_H_
+#define GDMIX_RE_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDMIX_RE_ABI_VERSION 1
+
+/* error codes */
+#define GDMIX_RE_OK          0
+#define GDMIX_RE_EINVAL    (-1)   /* bad argument */
+#define GDMIX_RE_EHIP      (-2)   /* a HIP runtime call failed (no device, launch failure, ...) */
+#define GDMIX_RE_ENOMEM    (-3)   /* workspace too small */
+#define GDMIX_RE_ERANGE    (-4)   /* an entity exceeds an int32 per-entity limit */
+
+/* per-entity solver status, mirrors scipy fmin_l_bfgs_b's task/warnflag */
+#define GDMIX_RE_ST_PGTOL     0   /* CONVERGENCE: NORM OF PROJECTED GRADIENT <= PGTOL      */
+#define GDMIX_RE_ST_FACTR     1   /* CONVERGENCE: REL_REDUCTION_OF_F <= FACTR*EPSMCH         */
+#define GDMIX_RE_ST_MAXITER   2   /* STOP: TOTAL NO. of ITERATIONS REACHED LIMIT             */
+#define GDMIX_RE_ST_MAXFUN    3   /* STOP: TOTAL NO. of f AND g EVALUATIONS EXCEEDS LIMIT    */
+#define GDMIX_RE_ST_ABNORMAL  4   /* ABNORMAL_TERMINATION_IN_LNSRCH                          */
+/* "converged" for the entities/sec metric = status in {PGTOL, FACTR, MAXITER}: the reference treats
+ * all three as a finished model (job_consumers.py:36-63 never looks at warnflag). */
+
+#define GDMIX_RE_VAR_NONE    0
+#define GDMIX_RE_VAR_SIMPLE  1    /* 1/(diag(X'DX) + l2 + 1e-12), binary_logistic_regression.py:175-180 */
+#define GDMIX_RE_VAR_FULL    2    /* diag(inv(X'DX + (l2+1e-12)I)),                         :181-187 */
+
+typedef struct gdmix_re_ctx gdmix_re_ctx;
+
+/* ---- raw entity-grouped batch: exactly what prepare_jobs slices per entity ------------------------
+ * E entities, N samples, Z non-zeros, entity-major then sample-major (the order of the TF sparse
+ * tensors in job_consumers.py:176-199). Pointers are DEVICE pointers for gdmix_re_pack and HOST
+ * pointers for the oracle. */
+typedef struct {
+  int64_t E, N, Z;
+  const int64_t* ent_row_ptr;   /* [E+1] sample offsets of each entity                              */
+  const int64_t* row_nnz_ptr;   /* [N+1] non-zero offsets of each sample                            */
+  const int64_t* col_global;    /* [Z]   global feature index ("<bag>_indices")                     */
+  const float*   val;           /* [Z]   feature value        ("<bag>_values")                      */
+  const float*   y;             /* [N]   label, exactly 0.0f or 1.0f (fit() asserts this, :208)     */
+  const float*   offset;        /* [N]   fixed-effect score (offset_column_name)                    */
+  const float*   weight;        /* [N]   sample weight, or NULL => ones (job_consumers.py:255-256)  */
+} gdmix_re_raw_batch;
+
+/* ---- packed ragged CSR(+CSC) batch in HBM, produced by gdmix_re_pack ------------------------------
+ * All pointers point into the caller-provided workspace (or alias the raw batch for y/offset/weight).
+ * Entity e owns
+ *   samples       [ent_row_ptr[e],  ent_row_ptr[e+1])            n_e
+ *   non-zeros     [ent_nnz_ptr[e],  ent_nnz_ptr[e+1])            z_e  (must be < 2^31)
+ *   features      [ent_feat_ptr[e], ent_feat_ptr[e+1])           d_e  distinct global indices
+ *   coefficients  [ent_feat_ptr[e] + e*has_intercept, +p_e)      p_e = d_e + has_intercept
+ *   row_ptr       [ent_row_ptr[e] + e,  + n_e + 1)   entity-relative nnz offsets (CSR)
+ *   col_ptr       [ent_feat_ptr[e] + e, + d_e + 1)   entity-relative nnz offsets (CSC)
+ * unique_global is sorted ascending inside an entity (np.unique, job_consumers.py:243); csr_col are
+ * local indices 0..d_e-1; the CSC copy is sorted by (local col, sample) so that the transposed
+ * product X'r is an ordered, atomic-free per-coefficient sum. */
+typedef struct {
+  int64_t E, N, Z, D;           /* D = sum of d_e; valid on the host once the pack stream is synced */
+  const int64_t* ent_row_ptr;   /* [E+1] */
+  int64_t*       ent_nnz_ptr;   /* [E+1] */
+  int64_t*       ent_feat_ptr;  /* [E+1] */
+  int32_t*       row_ptr;       /* [N+E] */
+  int32_t*       csr_col;       /* [Z]   */
+  float*         csr_val;       /* [Z]   */
+  int32_t*       col_ptr;       /* [D+E] (allocated Z+E) */
+  int32_t*       csc_row;       /* [Z]   entity-relative sample index */
+  float*         csc_val;       /* [Z]   */
+  int64_t*       unique_global; /* [D]   (allocated Z) local -> global feature index */
+  const float*   y;             /* [N]   */
+  const float*   offset;        /* [N]   */
+  const float*   weight;        /* [N] or NULL */
+  int32_t*       order;         /* [E]   entity ids grouped by size class (solver launch order)     */
+  int32_t*       class_count;   /* [GDMIX_RE_NUM_CLASSES] entities per size class (device)          */
+  void*          scratch;       /* pack-time scratch, reused by the solver for large entities       */
+  size_t         scratch_bytes;
+} gdmix_re_packed;
+
+#define GDMIX_RE_NUM_CLASSES 8
+
+/* ---- solver options (defaults = REParams/LRParams defaults + scipy defaults) ----------------------
+ * base_lr_params.py:22-27, binary_logistic_regression.py:223-231 (pgtol/maxfun/maxls are scipy's). */
+typedef struct {
+  double  l2;               /* l2_reg_weight                          default 1.0   */
+  int32_t regularize_bias;  /*                                        default 1     */
+  int32_t has_intercept;    /*                                        default 1     */
+  int32_t m;                /* num_of_lbfgs_curvature_pairs           default 10    */
+  int32_t max_iter;         /* num_of_lbfgs_iterations                default 100   */
+  int32_t maxfun;           /* scipy default                          15000         */
+  int32_t maxls;            /* scipy default                          20            */
+  double  ftol;             /* = factr*eps = lbfgs_tolerance          default 1e-12 */
+  double  pgtol;            /* scipy default                          1e-5          */
+  int32_t variance_mode;    /* GDMIX_RE_VAR_*                         default NONE  */
+  double  threshold;        /* sparsity_threshold applied to theta_thr, default 1e-4 (model_utils.py:4-12) */
+} gdmix_re_opts;
+
+/* fills *o with the defaults above */
+void gdmix_re_default_opts(gdmix_re_opts* o);
+
+/* ---- per-entity / per-coefficient outputs of a solve (device pointers; any may be NULL) ----------- */
+typedef struct {
+  double*  theta;      /* [P]  raw L-BFGS result (result[0] of fmin_l_bfgs_b), local index space     */
+  double*  theta_thr;  /* [P]  after threshold_coefficients(|x|<=threshold -> 0)                     */
+  double*  variance;   /* [P]  when opts.variance_mode != NONE                                       */
+  double*  fval;       /* [E]  final objective                                                       */
+  double*  gnorm;      /* [E]  max|g| at the returned point                                          */
+  int32_t* nit;        /* [E]                                                                        */
+  int32_t* nfev;       /* [E]                                                                        */
+  int32_t* status;     /* [E]  GDMIX_RE_ST_*                                                         */
+} gdmix_re_result;
+
+int  gdmix_re_abi_version(void);
+const char* gdmix_re_last_error(void);
+
+int  gdmix_re_create(int hip_device, gdmix_re_ctx** out);
+void gdmix_re_destroy(gdmix_re_ctx* ctx);
+
+/* Bytes of device workspace gdmix_re_pack needs for a batch of this shape (upper bound; host-only). */
+size_t gdmix_re_pack_workspace_bytes(int64_t E, int64_t N, int64_t Z);
+
+/* Pack: per entity, unique-sort the global feature indices, re-index the non-zeros locally, build the
+ * CSR and CSC copies and the size-class launch order — all on the device. Fills *out (a host struct
+ * of device pointers into `workspace`). Synchronises `stream` once to read back D and the class
+ * counts. replaces job_consumers.py:209-258 (enable_local_indexing=True form; the reference's
+ * global-indexing form yields identical coefficients on the entity's support). */
+int gdmix_re_pack(gdmix_re_ctx* ctx, const gdmix_re_raw_batch* raw_dev, int has_intercept,
+                  void* workspace, size_t workspace_bytes, gdmix_re_packed* out, void* stream);
+
+/* Solve every entity of the packed batch: the whole L-BFGS loop runs on the device, one wavefront
+ * (or workgroup, for entities that do not fit a wavefront's LDS budget) per entity.
+ * theta0: [P] warm-start coefficients in local index space, or NULL => zeros (fit():220-221). */
+int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* batch, const gdmix_re_opts* opts,
+                   const double* theta0, const gdmix_re_result* out, void* stream);
+
+/* Bytes of device scratch gdmix_re_solve needs beyond the pack workspace (0 if none). */
+size_t gdmix_re_solve_scratch_bytes(const gdmix_re_packed* batch, const gdmix_re_opts* opts);
+int    gdmix_re_set_scratch(gdmix_re_ctx* ctx, void* scratch, size_t bytes);
+
+/* Score: logit[i] = x_i . theta_e + offset[i] (fp64 accumulate, stored fp32 as the score Avro
+ * does, io_utils.py:367-375), logit_per_coord[i] = logit[i] - offset[i] (job_consumers.py:145-150).
+ * has_model: [E] uint8, 0 => entity has no model and logit = offset (job_consumers.py:145-146);
+ * NULL => all entities have one. theta is in the batch's local index space [P]. */
+int gdmix_re_score(gdmix_re_ctx* ctx, const gdmix_re_packed* batch, int has_intercept,
+                   const double* theta, const uint8_t* has_model,
+                   float* logit, float* logit_per_coord, void* stream);
+
+/* Name of the kernel variant that solved size class c (for profiling reports), or NULL. */
+const char* gdmix_re_class_kernel_name(int c);
+
+/* ---- B4: the upstream Spark partitioner's hash, bit-exact (host functions) ------------------------
+ * hashCode over UTF-16 code units in wrapping int32; Math.abs(Int.MinValue) stays negative; Scala %
+ * keeps the dividend's sign (PartitionUtils.scala:31-37). */
+int32_t gdmix_java_string_hash(const uint16_t* utf16, int64_t len);
+int32_t gdmix_java_partition_id(const uint16_t* utf16, int64_t len, int32_t num_partitions);
+/* Batched device form for decimal int64 entity ids (id.toString of a Long): out[i] = partition id. */
+int gdmix_java_partition_ids_i64(gdmix_re_ctx* ctx, const int64_t* ids_dev, int64_t count,
+                                 int32_t num_partitions, int32_t* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDMIX_RE_H_ */

@@ -1,0 +1,580 @@
+/*
+ * re_oracle.c — CPU restatement (plain C, IEEE fp64, scalar, single thread) of the reference's
+ * random-effect hot path. TEST INFRASTRUCTURE ONLY: nothing under gdmix_amd/ may import, link or
+ * call this file; it is the checker for tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg.
+ *
+ * Parity status: PINNED by tests/golden/ fixtures generated in the build container by importing the
+ * reference's own Python (tests/golden/generate_fixtures.py) — theta, f, nit, nfev, stop reason.
+ * The optimiser itself (scipy.optimize.fmin_l_bfgs_b = L-BFGS-B 3.0) is a third-party dependency
+ * that is NOT under /root/reference (pinned scipy==1.5.4 in gdmix-trainer/setup.py:47; the container
+ * that generated the fixtures has scipy 1.15.3, a C translation of the same Fortran). Its published
+ * algorithm is restated here for the unconstrained case (no bounds are ever passed,
+ * binary_logistic_regression.py:223-231), see lbfgs_solve_entity().
+ *
+ * Each function cites the reference lines it follows (paths relative to the reference checkout,
+ * gdmix-trainer/src/gdmix/...).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define EPSMCH 2.220446049250313e-16
+
+/* ------------------------------------------------------------------------------------------------
+ * prepare_jobs: per-entity np.unique(cols, return_inverse=True)   (scipy/job_consumers.py:243)
+ * ---------------------------------------------------------------------------------------------- */
+static int cmp_i64(const void* a, const void* b) {
+  int64_t x = *(const int64_t*)a, y = *(const int64_t*)b;
+  return (x > y) - (x < y);
+}
+
+/* Outputs: ent_nnz_ptr[E+1], ent_feat_ptr[E+1], row_ptr[N+E] (entity-relative), csr_col[Z] (local),
+ * unique_global[<=Z]. Returns D (total distinct features) or <0 on error. */
+int64_t oracle_pack(int64_t E, const int64_t* ent_row_ptr, const int64_t* row_nnz_ptr,
+                    const int64_t* col_global, int64_t* ent_nnz_ptr, int64_t* ent_feat_ptr,
+                    int32_t* row_ptr, int32_t* csr_col, int64_t* unique_global) {
+  int64_t D = 0;
+  ent_nnz_ptr[0] = 0;
+  ent_feat_ptr[0] = 0;
+  for (int64_t e = 0; e < E; ++e) {
+    int64_t r0 = ent_row_ptr[e], r1 = ent_row_ptr[e + 1];
+    int64_t z0 = row_nnz_ptr[r0], z1 = row_nnz_ptr[r1];
+    int64_t nz = z1 - z0;
+    ent_nnz_ptr[e] = z0;
+    ent_nnz_ptr[e + 1] = z1;
+    for (int64_t r = r0; r <= r1; ++r) row_ptr[r + e] = (int32_t)(row_nnz_ptr[r] - z0);
+    int64_t* tmp = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nz > 0 ? nz : 1));
+    if (!tmp) return -1;
+    memcpy(tmp, col_global + z0, sizeof(int64_t) * (size_t)nz);
+    qsort(tmp, (size_t)nz, sizeof(int64_t), cmp_i64);
+    int64_t d = 0;
+    for (int64_t k = 0; k < nz; ++k)
+      if (k == 0 || tmp[k] != tmp[k - 1]) unique_global[D + d++] = tmp[k];
+    free(tmp);
+    for (int64_t k = z0; k < z1; ++k) { /* return_inverse: position in the sorted unique array */
+      int64_t lo = 0, hi = d - 1, key = col_global[k];
+      while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (unique_global[D + mid] < key) lo = mid + 1; else hi = mid;
+      }
+      csr_col[k] = (int32_t)lo;
+    }
+    D += d;
+    ent_feat_ptr[e + 1] = D;
+  }
+  return D;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * One entity's problem
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int n, d, p, ic;            /* samples, local features, coefficients, has_intercept */
+  const int32_t* row_ptr;     /* [n+1] entity-relative */
+  const int32_t* col;         /* local */
+  const float* val;
+  const float *y, *o, *w;     /* w may be NULL */
+  double l2;
+  int reg_bias;
+  double* z;                  /* [n] scratch */
+  double* r;                  /* [n] scratch */
+} problem;
+
+/* sigmoid as scipy.special.expit does for doubles: 1/(1+exp(-x))  (binary_logistic_regression.py:45-51) */
+static double expit_(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+/* X~ theta + offsets, X~ = [1 | X]   (binary_logistic_regression.py:53-65,133-142,219) */
+static void logits_(const problem* P, const double* th, double* z) {
+  for (int i = 0; i < P->n; ++i) {
+    double acc = P->ic ? th[0] : 0.0;
+    for (int k = P->row_ptr[i]; k < P->row_ptr[i + 1]; ++k)
+      acc += (double)P->val[k] * th[P->ic + P->col[k]];
+    z[i] = acc + (double)P->o[i];
+  }
+}
+
+/* _loss (:84-110) and _gradient (:121-131), fused: f and g at theta. */
+static double fg_(const problem* P, const double* th, double* g) {
+  const int n = P->n, p = P->p, ic = P->ic;
+  logits_(P, th, P->z);
+  double cost = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double zi = P->z[i], yi = (double)P->y[i], wi = P->w ? (double)P->w[i] : 1.0;
+    /* max(x,0) - x*y + log(1 + exp(-|x|))   (:103) */
+    double ce = fmax(zi, 0.0) - zi * yi + log(1.0 + exp(-fabs(zi)));
+    cost += wi * ce;
+    P->r[i] = wi * (expit_(zi) - yi);                                  /* (:127) */
+  }
+  /* regularisation (:73-82,:112-119): intercept excluded unless regularize_bias */
+  int first_reg = (ic && !P->reg_bias) ? 1 : 0;
+  double sq = 0.0;
+  for (int j = first_reg; j < p; ++j) sq += th[j] * th[j];
+  double f = (1.0 / n) * (cost + (P->l2 / 2.0) * sq);                  /* (:108) */
+  for (int j = 0; j < p; ++j) g[j] = 0.0;
+  if (ic) for (int i = 0; i < n; ++i) g[0] += P->r[i];
+  for (int i = 0; i < n; ++i)
+    for (int k = P->row_ptr[i]; k < P->row_ptr[i + 1]; ++k)
+      g[ic + P->col[k]] += (double)P->val[k] * P->r[i];               /* X.T.dot(...) (:127) */
+  for (int j = 0; j < p; ++j) {
+    double reg = P->l2 * th[j];
+    if (j < first_reg) reg = 0.0;
+    g[j] = (1.0 / n) * (g[j] + reg);                                   /* (:129) */
+  }
+  return f;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * MINPACK-2 dcsrch/dcstep (More'-Thuente), as called by L-BFGS-B 3.0's lnsrlb with
+ * ftol=1e-3, gtol=0.9, xtol=0.1, stpmin=0, stpmax=1e10.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int brackt, stage;
+  double ginit, gtest, gx, gy, finit, fx, fy, stx, sty, stmin, stmax, width, width1;
+} ls_state;
+
+enum { LS_FG = 0, LS_CONV = 1, LS_WARN = 2 };
+
+#define LS_FTOL 1.0e-3
+#define LS_GTOL 0.9
+#define LS_XTOL 0.1
+#define LS_STPMIN 0.0
+#define LS_STPMAX 1.0e10
+
+static void dcsrch_start(ls_state* S, double f, double g, double stp) {
+  S->brackt = 0;
+  S->stage = 1;
+  S->finit = f;
+  S->ginit = g;
+  S->gtest = LS_FTOL * g;
+  S->width = LS_STPMAX - LS_STPMIN;
+  S->width1 = S->width / 0.5;
+  S->stx = 0.0; S->fx = f; S->gx = g;
+  S->sty = 0.0; S->fy = f; S->gy = g;
+  S->stmin = 0.0;
+  S->stmax = stp + 4.0 * stp;
+}
+
+static void dcstep(double* stx, double* fx, double* dx, double* sty, double* fy, double* dy,
+                   double* stp, double fp, double dp, int* brackt, double stpmin, double stpmax) {
+  double gamma, p, q, r, s, sgnd, stpc, stpf, stpq, theta;
+  sgnd = dp * (*dx / fabs(*dx));
+  if (fp > *fx) {
+    theta = 3.0 * (*fx - fp) / (*stp - *stx) + *dx + dp;
+    s = fmax(fabs(theta), fmax(fabs(*dx), fabs(dp)));
+    gamma = s * sqrt((theta / s) * (theta / s) - (*dx / s) * (dp / s));
+    if (*stp < *stx) gamma = -gamma;
+    p = (gamma - *dx) + theta;
+    q = ((gamma - *dx) + gamma) + dp;
+    r = p / q;
+    stpc = *stx + r * (*stp - *stx);
+    stpq = *stx + ((*dx / ((*fx - fp) / (*stp - *stx) + *dx)) / 2.0) * (*stp - *stx);
+    if (fabs(stpc - *stx) < fabs(stpq - *stx)) stpf = stpc;
+    else stpf = stpc + (stpq - stpc) / 2.0;
+    *brackt = 1;
+  } else if (sgnd < 0.0) {
+    theta = 3.0 * (*fx - fp) / (*stp - *stx) + *dx + dp;
+    s = fmax(fabs(theta), fmax(fabs(*dx), fabs(dp)));
+    gamma = s * sqrt((theta / s) * (theta / s) - (*dx / s) * (dp / s));
+    if (*stp > *stx) gamma = -gamma;
+    p = (gamma - dp) + theta;
+    q = ((gamma - dp) + gamma) + *dx;
+    r = p / q;
+    stpc = *stp + r * (*stx - *stp);
+    stpq = *stp + (dp / (dp - *dx)) * (*stx - *stp);
+    if (fabs(stpc - *stp) > fabs(stpq - *stp)) stpf = stpc;
+    else stpf = stpq;
+    *brackt = 1;
+  } else if (fabs(dp) < fabs(*dx)) {
+    theta = 3.0 * (*fx - fp) / (*stp - *stx) + *dx + dp;
+    s = fmax(fabs(theta), fmax(fabs(*dx), fabs(dp)));
+    gamma = s * sqrt(fmax(0.0, (theta / s) * (theta / s) - (*dx / s) * (dp / s)));
+    if (*stp > *stx) gamma = -gamma;
+    p = (gamma - dp) + theta;
+    q = (gamma + (*dx - dp)) + gamma;
+    r = p / q;
+    if (r < 0.0 && gamma != 0.0) stpc = *stp + r * (*stx - *stp);
+    else if (*stp > *stx) stpc = stpmax;
+    else stpc = stpmin;
+    stpq = *stp + (dp / (dp - *dx)) * (*stx - *stp);
+    if (*brackt) {
+      if (fabs(stpc - *stp) < fabs(stpq - *stp)) stpf = stpc;
+      else stpf = stpq;
+      if (*stp > *stx) stpf = fmin(*stp + 0.66 * (*sty - *stp), stpf);
+      else stpf = fmax(*stp + 0.66 * (*sty - *stp), stpf);
+    } else {
+      if (fabs(stpc - *stp) > fabs(stpq - *stp)) stpf = stpc;
+      else stpf = stpq;
+      stpf = fmin(stpmax, stpf);
+      stpf = fmax(stpmin, stpf);
+    }
+  } else {
+    if (*brackt) {
+      theta = 3.0 * (fp - *fy) / (*sty - *stp) + *dy + dp;
+      s = fmax(fabs(theta), fmax(fabs(*dy), fabs(dp)));
+      gamma = s * sqrt((theta / s) * (theta / s) - (*dy / s) * (dp / s));
+      if (*stp > *sty) gamma = -gamma;
+      p = (gamma - dp) + theta;
+      q = ((gamma - dp) + gamma) + *dy;
+      r = p / q;
+      stpc = *stp + r * (*sty - *stp);
+      stpf = stpc;
+    } else if (*stp > *stx) stpf = stpmax;
+    else stpf = stpmin;
+  }
+  if (fp > *fx) {
+    *sty = *stp; *fy = fp; *dy = dp;
+  } else {
+    if (sgnd < 0.0) { *sty = *stx; *fy = *fx; *dy = *dx; }
+    *stx = *stp; *fx = fp; *dx = dp;
+  }
+  *stp = stpf;
+}
+
+static int dcsrch_step(ls_state* S, double f, double g, double* stp_io) {
+  double stp = *stp_io;
+  int task = LS_FG;
+  double ftest = S->finit + stp * S->gtest;
+  if (S->stage == 1 && f <= ftest && g >= 0.0) S->stage = 2;
+  if (S->brackt && (stp <= S->stmin || stp >= S->stmax)) task = LS_WARN;
+  if (S->brackt && S->stmax - S->stmin <= LS_XTOL * S->stmax) task = LS_WARN;
+  if (stp == LS_STPMAX && f <= ftest && g <= S->gtest) task = LS_WARN;
+  if (stp == LS_STPMIN && (f > ftest || g >= S->gtest)) task = LS_WARN;
+  if (f <= ftest && fabs(g) <= LS_GTOL * (-S->ginit)) task = LS_CONV;
+  if (task != LS_FG) return task;
+  if (S->stage == 1 && f <= S->fx && f > ftest) {
+    double fm = f - stp * S->gtest, fxm = S->fx - S->stx * S->gtest, fym = S->fy - S->sty * S->gtest;
+    double gm = g - S->gtest, gxm = S->gx - S->gtest, gym = S->gy - S->gtest;
+    dcstep(&S->stx, &fxm, &gxm, &S->sty, &fym, &gym, &stp, fm, gm, &S->brackt, S->stmin, S->stmax);
+    S->fx = fxm + S->stx * S->gtest;
+    S->fy = fym + S->sty * S->gtest;
+    S->gx = gxm + S->gtest;
+    S->gy = gym + S->gtest;
+  } else {
+    dcstep(&S->stx, &S->fx, &S->gx, &S->sty, &S->fy, &S->gy, &stp, f, g, &S->brackt, S->stmin, S->stmax);
+  }
+  if (S->brackt) {
+    if (fabs(S->sty - S->stx) >= 0.66 * S->width1) stp = S->stx + 0.5 * (S->sty - S->stx);
+    S->width1 = S->width;
+    S->width = fabs(S->sty - S->stx);
+  }
+  if (S->brackt) {
+    S->stmin = fmin(S->stx, S->sty);
+    S->stmax = fmax(S->stx, S->sty);
+  } else {
+    S->stmin = stp + 1.1 * (stp - S->stx);
+    S->stmax = stp + 4.0 * (stp - S->stx);
+  }
+  stp = fmax(stp, LS_STPMIN);
+  stp = fmin(stp, LS_STPMAX);
+  if ((S->brackt && (stp <= S->stmin || stp >= S->stmax)) ||
+      (S->brackt && S->stmax - S->stmin <= LS_XTOL * S->stmax))
+    stp = S->stx;
+  *stp_io = stp;
+  return LS_FG;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * fmin_l_bfgs_b without bounds (binary_logistic_regression.py:223-231; scipy _lbfgsb_py driver loop
+ * + L-BFGS-B 3.0 mainlb/lnsrlb/matupd). For an unconstrained problem the compact-form direction
+ * equals the two-loop recursion over the stored pairs with H0 = (s'y / y'y) I of the newest stored
+ * pair; L-BFGS-B forms z = x + d and then re-derives d = z - x, which is restated here.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  double l2, ftol, pgtol;
+  int regularize_bias, has_intercept, m, max_iter, maxfun, maxls;
+} solve_opts;
+
+static double dot_(const double* a, const double* b, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += a[i] * b[i];
+  return s;
+}
+
+static double maxabs_(const double* a, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s = fmax(s, fabs(a[i]));
+  return s;
+}
+
+/* Returns status 0..4 (PGTOL, FACTR, MAXITER, MAXFUN, ABNORMAL); x holds theta0 on entry. */
+static int lbfgs_solve_entity(const problem* P, const solve_opts* O, double* x, double* f_out,
+                              double* gnorm_out, int* nit_out, int* nfev_out, double* work) {
+  const int p = P->p, m = O->m;
+  double* g = work;
+  double* d = g + p;
+  double* t = d + p;       /* x_old */
+  double* r = t + p;       /* g_old, then y */
+  double* ws = r + p;      /* m x p */
+  double* wy = ws + (size_t)m * p;
+  double* alpha = wy + (size_t)m * p;   /* m */
+  double* rho = alpha + m;              /* m: 1/(s'y) of slot */
+  int col = 0, head = 0;                /* stored pairs; oldest slot */
+  double theta = 1.0;
+  int nit = 0, nfev = 0, status = -1, iter0 = 1;
+  double f = fg_(P, x, g);
+  nfev = 1;
+  double sbgnrm = maxabs_(g, p);
+  if (sbgnrm <= O->pgtol) { status = 0; goto done; }
+  for (;;) {
+    /* direction */
+    for (int j = 0; j < p; ++j) d[j] = -g[j];
+    if (col > 0) {
+      for (int a = col - 1; a >= 0; --a) {
+        int sl = (head + a) % m;
+        alpha[a] = rho[sl] * dot_(ws + (size_t)sl * p, d, p);
+        for (int j = 0; j < p; ++j) d[j] -= alpha[a] * wy[(size_t)sl * p + j];
+      }
+      for (int j = 0; j < p; ++j) d[j] *= 1.0 / theta;
+      for (int a = 0; a < col; ++a) {
+        int sl = (head + a) % m;
+        double beta = rho[sl] * dot_(wy + (size_t)sl * p, d, p);
+        for (int j = 0; j < p; ++j) d[j] += (alpha[a] - beta) * ws[(size_t)sl * p + j];
+      }
+    }
+    /* z = x + d ; d = z - x (mainlb) */
+    for (int j = 0; j < p; ++j) { double z = x[j] + d[j]; d[j] = z - x[j]; }
+    /* lnsrlb */
+    double dnorm = sqrt(dot_(d, d, p));
+    double stp = iter0 ? fmin(1.0 / dnorm, LS_STPMAX) : 1.0;
+    memcpy(t, x, sizeof(double) * (size_t)p);
+    memcpy(r, g, sizeof(double) * (size_t)p);
+    double fold = f;
+    double gd = dot_(g, d, p), gdold = gd;
+    int restart = 0;
+    if (gd >= 0.0) {
+      restart = 1; /* info = -4 */
+    } else {
+      ls_state S;
+      dcsrch_start(&S, f, gd, stp);
+      int ifun = 0;
+      for (;;) {
+        ifun++;
+        if (ifun - 1 >= O->maxls) { restart = 1; break; }   /* iback >= maxls */
+        if (stp == 1.0) for (int j = 0; j < p; ++j) x[j] = t[j] + d[j];
+        else for (int j = 0; j < p; ++j) x[j] = stp * d[j] + t[j];
+        f = fg_(P, x, g);
+        nfev++;
+        gd = dot_(g, d, p);
+        if (dcsrch_step(&S, f, gd, &stp) != LS_FG) break;
+      }
+    }
+    if (restart) {
+      memcpy(x, t, sizeof(double) * (size_t)p);
+      memcpy(g, r, sizeof(double) * (size_t)p);
+      f = fold;
+      if (col == 0) { status = 4; goto done; }
+      col = 0; head = 0; theta = 1.0;
+      continue; /* iter0 unchanged: L-BFGS-B's iter counter is untouched by a restart */
+    }
+    /* NEW_X: scipy's python loop (nit, maxiter, maxfun) runs before mainlb's own tests */
+    nit++;
+    iter0 = 0;
+    sbgnrm = maxabs_(g, p);
+    if (nit >= O->max_iter) { status = 2; goto done; }
+    if (nfev > O->maxfun) { status = 3; goto done; }
+    if (sbgnrm <= O->pgtol) { status = 0; goto done; }
+    {
+      double ddum = fmax(fabs(fold), fmax(fabs(f), 1.0));
+      if (fold - f <= O->ftol * ddum) { status = 1; goto done; }
+    }
+    /* pair: s = stp*d, y = g - g_old ; skip rule dr <= epsmch*ddum */
+    for (int j = 0; j < p; ++j) r[j] = g[j] - r[j];
+    double rr = dot_(r, r, p), dr, ddum;
+    if (stp == 1.0) { dr = gd - gdold; ddum = -gdold; }
+    else { dr = (gd - gdold) * stp; for (int j = 0; j < p; ++j) d[j] *= stp; ddum = -gdold * stp; }
+    if (dr <= EPSMCH * ddum) continue;
+    int sl;
+    if (col < m) { sl = (head + col) % m; col++; }
+    else { sl = head; head = (head + 1) % m; }
+    memcpy(ws + (size_t)sl * p, d, sizeof(double) * (size_t)p);
+    memcpy(wy + (size_t)sl * p, r, sizeof(double) * (size_t)p);
+    rho[sl] = 1.0 / dr;
+    theta = rr / dr;
+  }
+done:
+  *f_out = f;
+  *gnorm_out = sbgnrm;
+  *nit_out = nit;
+  *nfev_out = nfev;
+  return status;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * _compute_variance (binary_logistic_regression.py:144-189). mode 1 = SIMPLE, 2 = FULL.
+ * ---------------------------------------------------------------------------------------------- */
+static int variance_(const problem* P, const double* th, int mode, double* var, double* H) {
+  const int n = P->n, p = P->p, ic = P->ic;
+  const double eps = 1.0e-12;
+  logits_(P, th, P->z);
+  for (int i = 0; i < n; ++i) {
+    double rho = expit_(P->z[i]);
+    P->r[i] = rho * (1.0 - rho) * (P->w ? (double)P->w[i] : 1.0);
+  }
+  int unreg0 = (ic && !P->reg_bias);
+  if (mode == 1) {
+    for (int j = 0; j < p; ++j) var[j] = 0.0;
+    for (int i = 0; i < n; ++i) {
+      if (ic) var[0] += P->r[i];
+      /* dense X[:, j].dot(dX[:, j]): duplicate (row,col) entries are summed by toarray() first */
+      for (int k = P->row_ptr[i]; k < P->row_ptr[i + 1]; ++k) {
+        int c = P->col[k];
+        double v = 0.0;
+        int first = 1;
+        for (int k2 = P->row_ptr[i]; k2 < P->row_ptr[i + 1]; ++k2)
+          if (P->col[k2] == c) { if (k2 < k) first = 0; v += (double)P->val[k2]; }
+        if (first) var[ic + c] += v * v * P->r[i];
+      }
+    }
+    for (int j = 0; j < p; ++j) {
+      double h = var[j] + P->l2;
+      if (j == 0 && unreg0) h -= P->l2;
+      var[j] = 1.0 / (h + eps);
+    }
+    return 0;
+  }
+  /* FULL: H = X~' D X~ + (l2+eps) I, H[0][0] -= l2 if bias unregularised; var = diag(inv(H)) */
+  double* xi = (double*)malloc(sizeof(double) * (size_t)p);
+  if (!xi) return -1;
+  for (int a = 0; a < p * p; ++a) H[a] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < p; ++j) xi[j] = 0.0;
+    if (ic) xi[0] = 1.0;
+    for (int k = P->row_ptr[i]; k < P->row_ptr[i + 1]; ++k) xi[ic + P->col[k]] += (double)P->val[k];
+    for (int a = 0; a < p; ++a) {
+      if (xi[a] == 0.0) continue;
+      for (int b = 0; b < p; ++b) H[a * p + b] += xi[a] * P->r[i] * xi[b];
+    }
+  }
+  free(xi);
+  for (int a = 0; a < p; ++a) H[a * p + a] += P->l2 + eps;
+  if (unreg0) H[0] -= P->l2;
+  /* Gauss-Jordan inverse with partial pivoting (np.linalg.inv is LU with partial pivoting) */
+  double* Inv = (double*)malloc(sizeof(double) * (size_t)p * p);
+  if (!Inv) return -1;
+  for (int a = 0; a < p; ++a) for (int b = 0; b < p; ++b) Inv[a * p + b] = (a == b);
+  for (int c = 0; c < p; ++c) {
+    int piv = c;
+    for (int a = c + 1; a < p; ++a) if (fabs(H[a * p + c]) > fabs(H[piv * p + c])) piv = a;
+    if (piv != c)
+      for (int b = 0; b < p; ++b) {
+        double tmp = H[c * p + b]; H[c * p + b] = H[piv * p + b]; H[piv * p + b] = tmp;
+        tmp = Inv[c * p + b]; Inv[c * p + b] = Inv[piv * p + b]; Inv[piv * p + b] = tmp;
+      }
+    double dg = H[c * p + c];
+    for (int b = 0; b < p; ++b) { H[c * p + b] /= dg; Inv[c * p + b] /= dg; }
+    for (int a = 0; a < p; ++a) {
+      if (a == c) continue;
+      double fct = H[a * p + c];
+      if (fct == 0.0) continue;
+      for (int b = 0; b < p; ++b) { H[a * p + b] -= fct * H[c * p + b]; Inv[a * p + b] -= fct * Inv[c * p + b]; }
+    }
+  }
+  for (int a = 0; a < p; ++a) var[a] = Inv[a * p + a];
+  free(Inv);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch entry points (host pointers, packed layout of include/gdmix_re.h).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  double l2; int32_t regularize_bias, has_intercept, m, max_iter, maxfun, maxls;
+  double ftol, pgtol; int32_t variance_mode; double threshold;
+} oracle_opts;  /* same field order as gdmix_re_opts */
+
+/* Solves entities [e_begin, e_end). Any output pointer may be NULL. Returns 0 or <0. */
+int oracle_solve(int64_t e_begin, int64_t e_end, const int64_t* ent_row_ptr, const int64_t* ent_nnz_ptr,
+                 const int64_t* ent_feat_ptr, const int32_t* row_ptr, const int32_t* csr_col,
+                 const float* csr_val, const float* y, const float* offset, const float* weight,
+                 const oracle_opts* opt, const double* theta0, double* theta, double* theta_thr,
+                 double* variance, double* fval, double* gnorm, int32_t* nit, int32_t* nfev,
+                 int32_t* status) {
+  const int ic = opt->has_intercept ? 1 : 0;
+  solve_opts O = {opt->l2, opt->ftol, opt->pgtol, opt->regularize_bias, ic, opt->m,
+                  opt->max_iter, opt->maxfun, opt->maxls};
+  for (int64_t e = e_begin; e < e_end; ++e) {
+    problem P;
+    int64_t r0 = ent_row_ptr[e], z0 = ent_nnz_ptr[e], c0 = ent_feat_ptr[e] + e * ic;
+    P.n = (int)(ent_row_ptr[e + 1] - r0);
+    P.d = (int)(ent_feat_ptr[e + 1] - ent_feat_ptr[e]);
+    P.ic = ic;
+    P.p = P.d + ic;
+    P.row_ptr = row_ptr + r0 + e;
+    P.col = csr_col + z0;
+    P.val = csr_val + z0;
+    P.y = y + r0; P.o = offset + r0; P.w = weight ? weight + r0 : NULL;
+    P.l2 = opt->l2; P.reg_bias = opt->regularize_bias;
+    const int p = P.p, m = O.m;
+    size_t wsz = (size_t)4 * p + (size_t)2 * m * p + (size_t)2 * m + (size_t)2 * P.n + (size_t)p;
+    double* work = (double*)malloc(sizeof(double) * wsz);
+    if (!work) return -1;
+    P.z = work + (size_t)4 * p + (size_t)2 * m * p + (size_t)2 * m;
+    P.r = P.z + P.n;
+    double* x = P.r + P.n;
+    for (int j = 0; j < p; ++j) x[j] = theta0 ? theta0[c0 + j] : 0.0;
+    double f, gn; int it, fe;
+    int st = lbfgs_solve_entity(&P, &O, x, &f, &gn, &it, &fe, work);
+    if (theta) for (int j = 0; j < p; ++j) theta[c0 + j] = x[j];
+    if (theta_thr)  /* threshold_coefficients, util/model_utils.py:4-12 */
+      for (int j = 0; j < p; ++j) theta_thr[c0 + j] = (fabs(x[j]) <= opt->threshold) ? 0.0 : x[j];
+    if (variance && opt->variance_mode) {
+      double* H = opt->variance_mode == 2 ? (double*)malloc(sizeof(double) * (size_t)p * p) : NULL;
+      if (opt->variance_mode == 2 && !H) { free(work); return -1; }
+      int rc = variance_(&P, x, opt->variance_mode, variance + c0, H);
+      free(H);
+      if (rc) { free(work); return rc; }
+    }
+    if (fval) fval[e] = f;
+    if (gnorm) gnorm[e] = gn;
+    if (nit) nit[e] = it;
+    if (nfev) nfev[e] = fe;
+    if (status) status[e] = st;
+    free(work);
+  }
+  return 0;
+}
+
+/* predict_proba(return_logits=True) + InferenceJobConsumer (binary_logistic_regression.py:241-262,
+ * job_consumers.py:138-152): logit = X~ theta + offset, or offset if the entity has no model. */
+int oracle_score(int64_t E, const int64_t* ent_row_ptr, const int64_t* ent_nnz_ptr,
+                 const int64_t* ent_feat_ptr, const int32_t* row_ptr, const int32_t* csr_col,
+                 const float* csr_val, const float* offset, int has_intercept, const double* theta,
+                 const uint8_t* has_model, float* logit, float* logit_per_coord) {
+  const int ic = has_intercept ? 1 : 0;
+  for (int64_t e = 0; e < E; ++e) {
+    int64_t r0 = ent_row_ptr[e], z0 = ent_nnz_ptr[e], c0 = ent_feat_ptr[e] + e * ic;
+    int n = (int)(ent_row_ptr[e + 1] - r0);
+    const int32_t* rp = row_ptr + r0 + e;
+    for (int i = 0; i < n; ++i) {
+      double off = (double)offset[r0 + i], z;
+      if (has_model && !has_model[e]) {
+        z = off;
+      } else {
+        double acc = ic ? theta[c0] : 0.0;
+        for (int k = rp[i]; k < rp[i + 1]; ++k)
+          acc += (double)csr_val[z0 + k] * theta[c0 + ic + csr_col[z0 + k]];
+        z = acc + off;
+      }
+      logit[r0 + i] = (float)z;
+      logit_per_coord[r0 + i] = (float)(z - off);
+    }
+  }
+  return 0;
+}
+
+/* Math.abs(s.hashCode) % n  (gdmix-data/.../utils/PartitionUtils.scala:31-37): String.hashCode is
+ * sum cu[i]*31^(len-1-i) in wrapping int32 over UTF-16 code units; Math.abs(Int.MinValue) is
+ * Int.MinValue; Scala's % keeps the sign of the dividend. */
+int32_t oracle_java_string_hash(const uint16_t* cu, int64_t len) {
+  uint32_t h = 0;
+  for (int64_t i = 0; i < len; ++i) h = 31u * h + (uint32_t)cu[i];
+  return (int32_t)h;
+}
+
+int32_t oracle_java_partition_id(const uint16_t* cu, int64_t len, int32_t num_partitions) {
+  int32_t h = oracle_java_string_hash(cu, len);
+  int32_t a = (h == INT32_MIN) ? h : (h < 0 ? -h : h);
+  return (int32_t)((int64_t)a % (int64_t)num_partitions);   /* C99 % truncates toward zero like the JVM */
+}

@@ -1,0 +1,70 @@
+"""Shared helpers for the parity tests: golden-fixture loading and parity-class bookkeeping."""
+import glob
+import json
+import os
+
+import numpy as np
+
+from gdmix_amd.batch import RawBatch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# theta parity bar of BASELINE.json's north_star: 1e-5 relative (max-norm, per entity) on well-posed
+# entities. With fp64 solver state the restatement is expected to sit many orders below it.
+REL_TOL_NORTH_STAR = 1e-5
+REL_TOL_ORACLE = 1e-8      # CPU restatement vs reference scipy fixtures (well-posed class)
+
+
+def fixture_names(solve_only=True):
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+    if solve_only:
+        names = [n for n in names if not n.startswith("score_")]
+    return names
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    opts = json.loads(str(z["opts"])) if "opts" in z.files else {}
+    batch = None
+    if "ent_row_ptr" in z.files:
+        batch = RawBatch(ent_row_ptr=z["ent_row_ptr"], row_nnz_ptr=z["row_nnz_ptr"], col_global=z["col_global"],
+                         val=z["val"], y=z["y"], offset=z["offset"],
+                         weight=z["weight"] if "weight" in z.files else None, uid=z["uid"],
+                         entity_ids=[str(s) for s in z["exp_entity_ids"]])
+    exp = {k[4:]: z[k] for k in z.files if k.startswith("exp_")}
+    extra = {k: z[k] for k in z.files if k.startswith("prior_") or k in ("n_with_model",)}
+    return batch, opts, exp, extra
+
+
+VAR_MODE = {None: 0, "simple": 1, "full": 2}
+
+
+def opts_kwargs(opts):
+    """Fixture opts json -> kwargs shared by oracle.make_opts and gdmix_amd SolverOptions."""
+    return dict(l2=opts["l2"], regularize_bias=opts["regularize_bias"], has_intercept=opts["has_intercept"],
+                m=opts["m"], max_iter=opts["max_iter"], ftol=opts["tol"],
+                variance_mode=VAR_MODE[opts.get("variance_mode")])
+
+
+def well_posed_mask(batch, opts):
+    """Parity class W of SURVEY.md §8(d): both labels present, or the intercept is regularised with
+    l2 > 0 (or there is no intercept and l2 > 0). Class D entities have no finite optimum and the
+    reference's own answer there is chaotic; only invariants are checked for them."""
+    E = batch.E
+    n1 = np.add.reduceat(batch.y, batch.ent_row_ptr[:-1]) if batch.N else np.zeros(E)
+    n = batch.ent_n()
+    mixed = (n1 > 0) & (n1 < n)
+    if opts["l2"] > 0 and (opts["regularize_bias"] or not opts["has_intercept"]):
+        return np.ones(E, bool)
+    return mixed
+
+
+def per_entity_rel_err(a, b, coef_ptr):
+    """max-norm relative error per entity: max|a-b| / max(max|b|, tiny)."""
+    E = coef_ptr.size - 1
+    out = np.zeros(E)
+    for e in range(E):
+        s = slice(coef_ptr[e], coef_ptr[e + 1])
+        den = max(np.max(np.abs(b[s])) if coef_ptr[e + 1] > coef_ptr[e] else 0.0, 1e-300)
+        out[e] = (np.max(np.abs(a[s] - b[s])) if coef_ptr[e + 1] > coef_ptr[e] else 0.0) / den
+    return out
