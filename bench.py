@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — random-effect entities converged / second on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the device hot path over one resident batch: gdmix_re_pack (per-entity
+unique/local-index/CSC build) followed by gdmix_re_solve (the whole per-entity L-BFGS on the device),
+on the configuration BASELINE.json's metric is quoted on for one GPU: configs[1], synthetic 1M
+entities x avg 64 nnz (n ~ max(1, Poisson(16)), k = 4, D = 1024, seed 20240601), solver options of the
+shipped MovieLens config (l2 = 1, regularize_bias = false, m = 10, max_iter = 100, tol = 1e-12).
+Inputs are resident in HBM before the timed region; outputs stay in HBM. With N > 1 every rank owns
+its own shard of 1M entities (weak scaling; entities are independent, no data-path collective).
+
+One JSON line is printed by rank 0. `roofline` is the HBM roofline of the dominant kernel
+(re_solve_wave_kernel) by the algorithmic-bytes formula of SURVEY.md §8(d); `cpu_baseline` times the
+CPU oracle (oracle/re_oracle.c, a port) on a bounded sample on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--entities", type=int, default=1_000_000, help="entities per GPU (C2: 1M)")
+    ap.add_argument("--mean-n", type=int, default=16)
+    ap.add_argument("--k", type=int, default=4)
+    ap.add_argument("--dim", type=int, default=1024)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="entities for the CPU baseline (0 = auto ~15 s)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solve-only", action="store_true", help="time gdmix_re_solve alone (batch packed once)")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, opts_kw, sample):
+    """Time the fp64 CPU restatement (the oracle, kind 'port') on `sample` entities, all host cores.
+    ctypes releases the GIL, so plain threads give one oracle call per core."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    sub = batch.select(np.arange(min(sample, batch.E)))
+    pk = oracle.pack(sub.ent_row_ptr, sub.row_nnz_ptr, sub.col_global)
+    o = oracle.make_opts(**opts_kw)
+    E = sub.E
+    bounds = np.linspace(0, E, cores + 1).astype(int)
+
+    def run(i):
+        return oracle.solve(pk, sub.val, sub.y, sub.offset, sub.weight, o, e_begin=int(bounds[i]), e_end=int(bounds[i + 1]))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        outs = list(ex.map(run, range(cores)))
+    dt = time.perf_counter() - t0
+    conv = sum(int(np.isin(r["status"][bounds[i]:bounds[i + 1]], (0, 1, 2)).sum()) for i, r in enumerate(outs))
+    return conv / dt, cores, E, dt
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from gdmix_amd import build, synthetic
+    if rank == 0:
+        build.build_library()
+    if world > 1:
+        dist.barrier()
+    from gdmix_amd.solver import REDeviceSolver, SolverOptions
+
+    opts_kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
+    opts = SolverOptions(**opts_kw)
+    t_gen = time.perf_counter()
+    batch = synthetic.make_batch(a.entities, a.mean_n, a.k, a.dim, seed=synthetic.C2_SEED + rank,
+                                 entity_id_base=rank * a.entities, with_uid=False)
+    t_gen = time.perf_counter() - t_gen
+    solver = REDeviceSolver(local_rank)
+    raw_dev = solver.upload(batch)
+    packed = solver.pack(raw_dev)
+    out = solver.alloc_result(packed)
+    solver.set_timing(True)
+
+    def step():
+        nonlocal packed
+        if not a.solve_only:
+            packed = solver.pack(raw_dev)
+        return solver.solve(packed, opts, out=out)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    kernel_ms = np.zeros(8)
+    ev_pack = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    pack_ms = solve_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ev_pack[0].record()
+        if not a.solve_only:
+            packed = solver.pack(raw_dev)
+        ev_pack[1].record()
+        res = solver.solve(packed, opts, out=out)
+        ev_pack[2].record()
+        kernel_ms += np.array(solver.last_solve_ms())      # waits for this step's solve kernels
+        pack_ms += ev_pack[0].elapsed_time(ev_pack[1])
+        solve_ms += ev_pack[1].elapsed_time(ev_pack[2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    status = res.status
+    converged = int(((status >= 0) & (status <= 2)).sum().item())
+    if world > 1:
+        ct = torch.tensor([converged], dtype=torch.int64, device="cuda")
+        dist.all_reduce(ct)
+        converged_all = int(ct.item())
+    else:
+        converged_all = converged
+    value = converged_all * a.steps / dt
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (re_solve_wave_kernel), rank 0's shard ---------------
+        n = batch.ent_n()
+        z = batch.ent_nnz()
+        p = np.diff(packed.coef_ptr_host())
+        alg_bytes = synthetic.algorithmic_bytes(n, z, p)            # sum_e B(e), one step
+        classes = solver.class_counts(packed)
+        wave_launches = sum(1 for (name, c) in classes[:-1] if c > 0)
+        wave_ms = float(kernel_ms[:-1].sum()) / a.steps              # all wave-kernel launches of a step
+        block_ent = classes[-1][1]
+        frac_wave = 1.0 - block_ent / max(1, batch.E)
+        per_launch_bytes = alg_bytes * frac_wave / max(1, wave_launches)
+        per_launch_ms = wave_ms / max(1, wave_launches)
+        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        nfev = res.nfev.double().mean().item()
+        nit = res.nit.double().mean().item()
+        roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "re_solve_wave_kernel", "launches_per_step": wave_launches,
+                    "avg_launch_ms": per_launch_ms, "alg_bytes_per_launch": per_launch_bytes,
+                    "alg_bytes_per_entity": alg_bytes / batch.E,
+                    "note": "LDS-resident solve: latency/ALU-bound fp64 work, not HBM-bound (SURVEY.md §8d honesty note)"}
+        cpu = None
+        if not a.no_cpu_baseline:
+            sample = a.cpu_sample
+            if sample <= 0:
+                v0, cores, e0, d0 = cpu_baseline(batch, opts_kw, 4000)
+                sample = int(min(batch.E, max(4000, v0 * 15.0)))
+            v, cores, es, d = cpu_baseline(batch, opts_kw, sample)
+            cpu = {"value": round(v, 1), "unit": "entities/s", "cores": cores, "kind": "port",
+                   "sample": f"first {es} entities of the same C2 batch, oracle/re_oracle.c fp64, {cores} threads, {d:.1f} s"}
+        line = {
+            "metric": "random-effect entities converged/sec", "value": round(value, 1), "unit": "entities/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"C2: synthetic {a.entities} entities/GPU x avg {a.mean_n * a.k} nnz "
+                                   f"(n~Poisson({a.mean_n}), k={a.k}, D={a.dim}), per-entity L2 LR, L-BFGS m=10",
+                       "entities_per_gpu": a.entities, "step": "solve" if a.solve_only else "pack+solve",
+                       "l2": 1.0, "regularize_bias": False, "max_iter": 100, "parallelism": f"entity-shard x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "detail": {"pack_ms_per_step": pack_ms / a.steps, "solve_ms_per_step": solve_ms / a.steps,
+                       "solve_kernel_ms_per_step": float(kernel_ms.sum()) / a.steps,
+                       "classes": classes, "mean_nit": nit, "mean_nfev": nfev,
+                       "converged_per_step": converged_all, "N": batch.N, "Z": batch.Z, "P": packed.P,
+                       "host_generate_s": t_gen},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

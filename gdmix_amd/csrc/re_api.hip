@@ -1,0 +1,306 @@
+// re_api.hip — the extern "C" surface of libgdmix_re.so (include/gdmix_re.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "re_internal.hpp"
+
+namespace gdmix {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t _rc = (expr);                                                                 \
+    if (_rc != hipSuccess) {                                                                 \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_rc), __FILE__, __LINE__); \
+      return GDMIX_RE_EHIP;                                                                  \
+    }                                                                                        \
+  } while (0)
+
+// LDS buckets of the wave-per-entity kernel. A 64-thread workgroup may use up to 64 KiB here: larger
+// blocks go to the workgroup-per-entity kernel.
+static const int kWaveBuckets[NUM_WAVE_CLASSES] = {4096, 8192, 12288, 16384, 24576, 32768, 65536};
+
+static const char* kClassNames[GDMIX_RE_NUM_CLASSES] = {
+    "re_solve_wave_kernel<=4K",  "re_solve_wave_kernel<=8K",  "re_solve_wave_kernel<=12K", "re_solve_wave_kernel<=16K",
+    "re_solve_wave_kernel<=24K", "re_solve_wave_kernel<=32K", "re_solve_wave_kernel<=64K", "re_solve_block_kernel"};
+
+__global__ void class_base_kernel(int32_t* cc) {
+  // cc[0..7] counts -> cc[16..23] exclusive bases, cc[32..39] cursors = 0
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int run = 0;
+    for (int c = 0; c < GDMIX_RE_NUM_CLASSES; ++c) { cc[16 + c] = run; run += cc[c]; cc[32 + c] = 0; }
+  }
+}
+
+static BatchDev make_batch_dev(const gdmix_re_packed* b) {
+  BatchDev B;
+  B.ent_row_ptr = b->ent_row_ptr; B.ent_nnz_ptr = b->ent_nnz_ptr; B.ent_feat_ptr = b->ent_feat_ptr;
+  B.row_ptr = b->row_ptr; B.csr_col = b->csr_col; B.csr_val = b->csr_val;
+  B.col_ptr = b->col_ptr; B.csc_row = b->csc_row; B.csc_val = b->csc_val;
+  B.y = b->y; B.offset = b->offset; B.weight = b->weight; B.order = b->order;
+  return B;
+}
+
+}  // namespace gdmix
+
+using namespace gdmix;
+
+struct gdmix_re_ctx {
+  gdmix_ctx_impl impl;
+};
+
+extern "C" {
+
+GDMIX_API int gdmix_re_abi_version(void) { return GDMIX_RE_ABI_VERSION; }
+
+GDMIX_API const char* gdmix_re_last_error(void) { return g_err; }
+
+GDMIX_API void gdmix_re_default_opts(gdmix_re_opts* o) {
+  if (!o) return;
+  o->l2 = 1.0; o->regularize_bias = 1; o->has_intercept = 1; o->m = 10; o->max_iter = 100;
+  o->maxfun = 15000; o->maxls = 20; o->ftol = 1e-12; o->pgtol = 1e-5;
+  o->variance_mode = GDMIX_RE_VAR_NONE; o->threshold = 1e-4;
+}
+
+GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
+  if (!out) { set_error("out is NULL"); return GDMIX_RE_EINVAL; }
+  *out = nullptr;
+  int count = 0;
+  HIP_TRY(hipGetDeviceCount(&count));
+  if (hip_device < 0 || hip_device >= count) {
+    set_error("HIP device %d not present (%d visible)", hip_device, count);
+    return GDMIX_RE_EHIP;
+  }
+  HIP_TRY(hipSetDevice(hip_device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, hip_device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device %d is %s; this library only carries gfx950 (MI355X) code", hip_device, prop.gcnArchName);
+    return GDMIX_RE_EHIP;
+  }
+  gdmix_re_ctx* c = new (std::nothrow) gdmix_re_ctx();
+  if (!c) { set_error("out of host memory"); return GDMIX_RE_ENOMEM; }
+  c->impl.device = hip_device;
+  c->impl.num_cus = prop.multiProcessorCount;
+  c->impl.scratch = nullptr;
+  c->impl.scratch_bytes = 0;
+  c->impl.host_pinned = nullptr;
+  c->impl.wave_lds_limit = 65536;
+  c->impl.timing = 0;
+  for (int k = 0; k < GDMIX_RE_NUM_CLASSES; ++k) { c->impl.ev0[k] = nullptr; c->impl.ev1[k] = nullptr; c->impl.ev_used[k] = false; }
+  hipError_t rc = hipHostMalloc(reinterpret_cast<void**>(&c->impl.host_pinned), 4096, hipHostMallocDefault);
+  if (rc != hipSuccess) {
+    set_error("hipHostMalloc failed: %s", hipGetErrorString(rc));
+    delete c;
+    return GDMIX_RE_EHIP;
+  }
+  *out = c;
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API void gdmix_re_destroy(gdmix_re_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->impl.host_pinned) (void)hipHostFree(ctx->impl.host_pinned);
+  for (int k = 0; k < GDMIX_RE_NUM_CLASSES; ++k) {
+    if (ctx->impl.ev0[k]) (void)hipEventDestroy(ctx->impl.ev0[k]);
+    if (ctx->impl.ev1[k]) (void)hipEventDestroy(ctx->impl.ev1[k]);
+  }
+  delete ctx;
+}
+
+GDMIX_API size_t gdmix_re_pack_workspace_bytes(int64_t E, int64_t N, int64_t Z) {
+  if (E < 0 || N < 0 || Z < 0) return 0;
+  return pack_workspace_bytes(E, N, Z);
+}
+
+GDMIX_API int gdmix_re_pack(gdmix_re_ctx* ctx, const gdmix_re_raw_batch* raw_dev, int has_intercept, void* workspace,
+                  size_t workspace_bytes, gdmix_re_packed* out, void* stream) {
+  if (!ctx || !raw_dev || !out || (!workspace && workspace_bytes)) { set_error("NULL argument"); return GDMIX_RE_EINVAL; }
+  if (raw_dev->E > 0 && (!raw_dev->ent_row_ptr || !raw_dev->row_nnz_ptr || !raw_dev->y || !raw_dev->offset)) {
+    set_error("raw batch has NULL arrays");
+    return GDMIX_RE_EINVAL;
+  }
+  if (raw_dev->Z > 0 && (!raw_dev->col_global || !raw_dev->val)) { set_error("raw batch has NULL arrays"); return GDMIX_RE_EINVAL; }
+  HIP_TRY(hipSetDevice(ctx->impl.device));
+  return pack_impl(&ctx->impl, raw_dev, has_intercept, workspace, workspace_bytes, out, static_cast<hipStream_t>(stream));
+}
+
+static int slots_for(const gdmix_re_packed* b, const gdmix_re_opts* o, size_t* slot_doubles) {
+  *slot_doubles = block_slot_doubles(b->max_p, b->max_n, o->m);
+  // enough workgroups to fill the chip a few times over, bounded to ~4 GiB of scratch
+  size_t bytes = *slot_doubles * 8;
+  size_t by_budget = ((size_t)4 << 30) / (bytes ? bytes : 1);
+  size_t slots = 1024;
+  if (slots > by_budget) slots = by_budget;
+  if (slots < 8) slots = 8;
+  if ((int64_t)slots > b->E) slots = (size_t)(b->E > 0 ? b->E : 1);
+  return (int)slots;
+}
+
+GDMIX_API size_t gdmix_re_solve_scratch_bytes(const gdmix_re_packed* batch, const gdmix_re_opts* opts) {
+  if (!batch || !opts || batch->E == 0) return 0;
+  size_t slot_doubles;
+  int slots = slots_for(batch, opts, &slot_doubles);
+  return (size_t)slots * slot_doubles * 8;
+}
+
+GDMIX_API int gdmix_re_set_wave_lds_limit(gdmix_re_ctx* ctx, int bytes) {
+  if (!ctx || bytes < 0) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
+  ctx->impl.wave_lds_limit = bytes > 65536 ? 65536 : bytes;
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_re_set_timing(gdmix_re_ctx* ctx, int enabled) {
+  if (!ctx) { set_error("ctx is NULL"); return GDMIX_RE_EINVAL; }
+  if (enabled && !ctx->impl.ev0[0]) {
+    HIP_TRY(hipSetDevice(ctx->impl.device));
+    for (int k = 0; k < GDMIX_RE_NUM_CLASSES; ++k) {
+      HIP_TRY(hipEventCreate(&ctx->impl.ev0[k]));
+      HIP_TRY(hipEventCreate(&ctx->impl.ev1[k]));
+    }
+  }
+  ctx->impl.timing = enabled ? 1 : 0;
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_re_last_solve_ms(gdmix_re_ctx* ctx, float* ms_out) {
+  if (!ctx || !ms_out) { set_error("NULL argument"); return GDMIX_RE_EINVAL; }
+  for (int k = 0; k < GDMIX_RE_NUM_CLASSES; ++k) {
+    ms_out[k] = 0.0f;
+    if (ctx->impl.ev_used[k]) {
+      HIP_TRY(hipEventSynchronize(ctx->impl.ev1[k]));
+      HIP_TRY(hipEventElapsedTime(&ms_out[k], ctx->impl.ev0[k], ctx->impl.ev1[k]));
+    }
+  }
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_re_set_scratch(gdmix_re_ctx* ctx, void* scratch, size_t bytes) {
+  if (!ctx) { set_error("ctx is NULL"); return GDMIX_RE_EINVAL; }
+  ctx->impl.scratch = scratch;
+  ctx->impl.scratch_bytes = bytes;
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const gdmix_re_opts* opts, const double* theta0,
+                   const gdmix_re_result* out, void* stream) {
+  if (!ctx || !b || !opts || !out) { set_error("NULL argument"); return GDMIX_RE_EINVAL; }
+  if (opts->m < 1 || opts->max_iter < 0 || opts->maxls < 1) { set_error("bad solver options (m, max_iter, maxls)"); return GDMIX_RE_EINVAL; }
+  if (opts->regularize_bias && !opts->has_intercept) {
+    // LRParams.__post_init__: "Intercept must be used when it is regularized" (base_lr_params.py:40-41)
+    set_error("regularize_bias requires has_intercept");
+    return GDMIX_RE_EINVAL;
+  }
+  if (opts->variance_mode == GDMIX_RE_VAR_FULL) { set_error("variance_mode FULL is not implemented on the device yet"); return GDMIX_RE_EINVAL; }
+  if (opts->variance_mode != GDMIX_RE_VAR_NONE && !out->variance) { set_error("variance requested but out->variance is NULL"); return GDMIX_RE_EINVAL; }
+  if (b->E == 0) return GDMIX_RE_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipSetDevice(ctx->impl.device));
+  const int ic = opts->has_intercept ? 1 : 0;
+
+  ClassTable tab;
+  for (int c = 0; c < NUM_WAVE_CLASSES; ++c) tab.lds_bytes[c] = kWaveBuckets[c] <= ctx->impl.wave_lds_limit ? kWaveBuckets[c] : 0;
+  tab.lds_bytes[BLOCK_CLASS] = 0;
+
+  int32_t* cc = b->class_count;
+  HIP_TRY(hipMemsetAsync(cc, 0, 64 * sizeof(int32_t), s));
+  HIP_TRY(launch_classify(b, ic, opts->m, tab, b->cls_tmp, cc, s));
+  hipLaunchKernelGGL(class_base_kernel, dim3(1), dim3(1), 0, s, cc);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(launch_order(b, b->cls_tmp, cc + 16, cc + 32, s));
+  int32_t* hc = ctx->impl.host_pinned + 256;
+  HIP_TRY(hipMemcpyAsync(hc, cc, GDMIX_RE_NUM_CLASSES * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+
+  SolveParams P;
+  P.l2 = opts->l2; P.ftol = opts->ftol; P.pgtol = opts->pgtol; P.threshold = opts->threshold;
+  P.regularize_bias = opts->regularize_bias; P.has_intercept = ic; P.m = opts->m; P.max_iter = opts->max_iter;
+  P.maxfun = opts->maxfun; P.maxls = opts->maxls; P.variance_mode = opts->variance_mode;
+  BatchDev B = make_batch_dev(b);
+  OutDev O{out->theta, out->theta_thr, out->variance, out->fval, out->gnorm, out->nit, out->nfev, out->status};
+
+  const bool timing = ctx->impl.timing != 0;
+  for (int c = 0; c < GDMIX_RE_NUM_CLASSES; ++c) ctx->impl.ev_used[c] = false;
+  int begin = 0;
+  for (int c = 0; c < NUM_WAVE_CLASSES; ++c) {
+    if (timing && hc[c] > 0) { HIP_TRY(hipEventRecord(ctx->impl.ev0[c], s)); }
+    HIP_TRY(launch_solve_wave(B, O, P, theta0, begin, hc[c], tab.lds_bytes[c], s));
+    if (timing && hc[c] > 0) { HIP_TRY(hipEventRecord(ctx->impl.ev1[c], s)); ctx->impl.ev_used[c] = true; }
+    begin += hc[c];
+  }
+  if (hc[BLOCK_CLASS] > 0) {
+    size_t slot_doubles;
+    int slots = slots_for(b, opts, &slot_doubles);
+    size_t need = (size_t)slots * slot_doubles * 8;
+    double* scratch = nullptr;
+    if (ctx->impl.scratch && ctx->impl.scratch_bytes >= need) scratch = static_cast<double*>(ctx->impl.scratch);
+    else if (b->scratch && b->scratch_bytes >= need) scratch = static_cast<double*>(b->scratch);
+    else {
+      // shrink the slot count to what is available rather than failing, but never below one slot
+      size_t avail = ctx->impl.scratch ? ctx->impl.scratch_bytes : 0;
+      void* base = ctx->impl.scratch;
+      if (b->scratch_bytes > avail) { avail = b->scratch_bytes; base = b->scratch; }
+      slots = (int)(avail / (slot_doubles * 8));
+      if (slots < 1) {
+        set_error("%d entities need the workgroup kernel: provide >= %zu bytes via gdmix_re_set_scratch", hc[BLOCK_CLASS],
+                  slot_doubles * 8);
+        return GDMIX_RE_ENOMEM;
+      }
+      scratch = static_cast<double*>(base);
+    }
+    if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[BLOCK_CLASS], s)); }
+    HIP_TRY(launch_solve_block(B, O, P, theta0, begin, hc[BLOCK_CLASS], scratch, slot_doubles, slots, b->max_p, s));
+    if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[BLOCK_CLASS], s)); ctx->impl.ev_used[BLOCK_CLASS] = true; }
+  }
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_re_score(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int has_intercept, const double* theta,
+                   const uint8_t* has_model, float* logit, float* logit_per_coord, void* stream) {
+  if (!ctx || !b || !logit || !logit_per_coord) { set_error("NULL argument"); return GDMIX_RE_EINVAL; }
+  if (!theta && !has_model) { set_error("theta is NULL"); return GDMIX_RE_EINVAL; }
+  HIP_TRY(hipSetDevice(ctx->impl.device));
+  BatchDev B = make_batch_dev(b);
+  HIP_TRY(launch_score(B, b->E, has_intercept ? 1 : 0, theta, has_model, logit, logit_per_coord,
+                       static_cast<hipStream_t>(stream)));
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API const char* gdmix_re_class_kernel_name(int c) {
+  if (c < 0 || c >= GDMIX_RE_NUM_CLASSES) return nullptr;
+  return kClassNames[c];
+}
+
+GDMIX_API int32_t gdmix_java_string_hash(const uint16_t* utf16, int64_t len) {
+  uint32_t h = 0;
+  for (int64_t i = 0; i < len; ++i) h = 31u * h + (uint32_t)utf16[i];
+  return (int32_t)h;
+}
+
+GDMIX_API int32_t gdmix_java_partition_id(const uint16_t* utf16, int64_t len, int32_t num_partitions) {
+  if (num_partitions <= 0) return -1;
+  const int32_t h = gdmix_java_string_hash(utf16, len);
+  const int32_t a = (h == INT32_MIN) ? h : (h < 0 ? -h : h);
+  return (int32_t)((int64_t)a % (int64_t)num_partitions);
+}
+
+GDMIX_API int gdmix_java_partition_ids_i64(gdmix_re_ctx* ctx, const int64_t* ids_dev, int64_t count, int32_t num_partitions,
+                                 int32_t* out_dev, void* stream) {
+  if (!ctx || (count > 0 && (!ids_dev || !out_dev)) || num_partitions <= 0) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
+  HIP_TRY(hipSetDevice(ctx->impl.device));
+  HIP_TRY(launch_partition_ids(ids_dev, count, num_partitions, out_dev, static_cast<hipStream_t>(stream)));
+  return GDMIX_RE_OK;
+}
+
+}  // extern "C"

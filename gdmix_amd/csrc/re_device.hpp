@@ -1,0 +1,247 @@
+// re_device.hpp — device-side building blocks of the gfx950 random-effect solver.
+//
+// Wave64 only (CDNA4). Cross-lane reductions use DPP row shifts + row broadcasts and land in SGPRs
+// through v_readlane, so every reduction result is wave-uniform and bit-identical in all lanes: the
+// whole L-BFGS control flow (line search, stop tests) is then uniform by construction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gdmix {
+
+constexpr int WAVE = 64;
+
+// ---- DPP helpers -------------------------------------------------------------------------------
+// dpp_ctrl encodings (GFX9): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_get0(double v) {
+  // value of the DPP source lane, or 0.0 where the source lane is invalid / the row is masked off
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi2, lo2);
+}
+
+__device__ __forceinline__ double readlane63(double v) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readlane0(double v) {
+  int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes of a wave; all lanes must be active. Fixed association order.
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_get0<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_get0<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_get0<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_get0<0x118, 0xf>(v);   // row_shr:8  -> lane 15 of each row holds the row sum
+  v += dpp_get0<0x142, 0xa>(v);   // row_bcast:15 into rows 1,3
+  v += dpp_get0<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the total
+  return readlane63(v);
+}
+
+// Max over the wave of NON-NEGATIVE values (0 is the identity used for invalid DPP sources).
+__device__ __forceinline__ double wave_max_nonneg(double v) {
+  v = fmax(v, dpp_get0<0x111, 0xf>(v));
+  v = fmax(v, dpp_get0<0x112, 0xf>(v));
+  v = fmax(v, dpp_get0<0x114, 0xf>(v));
+  v = fmax(v, dpp_get0<0x118, 0xf>(v));
+  v = fmax(v, dpp_get0<0x142, 0xa>(v));
+  v = fmax(v, dpp_get0<0x143, 0xc>(v));
+  return readlane63(v);
+}
+
+// Compiler-level ordering point between LDS accesses of different lanes of ONE wave. The LDS queue
+// of a wave is processed in order, so no hardware wait is needed; the fences only stop the compiler
+// from moving memory operations across this point.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Same, for data that may live in global memory (HBM scratch): additionally waits for the wave's own
+// outstanding stores so that another lane's later load observes them (same CU, same L1).
+__device__ __forceinline__ void wave_mem_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ---- thread groups ------------------------------------------------------------------------------
+// One wavefront cooperating on one entity.
+struct WaveGroup {
+  int tid;
+  static constexpr int NT = WAVE;
+  __device__ __forceinline__ double sum(double v) const { return wave_sum(v); }
+  __device__ __forceinline__ double max_nonneg(double v) const { return wave_max_nonneg(v); }
+  __device__ __forceinline__ void sync() const { wave_lds_fence(); }
+};
+
+// One workgroup of NW wavefronts cooperating on one (large) entity.
+template <int NW>
+struct BlockGroup {
+  int tid;
+  double* red;   // LDS, 2*NW doubles (double-buffered so one barrier per reduction suffices)
+  int phase;
+  static constexpr int NT = WAVE * NW;
+  __device__ __forceinline__ double combine(double v, bool is_max) {
+    double* buf = red + phase * NW;
+    phase ^= 1;
+    if ((tid & (WAVE - 1)) == 0) buf[tid >> 6] = v;
+    __syncthreads();
+    double s = buf[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s = is_max ? fmax(s, buf[w]) : s + buf[w];
+    return s;
+  }
+  __device__ __forceinline__ double sum(double v) { return combine(wave_sum(v), false); }
+  __device__ __forceinline__ double max_nonneg(double v) { return combine(wave_max_nonneg(v), true); }
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+};
+
+// ---- More'-Thuente line search (MINPACK-2 dcsrch/dcstep as L-BFGS-B 3.0's lnsrlb calls it) --------
+// All state is uniform across the cooperating threads.
+struct LineSearch {
+  double ginit, gtest, gx, gy, finit, fx, fy, stx, sty, stmin, stmax, width, width1;
+  int brackt, stage;
+};
+
+constexpr double LS_FTOL = 1.0e-3, LS_GTOL = 0.9, LS_XTOL = 0.1, LS_STPMIN = 0.0, LS_STPMAX = 1.0e10;
+enum { LS_FG = 0, LS_CONV = 1, LS_WARN = 2 };
+
+__device__ __forceinline__ void dcsrch_start(LineSearch& S, double f, double g, double stp) {
+  S.brackt = 0; S.stage = 1;
+  S.finit = f; S.ginit = g; S.gtest = LS_FTOL * g;
+  S.width = LS_STPMAX - LS_STPMIN; S.width1 = S.width / 0.5;
+  S.stx = 0.0; S.fx = f; S.gx = g;
+  S.sty = 0.0; S.fy = f; S.gy = g;
+  S.stmin = 0.0; S.stmax = stp + 4.0 * stp;
+}
+
+__device__ __noinline__ void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy,
+                                    double& dy, double& stp, double fp, double dp, int& brackt,
+                                    double stpmin, double stpmax) {
+  double gamma, p, q, r, s, sgnd, stpc, stpf, stpq, theta;
+  sgnd = dp * (dx / fabs(dx));
+  if (fp > fx) {
+    theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    s = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
+    gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+    if (stp < stx) gamma = -gamma;
+    p = (gamma - dx) + theta;
+    q = ((gamma - dx) + gamma) + dp;
+    r = p / q;
+    stpc = stx + r * (stp - stx);
+    stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
+    if (fabs(stpc - stx) < fabs(stpq - stx)) stpf = stpc;
+    else stpf = stpc + (stpq - stpc) / 2.0;
+    brackt = 1;
+  } else if (sgnd < 0.0) {
+    theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    s = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
+    gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+    if (stp > stx) gamma = -gamma;
+    p = (gamma - dp) + theta;
+    q = ((gamma - dp) + gamma) + dx;
+    r = p / q;
+    stpc = stp + r * (stx - stp);
+    stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    if (fabs(stpc - stp) > fabs(stpq - stp)) stpf = stpc;
+    else stpf = stpq;
+    brackt = 1;
+  } else if (fabs(dp) < fabs(dx)) {
+    theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    s = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
+    gamma = s * sqrt(fmax(0.0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
+    if (stp > stx) gamma = -gamma;
+    p = (gamma - dp) + theta;
+    q = (gamma + (dx - dp)) + gamma;
+    r = p / q;
+    if (r < 0.0 && gamma != 0.0) stpc = stp + r * (stx - stp);
+    else if (stp > stx) stpc = stpmax;
+    else stpc = stpmin;
+    stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    if (brackt) {
+      if (fabs(stpc - stp) < fabs(stpq - stp)) stpf = stpc;
+      else stpf = stpq;
+      if (stp > stx) stpf = fmin(stp + 0.66 * (sty - stp), stpf);
+      else stpf = fmax(stp + 0.66 * (sty - stp), stpf);
+    } else {
+      if (fabs(stpc - stp) > fabs(stpq - stp)) stpf = stpc;
+      else stpf = stpq;
+      stpf = fmin(stpmax, stpf);
+      stpf = fmax(stpmin, stpf);
+    }
+  } else {
+    if (brackt) {
+      theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
+      s = fmax(fabs(theta), fmax(fabs(dy), fabs(dp)));
+      gamma = s * sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
+      if (stp > sty) gamma = -gamma;
+      p = (gamma - dp) + theta;
+      q = ((gamma - dp) + gamma) + dy;
+      r = p / q;
+      stpc = stp + r * (sty - stp);
+      stpf = stpc;
+    } else if (stp > stx) stpf = stpmax;
+    else stpf = stpmin;
+  }
+  if (fp > fx) {
+    sty = stp; fy = fp; dy = dp;
+  } else {
+    if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
+    stx = stp; fx = fp; dx = dp;
+  }
+  stp = stpf;
+}
+
+__device__ __forceinline__ int dcsrch_step(LineSearch& S, double f, double g, double& stp_io) {
+  double stp = stp_io;
+  int task = LS_FG;
+  const double ftest = S.finit + stp * S.gtest;
+  if (S.stage == 1 && f <= ftest && g >= 0.0) S.stage = 2;
+  if (S.brackt && (stp <= S.stmin || stp >= S.stmax)) task = LS_WARN;
+  if (S.brackt && S.stmax - S.stmin <= LS_XTOL * S.stmax) task = LS_WARN;
+  if (stp == LS_STPMAX && f <= ftest && g <= S.gtest) task = LS_WARN;
+  if (stp == LS_STPMIN && (f > ftest || g >= S.gtest)) task = LS_WARN;
+  if (f <= ftest && fabs(g) <= LS_GTOL * (-S.ginit)) task = LS_CONV;
+  if (task != LS_FG) return task;
+  if (S.stage == 1 && f <= S.fx && f > ftest) {
+    double fm = f - stp * S.gtest, fxm = S.fx - S.stx * S.gtest, fym = S.fy - S.sty * S.gtest;
+    double gm = g - S.gtest, gxm = S.gx - S.gtest, gym = S.gy - S.gtest;
+    dcstep(S.stx, fxm, gxm, S.sty, fym, gym, stp, fm, gm, S.brackt, S.stmin, S.stmax);
+    S.fx = fxm + S.stx * S.gtest;
+    S.fy = fym + S.sty * S.gtest;
+    S.gx = gxm + S.gtest;
+    S.gy = gym + S.gtest;
+  } else {
+    dcstep(S.stx, S.fx, S.gx, S.sty, S.fy, S.gy, stp, f, g, S.brackt, S.stmin, S.stmax);
+  }
+  if (S.brackt) {
+    if (fabs(S.sty - S.stx) >= 0.66 * S.width1) stp = S.stx + 0.5 * (S.sty - S.stx);
+    S.width1 = S.width;
+    S.width = fabs(S.sty - S.stx);
+  }
+  if (S.brackt) {
+    S.stmin = fmin(S.stx, S.sty);
+    S.stmax = fmax(S.stx, S.sty);
+  } else {
+    S.stmin = stp + 1.1 * (stp - S.stx);
+    S.stmax = stp + 4.0 * (stp - S.stx);
+  }
+  stp = fmax(stp, LS_STPMIN);
+  stp = fmin(stp, LS_STPMAX);
+  if ((S.brackt && (stp <= S.stmin || stp >= S.stmax)) ||
+      (S.brackt && S.stmax - S.stmin <= LS_XTOL * S.stmax))
+    stp = S.stx;
+  stp_io = stp;
+  return LS_FG;
+}
+
+}  // namespace gdmix

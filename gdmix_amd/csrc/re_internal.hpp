@@ -1,0 +1,95 @@
+// re_internal.hpp — host-side declarations shared by the translation units of libgdmix_re.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/gdmix_re.h"
+#include "re_solve_core.hpp"
+
+namespace gdmix {
+
+// number of LDS-size buckets solved by the wave-per-entity kernel; the last class is the
+// workgroup-per-entity kernel working out of a global scratch slot.
+constexpr int NUM_WAVE_CLASSES = GDMIX_RE_NUM_CLASSES - 1;
+constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 1;
+constexpr int BLOCK_NW = 4;   // wavefronts per workgroup of the block kernel
+
+struct ClassTable {
+  int lds_bytes[GDMIX_RE_NUM_CLASSES];   // upper LDS size of each wave class; 0 for the block class
+};
+
+// Device pointers of a packed batch, passed by value to kernels.
+struct BatchDev {
+  const int64_t* ent_row_ptr;
+  const int64_t* ent_nnz_ptr;
+  const int64_t* ent_feat_ptr;
+  const int32_t* row_ptr;
+  const int32_t* csr_col;
+  const float* csr_val;
+  const int32_t* col_ptr;
+  const int32_t* csc_row;
+  const float* csc_val;
+  const float* y;
+  const float* offset;
+  const float* weight;
+  const int32_t* order;
+};
+
+struct OutDev {
+  double* theta;
+  double* theta_thr;
+  double* variance;
+  double* fval;
+  double* gnorm;
+  int32_t* nit;
+  int32_t* nfev;
+  int32_t* status;
+};
+
+struct gdmix_ctx_impl {
+  int device;
+  int num_cus;
+  void* scratch;
+  size_t scratch_bytes;
+  int32_t* host_pinned;   // small pinned buffer for count read-backs
+  int wave_lds_limit;     // entities above this LDS footprint use the block kernel
+  int timing;             // bracket class launches with events
+  hipEvent_t ev0[GDMIX_RE_NUM_CLASSES], ev1[GDMIX_RE_NUM_CLASSES];
+  bool ev_used[GDMIX_RE_NUM_CLASSES];
+};
+
+// LDS bytes the wave kernel needs for an entity of this shape (must match the kernel's carve-up).
+__host__ __device__ inline size_t wave_lds_bytes(int p, int n, int nnz, int d, int m, bool has_w) {
+  size_t dbl = (size_t)(5 + 2 * m) * p + n + 2 * m;
+  size_t w32 = (size_t)4 * nnz + (n + 1) + (d + 1) + (has_w ? 3 : 2) * (size_t)n;
+  return ((dbl * 8 + w32 * 4) + 15) & ~(size_t)15;
+}
+
+// doubles of global scratch one block-kernel slot needs
+inline size_t block_slot_doubles(int64_t max_p, int64_t max_n, int m) {
+  return (size_t)(5 + 2 * m) * max_p + max_n + 2 * m + 8;
+}
+
+hipError_t launch_classify(const gdmix_re_packed* b, int ic, int m, const ClassTable& tab, int32_t* cls_tmp,
+                           int32_t* counts_dev, hipStream_t s);
+hipError_t launch_order(const gdmix_re_packed* b, const int32_t* cls_tmp, const int32_t* class_base_dev,
+                        int32_t* cursor_dev, hipStream_t s);
+hipError_t launch_solve_wave(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
+                             int begin, int count, int lds_bytes, hipStream_t s);
+hipError_t launch_solve_block(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
+                              int begin, int count, double* scratch, size_t slot_doubles, int slots,
+                              int64_t max_p, hipStream_t s);
+hipError_t launch_score(const BatchDev& B, int64_t E, int ic, const double* theta, const uint8_t* has_model,
+                        float* logit, float* per_coord, hipStream_t s);
+
+// pack (re_pack.hip)
+size_t pack_workspace_bytes(int64_t E, int64_t N, int64_t Z);
+int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_intercept, void* ws, size_t ws_bytes,
+              gdmix_re_packed* out, hipStream_t s);
+hipError_t launch_partition_ids(const int64_t* ids, int64_t count, int32_t num_partitions, int32_t* out,
+                                hipStream_t s);
+
+void set_error(const char* fmt, ...);
+
+}  // namespace gdmix

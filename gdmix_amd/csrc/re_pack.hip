@@ -1,0 +1,347 @@
+// re_pack.hip — device-side replacement of the per-entity slicing in prepare_jobs
+// (gdmix-trainer/src/gdmix/models/custom/scipy/job_consumers.py:209-258): for every entity,
+// np.unique(cols, return_inverse=True) (:243), the locally indexed COO/CSR block (:247) and — new
+// here — a column-sorted copy so that X'r needs no atomics. One wavefront per entity.
+//
+// Sort key = (global column << 32) | position-in-entity, so equal columns stay in row-major order
+// (the order scipy's COO mat-vec accumulates them in) and the sort needs no stability.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "re_internal.hpp"
+
+namespace gdmix {
+
+constexpr int PACK_WAVES = 4;          // wavefronts (entities) per workgroup
+constexpr int PACK_LDS_KEYS = 512;     // per-wave LDS sort capacity; larger entities sort in HBM scratch
+
+struct PackStats {      // device-side, read back once per pack
+  unsigned long long D;
+  int max_p, max_n, max_nnz, err;
+};
+
+__global__ void pack_entnnz_kernel(const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ row_nnz_ptr,
+                                   int64_t E, int64_t* __restrict__ ent_nnz_ptr) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e <= E; e += (int64_t)gridDim.x * blockDim.x)
+    ent_nnz_ptr[e] = row_nnz_ptr[ent_row_ptr[e]];
+}
+
+// All comparators ascending, so keys at index >= n act as +inf padding and are simply skipped.
+__device__ __forceinline__ void wave_bitonic_sort(unsigned long long* a, int n, int lane) {
+  if (n < 2) return;
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  const int half = np2 >> 1;
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < half; t += WAVE) {
+        int i, partner;
+        if (j == (k >> 1)) {
+          const int blk = t / j, off = t - blk * j;
+          i = blk * k + off;
+          partner = blk * k + (k - 1 - off);
+        } else {
+          const int blk = t / j, off = t - blk * j;
+          i = blk * 2 * j + off;
+          partner = i + j;
+        }
+        if (partner < n) {
+          const unsigned long long x = a[i], y = a[partner];
+          if (x > y) { a[i] = y; a[partner] = x; }
+        }
+      }
+      wave_mem_fence();
+    }
+  }
+}
+
+// Phase 1: entity-relative row pointers, sorted keys (to HBM scratch), distinct-column count, stats.
+__global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_sort_kernel(
+    const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ row_nnz_ptr,
+    const int64_t* __restrict__ ent_nnz_ptr, const int64_t* __restrict__ col_global, int64_t E, int ic,
+    int32_t* __restrict__ row_ptr, unsigned long long* __restrict__ sort_key, int32_t* __restrict__ d_cnt,
+    PackStats* __restrict__ stats) {
+  __shared__ unsigned long long lds_keys[PACK_WAVES][PACK_LDS_KEYS];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wv = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * PACK_WAVES + wv;
+  if (e >= E) return;
+  const int64_t r0 = ent_row_ptr[e], r1 = ent_row_ptr[e + 1];
+  const int64_t z0 = ent_nnz_ptr[e], z1 = ent_nnz_ptr[e + 1];
+  const int64_t n64 = r1 - r0, nnz64 = z1 - z0;
+  if (n64 > 0x7ffffff0ll || nnz64 > 0x7ffffff0ll) {
+    if (lane == 0) { atomicExch(&stats->err, GDMIX_RE_ERANGE); d_cnt[e] = 0; }
+    return;
+  }
+  const int n = (int)n64, nnz = (int)nnz64;
+  for (int i = lane; i <= n; i += WAVE) row_ptr[r0 + e + i] = (int32_t)(row_nnz_ptr[r0 + i] - z0);
+  unsigned long long* keys = (nnz <= PACK_LDS_KEYS) ? lds_keys[wv] : (sort_key + z0);
+  bool bad = false;
+  for (int k = lane; k < nnz; k += WAVE) {
+    const int64_t c = col_global[z0 + k];
+    bad |= (c < 0 || c > 0x7fffffffll);
+    keys[k] = ((unsigned long long)(uint32_t)c << 32) | (unsigned)k;
+  }
+  if (__ballot(bad)) {
+    if (lane == 0) atomicExch(&stats->err, GDMIX_RE_ERANGE);
+  }
+  wave_mem_fence();
+  wave_bitonic_sort(keys, nnz, lane);
+  int d = 0;
+  for (int base = 0; base < nnz; base += WAVE) {
+    const int k = base + lane;
+    bool head = false;
+    if (k < nnz) {
+      const unsigned long long key = keys[k];
+      head = (k == 0) || ((keys[k - 1] >> 32) != (key >> 32));
+      if (keys != sort_key + z0) sort_key[z0 + k] = key;
+    }
+    d += __popcll(__ballot(head));
+  }
+  if (lane == 0) {
+    d_cnt[e] = d;
+    atomicMax(&stats->max_p, d + ic);
+    atomicMax(&stats->max_n, n);
+    atomicMax(&stats->max_nnz, nnz);
+  }
+}
+
+// ---- exclusive scan int32 -> int64 over E+1 outputs (three small kernels) --------------------------
+constexpr int SCAN_CHUNK = 2048;   // elements per workgroup (256 threads x 8)
+
+__global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t* __restrict__ in, int64_t count,
+                                                          long long* __restrict__ block_sums) {
+  __shared__ long long part[4];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+  long long s = 0;
+  for (int k = threadIdx.x; k < SCAN_CHUNK; k += 256) {
+    const int64_t i = base + k;
+    if (i < count) s += in[i];
+  }
+  double sd = wave_sum((double)s);   // exact: per-wave partials stay far below 2^53
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = (long long)sd;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ void scan_blocksums_kernel(long long* __restrict__ block_sums, int nb, PackStats* __restrict__ stats) {
+  // single thread: nb = ceil(E / 2048) is at most a few tens of thousands
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    long long run = 0;
+    for (int b = 0; b < nb; ++b) { const long long v = block_sums[b]; block_sums[b] = run; run += v; }
+    stats->D = (unsigned long long)run;
+  }
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ in, int64_t count,
+                                                         const long long* __restrict__ block_sums,
+                                                         int64_t* __restrict__ out /* [count+1] */) {
+  __shared__ long long tsum[256];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * 8;
+  long long v[8], s = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { v[k] = (base + k < count) ? in[base + k] : 0; s += v[k]; }
+  tsum[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {   // Hillis-Steele inclusive scan of the thread sums
+    long long add = (threadIdx.x >= off) ? tsum[threadIdx.x - off] : 0;
+    __syncthreads();
+    tsum[threadIdx.x] += add;
+    __syncthreads();
+  }
+  long long run = block_sums[blockIdx.x] + tsum[threadIdx.x] - s;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (base + k < count) out[base + k] = run;
+    run += v[k];
+    if (base + k == count - 1) out[count] = run;
+  }
+}
+
+// Phase 2: local indices, unique global list, CSC copy.
+__global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_fill_kernel(
+    const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ ent_nnz_ptr,
+    const int64_t* __restrict__ ent_feat_ptr, const float* __restrict__ val, int64_t E,
+    const int32_t* __restrict__ row_ptr, const unsigned long long* __restrict__ sort_key,
+    int32_t* __restrict__ csr_col, int32_t* __restrict__ col_ptr, int32_t* __restrict__ csc_row,
+    float* __restrict__ csc_val, int64_t* __restrict__ unique_global) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t e = (int64_t)blockIdx.x * PACK_WAVES + (threadIdx.x >> 6);
+  if (e >= E) return;
+  const int64_t r0 = ent_row_ptr[e], z0 = ent_nnz_ptr[e], f0 = ent_feat_ptr[e];
+  const int n = (int)(ent_row_ptr[e + 1] - r0);
+  const int nnz = (int)(ent_nnz_ptr[e + 1] - z0);
+  const int d = (int)(ent_feat_ptr[e + 1] - f0);
+  const int32_t* rp = row_ptr + r0 + e;
+  int carry = 0;
+  for (int base = 0; base < nnz; base += WAVE) {
+    const int k = base + lane;
+    bool head = false;
+    unsigned long long key = 0;
+    if (k < nnz) {
+      key = sort_key[z0 + k];
+      head = (k == 0) || ((sort_key[z0 + k - 1] >> 32) != (key >> 32));
+    }
+    const unsigned long long mask = __ballot(head);
+    const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const int lid = carry + __popcll(mask & below) - 1;
+    if (k < nnz) {
+      const int pos = (int)(key & 0xffffffffull);
+      if (head) {
+        unique_global[f0 + lid] = (int64_t)(key >> 32);
+        col_ptr[f0 + e + lid] = k;
+      }
+      csr_col[z0 + pos] = lid;
+      csc_val[z0 + k] = val[z0 + pos];
+      // sample of non-zero `pos`: last i with rp[i] <= pos
+      int lo = 0, hi = n - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rp[mid] <= pos) lo = mid; else hi = mid - 1;
+      }
+      csc_row[z0 + k] = lo;
+    }
+    carry += __popcll(mask);
+  }
+  if (lane == 0) col_ptr[f0 + e + d] = nnz;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct PackLayout {
+  size_t ent_nnz_ptr, ent_feat_ptr, row_ptr, csr_col, col_ptr, csc_row, csc_val, unique_global, order, cls_tmp,
+      d_cnt, class_count, block_sums, stats, sort_key, total;
+};
+
+static PackLayout pack_layout(int64_t E, int64_t N, int64_t Z) {
+  PackLayout L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+  L.ent_nnz_ptr = take((size_t)(E + 1) * 8);
+  L.ent_feat_ptr = take((size_t)(E + 1) * 8);
+  L.row_ptr = take((size_t)(N + E + 1) * 4);
+  L.csr_col = take((size_t)(Z + 1) * 4);
+  L.col_ptr = take((size_t)(Z + E + 1) * 4);
+  L.csc_row = take((size_t)(Z + 1) * 4);
+  L.csc_val = take((size_t)(Z + 1) * 4);
+  L.unique_global = take((size_t)(Z + 1) * 8);
+  L.order = take((size_t)(E + 1) * 4);
+  L.cls_tmp = take((size_t)(E + 1) * 4);
+  L.d_cnt = take((size_t)(E + 1) * 4);
+  L.class_count = take(64 * 4);
+  L.block_sums = take((size_t)((E + 1) / SCAN_CHUNK + 2) * 8);
+  L.stats = take(sizeof(PackStats));
+  L.sort_key = take((size_t)(Z + 1) * 8);
+  L.total = off;
+  return L;
+}
+
+size_t pack_workspace_bytes(int64_t E, int64_t N, int64_t Z) { return pack_layout(E, N, Z).total; }
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t _rc = (expr);                                                            \
+    if (_rc != hipSuccess) {                                                            \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_rc), __FILE__, __LINE__); \
+      return GDMIX_RE_EHIP;                                                             \
+    }                                                                                   \
+  } while (0)
+
+int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_intercept, void* ws, size_t ws_bytes,
+              gdmix_re_packed* out, hipStream_t s) {
+  const int64_t E = raw->E, N = raw->N, Z = raw->Z;
+  if (E < 0 || N < 0 || Z < 0) { set_error("negative batch dimension"); return GDMIX_RE_EINVAL; }
+  if (E > 0x7ffffff0ll) { set_error("more than 2^31 entities in one batch"); return GDMIX_RE_ERANGE; }
+  const PackLayout L = pack_layout(E, N, Z);
+  if (ws_bytes < L.total) {
+    set_error("pack workspace too small: %zu < %zu", ws_bytes, L.total);
+    return GDMIX_RE_ENOMEM;
+  }
+  char* base = static_cast<char*>(ws);
+  const int ic = has_intercept ? 1 : 0;
+  out->E = E; out->N = N; out->Z = Z; out->D = 0;
+  out->ent_row_ptr = raw->ent_row_ptr;
+  out->ent_nnz_ptr = reinterpret_cast<int64_t*>(base + L.ent_nnz_ptr);
+  out->ent_feat_ptr = reinterpret_cast<int64_t*>(base + L.ent_feat_ptr);
+  out->row_ptr = reinterpret_cast<int32_t*>(base + L.row_ptr);
+  out->csr_col = reinterpret_cast<int32_t*>(base + L.csr_col);
+  out->csr_val = const_cast<float*>(raw->val);   // CSR order is the raw order: no copy
+  out->col_ptr = reinterpret_cast<int32_t*>(base + L.col_ptr);
+  out->csc_row = reinterpret_cast<int32_t*>(base + L.csc_row);
+  out->csc_val = reinterpret_cast<float*>(base + L.csc_val);
+  out->unique_global = reinterpret_cast<int64_t*>(base + L.unique_global);
+  out->y = raw->y; out->offset = raw->offset; out->weight = raw->weight;
+  out->order = reinterpret_cast<int32_t*>(base + L.order);
+  out->class_count = reinterpret_cast<int32_t*>(base + L.class_count);
+  out->cls_tmp = reinterpret_cast<int32_t*>(base + L.cls_tmp);
+  out->scratch = base + L.sort_key;
+  out->scratch_bytes = (size_t)(Z + 1) * 8;
+  out->max_p = ic; out->max_n = 0; out->max_nnz = 0;
+  if (E == 0) return GDMIX_RE_OK;
+
+  int32_t* d_cnt = reinterpret_cast<int32_t*>(base + L.d_cnt);
+  long long* block_sums = reinterpret_cast<long long*>(base + L.block_sums);
+  PackStats* stats = reinterpret_cast<PackStats*>(base + L.stats);
+  unsigned long long* sort_key = reinterpret_cast<unsigned long long*>(base + L.sort_key);
+
+  HIP_TRY(hipMemsetAsync(stats, 0, sizeof(PackStats), s));
+  {
+    int grid = (int)((E + 1 + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pack_entnnz_kernel, dim3(grid), dim3(256), 0, s, raw->ent_row_ptr, raw->row_nnz_ptr, E,
+                       out->ent_nnz_ptr);
+  }
+  const int eblocks = (int)((E + PACK_WAVES - 1) / PACK_WAVES);
+  hipLaunchKernelGGL(pack_sort_kernel, dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s, raw->ent_row_ptr,
+                     raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, E, ic, out->row_ptr, sort_key, d_cnt, stats);
+  const int nb = (int)((E + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, s, d_cnt, E, block_sums);
+  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1), 0, s, block_sums, nb, stats);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, s, d_cnt, E, block_sums, out->ent_feat_ptr);
+  hipLaunchKernelGGL(pack_fill_kernel, dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s, raw->ent_row_ptr,
+                     out->ent_nnz_ptr, out->ent_feat_ptr, raw->val, E, out->row_ptr, sort_key, out->csr_col,
+                     out->col_ptr, out->csc_row, out->csc_val, out->unique_global);
+  HIP_TRY(hipGetLastError());
+  PackStats* hs = reinterpret_cast<PackStats*>(ctx->host_pinned);
+  HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(PackStats), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (hs->err) {
+    set_error("pack: an entity exceeds a per-entity int32 limit or a feature index is outside [0, 2^31)");
+    return hs->err;
+  }
+  out->D = (int64_t)hs->D;
+  out->max_p = hs->max_p; out->max_n = hs->max_n; out->max_nnz = hs->max_nnz;
+  return GDMIX_RE_OK;
+}
+
+// ---- B4: partition ids of decimal int64 entity ids ----------------------------------------------------
+// id.toString for a Long is its decimal rendering with a leading '-' when negative; hashCode runs over
+// the UTF-16 code units (ASCII here); Math.abs(Int.MinValue) stays Int.MinValue; % keeps the sign.
+__global__ void partition_ids_kernel(const int64_t* __restrict__ ids, int64_t count, int32_t num_partitions,
+                                     int32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = ids[i];
+    unsigned long long mag = v < 0 ? (unsigned long long)(-(v + 1)) + 1ull : (unsigned long long)v;
+    char digits[20];
+    int nd = 0;
+    do { digits[nd++] = (char)('0' + (int)(mag % 10ull)); mag /= 10ull; } while (mag);
+    uint32_t h = 0;
+    if (v < 0) h = 31u * h + (uint32_t)'-';
+    for (int k = nd - 1; k >= 0; --k) h = 31u * h + (uint32_t)digits[k];
+    const int32_t hs = (int32_t)h;
+    const int32_t a = (hs == INT32_MIN) ? hs : (hs < 0 ? -hs : hs);
+    out[i] = (int32_t)((int64_t)a % (int64_t)num_partitions);
+  }
+}
+
+hipError_t launch_partition_ids(const int64_t* ids, int64_t count, int32_t num_partitions, int32_t* out,
+                                hipStream_t s) {
+  if (count <= 0) return hipSuccess;
+  int grid = (int)((count + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(partition_ids_kernel, dim3(grid), dim3(256), 0, s, ids, count, num_partitions, out);
+  return hipGetLastError();
+}
+
+}  // namespace gdmix

@@ -1,0 +1,267 @@
+// re_solve.hip — gfx950 kernels of the random-effect solve and score.
+//
+//   re_classify_kernel / re_order_kernel   bucket entities by the LDS footprint of their solve
+//   re_solve_wave_kernel                   ONE WAVEFRONT PER ENTITY: the entity's (X, y, offset, weight)
+//                                          block and all L-BFGS state live in LDS for the whole solve
+//   re_solve_block_kernel                  one 256-thread workgroup per entity for blocks that do not
+//                                          fit the LDS budget: X streams from HBM/L2 every evaluation,
+//                                          L-BFGS state lives in a per-workgroup global scratch slot
+//   re_score_kernel                        logits X~theta + offset
+#include "re_internal.hpp"
+
+namespace gdmix {
+
+// ---------------------------------------------------------------------------------------------------
+// classification
+// ---------------------------------------------------------------------------------------------------
+__global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ ent_nnz_ptr,
+                                   const int64_t* __restrict__ ent_feat_ptr, int64_t E, int ic, int m, bool has_w,
+                                   ClassTable tab, int32_t* __restrict__ cls_out, int32_t* __restrict__ counts) {
+  __shared__ int32_t local[GDMIX_RE_NUM_CLASSES];
+  if (threadIdx.x < GDMIX_RE_NUM_CLASSES) local[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(ent_row_ptr[e + 1] - ent_row_ptr[e]);
+    const int z = (int)(ent_nnz_ptr[e + 1] - ent_nnz_ptr[e]);
+    const int d = (int)(ent_feat_ptr[e + 1] - ent_feat_ptr[e]);
+    const size_t bytes = wave_lds_bytes(d + ic, n, z, d, m, has_w);
+    int c = BLOCK_CLASS;
+    for (int k = 0; k < NUM_WAVE_CLASSES; ++k)
+      if (tab.lds_bytes[k] > 0 && bytes <= (size_t)tab.lds_bytes[k]) { c = k; break; }
+    cls_out[e] = c;
+    atomicAdd(&local[c], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < GDMIX_RE_NUM_CLASSES && local[threadIdx.x]) atomicAdd(&counts[threadIdx.x], local[threadIdx.x]);
+}
+
+// order[class_base[c] + k] = e. Position inside a class is by atomic ticket: the launch order inside a
+// class does not influence any entity's result (every entity is solved independently and
+// deterministically), only which workgroup picks it up.
+__global__ void re_order_kernel(const int32_t* __restrict__ cls, int64_t E, const int32_t* __restrict__ class_base,
+                                int32_t* __restrict__ cursor, int32_t* __restrict__ order) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = cls[e];
+    const int pos = atomicAdd(&cursor[c], 1);
+    order[class_base[c] + pos] = (int32_t)e;
+  }
+}
+
+hipError_t launch_classify(const gdmix_re_packed* b, int ic, int m, const ClassTable& tab, int32_t* cls_tmp,
+                           int32_t* counts_dev, hipStream_t s) {
+  if (b->E == 0) return hipSuccess;
+  int grid = (int)((b->E + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(re_classify_kernel, dim3(grid), dim3(256), 0, s, b->ent_row_ptr, b->ent_nnz_ptr,
+                     b->ent_feat_ptr, b->E, ic, m, b->weight != nullptr, tab, cls_tmp, counts_dev);
+  return hipGetLastError();
+}
+
+hipError_t launch_order(const gdmix_re_packed* b, const int32_t* cls_tmp, const int32_t* class_base_dev,
+                        int32_t* cursor_dev, hipStream_t s) {
+  if (b->E == 0) return hipSuccess;
+  int grid = (int)((b->E + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(re_order_kernel, dim3(grid), dim3(256), 0, s, cls_tmp, b->E, class_base_dev, cursor_dev,
+                     b->order);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// shared epilogue: theta, thresholded theta, stats
+// ---------------------------------------------------------------------------------------------------
+template <class G>
+__device__ __forceinline__ void write_results(G& grp, const OutDev& O, const SolveParams& o, int64_t e, int64_t c0,
+                                              int p, const double* x, const SolveStats& st) {
+  for (int j = grp.tid; j < p; j += G::NT) {
+    const double v = x[j];
+    if (O.theta) O.theta[c0 + j] = v;
+    // threshold_coefficients: |x| <= threshold -> 0.0, intercept included (util/model_utils.py:4-12)
+    if (O.theta_thr) O.theta_thr[c0 + j] = (fabs(v) <= o.threshold) ? 0.0 : v;
+  }
+  if (grp.tid == 0) {
+    if (O.fval) O.fval[e] = st.f;
+    if (O.gnorm) O.gnorm[e] = st.gnorm;
+    if (O.nit) O.nit[e] = st.nit;
+    if (O.nfev) O.nfev[e] = st.nfev;
+    if (O.status) O.status[e] = st.status;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one wavefront per entity, everything LDS-resident
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void re_solve_wave_kernel(BatchDev B, OutDev O, SolveParams o,
+                                                             const double* __restrict__ theta0, int begin) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int64_t e = B.order[begin + blockIdx.x];
+  const int ic = o.has_intercept ? 1 : 0;
+  const int64_t r0 = B.ent_row_ptr[e], z0 = B.ent_nnz_ptr[e], f0 = B.ent_feat_ptr[e];
+  const int n = (int)(B.ent_row_ptr[e + 1] - r0);
+  const int nnz = (int)(B.ent_nnz_ptr[e + 1] - z0);
+  const int d = (int)(B.ent_feat_ptr[e + 1] - f0);
+  const int p = d + ic;
+  const int m = o.m;
+  const int64_t c0 = f0 + e * ic;
+
+  // carve-up: doubles first (8-byte aligned), then 4-byte arrays; must match wave_lds_bytes()
+  double* dp = reinterpret_cast<double*>(smem);
+  Work W;
+  W.x = dp; dp += p;
+  W.g = dp; dp += p;
+  W.d = dp; dp += p;
+  W.t = dp; dp += p;
+  W.r = dp; dp += p;
+  W.ws = dp; dp += (size_t)m * p;
+  W.wy = dp; dp += (size_t)m * p;
+  W.rs = dp; dp += n;
+  W.alpha = dp; dp += m;
+  W.rho = dp; dp += m;
+  float* fp = reinterpret_cast<float*>(dp);
+  float* s_csr_val = fp; fp += nnz;
+  float* s_csc_val = fp; fp += nnz;
+  float* s_y = fp; fp += n;
+  float* s_o = fp; fp += n;
+  float* s_w = nullptr;
+  if (B.weight) { s_w = fp; fp += n; }
+  int32_t* ip = reinterpret_cast<int32_t*>(fp);
+  int32_t* s_csr_col = ip; ip += nnz;
+  int32_t* s_csc_row = ip; ip += nnz;
+  int32_t* s_row_ptr = ip; ip += n + 1;
+  int32_t* s_col_ptr = ip; ip += d + 1;
+
+  // stage the entity's block: every array is a contiguous slice of the packed batch -> coalesced reads
+  for (int k = lane; k < nnz; k += WAVE) {
+    s_csr_val[k] = B.csr_val[z0 + k];
+    s_csr_col[k] = B.csr_col[z0 + k];
+    s_csc_val[k] = B.csc_val[z0 + k];
+    s_csc_row[k] = B.csc_row[z0 + k];
+  }
+  for (int i = lane; i < n; i += WAVE) {
+    s_y[i] = B.y[r0 + i];
+    s_o[i] = B.offset[r0 + i];
+    if (s_w) s_w[i] = B.weight[r0 + i];
+  }
+  for (int i = lane; i <= n; i += WAVE) s_row_ptr[i] = B.row_ptr[r0 + e + i];
+  for (int i = lane; i <= d; i += WAVE) s_col_ptr[i] = B.col_ptr[f0 + e + i];
+  for (int j = lane; j < p; j += WAVE) W.x[j] = theta0 ? theta0[c0 + j] : 0.0;
+
+  WaveGroup grp{lane};
+  grp.sync();
+  EntityView P{n, d, p, ic, s_row_ptr, s_csr_col, s_csr_val, s_col_ptr, s_csc_row, s_csc_val, s_y, s_o, s_w};
+  SolveStats st;
+  lbfgs_solve(grp, P, o, W, st);
+  write_results(grp, O, o, e, c0, p, W.x, st);
+  if (o.variance_mode == GDMIX_RE_VAR_SIMPLE && O.variance) variance_simple(grp, P, o, W, O.variance + c0);
+}
+
+hipError_t launch_solve_wave(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
+                             int begin, int count, int lds_bytes, hipStream_t s) {
+  if (count <= 0) return hipSuccess;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(re_solve_wave_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (rc != hipSuccess) return rc;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(re_solve_wave_kernel, dim3(count), dim3(WAVE), (size_t)lds_bytes, s, B, O, o, theta0, begin);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one workgroup per entity, state in a global scratch slot, X streamed from HBM/L2
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE* BLOCK_NW) void re_solve_block_kernel(BatchDev B, OutDev O, SolveParams o,
+                                                                        const double* __restrict__ theta0,
+                                                                        int begin, int count, double* scratch,
+                                                                        size_t slot_doubles, int64_t max_p) {
+  __shared__ double red[2 * BLOCK_NW];
+  const int ic = o.has_intercept ? 1 : 0;
+  const int m = o.m;
+  double* slot = scratch + (size_t)blockIdx.x * slot_doubles;
+  for (int idx = blockIdx.x; idx < count; idx += gridDim.x) {
+    const int64_t e = B.order[begin + idx];
+    const int64_t r0 = B.ent_row_ptr[e], z0 = B.ent_nnz_ptr[e], f0 = B.ent_feat_ptr[e];
+    const int n = (int)(B.ent_row_ptr[e + 1] - r0);
+    const int d = (int)(B.ent_feat_ptr[e + 1] - f0);
+    const int p = d + ic;
+    const int64_t c0 = f0 + e * ic;
+    double* dp = slot;
+    Work W;
+    W.x = dp; dp += max_p;
+    W.g = dp; dp += max_p;
+    W.d = dp; dp += max_p;
+    W.t = dp; dp += max_p;
+    W.r = dp; dp += max_p;
+    W.ws = dp; dp += (size_t)m * max_p;
+    W.wy = dp; dp += (size_t)m * max_p;
+    W.alpha = dp; dp += m;
+    W.rho = dp; dp += m;
+    W.rs = dp;
+    BlockGroup<BLOCK_NW> grp{(int)threadIdx.x, red, 0};
+    for (int j = grp.tid; j < p; j += grp.NT) W.x[j] = theta0 ? theta0[c0 + j] : 0.0;
+    grp.sync();
+    EntityView P{n, d, p, ic, B.row_ptr + r0 + e, B.csr_col + z0, B.csr_val + z0, B.col_ptr + f0 + e,
+                 B.csc_row + z0, B.csc_val + z0, B.y + r0, B.offset + r0, B.weight ? B.weight + r0 : nullptr};
+    SolveStats st;
+    lbfgs_solve(grp, P, o, W, st);
+    write_results(grp, O, o, e, c0, p, W.x, st);
+    if (o.variance_mode == GDMIX_RE_VAR_SIMPLE && O.variance) variance_simple(grp, P, o, W, O.variance + c0);
+    grp.sync();   // the slot is reused by the next entity
+  }
+}
+
+hipError_t launch_solve_block(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
+                              int begin, int count, double* scratch, size_t slot_doubles, int slots,
+                              int64_t max_p, hipStream_t s) {
+  if (count <= 0) return hipSuccess;
+  int grid = count < slots ? count : slots;
+  hipLaunchKernelGGL(re_solve_block_kernel, dim3(grid), dim3(WAVE * BLOCK_NW), 0, s, B, O, o, theta0, begin, count,
+                     scratch, slot_doubles, max_p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// scoring: one wavefront per entity, lane per sample  (job_consumers.py:138-152)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void re_score_kernel(BatchDev B, int64_t E, int ic, const double* __restrict__ theta,
+                                                       const uint8_t* __restrict__ has_model,
+                                                       float* __restrict__ logit, float* __restrict__ per_coord) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t e = wave0; e < E; e += nwaves) {
+    const int64_t r0 = B.ent_row_ptr[e], z0 = B.ent_nnz_ptr[e];
+    const int n = (int)(B.ent_row_ptr[e + 1] - r0);
+    const int64_t c0 = B.ent_feat_ptr[e] + e * ic;
+    const bool model = has_model ? has_model[e] != 0 : true;
+    const int32_t* rp = B.row_ptr + r0 + e;
+    const double x0 = (ic && model) ? theta[c0] : 0.0;
+    for (int i = lane; i < n; i += WAVE) {
+      const double off = (double)B.offset[r0 + i];
+      double z;
+      if (model) {
+        double acc = x0;
+        for (int k = rp[i]; k < rp[i + 1]; ++k) acc += (double)B.csr_val[z0 + k] * theta[c0 + ic + B.csr_col[z0 + k]];
+        z = acc + off;
+      } else {
+        z = off;
+      }
+      logit[r0 + i] = (float)z;
+      per_coord[r0 + i] = (float)(z - off);
+    }
+  }
+}
+
+hipError_t launch_score(const BatchDev& B, int64_t E, int ic, const double* theta, const uint8_t* has_model,
+                        float* logit, float* per_coord, hipStream_t s) {
+  if (E <= 0) return hipSuccess;
+  int64_t blocks = (E + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(re_score_kernel, dim3((int)blocks), dim3(256), 0, s, B, E, ic, theta, has_model, logit, per_coord);
+  return hipGetLastError();
+}
+
+}  // namespace gdmix

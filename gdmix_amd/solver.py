@@ -1,0 +1,370 @@
+"""ctypes binding of libgdmix_re.so (include/gdmix_re.h) — the device solve behind the model API.
+
+PyTorch-ROCm is used for plumbing only: device buffers (torch tensors), the current HIP stream and
+host<->device copies. Every numeric step runs in the hand-written HIP kernels of gdmix_amd/csrc.
+
+There is NO CPU fallback: if the library is missing or no gfx950 device is visible, construction
+raises. (The CPU restatement under oracle/ is test infrastructure and is never imported here.)
+"""
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from .batch import RawBatch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgdmix_re.so")
+
+NUM_CLASSES = 8
+STATUS_NAMES = ("PGTOL", "FACTR", "MAXITER", "MAXFUN", "ABNORMAL")
+VAR_NONE, VAR_SIMPLE, VAR_FULL = 0, 1, 2
+VARIANCE_MODES = {None: VAR_NONE, "simple": VAR_SIMPLE, "SIMPLE": VAR_SIMPLE, "full": VAR_FULL, "FULL": VAR_FULL,
+                  0: VAR_NONE, 1: VAR_SIMPLE, 2: VAR_FULL}
+
+
+class GdmixReError(RuntimeError):
+    pass
+
+
+class _RawBatch(C.Structure):
+    _fields_ = [("E", C.c_int64), ("N", C.c_int64), ("Z", C.c_int64),
+                ("ent_row_ptr", C.c_void_p), ("row_nnz_ptr", C.c_void_p), ("col_global", C.c_void_p),
+                ("val", C.c_void_p), ("y", C.c_void_p), ("offset", C.c_void_p), ("weight", C.c_void_p)]
+
+
+class _Packed(C.Structure):
+    _fields_ = [("E", C.c_int64), ("N", C.c_int64), ("Z", C.c_int64), ("D", C.c_int64),
+                ("ent_row_ptr", C.c_void_p), ("ent_nnz_ptr", C.c_void_p), ("ent_feat_ptr", C.c_void_p),
+                ("row_ptr", C.c_void_p), ("csr_col", C.c_void_p), ("csr_val", C.c_void_p),
+                ("col_ptr", C.c_void_p), ("csc_row", C.c_void_p), ("csc_val", C.c_void_p),
+                ("unique_global", C.c_void_p), ("y", C.c_void_p), ("offset", C.c_void_p), ("weight", C.c_void_p),
+                ("order", C.c_void_p), ("cls_tmp", C.c_void_p), ("class_count", C.c_void_p),
+                ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
+                ("max_p", C.c_int32), ("max_n", C.c_int32), ("max_nnz", C.c_int32)]
+
+
+class _Opts(C.Structure):
+    _fields_ = [("l2", C.c_double), ("regularize_bias", C.c_int32), ("has_intercept", C.c_int32),
+                ("m", C.c_int32), ("max_iter", C.c_int32), ("maxfun", C.c_int32), ("maxls", C.c_int32),
+                ("ftol", C.c_double), ("pgtol", C.c_double), ("variance_mode", C.c_int32),
+                ("threshold", C.c_double)]
+
+
+class _Result(C.Structure):
+    _fields_ = [("theta", C.c_void_p), ("theta_thr", C.c_void_p), ("variance", C.c_void_p),
+                ("fval", C.c_void_p), ("gnorm", C.c_void_p), ("nit", C.c_void_p), ("nfev", C.c_void_p),
+                ("status", C.c_void_p)]
+
+
+EXPORTED_SYMBOLS = (
+    "gdmix_re_abi_version", "gdmix_re_last_error", "gdmix_re_default_opts", "gdmix_re_create",
+    "gdmix_re_destroy", "gdmix_re_pack_workspace_bytes", "gdmix_re_pack", "gdmix_re_solve",
+    "gdmix_re_solve_scratch_bytes", "gdmix_re_set_scratch", "gdmix_re_set_wave_lds_limit", "gdmix_re_score",
+    "gdmix_re_set_timing", "gdmix_re_last_solve_ms",
+    "gdmix_re_class_kernel_name", "gdmix_java_string_hash", "gdmix_java_partition_id",
+    "gdmix_java_partition_ids_i64")
+
+_lib = None
+
+
+def load_library():
+    """dlopen libgdmix_re.so (built in-tree by gdmix_amd.build). Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GdmixReError(
+            f"{LIB_PATH} is missing: build it with `python -m gdmix_amd.build` "
+            "(there is no CPU fallback for the random-effect solve)")
+    try:  # make sure the HIP runtime torch already loaded (if any) is the one the library binds to
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is always present in this image
+        pass
+    lib = C.CDLL(LIB_PATH)
+    lib.gdmix_re_abi_version.restype = C.c_int
+    lib.gdmix_re_last_error.restype = C.c_char_p
+    lib.gdmix_re_default_opts.argtypes = [C.POINTER(_Opts)]
+    lib.gdmix_re_default_opts.restype = None
+    lib.gdmix_re_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.gdmix_re_destroy.argtypes = [C.c_void_p]
+    lib.gdmix_re_destroy.restype = None
+    lib.gdmix_re_pack_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64]
+    lib.gdmix_re_pack_workspace_bytes.restype = C.c_size_t
+    lib.gdmix_re_pack.argtypes = [C.c_void_p, C.POINTER(_RawBatch), C.c_int, C.c_void_p, C.c_size_t,
+                                  C.POINTER(_Packed), C.c_void_p]
+    lib.gdmix_re_solve.argtypes = [C.c_void_p, C.POINTER(_Packed), C.POINTER(_Opts), C.c_void_p,
+                                   C.POINTER(_Result), C.c_void_p]
+    lib.gdmix_re_solve_scratch_bytes.argtypes = [C.POINTER(_Packed), C.POINTER(_Opts)]
+    lib.gdmix_re_solve_scratch_bytes.restype = C.c_size_t
+    lib.gdmix_re_set_scratch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.gdmix_re_set_wave_lds_limit.argtypes = [C.c_void_p, C.c_int]
+    lib.gdmix_re_set_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.gdmix_re_last_solve_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.gdmix_re_score.argtypes = [C.c_void_p, C.POINTER(_Packed), C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gdmix_re_class_kernel_name.argtypes = [C.c_int]
+    lib.gdmix_re_class_kernel_name.restype = C.c_char_p
+    lib.gdmix_java_string_hash.argtypes = [C.c_void_p, C.c_int64]
+    lib.gdmix_java_string_hash.restype = C.c_int32
+    lib.gdmix_java_partition_id.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+    lib.gdmix_java_partition_id.restype = C.c_int32
+    lib.gdmix_java_partition_ids_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+    if lib.gdmix_re_abi_version() != 1:
+        raise GdmixReError("libgdmix_re.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().gdmix_re_last_error().decode("utf-8", "replace")
+        raise GdmixReError(f"{what} failed ({rc}): {msg}")
+
+
+@dataclass
+class SolverOptions:
+    """Solver knobs; defaults are REParams/LRParams defaults (base_lr_params.py:22-27) plus scipy's
+    fmin_l_bfgs_b defaults for the arguments the reference leaves unset (pgtol, maxfun, maxls)."""
+    l2: float = 1.0
+    regularize_bias: bool = True
+    has_intercept: bool = True
+    m: int = 10
+    max_iter: int = 100
+    maxfun: int = 15000
+    maxls: int = 20
+    ftol: float = 1e-12           # = factr*eps = lbfgs_tolerance (random_effect_lr_lbfgs_model.py:142-146)
+    pgtol: float = 1e-5
+    variance_mode: int = VAR_NONE
+    threshold: float = 1e-4       # sparsity_threshold (base_lr_params.py:32)
+
+    def to_c(self):
+        return _Opts(float(self.l2), int(bool(self.regularize_bias)), int(bool(self.has_intercept)),
+                     int(self.m), int(self.max_iter), int(self.maxfun), int(self.maxls), float(self.ftol),
+                     float(self.pgtol), int(VARIANCE_MODES[self.variance_mode]), float(self.threshold))
+
+
+def java_string_hash(s: str) -> int:
+    """String.hashCode of the JVM (PartitionUtils.scala:31-37), over UTF-16 code units."""
+    cu = np.frombuffer(s.encode("utf-16-le"), dtype=np.uint16).copy()
+    return int(load_library().gdmix_java_string_hash(cu.ctypes.data_as(C.c_void_p), cu.size))
+
+
+def java_partition_id(s: str, num_partitions: int) -> int:
+    """Math.abs(s.hashCode) % numPartitions, bit-exact incl. Int.MinValue (PartitionUtils.scala:31-37)."""
+    cu = np.frombuffer(s.encode("utf-16-le"), dtype=np.uint16).copy()
+    return int(load_library().gdmix_java_partition_id(cu.ctypes.data_as(C.c_void_p), cu.size, num_partitions))
+
+
+class PackedBatch:
+    """A packed ragged CSR/CSC batch resident in HBM. Keeps the torch tensors that back it alive."""
+
+    def __init__(self, c_struct, tensors, raw_dev, has_intercept):
+        self.c = c_struct
+        self._tensors = tensors
+        self._raw_dev = raw_dev
+        self.has_intercept = bool(has_intercept)
+        self.E, self.N, self.Z, self.D = int(c_struct.E), int(c_struct.N), int(c_struct.Z), int(c_struct.D)
+        self.P = self.D + (self.E if has_intercept else 0)
+        self.max_p, self.max_n, self.max_nnz = int(c_struct.max_p), int(c_struct.max_n), int(c_struct.max_nnz)
+
+    def _view(self, ptr, count, dtype):
+        import torch
+        ws = self._tensors["workspace"]
+        off = ptr - ws.data_ptr()
+        nbytes = count * torch.empty(0, dtype=dtype).element_size()
+        return ws[off:off + nbytes].view(dtype)
+
+    # device views (torch tensors) of the arrays produced by the pack kernels
+    def ent_feat_ptr(self):
+        import torch
+        return self._view(self.c.ent_feat_ptr, self.E + 1, torch.int64)
+
+    def ent_nnz_ptr(self):
+        import torch
+        return self._view(self.c.ent_nnz_ptr, self.E + 1, torch.int64)
+
+    def unique_global(self):
+        import torch
+        return self._view(self.c.unique_global, self.D, torch.int64)
+
+    def csr_col(self):
+        import torch
+        return self._view(self.c.csr_col, self.Z, torch.int32)
+
+    def row_ptr(self):
+        import torch
+        return self._view(self.c.row_ptr, self.N + self.E, torch.int32)
+
+    def col_ptr(self):
+        import torch
+        return self._view(self.c.col_ptr, self.D + self.E, torch.int32)
+
+    def csc_row(self):
+        import torch
+        return self._view(self.c.csc_row, self.Z, torch.int32)
+
+    def csc_val(self):
+        import torch
+        return self._view(self.c.csc_val, self.Z, torch.float32)
+
+    def coef_ptr_host(self):
+        """[E+1] int64 numpy: offsets of each entity's coefficient slice in theta."""
+        fp = self.ent_feat_ptr().cpu().numpy()
+        return fp + (np.arange(self.E + 1, dtype=np.int64) if self.has_intercept else 0)
+
+
+class SolveResult:
+    def __init__(self, tensors, E, P):
+        self._t = tensors
+        self.E, self.P = E, P
+
+    def __getattr__(self, k):
+        t = self.__dict__.get("_t", {})
+        if k in t:
+            return t[k]
+        raise AttributeError(k)
+
+    def to_host(self):
+        return {k: (v.cpu().numpy() if v is not None else None) for k, v in self._t.items()}
+
+
+class REDeviceSolver:
+    """One MI355X: pack, solve and score entity batches through the C ABI."""
+
+    def __init__(self, device: int = 0):
+        import torch
+        if not torch.cuda.is_available():
+            raise GdmixReError("no HIP device visible: the random-effect solve runs on MI355X only "
+                               "(there is no CPU fallback)")
+        self.torch = torch
+        self.lib = load_library()
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        torch.cuda.set_device(self.device)
+        torch.zeros(1, device=self.device)  # force HIP context creation through torch's runtime
+        h = C.c_void_p()
+        _check(self.lib.gdmix_re_create(self.device_index, C.byref(h)), "gdmix_re_create")
+        self._h = h
+        self._scratch = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.gdmix_re_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_wave_lds_limit(self, nbytes: int):
+        """Entities whose LDS footprint exceeds nbytes go to the workgroup-per-entity kernel (0 = all)."""
+        _check(self.lib.gdmix_re_set_wave_lds_limit(self._h, int(nbytes)), "set_wave_lds_limit")
+
+    def set_timing(self, enabled: bool):
+        _check(self.lib.gdmix_re_set_timing(self._h, int(bool(enabled))), "set_timing")
+
+    def last_solve_ms(self):
+        """Per-size-class kernel milliseconds of the last solve (HIP events on the launch stream)."""
+        ms = (C.c_float * NUM_CLASSES)()
+        _check(self.lib.gdmix_re_last_solve_ms(self._h, ms), "last_solve_ms")
+        return [float(x) for x in ms]
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- upload + pack -------------------------------------------------------------------------
+    def upload(self, raw: RawBatch):
+        """Copy the raw ragged arrays to HBM (pinned-free simple path). Returns dict of device tensors."""
+        t = self.torch
+        dev = self.device
+        d = dict(ent_row_ptr=t.from_numpy(raw.ent_row_ptr).to(dev), row_nnz_ptr=t.from_numpy(raw.row_nnz_ptr).to(dev),
+                 col_global=t.from_numpy(raw.col_global).to(dev), val=t.from_numpy(raw.val).to(dev),
+                 y=t.from_numpy(raw.y).to(dev), offset=t.from_numpy(raw.offset).to(dev),
+                 weight=None if raw.weight is None else t.from_numpy(raw.weight).to(dev))
+        d["E"], d["N"], d["Z"] = raw.E, raw.N, raw.Z
+        return d
+
+    def pack(self, raw, has_intercept=True) -> PackedBatch:
+        """raw: RawBatch (host) or the dict returned by upload() (device)."""
+        t = self.torch
+        rd = self.upload(raw) if isinstance(raw, RawBatch) else raw
+        E, N, Z = rd["E"], rd["N"], rd["Z"]
+        ptr = lambda x: None if x is None or x.numel() == 0 else x.data_ptr()
+        c_raw = _RawBatch(E, N, Z, rd["ent_row_ptr"].data_ptr(), rd["row_nnz_ptr"].data_ptr(), ptr(rd["col_global"]),
+                          ptr(rd["val"]), ptr(rd["y"]), ptr(rd["offset"]), ptr(rd["weight"]))
+        nbytes = self.lib.gdmix_re_pack_workspace_bytes(E, N, Z)
+        ws = t.empty(nbytes, dtype=t.uint8, device=self.device)
+        c_packed = _Packed()
+        _check(self.lib.gdmix_re_pack(self._h, C.byref(c_raw), int(bool(has_intercept)), ws.data_ptr(), nbytes,
+                                      C.byref(c_packed), self._stream()), "gdmix_re_pack")
+        return PackedBatch(c_packed, {"workspace": ws}, rd, has_intercept)
+
+    # ---- solve -----------------------------------------------------------------------------------
+    def alloc_result(self, packed: PackedBatch, variance=False):
+        t, dev = self.torch, self.device
+        E, P = packed.E, packed.P
+        return dict(theta=t.empty(P, dtype=t.float64, device=dev), theta_thr=t.empty(P, dtype=t.float64, device=dev),
+                    variance=t.empty(P, dtype=t.float64, device=dev) if variance else None,
+                    fval=t.empty(E, dtype=t.float64, device=dev), gnorm=t.empty(E, dtype=t.float64, device=dev),
+                    nit=t.empty(E, dtype=t.int32, device=dev), nfev=t.empty(E, dtype=t.int32, device=dev),
+                    status=t.full((E,), -1, dtype=t.int32, device=dev))
+
+    def solve(self, packed: PackedBatch, opts: Optional[SolverOptions] = None, theta0=None, out=None) -> SolveResult:
+        t = self.torch
+        opts = opts or SolverOptions()
+        if bool(opts.has_intercept) != packed.has_intercept:
+            raise GdmixReError("has_intercept of the options differs from the packed batch")
+        c_opts = opts.to_c()
+        need = self.lib.gdmix_re_solve_scratch_bytes(C.byref(packed.c), C.byref(c_opts))
+        if need > packed.c.scratch_bytes and (self._scratch is None or self._scratch.numel() < need):
+            self._scratch = t.empty(need, dtype=t.uint8, device=self.device)
+        if self._scratch is not None:
+            _check(self.lib.gdmix_re_set_scratch(self._h, self._scratch.data_ptr(), self._scratch.numel()), "set_scratch")
+        if theta0 is not None:
+            if isinstance(theta0, np.ndarray):
+                theta0 = t.from_numpy(np.ascontiguousarray(theta0, np.float64)).to(self.device)
+            if theta0.numel() != packed.P or theta0.dtype != t.float64:
+                raise GdmixReError("theta0 must be float64 with one entry per coefficient")
+        tensors = out or self.alloc_result(packed, variance=c_opts.variance_mode != VAR_NONE)
+        p = lambda x: None if x is None else x.data_ptr()
+        c_res = _Result(p(tensors["theta"]), p(tensors["theta_thr"]), p(tensors.get("variance")), p(tensors["fval"]),
+                        p(tensors["gnorm"]), p(tensors["nit"]), p(tensors["nfev"]), p(tensors["status"]))
+        _check(self.lib.gdmix_re_solve(self._h, C.byref(packed.c), C.byref(c_opts), p(theta0), C.byref(c_res),
+                                       self._stream()), "gdmix_re_solve")
+        return SolveResult(tensors, packed.E, packed.P)
+
+    def class_counts(self, packed: PackedBatch):
+        """Entities per size class of the last solve on this batch (host list) + kernel names."""
+        t = self.torch
+        cc = packed._view(packed.c.class_count, 64, t.int32).cpu().numpy()
+        names = [self.lib.gdmix_re_class_kernel_name(c).decode() for c in range(NUM_CLASSES)]
+        return list(zip(names, cc[:NUM_CLASSES].tolist()))
+
+    # ---- score -----------------------------------------------------------------------------------
+    def score(self, packed: PackedBatch, theta, has_model=None):
+        t = self.torch
+        if isinstance(theta, np.ndarray):
+            theta = t.from_numpy(np.ascontiguousarray(theta, np.float64)).to(self.device)
+        if has_model is not None and isinstance(has_model, np.ndarray):
+            has_model = t.from_numpy(np.ascontiguousarray(has_model, np.uint8)).to(self.device)
+        logit = t.empty(packed.N, dtype=t.float32, device=self.device)
+        per = t.empty(packed.N, dtype=t.float32, device=self.device)
+        _check(self.lib.gdmix_re_score(self._h, C.byref(packed.c), int(packed.has_intercept), theta.data_ptr(),
+                                       None if has_model is None else has_model.data_ptr(), logit.data_ptr(),
+                                       per.data_ptr(), self._stream()), "gdmix_re_score")
+        return logit, per
+
+    def partition_ids(self, ids, num_partitions: int):
+        """Math.abs(id.toString.hashCode) % numPartitions for int64 entity ids, on the device."""
+        t = self.torch
+        if isinstance(ids, np.ndarray):
+            ids = t.from_numpy(np.ascontiguousarray(ids, np.int64)).to(self.device)
+        out = t.empty(ids.numel(), dtype=t.int32, device=self.device)
+        _check(self.lib.gdmix_java_partition_ids_i64(self._h, ids.data_ptr(), ids.numel(), int(num_partitions),
+                                                     out.data_ptr(), self._stream()), "partition_ids")
+        return out

@@ -40,6 +40,12 @@ extern "C" {
 
 #define GDMIX_RE_ABI_VERSION 1
 
+#if defined(__GNUC__)
+#define GDMIX_API __attribute__((visibility("default")))
+#else
+#define GDMIX_API
+#endif
+
 /* error codes */
 #define GDMIX_RE_OK          0
 #define GDMIX_RE_EINVAL    (-1)   /* bad argument */
@@ -104,10 +110,13 @@ typedef struct {
   const float*   y;             /* [N]   */
   const float*   offset;        /* [N]   */
   const float*   weight;        /* [N] or NULL */
+  /* solver-owned scratch inside the workspace (written by gdmix_re_solve) */
   int32_t*       order;         /* [E]   entity ids grouped by size class (solver launch order)     */
-  int32_t*       class_count;   /* [GDMIX_RE_NUM_CLASSES] entities per size class (device)          */
-  void*          scratch;       /* pack-time scratch, reused by the solver for large entities       */
+  int32_t*       cls_tmp;       /* [E]   size class of each entity                                  */
+  int32_t*       class_count;   /* [64]  per-class counts / bases / cursors (device)                */
+  void*          scratch;       /* pack-time sort scratch, free for reuse once pack has returned    */
   size_t         scratch_bytes;
+  int32_t        max_p, max_n, max_nnz;  /* per-entity maxima over the batch (host, after pack)     */
 } gdmix_re_packed;
 
 #define GDMIX_RE_NUM_CLASSES 8
@@ -129,7 +138,7 @@ typedef struct {
 } gdmix_re_opts;
 
 /* fills *o with the defaults above */
-void gdmix_re_default_opts(gdmix_re_opts* o);
+GDMIX_API void gdmix_re_default_opts(gdmix_re_opts* o);
 
 /* ---- per-entity / per-coefficient outputs of a solve (device pointers; any may be NULL) ----------- */
 typedef struct {
@@ -143,51 +152,61 @@ typedef struct {
   int32_t* status;     /* [E]  GDMIX_RE_ST_*                                                         */
 } gdmix_re_result;
 
-int  gdmix_re_abi_version(void);
-const char* gdmix_re_last_error(void);
+GDMIX_API int  gdmix_re_abi_version(void);
+GDMIX_API const char* gdmix_re_last_error(void);
 
-int  gdmix_re_create(int hip_device, gdmix_re_ctx** out);
-void gdmix_re_destroy(gdmix_re_ctx* ctx);
+GDMIX_API int  gdmix_re_create(int hip_device, gdmix_re_ctx** out);
+GDMIX_API void gdmix_re_destroy(gdmix_re_ctx* ctx);
 
 /* Bytes of device workspace gdmix_re_pack needs for a batch of this shape (upper bound; host-only). */
-size_t gdmix_re_pack_workspace_bytes(int64_t E, int64_t N, int64_t Z);
+GDMIX_API size_t gdmix_re_pack_workspace_bytes(int64_t E, int64_t N, int64_t Z);
 
 /* Pack: per entity, unique-sort the global feature indices, re-index the non-zeros locally, build the
  * CSR and CSC copies and the size-class launch order — all on the device. Fills *out (a host struct
  * of device pointers into `workspace`). Synchronises `stream` once to read back D and the class
  * counts. replaces job_consumers.py:209-258 (enable_local_indexing=True form; the reference's
  * global-indexing form yields identical coefficients on the entity's support). */
-int gdmix_re_pack(gdmix_re_ctx* ctx, const gdmix_re_raw_batch* raw_dev, int has_intercept,
+GDMIX_API int gdmix_re_pack(gdmix_re_ctx* ctx, const gdmix_re_raw_batch* raw_dev, int has_intercept,
                   void* workspace, size_t workspace_bytes, gdmix_re_packed* out, void* stream);
 
 /* Solve every entity of the packed batch: the whole L-BFGS loop runs on the device, one wavefront
  * (or workgroup, for entities that do not fit a wavefront's LDS budget) per entity.
  * theta0: [P] warm-start coefficients in local index space, or NULL => zeros (fit():220-221). */
-int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* batch, const gdmix_re_opts* opts,
+GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* batch, const gdmix_re_opts* opts,
                    const double* theta0, const gdmix_re_result* out, void* stream);
 
 /* Bytes of device scratch gdmix_re_solve needs beyond the pack workspace (0 if none). */
-size_t gdmix_re_solve_scratch_bytes(const gdmix_re_packed* batch, const gdmix_re_opts* opts);
-int    gdmix_re_set_scratch(gdmix_re_ctx* ctx, void* scratch, size_t bytes);
+GDMIX_API size_t gdmix_re_solve_scratch_bytes(const gdmix_re_packed* batch, const gdmix_re_opts* opts);
+GDMIX_API int    gdmix_re_set_scratch(gdmix_re_ctx* ctx, void* scratch, size_t bytes);
 
 /* Score: logit[i] = x_i . theta_e + offset[i] (fp64 accumulate, stored fp32 as the score Avro
  * does, io_utils.py:367-375), logit_per_coord[i] = logit[i] - offset[i] (job_consumers.py:145-150).
  * has_model: [E] uint8, 0 => entity has no model and logit = offset (job_consumers.py:145-146);
  * NULL => all entities have one. theta is in the batch's local index space [P]. */
-int gdmix_re_score(gdmix_re_ctx* ctx, const gdmix_re_packed* batch, int has_intercept,
+GDMIX_API int gdmix_re_score(gdmix_re_ctx* ctx, const gdmix_re_packed* batch, int has_intercept,
                    const double* theta, const uint8_t* has_model,
                    float* logit, float* logit_per_coord, void* stream);
 
+/* Tuning/testing knob: entities whose LDS footprint exceeds `bytes` are solved by the
+ * workgroup-per-entity kernel (0 => every entity). Default and maximum 65536. */
+GDMIX_API int gdmix_re_set_wave_lds_limit(gdmix_re_ctx* ctx, int bytes);
+
+/* Optional kernel timing: when enabled, gdmix_re_solve brackets each size class's kernel launch with
+ * HIP events on the caller's stream; gdmix_re_last_solve_ms waits for them and returns the elapsed
+ * milliseconds per class ([GDMIX_RE_NUM_CLASSES] floats, 0 for classes that were not launched). */
+GDMIX_API int gdmix_re_set_timing(gdmix_re_ctx* ctx, int enabled);
+GDMIX_API int gdmix_re_last_solve_ms(gdmix_re_ctx* ctx, float* ms_out);
+
 /* Name of the kernel variant that solved size class c (for profiling reports), or NULL. */
-const char* gdmix_re_class_kernel_name(int c);
+GDMIX_API const char* gdmix_re_class_kernel_name(int c);
 
 /* ---- B4: the upstream Spark partitioner's hash, bit-exact (host functions) ------------------------
  * hashCode over UTF-16 code units in wrapping int32; Math.abs(Int.MinValue) stays negative; Scala %
  * keeps the dividend's sign (PartitionUtils.scala:31-37). */
-int32_t gdmix_java_string_hash(const uint16_t* utf16, int64_t len);
-int32_t gdmix_java_partition_id(const uint16_t* utf16, int64_t len, int32_t num_partitions);
+GDMIX_API int32_t gdmix_java_string_hash(const uint16_t* utf16, int64_t len);
+GDMIX_API int32_t gdmix_java_partition_id(const uint16_t* utf16, int64_t len, int32_t num_partitions);
 /* Batched device form for decimal int64 entity ids (id.toString of a Long): out[i] = partition id. */
-int gdmix_java_partition_ids_i64(gdmix_re_ctx* ctx, const int64_t* ids_dev, int64_t count,
+GDMIX_API int gdmix_java_partition_ids_i64(gdmix_re_ctx* ctx, const int64_t* ids_dev, int64_t count,
                                  int32_t num_partitions, int32_t* out_dev, void* stream);
 
 #ifdef __cplusplus

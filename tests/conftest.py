@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def device_solver():
+    """One REDeviceSolver for the session; fails (not skips) if the HIP path cannot be used."""
+    from gdmix_amd import build
+    build.build_library()
+    from gdmix_amd.solver import REDeviceSolver
+    s = REDeviceSolver(0)
+    yield s
+    s.close()
