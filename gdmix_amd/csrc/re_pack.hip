@@ -7,13 +7,17 @@
 // (the order scipy's COO mat-vec accumulates them in) and the sort needs no stability.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "re_internal.hpp"
 
 namespace gdmix {
 
 constexpr int PACK_WAVES = 4;          // wavefronts (entities) per workgroup
-constexpr int PACK_LDS_KEYS = 512;     // per-wave LDS sort capacity; larger entities sort in HBM scratch
+#ifndef GDMIX_PACK_LDS_KEYS
+#define GDMIX_PACK_LDS_KEYS 512
+#endif
+constexpr int PACK_LDS_KEYS = GDMIX_PACK_LDS_KEYS;     // per-wave LDS sort capacity; larger entities sort in HBM scratch
 
 struct PackStats {      // device-side, read back once per pack
   unsigned long long D;
@@ -27,7 +31,8 @@ __global__ void pack_entnnz_kernel(const int64_t* __restrict__ ent_row_ptr, cons
 }
 
 // All comparators ascending, so keys at index >= n act as +inf padding and are simply skipped.
-__device__ __forceinline__ void wave_bitonic_sort(unsigned long long* a, int n, int lane) {
+template <class KeyPtr>
+__device__ __forceinline__ void wave_bitonic_sort(KeyPtr a, int n, int lane) {
   if (n < 2) return;
   int np2 = 1;
   while (np2 < n) np2 <<= 1;
@@ -55,13 +60,44 @@ __device__ __forceinline__ void wave_bitonic_sort(unsigned long long* a, int n, 
   }
 }
 
+// Build (col << 32 | pos) keys in `keys`, sort them, copy them to `dst` when `keys` is a staging
+// buffer, and return the number of distinct columns. `bad` reports a column outside [0, 2^31).
+template <class KeyPtr>
+__device__ __forceinline__ int sort_entity_keys(KeyPtr keys, const int64_t* __restrict__ cols,
+                                                unsigned long long* dst, int nnz, int lane,
+                                                bool copy_out, bool& bad_out) {
+  bool bad = false;
+  for (int k = lane; k < nnz; k += WAVE) {
+    const int64_t c = cols[k];
+    bad |= (c < 0 || c > 0x7fffffffll);
+    keys[k] = ((unsigned long long)(uint32_t)c << 32) | (unsigned)k;
+  }
+  bad_out = __ballot(bad) != 0ull;
+  wave_mem_fence();
+  wave_bitonic_sort(keys, nnz, lane);
+  int d = 0;
+  for (int base = 0; base < nnz; base += WAVE) {
+    const int k = base + lane;
+    bool head = false;
+    if (k < nnz) {
+      const unsigned long long key = keys[k];
+      unsigned long long prev = ~key;
+      if (k > 0) prev = keys[k - 1];
+      head = (prev >> 32) != (key >> 32);
+      if (copy_out) dst[k] = key;
+    }
+    d += __popcll(__ballot(head));
+  }
+  return d;
+}
+
 // Phase 1: entity-relative row pointers, sorted keys (to HBM scratch), distinct-column count, stats.
 __global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_sort_kernel(
     const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ row_nnz_ptr,
     const int64_t* __restrict__ ent_nnz_ptr, const int64_t* __restrict__ col_global, int64_t E, int ic,
     int32_t* __restrict__ row_ptr, unsigned long long* __restrict__ sort_key, int32_t* __restrict__ d_cnt,
     PackStats* __restrict__ stats) {
-  __shared__ unsigned long long lds_keys[PACK_WAVES][PACK_LDS_KEYS];
+  __shared__ unsigned long long lds_keys[PACK_WAVES][PACK_LDS_KEYS > 0 ? PACK_LDS_KEYS : 1];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wv = threadIdx.x >> 6;
   const int64_t e = (int64_t)blockIdx.x * PACK_WAVES + wv;
@@ -75,29 +111,14 @@ __global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_sort_kernel(
   }
   const int n = (int)n64, nnz = (int)nnz64;
   for (int i = lane; i <= n; i += WAVE) row_ptr[r0 + e + i] = (int32_t)(row_nnz_ptr[r0 + i] - z0);
-  unsigned long long* keys = (nnz <= PACK_LDS_KEYS) ? lds_keys[wv] : (sort_key + z0);
-  bool bad = false;
-  for (int k = lane; k < nnz; k += WAVE) {
-    const int64_t c = col_global[z0 + k];
-    bad |= (c < 0 || c > 0x7fffffffll);
-    keys[k] = ((unsigned long long)(uint32_t)c << 32) | (unsigned)k;
-  }
-  if (__ballot(bad)) {
-    if (lane == 0) atomicExch(&stats->err, GDMIX_RE_ERANGE);
-  }
-  wave_mem_fence();
-  wave_bitonic_sort(keys, nnz, lane);
-  int d = 0;
-  for (int base = 0; base < nnz; base += WAVE) {
-    const int k = base + lane;
-    bool head = false;
-    if (k < nnz) {
-      const unsigned long long key = keys[k];
-      head = (k == 0) || ((keys[k - 1] >> 32) != (key >> 32));
-      if (keys != sort_key + z0) sort_key[z0 + k] = key;
-    }
-    d += __popcll(__ballot(head));
-  }
+  // Two explicit instantiations so that each path keeps its address space (ds_* vs global_*): a
+  // generic pointer selecting between LDS and HBM compiles to flat_* accesses whose base+offset
+  // folding faults at the LDS aperture edge (keys[k-1] with k = 0).
+  int d;
+  bool bad;
+  if (nnz <= PACK_LDS_KEYS) d = sort_entity_keys(lds_keys[wv], col_global + z0, sort_key + z0, nnz, lane, true, bad);
+  else d = sort_entity_keys(sort_key + z0, col_global + z0, sort_key + z0, nnz, lane, false, bad);
+  if (bad && lane == 0) atomicExch(&stats->err, GDMIX_RE_ERANGE);
   if (lane == 0) {
     d_cnt[e] = d;
     atomicMax(&stats->max_p, d + ic);
@@ -248,6 +269,20 @@ size_t pack_workspace_bytes(int64_t E, int64_t N, int64_t Z) { return pack_layou
     }                                                                                   \
   } while (0)
 
+static bool debug_sync() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("GDMIX_RE_DEBUG_SYNC"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+#define DBG_STAGE(name)                                                        \
+  do {                                                                         \
+    if (debug_sync()) {                                                        \
+      hipError_t _e = hipStreamSynchronize(s);                                 \
+      fprintf(stderr, "[gdmix_re] %s: %s\n", name, hipGetErrorString(_e));     \
+      fflush(stderr);                                                          \
+    }                                                                          \
+  } while (0)
+
 int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_intercept, void* ws, size_t ws_bytes,
               gdmix_re_packed* out, hipStream_t s) {
   const int64_t E = raw->E, N = raw->N, Z = raw->Z;
@@ -292,16 +327,20 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
     hipLaunchKernelGGL(pack_entnnz_kernel, dim3(grid), dim3(256), 0, s, raw->ent_row_ptr, raw->row_nnz_ptr, E,
                        out->ent_nnz_ptr);
   }
+  DBG_STAGE("pack_entnnz_kernel");
   const int eblocks = (int)((E + PACK_WAVES - 1) / PACK_WAVES);
   hipLaunchKernelGGL(pack_sort_kernel, dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s, raw->ent_row_ptr,
                      raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, E, ic, out->row_ptr, sort_key, d_cnt, stats);
+  DBG_STAGE("pack_sort_kernel");
   const int nb = (int)((E + SCAN_CHUNK - 1) / SCAN_CHUNK);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, s, d_cnt, E, block_sums);
   hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1), 0, s, block_sums, nb, stats);
   hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, s, d_cnt, E, block_sums, out->ent_feat_ptr);
+  DBG_STAGE("scan kernels");
   hipLaunchKernelGGL(pack_fill_kernel, dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s, raw->ent_row_ptr,
                      out->ent_nnz_ptr, out->ent_feat_ptr, raw->val, E, out->row_ptr, sort_key, out->csr_col,
                      out->col_ptr, out->csc_row, out->csc_val, out->unique_global);
+  DBG_STAGE("pack_fill_kernel");
   HIP_TRY(hipGetLastError());
   PackStats* hs = reinterpret_cast<PackStats*>(ctx->host_pinned);
   HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(PackStats), hipMemcpyDeviceToHost, s));
