@@ -124,7 +124,7 @@ __device__ __forceinline__ void dcsrch_start(LineSearch& S, double f, double g, 
   S.stmin = 0.0; S.stmax = stp + 4.0 * stp;
 }
 
-__device__ __noinline__ void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy,
+__device__ __forceinline__ void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy,
                                     double& dy, double& stp, double fp, double dp, int& brackt,
                                     double stpmin, double stpmax) {
   double gamma, p, q, r, s, sgnd, stpc, stpf, stpq, theta;

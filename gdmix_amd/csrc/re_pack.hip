@@ -98,32 +98,44 @@ __global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_sort_kernel(
     int32_t* __restrict__ row_ptr, unsigned long long* __restrict__ sort_key, int32_t* __restrict__ d_cnt,
     PackStats* __restrict__ stats) {
   __shared__ unsigned long long lds_keys[PACK_WAVES][PACK_LDS_KEYS > 0 ? PACK_LDS_KEYS : 1];
+  __shared__ int blk_max[3];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wv = threadIdx.x >> 6;
-  const int64_t e = (int64_t)blockIdx.x * PACK_WAVES + wv;
-  if (e >= E) return;
-  const int64_t r0 = ent_row_ptr[e], r1 = ent_row_ptr[e + 1];
-  const int64_t z0 = ent_nnz_ptr[e], z1 = ent_nnz_ptr[e + 1];
-  const int64_t n64 = r1 - r0, nnz64 = z1 - z0;
-  if (n64 > 0x7ffffff0ll || nnz64 > 0x7ffffff0ll) {
-    if (lane == 0) { atomicExch(&stats->err, GDMIX_RE_ERANGE); d_cnt[e] = 0; }
-    return;
+  if (threadIdx.x < 3) blk_max[threadIdx.x] = 0;
+  __syncthreads();
+  int mx_p = 0, mx_n = 0, mx_z = 0;
+  // grid-stride over entities: per-entity same-address atomics would serialise in L2 (~10 ns each),
+  // so maxima are carried in registers and published once per workgroup.
+  for (int64_t e = (int64_t)blockIdx.x * PACK_WAVES + wv; e < E; e += (int64_t)gridDim.x * PACK_WAVES) {
+    const int64_t r0 = ent_row_ptr[e], r1 = ent_row_ptr[e + 1];
+    const int64_t z0 = ent_nnz_ptr[e], z1 = ent_nnz_ptr[e + 1];
+    const int64_t n64 = r1 - r0, nnz64 = z1 - z0;
+    if (n64 > 0x7ffffff0ll || nnz64 > 0x7ffffff0ll) {
+      if (lane == 0) { atomicExch(&stats->err, GDMIX_RE_ERANGE); d_cnt[e] = 0; }
+      continue;
+    }
+    const int n = (int)n64, nnz = (int)nnz64;
+    for (int i = lane; i <= n; i += WAVE) row_ptr[r0 + e + i] = (int32_t)(row_nnz_ptr[r0 + i] - z0);
+    // Two explicit instantiations so that each path keeps its address space (ds_* vs global_*): a
+    // generic pointer selecting between LDS and HBM compiles to flat_* accesses whose base+offset
+    // folding faults at the LDS aperture edge (keys[k-1] with k = 0).
+    int d;
+    bool bad;
+    if (nnz <= PACK_LDS_KEYS) d = sort_entity_keys(lds_keys[wv], col_global + z0, sort_key + z0, nnz, lane, true, bad);
+    else d = sort_entity_keys(sort_key + z0, col_global + z0, sort_key + z0, nnz, lane, false, bad);
+    if (bad && lane == 0) atomicExch(&stats->err, GDMIX_RE_ERANGE);
+    if (lane == 0) d_cnt[e] = d;
+    mx_p = max(mx_p, d + ic); mx_n = max(mx_n, n); mx_z = max(mx_z, nnz);
+    wave_mem_fence();   // the LDS staging buffer is reused by the next entity of this wave
   }
-  const int n = (int)n64, nnz = (int)nnz64;
-  for (int i = lane; i <= n; i += WAVE) row_ptr[r0 + e + i] = (int32_t)(row_nnz_ptr[r0 + i] - z0);
-  // Two explicit instantiations so that each path keeps its address space (ds_* vs global_*): a
-  // generic pointer selecting between LDS and HBM compiles to flat_* accesses whose base+offset
-  // folding faults at the LDS aperture edge (keys[k-1] with k = 0).
-  int d;
-  bool bad;
-  if (nnz <= PACK_LDS_KEYS) d = sort_entity_keys(lds_keys[wv], col_global + z0, sort_key + z0, nnz, lane, true, bad);
-  else d = sort_entity_keys(sort_key + z0, col_global + z0, sort_key + z0, nnz, lane, false, bad);
-  if (bad && lane == 0) atomicExch(&stats->err, GDMIX_RE_ERANGE);
   if (lane == 0) {
-    d_cnt[e] = d;
-    atomicMax(&stats->max_p, d + ic);
-    atomicMax(&stats->max_n, n);
-    atomicMax(&stats->max_nnz, nnz);
+    atomicMax(&blk_max[0], mx_p); atomicMax(&blk_max[1], mx_n); atomicMax(&blk_max[2], mx_z);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMax(&stats->max_p, blk_max[0]);
+    atomicMax(&stats->max_n, blk_max[1]);
+    atomicMax(&stats->max_nnz, blk_max[2]);
   }
 }
 
@@ -187,8 +199,7 @@ __global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_fill_kernel(
     int32_t* __restrict__ csr_col, int32_t* __restrict__ col_ptr, int32_t* __restrict__ csc_row,
     float* __restrict__ csc_val, int64_t* __restrict__ unique_global) {
   const int lane = threadIdx.x & (WAVE - 1);
-  const int64_t e = (int64_t)blockIdx.x * PACK_WAVES + (threadIdx.x >> 6);
-  if (e >= E) return;
+  for (int64_t e = (int64_t)blockIdx.x * PACK_WAVES + (threadIdx.x >> 6); e < E; e += (int64_t)gridDim.x * PACK_WAVES) {
   const int64_t r0 = ent_row_ptr[e], z0 = ent_nnz_ptr[e], f0 = ent_feat_ptr[e];
   const int n = (int)(ent_row_ptr[e + 1] - r0);
   const int nnz = (int)(ent_nnz_ptr[e + 1] - z0);
@@ -225,6 +236,7 @@ __global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_fill_kernel(
     carry += __popcll(mask);
   }
   if (lane == 0) col_ptr[f0 + e + d] = nnz;
+  }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------
@@ -328,7 +340,8 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
                        out->ent_nnz_ptr);
   }
   DBG_STAGE("pack_entnnz_kernel");
-  const int eblocks = (int)((E + PACK_WAVES - 1) / PACK_WAVES);
+  int eblocks = (int)((E + PACK_WAVES - 1) / PACK_WAVES);
+  if (eblocks > ctx->num_cus * 16) eblocks = ctx->num_cus * 16;
   hipLaunchKernelGGL(pack_sort_kernel, dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s, raw->ent_row_ptr,
                      raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, E, ic, out->row_ptr, sort_key, d_cnt, stats);
   DBG_STAGE("pack_sort_kernel");

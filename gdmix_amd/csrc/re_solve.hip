@@ -35,15 +35,35 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
   if (threadIdx.x < GDMIX_RE_NUM_CLASSES && local[threadIdx.x]) atomicAdd(&counts[threadIdx.x], local[threadIdx.x]);
 }
 
-// order[class_base[c] + k] = e. Position inside a class is by atomic ticket: the launch order inside a
-// class does not influence any entity's result (every entity is solved independently and
-// deterministically), only which workgroup picks it up.
-__global__ void re_order_kernel(const int32_t* __restrict__ cls, int64_t E, const int32_t* __restrict__ class_base,
-                                int32_t* __restrict__ cursor, int32_t* __restrict__ order) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
-    const int c = cls[e];
-    const int pos = atomicAdd(&cursor[c], 1);
-    order[class_base[c] + pos] = (int32_t)e;
+// order[class_base[c] + k] = e. Position inside a class is by ticket: the launch order inside a class
+// does not influence any entity's result (every entity is solved independently and deterministically),
+// only which workgroup picks it up. Tickets are taken per workgroup (LDS histogram, then one global
+// atomic per class per workgroup): per-entity global atomics on 8 addresses serialise in L2.
+__global__ __launch_bounds__(256) void re_order_kernel(const int32_t* __restrict__ cls, int64_t E,
+                                                       const int32_t* __restrict__ class_base,
+                                                       int32_t* __restrict__ cursor, int32_t* __restrict__ order) {
+  __shared__ int32_t cnt[GDMIX_RE_NUM_CLASSES], base[GDMIX_RE_NUM_CLASSES];
+  const int64_t chunk = (int64_t)blockDim.x * 8;
+  for (int64_t start = (int64_t)blockIdx.x * chunk; start < E; start += (int64_t)gridDim.x * chunk) {
+    if (threadIdx.x < GDMIX_RE_NUM_CLASSES) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int c[8], pos[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t e = start + (int64_t)k * blockDim.x + threadIdx.x;
+      c[k] = (e < E) ? cls[e] : -1;
+      pos[k] = (c[k] >= 0) ? atomicAdd(&cnt[c[k]], 1) : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < GDMIX_RE_NUM_CLASSES)
+      base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], cnt[threadIdx.x]) : 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t e = start + (int64_t)k * blockDim.x + threadIdx.x;
+      if (c[k] >= 0) order[class_base[c[k]] + base[c[k]] + pos[k]] = (int32_t)e;
+    }
+    __syncthreads();
   }
 }
 
@@ -60,7 +80,7 @@ hipError_t launch_classify(const gdmix_re_packed* b, int ic, int m, const ClassT
 hipError_t launch_order(const gdmix_re_packed* b, const int32_t* cls_tmp, const int32_t* class_base_dev,
                         int32_t* cursor_dev, hipStream_t s) {
   if (b->E == 0) return hipSuccess;
-  int grid = (int)((b->E + 255) / 256);
+  int grid = (int)((b->E + 2047) / 2048);
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(re_order_kernel, dim3(grid), dim3(256), 0, s, cls_tmp, b->E, class_base_dev, cursor_dev,
                      b->order);
