@@ -111,7 +111,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    kernel_ms = np.zeros(8)
+    kernel_ms = np.zeros(16)
     ev_pack = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     pack_ms = solve_ms = 0.0
     t0 = time.perf_counter()
@@ -187,7 +187,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "detail": {"pack_ms_per_step": pack_ms / a.steps, "solve_ms_per_step": solve_ms / a.steps,
                        "solve_kernel_ms_per_step": float(kernel_ms.sum()) / a.steps,
-                       "classes": classes, "mean_nit": nit, "mean_nfev": nfev,
+                       "classes": classes, "class_ms": [round(float(x) / a.steps, 3) for x in kernel_ms],
+                       "mean_nit": nit, "mean_nfev": nfev,
                        "converged_per_step": converged_all, "N": batch.N, "Z": batch.Z, "P": packed.P,
                        "host_generate_s": t_gen},
         }

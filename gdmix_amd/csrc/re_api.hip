@@ -27,19 +27,24 @@ void set_error(const char* fmt, ...) {
     }                                                                                        \
   } while (0)
 
-// LDS buckets of the wave-per-entity kernel. A 64-thread workgroup may use up to 64 KiB here: larger
-// blocks go to the workgroup-per-entity kernel.
-static const int kWaveBuckets[NUM_WAVE_CLASSES] = {4096, 8192, 12288, 16384, 24576, 32768, 65536};
-
-static const char* kClassNames[GDMIX_RE_NUM_CLASSES] = {
-    "re_solve_wave_kernel<=4K",  "re_solve_wave_kernel<=8K",  "re_solve_wave_kernel<=12K", "re_solve_wave_kernel<=16K",
-    "re_solve_wave_kernel<=24K", "re_solve_wave_kernel<=32K", "re_solve_wave_kernel<=64K", "re_solve_block_kernel"};
+// Size classes in routing order (see re_internal.hpp). A 64-thread workgroup may use up to 64 KiB of LDS
+// here; larger blocks go to the workgroup-per-entity kernel.
+struct ClassDesc { int kind; int lds; const char* name; };
+static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
+    {KIND_WREG1, 3072, "re_solve_wreg_kernel<1> lds<=3K"},   {KIND_WREG1, 6144, "re_solve_wreg_kernel<1> lds<=6K"},
+    {KIND_WREG1, 16384, "re_solve_wreg_kernel<1> lds<=16K"}, {KIND_WREG1, 65536, "re_solve_wreg_kernel<1> lds<=64K"},
+    {KIND_WREG2, 3072, "re_solve_wreg_kernel<2> lds<=3K"},   {KIND_WREG2, 6144, "re_solve_wreg_kernel<2> lds<=6K"},
+    {KIND_WREG2, 16384, "re_solve_wreg_kernel<2> lds<=16K"}, {KIND_WREG2, 65536, "re_solve_wreg_kernel<2> lds<=64K"},
+    {KIND_WREG4, 6144, "re_solve_wreg_kernel<4> lds<=6K"},   {KIND_WREG4, 12288, "re_solve_wreg_kernel<4> lds<=12K"},
+    {KIND_WREG4, 24576, "re_solve_wreg_kernel<4> lds<=24K"}, {KIND_WREG4, 65536, "re_solve_wreg_kernel<4> lds<=64K"},
+    {KIND_WLDS, 16384, "re_solve_wave_kernel lds<=16K"},     {KIND_WLDS, 32768, "re_solve_wave_kernel lds<=32K"},
+    {KIND_WLDS, 65536, "re_solve_wave_kernel lds<=64K"},     {KIND_BLOCK, 0, "re_solve_block_kernel"}};
 
 __global__ void class_base_kernel(int32_t* cc) {
-  // cc[0..7] counts -> cc[16..23] exclusive bases, cc[32..39] cursors = 0
+  // cc[0..NC) counts -> cc[NC..2NC) exclusive bases, cc[2NC..3NC) cursors = 0
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     int run = 0;
-    for (int c = 0; c < GDMIX_RE_NUM_CLASSES; ++c) { cc[16 + c] = run; run += cc[c]; cc[32 + c] = 0; }
+    for (int c = 0; c < GDMIX_RE_NUM_CLASSES; ++c) { cc[GDMIX_RE_NUM_CLASSES + c] = run; run += cc[c]; cc[2 * GDMIX_RE_NUM_CLASSES + c] = 0; }
   }
 }
 
@@ -97,6 +102,7 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   c->impl.scratch_bytes = 0;
   c->impl.host_pinned = nullptr;
   c->impl.wave_lds_limit = 65536;
+  c->impl.kernel_mask = 3;
   c->impl.timing = 0;
   for (int k = 0; k < GDMIX_RE_NUM_CLASSES; ++k) { c->impl.ev0[k] = nullptr; c->impl.ev1[k] = nullptr; c->impl.ev_used[k] = false; }
   hipError_t rc = hipHostMalloc(reinterpret_cast<void**>(&c->impl.host_pinned), 4096, hipHostMallocDefault);
@@ -161,6 +167,12 @@ GDMIX_API int gdmix_re_set_wave_lds_limit(gdmix_re_ctx* ctx, int bytes) {
   return GDMIX_RE_OK;
 }
 
+GDMIX_API int gdmix_re_set_kernel_mask(gdmix_re_ctx* ctx, int mask) {
+  if (!ctx) { set_error("ctx is NULL"); return GDMIX_RE_EINVAL; }
+  ctx->impl.kernel_mask = mask & 3;
+  return GDMIX_RE_OK;
+}
+
 GDMIX_API int gdmix_re_set_timing(gdmix_re_ctx* ctx, int enabled) {
   if (!ctx) { set_error("ctx is NULL"); return GDMIX_RE_EINVAL; }
   if (enabled && !ctx->impl.ev0[0]) {
@@ -210,15 +222,20 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   const int ic = opts->has_intercept ? 1 : 0;
 
   ClassTable tab;
-  for (int c = 0; c < NUM_WAVE_CLASSES; ++c) tab.lds_bytes[c] = kWaveBuckets[c] <= ctx->impl.wave_lds_limit ? kWaveBuckets[c] : 0;
-  tab.lds_bytes[BLOCK_CLASS] = 0;
+  for (int c = 0; c < GDMIX_RE_NUM_CLASSES; ++c) {
+    tab.kind[c] = kClasses[c].kind;
+    bool on = kClasses[c].lds > 0 && kClasses[c].lds <= ctx->impl.wave_lds_limit;
+    if (kClasses[c].kind <= KIND_WREG4 && !(ctx->impl.kernel_mask & 1)) on = false;
+    if (kClasses[c].kind == KIND_WLDS && !(ctx->impl.kernel_mask & 2)) on = false;
+    tab.lds_bytes[c] = on ? kClasses[c].lds : 0;
+  }
 
   int32_t* cc = b->class_count;
   HIP_TRY(hipMemsetAsync(cc, 0, 64 * sizeof(int32_t), s));
   HIP_TRY(launch_classify(b, ic, opts->m, tab, b->cls_tmp, cc, s));
   hipLaunchKernelGGL(class_base_kernel, dim3(1), dim3(1), 0, s, cc);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(launch_order(b, b->cls_tmp, cc + 16, cc + 32, s));
+  HIP_TRY(launch_order(b, b->cls_tmp, cc + GDMIX_RE_NUM_CLASSES, cc + 2 * GDMIX_RE_NUM_CLASSES, s));
   int32_t* hc = ctx->impl.host_pinned + 256;
   HIP_TRY(hipMemcpyAsync(hc, cc, GDMIX_RE_NUM_CLASSES * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -233,10 +250,16 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   const bool timing = ctx->impl.timing != 0;
   for (int c = 0; c < GDMIX_RE_NUM_CLASSES; ++c) ctx->impl.ev_used[c] = false;
   int begin = 0;
-  for (int c = 0; c < NUM_WAVE_CLASSES; ++c) {
-    if (timing && hc[c] > 0) { HIP_TRY(hipEventRecord(ctx->impl.ev0[c], s)); }
-    HIP_TRY(launch_solve_wave(B, O, P, theta0, begin, hc[c], tab.lds_bytes[c], s));
-    if (timing && hc[c] > 0) { HIP_TRY(hipEventRecord(ctx->impl.ev1[c], s)); ctx->impl.ev_used[c] = true; }
+  for (int c = 0; c < GDMIX_RE_NUM_CLASSES - 1; ++c) {
+    if (hc[c] <= 0) continue;
+    if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[c], s)); }
+    switch (kClasses[c].kind) {
+      case KIND_WREG1: HIP_TRY(launch_solve_wreg(1, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
+      case KIND_WREG2: HIP_TRY(launch_solve_wreg(2, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
+      case KIND_WREG4: HIP_TRY(launch_solve_wreg(4, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
+      default: HIP_TRY(launch_solve_wave(B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
+    }
+    if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[c], s)); ctx->impl.ev_used[c] = true; }
     begin += hc[c];
   }
   if (hc[BLOCK_CLASS] > 0) {
@@ -279,7 +302,7 @@ GDMIX_API int gdmix_re_score(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int ha
 
 GDMIX_API const char* gdmix_re_class_kernel_name(int c) {
   if (c < 0 || c >= GDMIX_RE_NUM_CLASSES) return nullptr;
-  return kClassNames[c];
+  return kClasses[c].name;
 }
 
 GDMIX_API int32_t gdmix_java_string_hash(const uint16_t* utf16, int64_t len) {

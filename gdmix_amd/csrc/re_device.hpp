@@ -13,12 +13,15 @@ constexpr int WAVE = 64;
 
 // ---- DPP helpers -------------------------------------------------------------------------------
 // dpp_ctrl encodings (GFX9): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+// Value of the DPP source lane, 0.0 where the source lane does not exist (bound_ctrl). All rows are
+// enabled: the reductions below only guarantee their result in lane 63 (what readlane63 reads), so the
+// row broadcasts need no row mask and the destination needs no zero pre-load (ROW_MASK is kept as
+// documentation of which rows matter).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_get0(double v) {
-  // value of the DPP source lane, or 0.0 where the source lane is invalid / the row is masked off
   int lo = __double2loint(v), hi = __double2hiint(v);
-  int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-  int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  int lo2 = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+  int hi2 = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi2, lo2);
 }
 
@@ -124,11 +127,19 @@ __device__ __forceinline__ void dcsrch_start(LineSearch& S, double f, double g, 
   S.stmin = 0.0; S.stmax = stp + 4.0 * stp;
 }
 
-__device__ __forceinline__ void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy,
-                                    double& dy, double& stp, double fp, double dp, int& brackt,
-                                    double stpmin, double stpmax) {
-  double gamma, p, q, r, s, sgnd, stpc, stpf, stpq, theta;
-  sgnd = dp * (dx / fabs(dx));
+// One dcstep: safeguarded cubic/quadratic step and interval update. Everything is passed and returned by
+// value (no references, no conditional stores through pointers: those made the compiler materialise the
+// interval in scratch memory).
+struct StepIO {
+  double stx, fx, dx, sty, fy, dy, stp;
+  int brackt;
+};
+
+__device__ __forceinline__ StepIO dcstep(StepIO v, double fp, double dp, double stpmin, double stpmax) {
+  const double stx = v.stx, fx = v.fx, dx = v.dx, sty = v.sty, fy = v.fy, dy = v.dy, stp = v.stp;
+  int brackt = v.brackt;
+  double gamma, p, q, r, s, stpc, stpf, stpq, theta;
+  const double sgnd = dp * (dx / fabs(dx));
   if (fp > fx) {
     theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
     s = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
@@ -192,13 +203,19 @@ __device__ __forceinline__ void dcstep(double& stx, double& fx, double& dx, doub
     } else if (stp > stx) stpf = stpmax;
     else stpf = stpmin;
   }
-  if (fp > fx) {
-    sty = stp; fy = fp; dy = dp;
-  } else {
-    if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
-    stx = stp; fx = fp; dx = dp;
-  }
-  stp = stpf;
+  // interval update, written as selects
+  const bool worse = fp > fx;
+  const bool flip = !worse && (sgnd < 0.0);
+  StepIO o;
+  o.sty = worse ? stp : (flip ? stx : sty);
+  o.fy = worse ? fp : (flip ? fx : fy);
+  o.dy = worse ? dp : (flip ? dx : dy);
+  o.stx = worse ? stx : stp;
+  o.fx = worse ? fx : fp;
+  o.dx = worse ? dx : dp;
+  o.stp = stpf;
+  o.brackt = brackt;
+  return o;
 }
 
 __device__ __forceinline__ int dcsrch_step(LineSearch& S, double f, double g, double& stp_io) {
@@ -212,16 +229,21 @@ __device__ __forceinline__ int dcsrch_step(LineSearch& S, double f, double g, do
   if (stp == LS_STPMIN && (f > ftest || g >= S.gtest)) task = LS_WARN;
   if (f <= ftest && fabs(g) <= LS_GTOL * (-S.ginit)) task = LS_CONV;
   if (task != LS_FG) return task;
-  if (S.stage == 1 && f <= S.fx && f > ftest) {
-    double fm = f - stp * S.gtest, fxm = S.fx - S.stx * S.gtest, fym = S.fy - S.sty * S.gtest;
-    double gm = g - S.gtest, gxm = S.gx - S.gtest, gym = S.gy - S.gtest;
-    dcstep(S.stx, fxm, gxm, S.sty, fym, gym, stp, fm, gm, S.brackt, S.stmin, S.stmax);
-    S.fx = fxm + S.stx * S.gtest;
-    S.fy = fym + S.sty * S.gtest;
-    S.gx = gxm + S.gtest;
-    S.gy = gym + S.gtest;
-  } else {
-    dcstep(S.stx, S.fx, S.gx, S.sty, S.fy, S.gy, stp, f, g, S.brackt, S.stmin, S.stmax);
+  // dcsrch calls dcstep either on the function values or, in stage 1 while f > ftest, on the modified
+  // function psi(a) = phi(a) - a*gtest. Both forms are one call here: with gt = 0 the subtractions and
+  // the add-backs below are exact identities, so the unmodified branch is reproduced bit for bit.
+  const double gt = (S.stage == 1 && f <= S.fx && f > ftest) ? S.gtest : 0.0;
+  {
+    StepIO v;
+    v.stx = S.stx; v.sty = S.sty; v.stp = stp; v.brackt = S.brackt;
+    v.fx = S.fx - S.stx * gt; v.fy = S.fy - S.sty * gt;
+    v.dx = S.gx - gt; v.dy = S.gy - gt;
+    const StepIO w = dcstep(v, f - stp * gt, g - gt, S.stmin, S.stmax);
+    S.stx = w.stx; S.sty = w.sty; S.brackt = w.brackt; stp = w.stp;
+    S.fx = w.fx + w.stx * gt;
+    S.fy = w.fy + w.sty * gt;
+    S.gx = w.dx + gt;
+    S.gy = w.dy + gt;
   }
   if (S.brackt) {
     if (fabs(S.sty - S.stx) >= 0.66 * S.width1) stp = S.stx + 0.5 * (S.sty - S.stx);

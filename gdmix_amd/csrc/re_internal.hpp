@@ -6,17 +6,22 @@
 
 #include "../../include/gdmix_re.h"
 #include "re_solve_core.hpp"
+#include "re_solve_wreg.hpp"
 
 namespace gdmix {
 
-// number of LDS-size buckets solved by the wave-per-entity kernel; the last class is the
-// workgroup-per-entity kernel working out of a global scratch slot.
-constexpr int NUM_WAVE_CLASSES = GDMIX_RE_NUM_CLASSES - 1;
+// Size classes: every entity is routed to the cheapest kernel variant that can hold it.
+//   KIND_WREG1/2/4  register-resident wavefront kernel with 1/2/4 coefficients per lane (p <= 64/128/256)
+//   KIND_WLDS       LDS-resident wavefront kernel (any p whose state fits 64 KiB of LDS, any m)
+//   KIND_BLOCK      workgroup-per-entity kernel working out of a global scratch slot (anything)
+// Each wavefront kind is split into LDS-footprint buckets so that small entities keep high occupancy.
+enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4 };
 constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 1;
 constexpr int BLOCK_NW = 4;   // wavefronts per workgroup of the block kernel
 
 struct ClassTable {
-  int lds_bytes[GDMIX_RE_NUM_CLASSES];   // upper LDS size of each wave class; 0 for the block class
+  int kind[GDMIX_RE_NUM_CLASSES];
+  int lds_bytes[GDMIX_RE_NUM_CLASSES];   // LDS bucket of the class; 0 = class disabled (or block class)
 };
 
 // Device pointers of a packed batch, passed by value to kernels.
@@ -54,6 +59,7 @@ struct gdmix_ctx_impl {
   size_t scratch_bytes;
   int32_t* host_pinned;   // small pinned buffer for count read-backs
   int wave_lds_limit;     // entities above this LDS footprint use the block kernel
+  int kernel_mask;        // bit0 register wave kernel, bit1 LDS wave kernel
   int timing;             // bracket class launches with events
   hipEvent_t ev0[GDMIX_RE_NUM_CLASSES], ev1[GDMIX_RE_NUM_CLASSES];
   bool ev_used[GDMIX_RE_NUM_CLASSES];
@@ -75,6 +81,8 @@ hipError_t launch_classify(const gdmix_re_packed* b, int ic, int m, const ClassT
                            int32_t* counts_dev, hipStream_t s);
 hipError_t launch_order(const gdmix_re_packed* b, const int32_t* cls_tmp, const int32_t* class_base_dev,
                         int32_t* cursor_dev, hipStream_t s);
+hipError_t launch_solve_wreg(int epl, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
+                             int begin, int count, int lds_bytes, hipStream_t s);
 hipError_t launch_solve_wave(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
                              int begin, int count, int lds_bytes, hipStream_t s);
 hipError_t launch_solve_block(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,

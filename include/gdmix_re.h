@@ -119,7 +119,7 @@ typedef struct {
   int32_t        max_p, max_n, max_nnz;  /* per-entity maxima over the batch (host, after pack)     */
 } gdmix_re_packed;
 
-#define GDMIX_RE_NUM_CLASSES 8
+#define GDMIX_RE_NUM_CLASSES 16
 
 /* ---- solver options (defaults = REParams/LRParams defaults + scipy defaults) ----------------------
  * base_lr_params.py:22-27, binary_logistic_regression.py:223-231 (pgtol/maxfun/maxls are scipy's). */
@@ -190,6 +190,10 @@ GDMIX_API int gdmix_re_score(gdmix_re_ctx* ctx, const gdmix_re_packed* batch, in
 /* Tuning/testing knob: entities whose LDS footprint exceeds `bytes` are solved by the
  * workgroup-per-entity kernel (0 => every entity). Default and maximum 65536. */
 GDMIX_API int gdmix_re_set_wave_lds_limit(gdmix_re_ctx* ctx, int bytes);
+
+/* Tuning/testing knob: which per-entity kernels the solver may use. bit 0 = register-resident wavefront
+ * kernel, bit 1 = LDS-resident wavefront kernel; the workgroup kernel is always available. Default 3. */
+GDMIX_API int gdmix_re_set_kernel_mask(gdmix_re_ctx* ctx, int mask);
 
 /* Optional kernel timing: when enabled, gdmix_re_solve brackets each size class's kernel launch with
  * HIP events on the caller's stream; gdmix_re_last_solve_ms waits for them and returns the elapsed
