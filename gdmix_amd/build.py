@@ -27,7 +27,8 @@ def needs_build():
 def build_library(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+    extra = os.environ.get("GDMIX_EXTRA_FLAGS", "").split()   # tuning experiments only
+    cmd = [HIPCC] + FLAGS + extra + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

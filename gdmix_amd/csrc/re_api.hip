@@ -31,6 +31,10 @@ void set_error(const char* fmt, ...) {
 // here; larger blocks go to the workgroup-per-entity kernel.
 struct ClassDesc { int kind; int lds; const char* name; };
 static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
+    {KIND_QUAD2, 2560, "re_solve_quad_kernel<2> row lds<=2.5K"}, {KIND_QUAD2, 4096, "re_solve_quad_kernel<2> row lds<=4K"},
+    {KIND_QUAD2, 8192, "re_solve_quad_kernel<2> row lds<=8K"},   {KIND_QUAD2, 16384, "re_solve_quad_kernel<2> row lds<=16K"},
+    {KIND_QUAD4, 2560, "re_solve_quad_kernel<4> row lds<=2.5K"}, {KIND_QUAD4, 4096, "re_solve_quad_kernel<4> row lds<=4K"},
+    {KIND_QUAD4, 8192, "re_solve_quad_kernel<4> row lds<=8K"},   {KIND_QUAD4, 16384, "re_solve_quad_kernel<4> row lds<=16K"},
     {KIND_WREG1, 3072, "re_solve_wreg_kernel<1> lds<=3K"},   {KIND_WREG1, 6144, "re_solve_wreg_kernel<1> lds<=6K"},
     {KIND_WREG1, 16384, "re_solve_wreg_kernel<1> lds<=16K"}, {KIND_WREG1, 65536, "re_solve_wreg_kernel<1> lds<=64K"},
     {KIND_WREG2, 3072, "re_solve_wreg_kernel<2> lds<=3K"},   {KIND_WREG2, 6144, "re_solve_wreg_kernel<2> lds<=6K"},
@@ -102,7 +106,7 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   c->impl.scratch_bytes = 0;
   c->impl.host_pinned = nullptr;
   c->impl.wave_lds_limit = 65536;
-  c->impl.kernel_mask = 3;
+  c->impl.kernel_mask = 7;
   c->impl.timing = 0;
   for (int k = 0; k < GDMIX_RE_NUM_CLASSES; ++k) { c->impl.ev0[k] = nullptr; c->impl.ev1[k] = nullptr; c->impl.ev_used[k] = false; }
   hipError_t rc = hipHostMalloc(reinterpret_cast<void**>(&c->impl.host_pinned), 4096, hipHostMallocDefault);
@@ -169,7 +173,7 @@ GDMIX_API int gdmix_re_set_wave_lds_limit(gdmix_re_ctx* ctx, int bytes) {
 
 GDMIX_API int gdmix_re_set_kernel_mask(gdmix_re_ctx* ctx, int mask) {
   if (!ctx) { set_error("ctx is NULL"); return GDMIX_RE_EINVAL; }
-  ctx->impl.kernel_mask = mask & 3;
+  ctx->impl.kernel_mask = mask & 7;
   return GDMIX_RE_OK;
 }
 
@@ -226,12 +230,13 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     tab.kind[c] = kClasses[c].kind;
     bool on = kClasses[c].lds > 0 && kClasses[c].lds <= ctx->impl.wave_lds_limit;
     if (kClasses[c].kind <= KIND_WREG4 && !(ctx->impl.kernel_mask & 1)) on = false;
+    if ((kClasses[c].kind == KIND_QUAD2 || kClasses[c].kind == KIND_QUAD4) && !(ctx->impl.kernel_mask & 4)) on = false;
     if (kClasses[c].kind == KIND_WLDS && !(ctx->impl.kernel_mask & 2)) on = false;
     tab.lds_bytes[c] = on ? kClasses[c].lds : 0;
   }
 
   int32_t* cc = b->class_count;
-  HIP_TRY(hipMemsetAsync(cc, 0, 64 * sizeof(int32_t), s));
+  HIP_TRY(hipMemsetAsync(cc, 0, 3 * GDMIX_RE_NUM_CLASSES * sizeof(int32_t), s));
   HIP_TRY(launch_classify(b, ic, opts->m, tab, b->cls_tmp, cc, s));
   hipLaunchKernelGGL(class_base_kernel, dim3(1), dim3(1), 0, s, cc);
   HIP_TRY(hipGetLastError());
@@ -254,6 +259,8 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     if (hc[c] <= 0) continue;
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[c], s)); }
     switch (kClasses[c].kind) {
+      case KIND_QUAD2: HIP_TRY(launch_solve_quad(2, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
+      case KIND_QUAD4: HIP_TRY(launch_solve_quad(4, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
       case KIND_WREG1: HIP_TRY(launch_solve_wreg(1, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
       case KIND_WREG2: HIP_TRY(launch_solve_wreg(2, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
       case KIND_WREG4: HIP_TRY(launch_solve_wreg(4, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;

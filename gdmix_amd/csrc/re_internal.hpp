@@ -7,15 +7,17 @@
 #include "../../include/gdmix_re.h"
 #include "re_solve_core.hpp"
 #include "re_solve_wreg.hpp"
+#include "re_solve_quad.hpp"
 
 namespace gdmix {
 
 // Size classes: every entity is routed to the cheapest kernel variant that can hold it.
+//   KIND_QUAD2/4    four entities per wavefront (one per 16-lane DPP row), p <= 32/64, state in registers
 //   KIND_WREG1/2/4  register-resident wavefront kernel with 1/2/4 coefficients per lane (p <= 64/128/256)
 //   KIND_WLDS       LDS-resident wavefront kernel (any p whose state fits 64 KiB of LDS, any m)
 //   KIND_BLOCK      workgroup-per-entity kernel working out of a global scratch slot (anything)
 // Each wavefront kind is split into LDS-footprint buckets so that small entities keep high occupancy.
-enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4 };
+enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4, KIND_QUAD2 = 5, KIND_QUAD4 = 6 };
 constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 1;
 constexpr int BLOCK_NW = 4;   // wavefronts per workgroup of the block kernel
 
@@ -59,7 +61,7 @@ struct gdmix_ctx_impl {
   size_t scratch_bytes;
   int32_t* host_pinned;   // small pinned buffer for count read-backs
   int wave_lds_limit;     // entities above this LDS footprint use the block kernel
-  int kernel_mask;        // bit0 register wave kernel, bit1 LDS wave kernel
+  int kernel_mask;        // bit0 register wave kernel, bit1 LDS wave kernel, bit2 quad kernel
   int timing;             // bracket class launches with events
   hipEvent_t ev0[GDMIX_RE_NUM_CLASSES], ev1[GDMIX_RE_NUM_CLASSES];
   bool ev_used[GDMIX_RE_NUM_CLASSES];
@@ -83,6 +85,8 @@ hipError_t launch_order(const gdmix_re_packed* b, const int32_t* cls_tmp, const 
                         int32_t* cursor_dev, hipStream_t s);
 hipError_t launch_solve_wreg(int epl, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
                              int begin, int count, int lds_bytes, hipStream_t s);
+hipError_t launch_solve_quad(int epl, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
+                             int begin, int count, int row_lds_bytes, hipStream_t s);
 hipError_t launch_solve_wave(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
                              int begin, int count, int lds_bytes, hipStream_t s);
 hipError_t launch_solve_block(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,

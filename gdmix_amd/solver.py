@@ -18,7 +18,7 @@ from .batch import RawBatch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgdmix_re.so")
 
-NUM_CLASSES = 16
+NUM_CLASSES = 24
 STATUS_NAMES = ("PGTOL", "FACTR", "MAXITER", "MAXFUN", "ABNORMAL")
 VAR_NONE, VAR_SIMPLE, VAR_FULL = 0, 1, 2
 VARIANCE_MODES = {None: VAR_NONE, "simple": VAR_SIMPLE, "SIMPLE": VAR_SIMPLE, "full": VAR_FULL, "FULL": VAR_FULL,
@@ -346,7 +346,7 @@ class REDeviceSolver:
     def class_counts(self, packed: PackedBatch):
         """Entities per size class of the last solve on this batch (host list) + kernel names."""
         t = self.torch
-        cc = packed._view(packed.c.class_count, 64, t.int32).cpu().numpy()
+        cc = packed._view(packed.c.class_count, NUM_CLASSES, t.int32).cpu().numpy()
         names = [self.lib.gdmix_re_class_kernel_name(c).decode() for c in range(NUM_CLASSES)]
         return list(zip(names, cc[:NUM_CLASSES].tolist()))
 

@@ -113,13 +113,13 @@ typedef struct {
   /* solver-owned scratch inside the workspace (written by gdmix_re_solve) */
   int32_t*       order;         /* [E]   entity ids grouped by size class (solver launch order)     */
   int32_t*       cls_tmp;       /* [E]   size class of each entity                                  */
-  int32_t*       class_count;   /* [64]  per-class counts / bases / cursors (device)                */
+  int32_t*       class_count;   /* [3*NUM_CLASSES] per-class counts / bases / cursors (device)     */
   void*          scratch;       /* pack-time sort scratch, free for reuse once pack has returned    */
   size_t         scratch_bytes;
   int32_t        max_p, max_n, max_nnz;  /* per-entity maxima over the batch (host, after pack)     */
 } gdmix_re_packed;
 
-#define GDMIX_RE_NUM_CLASSES 16
+#define GDMIX_RE_NUM_CLASSES 24
 
 /* ---- solver options (defaults = REParams/LRParams defaults + scipy defaults) ----------------------
  * base_lr_params.py:22-27, binary_logistic_regression.py:223-231 (pgtol/maxfun/maxls are scipy's). */
@@ -192,7 +192,8 @@ GDMIX_API int gdmix_re_score(gdmix_re_ctx* ctx, const gdmix_re_packed* batch, in
 GDMIX_API int gdmix_re_set_wave_lds_limit(gdmix_re_ctx* ctx, int bytes);
 
 /* Tuning/testing knob: which per-entity kernels the solver may use. bit 0 = register-resident wavefront
- * kernel, bit 1 = LDS-resident wavefront kernel; the workgroup kernel is always available. Default 3. */
+ * kernel, bit 1 = LDS-resident wavefront kernel, bit 2 = four-entities-per-wavefront kernel; the workgroup
+ * kernel is always available. Default 7. */
 GDMIX_API int gdmix_re_set_kernel_mask(gdmix_re_ctx* ctx, int mask);
 
 /* Optional kernel timing: when enabled, gdmix_re_solve brackets each size class's kernel launch with

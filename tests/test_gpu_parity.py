@@ -51,7 +51,7 @@ def _check_pack(packed, pk, val):
     assert np.array_equal(packed.csc_val().cpu().numpy(), csc_val)
 
 
-def _solve_and_compare(device_solver, name, lds_limit=65536):
+def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7):
     b, opts, exp, _ = load_fixture(name)
     kw = opts_kwargs(opts)
     if kw["variance_mode"] == 2:
@@ -61,10 +61,12 @@ def _solve_and_compare(device_solver, name, lds_limit=65536):
     _check_pack(packed, pk, b.val)
     th0 = exp["theta0"] if np.any(exp["theta0"]) else None
     device_solver.set_wave_lds_limit(lds_limit)
+    device_solver.set_kernel_mask(kernel_mask)
     try:
         res = device_solver.solve(packed, SolverOptions(**kw), theta0=th0).to_host()
     finally:
         device_solver.set_wave_lds_limit(65536)
+        device_solver.set_kernel_mask(7)
     ref = oracle.solve(pk, b.val, b.y, b.offset, b.weight, oracle.make_opts(**kw), theta0=th0)
     coef_ptr = packed.coef_ptr_host()
     wp = well_posed_mask(b, opts)
@@ -95,8 +97,30 @@ def _solve_and_compare(device_solver, name, lds_limit=65536):
 
 
 @pytest.mark.parametrize("name", fixture_names())
-def test_wave_kernel_matches_reference_fixture(device_solver, name):
+def test_default_routing_matches_reference_fixture(device_solver, name):
+    """Default routing: quad kernel (4 entities / wavefront) for p <= 64, register wave kernel above."""
     _solve_and_compare(device_solver, name)
+
+
+VARIANT_FIXTURES = ["ref_fixture_l2_0.1", "ref_dataset1", "ref_dataset2", "c2_shipped_cfg", "c2_defaults", "c2_l2_1e-3",
+                    "c2_large_offsets", "c2_weights", "c2_no_intercept", "c2_maxiter1", "c2_maxiter3_m2", "c2_m3",
+                    "ragged", "ragged_variance_simple", "ml_per_user", "ml_per_movie", "c5_mean_shape", "zipf_tail",
+                    "tiny_entities_regbias", "tiny_entities_shipped_cfg", "warm_stage2"]
+
+
+@pytest.mark.parametrize("name", VARIANT_FIXTURES)
+def test_register_wave_kernel_matches_reference_fixture(device_solver, name):
+    _solve_and_compare(device_solver, name, kernel_mask=1)
+
+
+@pytest.mark.parametrize("name", VARIANT_FIXTURES)
+def test_lds_wave_kernel_matches_reference_fixture(device_solver, name):
+    _solve_and_compare(device_solver, name, kernel_mask=2)
+
+
+@pytest.mark.parametrize("name", VARIANT_FIXTURES)
+def test_quad_kernel_matches_reference_fixture(device_solver, name):
+    _solve_and_compare(device_solver, name, kernel_mask=4)
 
 
 @pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "c2_shipped_cfg", "c2_l2_1e-3", "ragged", "ml_per_user",
