@@ -13,8 +13,10 @@ LIB = os.path.join(HERE, "libgdmix_re.so")
 SOURCES = ["re_api.hip", "re_solve.hip", "re_pack.hip"]
 HEADERS = ["re_device.hpp", "re_solve_core.hpp", "re_internal.hpp", os.path.join("..", "..", "include", "gdmix_re.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -disable-machine-licm: MachineLICM hoists the ~35 fp64 polynomial constants of exp/log out of the solver's
+# main loop, where they stay live in VGPRs across the whole solve and cost a wave of occupancy.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-mllvm", "-disable-machine-licm"]
 
 
 def needs_build():

@@ -29,19 +29,20 @@ void set_error(const char* fmt, ...) {
 
 // Size classes in routing order (see re_internal.hpp). A 64-thread workgroup may use up to 64 KiB of LDS
 // here; larger blocks go to the workgroup-per-entity kernel.
-struct ClassDesc { int kind; int lds; const char* name; };
+struct ClassDesc { int kind; int lds; const char* name; int ncap, zcap; };   // quad: lds = LDS of a whole wave (4 rows)
 static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
-    {KIND_QUAD2, 2560, "re_solve_quad_kernel<2> row lds<=2.5K"}, {KIND_QUAD2, 4096, "re_solve_quad_kernel<2> row lds<=4K"},
-    {KIND_QUAD2, 8192, "re_solve_quad_kernel<2> row lds<=8K"},   {KIND_QUAD2, 16384, "re_solve_quad_kernel<2> row lds<=16K"},
-    {KIND_QUAD4, 2560, "re_solve_quad_kernel<4> row lds<=2.5K"}, {KIND_QUAD4, 4096, "re_solve_quad_kernel<4> row lds<=4K"},
-    {KIND_QUAD4, 8192, "re_solve_quad_kernel<4> row lds<=8K"},   {KIND_QUAD4, 16384, "re_solve_quad_kernel<4> row lds<=16K"},
-    {KIND_WREG1, 3072, "re_solve_wreg_kernel<1> lds<=3K"},   {KIND_WREG1, 6144, "re_solve_wreg_kernel<1> lds<=6K"},
-    {KIND_WREG1, 16384, "re_solve_wreg_kernel<1> lds<=16K"}, {KIND_WREG1, 65536, "re_solve_wreg_kernel<1> lds<=64K"},
+    {KIND_QUAD2, 1, "re_solve_grp_kernel<16,2> n<=16 nnz<=64", 16, 64},     {KIND_QUAD2, 1, "re_solve_grp_kernel<16,2> n<=32 nnz<=128", 32, 128},
+    {KIND_QUAD2, 1, "re_solve_grp_kernel<16,2> n<=128 nnz<=512", 128, 512}, {KIND_QUAD2, 1, "re_solve_grp_kernel<16,2> n<=512 nnz<=1536", 512, 1536},
+    {KIND_QUAD4, 1, "re_solve_grp_kernel<16,4> n<=16 nnz<=64", 16, 64},     {KIND_QUAD4, 1, "re_solve_grp_kernel<16,4> n<=32 nnz<=128", 32, 128},
+    {KIND_QUAD4, 1, "re_solve_grp_kernel<16,4> n<=128 nnz<=512", 128, 512}, {KIND_QUAD4, 1, "re_solve_grp_kernel<16,4> n<=512 nnz<=1536", 512, 1536},
+    {KIND_PAIR4, 1, "re_solve_grp_kernel<32,4> n<=32 nnz<=128", 32, 128},  {KIND_PAIR4, 1, "re_solve_grp_kernel<32,4> n<=64 nnz<=256", 64, 256},
+    {KIND_PAIR4, 1, "re_solve_grp_kernel<32,4> n<=256 nnz<=1024", 256, 1024},
+    {KIND_WREG1, 3072, "re_solve_wreg_kernel<1> lds<=3K"},   {KIND_WREG1, 65536, "re_solve_wreg_kernel<1> lds<=64K"},
     {KIND_WREG2, 3072, "re_solve_wreg_kernel<2> lds<=3K"},   {KIND_WREG2, 6144, "re_solve_wreg_kernel<2> lds<=6K"},
     {KIND_WREG2, 16384, "re_solve_wreg_kernel<2> lds<=16K"}, {KIND_WREG2, 65536, "re_solve_wreg_kernel<2> lds<=64K"},
     {KIND_WREG4, 6144, "re_solve_wreg_kernel<4> lds<=6K"},   {KIND_WREG4, 12288, "re_solve_wreg_kernel<4> lds<=12K"},
     {KIND_WREG4, 24576, "re_solve_wreg_kernel<4> lds<=24K"}, {KIND_WREG4, 65536, "re_solve_wreg_kernel<4> lds<=64K"},
-    {KIND_WLDS, 16384, "re_solve_wave_kernel lds<=16K"},     {KIND_WLDS, 32768, "re_solve_wave_kernel lds<=32K"},
+    {KIND_WLDS, 24576, "re_solve_wave_kernel lds<=24K"},
     {KIND_WLDS, 65536, "re_solve_wave_kernel lds<=64K"},     {KIND_BLOCK, 0, "re_solve_block_kernel"}};
 
 __global__ void class_base_kernel(int32_t* cc) {
@@ -228,11 +229,17 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   ClassTable tab;
   for (int c = 0; c < GDMIX_RE_NUM_CLASSES; ++c) {
     tab.kind[c] = kClasses[c].kind;
-    bool on = kClasses[c].lds > 0 && kClasses[c].lds <= ctx->impl.wave_lds_limit;
+    tab.ncap[c] = kClasses[c].ncap;
+    tab.zcap[c] = kClasses[c].zcap;
+    int lds = kClasses[c].lds;
+    if (kClasses[c].kind == KIND_QUAD2) lds = 4 * quad_layout(2 * ROW, kClasses[c].ncap, kClasses[c].zcap).bytes;
+    if (kClasses[c].kind == KIND_QUAD4) lds = 4 * quad_layout(4 * ROW, kClasses[c].ncap, kClasses[c].zcap).bytes;
+    if (kClasses[c].kind == KIND_PAIR4) lds = 2 * quad_layout(128, kClasses[c].ncap, kClasses[c].zcap).bytes;
+    bool on = lds > 0 && lds <= ctx->impl.wave_lds_limit;
     if (kClasses[c].kind <= KIND_WREG4 && !(ctx->impl.kernel_mask & 1)) on = false;
-    if ((kClasses[c].kind == KIND_QUAD2 || kClasses[c].kind == KIND_QUAD4) && !(ctx->impl.kernel_mask & 4)) on = false;
+    if ((kClasses[c].kind == KIND_QUAD2 || kClasses[c].kind == KIND_QUAD4 || kClasses[c].kind == KIND_PAIR4) && !(ctx->impl.kernel_mask & 4)) on = false;
     if (kClasses[c].kind == KIND_WLDS && !(ctx->impl.kernel_mask & 2)) on = false;
-    tab.lds_bytes[c] = on ? kClasses[c].lds : 0;
+    tab.lds_bytes[c] = on ? lds : 0;
   }
 
   int32_t* cc = b->class_count;
@@ -259,8 +266,9 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     if (hc[c] <= 0) continue;
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[c], s)); }
     switch (kClasses[c].kind) {
-      case KIND_QUAD2: HIP_TRY(launch_solve_quad(2, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
-      case KIND_QUAD4: HIP_TRY(launch_solve_quad(4, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
+      case KIND_PAIR4: HIP_TRY(launch_solve_quad(32, 4, B, O, P, theta0, begin, hc[c], kClasses[c].ncap, kClasses[c].zcap, s)); break;
+      case KIND_QUAD2: HIP_TRY(launch_solve_quad(16, 2, B, O, P, theta0, begin, hc[c], kClasses[c].ncap, kClasses[c].zcap, s)); break;
+      case KIND_QUAD4: HIP_TRY(launch_solve_quad(16, 4, B, O, P, theta0, begin, hc[c], kClasses[c].ncap, kClasses[c].zcap, s)); break;
       case KIND_WREG1: HIP_TRY(launch_solve_wreg(1, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
       case KIND_WREG2: HIP_TRY(launch_solve_wreg(2, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
       case KIND_WREG4: HIP_TRY(launch_solve_wreg(4, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;

@@ -13,17 +13,20 @@ namespace gdmix {
 
 // Size classes: every entity is routed to the cheapest kernel variant that can hold it.
 //   KIND_QUAD2/4    four entities per wavefront (one per 16-lane DPP row), p <= 32/64, state in registers
+//   KIND_PAIR4      two entities per wavefront (one per pair of DPP rows), p <= 128
 //   KIND_WREG1/2/4  register-resident wavefront kernel with 1/2/4 coefficients per lane (p <= 64/128/256)
 //   KIND_WLDS       LDS-resident wavefront kernel (any p whose state fits 64 KiB of LDS, any m)
 //   KIND_BLOCK      workgroup-per-entity kernel working out of a global scratch slot (anything)
 // Each wavefront kind is split into LDS-footprint buckets so that small entities keep high occupancy.
-enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4, KIND_QUAD2 = 5, KIND_QUAD4 = 6 };
+enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4, KIND_QUAD2 = 5, KIND_QUAD4 = 6, KIND_PAIR4 = 7 };
 constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 1;
 constexpr int BLOCK_NW = 4;   // wavefronts per workgroup of the block kernel
 
 struct ClassTable {
   int kind[GDMIX_RE_NUM_CLASSES];
   int lds_bytes[GDMIX_RE_NUM_CLASSES];   // LDS bucket of the class; 0 = class disabled (or block class)
+  int ncap[GDMIX_RE_NUM_CLASSES];        // quad classes: sample / non-zero capacity of a row's LDS block
+  int zcap[GDMIX_RE_NUM_CLASSES];
 };
 
 // Device pointers of a packed batch, passed by value to kernels.
@@ -85,8 +88,8 @@ hipError_t launch_order(const gdmix_re_packed* b, const int32_t* cls_tmp, const 
                         int32_t* cursor_dev, hipStream_t s);
 hipError_t launch_solve_wreg(int epl, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
                              int begin, int count, int lds_bytes, hipStream_t s);
-hipError_t launch_solve_quad(int epl, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
-                             int begin, int count, int row_lds_bytes, hipStream_t s);
+hipError_t launch_solve_quad(int g, int epl, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
+                             int begin, int count, int ncap, int zcap, hipStream_t s);
 hipError_t launch_solve_wave(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
                              int begin, int count, int lds_bytes, hipStream_t s);
 hipError_t launch_solve_block(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,

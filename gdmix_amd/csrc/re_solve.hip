@@ -33,9 +33,9 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
     for (int k = 0; k < GDMIX_RE_NUM_CLASSES - 1; ++k) {
       if (tab.lds_bytes[k] <= 0) continue;
       const int kind = tab.kind[k];
-      if (kind == KIND_QUAD2 || kind == KIND_QUAD4) {
-        const int cap = (kind == KIND_QUAD2) ? 2 * ROW : 4 * ROW;
-        if (m <= M_REG && p <= cap && wreg_bytes <= (size_t)tab.lds_bytes[k]) { c = k; break; }
+      if (kind == KIND_QUAD2 || kind == KIND_QUAD4 || kind == KIND_PAIR4) {
+        const int cap = (kind == KIND_QUAD2) ? 32 : (kind == KIND_QUAD4 ? 64 : 128);
+        if (m <= M_REG && p <= cap && n <= tab.ncap[k] && z <= tab.zcap[k]) { c = k; break; }
       } else if (kind <= KIND_WREG4) {
         if (kind >= want && want >= 0 && wreg_bytes <= (size_t)tab.lds_bytes[k]) { c = k; break; }
       } else if (kind == KIND_WLDS) {
@@ -128,7 +128,7 @@ __device__ __forceinline__ void write_results(G& grp, const OutDev& O, const Sol
 // Occupancy targets (waves per SIMD) the register allocator must meet: EPL = 1 -> 3 (<= 168 VGPRs),
 // EPL = 2 -> 2 (<= 256), EPL = 4 -> 1.
 #ifndef GDMIX_WREG_WAVES_EPL1
-#define GDMIX_WREG_WAVES_EPL1 3
+#define GDMIX_WREG_WAVES_EPL1 4
 #endif
 #ifndef GDMIX_WREG_WAVES_EPL2
 #define GDMIX_WREG_WAVES_EPL2 2
@@ -288,20 +288,22 @@ hipError_t launch_solve_wreg(int epl, const BatchDev& B, const OutDev& O, const 
 // ---------------------------------------------------------------------------------------------------
 // four entities per wavefront, one per 16-lane DPP row (re_solve_quad.hpp)
 // ---------------------------------------------------------------------------------------------------
+// G lanes per entity: G = 16 -> four entities per wavefront ("quad"), G = 32 -> two ("pair").
 #ifndef GDMIX_QUAD_WAVES_EPL4
-#define GDMIX_QUAD_WAVES_EPL4 1
+#define GDMIX_QUAD_WAVES_EPL4 2
 #endif
 #ifndef GDMIX_QUAD_WAVES_EPL2
 #define GDMIX_QUAD_WAVES_EPL2 2
 #endif
-template <int EPL>
+template <int G, int EPL>
 __global__ __launch_bounds__(WAVE)
-__attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL == 4 ? GDMIX_QUAD_WAVES_EPL4 : 1)))) void re_solve_quad_kernel(
-    BatchDev B, OutDev O, SolveParams o, const double* __restrict__ theta0, int begin, int count, int row_lds_bytes) {
+__attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL == 4 ? GDMIX_QUAD_WAVES_EPL4 : 1)))) void re_solve_grp_kernel(
+    BatchDev B, OutDev O, SolveParams o, const double* __restrict__ theta0, int begin, int count, int ncap, int zcap) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
-  const int row = lane >> 4, gl = lane & (ROW - 1);
-  const int slot = blockIdx.x * 4 + row;
+  constexpr int NG = WAVE / G;   // entities per wavefront
+  const int row = lane / G, gl = lane & (G - 1);
+  const int slot = blockIdx.x * NG + row;
   const bool valid = slot < count;
   const int64_t e = valid ? (int64_t)B.order[begin + slot] : 0;
   const int ic = o.has_intercept ? 1 : 0;
@@ -312,53 +314,50 @@ __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL == 4 
   const int p = valid ? d + ic : 0;
   const int64_t c0 = f0 + e * ic;
 
-  WregLds L;
-  double* dp = reinterpret_cast<double*>(smem + (size_t)row * row_lds_bytes);
-  L.rho = dp; dp += M_REG;
-  L.alpha = dp; dp += M_REG;
-  L.ls = reinterpret_cast<LineSearch*>(dp); dp += 16;
-  L.xs = dp; dp += p;
-  L.rs = dp; dp += n;
-  int2* pp = reinterpret_cast<int2*>(dp);
-  L.csr = pp; pp += nnz;
-  L.csc = pp; pp += nnz;
-  int32_t* ip = reinterpret_cast<int32_t*>(pp);
-  L.row_ptr = ip; ip += n + 1;
-  L.col_ptr = ip; ip += d + 1;
-  float* fp = reinterpret_cast<float*>(ip);
-  L.y = fp; fp += n;
-  L.o = fp; fp += n;
-  L.w = nullptr;
-  if (B.weight) { L.w = fp; fp += n; }
+  QuadLds L;
+  L.q = quad_layout(G * EPL, ncap, zcap);
+  L.base = smem + (size_t)row * L.q.bytes;
+  L.has_w = B.weight != nullptr;
 
   if (valid) {
-    for (int k = gl; k < nnz; k += ROW) {
-      L.csr[k] = make_int2(B.csr_col[z0 + k], __float_as_int(B.csr_val[z0 + k]));
-      L.csc[k] = make_int2(B.csc_row[z0 + k], __float_as_int(B.csc_val[z0 + k]));
+    for (int k = gl; k < nnz; k += G) {
+      L.csr()[k] = make_int2(B.csr_col[z0 + k], __float_as_int(B.csr_val[z0 + k]));
+      L.csc()[k] = make_int2(B.csc_row[z0 + k], __float_as_int(B.csc_val[z0 + k]));
     }
-    for (int i = gl; i < n; i += ROW) {
-      L.y[i] = B.y[r0 + i];
-      L.o[i] = B.offset[r0 + i];
-      if (L.w) L.w[i] = B.weight[r0 + i];
+    for (int i = gl; i < n; i += G) {
+      L.y()[i] = B.y[r0 + i];
+      L.o()[i] = B.offset[r0 + i];
+      if (L.has_w) L.w()[i] = B.weight[r0 + i];
     }
-    for (int i = gl; i <= n; i += ROW) L.row_ptr[i] = B.row_ptr[r0 + e + i];
-    for (int i = gl; i <= d; i += ROW) L.col_ptr[i] = B.col_ptr[f0 + e + i];
+    for (int i = gl; i <= n; i += G) L.row_ptr()[i] = B.row_ptr[r0 + e + i];
+    for (int i = gl; i <= d; i += G) L.col_ptr()[i] = B.col_ptr[f0 + e + i];
   }
-  WregState<EPL> V;
+  // packed (start | len << 16) extents of the lane's first sample and of its coefficient slots
+  unsigned rowc = 0, colc[EPL];
+  if (gl < n) {
+    const int k0 = B.row_ptr[r0 + e + gl], k1 = B.row_ptr[r0 + e + gl + 1];
+    rowc = (unsigned)k0 | ((unsigned)(k1 - k0) << 16);
+  }
+  QuadState<EPL> V;
 #pragma unroll
   for (int s = 0; s < EPL; ++s) {
-    const int j = gl + ROW * s;
+    const int j = gl + G * s;
+    colc[s] = 0;
+    if (j < p && j >= ic) {
+      const int k0 = B.col_ptr[f0 + e + (j - ic)], k1 = B.col_ptr[f0 + e + (j - ic) + 1];
+      colc[s] = (unsigned)k0 | ((unsigned)(k1 - k0) << 16);
+    }
     V.x[s] = (theta0 && j < p) ? theta0[c0 + j] : 0.0;
-    V.g[s] = 0.0; V.d[s] = 0.0; V.xo[s] = 0.0; V.go[s] = 0.0;
+    V.g[s] = 0.0; V.d[s] = 0.0;
   }
   wave_lds_fence();
   SolveStats st;
-  quad_solve<EPL>(L, o, gl, n, p, ic, valid, V, st);
+  quad_solve<G, EPL>(L, o, gl, n, p, ic, valid, rowc, colc, V, st);
   if (!valid) return;
 
 #pragma unroll
   for (int s = 0; s < EPL; ++s) {
-    const int j = gl + ROW * s;
+    const int j = gl + G * s;
     if (j < p) {
       const double v = V.x[s];
       if (O.theta) O.theta[c0 + j] = v;
@@ -374,48 +373,45 @@ __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL == 4 
   }
   if (o.variance_mode == GDMIX_RE_VAR_SIMPLE && O.variance) {
     // _compute_variance SIMPLE (binary_logistic_regression.py:175-180) with the final theta
+    double* const xs = L.xs();
+    double* const rs = L.rs();
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-      const int j = gl + ROW * s;
-      if (j < p) L.xs[j] = V.x[s];
+      const int j = gl + G * s;
+      if (j < p) xs[j] = V.x[s];
     }
     wave_lds_fence();
-    const double x0 = ic ? L.xs[0] : 0.0;
+    const double x0 = ic ? xs[0] : 0.0;
     double dpart = 0.0;
-    for (int i = gl; i < n; i += ROW) {
-      double acc = x0;
-      const int k1 = L.row_ptr[i + 1];
-      for (int k = L.row_ptr[i]; k < k1; ++k) {
-        const int2 cv = L.csr[k];
-        acc += (double)__int_as_float(cv.y) * L.xs[ic + cv.x];
-      }
-      const double z = acc + (double)L.o[i];
+    for (int i = gl; i < n; i += G) {
+      const int k0 = L.row_ptr()[i], k1 = L.row_ptr()[i + 1];
+      const double z = gather_dot(L.csr() + k0, k1 - k0, xs + ic, x0) + (double)L.o()[i];
       const double rho = 1.0 / (1.0 + exp(-z));
-      const double di = rho * (1.0 - rho) * (L.w ? (double)L.w[i] : 1.0);
-      L.rs[i] = di;
+      const double di = rho * (1.0 - rho) * (L.has_w ? (double)L.w()[i] : 1.0);
+      rs[i] = di;
       dpart += di;
     }
-    const double dsum = row_sum(dpart);
+    const double dsum = grp_sum<G>(dpart);
     wave_lds_fence();
     const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-      const int j = gl + ROW * s;
+      const int j = gl + G * s;
       if (j < p) {
         double h;
         if (ic && j == 0) {
           h = dsum;
         } else {
           h = 0.0;
-          const int c = j - ic;
-          const int k1 = L.col_ptr[c + 1];
-          int k = L.col_ptr[c];
-          while (k < k1) {
-            const int rw = L.csc[k].x;
-            double v = (double)__int_as_float(L.csc[k].y);
+          const int2* csc = L.csc();
+          int k = (int)(colc[s] & 0xffffu);
+          const int k1 = k + (int)(colc[s] >> 16);
+          while (k < k1) {   // runs of equal sample = duplicates of one matrix cell
+            const int rw = csc[k].x;
+            double v = (double)__int_as_float(csc[k].y);
             ++k;
-            while (k < k1 && L.csc[k].x == rw) { v += (double)__int_as_float(L.csc[k].y); ++k; }
-            h += v * v * L.rs[rw];
+            while (k < k1 && csc[k].x == rw) { v += (double)__int_as_float(csc[k].y); ++k; }
+            h += v * v * rs[rw];
           }
         }
         h += (j < first_reg) ? 0.0 : o.l2;
@@ -425,29 +421,30 @@ __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL == 4 
   }
 }
 
-template <int EPL>
+template <int G, int EPL>
 static hipError_t launch_quad_t(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
-                                int begin, int count, int row_lds_bytes, hipStream_t s) {
+                                int begin, int count, int ncap, int zcap, hipStream_t s) {
+  constexpr int NG = WAVE / G;
+  const int row_lds_bytes = quad_layout(G * EPL, ncap, zcap).bytes;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(re_solve_quad_kernel<EPL>),
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(re_solve_grp_kernel<G, EPL>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (rc != hipSuccess) return rc;
     attr_set = true;
   }
-  hipLaunchKernelGGL(re_solve_quad_kernel<EPL>, dim3((count + 3) / 4), dim3(WAVE), (size_t)row_lds_bytes * 4, s, B, O, o,
-                     theta0, begin, count, row_lds_bytes);
+  hipLaunchKernelGGL((re_solve_grp_kernel<G, EPL>), dim3((count + NG - 1) / NG), dim3(WAVE), (size_t)row_lds_bytes * NG, s, B, O, o,
+                     theta0, begin, count, ncap, zcap);
   return hipGetLastError();
 }
 
-hipError_t launch_solve_quad(int epl, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
-                             int begin, int count, int row_lds_bytes, hipStream_t s) {
+hipError_t launch_solve_quad(int g, int epl, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
+                             int begin, int count, int ncap, int zcap, hipStream_t s) {
   if (count <= 0) return hipSuccess;
-  switch (epl) {
-    case 2: return launch_quad_t<2>(B, O, o, theta0, begin, count, row_lds_bytes, s);
-    case 4: return launch_quad_t<4>(B, O, o, theta0, begin, count, row_lds_bytes, s);
-    default: return hipErrorInvalidValue;
-  }
+  if (g == 16 && epl == 2) return launch_quad_t<16, 2>(B, O, o, theta0, begin, count, ncap, zcap, s);
+  if (g == 16 && epl == 4) return launch_quad_t<16, 4>(B, O, o, theta0, begin, count, ncap, zcap, s);
+  if (g == 32 && epl == 4) return launch_quad_t<32, 4>(B, O, o, theta0, begin, count, ncap, zcap, s);
+  return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------------------------------

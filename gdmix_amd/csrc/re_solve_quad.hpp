@@ -14,6 +14,13 @@
 // of a wave advance independently, one function evaluation per trip of the main loop; an entity that is
 // still line-searching simply sits out the direction update of that trip.
 //
+// Register diet (the (s, y) history alone is 40*EPL VGPRs): x, g, d and the history live in VGPRs;
+// x_old, g_old and the per-entity scalars that are only needed between evaluations are parked in the
+// row's LDS block. LDS offsets are the same for all four rows (capacity-based layout) so addressing
+// needs one base VGPR. Row/column extents of the CSR/CSC copies are cached as packed (start | len << 16)
+// registers, and the gathers are issued four at a time before the ordered FMA chain, so that an
+// evaluation costs ~3 dependent LDS round trips instead of ~2 per non-zero.
+//
 // Same algorithm, stopping rules and accumulation order inside X~theta and X'r as re_solve_core.hpp /
 // oracle/re_oracle.c (fit(), binary_logistic_regression.py:191-239).
 #pragma once
@@ -52,8 +59,38 @@ __device__ __forceinline__ void row_sum2(double& a, double& b) {
 #undef GDMIX_RSTEP2
 }
 
-// max of non-negative values via the bit pattern order of IEEE doubles (no canonicalising v_max needed)
 __device__ __forceinline__ double max_nn(double a, double b) { return (a > b) ? a : b; }
+
+// ---- 32-lane groups (two DPP rows per entity): one more butterfly stage across the row pair ----------
+// v_permlane16_swap (gfx950) swaps the odd rows of its first operand with the even rows of the second;
+// fed with two copies of v it leaves {r0, r0, r2, r2} and {r1, r1, r3, r3}, whose sum is the pair total
+// in all 32 lanes of each pair (same operand order in both rows -> bit-identical).
+__device__ __forceinline__ void rowpair_split(double v, double& even, double& odd) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  even = __hiloint2double((int)h[0], (int)l[0]);
+  odd = __hiloint2double((int)h[1], (int)l[1]);
+}
+
+template <int G>
+__device__ __forceinline__ double grp_sum(double v) {
+  v = row_sum(v);
+  if (G == 32) { double a, b; rowpair_split(v, a, b); v = a + b; }
+  return v;
+}
+
+template <int G>
+__device__ __forceinline__ void grp_sum2(double& a, double& b) {
+  row_sum2(a, b);
+  if (G == 32) {
+    double a0, a1, b0, b1;
+    rowpair_split(a, a0, a1);
+    rowpair_split(b, b0, b1);
+    a = a0 + a1;
+    b = b0 + b1;
+  }
+}
 
 __device__ __forceinline__ void row_sum2_max(double& a, double& b, double& c) {
 #define GDMIX_RSTEP3(CTRL)              \
@@ -69,68 +106,150 @@ __device__ __forceinline__ void row_sum2_max(double& a, double& b, double& c) {
 #undef GDMIX_RSTEP3
 }
 
-// LDS bytes of ONE entity (row) in the quad kernel; a wavefront uses four of these
-__host__ __device__ inline size_t quad_lds_bytes(int p, int n, int nnz, int d, bool has_w) {
-  return wreg_lds_bytes(p, n, nnz, d, has_w);   // same carve-up as the register wave kernel
+template <int G>
+__device__ __forceinline__ void grp_sum2_max(double& a, double& b, double& c) {
+  row_sum2_max(a, b, c);
+  if (G == 32) {
+    double a0, a1, b0, b1, c0, c1;
+    rowpair_split(a, a0, a1);
+    rowpair_split(b, b0, b1);
+    rowpair_split(c, c0, c1);
+    a = a0 + a1;
+    b = b0 + b1;
+    c = max_nn(c0, c1);
+  }
 }
 
-template <int EPL>
-__device__ __forceinline__ double quad_eval(const WregLds& L, const SolveParams& o, int gl, int n, int p, int ic,
-                                            const double (&xt)[EPL], double (&g)[EPL]) {
+// ---- capacity-based LDS layout of one row (entity) ---------------------------------------------------
+// Offsets depend only on (PCAP = 16*EPL, NCAP, ZCAP), i.e. they are wave-uniform.
+struct QuadLayout {
+  int xs, xo, go, rs, csr, csc, row_ptr, col_ptr, y, o, w, bytes;
+};
+
+constexpr int QUAD_HDR_BYTES = 8 * (2 * M_REG + 16 + 8);   // rho, alpha, LineSearch slot, 8 scalars
+
+__host__ __device__ inline QuadLayout quad_layout(int pcap, int ncap, int zcap) {
+  QuadLayout q;
+  int off = QUAD_HDR_BYTES;
+  q.xs = off; off += 8 * pcap;
+  q.xo = off; off += 8 * pcap;
+  q.go = off; off += 8 * pcap;
+  q.rs = off; off += 8 * ncap;
+  q.csr = off; off += 8 * zcap;
+  q.csc = off; off += 8 * zcap;
+  q.row_ptr = off; off += 4 * (ncap + 1);
+  q.col_ptr = off; off += 4 * (pcap + 1);
+  q.y = off; off += 4 * ncap;
+  q.o = off; off += 4 * ncap;
+  q.w = off; off += 4 * ncap;
+  q.bytes = (off + 15) & ~15;
+  return q;
+}
+
+// Pointers into one row's LDS block (derived from one per-lane base + uniform offsets).
+struct QuadLds {
+  unsigned char* base;
+  QuadLayout q;
+  bool has_w;
+  __device__ __forceinline__ double* rho() const { return reinterpret_cast<double*>(base); }
+  __device__ __forceinline__ double* alpha() const { return reinterpret_cast<double*>(base) + M_REG; }
+  __device__ __forceinline__ LineSearch* ls() const { return reinterpret_cast<LineSearch*>(base + 16 * M_REG); }
+  __device__ __forceinline__ double* scal() const { return reinterpret_cast<double*>(base + 16 * M_REG + 128); }
+  __device__ __forceinline__ double* xs() const { return reinterpret_cast<double*>(base + q.xs); }
+  __device__ __forceinline__ double* xo() const { return reinterpret_cast<double*>(base + q.xo); }
+  __device__ __forceinline__ double* go() const { return reinterpret_cast<double*>(base + q.go); }
+  __device__ __forceinline__ double* rs() const { return reinterpret_cast<double*>(base + q.rs); }
+  __device__ __forceinline__ int2* csr() const { return reinterpret_cast<int2*>(base + q.csr); }
+  __device__ __forceinline__ int2* csc() const { return reinterpret_cast<int2*>(base + q.csc); }
+  __device__ __forceinline__ int32_t* row_ptr() const { return reinterpret_cast<int32_t*>(base + q.row_ptr); }
+  __device__ __forceinline__ int32_t* col_ptr() const { return reinterpret_cast<int32_t*>(base + q.col_ptr); }
+  __device__ __forceinline__ float* y() const { return reinterpret_cast<float*>(base + q.y); }
+  __device__ __forceinline__ float* o() const { return reinterpret_cast<float*>(base + q.o); }
+  __device__ __forceinline__ float* w() const { return reinterpret_cast<float*>(base + q.w); }
+};
+static_assert(sizeof(LineSearch) <= 128, "LineSearch must fit its LDS slot");
+
+enum { SC_FOLD = 0, SC_GDOLD = 1, SC_THETA = 2 };
+
+// sum_k val[k] * vec[idx[k]] over `len` packed {idx, float bits} pairs starting at `pairs`, added to acc
+// in index order. Gathers are issued four at a time; the FMA chain keeps the sequential order (masked
+// tail entries multiply by an exact 0).
+__device__ __forceinline__ double gather_dot(const int2* pairs, int len, const double* vec, double acc) {
+  for (int c = 0; c < len; c += 4) {
+    const int r = len - c;   // >= 1
+    const int2 p0 = pairs[c];
+    const int2 p1 = pairs[c + (r > 1 ? 1 : 0)];
+    const int2 p2 = pairs[c + (r > 2 ? 2 : 0)];
+    const int2 p3 = pairs[c + (r > 3 ? 3 : 0)];
+    const double v0 = vec[p0.x], v1 = vec[p1.x], v2 = vec[p2.x], v3 = vec[p3.x];
+    acc += (double)__int_as_float(p0.y) * v0;
+    acc += (r > 1 ? (double)__int_as_float(p1.y) : 0.0) * v1;
+    acc += (r > 2 ? (double)__int_as_float(p2.y) : 0.0) * v2;
+    acc += (r > 3 ? (double)__int_as_float(p3.y) : 0.0) * v3;
+  }
+  return acc;
+}
+
+// per-sample part of the objective: returns w*ce, writes r = w*(sigma(z) - y)
+__device__ __forceinline__ double sample_terms(double z, double yi, double wi, double& ri) {
+  const double e = exp(-fabs(z));
+  // max(z,0) - z*y + log(1 + exp(-|z|))          (binary_logistic_regression.py:103)
+  const double ce = fmax(z, 0.0) - z * yi + log(1.0 + e);
+  // expit(z) = 1/(1+exp(-z)); for z<0 use e/(1+e) with e = exp(-|z|) (same value, no overflow)
+  const double sig = (z >= 0.0) ? 1.0 / (1.0 + e) : e / (1.0 + e);
+  ri = wi * (sig - yi);
+  return wi * ce;
+}
+
+// f and g at xt. rowc: packed (start | len << 16) of the lane's first sample; colc[s]: same for the
+// lane's coefficient slots (len = 0 for the intercept / unused slots).
+template <int G, int EPL>
+__device__ __forceinline__ double quad_eval(const QuadLds& L, const SolveParams& o, int gl, int n, int p, int ic,
+                                            unsigned rowc, const unsigned (&colc)[EPL], const double (&xt)[EPL],
+                                            double (&g)[EPL]) {
+  double* const xs = L.xs();
+  double* const rs = L.rs();
 #pragma unroll
   for (int s = 0; s < EPL; ++s) {
-    const int j = gl + ROW * s;
-    if (j < p) L.xs[j] = xt[s];
+    const int j = gl + G * s;
+    if (j < p) xs[j] = xt[s];
   }
   wave_lds_fence();
   double part = 0.0, rpart = 0.0;
-  const double x0 = ic ? L.xs[0] : 0.0;
-  for (int i = gl; i < n; i += ROW) {
-    double acc = x0;
-    const int k1 = L.row_ptr[i + 1];
-    for (int k = L.row_ptr[i]; k < k1; ++k) {
-      const int2 cv = L.csr[k];
-      acc += (double)__int_as_float(cv.y) * L.xs[ic + cv.x];
-    }
-    const double z = acc + (double)L.o[i];
-    const double yi = (double)L.y[i];
-    const double wi = L.w ? (double)L.w[i] : 1.0;
-    const double e = exp(-fabs(z));
-    const double ce = fmax(z, 0.0) - z * yi + log(1.0 + e);
-    const double sig = (z >= 0.0) ? 1.0 / (1.0 + e) : e / (1.0 + e);
-    const double ri = wi * (sig - yi);
-    L.rs[i] = ri;
-    part += wi * ce;
+  const double x0 = ic ? xs[0] : 0.0;
+  if (gl < n) {
+    const double z = gather_dot(L.csr() + (rowc & 0xffffu), (int)(rowc >> 16), xs + ic, x0) + (double)L.o()[gl];
+    double ri;
+    part = sample_terms(z, (double)L.y()[gl], L.has_w ? (double)L.w()[gl] : 1.0, ri);
+    rs[gl] = ri;
+    rpart = ri;
+  }
+  for (int i = gl + G; i < n; i += G) {   // entities with more samples than lanes
+    const int k0 = L.row_ptr()[i], k1 = L.row_ptr()[i + 1];
+    const double z = gather_dot(L.csr() + k0, k1 - k0, xs + ic, x0) + (double)L.o()[i];
+    double ri;
+    part += sample_terms(z, (double)L.y()[i], L.has_w ? (double)L.w()[i] : 1.0, ri);
+    rs[i] = ri;
     rpart += ri;
   }
   const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
   double sq = 0.0;
 #pragma unroll
   for (int s = 0; s < EPL; ++s) {
-    const int j = gl + ROW * s;
+    const int j = gl + G * s;
     if (j >= first_reg && j < p) sq += xt[s] * xt[s];
   }
   part += 0.5 * o.l2 * sq;
-  row_sum2(part, rpart);
+  grp_sum2<G>(part, rpart);
   wave_lds_fence();
   const double inv_n = 1.0 / (double)n;
 #pragma unroll
   for (int s = 0; s < EPL; ++s) {
-    const int j = gl + ROW * s;
+    const int j = gl + G * s;
     double gj = 0.0;
     if (j < p) {
-      double acc;
-      if (ic && j == 0) {
-        acc = rpart;
-      } else {
-        acc = 0.0;
-        const int c = j - ic;
-        const int k1 = L.col_ptr[c + 1];
-        for (int k = L.col_ptr[c]; k < k1; ++k) {
-          const int2 rv = L.csc[k];
-          acc += (double)__int_as_float(rv.y) * L.rs[rv.x];
-        }
-      }
+      double acc = (ic && j == 0) ? rpart : 0.0;
+      acc = gather_dot(L.csc() + (colc[s] & 0xffffu), (int)(colc[s] >> 16), rs, acc);
       const double reg = (j < first_reg) ? 0.0 : o.l2 * xt[s];
       gj = inv_n * (acc + reg);
     }
@@ -139,41 +258,59 @@ __device__ __forceinline__ double quad_eval(const WregLds& L, const SolveParams&
   return inv_n * part;
 }
 
-// The solve of the (up to) four entities of a wave. `valid` marks rows that own an entity.
 template <int EPL>
-__device__ __forceinline__ void quad_solve(const WregLds& L, const SolveParams& o, int gl, int n, int p, int ic,
-                                           bool valid, WregState<EPL>& V, SolveStats& out) {
+struct QuadState {
+  double x[EPL], g[EPL], d[EPL];
+};
+
+// The solve of the (up to) four entities of a wave. `valid` marks rows that own an entity.
+template <int G, int EPL>
+__device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& o, int gl, int n, int p, int ic,
+                                           bool valid, unsigned rowc, const unsigned (&colc)[EPL], QuadState<EPL>& V,
+                                           SolveStats& out) {
   double S[M_REG][EPL], Y[M_REG][EPL];
 #pragma unroll
   for (int a = 0; a < M_REG; ++a) {
 #pragma unroll
     for (int s = 0; s < EPL; ++s) { S[a][s] = 0.0; Y[a][s] = 0.0; }
   }
-  double* const rho = L.rho;      // per-entity uniform state, every lane of the row stores the same value
-  double* const alpha = L.alpha;
+  double* const rho = L.rho();      // per-entity uniform state: every lane of the row stores the same value
+  double* const alpha = L.alpha();
+  double* const scal = L.scal();
+  double* const xo = L.xo();
+  double* const go = L.go();
   const int m = o.m;
   int cnt = 0;
-  double theta = 1.0;
   int nit = 0, nfev = 0, ifun = 0;
   int status = valid ? -1 : 0;
   bool iter0 = true, first = true;
-  double f = 0.0, fold = 0.0, gd = 0.0, gdold = 0.0, rr = 0.0, stp = 0.0, sbgnrm = 0.0;
+  double f = 0.0, gd = 0.0, rr = 0.0, stp = 0.0, sbgnrm = 0.0;
+  if (valid) {
+    scal[SC_FOLD] = 0.0; scal[SC_GDOLD] = 0.0; scal[SC_THETA] = 1.0;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+      const int j = gl + G * s;
+      if (j < p) { xo[j] = 0.0; go[j] = 0.0; }
+    }
+  }
   while (__any(status < 0)) {
     bool need_dir = false, restart = false;
     if (status < 0) {
       // ---- f, g at the trial point; g'd, y'y and max|g| in one reduction pass ------------------------
-      f = quad_eval<EPL>(L, o, gl, n, p, ic, V.x, V.g);
+      f = quad_eval<G, EPL>(L, o, gl, n, p, ic, rowc, colc, V.x, V.g);
       ++nfev;
       {
         double a = 0.0, b = 0.0, c = 0.0;
 #pragma unroll
         for (int s = 0; s < EPL; ++s) {
+          const int j = gl + G * s;
+          const double gold = (j < p) ? go[j] : 0.0;
           a += V.g[s] * V.d[s];
-          const double yj = V.g[s] - V.go[s];
+          const double yj = V.g[s] - gold;
           b += yj * yj;
           c = max_nn(c, fabs(V.g[s]));
         }
-        row_sum2_max(a, b, c);
+        grp_sum2_max<G>(a, b, c);
         gd = a; rr = b; sbgnrm = c;
       }
       if (first) {
@@ -181,14 +318,17 @@ __device__ __forceinline__ void quad_solve(const WregLds& L, const SolveParams& 
         if (sbgnrm <= o.pgtol) status = 0;
         else need_dir = true;
       } else {
-        LineSearch LS = *L.ls;
+        LineSearch LS = *L.ls();
         const int task = dcsrch_step(LS, f, gd, stp);
-        *L.ls = LS;
+        *L.ls() = LS;
         if (task == LS_FG) {
           ++ifun;
           if (ifun - 1 < o.maxls) {
 #pragma unroll
-            for (int s = 0; s < EPL; ++s) V.x[s] = stp * V.d[s] + V.xo[s];   // stp == 1: exactly xo + d
+            for (int s = 0; s < EPL; ++s) {
+              const int j = gl + G * s;
+              if (j < p) V.x[s] = stp * V.d[s] + xo[j];   // stp == 1: exactly xo + d
+            }
           } else {
             restart = true;   // iback >= maxls
             need_dir = true;
@@ -197,6 +337,7 @@ __device__ __forceinline__ void quad_solve(const WregLds& L, const SolveParams& 
           // ---- NEW_X: scipy's python loop first (nit / maxiter / maxfun), then mainlb's own tests ---
           ++nit;
           iter0 = false;
+          const double fold = scal[SC_FOLD];
           const double dmx = fmax(fabs(fold), fmax(fabs(f), 1.0));
           if (nit >= o.max_iter) status = 2;
           else if (nfev > o.maxfun) status = 3;
@@ -204,6 +345,7 @@ __device__ __forceinline__ void quad_solve(const WregLds& L, const SolveParams& 
           else if (fold - f <= o.ftol * dmx) status = 1;
           else {
             need_dir = true;
+            const double gdold = scal[SC_GDOLD];
             double dr, ddum;
             if (stp == 1.0) { dr = gd - gdold; ddum = -gdold; }
             else { dr = (gd - gdold) * stp; ddum = -gdold * stp; }
@@ -217,11 +359,12 @@ __device__ __forceinline__ void quad_solve(const WregLds& L, const SolveParams& 
               }
 #pragma unroll
               for (int s = 0; s < EPL; ++s) {
+                const int j = gl + G * s;
                 S[M_REG - 1][s] = stp * V.d[s];   // exact for stp == 1
-                Y[M_REG - 1][s] = V.g[s] - V.go[s];
+                Y[M_REG - 1][s] = V.g[s] - ((j < p) ? go[j] : 0.0);
               }
               rho[M_REG - 1] = 1.0 / dr;
-              theta = rr / dr;
+              scal[SC_THETA] = rr / dr;
               if (cnt < m) ++cnt;
             }
           }
@@ -232,11 +375,14 @@ __device__ __forceinline__ void quad_solve(const WregLds& L, const SolveParams& 
     while (__any(need_dir)) {
       if (need_dir && restart) {
 #pragma unroll
-        for (int s = 0; s < EPL; ++s) { V.x[s] = V.xo[s]; V.g[s] = V.go[s]; }
-        f = fold;
+        for (int s = 0; s < EPL; ++s) {
+          const int j = gl + G * s;
+          if (j < p) { V.x[s] = xo[j]; V.g[s] = go[j]; }
+        }
+        f = scal[SC_FOLD];
         restart = false;
         if (cnt == 0) { status = 4; need_dir = false; }
-        else { cnt = 0; theta = 1.0; }
+        else { cnt = 0; scal[SC_THETA] = 1.0; }
       }
       if (need_dir) {
 #pragma unroll
@@ -251,7 +397,7 @@ __device__ __forceinline__ void quad_solve(const WregLds& L, const SolveParams& 
             double t = 0.0;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) t += S[a][s] * V.d[s];
-            const double al = rho[a] * row_sum(t);
+            const double al = rho[a] * grp_sum<G>(t);
             alpha[a] = al;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) V.d[s] -= al * Y[a][s];
@@ -259,7 +405,7 @@ __device__ __forceinline__ void quad_solve(const WregLds& L, const SolveParams& 
         }
       }
       if (need_dir && cnt > 0) {
-        const double h0 = 1.0 / theta;
+        const double h0 = 1.0 / scal[SC_THETA];
 #pragma unroll
         for (int s = 0; s < EPL; ++s) V.d[s] *= h0;
       }
@@ -271,7 +417,7 @@ __device__ __forceinline__ void quad_solve(const WregLds& L, const SolveParams& 
             double t = 0.0;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) t += Y[a][s] * V.d[s];
-            const double c = alpha[a] - rho[a] * row_sum(t);
+            const double c = alpha[a] - rho[a] * grp_sum<G>(t);
 #pragma unroll
             for (int s = 0; s < EPL; ++s) V.d[s] += c * S[a][s];
           }
@@ -282,29 +428,29 @@ __device__ __forceinline__ void quad_solve(const WregLds& L, const SolveParams& 
         double dd = 0.0, gdp = 0.0;
 #pragma unroll
         for (int s = 0; s < EPL; ++s) {
+          const int j = gl + G * s;
           const double xj = V.x[s];
           const double z = xj + V.d[s];
           const double dj = z - xj;
           V.d[s] = dj;
-          V.xo[s] = xj;
-          V.go[s] = V.g[s];
+          if (j < p) { xo[j] = xj; go[j] = V.g[s]; }
           dd += dj * dj;
           gdp += V.g[s] * dj;
         }
-        row_sum2(dd, gdp);
+        grp_sum2<G>(dd, gdp);
         gd = gdp;
-        gdold = gd;
-        fold = f;
+        scal[SC_GDOLD] = gd;
+        scal[SC_FOLD] = f;
         if (gd >= 0.0) {
           restart = true;   // lnsrlb info = -4: stay in this loop
         } else {
           stp = iter0 ? fmin(1.0 / sqrt(dd), LS_STPMAX) : 1.0;
           LineSearch LS;
           dcsrch_start(LS, f, gd, stp);
-          *L.ls = LS;
+          *L.ls() = LS;
           ifun = 1;
 #pragma unroll
-          for (int s = 0; s < EPL; ++s) V.x[s] = stp * V.d[s] + V.xo[s];
+          for (int s = 0; s < EPL; ++s) V.x[s] = stp * V.d[s] + V.x[s];   // V.x still holds x_old here
           need_dir = false;
         }
       }
@@ -315,7 +461,7 @@ __device__ __forceinline__ void quad_solve(const WregLds& L, const SolveParams& 
 #pragma unroll
     for (int s = 0; s < EPL; ++s) mx = max_nn(mx, fabs(V.g[s]));
     double d0 = 0.0, d1 = 0.0;
-    row_sum2_max(d0, d1, mx);
+    grp_sum2_max<G>(d0, d1, mx);
     sbgnrm = mx;
   }
   out.f = f;
