@@ -14,7 +14,7 @@ Inputs are resident in HBM before the timed region; outputs stay in HBM. With N 
 its own shard of 1M entities (weak scaling; entities are independent, no data-path collective).
 
 One JSON line is printed by rank 0. `roofline` is the HBM roofline of the dominant kernel
-(re_solve_wave_kernel) by the algorithmic-bytes formula of SURVEY.md §8(d); `cpu_baseline` times the
+(the size-class launch that takes the largest share of a step) by the algorithmic-bytes formula of SURVEY.md §8(d); `cpu_baseline` times the
 CPU oracle (oracle/re_oracle.c, a port) on a bounded sample on this box's host cores.
 """
 import argparse
@@ -40,15 +40,15 @@ def parse():
     ap.add_argument("--mean-n", type=int, default=16)
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--dim", type=int, default=1024)
-    ap.add_argument("--cpu-sample", type=int, default=0, help="entities for the CPU baseline (0 = auto ~15 s)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="entities per pass of the CPU baseline (0 = 200k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solve-only", action="store_true", help="time gdmix_re_solve alone (batch packed once)")
     return ap.parse_args()
 
 
-def cpu_baseline(batch, opts_kw, sample):
-    """Time the fp64 CPU restatement (the oracle, kind 'port') on `sample` entities, all host cores.
-    ctypes releases the GIL, so plain threads give one oracle call per core."""
+def cpu_baseline(batch, opts_kw, sample, min_seconds=10.0):
+    """Time the fp64 CPU restatement (the oracle, kind 'port') on the first `sample` entities, repeated
+    until at least `min_seconds` of wall time, one oracle call per host core (ctypes releases the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
     cores = os.cpu_count() or 1
@@ -59,13 +59,18 @@ def cpu_baseline(batch, opts_kw, sample):
     bounds = np.linspace(0, E, cores + 1).astype(int)
 
     def run(i):
-        return oracle.solve(pk, sub.val, sub.y, sub.offset, sub.weight, o, e_begin=int(bounds[i]), e_end=int(bounds[i + 1]))
+        r = oracle.solve(pk, sub.val, sub.y, sub.offset, sub.weight, o, e_begin=int(bounds[i]), e_end=int(bounds[i + 1]))
+        return int(np.isin(r["status"][bounds[i]:bounds[i + 1]], (0, 1, 2)).sum())
+    conv, passes = 0, 0
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
-        outs = list(ex.map(run, range(cores)))
-    dt = time.perf_counter() - t0
-    conv = sum(int(np.isin(r["status"][bounds[i]:bounds[i + 1]], (0, 1, 2)).sum()) for i, r in enumerate(outs))
-    return conv / dt, cores, E, dt
+        while True:
+            conv += sum(ex.map(run, range(cores)))
+            passes += 1
+            dt = time.perf_counter() - t0
+            if dt >= min_seconds or passes >= 200:
+                break
+    return conv / dt, cores, E, dt, passes
 
 
 def main():
@@ -145,36 +150,43 @@ def main():
     value = converged_all * a.steps / dt
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (re_solve_wave_kernel), rank 0's shard ---------------
+        # ---- roofline of the dominant kernel = the size-class launch with the largest share of a step ----
         n = batch.ent_n()
         z = batch.ent_nnz()
         p = np.diff(packed.coef_ptr_host())
-        alg_bytes = synthetic.algorithmic_bytes(n, z, p)            # sum_e B(e), one step
+        b_e = 8.0 * z + 16.0 * n + 8.0 * p + 32.0                    # B(e), SURVEY.md §8(d)
+        alg_bytes = float(b_e.sum())
         classes = solver.class_counts(packed)
-        wave_launches = sum(1 for (name, c) in classes[:-1] if c > 0)
-        wave_ms = float(kernel_ms[:-1].sum()) / a.steps              # all wave-kernel launches of a step
-        block_ent = classes[-1][1]
-        frac_wave = 1.0 - block_ent / max(1, batch.E)
-        per_launch_bytes = alg_bytes * frac_wave / max(1, wave_launches)
-        per_launch_ms = wave_ms / max(1, wave_launches)
-        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        cls = packed._view(packed.c.cls_tmp, packed.E, torch.int32).cpu().numpy()
+        cls_ms = kernel_ms / a.steps
+        dom = int(np.argmax(cls_ms))
+        dom_bytes = float(b_e[cls == dom].sum())
+        dom_ms = float(cls_ms[dom])
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        all_ms = float(cls_ms.sum())
         nfev = res.nfev.double().mean().item()
         nit = res.nit.double().mean().item()
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+        if os.path.exists(tpath):   # PMC bytes of the same kernel from a separate rocprofv3 --pmc run
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            traffic = tj.get(classes[dom][0])
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "re_solve_wave_kernel", "launches_per_step": wave_launches,
-                    "avg_launch_ms": per_launch_ms, "alg_bytes_per_launch": per_launch_bytes,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "kernel": classes[dom][0], "entities_in_launch": int(classes[dom][1]),
+                    "avg_launch_ms": dom_ms, "alg_bytes_per_launch": dom_bytes,
                     "alg_bytes_per_entity": alg_bytes / batch.E,
-                    "note": "LDS-resident solve: latency/ALU-bound fp64 work, not HBM-bound (SURVEY.md §8d honesty note)"}
+                    "all_solve_kernels": {"ms_per_step": all_ms, "alg_GBps": alg_bytes / (all_ms * 1e-3) / 1e9 if all_ms else 0.0},
+                    "note": "LDS/register-resident L-BFGS: bound by fp64 VALU issue and latency, not by HBM "
+                            "(SURVEY.md §8d honesty note); see DESIGN.md for the VALU-side accounting"}
         cpu = None
         if not a.no_cpu_baseline:
-            sample = a.cpu_sample
-            if sample <= 0:
-                v0, cores, e0, d0 = cpu_baseline(batch, opts_kw, 4000)
-                sample = int(min(batch.E, max(4000, v0 * 15.0)))
-            v, cores, es, d = cpu_baseline(batch, opts_kw, sample)
+            sample = a.cpu_sample if a.cpu_sample > 0 else min(batch.E, 200_000)
+            v, cores, es, d, passes = cpu_baseline(batch, opts_kw, sample)
             cpu = {"value": round(v, 1), "unit": "entities/s", "cores": cores, "kind": "port",
-                   "sample": f"first {es} entities of the same C2 batch, oracle/re_oracle.c fp64, {cores} threads, {d:.1f} s"}
+                   "sample": f"first {es} entities of the same C2 batch x {passes} passes, oracle/re_oracle.c fp64 "
+                             f"(restatement pinned to the reference by tests/golden), {cores} threads, {d:.1f} s"}
         line = {
             "metric": "random-effect entities converged/sec", "value": round(value, 1), "unit": "entities/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,

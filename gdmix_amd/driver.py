@@ -1,0 +1,129 @@
+"""RandomEffectDriver: partition list -> per-worker partition striding -> model.train / model.predict per
+partition, with the directory and file naming of the reference
+(gdmix-trainer/src/gdmix/drivers/driver.py:85-216, drivers/random_effect_driver.py:12-73).
+
+One process per GPU: the worker identity comes from TF_CONFIG exactly as in the reference; when it is absent
+and the process was started by torch.distributed.run, RANK / WORLD_SIZE are used instead, so that
+`python -m torch.distributed.run --nproc-per-node 8 -m gdmix_amd.gdmix ...` shards the partitions over the 8
+GPUs of a node (worker w trains partitions[w::num_workers], random_effect_driver.py:60-68).
+"""
+import glob
+import json
+import logging
+import os
+
+from . import constants
+
+logger = logging.getLogger(__name__)
+logger.setLevel(logging.INFO)
+
+
+def is_empty_directory(input_dir):
+    if not os.path.isdir(input_dir):
+        raise ValueError(f"Directory expected, but {input_dir} is not a directory")
+    return len(os.listdir(input_dir)) == 0
+
+
+class RandomEffectDriver:
+    _RANDOM_EFFECT_PARTITION_DIR_PREFIX = "partitionId="
+
+    def __init__(self, base_training_params, model):
+        self.base_training_params = base_training_params
+        self.model = model
+        self._validate_params()
+        self.execution_context = self._setup_cluster()
+        self.effect_name = constants.RANDOM_EFFECT
+
+    def _validate_params(self):
+        assert self.base_training_params.model_type == constants.LOGISTIC_REGRESSION, \
+            "Random effect supports logistic_regression only"
+        assert self.base_training_params.partition_list_file is not None, \
+            "Random effect requires partition list file"
+
+    def _setup_cluster(self):
+        tf_config = os.environ.get(constants.TF_CONFIG)
+        if not tf_config:
+            rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+            return {constants.TASK_TYPE: "worker", constants.TASK_INDEX: rank, constants.CLUSTER_SPEC: None,
+                    constants.NUM_WORKERS: world, constants.NUM_SHARDS: 1, constants.SHARD_INDEX: 0,
+                    constants.IS_CHIEF: rank == 0}
+        cfg = json.loads(tf_config)
+        cluster = cfg.get("cluster") or {}
+        task = cfg.get("task", {})
+        ctx = {constants.TASK_TYPE: task.get("type"), constants.TASK_INDEX: task.get("index"),
+               constants.CLUSTER_SPEC: None,   # random effect runs in local mode
+               constants.NUM_WORKERS: len(cluster.get(constants.WORKER, [])),
+               constants.NUM_SHARDS: 1, constants.SHARD_INDEX: 0, constants.IS_CHIEF: task.get("index") == 0}
+        if ctx[constants.TASK_TYPE] is None or ctx[constants.TASK_INDEX] is None:
+            raise Exception("No job name found")
+        if ctx[constants.NUM_WORKERS] < 1:
+            raise Exception("No worker found")
+        os.environ.pop(constants.TF_CONFIG, None)   # random effect runs in local mode
+        return ctx
+
+    def _get_partition_list(self):
+        with open(self.base_training_params.partition_list_file) as f:
+            line = f.readline()
+        all_partitions = [int(x) for x in line.split(",")]
+        idx = range(self.execution_context[constants.TASK_INDEX], len(all_partitions),
+                    self.execution_context[constants.NUM_WORKERS])
+        return [all_partitions[i] for i in idx]
+
+    def _anchor_directory(self, directory_path, partition_index):
+        return os.path.join(directory_path, self._RANDOM_EFFECT_PARTITION_DIR_PREFIX + str(partition_index))
+
+    def run_training(self, schema_params, export_model=False, output_model_dir=None):
+        logger.info(f"Commencing {self.effect_name} training")
+        logger.info(f"Execution context : {self.execution_context}")
+        partition_index_list = self._get_partition_list()
+        logger.info(f"This worker on work on the following list of partitions : {partition_index_list}")
+        for partition_index in partition_index_list:
+            checkpoint_path = self._anchor_directory(self.model.checkpoint_path, partition_index)
+            training_data_dir = self._anchor_directory(self.model.training_data_dir, partition_index)
+            validation_data_dir = self._anchor_directory(self.model.validation_data_dir, partition_index) \
+                if self.model.validation_data_dir else None
+            if is_empty_directory(training_data_dir):
+                logger.info(f"{training_data_dir} is empty, no dataset to train on.")
+                continue
+            self.execution_context[constants.PARTITION_INDEX] = partition_index
+            self.model.train(training_data_dir=training_data_dir, validation_data_dir=validation_data_dir,
+                             metadata_file=self.model.metadata_file, checkpoint_path=checkpoint_path,
+                             execution_context=self._prepare_training_context(partition_index),
+                             schema_params=schema_params)
+            if export_model and self.execution_context[constants.IS_CHIEF]:
+                self.model.export(output_model_dir=output_model_dir)
+
+    def run_inference(self, schema_params):
+        logger.info(f"Commencing {self.effect_name} inference")
+        if self.execution_context[constants.TASK_TYPE] != constants.TASK_TYPE_WORKER:
+            logger.info("Only workers should run inference. Exiting")
+            return
+        for partition_index in self._get_partition_list():
+            self.execution_context[constants.PARTITION_INDEX] = partition_index
+            for input_path, output_path in ((self.model.training_data_dir, self.base_training_params.training_score_dir),
+                                            (self.model.validation_data_dir, self.base_training_params.validation_score_dir)):
+                if input_path and output_path:
+                    data_path = self._anchor_directory(input_path, partition_index)
+                    output_dir = os.path.join(self._anchor_directory(output_path, partition_index))
+                    if is_empty_directory(input_path):
+                        logger.info(f"{input_path} is empty, no dataset to inference on.")
+                        continue
+                    self.model.predict(output_dir=output_dir, input_data_path=data_path,
+                                       metadata_file=self.model.metadata_file, checkpoint_path=self.model.checkpoint_path,
+                                       execution_context=self.execution_context, schema_params=schema_params)
+        logger.info("Inference complete")
+
+    def _prepare_training_context(self, partition_index):
+        p = self.base_training_params
+        task = self.execution_context[constants.TASK_INDEX]
+        anchored = self._anchor_directory(p.training_score_dir, partition_index)
+        ctx = dict(self.execution_context)
+        passive = self._anchor_directory(self.model.passive_training_data_dir, partition_index)
+        if os.path.exists(passive) and len(glob.glob(os.path.join(passive, "[!.]*"))) != 0:
+            ctx[constants.PASSIVE_TRAINING_DATA_DIR] = passive
+        ctx[constants.ACTIVE_TRAINING_OUTPUT_FILE] = os.path.join(anchored, f"part-{task:05d}-active.avro")
+        ctx[constants.PASSIVE_TRAINING_OUTPUT_FILE] = os.path.join(anchored, f"part-{task:05d}-passive.avro")
+        ctx[constants.VALIDATION_OUTPUT_FILE] = os.path.join(
+            self._anchor_directory(p.validation_score_dir, partition_index), f"part-{task:05d}.avro") \
+            if p.validation_score_dir else None
+        return ctx

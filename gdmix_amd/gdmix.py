@@ -1,0 +1,40 @@
+"""CLI entry of the random-effect stage, flag-compatible with the reference's
+`python -m gdmix.gdmix --stage=random_effect ...` (gdmix-trainer/src/gdmix/gdmix.py:13-36): one flat argv is
+shared by Params, SchemaParams and REParams, unknown flags are ignored, any failure exits non-zero.
+
+    python -m gdmix_amd.gdmix --stage=random_effect --action=train --model_type=logistic_regression \\
+        --partition_list_file=... --training_data_dir=... --metadata_file=... --output_model_dir=... ...
+
+Only --stage=random_effect is implemented (the fixed-effect and DeText stages are out of scope).
+"""
+import logging
+import sys
+
+from . import constants
+from .driver import RandomEffectDriver
+from .model import RandomEffectLRLBFGSModel
+from .params import Params, SchemaParams
+
+logging.basicConfig(level=logging.INFO)
+logger = logging.getLogger(__name__)
+
+
+def run(args):
+    params = Params.__from_argv__(args, error_on_unknown=False)
+    schema_params = SchemaParams.__from_argv__(args, error_on_unknown=False)
+    logger.info(f"Parsed schema params amd gdmix args (params): {params}")
+    if params.stage != constants.RANDOM_EFFECT:
+        raise NotImplementedError(f"stage {params.stage!r}: only the random-effect stage runs on this library")
+    if params.model_type != constants.LOGISTIC_REGRESSION:
+        raise ValueError("Random effect supports logistic_regression only")
+    driver = RandomEffectDriver(base_training_params=params, model=RandomEffectLRLBFGSModel(raw_model_params=args))
+    if params.action == constants.ACTION_TRAIN:
+        driver.run_training(schema_params=schema_params, export_model=True)
+    elif params.action == constants.ACTION_INFERENCE:
+        driver.run_inference(schema_params=schema_params)
+    else:
+        raise Exception(f"Unsupported action {params.action}")
+
+
+if __name__ == "__main__":
+    run(sys.argv)

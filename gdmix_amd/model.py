@@ -1,0 +1,439 @@
+"""RandomEffectLRLBFGSModel on MI355X: the reference's RE model API
+(gdmix-trainer/src/gdmix/models/custom/random_effect_lr_lbfgs_model.py:56-317, models/api.py:4-84) with the
+producer/consumer pool of scipy solves replaced by one batched device call per partition.
+
+What stays as in the reference: parameters (REParams), directory conventions (active/passive), warm start
+from `output_model_dir/part-000KK.avro`, carrying over prior entities that are absent from the new data,
+the photon-ml Avro model format, the score Avro format, scoring of validation / active / passive data
+after training. What changes: per_entity_grouped_input_fn + prepare_jobs + N scipy consumers become
+read_grouped_partition -> gdmix_re_pack -> gdmix_re_solve / gdmix_re_score (gdmix_amd/csrc).
+"""
+import logging
+import os
+import struct
+from collections import namedtuple
+
+import numpy as np
+
+from . import constants
+from .io import avro
+from .io.features import get_feature_map, read_feature_list
+from .io.grouped_reader import read_grouped_partition
+from .io.metadata import DatasetMetadata, read_json_file
+from .params import REParams
+from .solver import REDeviceSolver, SolverOptions, VARIANCE_MODES
+
+logger = logging.getLogger(__name__)
+logger.setLevel(logging.INFO)
+
+# entity_id -> TrainingResult, exactly the reference's value type (scipy/job_consumers.py:18)
+TrainingResult = namedtuple("TrainingResult", ("theta", "variance", "unique_global_indices"))
+
+
+class ModelTable:
+    """entity id -> TrainingResult, stored as flat arrays per chunk so that a million models do not become
+    a million Python objects. Iteration order follows dict.update semantics: existing ids keep their place,
+    new ids are appended (random_effect_lr_lbfgs_model.py:162)."""
+
+    def __init__(self):
+        self._chunks = []      # dict(theta, variance|None, idx, coef_ptr, feat_ptr)
+        self._where = {}       # id -> (chunk index, row)
+
+    def __len__(self):
+        return len(self._where)
+
+    def __bool__(self):
+        return len(self._where) > 0
+
+    def __contains__(self, k):
+        return k in self._where
+
+    def add_chunk(self, ids, theta, coef_ptr, idx, feat_ptr, variance=None):
+        c = len(self._chunks)
+        self._chunks.append(dict(theta=np.asarray(theta, np.float64), variance=None if variance is None else np.asarray(variance, np.float64),
+                                 idx=np.asarray(idx, np.int64), coef_ptr=np.asarray(coef_ptr, np.int64),
+                                 feat_ptr=np.asarray(feat_ptr, np.int64)))
+        for r, k in enumerate(ids):
+            self._where[k] = (c, r)    # an existing key keeps its position in the dict, only the value changes
+
+    def get(self, k, default=None):
+        w = self._where.get(k)
+        if w is None:
+            return default
+        c, r = w
+        ch = self._chunks[c]
+        a, b = ch["coef_ptr"][r], ch["coef_ptr"][r + 1]
+        fa, fb = ch["feat_ptr"][r], ch["feat_ptr"][r + 1]
+        return TrainingResult(ch["theta"][a:b], None if ch["variance"] is None else ch["variance"][a:b], ch["idx"][fa:fb])
+
+    def __getitem__(self, k):
+        v = self.get(k)
+        if v is None:
+            raise KeyError(k)
+        return v
+
+    def keys(self):
+        return self._where.keys()
+
+    def items(self):
+        for k in self._where:
+            yield k, self.get(k)
+
+    def update(self, other):
+        if isinstance(other, ModelTable):
+            base = len(self._chunks)
+            self._chunks.extend(other._chunks)
+            for k, (c, r) in other._where.items():
+                self._where[k] = (base + c, r)
+        else:
+            for k, tr in dict(other).items():
+                p = len(tr.theta)
+                d = len(tr.unique_global_indices)
+                self.add_chunk([k], tr.theta, [0, p], tr.unique_global_indices, [0, d], tr.variance)
+
+    def lookup(self, ids):
+        """Vectorised: for every id, (found mask, chunk index, row)."""
+        found = np.zeros(len(ids), bool)
+        chunk = np.zeros(len(ids), np.int64)
+        row = np.zeros(len(ids), np.int64)
+        for i, k in enumerate(ids):
+            w = self._where.get(k)
+            if w is not None:
+                found[i] = True
+                chunk[i], row[i] = w
+        return found, chunk, row
+
+
+def _model_coefficients_for_batch(table, entity_ids, unique_global, ent_feat_ptr, has_intercept, num_features):
+    """Coefficients of the prior / trained models in the packed batch's local index space.
+
+    For every entity that has a model: intercept from the model (always), and for every feature present in
+    the current data the model's coefficient if it has one, else 0 (prepare_jobs:262-288 for training warm
+    start; InferenceJobConsumer for scoring). Returns (theta [P] float64, has_model [E] uint8)."""
+    E = len(entity_ids)
+    ic = 1 if has_intercept else 0
+    d = np.diff(ent_feat_ptr)
+    coef_ptr = ent_feat_ptr + np.arange(E + 1, dtype=np.int64) * ic
+    theta = np.zeros(int(coef_ptr[-1]), np.float64)
+    found, chunk, row = table.lookup(entity_ids)
+    has_model = found.astype(np.uint8)
+    if not found.any():
+        return theta, has_model
+    F = int(num_features) + 1
+    ent_of_feat = np.repeat(np.arange(E, dtype=np.int64), d)
+    cur_key = ent_of_feat * F + unique_global
+    feat_coef_pos = coef_ptr[:-1][ent_of_feat] + ic + (np.arange(unique_global.size, dtype=np.int64) - ent_feat_ptr[:-1][ent_of_feat])
+    for c in np.unique(chunk[found]):
+        ch = table._chunks[int(c)]
+        sel = np.flatnonzero(found & (chunk == c))
+        rows = row[sel]
+        if ic:
+            theta[coef_ptr[sel]] = ch["theta"][ch["coef_ptr"][rows]]
+        fa, fb = ch["feat_ptr"][rows], ch["feat_ptr"][rows + 1]
+        cnt = fb - fa
+        if cnt.sum() == 0:
+            continue
+        from .batch import _ranges
+        src_feat = _ranges(fa, cnt)                              # positions in the chunk's idx array
+        src_ent = np.repeat(sel, cnt)                            # batch entity of each prior feature
+        within = src_feat - np.repeat(fa, cnt)
+        src_val = ch["theta"][np.repeat(ch["coef_ptr"][rows], cnt) + ic + within]
+        prior_key = src_ent * F + ch["idx"][src_feat]
+        order = np.argsort(prior_key, kind="stable")
+        pk, pv = prior_key[order], src_val[order]
+        pos = np.searchsorted(pk, cur_key)
+        pos_c = np.minimum(pos, pk.size - 1)
+        hit = (pos < pk.size) & (pk[pos_c] == cur_key)
+        theta[feat_coef_pos[hit]] = pv[pos_c[hit]]
+    return theta, has_model
+
+
+class RandomEffectLRLBFGSModel:
+    """Per-entity L2-regularised logistic regression, all entities of a partition solved on one MI355X."""
+
+    def __init__(self, raw_model_params, device=None):
+        self.model_params: REParams = self._parse_parameters(raw_model_params)
+        self.checkpoint_path = os.path.join(self.model_params.output_model_dir)
+        self.metadata_file = self.model_params.metadata_file
+        self.feature_bag_name = self.model_params.feature_bag
+        self.has_intercept = self.model_params.has_intercept
+        # If no features, then make sure feature file is None. This is intercept only model.
+        self.feature_file = None if self.feature_bag_name is None else self.model_params.feature_file
+        if self.model_params.training_data_dir is not None:
+            self.training_data_dir = os.path.join(self.model_params.training_data_dir, constants.ACTIVE)
+            self.passive_training_data_dir = os.path.join(self.model_params.training_data_dir, constants.PASSIVE)
+        else:
+            self.training_data_dir = None
+            self.passive_training_data_dir = None
+        self.validation_data_dir = self.model_params.validation_data_dir
+        self.disable_random_effect_scoring_after_training = self.model_params.disable_random_effect_scoring_after_training
+        self._device_index = device
+        self._solver = None
+        self.last_training_stats = None
+
+    # ---- Model API (models/api.py) ---------------------------------------------------------------------
+    def train(self, training_data_dir, validation_data_dir, metadata_file, checkpoint_path, execution_context, schema_params):
+        logger.info("Kicking off random effect custom LR training")
+        self._action(constants.ACTION_TRAIN, (training_data_dir, validation_data_dir), metadata_file, checkpoint_path,
+                     execution_context, schema_params)
+
+    def predict(self, output_dir, input_data_path, metadata_file, checkpoint_path, execution_context, schema_params):
+        logger.info(f"Running inference on dataset : {input_data_path}, results to be written to path : {output_dir}")
+        self._action(constants.ACTION_INFERENCE, (output_dir, input_data_path), metadata_file, checkpoint_path,
+                     execution_context, schema_params)
+
+    def export(self, output_model_dir):
+        logger.info("Model export is done as part of the training() API for random effect LR LBFGS training. Skipping.")
+
+    def _parse_parameters(self, raw_model_parameters) -> REParams:
+        params = REParams.__from_argv__(raw_model_parameters, error_on_unknown=False)
+        logger.info(params)
+        return params
+
+    # ---- internals ----------------------------------------------------------------------------------
+    def _get_solver(self):
+        if self._solver is None:
+            dev = self._device_index
+            if dev is None:
+                dev = int(os.environ.get("LOCAL_RANK", "0"))
+            self._solver = REDeviceSolver(dev)   # raises if no MI355X / no library: there is no CPU fallback
+        return self._solver
+
+    def _solver_options(self):
+        mp = self.model_params
+        return SolverOptions(l2=mp.l2_reg_weight, regularize_bias=mp.regularize_bias, has_intercept=self.has_intercept,
+                             m=mp.num_of_lbfgs_curvature_pairs, max_iter=mp.num_of_lbfgs_iterations,
+                             ftol=mp.lbfgs_tolerance, variance_mode=VARIANCE_MODES[mp.random_effect_variance_mode],
+                             threshold=mp.sparsity_threshold)
+
+    def _action(self, action, action_context, metadata_file, checkpoint_path, execution_context, schema_params):
+        partition_index = execution_context[constants.PARTITION_INDEX]
+        metadata = read_json_file(metadata_file)
+        tensor_metadata = DatasetMetadata(metadata)
+        # if intercept only model, pad a dummy feature, otherwise, read number of features from the metadata
+        num_features = 1 if self.feature_bag_name is None else tensor_metadata.get_feature_shape(self.feature_bag_name)[0]
+        logger.info(f"Found {num_features} features in feature bag {self.feature_bag_name}")
+        assert num_features > 0, "number of features must > 0"
+        avro_filename = f"part-{partition_index:05d}.avro"
+        if action == constants.ACTION_INFERENCE:
+            output_dir, input_data_path = action_context
+            model_weights = self._load_weights(os.path.join(checkpoint_path, avro_filename))
+            self._predict(input_path=input_data_path, tensor_metadata=tensor_metadata,
+                          output_file=os.path.join(output_dir, avro_filename), model_weights=model_weights,
+                          schema_params=schema_params, num_features=num_features)
+        elif action == constants.ACTION_TRAIN:
+            training_data_dir, validation_data_dir = action_context
+            model_file = os.path.join(self.model_params.output_model_dir, avro_filename)
+            model_weights = self._load_weights(model_file, True)    # load initial model if available
+            model_weights = self._train(training_data_dir, tensor_metadata, model_weights, num_features, schema_params,
+                                        model_file)
+
+            def predict(input_path, output_file):
+                self._predict(input_path=input_path, tensor_metadata=tensor_metadata, output_file=output_file,
+                              model_weights=model_weights, schema_params=schema_params, num_features=num_features)
+            if validation_data_dir:
+                o = execution_context.get(constants.VALIDATION_OUTPUT_FILE, None)
+                o and predict(validation_data_dir, o)
+            if not self.disable_random_effect_scoring_after_training:
+                o = execution_context.get(constants.ACTIVE_TRAINING_OUTPUT_FILE, None)
+                o and predict(training_data_dir, o)
+                i, o = execution_context.get(constants.PASSIVE_TRAINING_DATA_DIR, None), \
+                    execution_context.get(constants.PASSIVE_TRAINING_OUTPUT_FILE, None)
+                i and o and predict(i, o)
+        else:
+            raise ValueError(f"Invalid action {action!r}.")
+
+    def _read(self, input_path, tensor_metadata, schema_params, num_features, need_label):
+        assert self.model_params.data_format == constants.TFRECORD
+        return read_grouped_partition(
+            input_path, tensor_metadata, entity_name=self.model_params.partition_entity,
+            feature_bag=self.feature_bag_name, offset_column_name=self.model_params.offset_column_name,
+            uid_column_name=schema_params.uid_column_name,
+            label_column_name=schema_params.label_column_name, weight_column_name=schema_params.weight_column_name,
+            num_features=num_features)
+
+    def _train(self, input_path, tensor_metadata, model_weights, num_features, schema_params, output_model_file):
+        logger.info(f"Start training with {f'loaded {len(model_weights)} previous models' if model_weights else 'zeros'} "
+                    f"as the model initial value.")
+        batch = self._read(input_path, tensor_metadata, schema_params, num_features, need_label=True)
+        if not batch.has_label:
+            raise KeyError(f"label column {schema_params.label_column_name!r} is missing from the training data")
+        solver = self._get_solver()
+        opts = self._solver_options()
+        packed = solver.pack(batch, has_intercept=self.has_intercept)
+        feat_ptr = packed.ent_feat_ptr().cpu().numpy()
+        uniq = packed.unique_global().cpu().numpy()
+        theta0 = None
+        if model_weights:
+            theta0, _ = _model_coefficients_for_batch(model_weights, batch.entity_ids, uniq, feat_ptr,
+                                                      self.has_intercept, num_features)
+        res = solver.solve(packed, opts, theta0=theta0).to_host()
+        ic = 1 if self.has_intercept else 0
+        coef_ptr = feat_ptr + np.arange(batch.E + 1, dtype=np.int64) * ic
+        self.last_training_stats = dict(entities=batch.E, samples=batch.N, nnz=batch.Z, nit=res["nit"], nfev=res["nfev"],
+                                        status=res["status"], fval=res["fval"], gnorm=res["gnorm"])
+        results = ModelTable()
+        results.add_chunk(batch.entity_ids, res["theta_thr"], coef_ptr, uniq, feat_ptr, res.get("variance"))
+        # The trained model is updated over the prior model: prior entities that are not in the current data
+        # are carried over (random_effect_lr_lbfgs_model.py:155-162).
+        model_weights.update(results)
+        logger.info(f"{len(model_weights)} models in total after training/refreshing.")
+        self._save_model(output_model_file, model_coefficients=model_weights, num_features=num_features,
+                         feature_file=self.feature_file)
+        return model_weights
+
+    def _predict(self, input_path, tensor_metadata, output_file, schema_params, num_features, model_weights):
+        logger.info(f"Start inference for {input_path}.")
+        batch = self._read(input_path, tensor_metadata, schema_params, num_features, need_label=False)
+        has_weight = any(schema_params.weight_column_name == f.name for f in tensor_metadata.get_features())
+        schema = avro.inference_output_schema(schema_params, has_weight=has_weight)
+        if batch.E == 0:
+            avro.write_file(output_file, schema, [])
+            return
+        solver = self._get_solver()
+        packed = solver.pack(batch, has_intercept=self.has_intercept)
+        feat_ptr = packed.ent_feat_ptr().cpu().numpy()
+        uniq = packed.unique_global().cpu().numpy()
+        theta, has_model = _model_coefficients_for_batch(model_weights, batch.entity_ids, uniq, feat_ptr,
+                                                         self.has_intercept, num_features)
+        logit, per_coord = solver.score(packed, theta, has_model)
+        logit, per_coord = logit.cpu().numpy(), per_coord.cpu().numpy()
+        weights = batch.weight if batch.weight is not None else np.ones(batch.N, np.float32)
+        _write_scores(output_file, schema, schema_params, batch.uid, logit, batch.y if batch.has_label else None,
+                      weights if has_weight else None, per_coord)
+        logger.info(f"Inference complete: {input_path}.")
+
+    def _save_model(self, output_file, model_coefficients, num_features, feature_file):
+        feature_list = read_feature_list(feature_file) if feature_file else None
+        if feature_file is None:
+            assert num_features == 1   # intercept only model
+        with_variance = self.model_params.random_effect_variance_mode is not None
+        n = _export_models_to_avro(output_file, model_coefficients, feature_list, self.has_intercept, with_variance,
+                                   sparsity_threshold=1.0e-4)   # export threshold is always the default
+        logger.info(f"dumped {n} models to avro file at {output_file}.")
+
+    def _load_weights(self, model_file, catch_exception=False):
+        logger.info(f"Loading model from {model_file}")
+        if not os.path.exists(model_file):
+            if catch_exception:
+                logger.info(f"No model found at {model_file}.")
+                return ModelTable()
+            raise FileNotFoundError(f"Model file {model_file} does not exist")
+        feature2global_id = None if self.feature_file is None else get_feature_map(self.feature_file)
+        table = ModelTable()
+        ids, theta, var, idx, coef_ptr, feat_ptr = [], [], [], [], [0], [0]
+        any_var = False
+        for record in avro.read_file(model_file):
+            mid, tr = self._convert_avro_model_record_to_sparse_coefficients(self.has_intercept, record, feature2global_id)
+            ids.append(mid)
+            theta.append(tr.theta)
+            idx.append(tr.unique_global_indices)
+            if tr.variance is not None:
+                any_var = True
+                var.append(tr.variance)
+            else:
+                var.append(np.zeros(len(tr.theta)))
+            coef_ptr.append(coef_ptr[-1] + len(tr.theta))
+            feat_ptr.append(feat_ptr[-1] + len(tr.unique_global_indices))
+        if ids:
+            table.add_chunk(ids, np.concatenate(theta), coef_ptr, np.concatenate(idx) if idx else np.zeros(0, np.int64),
+                            feat_ptr, np.concatenate(var) if any_var else None)
+        return table
+
+    @staticmethod
+    def _convert_avro_model_record_to_sparse_coefficients(has_intercept, model_record, feature2global_id):
+        """random_effect_lr_lbfgs_model.py:275-309."""
+        model_id = model_record["modelId"]
+        coeffs, uidx, variance = [], [], []
+        for i, ntv in enumerate(model_record["means"]):
+            coeffs.append(np.float64(ntv["value"]))
+            if has_intercept and i == 0:
+                assert ntv["name"] == constants.INTERCEPT and ntv["term"] == ""
+            else:
+                uidx.append(feature2global_id[(ntv["name"], ntv["term"])])
+        if model_record.get("variances"):
+            for i, ntv in enumerate(model_record["variances"]):
+                variance.append(np.float64(ntv["value"]))
+                if has_intercept and i == 0:
+                    assert ntv["name"] == constants.INTERCEPT and ntv["term"] == ""
+                else:
+                    assert uidx[i - 1] == feature2global_id[(ntv["name"], ntv["term"])]
+        if feature2global_id is None:
+            # intercept-only model, add one dummy feature
+            assert len(uidx) == 0
+            coeffs.append(np.float64(0.0))
+            uidx.append(0)
+            if variance:
+                variance.append(np.float64(0.0))
+        return model_id, TrainingResult(theta=np.array(coeffs), variance=np.array(variance) if variance else None,
+                                        unique_global_indices=np.array(uidx, np.int64))
+
+
+# ---- Avro writers (record layout of util/io_utils.py:102-212 and :299-375) ----------------------------------
+def _export_models_to_avro(output_file, table, feature_list, has_intercept, with_variance, sparsity_threshold=1e-4):
+    """One BayesianLinearModelAvro per entity: intercept always, features with |value| > threshold
+    (gen_one_avro_model, util/io_utils.py:102-160). The array payloads are assembled from pre-encoded
+    name/term prefixes instead of per-field schema dispatch."""
+    model_class = constants.PHOTON_LR_MODEL_CLASS
+    head_class = avro.enc_long(1) + avro.enc_string(model_class)       # union branch 1 (string)
+    loss = avro.enc_long(1) + avro.enc_string("")                      # lossFunction = "" (not null)
+    icpt = avro.enc_string(constants.INTERCEPT) + avro.enc_string("")
+    prefix = None
+    if feature_list is not None:
+        prefix = [avro.enc_string(n) + avro.enc_string(t) for (n, t) in feature_list]
+    pack_d = struct.Struct("<d").pack
+    ic = 1 if has_intercept else 0
+    count = 0
+    with avro.Writer(output_file, avro.BAYESIAN_LINEAR_MODEL_SCHEMA) as w:
+        buf = bytearray()
+        nbuf = 0
+        for model_id, (mean, variance, uidx) in table.items():
+            has_var = with_variance and variance is not None
+            items, vitems = [], []
+            if ic:
+                items.append(icpt + pack_d(float(mean[0])))
+                if has_var:
+                    vitems.append(icpt + pack_d(float(variance[0])))
+            if prefix is not None:
+                vals = mean[ic:]
+                keep = np.flatnonzero(np.abs(vals) > sparsity_threshold)
+                for k in keep:
+                    items.append(prefix[int(uidx[k])] + pack_d(float(vals[k])))
+                    if has_var:
+                        vitems.append(prefix[int(uidx[k])] + pack_d(float(variance[ic + k])))
+            buf += avro.enc_string(str(model_id)) + head_class
+            buf += (avro.enc_long(len(items)) + b"".join(items) if items else b"") + avro.enc_long(0)
+            if has_var:
+                buf += avro.enc_long(1) + (avro.enc_long(len(vitems)) + b"".join(vitems) if vitems else b"") + avro.enc_long(0)
+            else:
+                buf += avro.enc_long(0)
+            buf += loss
+            nbuf += 1
+            count += 1
+            if nbuf >= 1024:
+                w.write_encoded(bytes(buf), nbuf)
+                buf, nbuf = bytearray(), 0
+        if nbuf:
+            w.write_encoded(bytes(buf), nbuf)
+    return count
+
+
+def _write_scores(output_file, schema, schema_params, uid, score, label, weight, per_coord):
+    """Records {uid long, predictionScore float, label [null,float], weight float?, perCoordinate float} in
+    blocks of 1024 (batched_write_avro, util/io_utils.py:299-334)."""
+    pack_f = struct.Struct("<f").pack
+    n = len(uid)
+    with avro.Writer(output_file, schema) as w:
+        for b0 in range(0, n, 1024):
+            b1 = min(n, b0 + 1024)
+            buf = bytearray()
+            for i in range(b0, b1):
+                buf += avro.enc_long(int(uid[i])) + pack_f(float(score[i]))
+                if label is None:
+                    buf += b"\x00"
+                else:
+                    buf += b"\x02" + pack_f(float(label[i]))
+                if weight is not None:
+                    buf += pack_f(float(weight[i]))
+                buf += pack_f(float(per_coord[i]))
+            w.write_encoded(bytes(buf), b1 - b0)

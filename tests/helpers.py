@@ -68,3 +68,64 @@ def per_entity_rel_err(a, b, coef_ptr):
         den = max(np.max(np.abs(b[s])) if coef_ptr[e + 1] > coef_ptr[e] else 0.0, 1e-300)
         out[e] = (np.max(np.abs(a[s] - b[s])) if coef_ptr[e + 1] > coef_ptr[e] else 0.0) / den
     return out
+
+
+# ---- CPU test double of REDeviceSolver built on the oracle (tests only) ---------------------------------
+class _Arr:
+    """numpy array with the .cpu().numpy() surface of a torch tensor."""
+
+    def __init__(self, a):
+        self.a = a
+
+    def cpu(self):
+        return self
+
+    def numpy(self):
+        return self.a
+
+
+class OraclePacked:
+    def __init__(self, pk, batch, has_intercept):
+        self.pk, self.batch, self.has_intercept = pk, batch, has_intercept
+        self.E, self.N, self.Z, self.D = pk["E"], pk["N"], pk["Z"], pk["D"]
+        self.P = self.D + (self.E if has_intercept else 0)
+
+    def ent_feat_ptr(self):
+        return _Arr(self.pk["ent_feat_ptr"])
+
+    def unique_global(self):
+        return _Arr(self.pk["unique_global"])
+
+    def coef_ptr_host(self):
+        return self.pk["ent_feat_ptr"] + (np.arange(self.E + 1) if self.has_intercept else 0)
+
+
+class _Res:
+    def __init__(self, d):
+        self.d = d
+
+    def to_host(self):
+        return self.d
+
+
+class OracleSolverDouble:
+    """Stands in for gdmix_amd.solver.REDeviceSolver in CPU-only tests of the host logic (model, driver,
+    I/O). It routes pack/solve/score through oracle/ — allowed for tests, never for the product path."""
+
+    def pack(self, batch, has_intercept=True):
+        from oracle import oracle
+        return OraclePacked(oracle.pack(batch.ent_row_ptr, batch.row_nnz_ptr, batch.col_global), batch, has_intercept)
+
+    def solve(self, packed, opts, theta0=None, out=None):
+        from oracle import oracle
+        b = packed.batch
+        o = oracle.make_opts(l2=opts.l2, regularize_bias=opts.regularize_bias, has_intercept=opts.has_intercept, m=opts.m,
+                             max_iter=opts.max_iter, ftol=opts.ftol, variance_mode=int(opts.variance_mode),
+                             threshold=opts.threshold)
+        return _Res(oracle.solve(packed.pk, b.val, b.y, b.offset, b.weight, o, theta0=theta0))
+
+    def score(self, packed, theta, has_model=None):
+        from oracle import oracle
+        b = packed.batch
+        lo, pc = oracle.score(packed.pk, b.val, b.offset, theta, packed.has_intercept, has_model)
+        return _Arr(lo), _Arr(pc)
