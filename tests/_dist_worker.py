@@ -1,0 +1,43 @@
+"""Worker of the world_size-2 gloo test: each rank runs the RandomEffectDriver over a shared partition list
+with the oracle-backed solver double and reports which partitions it trained."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch
+import torch.distributed as dist
+
+from helpers import OracleSolverDouble
+from gdmix_amd.driver import RandomEffectDriver
+from gdmix_amd.model import RandomEffectLRLBFGSModel
+from gdmix_amd.params import Params, SchemaParams
+
+
+def main():
+    base = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    argv = json.load(open(os.path.join(base, "argv.json")))
+    model = RandomEffectLRLBFGSModel(argv)
+    model._solver = OracleSolverDouble()
+    driver = RandomEffectDriver(Params.__from_argv__(argv), model)
+    assert driver.execution_context["task_index"] == rank and driver.execution_context["num_workers"] == world
+    mine = driver._get_partition_list()
+    driver.run_training(SchemaParams.__from_argv__(argv), export_model=True)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    # load totals: the only collective the RE path needs is this kind of tiny metadata exchange
+    t = torch.tensor([len(mine)], dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        json.dump({"per_rank": gathered, "total": int(t.item())}, open(os.path.join(base, "result.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,96 @@
+"""End-to-end on the MI355X: the RE model API and the CLI with the real device solver — TFRecord partitions
+in, photon-ml Avro model and score Avro out — against the reference's golden coefficients."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, load_fixture, well_posed_mask
+from gdmix_amd import gdmix as cli
+from gdmix_amd.io import avro
+from gdmix_amd.io.grouped_reader import write_grouped_partition
+from gdmix_amd.model import RandomEffectLRLBFGSModel
+from gdmix_amd.params import SchemaParams
+
+pytestmark = pytest.mark.gpu
+RES = os.path.join(GOLDEN, "ref_resources")
+SCHEMA = SchemaParams(uid_column_name="uid", weight_column_name="weight", label_column_name="response",
+                      prediction_score_column_name="predictionScore")
+
+
+def test_reference_fixture_through_model_api(tmp_path):
+    d = tmp_path / "train" / "partitionId=0"
+    os.makedirs(d)
+    shutil.copy(os.path.join(RES, "data.tfrecord"), d / "data.tfrecord")
+    argv = ["--uid_column_name", "uid", "--weight_column_name", "weight", "--label_column_name", "response",
+            "--output_model_dir", str(tmp_path / "models"), "--metadata_file", os.path.join(RES, "data.json"),
+            "--feature_bag", "per_member", "--feature_file", os.path.join(RES, "fake_feature_file.csv"),
+            "--partition_entity", "memberId", "--l2_reg_weight", "0.1"]
+    m = RandomEffectLRLBFGSModel(argv)
+    ctx = {"partition_index": 0, "active_training_output_file": str(tmp_path / "ts" / "a.avro")}
+    m.train(str(d), None, m.metadata_file, str(tmp_path / "models"), ctx, SCHEMA)
+    recs = list(avro.read_file(str(tmp_path / "models" / "part-00000.avro")))
+    _, _, exp, _ = load_fixture("ref_fixture_l2_0.1")
+    np.testing.assert_allclose([c["value"] for c in recs[0]["means"]], exp["theta_thr"][:8], rtol=1e-7)
+    np.testing.assert_allclose([c["value"] for c in recs[1]["means"]], exp["theta_thr"][8:], rtol=1e-7)
+    assert np.array_equal(m.last_training_stats["nit"], exp["nit"])
+    scores = list(avro.read_file(str(tmp_path / "ts" / "a.avro")))
+    m2 = RandomEffectLRLBFGSModel(argv)
+    m2.predict(str(tmp_path / "cold"), str(d), m2.metadata_file, str(tmp_path / "models"), {"partition_index": 0}, SCHEMA)
+    assert list(avro.read_file(str(tmp_path / "cold" / "part-00000.avro"))) == scores
+
+
+def test_cli_train_then_inference_on_partitioned_c2_data(tmp_path):
+    """python -m gdmix_amd.gdmix --stage=random_effect: 3 partitions of C2-shaped entities, shipped MovieLens
+    options, coefficients vs the reference fixture; then --action=inference reproduces the training scores."""
+    b, opts, exp, _ = load_fixture("c2_shipped_cfg")
+    md = {"features": [{"name": "bag", "dtype": "float", "shape": [1024], "isSparse": True},
+                       {"name": "offset", "dtype": "float", "shape": [], "isSparse": False},
+                       {"name": "uid", "dtype": "long", "shape": [], "isSparse": False},
+                       {"name": "ent", "dtype": "string", "shape": [], "isSparse": False}],
+          "labels": [{"name": "response", "dtype": "int", "shape": [], "isSparse": False}]}
+    json.dump(md, open(tmp_path / "meta.json", "w"))
+    with open(tmp_path / "features.csv", "w") as f:
+        f.write("".join(f"f{i},\n" for i in range(1024)))
+    parts = [0, 1, 2]
+    per = b.E // 3
+    for k in parts:
+        sub = b.select(np.arange(k * per, (k + 1) * per))
+        write_grouped_partition(str(tmp_path / "train" / "active" / f"partitionId={k}" / "part-0.tfrecord.gz"), sub,
+                                "ent", "bag", weight_column_name=None)
+        write_grouped_partition(str(tmp_path / "valid" / f"partitionId={k}" / "part-0.tfrecord"), sub, "ent", "bag",
+                                weight_column_name=None)
+    open(tmp_path / "plist.txt", "w").write("0,1,2")
+    common = ["gdmix", "--stage=random_effect", "--model_type=logistic_regression", "--uid_column_name=uid",
+              "--label_column_name=response", "--prediction_score_column_name=predictionScore",
+              f"--partition_list_file={tmp_path / 'plist.txt'}", f"--training_data_dir={tmp_path / 'train'}",
+              f"--validation_data_dir={tmp_path / 'valid'}", f"--metadata_file={tmp_path / 'meta.json'}",
+              f"--output_model_dir={tmp_path / 'models'}", "--feature_bag=bag", f"--feature_file={tmp_path / 'features.csv'}",
+              "--partition_entity=ent", "--regularize_bias=False", "--l2_reg_weight=1.0",
+              f"--training_score_dir={tmp_path / 'ts'}", f"--validation_score_dir={tmp_path / 'vs'}"]
+    os.environ.pop("TF_CONFIG", None)
+    cli.run(common + ["--action=train"])
+    wp = well_posed_mask(b, opts)
+    ic_ptr = exp["ent_feat_ptr"] + np.arange(b.E + 1)
+    for k in parts:
+        recs = list(avro.read_file(str(tmp_path / "models" / f"part-{k:05d}.avro")))
+        assert len(recs) == per
+        for r_i, rec in enumerate(recs):
+            e = k * per + r_i
+            assert rec["modelId"] == b.entity_ids[e]
+            if not wp[e]:
+                continue
+            want = exp["theta_thr"][ic_ptr[e]:ic_ptr[e + 1]]
+            keep = np.concatenate([[True], np.abs(want[1:]) > 1e-4])
+            np.testing.assert_allclose([c["value"] for c in rec["means"]], want[keep], rtol=1e-7)
+            assert [c["name"] for c in rec["means"][1:]] == [f"f{g}" for g in exp["unique_global"][exp["ent_feat_ptr"][e]:exp["ent_feat_ptr"][e + 1]][keep[1:]]]
+    train_scores = {k: list(avro.read_file(str(tmp_path / "ts" / f"partitionId={k}" / "part-00000-active.avro"))) for k in parts}
+    valid_scores = {k: list(avro.read_file(str(tmp_path / "vs" / f"partitionId={k}" / "part-00000.avro"))) for k in parts}
+    assert train_scores == valid_scores
+    infer = [a for a in common if not a.startswith("--training_score_dir") and not a.startswith("--validation_score_dir")]
+    cli.run(infer + ["--action=inference", f"--validation_score_dir={tmp_path / 'vs2'}"])
+    for k in parts:
+        again = list(avro.read_file(str(tmp_path / "vs2" / f"partitionId={k}" / f"part-{k:05d}.avro")))
+        assert again == valid_scores[k]
