@@ -159,11 +159,25 @@ static int slots_for(const gdmix_re_packed* b, const gdmix_re_opts* o, size_t* s
   return (int)slots;
 }
 
+static int var_slots_for(const gdmix_re_packed* b) {
+  size_t bytes = var_full_slot_doubles(b->max_p) * 8;
+  size_t slots = ((size_t)2 << 30) / (bytes ? bytes : 1);
+  if (slots > 2048) slots = 2048;
+  if (slots < 4) slots = 4;
+  slots &= ~(size_t)3;
+  return (int)slots;
+}
+
 GDMIX_API size_t gdmix_re_solve_scratch_bytes(const gdmix_re_packed* batch, const gdmix_re_opts* opts) {
   if (!batch || !opts || batch->E == 0) return 0;
   size_t slot_doubles;
   int slots = slots_for(batch, opts, &slot_doubles);
-  return (size_t)slots * slot_doubles * 8;
+  size_t need = (size_t)slots * slot_doubles * 8;
+  if (opts->variance_mode == GDMIX_RE_VAR_FULL && batch->max_p <= VAR_FULL_MAX_P) {
+    size_t v = (size_t)var_slots_for(batch) * var_full_slot_doubles(batch->max_p) * 8;
+    if (v > need) need = v;
+  }
+  return need;
 }
 
 GDMIX_API int gdmix_re_set_wave_lds_limit(gdmix_re_ctx* ctx, int bytes) {
@@ -219,7 +233,14 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     set_error("regularize_bias requires has_intercept");
     return GDMIX_RE_EINVAL;
   }
-  if (opts->variance_mode == GDMIX_RE_VAR_FULL) { set_error("variance_mode FULL is not implemented on the device yet"); return GDMIX_RE_EINVAL; }
+  if (opts->variance_mode == GDMIX_RE_VAR_FULL) {
+    if (!out->theta) { set_error("variance_mode FULL needs out->theta"); return GDMIX_RE_EINVAL; }
+    if (b->max_p > VAR_FULL_MAX_P) {
+      set_error("variance_mode FULL densifies a p x p Hessian per entity; largest entity has p = %d > %lld", b->max_p,
+                (long long)VAR_FULL_MAX_P);
+      return GDMIX_RE_ERANGE;
+    }
+  }
   if (opts->variance_mode != GDMIX_RE_VAR_NONE && !out->variance) { set_error("variance requested but out->variance is NULL"); return GDMIX_RE_EINVAL; }
   if (b->E == 0) return GDMIX_RE_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -300,6 +321,19 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[BLOCK_CLASS], s)); }
     HIP_TRY(launch_solve_block(B, O, P, theta0, begin, hc[BLOCK_CLASS], scratch, slot_doubles, slots, b->max_p, s));
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[BLOCK_CLASS], s)); ctx->impl.ev_used[BLOCK_CLASS] = true; }
+  }
+  if (opts->variance_mode == GDMIX_RE_VAR_FULL) {
+    const size_t vslot = var_full_slot_doubles(b->max_p);
+    int vslots = var_slots_for(b);
+    size_t avail = ctx->impl.scratch ? ctx->impl.scratch_bytes : 0;
+    void* base = ctx->impl.scratch;
+    if (b->scratch_bytes > avail) { avail = b->scratch_bytes; base = b->scratch; }
+    if ((size_t)vslots * vslot * 8 > avail) vslots = (int)(avail / (vslot * 8)) & ~3;
+    if (vslots < 4) {
+      set_error("variance_mode FULL needs >= %zu bytes of scratch (gdmix_re_set_scratch)", 4 * vslot * 8);
+      return GDMIX_RE_ENOMEM;
+    }
+    HIP_TRY(launch_variance_full(B, b->E, P, out->theta, out->variance, static_cast<double*>(base), vslot, vslots, b->max_p, s));
   }
   return GDMIX_RE_OK;
 }

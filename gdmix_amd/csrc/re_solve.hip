@@ -583,6 +583,113 @@ hipError_t launch_solve_block(const BatchDev& B, const OutDev& O, const SolvePar
 }
 
 // ---------------------------------------------------------------------------------------------------
+// FULL variance: diag((X~' D X~ + (l2 + 1e-12) I - l2 e0 e0')^-1)   (binary_logistic_regression.py:181-187)
+// One wavefront per entity, H and L^-1 in a global scratch slot (2 p^2 + p + n doubles). H is SPD, so the
+// inverse comes from a Cholesky factor: diag(H^-1)_j = sum_i (L^-1)_ij^2 (the reference uses LU,
+// np.linalg.inv; both agree to rounding on these well-conditioned matrices).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void re_variance_full_kernel(BatchDev B, int64_t E, SolveParams o,
+                                                               const double* __restrict__ theta,
+                                                               double* __restrict__ variance, double* scratch,
+                                                               size_t slot_doubles, int64_t max_p) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int ic = o.has_intercept ? 1 : 0;
+  double* slot = scratch + (size_t)wave0 * slot_doubles;
+  for (int64_t e = wave0; e < E; e += nwaves) {
+    const int64_t r0 = B.ent_row_ptr[e], z0 = B.ent_nnz_ptr[e], f0 = B.ent_feat_ptr[e];
+    const int n = (int)(B.ent_row_ptr[e + 1] - r0);
+    const int d = (int)(B.ent_feat_ptr[e + 1] - f0);
+    const int p = d + ic;
+    const int64_t c0 = f0 + e * ic;
+    double* H = slot;                         // p x p, row-major; becomes L (lower)
+    double* M = H + (size_t)max_p * max_p;    // p x p, L^-1
+    double* xi = M + (size_t)max_p * max_p;   // p: dense row of X~
+    const int32_t* rp = B.row_ptr + r0 + e;
+    const double* th = theta + c0;
+    for (int a = lane; a < p * p; a += WAVE) H[a] = 0.0;
+    for (int j = lane; j < p; j += WAVE) xi[j] = 0.0;
+    wave_mem_fence();
+    for (int i = 0; i < n; ++i) {
+      const int k0 = rp[i], k1 = rp[i + 1];
+      // logit and D_i (every lane computes the same scalar)
+      double acc = ic ? th[0] : 0.0;
+      for (int k = k0; k < k1; ++k) acc += (double)B.csr_val[z0 + k] * th[ic + B.csr_col[z0 + k]];
+      const double z = acc + (double)B.offset[r0 + i];
+      const double rho = 1.0 / (1.0 + exp(-z));
+      const double di = rho * (1.0 - rho) * (B.weight ? (double)B.weight[r0 + i] : 1.0);
+      // dense row (duplicates summed, as toarray() does)
+      if (lane == 0) {
+        if (ic) xi[0] = 1.0;
+        for (int k = k0; k < k1; ++k) xi[ic + B.csr_col[z0 + k]] += (double)B.csr_val[z0 + k];
+      }
+      wave_mem_fence();
+      // H += di * xi xi' over the non-zero pattern of the row: entries = intercept + first occurrences
+      const int m = (k1 - k0) + ic;
+      for (int t = lane; t < m * m; t += WAVE) {
+        const int ta = t / m, tb = t - ta * m;
+        int ca = (ic && ta == 0) ? 0 : ic + B.csr_col[z0 + k0 + ta - ic];
+        int cb = (ic && tb == 0) ? 0 : ic + B.csr_col[z0 + k0 + tb - ic];
+        bool first = true;   // skip repeated occurrences of a column inside the row
+        for (int k = k0; k < k0 + ta - ic; ++k) first &= (ic + B.csr_col[z0 + k] != ca) || (ic && ta == 0);
+        for (int k = k0; k < k0 + tb - ic; ++k) first &= (ic + B.csr_col[z0 + k] != cb) || (ic && tb == 0);
+        if (first) H[(size_t)ca * p + cb] += xi[ca] * di * xi[cb];
+      }
+      wave_mem_fence();
+      if (lane == 0) {
+        if (ic) xi[0] = 0.0;
+        for (int k = k0; k < k1; ++k) xi[ic + B.csr_col[z0 + k]] = 0.0;
+      }
+      wave_mem_fence();
+    }
+    for (int j = lane; j < p; j += WAVE) {
+      double add = o.l2 + 1.0e-12;
+      if (j == 0 && ic && !o.regularize_bias) add -= o.l2;
+      H[(size_t)j * p + j] += add;
+    }
+    wave_mem_fence();
+    // right-looking Cholesky, lower triangle in place
+    for (int j = 0; j < p; ++j) {
+      const double ljj = sqrt(H[(size_t)j * p + j]);
+      wave_mem_fence();
+      for (int i = j + lane; i < p; i += WAVE) H[(size_t)i * p + j] = (i == j) ? ljj : H[(size_t)i * p + j] / ljj;
+      wave_mem_fence();
+      for (int i = j + 1 + lane; i < p; i += WAVE) {
+        const double lij = H[(size_t)i * p + j];
+        for (int k = j + 1; k <= i; ++k) H[(size_t)i * p + k] -= lij * H[(size_t)k * p + j];
+      }
+      wave_mem_fence();
+    }
+    // M = L^-1 column by column (lane per column), then diag(H^-1)_c = sum_i M[i][c]^2
+    for (int c = lane; c < p; c += WAVE) {
+      double ss = 0.0;
+      for (int i = c; i < p; ++i) {
+        double sum = (i == c) ? 1.0 : 0.0;
+        for (int k = c; k < i; ++k) sum -= H[(size_t)i * p + k] * M[(size_t)k * p + c];
+        const double mic = sum / H[(size_t)i * p + i];
+        M[(size_t)i * p + c] = mic;
+        ss += mic * mic;
+      }
+      variance[c0 + c] = ss;
+    }
+    wave_mem_fence();
+  }
+}
+
+hipError_t launch_variance_full(const BatchDev& B, int64_t E, const SolveParams& o, const double* theta, double* variance,
+                                double* scratch, size_t slot_doubles, int slots, int64_t max_p, hipStream_t s) {
+  if (E <= 0) return hipSuccess;
+  int waves = slots;
+  if ((int64_t)waves > E) waves = (int)E;
+  const int blocks = (waves + 3) / 4;
+  // every wave of the grid owns one slot: grid = blocks * 4 waves <= slots is ensured by the caller
+  hipLaunchKernelGGL(re_variance_full_kernel, dim3(blocks), dim3(256), 0, s, B, E, o, theta, variance, scratch,
+                     slot_doubles, max_p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // scoring: one wavefront per entity, lane per sample  (job_consumers.py:138-152)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void re_score_kernel(BatchDev B, int64_t E, int ic, const double* __restrict__ theta,

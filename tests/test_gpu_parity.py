@@ -54,8 +54,6 @@ def _check_pack(packed, pk, val):
 def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7):
     b, opts, exp, _ = load_fixture(name)
     kw = opts_kwargs(opts)
-    if kw["variance_mode"] == 2:
-        pytest.skip("FULL variance is not on the device yet")
     pk = oracle.pack(b.ent_row_ptr, b.row_nnz_ptr, b.col_global)
     packed = device_solver.pack(b, has_intercept=kw["has_intercept"])
     _check_pack(packed, pk, b.val)
@@ -86,7 +84,7 @@ def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7):
     # (2) against the oracle on the same inputs
     err_o = per_entity_rel_err(res["theta"], ref["theta"], coef_ptr)
     assert err_o[wp].max() <= REL_TOL_DEVICE
-    if kw["variance_mode"] == 1:
+    if kw["variance_mode"] in (1, 2):   # SIMPLE: same sums; FULL: Cholesky here vs LU (np.linalg.inv) there
         np.testing.assert_allclose(res["variance"], exp["variance"], rtol=1e-7)
     # degenerate entities: invariants only
     dg = ~wp
@@ -104,7 +102,7 @@ def test_default_routing_matches_reference_fixture(device_solver, name):
 
 VARIANT_FIXTURES = ["ref_fixture_l2_0.1", "ref_dataset1", "ref_dataset2", "c2_shipped_cfg", "c2_defaults", "c2_l2_1e-3",
                     "c2_large_offsets", "c2_weights", "c2_no_intercept", "c2_maxiter1", "c2_maxiter3_m2", "c2_m3",
-                    "ragged", "ragged_variance_simple", "ml_per_user", "ml_per_movie", "c5_mean_shape", "zipf_tail",
+                    "ragged", "ragged_variance_simple", "ragged_variance_full", "ref_dataset1_variance_full", "ml_per_user", "ml_per_movie", "c5_mean_shape", "zipf_tail",
                     "tiny_entities_regbias", "tiny_entities_shipped_cfg", "warm_stage2"]
 
 
