@@ -32,9 +32,9 @@ void set_error(const char* fmt, ...) {
 struct ClassDesc { int kind; int lds; const char* name; int ncap, zcap; };   // quad: lds = LDS of a whole wave (4 rows)
 static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_QUAD2, 1, "re_solve_grp_kernel<16,2> n<=16 nnz<=64", 16, 64},     {KIND_QUAD2, 1, "re_solve_grp_kernel<16,2> n<=32 nnz<=128", 32, 128},
-    {KIND_QUAD2, 1, "re_solve_grp_kernel<16,2> n<=128 nnz<=512", 128, 512}, {KIND_QUAD2, 1, "re_solve_grp_kernel<16,2> n<=512 nnz<=1536", 512, 1536},
+    {KIND_QUAD2, 1, "re_solve_grp_kernel<16,2> n<=128 nnz<=512", 128, 512}, {KIND_QUAD2, 0, "(unused)", 0, 0},
     {KIND_QUAD4, 1, "re_solve_grp_kernel<16,4> n<=16 nnz<=64", 16, 64},     {KIND_QUAD4, 1, "re_solve_grp_kernel<16,4> n<=32 nnz<=128", 32, 128},
-    {KIND_QUAD4, 1, "re_solve_grp_kernel<16,4> n<=128 nnz<=512", 128, 512}, {KIND_QUAD4, 1, "re_solve_grp_kernel<16,4> n<=512 nnz<=1536", 512, 1536},
+    {KIND_QUAD4, 1, "re_solve_grp_kernel<16,4> n<=128 nnz<=512", 128, 512}, {KIND_QUAD4, 0, "(unused)", 0, 0},
     {KIND_PAIR4, 1, "re_solve_grp_kernel<32,4> n<=32 nnz<=128", 32, 128},  {KIND_PAIR4, 1, "re_solve_grp_kernel<32,4> n<=64 nnz<=256", 64, 256},
     {KIND_PAIR4, 1, "re_solve_grp_kernel<32,4> n<=256 nnz<=1024", 256, 1024},
     {KIND_WREG1, 3072, "re_solve_wreg_kernel<1> lds<=3K"},   {KIND_WREG1, 65536, "re_solve_wreg_kernel<1> lds<=64K"},
@@ -253,9 +253,9 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     tab.ncap[c] = kClasses[c].ncap;
     tab.zcap[c] = kClasses[c].zcap;
     int lds = kClasses[c].lds;
-    if (kClasses[c].kind == KIND_QUAD2) lds = 4 * quad_layout(2 * ROW, kClasses[c].ncap, kClasses[c].zcap).bytes;
-    if (kClasses[c].kind == KIND_QUAD4) lds = 4 * quad_layout(4 * ROW, kClasses[c].ncap, kClasses[c].zcap).bytes;
-    if (kClasses[c].kind == KIND_PAIR4) lds = 2 * quad_layout(128, kClasses[c].ncap, kClasses[c].zcap).bytes;
+    if (lds > 0 && kClasses[c].kind == KIND_QUAD2) lds = 4 * quad_layout(2 * ROW, kClasses[c].ncap, kClasses[c].zcap).bytes;
+    if (lds > 0 && kClasses[c].kind == KIND_QUAD4) lds = 4 * quad_layout(4 * ROW, kClasses[c].ncap, kClasses[c].zcap).bytes;
+    if (lds > 0 && kClasses[c].kind == KIND_PAIR4) lds = 2 * quad_layout(128, kClasses[c].ncap, kClasses[c].zcap).bytes;
     bool on = lds > 0 && lds <= ctx->impl.wave_lds_limit;
     if (kClasses[c].kind <= KIND_WREG4 && !(ctx->impl.kernel_mask & 1)) on = false;
     if ((kClasses[c].kind == KIND_QUAD2 || kClasses[c].kind == KIND_QUAD4 || kClasses[c].kind == KIND_PAIR4) && !(ctx->impl.kernel_mask & 4)) on = false;

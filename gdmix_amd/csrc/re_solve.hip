@@ -295,10 +295,12 @@ hipError_t launch_solve_wreg(int epl, const BatchDev& B, const OutDev& O, const 
 #ifndef GDMIX_QUAD_WAVES_EPL2
 #define GDMIX_QUAD_WAVES_EPL2 2
 #endif
-template <int G, int EPL>
+// NCAP / ZCAP (sample / non-zero capacity of a row's LDS block) are template constants so that every LDS
+// offset is an instruction immediate off one base register (runtime offsets cost ~12 VGPRs of addresses).
+template <int G, int EPL, int NCAP, int ZCAP>
 __global__ __launch_bounds__(WAVE)
 __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL == 4 ? GDMIX_QUAD_WAVES_EPL4 : 1)))) void re_solve_grp_kernel(
-    BatchDev B, OutDev O, SolveParams o, const double* __restrict__ theta0, int begin, int count, int ncap, int zcap) {
+    BatchDev B, OutDev O, SolveParams o, const double* __restrict__ theta0, int begin, int count) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
   constexpr int NG = WAVE / G;   // entities per wavefront
@@ -315,7 +317,7 @@ __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL == 4 
   const int64_t c0 = f0 + e * ic;
 
   QuadLds L;
-  L.q = quad_layout(G * EPL, ncap, zcap);
+  L.q = quad_layout(G * EPL, NCAP, ZCAP);
   L.base = smem + (size_t)row * L.q.bytes;
   L.has_w = B.weight != nullptr;
 
@@ -421,29 +423,32 @@ __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL == 4 
   }
 }
 
-template <int G, int EPL>
+template <int G, int EPL, int NCAP, int ZCAP>
 static hipError_t launch_quad_t(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
-                                int begin, int count, int ncap, int zcap, hipStream_t s) {
+                                int begin, int count, hipStream_t s) {
   constexpr int NG = WAVE / G;
-  const int row_lds_bytes = quad_layout(G * EPL, ncap, zcap).bytes;
+  const int row_lds_bytes = quad_layout(G * EPL, NCAP, ZCAP).bytes;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(re_solve_grp_kernel<G, EPL>),
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(re_solve_grp_kernel<G, EPL, NCAP, ZCAP>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (rc != hipSuccess) return rc;
     attr_set = true;
   }
-  hipLaunchKernelGGL((re_solve_grp_kernel<G, EPL>), dim3((count + NG - 1) / NG), dim3(WAVE), (size_t)row_lds_bytes * NG, s, B, O, o,
-                     theta0, begin, count, ncap, zcap);
+  hipLaunchKernelGGL((re_solve_grp_kernel<G, EPL, NCAP, ZCAP>), dim3((count + NG - 1) / NG), dim3(WAVE),
+                     (size_t)row_lds_bytes * NG, s, B, O, o, theta0, begin, count);
   return hipGetLastError();
 }
 
 hipError_t launch_solve_quad(int g, int epl, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
                              int begin, int count, int ncap, int zcap, hipStream_t s) {
   if (count <= 0) return hipSuccess;
-  if (g == 16 && epl == 2) return launch_quad_t<16, 2>(B, O, o, theta0, begin, count, ncap, zcap, s);
-  if (g == 16 && epl == 4) return launch_quad_t<16, 4>(B, O, o, theta0, begin, count, ncap, zcap, s);
-  if (g == 32 && epl == 4) return launch_quad_t<32, 4>(B, O, o, theta0, begin, count, ncap, zcap, s);
+#define GDMIX_GRP_CASE(GG, EE, NN, ZZ) \
+  if (g == GG && epl == EE && ncap == NN && zcap == ZZ) return launch_quad_t<GG, EE, NN, ZZ>(B, O, o, theta0, begin, count, s);
+  GDMIX_GRP_CASE(16, 2, 16, 64) GDMIX_GRP_CASE(16, 2, 32, 128) GDMIX_GRP_CASE(16, 2, 128, 512)
+  GDMIX_GRP_CASE(16, 4, 16, 64) GDMIX_GRP_CASE(16, 4, 32, 128) GDMIX_GRP_CASE(16, 4, 128, 512)
+  GDMIX_GRP_CASE(32, 4, 32, 128) GDMIX_GRP_CASE(32, 4, 64, 256) GDMIX_GRP_CASE(32, 4, 256, 1024)
+#undef GDMIX_GRP_CASE
   return hipErrorInvalidValue;
 }
 
