@@ -15,7 +15,7 @@ namespace gdmix {
 
 constexpr int PACK_WAVES = 4;          // wavefronts (entities) per workgroup
 #ifndef GDMIX_PACK_LDS_KEYS
-#define GDMIX_PACK_LDS_KEYS 512
+#define GDMIX_PACK_LDS_KEYS 256
 #endif
 constexpr int PACK_LDS_KEYS = GDMIX_PACK_LDS_KEYS;     // per-wave LDS sort capacity; larger entities sort in HBM scratch
 
@@ -28,6 +28,35 @@ __global__ void pack_entnnz_kernel(const int64_t* __restrict__ ent_row_ptr, cons
                                    int64_t E, int64_t* __restrict__ ent_nnz_ptr) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e <= E; e += (int64_t)gridDim.x * blockDim.x)
     ent_nnz_ptr[e] = row_nnz_ptr[ent_row_ptr[e]];
+}
+
+// ---- per-entity pack -----------------------------------------------------------------------------------------
+// Sort key = (global column << 32) | position-in-entity: equal columns stay in row-major order (the order
+// scipy's COO mat-vec accumulates them in) and the sort needs no stability.
+//
+// Small entities (nnz <= PACK_LDS_KEYS) are packed entirely out of LDS in one pass: keys + values staged in
+// LDS, RANK SORT for nnz <= 128 (every lane counts the keys below its own against LDS broadcast reads:
+// 2 VALU per comparison instead of the ~40 per compare-exchange step of a bitonic network), head-flag ballot
+// scan, then all outputs. col_ptr and the per-entity unique list are addressed by the entity's NON-ZERO
+// offset (z0 + e, z0), which is known up front, so nothing here waits for the prefix sum over d_e; the compact
+// unique_global[D] the host reads is produced by a small gather afterwards.
+constexpr int PACK_RANK_MAX = 128;
+
+template <class KeyPtr>
+__device__ __forceinline__ void wave_rank_sort(KeyPtr keys, KeyPtr sorted, int n, int lane) {
+  // n <= 128: lane owns keys lane and lane + 64
+  const unsigned long long k0 = (lane < n) ? keys[lane] : ~0ull;
+  const unsigned long long k1 = (lane + WAVE < n) ? keys[lane + WAVE] : ~0ull;
+  int r0 = 0, r1 = 0;
+  for (int j = 0; j < n; ++j) {
+    const unsigned long long kj = keys[j];   // same address in every lane: LDS broadcast
+    r0 += (kj < k0) ? 1 : 0;
+    r1 += (kj < k1) ? 1 : 0;
+  }
+  wave_lds_fence();
+  if (lane < n) sorted[r0] = k0;             // keys are distinct (position is part of the key)
+  if (lane + WAVE < n) sorted[r1] = k1;
+  wave_lds_fence();
 }
 
 // All comparators ascending, so keys at index >= n act as +inf padding and are simply skipped.
@@ -60,52 +89,66 @@ __device__ __forceinline__ void wave_bitonic_sort(KeyPtr a, int n, int lane) {
   }
 }
 
-// Build (col << 32 | pos) keys in `keys`, sort them, copy them to `dst` when `keys` is a staging
-// buffer, and return the number of distinct columns. `bad` reports a column outside [0, 2^31).
-template <class KeyPtr>
-__device__ __forceinline__ int sort_entity_keys(KeyPtr keys, const int64_t* __restrict__ cols,
-                                                unsigned long long* dst, int nnz, int lane,
-                                                bool copy_out, bool& bad_out) {
-  bool bad = false;
-  for (int k = lane; k < nnz; k += WAVE) {
-    const int64_t c = cols[k];
-    bad |= (c < 0 || c > 0x7fffffffll);
-    keys[k] = ((unsigned long long)(uint32_t)c << 32) | (unsigned)k;
-  }
-  bad_out = __ballot(bad) != 0ull;
-  wave_mem_fence();
-  wave_bitonic_sort(keys, nnz, lane);
-  int d = 0;
+// Outputs of one entity from its sorted keys (any address space) and a value source indexed by position.
+template <class KeyPtr, class ValPtr>
+__device__ __forceinline__ int emit_entity(KeyPtr sk, ValPtr vals, const int32_t* __restrict__ rp, int n, int nnz,
+                                           int lane, int32_t* __restrict__ csr_col, int32_t* __restrict__ col_ptr,
+                                           int32_t* __restrict__ csc_row, float* __restrict__ csc_val,
+                                           int32_t* __restrict__ uniq_sparse) {
+  int carry = 0;
   for (int base = 0; base < nnz; base += WAVE) {
     const int k = base + lane;
     bool head = false;
+    unsigned long long key = 0;
     if (k < nnz) {
-      const unsigned long long key = keys[k];
+      key = sk[k];
       unsigned long long prev = ~key;
-      if (k > 0) prev = keys[k - 1];
+      if (k > 0) prev = sk[k - 1];
       head = (prev >> 32) != (key >> 32);
-      if (copy_out) dst[k] = key;
     }
-    d += __popcll(__ballot(head));
+    const unsigned long long mask = __ballot(head);
+    const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const int lid = carry + __popcll(mask & below) - 1;
+    if (k < nnz) {
+      const int pos = (int)(key & 0xffffffffull);
+      if (head) {
+        uniq_sparse[lid] = (int32_t)(key >> 32);
+        col_ptr[lid] = k;
+      }
+      csr_col[pos] = lid;
+      csc_val[k] = vals[pos];
+      int lo = 0, hi = n - 1;   // sample of non-zero `pos`: last i with rp[i] <= pos
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rp[mid] <= pos) lo = mid; else hi = mid - 1;
+      }
+      csc_row[k] = lo;
+    }
+    carry += __popcll(mask);
   }
-  return d;
+  if (lane == 0) col_ptr[carry] = nnz;
+  return carry;
 }
 
-// Phase 1: entity-relative row pointers, sorted keys (to HBM scratch), distinct-column count, stats.
-__global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_sort_kernel(
+__global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_entity_kernel(
     const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ row_nnz_ptr,
-    const int64_t* __restrict__ ent_nnz_ptr, const int64_t* __restrict__ col_global, int64_t E, int ic,
-    int32_t* __restrict__ row_ptr, unsigned long long* __restrict__ sort_key, int32_t* __restrict__ d_cnt,
+    const int64_t* __restrict__ ent_nnz_ptr, const int64_t* __restrict__ col_global, const float* __restrict__ val,
+    int64_t E, int ic, int32_t* __restrict__ row_ptr, unsigned long long* __restrict__ sort_key,
+    int32_t* __restrict__ csr_col, int32_t* __restrict__ col_ptr, int32_t* __restrict__ csc_row,
+    float* __restrict__ csc_val, int32_t* __restrict__ uniq_sparse, int32_t* __restrict__ d_cnt,
     PackStats* __restrict__ stats) {
-  __shared__ unsigned long long lds_keys[PACK_WAVES][PACK_LDS_KEYS > 0 ? PACK_LDS_KEYS : 1];
+  __shared__ unsigned long long lds_keys[PACK_WAVES][PACK_LDS_KEYS];
+  __shared__ unsigned long long lds_sorted[PACK_WAVES][PACK_RANK_MAX];
+  __shared__ float lds_val[PACK_WAVES][PACK_LDS_KEYS];
+  __shared__ int32_t lds_rp[PACK_WAVES][PACK_LDS_KEYS + 1];
   __shared__ int blk_max[3];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wv = threadIdx.x >> 6;
   if (threadIdx.x < 3) blk_max[threadIdx.x] = 0;
   __syncthreads();
   int mx_p = 0, mx_n = 0, mx_z = 0;
-  // grid-stride over entities: per-entity same-address atomics would serialise in L2 (~10 ns each),
-  // so maxima are carried in registers and published once per workgroup.
+  // grid-stride over entities: per-entity same-address atomics would serialise in L2 (~10 ns each), so maxima
+  // are carried in registers and published once per workgroup.
   for (int64_t e = (int64_t)blockIdx.x * PACK_WAVES + wv; e < E; e += (int64_t)gridDim.x * PACK_WAVES) {
     const int64_t r0 = ent_row_ptr[e], r1 = ent_row_ptr[e + 1];
     const int64_t z0 = ent_nnz_ptr[e], z1 = ent_nnz_ptr[e + 1];
@@ -115,18 +158,50 @@ __global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_sort_kernel(
       continue;
     }
     const int n = (int)n64, nnz = (int)nnz64;
-    for (int i = lane; i <= n; i += WAVE) row_ptr[r0 + e + i] = (int32_t)(row_nnz_ptr[r0 + i] - z0);
-    // Two explicit instantiations so that each path keeps its address space (ds_* vs global_*): a
-    // generic pointer selecting between LDS and HBM compiles to flat_* accesses whose base+offset
-    // folding faults at the LDS aperture edge (keys[k-1] with k = 0).
+    const bool small = nnz <= PACK_LDS_KEYS && n <= PACK_LDS_KEYS;
+    int32_t* const rp_out = row_ptr + r0 + e;
+    for (int i = lane; i <= n; i += WAVE) {
+      const int32_t v = (int32_t)(row_nnz_ptr[r0 + i] - z0);
+      rp_out[i] = v;
+      if (small) lds_rp[wv][i] = v;
+    }
+    bool bad = false;
     int d;
-    bool bad;
-    if (nnz <= PACK_LDS_KEYS) d = sort_entity_keys(lds_keys[wv], col_global + z0, sort_key + z0, nnz, lane, true, bad);
-    else d = sort_entity_keys(sort_key + z0, col_global + z0, sort_key + z0, nnz, lane, false, bad);
-    if (bad && lane == 0) atomicExch(&stats->err, GDMIX_RE_ERANGE);
+    if (small) {
+      // explicit LDS instantiation (ds_* accesses; a generic pointer selecting between LDS and HBM compiles
+      // to flat_* accesses whose base+offset folding faults at the LDS aperture edge)
+      for (int k = lane; k < nnz; k += WAVE) {
+        const int64_t c = col_global[z0 + k];
+        bad |= (c < 0 || c > 0x7fffffffll);
+        lds_keys[wv][k] = ((unsigned long long)(uint32_t)c << 32) | (unsigned)k;
+        lds_val[wv][k] = val[z0 + k];
+      }
+      wave_lds_fence();
+      if (nnz <= PACK_RANK_MAX) {
+        wave_rank_sort(lds_keys[wv], lds_sorted[wv], nnz, lane);
+        d = emit_entity(lds_sorted[wv], lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0, col_ptr + z0 + e,
+                        csc_row + z0, csc_val + z0, uniq_sparse + z0);
+      } else {
+        wave_bitonic_sort(lds_keys[wv], nnz, lane);
+        d = emit_entity(lds_keys[wv], lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0, col_ptr + z0 + e,
+                        csc_row + z0, csc_val + z0, uniq_sparse + z0);
+      }
+    } else {
+      unsigned long long* keys = sort_key + z0;
+      for (int k = lane; k < nnz; k += WAVE) {
+        const int64_t c = col_global[z0 + k];
+        bad |= (c < 0 || c > 0x7fffffffll);
+        keys[k] = ((unsigned long long)(uint32_t)c << 32) | (unsigned)k;
+      }
+      wave_mem_fence();
+      wave_bitonic_sort(keys, nnz, lane);
+      d = emit_entity(keys, val + z0, rp_out, n, nnz, lane, csr_col + z0, col_ptr + z0 + e, csc_row + z0,
+                      csc_val + z0, uniq_sparse + z0);
+    }
+    if (__ballot(bad) && lane == 0) atomicExch(&stats->err, GDMIX_RE_ERANGE);
     if (lane == 0) d_cnt[e] = d;
     mx_p = max(mx_p, d + ic); mx_n = max(mx_n, n); mx_z = max(mx_z, nnz);
-    wave_mem_fence();   // the LDS staging buffer is reused by the next entity of this wave
+    wave_mem_fence();   // the LDS staging buffers are reused by the next entity of this wave
   }
   if (lane == 0) {
     atomicMax(&blk_max[0], mx_p); atomicMax(&blk_max[1], mx_n); atomicMax(&blk_max[2], mx_z);
@@ -136,6 +211,19 @@ __global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_sort_kernel(
     atomicMax(&stats->max_p, blk_max[0]);
     atomicMax(&stats->max_n, blk_max[1]);
     atomicMax(&stats->max_nnz, blk_max[2]);
+  }
+}
+
+// unique_global[ent_feat_ptr[e] + l] = uniq_sparse[ent_nnz_ptr[e] + l]: the compact local -> global map
+__global__ __launch_bounds__(256) void pack_compact_unique_kernel(const int64_t* __restrict__ ent_nnz_ptr,
+                                                                   const int64_t* __restrict__ ent_feat_ptr, int64_t E,
+                                                                   const int32_t* __restrict__ uniq_sparse,
+                                                                   int64_t* __restrict__ unique_global) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  for (int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; e < E; e += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const int64_t z0 = ent_nnz_ptr[e], f0 = ent_feat_ptr[e];
+    const int d = (int)(ent_feat_ptr[e + 1] - f0);
+    for (int l = lane; l < d; l += WAVE) unique_global[f0 + l] = (int64_t)uniq_sparse[z0 + l];
   }
 }
 
@@ -191,60 +279,12 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
   }
 }
 
-// Phase 2: local indices, unique global list, CSC copy.
-__global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_fill_kernel(
-    const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ ent_nnz_ptr,
-    const int64_t* __restrict__ ent_feat_ptr, const float* __restrict__ val, int64_t E,
-    const int32_t* __restrict__ row_ptr, const unsigned long long* __restrict__ sort_key,
-    int32_t* __restrict__ csr_col, int32_t* __restrict__ col_ptr, int32_t* __restrict__ csc_row,
-    float* __restrict__ csc_val, int64_t* __restrict__ unique_global) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  for (int64_t e = (int64_t)blockIdx.x * PACK_WAVES + (threadIdx.x >> 6); e < E; e += (int64_t)gridDim.x * PACK_WAVES) {
-  const int64_t r0 = ent_row_ptr[e], z0 = ent_nnz_ptr[e], f0 = ent_feat_ptr[e];
-  const int n = (int)(ent_row_ptr[e + 1] - r0);
-  const int nnz = (int)(ent_nnz_ptr[e + 1] - z0);
-  const int d = (int)(ent_feat_ptr[e + 1] - f0);
-  const int32_t* rp = row_ptr + r0 + e;
-  int carry = 0;
-  for (int base = 0; base < nnz; base += WAVE) {
-    const int k = base + lane;
-    bool head = false;
-    unsigned long long key = 0;
-    if (k < nnz) {
-      key = sort_key[z0 + k];
-      head = (k == 0) || ((sort_key[z0 + k - 1] >> 32) != (key >> 32));
-    }
-    const unsigned long long mask = __ballot(head);
-    const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-    const int lid = carry + __popcll(mask & below) - 1;
-    if (k < nnz) {
-      const int pos = (int)(key & 0xffffffffull);
-      if (head) {
-        unique_global[f0 + lid] = (int64_t)(key >> 32);
-        col_ptr[f0 + e + lid] = k;
-      }
-      csr_col[z0 + pos] = lid;
-      csc_val[z0 + k] = val[z0 + pos];
-      // sample of non-zero `pos`: last i with rp[i] <= pos
-      int lo = 0, hi = n - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (rp[mid] <= pos) lo = mid; else hi = mid - 1;
-      }
-      csc_row[z0 + k] = lo;
-    }
-    carry += __popcll(mask);
-  }
-  if (lane == 0) col_ptr[f0 + e + d] = nnz;
-  }
-}
-
 // ---- host side ----------------------------------------------------------------------------------------
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct PackLayout {
   size_t ent_nnz_ptr, ent_feat_ptr, row_ptr, csr_col, col_ptr, csc_row, csc_val, unique_global, order, cls_tmp,
-      d_cnt, class_count, block_sums, stats, sort_key, total;
+      d_cnt, class_count, block_sums, stats, sort_key, uniq_sparse, total;
 };
 
 static PackLayout pack_layout(int64_t E, int64_t N, int64_t Z) {
@@ -266,6 +306,7 @@ static PackLayout pack_layout(int64_t E, int64_t N, int64_t Z) {
   L.block_sums = take((size_t)((E + 1) / SCAN_CHUNK + 2) * 8);
   L.stats = take(sizeof(PackStats));
   L.sort_key = take((size_t)(Z + 1) * 8);
+  L.uniq_sparse = take((size_t)(Z + 1) * 4);
   L.total = off;
   return L;
 }
@@ -342,18 +383,23 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
   DBG_STAGE("pack_entnnz_kernel");
   int eblocks = (int)((E + PACK_WAVES - 1) / PACK_WAVES);
   if (eblocks > ctx->num_cus * 16) eblocks = ctx->num_cus * 16;
-  hipLaunchKernelGGL(pack_sort_kernel, dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s, raw->ent_row_ptr,
-                     raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, E, ic, out->row_ptr, sort_key, d_cnt, stats);
-  DBG_STAGE("pack_sort_kernel");
+  int32_t* uniq_sparse = reinterpret_cast<int32_t*>(base + L.uniq_sparse);
+  hipLaunchKernelGGL(pack_entity_kernel, dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s, raw->ent_row_ptr, raw->row_nnz_ptr,
+                     out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key, out->csr_col, out->col_ptr,
+                     out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
+  DBG_STAGE("pack_entity_kernel");
   const int nb = (int)((E + SCAN_CHUNK - 1) / SCAN_CHUNK);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, s, d_cnt, E, block_sums);
   hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1), 0, s, block_sums, nb, stats);
   hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, s, d_cnt, E, block_sums, out->ent_feat_ptr);
   DBG_STAGE("scan kernels");
-  hipLaunchKernelGGL(pack_fill_kernel, dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s, raw->ent_row_ptr,
-                     out->ent_nnz_ptr, out->ent_feat_ptr, raw->val, E, out->row_ptr, sort_key, out->csr_col,
-                     out->col_ptr, out->csc_row, out->csc_val, out->unique_global);
-  DBG_STAGE("pack_fill_kernel");
+  {
+    int grid = (int)((E + 3) / 4);
+    if (grid > ctx->num_cus * 16) grid = ctx->num_cus * 16;
+    hipLaunchKernelGGL(pack_compact_unique_kernel, dim3(grid), dim3(256), 0, s, out->ent_nnz_ptr, out->ent_feat_ptr, E,
+                       uniq_sparse, out->unique_global);
+  }
+  DBG_STAGE("pack_compact_unique_kernel");
   HIP_TRY(hipGetLastError());
   PackStats* hs = reinterpret_cast<PackStats*>(ctx->host_pinned);
   HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(PackStats), hipMemcpyDeviceToHost, s));

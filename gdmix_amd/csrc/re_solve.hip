@@ -178,7 +178,7 @@ __attribute__((amdgpu_waves_per_eu(EPL == 1 ? GDMIX_WREG_WAVES_EPL1 : (EPL == 2 
     if (L.w) L.w[i] = B.weight[r0 + i];
   }
   for (int i = lane; i <= n; i += WAVE) L.row_ptr[i] = B.row_ptr[r0 + e + i];
-  for (int i = lane; i <= d; i += WAVE) L.col_ptr[i] = B.col_ptr[f0 + e + i];
+  for (int i = lane; i <= d; i += WAVE) L.col_ptr[i] = B.col_ptr[z0 + e + i];
 
   WregState<EPL> V;
 #pragma unroll
@@ -332,7 +332,7 @@ __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL == 4 
       if (L.has_w) L.w()[i] = B.weight[r0 + i];
     }
     for (int i = gl; i <= n; i += G) L.row_ptr()[i] = B.row_ptr[r0 + e + i];
-    for (int i = gl; i <= d; i += G) L.col_ptr()[i] = B.col_ptr[f0 + e + i];
+    for (int i = gl; i <= d; i += G) L.col_ptr()[i] = B.col_ptr[z0 + e + i];
   }
   // packed (start | len << 16) extents of the lane's first sample and of its coefficient slots
   unsigned rowc = 0, colc[EPL];
@@ -346,7 +346,7 @@ __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL == 4 
     const int j = gl + G * s;
     colc[s] = 0;
     if (j < p && j >= ic) {
-      const int k0 = B.col_ptr[f0 + e + (j - ic)], k1 = B.col_ptr[f0 + e + (j - ic) + 1];
+      const int k0 = B.col_ptr[z0 + e + (j - ic)], k1 = B.col_ptr[z0 + e + (j - ic) + 1];
       colc[s] = (unsigned)k0 | ((unsigned)(k1 - k0) << 16);
     }
     V.x[s] = (theta0 && j < p) ? theta0[c0 + j] : 0.0;
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(WAVE) void re_solve_wave_kernel(BatchDev B, OutDev 
     if (s_w) s_w[i] = B.weight[r0 + i];
   }
   for (int i = lane; i <= n; i += WAVE) s_row_ptr[i] = B.row_ptr[r0 + e + i];
-  for (int i = lane; i <= d; i += WAVE) s_col_ptr[i] = B.col_ptr[f0 + e + i];
+  for (int i = lane; i <= d; i += WAVE) s_col_ptr[i] = B.col_ptr[z0 + e + i];
   for (int j = lane; j < p; j += WAVE) W.x[j] = theta0 ? theta0[c0 + j] : 0.0;
 
   WaveGroup grp{lane};
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(WAVE* BLOCK_NW) void re_solve_block_kernel(BatchDev
     BlockGroup<BLOCK_NW> grp{(int)threadIdx.x, red, 0};
     for (int j = grp.tid; j < p; j += grp.NT) W.x[j] = theta0 ? theta0[c0 + j] : 0.0;
     grp.sync();
-    EntityView P{n, d, p, ic, B.row_ptr + r0 + e, B.csr_col + z0, B.csr_val + z0, B.col_ptr + f0 + e,
+    EntityView P{n, d, p, ic, B.row_ptr + r0 + e, B.csr_col + z0, B.csr_val + z0, B.col_ptr + z0 + e,
                  B.csc_row + z0, B.csc_val + z0, B.y + r0, B.offset + r0, B.weight ? B.weight + r0 : nullptr};
     SolveStats st;
     lbfgs_solve(grp, P, o, W, st);

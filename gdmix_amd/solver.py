@@ -201,7 +201,7 @@ class PackedBatch:
 
     def col_ptr(self):
         import torch
-        return self._view(self.c.col_ptr, self.D + self.E, torch.int32)
+        return self._view(self.c.col_ptr, self.Z + self.E, torch.int32)   # d_e + 1 entries at ent_nnz_ptr[e] + e
 
     def csc_row(self):
         import torch

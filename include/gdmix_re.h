@@ -91,7 +91,8 @@ typedef struct {
  *   features      [ent_feat_ptr[e], ent_feat_ptr[e+1])           d_e  distinct global indices
  *   coefficients  [ent_feat_ptr[e] + e*has_intercept, +p_e)      p_e = d_e + has_intercept
  *   row_ptr       [ent_row_ptr[e] + e,  + n_e + 1)   entity-relative nnz offsets (CSR)
- *   col_ptr       [ent_feat_ptr[e] + e, + d_e + 1)   entity-relative nnz offsets (CSC)
+ *   col_ptr       [ent_nnz_ptr[e] + e,  + d_e + 1)   entity-relative nnz offsets (CSC); addressed by the
+ *                 entity's non-zero offset (d_e <= z_e) so that packing does not wait for the prefix sum of d_e
  * unique_global is sorted ascending inside an entity (np.unique, job_consumers.py:243); csr_col are
  * local indices 0..d_e-1; the CSC copy is sorted by (local col, sample) so that the transposed
  * product X'r is an ordered, atomic-free per-coefficient sum. */
@@ -103,7 +104,7 @@ typedef struct {
   int32_t*       row_ptr;       /* [N+E] */
   int32_t*       csr_col;       /* [Z]   */
   float*         csr_val;       /* [Z]   */
-  int32_t*       col_ptr;       /* [D+E] (allocated Z+E) */
+  int32_t*       col_ptr;       /* [Z+E] sparse: d_e + 1 entries at ent_nnz_ptr[e] + e */
   int32_t*       csc_row;       /* [Z]   entity-relative sample index */
   float*         csc_val;       /* [Z]   */
   int64_t*       unique_global; /* [D]   (allocated Z) local -> global feature index */
