@@ -61,14 +61,9 @@ __device__ __forceinline__ double eval_fg(G& grp, const EntityView& P, const Sol
     const double z = acc + (double)P.o[i];
     const double yi = (double)P.y[i];
     const double wi = P.w ? (double)P.w[i] : 1.0;
-    const double e = exp(-fabs(z));
-    // max(z,0) - z*y + log(1 + exp(-|z|))          (binary_logistic_regression.py:103)
-    const double ce = fmax(z, 0.0) - z * yi + log(1.0 + e);
-    // expit(z) = 1/(1+exp(-z)); for z<0 use e/(1+e) with e = exp(-|z|) (same value, no overflow)
-    const double sig = (z >= 0.0) ? 1.0 / (1.0 + e) : e / (1.0 + e);
-    const double ri = wi * (sig - yi);
+    double ri;
+    part += logistic_terms(z, yi, wi, ri);
     W.rs[i] = ri;
-    part += wi * ce;
     rpart += ri;
   }
   const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;

@@ -190,17 +190,6 @@ __device__ __forceinline__ double gather_dot(const int2* pairs, int len, const d
   return acc;
 }
 
-// per-sample part of the objective: returns w*ce, writes r = w*(sigma(z) - y)
-__device__ __forceinline__ double sample_terms(double z, double yi, double wi, double& ri) {
-  const double e = exp(-fabs(z));
-  // max(z,0) - z*y + log(1 + exp(-|z|))          (binary_logistic_regression.py:103)
-  const double ce = fmax(z, 0.0) - z * yi + log(1.0 + e);
-  // expit(z) = 1/(1+exp(-z)); for z<0 use e/(1+e) with e = exp(-|z|) (same value, no overflow)
-  const double sig = (z >= 0.0) ? 1.0 / (1.0 + e) : e / (1.0 + e);
-  ri = wi * (sig - yi);
-  return wi * ce;
-}
-
 // f and g at xt. rowc: packed (start | len << 16) of the lane's first sample; colc[s]: same for the
 // lane's coefficient slots (len = 0 for the intercept / unused slots).
 template <int G, int EPL>
@@ -220,7 +209,7 @@ __device__ __forceinline__ double quad_eval(const QuadLds& L, const SolveParams&
   if (gl < n) {
     const double z = gather_dot(L.csr() + (rowc & 0xffffu), (int)(rowc >> 16), xs + ic, x0) + (double)L.o()[gl];
     double ri;
-    part = sample_terms(z, (double)L.y()[gl], L.has_w ? (double)L.w()[gl] : 1.0, ri);
+    part = logistic_terms(z, (double)L.y()[gl], L.has_w ? (double)L.w()[gl] : 1.0, ri);
     rs[gl] = ri;
     rpart = ri;
   }
@@ -228,7 +217,7 @@ __device__ __forceinline__ double quad_eval(const QuadLds& L, const SolveParams&
     const int k0 = L.row_ptr()[i], k1 = L.row_ptr()[i + 1];
     const double z = gather_dot(L.csr() + k0, k1 - k0, xs + ic, x0) + (double)L.o()[i];
     double ri;
-    part += sample_terms(z, (double)L.y()[i], L.has_w ? (double)L.w()[i] : 1.0, ri);
+    part += logistic_terms(z, (double)L.y()[i], L.has_w ? (double)L.w()[i] : 1.0, ri);
     rs[i] = ri;
     rpart += ri;
   }

@@ -105,12 +105,9 @@ __device__ __forceinline__ double wreg_eval(const WregLds& L, const SolveParams&
     const double z = acc + (double)L.o[i];
     const double yi = (double)L.y[i];
     const double wi = L.w ? (double)L.w[i] : 1.0;
-    const double e = exp(-fabs(z));
-    const double ce = fmax(z, 0.0) - z * yi + log(1.0 + e);
-    const double sig = (z >= 0.0) ? 1.0 / (1.0 + e) : e / (1.0 + e);
-    const double ri = wi * (sig - yi);
+    double ri;
+    part += logistic_terms(z, yi, wi, ri);
     L.rs[i] = ri;
-    part += wi * ce;
     rpart += ri;
   }
   const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
