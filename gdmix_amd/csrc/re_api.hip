@@ -32,18 +32,23 @@ void set_error(const char* fmt, ...) {
 struct ClassDesc { int kind; int lds; const char* name; int ncap, zcap; };   // quad: lds = LDS of a whole wave (4 rows)
 static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_QUAD2, 1, "re_solve_grp_kernel<16,2> n<=16 nnz<=64", 16, 64},     {KIND_QUAD2, 1, "re_solve_grp_kernel<16,2> n<=32 nnz<=128", 32, 128},
-    {KIND_QUAD2, 1, "re_solve_grp_kernel<16,2> n<=128 nnz<=512", 128, 512}, {KIND_QUAD2, 0, "(unused)", 0, 0},
+    {KIND_QUAD2, 1, "re_solve_grp_kernel<16,2> n<=128 nnz<=512", 128, 512},
+    {KIND_QUAD3, 1, "re_solve_grp_kernel<16,3> n<=16 nnz<=64", 16, 64},     {KIND_QUAD3, 1, "re_solve_grp_kernel<16,3> n<=32 nnz<=128", 32, 128},
+    {KIND_QUAD3, 1, "re_solve_grp_kernel<16,3> n<=128 nnz<=512", 128, 512},
     {KIND_QUAD4, 1, "re_solve_grp_kernel<16,4> n<=16 nnz<=64", 16, 64},     {KIND_QUAD4, 1, "re_solve_grp_kernel<16,4> n<=32 nnz<=128", 32, 128},
-    {KIND_QUAD4, 1, "re_solve_grp_kernel<16,4> n<=128 nnz<=512", 128, 512}, {KIND_QUAD4, 0, "(unused)", 0, 0},
-    {KIND_PAIR4, 1, "re_solve_grp_kernel<32,4> n<=32 nnz<=128", 32, 128},  {KIND_PAIR4, 1, "re_solve_grp_kernel<32,4> n<=64 nnz<=256", 64, 256},
+    {KIND_QUAD4, 1, "re_solve_grp_kernel<16,4> n<=128 nnz<=512", 128, 512},
+    {KIND_PAIR3, 1, "re_solve_grp_kernel<32,3> n<=32 nnz<=128", 32, 128},   {KIND_PAIR3, 1, "re_solve_grp_kernel<32,3> n<=64 nnz<=256", 64, 256},
+    {KIND_PAIR3, 1, "re_solve_grp_kernel<32,3> n<=256 nnz<=1024", 256, 1024},
+    {KIND_PAIR4, 1, "re_solve_grp_kernel<32,4> n<=32 nnz<=128", 32, 128},   {KIND_PAIR4, 1, "re_solve_grp_kernel<32,4> n<=64 nnz<=256", 64, 256},
     {KIND_PAIR4, 1, "re_solve_grp_kernel<32,4> n<=256 nnz<=1024", 256, 1024},
     {KIND_WREG1, 3072, "re_solve_wreg_kernel<1> lds<=3K"},   {KIND_WREG1, 65536, "re_solve_wreg_kernel<1> lds<=64K"},
     {KIND_WREG2, 3072, "re_solve_wreg_kernel<2> lds<=3K"},   {KIND_WREG2, 6144, "re_solve_wreg_kernel<2> lds<=6K"},
     {KIND_WREG2, 16384, "re_solve_wreg_kernel<2> lds<=16K"}, {KIND_WREG2, 65536, "re_solve_wreg_kernel<2> lds<=64K"},
     {KIND_WREG4, 6144, "re_solve_wreg_kernel<4> lds<=6K"},   {KIND_WREG4, 12288, "re_solve_wreg_kernel<4> lds<=12K"},
     {KIND_WREG4, 24576, "re_solve_wreg_kernel<4> lds<=24K"}, {KIND_WREG4, 65536, "re_solve_wreg_kernel<4> lds<=64K"},
-    {KIND_WLDS, 24576, "re_solve_wave_kernel lds<=24K"},
-    {KIND_WLDS, 65536, "re_solve_wave_kernel lds<=64K"},     {KIND_BLOCK, 0, "re_solve_block_kernel"}};
+    {KIND_WLDS, 24576, "re_solve_wave_kernel lds<=24K"},     {KIND_WLDS, 65536, "re_solve_wave_kernel lds<=64K"},
+    {KIND_WLDS, 0, "(unused)"}, {KIND_WLDS, 0, "(unused)"}, {KIND_WLDS, 0, "(unused)"}, {KIND_WLDS, 0, "(unused)"},
+    {KIND_BLOCK, 0, "re_solve_block_kernel"}};
 
 __global__ void class_base_kernel(int32_t* cc) {
   // cc[0..NC) counts -> cc[NC..2NC) exclusive bases, cc[2NC..3NC) cursors = 0
@@ -253,12 +258,11 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     tab.ncap[c] = kClasses[c].ncap;
     tab.zcap[c] = kClasses[c].zcap;
     int lds = kClasses[c].lds;
-    if (lds > 0 && kClasses[c].kind == KIND_QUAD2) lds = 4 * quad_layout(2 * ROW, kClasses[c].ncap, kClasses[c].zcap).bytes;
-    if (lds > 0 && kClasses[c].kind == KIND_QUAD4) lds = 4 * quad_layout(4 * ROW, kClasses[c].ncap, kClasses[c].zcap).bytes;
-    if (lds > 0 && kClasses[c].kind == KIND_PAIR4) lds = 2 * quad_layout(128, kClasses[c].ncap, kClasses[c].zcap).bytes;
+    const int gl = group_lanes(kClasses[c].kind);
+    if (lds > 0 && gl > 0) lds = (WAVE / gl) * quad_layout(gl * group_epl(kClasses[c].kind), kClasses[c].ncap, kClasses[c].zcap).bytes;
     bool on = lds > 0 && lds <= ctx->impl.wave_lds_limit;
     if (kClasses[c].kind <= KIND_WREG4 && !(ctx->impl.kernel_mask & 1)) on = false;
-    if ((kClasses[c].kind == KIND_QUAD2 || kClasses[c].kind == KIND_QUAD4 || kClasses[c].kind == KIND_PAIR4) && !(ctx->impl.kernel_mask & 4)) on = false;
+    if (gl > 0 && !(ctx->impl.kernel_mask & 4)) on = false;
     if (kClasses[c].kind == KIND_WLDS && !(ctx->impl.kernel_mask & 2)) on = false;
     tab.lds_bytes[c] = on ? lds : 0;
   }
@@ -287,9 +291,10 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     if (hc[c] <= 0) continue;
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[c], s)); }
     switch (kClasses[c].kind) {
-      case KIND_PAIR4: HIP_TRY(launch_solve_quad(32, 4, B, O, P, theta0, begin, hc[c], kClasses[c].ncap, kClasses[c].zcap, s)); break;
-      case KIND_QUAD2: HIP_TRY(launch_solve_quad(16, 2, B, O, P, theta0, begin, hc[c], kClasses[c].ncap, kClasses[c].zcap, s)); break;
-      case KIND_QUAD4: HIP_TRY(launch_solve_quad(16, 4, B, O, P, theta0, begin, hc[c], kClasses[c].ncap, kClasses[c].zcap, s)); break;
+      case KIND_QUAD2: case KIND_QUAD3: case KIND_QUAD4: case KIND_PAIR3: case KIND_PAIR4:
+        HIP_TRY(launch_solve_quad(group_lanes(kClasses[c].kind), group_epl(kClasses[c].kind), B, O, P, theta0, begin, hc[c],
+                                  kClasses[c].ncap, kClasses[c].zcap, s));
+        break;
       case KIND_WREG1: HIP_TRY(launch_solve_wreg(1, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
       case KIND_WREG2: HIP_TRY(launch_solve_wreg(2, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
       case KIND_WREG4: HIP_TRY(launch_solve_wreg(4, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;

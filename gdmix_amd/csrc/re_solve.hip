@@ -33,8 +33,8 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
     for (int k = 0; k < GDMIX_RE_NUM_CLASSES - 1; ++k) {
       if (tab.lds_bytes[k] <= 0) continue;
       const int kind = tab.kind[k];
-      if (kind == KIND_QUAD2 || kind == KIND_QUAD4 || kind == KIND_PAIR4) {
-        const int cap = (kind == KIND_QUAD2) ? 32 : (kind == KIND_QUAD4 ? 64 : 128);
+      if (group_lanes(kind) > 0) {
+        const int cap = group_lanes(kind) * group_epl(kind);
         if (m <= M_REG && p <= cap && n <= tab.ncap[k] && z <= tab.zcap[k]) { c = k; break; }
       } else if (kind <= KIND_WREG4) {
         if (kind >= want && want >= 0 && wreg_bytes <= (size_t)tab.lds_bytes[k]) { c = k; break; }
@@ -299,7 +299,7 @@ hipError_t launch_solve_wreg(int epl, const BatchDev& B, const OutDev& O, const 
 // offset is an instruction immediate off one base register (runtime offsets cost ~12 VGPRs of addresses).
 template <int G, int EPL, int NCAP, int ZCAP>
 __global__ __launch_bounds__(WAVE)
-__attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL == 4 ? GDMIX_QUAD_WAVES_EPL4 : 1)))) void re_solve_grp_kernel(
+__attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL >= 3 ? GDMIX_QUAD_WAVES_EPL4 : 1)))) void re_solve_grp_kernel(
     BatchDev B, OutDev O, SolveParams o, const double* __restrict__ theta0, int begin, int count) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
@@ -446,7 +446,9 @@ hipError_t launch_solve_quad(int g, int epl, const BatchDev& B, const OutDev& O,
 #define GDMIX_GRP_CASE(GG, EE, NN, ZZ) \
   if (g == GG && epl == EE && ncap == NN && zcap == ZZ) return launch_quad_t<GG, EE, NN, ZZ>(B, O, o, theta0, begin, count, s);
   GDMIX_GRP_CASE(16, 2, 16, 64) GDMIX_GRP_CASE(16, 2, 32, 128) GDMIX_GRP_CASE(16, 2, 128, 512)
+  GDMIX_GRP_CASE(16, 3, 16, 64) GDMIX_GRP_CASE(16, 3, 32, 128) GDMIX_GRP_CASE(16, 3, 128, 512)
   GDMIX_GRP_CASE(16, 4, 16, 64) GDMIX_GRP_CASE(16, 4, 32, 128) GDMIX_GRP_CASE(16, 4, 128, 512)
+  GDMIX_GRP_CASE(32, 3, 32, 128) GDMIX_GRP_CASE(32, 3, 64, 256) GDMIX_GRP_CASE(32, 3, 256, 1024)
   GDMIX_GRP_CASE(32, 4, 32, 128) GDMIX_GRP_CASE(32, 4, 64, 256) GDMIX_GRP_CASE(32, 4, 256, 1024)
 #undef GDMIX_GRP_CASE
   return hipErrorInvalidValue;
