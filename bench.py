@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="entities per pass of the CPU baseline (0 = 200k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solve-only", action="store_true", help="time gdmix_re_solve alone (batch packed once)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5mean", "zipf", "ml_user", "ml_movie"],
+                    help="c2 (default, the benchmarked configuration) or an exploration shape")
     return ap.parse_args()
 
 
@@ -96,8 +98,15 @@ def main():
     opts_kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
     opts = SolverOptions(**opts_kw)
     t_gen = time.perf_counter()
-    batch = synthetic.make_batch(a.entities, a.mean_n, a.k, a.dim, seed=synthetic.C2_SEED + rank,
-                                 entity_id_base=rank * a.entities, with_uid=False)
+    if a.workload == "c2":
+        batch = synthetic.make_batch(a.entities, a.mean_n, a.k, a.dim, seed=synthetic.C2_SEED + rank,
+                                     entity_id_base=rank * a.entities, with_uid=False)
+    elif a.workload == "c5mean":
+        batch = synthetic.make_batch(a.entities, 32, 8, 65536, seed=synthetic.C5_SEED + rank, with_uid=False)
+    elif a.workload == "zipf":
+        batch = synthetic.make_batch(a.entities, 32, 8, 65536, seed=synthetic.C5_SEED + rank, size_dist="zipf", with_uid=False)
+    else:
+        batch = synthetic.make_movielens_like(a.entities, "per_user" if a.workload == "ml_user" else "per_movie", seed=100 + rank)
     t_gen = time.perf_counter() - t_gen
     solver = REDeviceSolver(local_rank)
     raw_dev = solver.upload(batch)
@@ -192,8 +201,9 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"C2: synthetic {a.entities} entities/GPU x avg {a.mean_n * a.k} nnz "
-                                   f"(n~Poisson({a.mean_n}), k={a.k}, D={a.dim}), per-entity L2 LR, L-BFGS m=10",
+            "config": {"workload": (f"C2: synthetic {a.entities} entities/GPU x avg {a.mean_n * a.k} nnz "
+                                    f"(n~Poisson({a.mean_n}), k={a.k}, D={a.dim}), per-entity L2 LR, L-BFGS m=10")
+                       if a.workload == "c2" else f"exploration shape {a.workload}, {a.entities} entities/GPU",
                        "entities_per_gpu": a.entities, "step": "solve" if a.solve_only else "pack+solve",
                        "l2": 1.0, "regularize_bias": False, "max_iter": 100, "parallelism": f"entity-shard x{world}"},
             "roofline": roofline, "cpu_baseline": cpu,

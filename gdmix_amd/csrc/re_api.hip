@@ -46,8 +46,10 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_WREG2, 16384, "re_solve_wreg_kernel<2> lds<=16K"}, {KIND_WREG2, 65536, "re_solve_wreg_kernel<2> lds<=64K"},
     {KIND_WREG4, 6144, "re_solve_wreg_kernel<4> lds<=6K"},   {KIND_WREG4, 12288, "re_solve_wreg_kernel<4> lds<=12K"},
     {KIND_WREG4, 24576, "re_solve_wreg_kernel<4> lds<=24K"}, {KIND_WREG4, 65536, "re_solve_wreg_kernel<4> lds<=64K"},
+    {KIND_WREG8, 12288, "re_solve_wreg_kernel<8> lds<=12K"}, {KIND_WREG8, 24576, "re_solve_wreg_kernel<8> lds<=24K"},
+    {KIND_WREG8, 65536, "re_solve_wreg_kernel<8> lds<=64K"},
     {KIND_WLDS, 24576, "re_solve_wave_kernel lds<=24K"},     {KIND_WLDS, 65536, "re_solve_wave_kernel lds<=64K"},
-    {KIND_WLDS, 0, "(unused)"}, {KIND_WLDS, 0, "(unused)"}, {KIND_WLDS, 0, "(unused)"}, {KIND_WLDS, 0, "(unused)"},
+    {KIND_WLDS, 0, "(unused)"},
     {KIND_BLOCK, 0, "re_solve_block_kernel"}};
 
 __global__ void class_base_kernel(int32_t* cc) {
@@ -261,7 +263,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     const int gl = group_lanes(kClasses[c].kind);
     if (lds > 0 && gl > 0) lds = (WAVE / gl) * quad_layout(gl * group_epl(kClasses[c].kind), kClasses[c].ncap, kClasses[c].zcap).bytes;
     bool on = lds > 0 && lds <= ctx->impl.wave_lds_limit;
-    if (kClasses[c].kind <= KIND_WREG4 && !(ctx->impl.kernel_mask & 1)) on = false;
+    if ((kClasses[c].kind <= KIND_WREG4 || kClasses[c].kind == KIND_WREG8) && !(ctx->impl.kernel_mask & 1)) on = false;
     if (gl > 0 && !(ctx->impl.kernel_mask & 4)) on = false;
     if (kClasses[c].kind == KIND_WLDS && !(ctx->impl.kernel_mask & 2)) on = false;
     tab.lds_bytes[c] = on ? lds : 0;
@@ -298,6 +300,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
       case KIND_WREG1: HIP_TRY(launch_solve_wreg(1, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
       case KIND_WREG2: HIP_TRY(launch_solve_wreg(2, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
       case KIND_WREG4: HIP_TRY(launch_solve_wreg(4, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
+      case KIND_WREG8: HIP_TRY(launch_solve_wreg(8, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
       default: HIP_TRY(launch_solve_wave(B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
     }
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[c], s)); ctx->impl.ev_used[c] = true; }

@@ -18,7 +18,7 @@ namespace gdmix {
 //   KIND_WLDS       LDS-resident wavefront kernel (any p whose state fits 64 KiB of LDS, any m)
 //   KIND_BLOCK      workgroup-per-entity kernel working out of a global scratch slot (anything)
 // Each wavefront kind is split into LDS-footprint buckets so that small entities keep high occupancy.
-enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4, KIND_QUAD2 = 5, KIND_QUAD4 = 6, KIND_PAIR4 = 7, KIND_QUAD3 = 8, KIND_PAIR3 = 9 };
+enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4, KIND_QUAD2 = 5, KIND_QUAD4 = 6, KIND_PAIR4 = 7, KIND_QUAD3 = 8, KIND_PAIR3 = 9, KIND_WREG8 = 10 };
 
 // group kernels (several entities per wavefront): lanes per entity, coefficient slots per lane; 0 if not a group kind
 __host__ __device__ inline int group_lanes(int kind) { return (kind == KIND_QUAD2 || kind == KIND_QUAD3 || kind == KIND_QUAD4) ? 16 : ((kind == KIND_PAIR3 || kind == KIND_PAIR4) ? 32 : 0); }

@@ -22,6 +22,7 @@ constexpr int PACK_LDS_KEYS = GDMIX_PACK_LDS_KEYS;     // per-wave LDS sort capa
 struct PackStats {      // device-side, read back once per pack
   unsigned long long D;
   int max_p, max_n, max_nnz, err;
+  int n_big, pad;         // entities deferred to the workgroup-per-entity pack kernel
 };
 
 __global__ void pack_entnnz_kernel(const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ row_nnz_ptr,
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_entity_kernel(
     int64_t E, int ic, int32_t* __restrict__ row_ptr, unsigned long long* __restrict__ sort_key,
     int32_t* __restrict__ csr_col, int32_t* __restrict__ col_ptr, int32_t* __restrict__ csc_row,
     float* __restrict__ csc_val, int32_t* __restrict__ uniq_sparse, int32_t* __restrict__ d_cnt,
-    PackStats* __restrict__ stats) {
+    int32_t* __restrict__ big_list, PackStats* __restrict__ stats) {
   __shared__ unsigned long long lds_keys[PACK_WAVES][PACK_LDS_KEYS];
   __shared__ unsigned long long lds_sorted[PACK_WAVES][PACK_RANK_MAX];
   __shared__ float lds_val[PACK_WAVES][PACK_LDS_KEYS];
@@ -187,16 +188,10 @@ __global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_entity_kernel(
                         csc_row + z0, csc_val + z0, uniq_sparse + z0);
       }
     } else {
-      unsigned long long* keys = sort_key + z0;
-      for (int k = lane; k < nnz; k += WAVE) {
-        const int64_t c = col_global[z0 + k];
-        bad |= (c < 0 || c > 0x7fffffffll);
-        keys[k] = ((unsigned long long)(uint32_t)c << 32) | (unsigned)k;
-      }
-      wave_mem_fence();
-      wave_bitonic_sort(keys, nnz, lane);
-      d = emit_entity(keys, val + z0, rp_out, n, nnz, lane, csr_col + z0, col_ptr + z0 + e, csc_row + z0,
-                      csc_val + z0, uniq_sparse + z0);
+      // too large for a wavefront's LDS staging: handled by pack_big_kernel (one workgroup per entity)
+      if (lane == 0) big_list[atomicAdd(&stats->n_big, 1)] = (int32_t)e;
+      mx_n = max(mx_n, n); mx_z = max(mx_z, nnz);
+      continue;
     }
     if (__ballot(bad) && lane == 0) atomicExch(&stats->err, GDMIX_RE_ERANGE);
     if (lane == 0) d_cnt[e] = d;
@@ -211,6 +206,106 @@ __global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_entity_kernel(
     atomicMax(&stats->max_p, blk_max[0]);
     atomicMax(&stats->max_n, blk_max[1]);
     atomicMax(&stats->max_nnz, blk_max[2]);
+  }
+}
+
+// ---- large entities: one 1024-thread workgroup per entity, keys sorted in place in HBM scratch ----------------
+constexpr int BIG_THREADS = 1024;
+
+__global__ __launch_bounds__(BIG_THREADS) void pack_big_kernel(
+    const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ ent_nnz_ptr,
+    const int64_t* __restrict__ col_global, const float* __restrict__ val, int ic, const int32_t* __restrict__ row_ptr,
+    unsigned long long* __restrict__ sort_key, int32_t* __restrict__ csr_col, int32_t* __restrict__ col_ptr,
+    int32_t* __restrict__ csc_row, float* __restrict__ csc_val, int32_t* __restrict__ uniq_sparse,
+    int32_t* __restrict__ d_cnt, const int32_t* __restrict__ big_list, PackStats* __restrict__ stats) {
+  __shared__ int wave_heads[BIG_THREADS / WAVE];
+  __shared__ int carry_s;
+  __shared__ int bad_s;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+  const int n_big = stats->n_big;
+  for (int b = blockIdx.x; b < n_big; b += gridDim.x) {
+    const int64_t e = big_list[b];
+    const int64_t r0 = ent_row_ptr[e], z0 = ent_nnz_ptr[e];
+    const int n = (int)(ent_row_ptr[e + 1] - r0);
+    const int nnz = (int)(ent_nnz_ptr[e + 1] - z0);
+    unsigned long long* keys = sort_key + z0;
+    const int32_t* rp = row_ptr + r0 + e;
+    if (tid == 0) { carry_s = 0; bad_s = 0; }
+    __syncthreads();
+    bool bad = false;
+    for (int k = tid; k < nnz; k += BIG_THREADS) {
+      const int64_t c = col_global[z0 + k];
+      bad |= (c < 0 || c > 0x7fffffffll);
+      keys[k] = ((unsigned long long)(uint32_t)c << 32) | (unsigned)k;
+    }
+    if (bad) bad_s = 1;
+    __syncthreads();
+    // bitonic network, all comparators ascending (indices >= nnz act as +inf)
+    int np2 = 1;
+    while (np2 < nnz) np2 <<= 1;
+    const int half = np2 >> 1;
+    for (int k = 2; k <= np2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < half; t += BIG_THREADS) {
+          int i, partner;
+          const int blk = t / j, off = t - blk * j;
+          if (j == (k >> 1)) { i = blk * k + off; partner = blk * k + (k - 1 - off); }
+          else { i = blk * 2 * j + off; partner = i + j; }
+          if (partner < nnz) {
+            const unsigned long long x = keys[i], y = keys[partner];
+            if (x > y) { keys[i] = y; keys[partner] = x; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // outputs; local index = number of column heads at or before the key
+    int32_t* const cp = col_ptr + z0 + e;
+    for (int base = 0; base < nnz; base += BIG_THREADS) {
+      const int k = base + tid;
+      bool head = false;
+      unsigned long long key = 0;
+      if (k < nnz) {
+        key = keys[k];
+        unsigned long long prev = ~key;
+        if (k > 0) prev = keys[k - 1];
+        head = (prev >> 32) != (key >> 32);
+      }
+      const unsigned long long mask = __ballot(head);
+      if (lane == 0) wave_heads[wv] = __popcll(mask);
+      __syncthreads();
+      int before = carry_s;
+      for (int w = 0; w < wv; ++w) before += wave_heads[w];
+      const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+      const int lid = before + __popcll(mask & below) - 1;
+      if (k < nnz) {
+        const int pos = (int)(key & 0xffffffffull);
+        if (head) { uniq_sparse[z0 + lid] = (int32_t)(key >> 32); cp[lid] = k; }
+        csr_col[z0 + pos] = lid;
+        csc_val[z0 + k] = val[z0 + pos];
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (rp[mid] <= pos) lo = mid; else hi = mid - 1;
+        }
+        csc_row[z0 + k] = lo;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < BIG_THREADS / WAVE; ++w) tot += wave_heads[w];
+        carry_s += tot;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const int d = carry_s;
+      cp[d] = nnz;
+      d_cnt[e] = d;
+      atomicMax(&stats->max_p, d + ic);
+      if (bad_s) atomicExch(&stats->err, GDMIX_RE_ERANGE);
+    }
+    __syncthreads();
   }
 }
 
@@ -284,7 +379,7 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct PackLayout {
   size_t ent_nnz_ptr, ent_feat_ptr, row_ptr, csr_col, col_ptr, csc_row, csc_val, unique_global, order, cls_tmp,
-      d_cnt, class_count, block_sums, stats, sort_key, uniq_sparse, total;
+      d_cnt, class_count, block_sums, stats, sort_key, uniq_sparse, big_list, total;
 };
 
 static PackLayout pack_layout(int64_t E, int64_t N, int64_t Z) {
@@ -307,6 +402,7 @@ static PackLayout pack_layout(int64_t E, int64_t N, int64_t Z) {
   L.stats = take(sizeof(PackStats));
   L.sort_key = take((size_t)(Z + 1) * 8);
   L.uniq_sparse = take((size_t)(Z + 1) * 4);
+  L.big_list = take((size_t)(E + 1) * 4);
   L.total = off;
   return L;
 }
@@ -384,10 +480,17 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
   int eblocks = (int)((E + PACK_WAVES - 1) / PACK_WAVES);
   if (eblocks > ctx->num_cus * 16) eblocks = ctx->num_cus * 16;
   int32_t* uniq_sparse = reinterpret_cast<int32_t*>(base + L.uniq_sparse);
+  int32_t* big_list = reinterpret_cast<int32_t*>(base + L.big_list);
   hipLaunchKernelGGL(pack_entity_kernel, dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s, raw->ent_row_ptr, raw->row_nnz_ptr,
                      out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key, out->csr_col, out->col_ptr,
-                     out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
+                     out->csc_row, out->csc_val, uniq_sparse, d_cnt, big_list, stats);
   DBG_STAGE("pack_entity_kernel");
+  // entities too large for the wavefront kernel (stats->n_big of them, usually none): the grid is fixed, idle
+  // workgroups exit at once
+  hipLaunchKernelGGL(pack_big_kernel, dim3(ctx->num_cus), dim3(BIG_THREADS), 0, s, raw->ent_row_ptr, out->ent_nnz_ptr,
+                     raw->col_global, raw->val, ic, out->row_ptr, sort_key, out->csr_col, out->col_ptr, out->csc_row,
+                     out->csc_val, uniq_sparse, d_cnt, big_list, stats);
+  DBG_STAGE("pack_big_kernel");
   const int nb = (int)((E + SCAN_CHUNK - 1) / SCAN_CHUNK);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, s, d_cnt, E, block_sums);
   hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1), 0, s, block_sums, nb, stats);

@@ -27,7 +27,8 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
     const int p = d + ic;
     int c = BLOCK_CLASS;
     // cheapest first: register kernel with the fewest coefficient slots that hold p, smallest LDS bucket
-    const int want = (m <= M_REG) ? (p <= WAVE ? KIND_WREG1 : (p <= 2 * WAVE ? KIND_WREG2 : (p <= 4 * WAVE ? KIND_WREG4 : -1))) : -1;
+    // register wave kernels: fewest coefficient slots per lane that hold p (1, 2, 4 or 8)
+    const int want_epl = (m <= M_REG) ? (p <= WAVE ? 1 : (p <= 2 * WAVE ? 2 : (p <= 4 * WAVE ? 4 : (p <= 8 * WAVE ? 8 : 0)))) : 0;
     const size_t wreg_bytes = wreg_lds_bytes(p, n, z, d, has_w);
     const size_t wlds_bytes = wave_lds_bytes(p, n, z, d, m, has_w);
     for (int k = 0; k < GDMIX_RE_NUM_CLASSES - 1; ++k) {
@@ -36,8 +37,9 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
       if (group_lanes(kind) > 0) {
         const int cap = group_lanes(kind) * group_epl(kind);
         if (m <= M_REG && p <= cap && n <= tab.ncap[k] && z <= tab.zcap[k]) { c = k; break; }
-      } else if (kind <= KIND_WREG4) {
-        if (kind >= want && want >= 0 && wreg_bytes <= (size_t)tab.lds_bytes[k]) { c = k; break; }
+      } else if (kind <= KIND_WREG4 || kind == KIND_WREG8) {
+        const int epl = (kind == KIND_WREG1) ? 1 : (kind == KIND_WREG2 ? 2 : (kind == KIND_WREG4 ? 4 : 8));
+        if (want_epl > 0 && epl >= want_epl && wreg_bytes <= (size_t)tab.lds_bytes[k]) { c = k; break; }
       } else if (kind == KIND_WLDS) {
         if (wlds_bytes <= (size_t)tab.lds_bytes[k]) { c = k; break; }
       }
@@ -281,6 +283,7 @@ hipError_t launch_solve_wreg(int epl, const BatchDev& B, const OutDev& O, const 
     case 1: return launch_wreg_t<1>(B, O, o, theta0, begin, count, lds_bytes, s);
     case 2: return launch_wreg_t<2>(B, O, o, theta0, begin, count, lds_bytes, s);
     case 4: return launch_wreg_t<4>(B, O, o, theta0, begin, count, lds_bytes, s);
+    case 8: return launch_wreg_t<8>(B, O, o, theta0, begin, count, lds_bytes, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -159,6 +159,29 @@ def test_c2_shape_against_oracle_at_scale(device_solver):
     assert np.isin(res["status"], (0, 1, 2)).all()
 
 
+def test_large_and_giant_entities_pack_and_solve(device_solver):
+    """Entities beyond the wavefront pack/solve paths: a Zipf tail with one ~50k-nnz entity (workgroup pack
+    kernel, workgroup-per-entity solve out of global scratch), pack bit-exact vs the oracle, theta vs oracle."""
+    rng = np.random.default_rng(3)
+    from gdmix_amd.batch import concat
+    small = synthetic.make_batch(300, 24, 8, 4096, seed=21, size_dist="zipf")
+    giant = synthetic.make_batch(2, 6000, 8, 4096, seed=22, size_dist="const")
+    mid = synthetic.make_batch(6, 300, 8, 4096, seed=23, size_dist="const")
+    b = concat([small, giant, mid])
+    kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
+    pk = oracle.pack(b.ent_row_ptr, b.row_nnz_ptr, b.col_global)
+    packed = device_solver.pack(b)
+    _check_pack(packed, pk, b.val)
+    assert packed.max_nnz == int(b.ent_nnz().max()) and packed.max_n == int(b.ent_n().max())
+    res = device_solver.solve(packed, SolverOptions(**kw)).to_host()
+    ref = oracle.solve(pk, b.val, b.y, b.offset, None, oracle.make_opts(**kw))
+    coef_ptr = packed.coef_ptr_host()
+    wp = well_posed_mask(b, dict(l2=1.0, regularize_bias=False, has_intercept=True))
+    err = per_entity_rel_err(res["theta"], ref["theta"], coef_ptr)
+    assert err[wp].max() <= REL_TOL_DEVICE, err[wp].max()
+    assert np.array_equal(res["nit"][wp], ref["nit"][wp])
+
+
 def test_score_matches_reference_inference(device_solver):
     import os
     from helpers import GOLDEN
