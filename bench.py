@@ -125,7 +125,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    kernel_ms = np.zeros(32)
+    kernel_ms = np.zeros(40)
     ev_pack = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     pack_ms = solve_ms = 0.0
     t0 = time.perf_counter()

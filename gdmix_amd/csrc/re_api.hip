@@ -41,6 +41,11 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_PAIR3, 1, "re_solve_grp_kernel<32,3> n<=256 nnz<=1024", 256, 1024},
     {KIND_PAIR4, 1, "re_solve_grp_kernel<32,4> n<=32 nnz<=128", 32, 128},   {KIND_PAIR4, 1, "re_solve_grp_kernel<32,4> n<=64 nnz<=256", 64, 256},
     {KIND_PAIR4, 1, "re_solve_grp_kernel<32,4> n<=256 nnz<=1024", 256, 1024},
+    {KIND_G64_3, 1, "re_solve_grp_kernel<64,3> n<=64 nnz<=512", 64, 512},    {KIND_G64_3, 1, "re_solve_grp_kernel<64,3> n<=512 nnz<=2048", 512, 2048},
+    {KIND_G64_4, 1, "re_solve_grp_kernel<64,4> n<=64 nnz<=512", 64, 512},    {KIND_G64_4, 1, "re_solve_grp_kernel<64,4> n<=512 nnz<=2048", 512, 2048},
+    {KIND_G128_4, 1, "re_solve_grp_kernel<128,4> n<=128 nnz<=1024", 128, 1024}, {KIND_G128_4, 1, "re_solve_grp_kernel<128,4> n<=1024 nnz<=3072", 1024, 3072},
+    {KIND_G256_4, 1, "re_solve_grp_kernel<256,4> n<=256 nnz<=2048", 256, 2048}, {KIND_G256_4, 1, "re_solve_grp_kernel<256,4> n<=2048 nnz<=4096", 2048, 4096},
+    {KIND_G512_4, 1, "re_solve_grp_kernel<512,4> n<=512 nnz<=4096", 512, 4096},
     {KIND_WREG1, 3072, "re_solve_wreg_kernel<1> lds<=3K"},   {KIND_WREG1, 65536, "re_solve_wreg_kernel<1> lds<=64K"},
     {KIND_WREG2, 3072, "re_solve_wreg_kernel<2> lds<=3K"},   {KIND_WREG2, 6144, "re_solve_wreg_kernel<2> lds<=6K"},
     {KIND_WREG2, 16384, "re_solve_wreg_kernel<2> lds<=16K"}, {KIND_WREG2, 65536, "re_solve_wreg_kernel<2> lds<=64K"},
@@ -49,7 +54,6 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_WREG8, 12288, "re_solve_wreg_kernel<8> lds<=12K"}, {KIND_WREG8, 24576, "re_solve_wreg_kernel<8> lds<=24K"},
     {KIND_WREG8, 65536, "re_solve_wreg_kernel<8> lds<=64K"},
     {KIND_WLDS, 24576, "re_solve_wave_kernel lds<=24K"},     {KIND_WLDS, 65536, "re_solve_wave_kernel lds<=64K"},
-    {KIND_WLDS, 0, "(unused)"},
     {KIND_BLOCK, 0, "re_solve_block_kernel"}};
 
 __global__ void class_base_kernel(int32_t* cc) {
@@ -261,8 +265,9 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     tab.zcap[c] = kClasses[c].zcap;
     int lds = kClasses[c].lds;
     const int gl = group_lanes(kClasses[c].kind);
-    if (lds > 0 && gl > 0) lds = (WAVE / gl) * quad_layout(gl * group_epl(kClasses[c].kind), kClasses[c].ncap, kClasses[c].zcap).bytes;
-    bool on = lds > 0 && lds <= ctx->impl.wave_lds_limit;
+    if (lds > 0 && gl > 0)
+      lds = (gl >= WAVE ? 1 : WAVE / gl) * quad_layout(gl * group_epl(kClasses[c].kind), kClasses[c].ncap, kClasses[c].zcap, gl > WAVE ? gl / WAVE : 1).bytes;
+    bool on = lds > 0 && (lds <= ctx->impl.wave_lds_limit || (gl > WAVE && ctx->impl.wave_lds_limit >= 65536 && lds <= 160 * 1024));
     if ((kClasses[c].kind <= KIND_WREG4 || kClasses[c].kind == KIND_WREG8) && !(ctx->impl.kernel_mask & 1)) on = false;
     if (gl > 0 && !(ctx->impl.kernel_mask & 4)) on = false;
     if (kClasses[c].kind == KIND_WLDS && !(ctx->impl.kernel_mask & 2)) on = false;
@@ -294,6 +299,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[c], s)); }
     switch (kClasses[c].kind) {
       case KIND_QUAD2: case KIND_QUAD3: case KIND_QUAD4: case KIND_PAIR3: case KIND_PAIR4:
+      case KIND_G64_3: case KIND_G64_4: case KIND_G128_4: case KIND_G256_4: case KIND_G512_4:
         HIP_TRY(launch_solve_quad(group_lanes(kClasses[c].kind), group_epl(kClasses[c].kind), B, O, P, theta0, begin, hc[c],
                                   kClasses[c].ncap, kClasses[c].zcap, s));
         break;

@@ -13,16 +13,24 @@ namespace gdmix {
 
 // Size classes: every entity is routed to the cheapest kernel variant that can hold it.
 //   KIND_QUAD2/4    four entities per wavefront (one per 16-lane DPP row), p <= 32/64, state in registers
-//   KIND_PAIR4      two entities per wavefront (one per pair of DPP rows), p <= 128
+//   KIND_PAIR3/4    two entities per wavefront (one per pair of DPP rows), p <= 96/128
+//   KIND_G64_3/4    one entity per wavefront, same register/LDS design, p <= 192/256
+//   KIND_G128..512  one entity per workgroup of 2/4/8 wavefronts (cross-wave reduction stage), p <= 512/1024/2048
 //   KIND_WREG1/2/4  register-resident wavefront kernel with 1/2/4 coefficients per lane (p <= 64/128/256)
 //   KIND_WLDS       LDS-resident wavefront kernel (any p whose state fits 64 KiB of LDS, any m)
 //   KIND_BLOCK      workgroup-per-entity kernel working out of a global scratch slot (anything)
 // Each wavefront kind is split into LDS-footprint buckets so that small entities keep high occupancy.
-enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4, KIND_QUAD2 = 5, KIND_QUAD4 = 6, KIND_PAIR4 = 7, KIND_QUAD3 = 8, KIND_PAIR3 = 9, KIND_WREG8 = 10 };
+enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4, KIND_QUAD2 = 5, KIND_QUAD4 = 6, KIND_PAIR4 = 7, KIND_QUAD3 = 8, KIND_PAIR3 = 9, KIND_WREG8 = 10,
+       KIND_G64_3 = 11, KIND_G64_4 = 12, KIND_G128_4 = 13, KIND_G256_4 = 14, KIND_G512_4 = 15 };
 
 // group kernels (several entities per wavefront): lanes per entity, coefficient slots per lane; 0 if not a group kind
-__host__ __device__ inline int group_lanes(int kind) { return (kind == KIND_QUAD2 || kind == KIND_QUAD3 || kind == KIND_QUAD4) ? 16 : ((kind == KIND_PAIR3 || kind == KIND_PAIR4) ? 32 : 0); }
-__host__ __device__ inline int group_epl(int kind) { return kind == KIND_QUAD2 ? 2 : ((kind == KIND_QUAD3 || kind == KIND_PAIR3) ? 3 : ((kind == KIND_QUAD4 || kind == KIND_PAIR4) ? 4 : 0)); }
+__host__ __device__ inline int group_lanes(int kind) {
+  return (kind == KIND_QUAD2 || kind == KIND_QUAD3 || kind == KIND_QUAD4) ? 16 : ((kind == KIND_PAIR3 || kind == KIND_PAIR4) ? 32 :
+         ((kind == KIND_G64_3 || kind == KIND_G64_4) ? 64 : (kind == KIND_G128_4 ? 128 : (kind == KIND_G256_4 ? 256 : (kind == KIND_G512_4 ? 512 : 0)))));
+}
+__host__ __device__ inline int group_epl(int kind) {
+  return kind == KIND_QUAD2 ? 2 : ((kind == KIND_QUAD3 || kind == KIND_PAIR3 || kind == KIND_G64_3) ? 3 : (group_lanes(kind) > 0 ? 4 : 0));
+}
 constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 1;
 constexpr int BLOCK_NW = 4;   // wavefronts per workgroup of the block kernel
 

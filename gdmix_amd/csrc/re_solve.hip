@@ -300,14 +300,18 @@ hipError_t launch_solve_wreg(int epl, const BatchDev& B, const OutDev& O, const 
 #endif
 // NCAP / ZCAP (sample / non-zero capacity of a row's LDS block) are template constants so that every LDS
 // offset is an instruction immediate off one base register (runtime offsets cost ~12 VGPRs of addresses).
+// G < 64: 64/G entities per wavefront; G = 64: one; G > 64: one entity per workgroup of G/64 wavefronts
+// (cross-wave stage of every reduction through LDS + one barrier).
 template <int G, int EPL, int NCAP, int ZCAP>
-__global__ __launch_bounds__(WAVE)
+__global__ __launch_bounds__(G > WAVE ? G : WAVE)
 __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL >= 3 ? GDMIX_QUAD_WAVES_EPL4 : 1)))) void re_solve_grp_kernel(
     BatchDev B, OutDev O, SolveParams o, const double* __restrict__ theta0, int begin, int count) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = threadIdx.x;
-  constexpr int NG = WAVE / G;   // entities per wavefront
-  const int row = lane / G, gl = lane & (G - 1);
+  constexpr int NG = G >= WAVE ? 1 : WAVE / G;   // entities per workgroup
+  constexpr int NWG = G > WAVE ? G / WAVE : 1;   // wavefronts per entity
+  const int tid = threadIdx.x;
+  const int row = (G >= WAVE) ? 0 : (tid / G);
+  const int gl = (G >= WAVE) ? tid : (tid & (G - 1));
   const int slot = blockIdx.x * NG + row;
   const bool valid = slot < count;
   const int64_t e = valid ? (int64_t)B.order[begin + slot] : 0;
@@ -320,9 +324,13 @@ __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL >= 3 
   const int64_t c0 = f0 + e * ic;
 
   QuadLds L;
-  L.q = quad_layout(G * EPL, NCAP, ZCAP);
+  L.q = quad_layout(G * EPL, NCAP, ZCAP, NWG);
   L.base = smem + (size_t)row * L.q.bytes;
+  L.hdr = L.base + (NWG > 1 ? (tid >> 6) * QUAD_HDR_BYTES : 0);
   L.has_w = B.weight != nullptr;
+  XWave X;
+  X.buf = reinterpret_cast<double*>(L.base + QUAD_HDR_BYTES * NWG);
+  X.phase = 0;
 
   if (valid) {
     for (int k = gl; k < nnz; k += G) {
@@ -355,9 +363,9 @@ __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL >= 3 
     V.x[s] = (theta0 && j < p) ? theta0[c0 + j] : 0.0;
     V.g[s] = 0.0; V.d[s] = 0.0;
   }
-  wave_lds_fence();
+  grp_fence<G>();
   SolveStats st;
-  quad_solve<G, EPL>(L, o, gl, n, p, ic, valid, rowc, colc, V, st);
+  quad_solve<G, EPL>(L, o, gl, n, p, ic, valid, rowc, colc, V, X, st);
   if (!valid) return;
 
 #pragma unroll
@@ -380,24 +388,25 @@ __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL >= 3 
     // _compute_variance SIMPLE (binary_logistic_regression.py:175-180) with the final theta
     double* const xs = L.xs();
     double* const rs = L.rs();
+    grp_fence<G>();
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
       const int j = gl + G * s;
       if (j < p) xs[j] = V.x[s];
     }
-    wave_lds_fence();
+    grp_fence<G>();
     const double x0 = ic ? xs[0] : 0.0;
     double dpart = 0.0;
     for (int i = gl; i < n; i += G) {
       const int k0 = L.row_ptr()[i], k1 = L.row_ptr()[i + 1];
       const double z = gather_dot(L.csr() + k0, k1 - k0, xs + ic, x0) + (double)L.o()[i];
-      const double rho = 1.0 / (1.0 + exp(-z));
+      const double rho = sigmoid_full(z);
       const double di = rho * (1.0 - rho) * (L.has_w ? (double)L.w()[i] : 1.0);
       rs[i] = di;
       dpart += di;
     }
-    const double dsum = grp_sum<G>(dpart);
-    wave_lds_fence();
+    const double dsum = grp_sum<G>(dpart, X);
+    grp_fence<G>();
     const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
@@ -429,8 +438,9 @@ __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL >= 3 
 template <int G, int EPL, int NCAP, int ZCAP>
 static hipError_t launch_quad_t(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
                                 int begin, int count, hipStream_t s) {
-  constexpr int NG = WAVE / G;
-  const int row_lds_bytes = quad_layout(G * EPL, NCAP, ZCAP).bytes;
+  constexpr int NG = G >= WAVE ? 1 : WAVE / G;
+  constexpr int NWG = G > WAVE ? G / WAVE : 1;
+  const int row_lds_bytes = quad_layout(G * EPL, NCAP, ZCAP, NWG).bytes;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(re_solve_grp_kernel<G, EPL, NCAP, ZCAP>),
@@ -438,7 +448,7 @@ static hipError_t launch_quad_t(const BatchDev& B, const OutDev& O, const SolveP
     if (rc != hipSuccess) return rc;
     attr_set = true;
   }
-  hipLaunchKernelGGL((re_solve_grp_kernel<G, EPL, NCAP, ZCAP>), dim3((count + NG - 1) / NG), dim3(WAVE),
+  hipLaunchKernelGGL((re_solve_grp_kernel<G, EPL, NCAP, ZCAP>), dim3((count + NG - 1) / NG), dim3(G > WAVE ? G : WAVE),
                      (size_t)row_lds_bytes * NG, s, B, O, o, theta0, begin, count);
   return hipGetLastError();
 }
@@ -453,6 +463,10 @@ hipError_t launch_solve_quad(int g, int epl, const BatchDev& B, const OutDev& O,
   GDMIX_GRP_CASE(16, 4, 16, 64) GDMIX_GRP_CASE(16, 4, 32, 128) GDMIX_GRP_CASE(16, 4, 128, 512)
   GDMIX_GRP_CASE(32, 3, 32, 128) GDMIX_GRP_CASE(32, 3, 64, 256) GDMIX_GRP_CASE(32, 3, 256, 1024)
   GDMIX_GRP_CASE(32, 4, 32, 128) GDMIX_GRP_CASE(32, 4, 64, 256) GDMIX_GRP_CASE(32, 4, 256, 1024)
+  GDMIX_GRP_CASE(64, 3, 64, 512) GDMIX_GRP_CASE(64, 3, 512, 2048) GDMIX_GRP_CASE(64, 4, 64, 512) GDMIX_GRP_CASE(64, 4, 512, 2048)
+  GDMIX_GRP_CASE(128, 4, 128, 1024) GDMIX_GRP_CASE(128, 4, 1024, 3072)
+  GDMIX_GRP_CASE(256, 4, 256, 2048) GDMIX_GRP_CASE(256, 4, 2048, 4096)
+  GDMIX_GRP_CASE(512, 4, 512, 4096)
 #undef GDMIX_GRP_CASE
   return hipErrorInvalidValue;
 }

@@ -73,22 +73,72 @@ __device__ __forceinline__ void rowpair_split(double v, double& even, double& od
   odd = __hiloint2double((int)h[1], (int)l[1]);
 }
 
+// v_permlane32_swap swaps the upper half of its first operand with the lower half of the second: fed with two
+// copies of v it leaves {lo, lo} and {hi, hi}; their sum is the wave total in all 64 lanes.
+__device__ __forceinline__ void half_split(double v, double& lower, double& upper) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  lower = __hiloint2double((int)h[0], (int)l[0]);
+  upper = __hiloint2double((int)h[1], (int)l[1]);
+}
+
+// Scratch of the cross-wave stage of groups wider than a wavefront (G = 64*NW): NW partials per value, double
+// buffered so that one barrier per reduction suffices (a wave cannot be more than one reduction ahead).
+struct XWave {
+  double* buf;   // LDS [2][3][NW]
+  int phase;
+};
+
 template <int G>
-__device__ __forceinline__ double grp_sum(double v) {
+__device__ __forceinline__ double xwave_combine(XWave& X, double v, int slot, bool is_max) {
+  constexpr int NW = G / WAVE;
+  double* b = X.buf + (X.phase * 3 + slot) * NW;
+  if ((threadIdx.x & (WAVE - 1)) == 0) b[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = b[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) r = is_max ? max_nn(r, b[w]) : r + b[w];
+  return r;
+}
+
+// Sum over the G lanes of an entity; every lane of the group receives the same bits.
+template <int G>
+__device__ __forceinline__ double grp_sum(double v, XWave& X) {
   v = row_sum(v);
-  if (G == 32) { double a, b; rowpair_split(v, a, b); v = a + b; }
+  if (G >= 32) { double a, b; rowpair_split(v, a, b); v = a + b; }
+  if (G >= 64) { double a, b; half_split(v, a, b); v = a + b; }
+  if (G > 64) { v = xwave_combine<G>(X, v, 0, false); X.phase ^= 1; }
   return v;
 }
 
 template <int G>
-__device__ __forceinline__ void grp_sum2(double& a, double& b) {
+__device__ __forceinline__ void grp_sum2(double& a, double& b, XWave& X) {
   row_sum2(a, b);
-  if (G == 32) {
+  if (G >= 32) {
     double a0, a1, b0, b1;
     rowpair_split(a, a0, a1);
     rowpair_split(b, b0, b1);
     a = a0 + a1;
     b = b0 + b1;
+  }
+  if (G >= 64) {
+    double a0, a1, b0, b1;
+    half_split(a, a0, a1);
+    half_split(b, b0, b1);
+    a = a0 + a1;
+    b = b0 + b1;
+  }
+  if (G > 64) {
+    constexpr int NW = G / WAVE;
+    double* pa = X.buf + (X.phase * 3 + 0) * NW;
+    double* pb = X.buf + (X.phase * 3 + 1) * NW;
+    if ((threadIdx.x & (WAVE - 1)) == 0) { pa[threadIdx.x >> 6] = a; pb[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    a = pa[0]; b = pb[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { a += pa[w]; b += pb[w]; }
+    X.phase ^= 1;
   }
 }
 
@@ -107,9 +157,9 @@ __device__ __forceinline__ void row_sum2_max(double& a, double& b, double& c) {
 }
 
 template <int G>
-__device__ __forceinline__ void grp_sum2_max(double& a, double& b, double& c) {
+__device__ __forceinline__ void grp_sum2_max(double& a, double& b, double& c, XWave& X) {
   row_sum2_max(a, b, c);
-  if (G == 32) {
+  if (G >= 32) {
     double a0, a1, b0, b1, c0, c1;
     rowpair_split(a, a0, a1);
     rowpair_split(b, b0, b1);
@@ -118,6 +168,34 @@ __device__ __forceinline__ void grp_sum2_max(double& a, double& b, double& c) {
     b = b0 + b1;
     c = max_nn(c0, c1);
   }
+  if (G >= 64) {
+    double a0, a1, b0, b1, c0, c1;
+    half_split(a, a0, a1);
+    half_split(b, b0, b1);
+    half_split(c, c0, c1);
+    a = a0 + a1;
+    b = b0 + b1;
+    c = max_nn(c0, c1);
+  }
+  if (G > 64) {
+    constexpr int NW = G / WAVE;
+    double* pa = X.buf + (X.phase * 3 + 0) * NW;
+    double* pb = X.buf + (X.phase * 3 + 1) * NW;
+    double* pc = X.buf + (X.phase * 3 + 2) * NW;
+    if ((threadIdx.x & (WAVE - 1)) == 0) { pa[threadIdx.x >> 6] = a; pb[threadIdx.x >> 6] = b; pc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    a = pa[0]; b = pb[0]; c = pc[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { a += pa[w]; b += pb[w]; c = max_nn(c, pc[w]); }
+    X.phase ^= 1;
+  }
+}
+
+// ordering point between LDS writes and reads of different lanes of one entity
+template <int G>
+__device__ __forceinline__ void grp_fence() {
+  if (G > 64) __syncthreads();
+  else wave_lds_fence();
 }
 
 // ---- capacity-based LDS layout of one row (entity) ---------------------------------------------------
@@ -126,11 +204,14 @@ struct QuadLayout {
   int xs, xo, go, rs, csr, csc, row_ptr, col_ptr, y, o, w, bytes;
 };
 
-constexpr int QUAD_HDR_BYTES = 8 * (2 * M_REG + 16 + 8);   // rho, alpha, LineSearch slot, 8 scalars
+constexpr int QUAD_HDR_BYTES = 8 * (2 * M_REG + 16 + 8);   // rho, alpha, LineSearch slot, 8 scalars (one per wavefront of the group)
 
-__host__ __device__ inline QuadLayout quad_layout(int pcap, int ncap, int zcap) {
+__host__ __device__ inline QuadLayout quad_layout(int pcap, int ncap, int zcap, int waves = 1) {
   QuadLayout q;
-  int off = QUAD_HDR_BYTES;
+  // groups wider than a wavefront keep one private copy of the uniform solver state per wavefront (all
+  // copies hold the same values; sharing one would race between a fast wave's write and a slow wave's read)
+  // plus the cross-wave reduction scratch
+  int off = QUAD_HDR_BYTES * waves + (waves > 1 ? 8 * 2 * 3 * waves : 0);
   q.xs = off; off += 8 * pcap;
   q.xo = off; off += 8 * pcap;
   q.go = off; off += 8 * pcap;
@@ -148,13 +229,14 @@ __host__ __device__ inline QuadLayout quad_layout(int pcap, int ncap, int zcap) 
 
 // Pointers into one row's LDS block (derived from one per-lane base + uniform offsets).
 struct QuadLds {
-  unsigned char* base;
+  unsigned char* base;   // the entity's LDS block
+  unsigned char* hdr;    // this wavefront's private header inside it
   QuadLayout q;
   bool has_w;
-  __device__ __forceinline__ double* rho() const { return reinterpret_cast<double*>(base); }
-  __device__ __forceinline__ double* alpha() const { return reinterpret_cast<double*>(base) + M_REG; }
-  __device__ __forceinline__ LineSearch* ls() const { return reinterpret_cast<LineSearch*>(base + 16 * M_REG); }
-  __device__ __forceinline__ double* scal() const { return reinterpret_cast<double*>(base + 16 * M_REG + 128); }
+  __device__ __forceinline__ double* rho() const { return reinterpret_cast<double*>(hdr); }
+  __device__ __forceinline__ double* alpha() const { return reinterpret_cast<double*>(hdr) + M_REG; }
+  __device__ __forceinline__ LineSearch* ls() const { return reinterpret_cast<LineSearch*>(hdr + 16 * M_REG); }
+  __device__ __forceinline__ double* scal() const { return reinterpret_cast<double*>(hdr + 16 * M_REG + 128); }
   __device__ __forceinline__ double* xs() const { return reinterpret_cast<double*>(base + q.xs); }
   __device__ __forceinline__ double* xo() const { return reinterpret_cast<double*>(base + q.xo); }
   __device__ __forceinline__ double* go() const { return reinterpret_cast<double*>(base + q.go); }
@@ -195,7 +277,7 @@ __device__ __forceinline__ double gather_dot(const int2* pairs, int len, const d
 template <int G, int EPL>
 __device__ __forceinline__ double quad_eval(const QuadLds& L, const SolveParams& o, int gl, int n, int p, int ic,
                                             unsigned rowc, const unsigned (&colc)[EPL], const double (&xt)[EPL],
-                                            double (&g)[EPL]) {
+                                            double (&g)[EPL], XWave& X) {
   double* const xs = L.xs();
   double* const rs = L.rs();
 #pragma unroll
@@ -203,7 +285,7 @@ __device__ __forceinline__ double quad_eval(const QuadLds& L, const SolveParams&
     const int j = gl + G * s;
     if (j < p) xs[j] = xt[s];
   }
-  wave_lds_fence();
+  grp_fence<G>();
   double part = 0.0, rpart = 0.0;
   const double x0 = ic ? xs[0] : 0.0;
   if (gl < n) {
@@ -229,8 +311,8 @@ __device__ __forceinline__ double quad_eval(const QuadLds& L, const SolveParams&
     if (j >= first_reg && j < p) sq += xt[s] * xt[s];
   }
   part += 0.5 * o.l2 * sq;
-  grp_sum2<G>(part, rpart);
-  wave_lds_fence();
+  grp_sum2<G>(part, rpart, X);
+  grp_fence<G>();
   const double inv_n = 1.0 / (double)n;
 #pragma unroll
   for (int s = 0; s < EPL; ++s) {
@@ -256,7 +338,7 @@ struct QuadState {
 template <int G, int EPL>
 __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& o, int gl, int n, int p, int ic,
                                            bool valid, unsigned rowc, const unsigned (&colc)[EPL], QuadState<EPL>& V,
-                                           SolveStats& out) {
+                                           XWave& X, SolveStats& out) {
   double S[M_REG][EPL], Y[M_REG][EPL];
 #pragma unroll
   for (int a = 0; a < M_REG; ++a) {
@@ -286,7 +368,7 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
     bool need_dir = false, restart = false;
     if (status < 0) {
       // ---- f, g at the trial point; g'd, y'y and max|g| in one reduction pass ------------------------
-      f = quad_eval<G, EPL>(L, o, gl, n, p, ic, rowc, colc, V.x, V.g);
+      f = quad_eval<G, EPL>(L, o, gl, n, p, ic, rowc, colc, V.x, V.g, X);
       ++nfev;
       {
         double a = 0.0, b = 0.0, c = 0.0;
@@ -299,7 +381,7 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
           b += yj * yj;
           c = max_nn(c, fabs(V.g[s]));
         }
-        grp_sum2_max<G>(a, b, c);
+        grp_sum2_max<G>(a, b, c, X);
         gd = a; rr = b; sbgnrm = c;
       }
       if (first) {
@@ -386,7 +468,7 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
             double t = 0.0;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) t += S[a][s] * V.d[s];
-            const double al = rho[a] * grp_sum<G>(t);
+            const double al = rho[a] * grp_sum<G>(t, X);
             alpha[a] = al;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) V.d[s] -= al * Y[a][s];
@@ -406,7 +488,7 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
             double t = 0.0;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) t += Y[a][s] * V.d[s];
-            const double c = alpha[a] - rho[a] * grp_sum<G>(t);
+            const double c = alpha[a] - rho[a] * grp_sum<G>(t, X);
 #pragma unroll
             for (int s = 0; s < EPL; ++s) V.d[s] += c * S[a][s];
           }
@@ -426,7 +508,7 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
           dd += dj * dj;
           gdp += V.g[s] * dj;
         }
-        grp_sum2<G>(dd, gdp);
+        grp_sum2<G>(dd, gdp, X);
         gd = gdp;
         scal[SC_GDOLD] = gd;
         scal[SC_FOLD] = f;
@@ -450,7 +532,7 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
 #pragma unroll
     for (int s = 0; s < EPL; ++s) mx = max_nn(mx, fabs(V.g[s]));
     double d0 = 0.0, d1 = 0.0;
-    grp_sum2_max<G>(d0, d1, mx);
+    grp_sum2_max<G>(d0, d1, mx, X);
     sbgnrm = mx;
   }
   out.f = f;
