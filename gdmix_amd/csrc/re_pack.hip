@@ -22,7 +22,7 @@ constexpr int PACK_LDS_KEYS = GDMIX_PACK_LDS_KEYS;     // per-wave LDS sort capa
 struct PackStats {      // device-side, read back once per pack
   unsigned long long D;
   int max_p, max_n, max_nnz, err;
-  int n_big, pad;         // entities deferred to the workgroup-per-entity pack kernel
+  int n_big, n_mid;       // entities deferred to the workgroup-per-entity / the larger-LDS wavefront pack kernel
 };
 
 __global__ void pack_entnnz_kernel(const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ row_nnz_ptr,
@@ -131,17 +131,23 @@ __device__ __forceinline__ int emit_entity(KeyPtr sk, ValPtr vals, const int32_t
   return carry;
 }
 
-__global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_entity_kernel(
+// CAP = LDS staging capacity (non-zeros and samples) of a wavefront, NWAVES = wavefronts per workgroup.
+// in_list == nullptr: all E entities; otherwise the *in_count entities of in_list. Entities above CAP are
+// appended to out_list (counter *out_count).
+template <int CAP, int NWAVES>
+__global__ __launch_bounds__(WAVE* NWAVES) void pack_entity_kernel(
+    const int32_t* __restrict__ in_list, const int* __restrict__ in_count, int32_t* __restrict__ out_list,
+    int* __restrict__ out_count,
     const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ row_nnz_ptr,
     const int64_t* __restrict__ ent_nnz_ptr, const int64_t* __restrict__ col_global, const float* __restrict__ val,
     int64_t E, int ic, int32_t* __restrict__ row_ptr, unsigned long long* __restrict__ sort_key,
     int32_t* __restrict__ csr_col, int32_t* __restrict__ col_ptr, int32_t* __restrict__ csc_row,
     float* __restrict__ csc_val, int32_t* __restrict__ uniq_sparse, int32_t* __restrict__ d_cnt,
-    int32_t* __restrict__ big_list, PackStats* __restrict__ stats) {
-  __shared__ unsigned long long lds_keys[PACK_WAVES][PACK_LDS_KEYS];
-  __shared__ unsigned long long lds_sorted[PACK_WAVES][PACK_RANK_MAX];
-  __shared__ float lds_val[PACK_WAVES][PACK_LDS_KEYS];
-  __shared__ int32_t lds_rp[PACK_WAVES][PACK_LDS_KEYS + 1];
+    PackStats* __restrict__ stats) {
+  __shared__ unsigned long long lds_keys[NWAVES][CAP];
+  __shared__ unsigned long long lds_sorted[NWAVES][PACK_RANK_MAX];
+  __shared__ float lds_val[NWAVES][CAP];
+  __shared__ int32_t lds_rp[NWAVES][CAP + 1];
   __shared__ int blk_max[3];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wv = threadIdx.x >> 6;
@@ -150,7 +156,9 @@ __global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_entity_kernel(
   int mx_p = 0, mx_n = 0, mx_z = 0;
   // grid-stride over entities: per-entity same-address atomics would serialise in L2 (~10 ns each), so maxima
   // are carried in registers and published once per workgroup.
-  for (int64_t e = (int64_t)blockIdx.x * PACK_WAVES + wv; e < E; e += (int64_t)gridDim.x * PACK_WAVES) {
+  const int64_t total = in_list ? (int64_t)*in_count : E;
+  for (int64_t it = (int64_t)blockIdx.x * NWAVES + wv; it < total; it += (int64_t)gridDim.x * NWAVES) {
+    const int64_t e = in_list ? (int64_t)in_list[it] : it;
     const int64_t r0 = ent_row_ptr[e], r1 = ent_row_ptr[e + 1];
     const int64_t z0 = ent_nnz_ptr[e], z1 = ent_nnz_ptr[e + 1];
     const int64_t n64 = r1 - r0, nnz64 = z1 - z0;
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_entity_kernel(
       continue;
     }
     const int n = (int)n64, nnz = (int)nnz64;
-    const bool small = nnz <= PACK_LDS_KEYS && n <= PACK_LDS_KEYS;
+    const bool small = nnz <= CAP && n <= CAP;
     int32_t* const rp_out = row_ptr + r0 + e;
     for (int i = lane; i <= n; i += WAVE) {
       const int32_t v = (int32_t)(row_nnz_ptr[r0 + i] - z0);
@@ -188,8 +196,8 @@ __global__ __launch_bounds__(WAVE* PACK_WAVES) void pack_entity_kernel(
                         csc_row + z0, csc_val + z0, uniq_sparse + z0);
       }
     } else {
-      // too large for a wavefront's LDS staging: handled by pack_big_kernel (one workgroup per entity)
-      if (lane == 0) big_list[atomicAdd(&stats->n_big, 1)] = (int32_t)e;
+      // too large for this kernel's LDS staging: deferred to the next pack kernel
+      if (lane == 0) out_list[atomicAdd(out_count, 1)] = (int32_t)e;
       mx_n = max(mx_n, n); mx_z = max(mx_z, nnz);
       continue;
     }
@@ -379,7 +387,7 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct PackLayout {
   size_t ent_nnz_ptr, ent_feat_ptr, row_ptr, csr_col, col_ptr, csc_row, csc_val, unique_global, order, cls_tmp,
-      d_cnt, class_count, block_sums, stats, sort_key, uniq_sparse, big_list, total;
+      d_cnt, class_count, block_sums, stats, sort_key, uniq_sparse, big_list, mid_list, total;
 };
 
 static PackLayout pack_layout(int64_t E, int64_t N, int64_t Z) {
@@ -403,6 +411,7 @@ static PackLayout pack_layout(int64_t E, int64_t N, int64_t Z) {
   L.sort_key = take((size_t)(Z + 1) * 8);
   L.uniq_sparse = take((size_t)(Z + 1) * 4);
   L.big_list = take((size_t)(E + 1) * 4);
+  L.mid_list = take((size_t)(E + 1) * 4);
   L.total = off;
   return L;
 }
@@ -481,10 +490,20 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
   if (eblocks > ctx->num_cus * 16) eblocks = ctx->num_cus * 16;
   int32_t* uniq_sparse = reinterpret_cast<int32_t*>(base + L.uniq_sparse);
   int32_t* big_list = reinterpret_cast<int32_t*>(base + L.big_list);
-  hipLaunchKernelGGL(pack_entity_kernel, dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s, raw->ent_row_ptr, raw->row_nnz_ptr,
-                     out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key, out->csr_col, out->col_ptr,
-                     out->csc_row, out->csc_val, uniq_sparse, d_cnt, big_list, stats);
-  DBG_STAGE("pack_entity_kernel");
+  int32_t* mid_list = reinterpret_cast<int32_t*>(base + L.mid_list);
+  // three tiers by entity size: wavefront + 256-key LDS staging (rank sort), wavefront + 1024-key staging,
+  // workgroup + in-place sort in HBM scratch. The later tiers read their entity lists from device counters
+  // (usually empty: the fixed grids exit at once).
+  hipLaunchKernelGGL((pack_entity_kernel<PACK_LDS_KEYS, PACK_WAVES>), dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s,
+                     (const int32_t*)nullptr, (const int*)nullptr, mid_list, &stats->n_mid, raw->ent_row_ptr,
+                     raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
+                     out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
+  DBG_STAGE("pack_entity_kernel<256>");
+  hipLaunchKernelGGL((pack_entity_kernel<1024, 2>), dim3(ctx->num_cus * 4), dim3(WAVE * 2), 0, s,
+                     (const int32_t*)mid_list, (const int*)&stats->n_mid, big_list, &stats->n_big, raw->ent_row_ptr,
+                     raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
+                     out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
+  DBG_STAGE("pack_entity_kernel<1024>");
   // entities too large for the wavefront kernel (stats->n_big of them, usually none): the grid is fixed, idle
   // workgroups exit at once
   hipLaunchKernelGGL(pack_big_kernel, dim3(ctx->num_cus), dim3(BIG_THREADS), 0, s, raw->ent_row_ptr, out->ent_nnz_ptr,
