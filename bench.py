@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--cpu-sample", type=int, default=0, help="entities per pass of the CPU baseline (0 = 200k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--giant-nnz", type=int, default=-1, help="override the device-wide kernel threshold (exploration)")
+    ap.add_argument("--team-nnz", type=int, default=-1, help="override the 8-team kernel threshold (exploration)")
     ap.add_argument("--solve-only", action="store_true", help="time gdmix_re_solve alone (batch packed once)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c5mean", "zipf", "ml_user", "ml_movie"],
                     help="c2 (default, the benchmarked configuration) or an exploration shape")
@@ -93,7 +95,7 @@ def main():
         build.build_library()
     if world > 1:
         dist.barrier()
-    from gdmix_amd.solver import REDeviceSolver, SolverOptions
+    from gdmix_amd.solver import NUM_CLASSES, REDeviceSolver, SolverOptions
 
     opts_kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
     opts = SolverOptions(**opts_kw)
@@ -113,6 +115,10 @@ def main():
     packed = solver.pack(raw_dev)
     out = solver.alloc_result(packed)
     solver.set_timing(True)
+    if a.giant_nnz >= 0:
+        solver.set_giant_nnz(a.giant_nnz)
+    if a.team_nnz >= 0:
+        solver.set_team_nnz(a.team_nnz)
 
     def step():
         nonlocal packed
@@ -125,7 +131,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    kernel_ms = np.zeros(40)
+    kernel_ms = np.zeros(NUM_CLASSES)
     ev_pack = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     pack_ms = solve_ms = 0.0
     t0 = time.perf_counter()

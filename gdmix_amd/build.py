@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgdmix_re.so")
-SOURCES = ["re_api.hip", "re_solve.hip", "re_pack.hip"]
+SOURCES = ["re_api.hip", "re_solve.hip", "re_pack.hip", "re_pack_big.hip"]
 HEADERS = ["re_device.hpp", "re_solve_core.hpp", "re_internal.hpp", os.path.join("..", "..", "include", "gdmix_re.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -disable-machine-licm: MachineLICM hoists the ~35 fp64 polynomial constants of exp/log out of the solver's

@@ -1,11 +1,13 @@
 // re_api.hip — the extern "C" surface of libgdmix_re.so (include/gdmix_re.h).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
 
 #include "re_internal.hpp"
+#include "re_solve_team.hpp"
 
 namespace gdmix {
 
@@ -54,7 +56,9 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_WREG8, 12288, "re_solve_wreg_kernel<8> lds<=12K"}, {KIND_WREG8, 24576, "re_solve_wreg_kernel<8> lds<=24K"},
     {KIND_WREG8, 65536, "re_solve_wreg_kernel<8> lds<=64K"},
     {KIND_WLDS, 24576, "re_solve_wave_kernel lds<=24K"},     {KIND_WLDS, 65536, "re_solve_wave_kernel lds<=64K"},
-    {KIND_BLOCK, 0, "re_solve_block_kernel"}};
+    {KIND_BLOCK, 0, "re_solve_team_kernel workgroup"},
+    {KIND_GRID, 0, "re_solve_team_kernel 8 teams"},
+    {KIND_GRID, 0, "re_solve_team_kernel device-wide"}};
 
 __global__ void class_base_kernel(int32_t* cc) {
   // cc[0..NC) counts -> cc[NC..2NC) exclusive bases, cc[2NC..3NC) cursors = 0
@@ -120,10 +124,22 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   c->impl.wave_lds_limit = 65536;
   c->impl.kernel_mask = 7;
   c->impl.timing = 0;
+  c->impl.giant_nnz = 524288;
+  c->impl.team_nnz = 16384;
+  c->impl.grid_sync = nullptr;
+  c->impl.big_tmp = nullptr;
+  c->impl.big_tmp_bytes = 0;
   for (int k = 0; k < GDMIX_RE_NUM_CLASSES; ++k) { c->impl.ev0[k] = nullptr; c->impl.ev1[k] = nullptr; c->impl.ev_used[k] = false; }
   hipError_t rc = hipHostMalloc(reinterpret_cast<void**>(&c->impl.host_pinned), 4096, hipHostMallocDefault);
   if (rc != hipSuccess) {
     set_error("hipHostMalloc failed: %s", hipGetErrorString(rc));
+    delete c;
+    return GDMIX_RE_EHIP;
+  }
+  rc = hipMalloc(&c->impl.grid_sync, TEAM_MAX_TEAMS * sizeof(TeamSync));
+  if (rc != hipSuccess) {
+    set_error("hipMalloc failed: %s", hipGetErrorString(rc));
+    (void)hipHostFree(c->impl.host_pinned);
     delete c;
     return GDMIX_RE_EHIP;
   }
@@ -133,6 +149,8 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
 
 GDMIX_API void gdmix_re_destroy(gdmix_re_ctx* ctx) {
   if (!ctx) return;
+  if (ctx->impl.grid_sync) (void)hipFree(ctx->impl.grid_sync);
+  if (ctx->impl.big_tmp) (void)hipFree(ctx->impl.big_tmp);
   if (ctx->impl.host_pinned) (void)hipHostFree(ctx->impl.host_pinned);
   for (int k = 0; k < GDMIX_RE_NUM_CLASSES; ++k) {
     if (ctx->impl.ev0[k]) (void)hipEventDestroy(ctx->impl.ev0[k]);
@@ -200,6 +218,18 @@ GDMIX_API int gdmix_re_set_wave_lds_limit(gdmix_re_ctx* ctx, int bytes) {
 GDMIX_API int gdmix_re_set_kernel_mask(gdmix_re_ctx* ctx, int mask) {
   if (!ctx) { set_error("ctx is NULL"); return GDMIX_RE_EINVAL; }
   ctx->impl.kernel_mask = mask & 7;
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_re_set_giant_nnz(gdmix_re_ctx* ctx, int64_t nnz) {
+  if (!ctx || nnz < 0) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
+  ctx->impl.giant_nnz = nnz;
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_re_set_team_nnz(gdmix_re_ctx* ctx, int64_t nnz) {
+  if (!ctx || nnz < 0) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
+  ctx->impl.team_nnz = nnz;
   return GDMIX_RE_OK;
 }
 
@@ -273,6 +303,9 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     if (kClasses[c].kind == KIND_WLDS && !(ctx->impl.kernel_mask & 2)) on = false;
     tab.lds_bytes[c] = on ? lds : 0;
   }
+  // the compact-form team kernels keep TEAM_MCAP history pairs
+  tab.giant_nnz = opts->m <= TEAM_MCAP ? ctx->impl.giant_nnz : 0;
+  tab.team_nnz = opts->m <= TEAM_MCAP ? ctx->impl.team_nnz : 0;
 
   int32_t* cc = b->class_count;
   HIP_TRY(hipMemsetAsync(cc, 0, 3 * GDMIX_RE_NUM_CLASSES * sizeof(int32_t), s));
@@ -294,7 +327,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   const bool timing = ctx->impl.timing != 0;
   for (int c = 0; c < GDMIX_RE_NUM_CLASSES; ++c) ctx->impl.ev_used[c] = false;
   int begin = 0;
-  for (int c = 0; c < GDMIX_RE_NUM_CLASSES - 1; ++c) {
+  for (int c = 0; c < BLOCK_CLASS; ++c) {
     if (hc[c] <= 0) continue;
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[c], s)); }
     switch (kClasses[c].kind) {
@@ -312,7 +345,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[c], s)); ctx->impl.ev_used[c] = true; }
     begin += hc[c];
   }
-  if (hc[BLOCK_CLASS] > 0) {
+  if (hc[BLOCK_CLASS] > 0 || hc[XTEAM_CLASS] > 0 || hc[GIANT_CLASS] > 0) {
     size_t slot_doubles;
     int slots = slots_for(b, opts, &slot_doubles);
     size_t need = (size_t)slots * slot_doubles * 8;
@@ -326,15 +359,36 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
       if (b->scratch_bytes > avail) { avail = b->scratch_bytes; base = b->scratch; }
       slots = (int)(avail / (slot_doubles * 8));
       if (slots < 1) {
-        set_error("%d entities need the workgroup kernel: provide >= %zu bytes via gdmix_re_set_scratch", hc[BLOCK_CLASS],
+        set_error("%d entities need the workgroup kernel: provide >= %zu bytes via gdmix_re_set_scratch", hc[BLOCK_CLASS] + hc[XTEAM_CLASS] + hc[GIANT_CLASS],
                   slot_doubles * 8);
         return GDMIX_RE_ENOMEM;
       }
       scratch = static_cast<double*>(base);
     }
-    if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[BLOCK_CLASS], s)); }
-    HIP_TRY(launch_solve_block(B, O, P, theta0, begin, hc[BLOCK_CLASS], scratch, slot_doubles, slots, b->max_p, s));
-    if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[BLOCK_CLASS], s)); ctx->impl.ev_used[BLOCK_CLASS] = true; }
+    if (hc[BLOCK_CLASS] > 0) {
+      if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[BLOCK_CLASS], s)); }
+      HIP_TRY(launch_solve_block(B, O, P, theta0, begin, hc[BLOCK_CLASS], scratch, slot_doubles, slots, b->max_p, s));
+      if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[BLOCK_CLASS], s)); ctx->impl.ev_used[BLOCK_CLASS] = true; }
+      begin += hc[BLOCK_CLASS];
+    }
+    // the team kernels run after the workgroup kernel on the same stream, so its slots are free again
+    if (hc[XTEAM_CLASS] > 0) {
+      int teams = 8;
+      if (const char* ev = getenv("GDMIX_RE_TEAMS")) teams = atoi(ev);   // exploration knob
+      if (teams > TEAM_MAX_TEAMS) teams = TEAM_MAX_TEAMS;
+      if (teams < 1 || slots < teams) teams = 1;
+      if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[XTEAM_CLASS], s)); }
+      HIP_TRY(launch_solve_grid(B, O, P, theta0, begin, hc[XTEAM_CLASS], scratch, slot_doubles, b->max_p,
+                                ctx->impl.grid_sync, ctx->impl.num_cus, teams, s));
+      if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[XTEAM_CLASS], s)); ctx->impl.ev_used[XTEAM_CLASS] = true; }
+      begin += hc[XTEAM_CLASS];
+    }
+    if (hc[GIANT_CLASS] > 0) {
+      if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[GIANT_CLASS], s)); }
+      HIP_TRY(launch_solve_grid(B, O, P, theta0, begin, hc[GIANT_CLASS], scratch, slot_doubles, b->max_p,
+                                ctx->impl.grid_sync, ctx->impl.num_cus, 1, s));
+      if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[GIANT_CLASS], s)); ctx->impl.ev_used[GIANT_CLASS] = true; }
+    }
   }
   if (opts->variance_mode == GDMIX_RE_VAR_FULL) {
     const size_t vslot = var_full_slot_doubles(b->max_p);

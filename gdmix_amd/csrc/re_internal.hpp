@@ -21,7 +21,7 @@ namespace gdmix {
 //   KIND_BLOCK      workgroup-per-entity kernel working out of a global scratch slot (anything)
 // Each wavefront kind is split into LDS-footprint buckets so that small entities keep high occupancy.
 enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4, KIND_QUAD2 = 5, KIND_QUAD4 = 6, KIND_PAIR4 = 7, KIND_QUAD3 = 8, KIND_PAIR3 = 9, KIND_WREG8 = 10,
-       KIND_G64_3 = 11, KIND_G64_4 = 12, KIND_G128_4 = 13, KIND_G256_4 = 14, KIND_G512_4 = 15 };
+       KIND_G64_3 = 11, KIND_G64_4 = 12, KIND_G128_4 = 13, KIND_G256_4 = 14, KIND_G512_4 = 15, KIND_GRID = 16 };
 
 // group kernels (several entities per wavefront): lanes per entity, coefficient slots per lane; 0 if not a group kind
 __host__ __device__ inline int group_lanes(int kind) {
@@ -31,14 +31,23 @@ __host__ __device__ inline int group_lanes(int kind) {
 __host__ __device__ inline int group_epl(int kind) {
   return kind == KIND_QUAD2 ? 2 : ((kind == KIND_QUAD3 || kind == KIND_PAIR3 || kind == KIND_G64_3) ? 3 : (group_lanes(kind) > 0 ? 4 : 0));
 }
-constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 1;
+constexpr int GIANT_CLASS = GDMIX_RE_NUM_CLASSES - 1;   // device-wide kernel, one entity at a time
+constexpr int XTEAM_CLASS = GDMIX_RE_NUM_CLASSES - 2;   // one XCD's worth of CUs per entity, 8 at a time
+constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 3;
 constexpr int BLOCK_NW = 4;   // wavefronts per workgroup of the block kernel
+#ifndef GDMIX_TEAM_BLOCK_NW
+#define GDMIX_TEAM_BLOCK_NW 8
+#endif
+constexpr int TEAM_BLOCK_NW = GDMIX_TEAM_BLOCK_NW;   // ... of the compact-form workgroup kernel
+constexpr int TEAM_GRID_NW = 8;    // ... of the device-wide kernel (one workgroup per CU)
 
 struct ClassTable {
   int kind[GDMIX_RE_NUM_CLASSES];
   int lds_bytes[GDMIX_RE_NUM_CLASSES];   // LDS bucket of the class; 0 = class disabled (or block class)
   int ncap[GDMIX_RE_NUM_CLASSES];        // quad classes: sample / non-zero capacity of a row's LDS block
   int zcap[GDMIX_RE_NUM_CLASSES];
+  int64_t giant_nnz;   // 0 = device-wide kernel off
+  int64_t team_nnz;    // 0 = 8-team kernel off
 };
 
 // Device pointers of a packed batch, passed by value to kernels.
@@ -78,6 +87,11 @@ struct gdmix_ctx_impl {
   int wave_lds_limit;     // entities above this LDS footprint use the block kernel
   int kernel_mask;        // bit0 register wave kernel, bit1 LDS wave kernel, bit2 quad kernel
   int timing;             // bracket class launches with events
+  int64_t giant_nnz;      // entities with >= this many non-zeros use the device-wide kernel (0 = never)
+  int64_t team_nnz;       // ... the 8-team kernel (0 = never)
+  void* grid_sync;        // device: TeamSync of the team kernels
+  void* big_tmp;          // device: grow-only temporary of the big-entity pack path
+  size_t big_tmp_bytes;
   hipEvent_t ev0[GDMIX_RE_NUM_CLASSES], ev1[GDMIX_RE_NUM_CLASSES];
   bool ev_used[GDMIX_RE_NUM_CLASSES];
 };
@@ -107,6 +121,9 @@ hipError_t launch_solve_wave(const BatchDev& B, const OutDev& O, const SolvePara
 hipError_t launch_solve_block(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
                               int begin, int count, double* scratch, size_t slot_doubles, int slots,
                               int64_t max_p, hipStream_t s);
+hipError_t launch_solve_grid(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
+                             int begin, int count, double* scratch, size_t slot_doubles, int64_t max_p,
+                             void* sync_buf, int blocks, int teams, hipStream_t s);
 hipError_t launch_variance_full(const BatchDev& B, int64_t E, const SolveParams& o, const double* theta, double* variance,
                                 double* scratch, size_t slot_doubles, int slots, int64_t max_p, hipStream_t s);
 constexpr int64_t VAR_FULL_MAX_P = 2048;   // FULL variance densifies p x p (as the reference does)
@@ -118,6 +135,28 @@ hipError_t launch_score(const BatchDev& B, int64_t E, int ic, const double* thet
 size_t pack_workspace_bytes(int64_t E, int64_t N, int64_t Z);
 int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_intercept, void* ws, size_t ws_bytes,
               gdmix_re_packed* out, hipStream_t s);
+// pack of the entities too large for the wavefront pack kernels (re_pack_big.hip)
+struct BigPackArgs {
+  const int64_t* ent_row_ptr;
+  const int64_t* ent_nnz_ptr;
+  const int64_t* col_global;
+  const float* val;
+  int ic;
+  const int32_t* row_ptr;
+  int32_t* csr_col;
+  int32_t* col_ptr;
+  int32_t* csc_row;
+  float* csc_val;
+  int32_t* uniq_sparse;
+  int32_t* d_cnt;
+  const int32_t* big_list;
+  int n_big;
+  int64_t big_nnz;
+  int* max_p;   // device
+  int* err;     // device
+};
+int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s);
+
 hipError_t launch_partition_ids(const int64_t* ids, int64_t count, int32_t num_partitions, int32_t* out,
                                 hipStream_t s);
 

@@ -22,7 +22,8 @@ constexpr int PACK_LDS_KEYS = GDMIX_PACK_LDS_KEYS;     // per-wave LDS sort capa
 struct PackStats {      // device-side, read back once per pack
   unsigned long long D;
   int max_p, max_n, max_nnz, err;
-  int n_big, n_mid;       // entities deferred to the workgroup-per-entity / the larger-LDS wavefront pack kernel
+  int n_big, n_mid;       // entities deferred to the device-wide sort / the larger-LDS wavefront pack kernel
+  unsigned long long big_nnz;   // non-zeros of the n_big entities
 };
 
 __global__ void pack_entnnz_kernel(const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ row_nnz_ptr,
@@ -137,7 +138,7 @@ __device__ __forceinline__ int emit_entity(KeyPtr sk, ValPtr vals, const int32_t
 template <int CAP, int NWAVES>
 __global__ __launch_bounds__(WAVE* NWAVES) void pack_entity_kernel(
     const int32_t* __restrict__ in_list, const int* __restrict__ in_count, int32_t* __restrict__ out_list,
-    int* __restrict__ out_count,
+    int* __restrict__ out_count, unsigned long long* __restrict__ out_nnz,
     const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ row_nnz_ptr,
     const int64_t* __restrict__ ent_nnz_ptr, const int64_t* __restrict__ col_global, const float* __restrict__ val,
     int64_t E, int ic, int32_t* __restrict__ row_ptr, unsigned long long* __restrict__ sort_key,
@@ -197,7 +198,10 @@ __global__ __launch_bounds__(WAVE* NWAVES) void pack_entity_kernel(
       }
     } else {
       // too large for this kernel's LDS staging: deferred to the next pack kernel
-      if (lane == 0) out_list[atomicAdd(out_count, 1)] = (int32_t)e;
+      if (lane == 0) {
+        out_list[atomicAdd(out_count, 1)] = (int32_t)e;
+        if (out_nnz) atomicAdd(out_nnz, (unsigned long long)nnz);
+      }
       mx_n = max(mx_n, n); mx_z = max(mx_z, nnz);
       continue;
     }
@@ -214,106 +218,6 @@ __global__ __launch_bounds__(WAVE* NWAVES) void pack_entity_kernel(
     atomicMax(&stats->max_p, blk_max[0]);
     atomicMax(&stats->max_n, blk_max[1]);
     atomicMax(&stats->max_nnz, blk_max[2]);
-  }
-}
-
-// ---- large entities: one 1024-thread workgroup per entity, keys sorted in place in HBM scratch ----------------
-constexpr int BIG_THREADS = 1024;
-
-__global__ __launch_bounds__(BIG_THREADS) void pack_big_kernel(
-    const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ ent_nnz_ptr,
-    const int64_t* __restrict__ col_global, const float* __restrict__ val, int ic, const int32_t* __restrict__ row_ptr,
-    unsigned long long* __restrict__ sort_key, int32_t* __restrict__ csr_col, int32_t* __restrict__ col_ptr,
-    int32_t* __restrict__ csc_row, float* __restrict__ csc_val, int32_t* __restrict__ uniq_sparse,
-    int32_t* __restrict__ d_cnt, const int32_t* __restrict__ big_list, PackStats* __restrict__ stats) {
-  __shared__ int wave_heads[BIG_THREADS / WAVE];
-  __shared__ int carry_s;
-  __shared__ int bad_s;
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
-  const int n_big = stats->n_big;
-  for (int b = blockIdx.x; b < n_big; b += gridDim.x) {
-    const int64_t e = big_list[b];
-    const int64_t r0 = ent_row_ptr[e], z0 = ent_nnz_ptr[e];
-    const int n = (int)(ent_row_ptr[e + 1] - r0);
-    const int nnz = (int)(ent_nnz_ptr[e + 1] - z0);
-    unsigned long long* keys = sort_key + z0;
-    const int32_t* rp = row_ptr + r0 + e;
-    if (tid == 0) { carry_s = 0; bad_s = 0; }
-    __syncthreads();
-    bool bad = false;
-    for (int k = tid; k < nnz; k += BIG_THREADS) {
-      const int64_t c = col_global[z0 + k];
-      bad |= (c < 0 || c > 0x7fffffffll);
-      keys[k] = ((unsigned long long)(uint32_t)c << 32) | (unsigned)k;
-    }
-    if (bad) bad_s = 1;
-    __syncthreads();
-    // bitonic network, all comparators ascending (indices >= nnz act as +inf)
-    int np2 = 1;
-    while (np2 < nnz) np2 <<= 1;
-    const int half = np2 >> 1;
-    for (int k = 2; k <= np2; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int t = tid; t < half; t += BIG_THREADS) {
-          int i, partner;
-          const int blk = t / j, off = t - blk * j;
-          if (j == (k >> 1)) { i = blk * k + off; partner = blk * k + (k - 1 - off); }
-          else { i = blk * 2 * j + off; partner = i + j; }
-          if (partner < nnz) {
-            const unsigned long long x = keys[i], y = keys[partner];
-            if (x > y) { keys[i] = y; keys[partner] = x; }
-          }
-        }
-        __syncthreads();
-      }
-    }
-    // outputs; local index = number of column heads at or before the key
-    int32_t* const cp = col_ptr + z0 + e;
-    for (int base = 0; base < nnz; base += BIG_THREADS) {
-      const int k = base + tid;
-      bool head = false;
-      unsigned long long key = 0;
-      if (k < nnz) {
-        key = keys[k];
-        unsigned long long prev = ~key;
-        if (k > 0) prev = keys[k - 1];
-        head = (prev >> 32) != (key >> 32);
-      }
-      const unsigned long long mask = __ballot(head);
-      if (lane == 0) wave_heads[wv] = __popcll(mask);
-      __syncthreads();
-      int before = carry_s;
-      for (int w = 0; w < wv; ++w) before += wave_heads[w];
-      const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-      const int lid = before + __popcll(mask & below) - 1;
-      if (k < nnz) {
-        const int pos = (int)(key & 0xffffffffull);
-        if (head) { uniq_sparse[z0 + lid] = (int32_t)(key >> 32); cp[lid] = k; }
-        csr_col[z0 + pos] = lid;
-        csc_val[z0 + k] = val[z0 + pos];
-        int lo = 0, hi = n - 1;
-        while (lo < hi) {
-          const int mid = (lo + hi + 1) >> 1;
-          if (rp[mid] <= pos) lo = mid; else hi = mid - 1;
-        }
-        csc_row[z0 + k] = lo;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        int tot = 0;
-        for (int w = 0; w < BIG_THREADS / WAVE; ++w) tot += wave_heads[w];
-        carry_s += tot;
-      }
-      __syncthreads();
-    }
-    if (tid == 0) {
-      const int d = carry_s;
-      cp[d] = nnz;
-      d_cnt[e] = d;
-      atomicMax(&stats->max_p, d + ic);
-      if (bad_s) atomicExch(&stats->err, GDMIX_RE_ERANGE);
-    }
-    __syncthreads();
   }
 }
 
@@ -495,21 +399,32 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
   // workgroup + in-place sort in HBM scratch. The later tiers read their entity lists from device counters
   // (usually empty: the fixed grids exit at once).
   hipLaunchKernelGGL((pack_entity_kernel<PACK_LDS_KEYS, PACK_WAVES>), dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s,
-                     (const int32_t*)nullptr, (const int*)nullptr, mid_list, &stats->n_mid, raw->ent_row_ptr,
+                     (const int32_t*)nullptr, (const int*)nullptr, mid_list, &stats->n_mid, (unsigned long long*)nullptr,
+                     raw->ent_row_ptr,
                      raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
                      out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
   DBG_STAGE("pack_entity_kernel<256>");
   hipLaunchKernelGGL((pack_entity_kernel<1024, 2>), dim3(ctx->num_cus * 4), dim3(WAVE * 2), 0, s,
-                     (const int32_t*)mid_list, (const int*)&stats->n_mid, big_list, &stats->n_big, raw->ent_row_ptr,
+                     (const int32_t*)mid_list, (const int*)&stats->n_mid, big_list, &stats->n_big, &stats->big_nnz,
+                     raw->ent_row_ptr,
                      raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
                      out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
   DBG_STAGE("pack_entity_kernel<1024>");
-  // entities too large for the wavefront kernel (stats->n_big of them, usually none): the grid is fixed, idle
-  // workgroups exit at once
-  hipLaunchKernelGGL(pack_big_kernel, dim3(ctx->num_cus), dim3(BIG_THREADS), 0, s, raw->ent_row_ptr, out->ent_nnz_ptr,
-                     raw->col_global, raw->val, ic, out->row_ptr, sort_key, out->csr_col, out->col_ptr, out->csc_row,
-                     out->csc_val, uniq_sparse, d_cnt, big_list, stats);
-  DBG_STAGE("pack_big_kernel");
+  // entities too large for the wavefront kernels (usually none): one device-wide sort over all of them. Their
+  // number and size are only known on the device, hence the read-back in the middle of the pack.
+  {
+    PackStats* hs = reinterpret_cast<PackStats*>(ctx->host_pinned);
+    HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(PackStats), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (hs->n_big > 0) {
+      BigPackArgs A{raw->ent_row_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, ic, out->row_ptr, out->csr_col,
+                    out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, big_list, hs->n_big,
+                    (int64_t)hs->big_nnz, &stats->max_p, &stats->err};
+      const int rc = pack_big_entities(ctx, A, s);
+      if (rc != GDMIX_RE_OK) return rc;
+    }
+  }
+  DBG_STAGE("pack_big_entities");
   const int nb = (int)((E + SCAN_CHUNK - 1) / SCAN_CHUNK);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, s, d_cnt, E, block_sums);
   hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1), 0, s, block_sums, nb, stats);

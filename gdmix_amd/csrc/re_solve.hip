@@ -8,6 +8,7 @@
 //                                          L-BFGS state lives in a per-workgroup global scratch slot
 //   re_score_kernel                        logits X~theta + offset
 #include "re_internal.hpp"
+#include "re_solve_team.hpp"
 
 namespace gdmix {
 
@@ -31,7 +32,7 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
     const int want_epl = (m <= M_REG) ? (p <= WAVE ? 1 : (p <= 2 * WAVE ? 2 : (p <= 4 * WAVE ? 4 : (p <= 8 * WAVE ? 8 : 0)))) : 0;
     const size_t wreg_bytes = wreg_lds_bytes(p, n, z, d, has_w);
     const size_t wlds_bytes = wave_lds_bytes(p, n, z, d, m, has_w);
-    for (int k = 0; k < GDMIX_RE_NUM_CLASSES - 1; ++k) {
+    for (int k = 0; k < BLOCK_CLASS; ++k) {
       if (tab.lds_bytes[k] <= 0) continue;
       const int kind = tab.kind[k];
       if (group_lanes(kind) > 0) {
@@ -44,6 +45,8 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
         if (wlds_bytes <= (size_t)tab.lds_bytes[k]) { c = k; break; }
       }
     }
+    if (tab.giant_nnz > 0 && z >= tab.giant_nnz) c = GIANT_CLASS;
+    else if (tab.team_nnz > 0 && z >= tab.team_nnz) c = XTEAM_CLASS;
     cls_out[e] = c;
     atomicAdd(&local[c], 1);
   }
@@ -109,7 +112,7 @@ hipError_t launch_order(const gdmix_re_packed* b, const int32_t* cls_tmp, const 
 template <class G>
 __device__ __forceinline__ void write_results(G& grp, const OutDev& O, const SolveParams& o, int64_t e, int64_t c0,
                                               int p, const double* x, const SolveStats& st) {
-  for (int j = grp.tid; j < p; j += G::NT) {
+  for (int j = grp.tid; j < p; j += grp.NT) {
     const double v = x[j];
     if (O.theta) O.theta[c0 + j] = v;
     // threshold_coefficients: |x| <= threshold -> 0.0, intercept included (util/model_utils.py:4-12)
@@ -596,13 +599,118 @@ __global__ __launch_bounds__(WAVE* BLOCK_NW) void re_solve_block_kernel(BatchDev
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// team kernels (re_solve_team.hpp): compact-form L-BFGS with X and the state vectors in HBM.
+//   GRID = false  one workgroup per entity, entities strided over the grid, one scratch slot per workgroup
+//   GRID = true   a persistent grid of one workgroup per CU split into `teams` teams (workgroup b belongs to
+//                 team b % teams: with 8 teams that is one XCD each, which only matters for speed); every team
+//                 takes entities team, team + teams, ... of the class, one after another
+// ---------------------------------------------------------------------------------------------------
+template <int NW, bool GRID>
+__global__ __launch_bounds__(WAVE* NW) void re_solve_team_kernel(BatchDev B, OutDev O, SolveParams o,
+                                                                 const double* __restrict__ theta0, int begin, int count,
+                                                                 double* scratch, size_t slot_doubles, int64_t max_p,
+                                                                 TeamSync* gs, int teams) {
+  __shared__ TeamLds<NW> lds;
+  const int ic = o.has_intercept ? 1 : 0;
+  const int m = o.m;
+  Team<NW> tm;
+  int team = 0;
+  if (GRID) {
+    team = (int)blockIdx.x % teams;
+    tm.bid = blockIdx.x / teams;
+    tm.nblocks = gridDim.x / teams;
+    tm.tid = (int)(tm.bid * blockDim.x + threadIdx.x);
+    tm.NT = (int)(tm.nblocks * blockDim.x);
+    gs += team;
+  } else {
+    tm.tid = (int)threadIdx.x;
+    tm.NT = WAVE * NW;
+    tm.nblocks = 1;
+    tm.bid = 0;
+  }
+  tm.wid = tm.tid >> 6;
+  tm.nwaves = tm.NT >> 6;
+  tm.lane = (int)threadIdx.x & (WAVE - 1);
+  tm.gs = gs;
+  tm.L = &lds;
+  tm.epoch = 0;
+  tm.phase = 0;
+  double* slot = scratch + (size_t)(GRID ? team : (int)blockIdx.x) * slot_doubles;
+  for (int idx = GRID ? team : (int)blockIdx.x; idx < count; idx += GRID ? teams : (int)gridDim.x) {
+    const int64_t e = B.order[begin + idx];
+    const int64_t r0 = B.ent_row_ptr[e], z0 = B.ent_nnz_ptr[e], f0 = B.ent_feat_ptr[e];
+    const int n = (int)(B.ent_row_ptr[e + 1] - r0);
+    const int d = (int)(B.ent_feat_ptr[e + 1] - f0);
+    const int p = d + ic;
+    const int64_t c0 = f0 + e * ic;
+    double* dp = slot;
+    Work W;
+    W.x = dp; dp += max_p;
+    W.g = dp; dp += max_p;
+    W.d = dp; dp += max_p;
+    W.t = dp; dp += max_p;
+    W.r = dp; dp += max_p;
+    W.ws = dp; dp += (size_t)m * max_p;
+    W.wy = dp; dp += (size_t)m * max_p;
+    W.alpha = dp; dp += m;
+    W.rho = dp; dp += m;
+    W.rs = dp;
+    for (int j = tm.tid; j < p; j += tm.NT) W.x[j] = theta0 ? theta0[c0 + j] : 0.0;
+    EntityView P{n, d, p, ic, B.row_ptr + r0 + e, B.csr_col + z0, B.csr_val + z0, B.col_ptr + z0 + e,
+                 B.csc_row + z0, B.csc_val + z0, B.y + r0, B.offset + r0, B.weight ? B.weight + r0 : nullptr};
+    SolveStats st;
+    team_solve(tm, P, o, W, st);
+    TeamAsGroup<NW> grp{tm, tm.tid, tm.NT};
+    write_results(grp, O, o, e, c0, p, W.x, st);
+    if (o.variance_mode == GDMIX_RE_VAR_SIMPLE && O.variance) variance_simple(grp, P, o, W, O.variance + c0);
+    tm.sync();   // the slot is reused by the next entity
+  }
+}
+
+template <int NW>
+static hipError_t launch_team_block(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
+                                    int begin, int count, double* scratch, size_t slot_doubles, int slots,
+                                    int64_t max_p, hipStream_t s) {
+  int grid = count < slots ? count : slots;
+  hipLaunchKernelGGL((re_solve_team_kernel<NW, false>), dim3(grid), dim3(WAVE * NW), 0, s, B, O, o, theta0, begin,
+                     count, scratch, slot_doubles, max_p, static_cast<TeamSync*>(nullptr), 1);
+  return hipGetLastError();
+}
+
 hipError_t launch_solve_block(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
                               int begin, int count, double* scratch, size_t slot_doubles, int slots,
                               int64_t max_p, hipStream_t s) {
   if (count <= 0) return hipSuccess;
-  int grid = count < slots ? count : slots;
-  hipLaunchKernelGGL(re_solve_block_kernel, dim3(grid), dim3(WAVE * BLOCK_NW), 0, s, B, O, o, theta0, begin, count,
-                     scratch, slot_doubles, max_p);
+  if (o.m > TEAM_MCAP) {   // two-loop form, any m
+    int grid = count < slots ? count : slots;
+    hipLaunchKernelGGL(re_solve_block_kernel, dim3(grid), dim3(WAVE * BLOCK_NW), 0, s, B, O, o, theta0, begin, count,
+                       scratch, slot_doubles, max_p);
+    return hipGetLastError();
+  }
+  return launch_team_block<TEAM_BLOCK_NW>(B, O, o, theta0, begin, count, scratch, slot_doubles, slots, max_p, s);
+}
+
+hipError_t launch_solve_grid(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
+                             int begin, int count, double* scratch, size_t slot_doubles, int64_t max_p,
+                             void* sync_buf, int blocks, int teams, hipStream_t s) {
+  if (count <= 0) return hipSuccess;
+  if (teams < 1 || teams > TEAM_MAX_TEAMS) return hipErrorInvalidValue;
+  blocks -= blocks % teams;
+  if (blocks > TEAM_MAX_BLOCKS * teams) blocks = TEAM_MAX_BLOCKS * teams;
+  if (blocks < teams) return hipErrorInvalidValue;
+  // the persistent grid must be fully resident: one workgroup per CU, which the register budget must admit
+  int per_cu = 0;
+  hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, re_solve_team_kernel<TEAM_GRID_NW, true>,
+                                                               WAVE * TEAM_GRID_NW, 0);
+  if (err != hipSuccess) return err;
+  if (per_cu < 1) return hipErrorLaunchOutOfResources;
+  for (int t = 0; t < teams; ++t) {
+    err = hipMemsetAsync(static_cast<TeamSync*>(sync_buf) + t, 0, 64, s);
+    if (err != hipSuccess) return err;
+  }
+  hipLaunchKernelGGL((re_solve_team_kernel<TEAM_GRID_NW, true>), dim3(blocks), dim3(WAVE * TEAM_GRID_NW), 0, s, B, O, o,
+                     theta0, begin, count, scratch, slot_doubles, max_p, static_cast<TeamSync*>(sync_buf), teams);
   return hipGetLastError();
 }
 

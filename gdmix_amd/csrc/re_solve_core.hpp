@@ -54,7 +54,7 @@ __device__ __forceinline__ double eval_fg(G& grp, const EntityView& P, const Sol
   double part = 0.0;   // per-thread partial of sum_i w_i*ce_i + (l2/2) * sum_j x_j^2
   double rpart = 0.0;  // per-thread partial of sum_i r_i (the intercept's gradient)
   const double x0 = ic ? x[0] : 0.0;
-  for (int i = grp.tid; i < n; i += G::NT) {
+  for (int i = grp.tid; i < n; i += grp.NT) {
     double acc = x0;
     const int k1 = P.row_ptr[i + 1];
     for (int k = P.row_ptr[i]; k < k1; ++k) acc += (double)P.csr_val[k] * x[ic + P.csr_col[k]];
@@ -68,13 +68,13 @@ __device__ __forceinline__ double eval_fg(G& grp, const EntityView& P, const Sol
   }
   const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
   double sq = 0.0;
-  for (int j = first_reg + grp.tid; j < p; j += G::NT) sq += x[j] * x[j];
+  for (int j = first_reg + grp.tid; j < p; j += grp.NT) sq += x[j] * x[j];
   part += 0.5 * o.l2 * sq;
   const double inv_n = 1.0 / (double)n;
   const double f = inv_n * grp.sum(part);
   const double rsum = grp.sum(rpart);   // also orders the rs[] writes before the reads below (block)
   grp.sync();
-  for (int j = grp.tid; j < p; j += G::NT) {
+  for (int j = grp.tid; j < p; j += grp.NT) {
     double acc;
     if (ic && j == 0) {
       acc = rsum;
@@ -94,14 +94,14 @@ __device__ __forceinline__ double eval_fg(G& grp, const EntityView& P, const Sol
 template <class G>
 __device__ __forceinline__ double dot(G& grp, const double* a, const double* b, int p) {
   double s = 0.0;
-  for (int j = grp.tid; j < p; j += G::NT) s += a[j] * b[j];
+  for (int j = grp.tid; j < p; j += grp.NT) s += a[j] * b[j];
   return grp.sum(s);
 }
 
 template <class G>
 __device__ __forceinline__ double maxabs(G& grp, const double* a, int p) {
   double s = 0.0;
-  for (int j = grp.tid; j < p; j += G::NT) s = fmax(s, fabs(a[j]));
+  for (int j = grp.tid; j < p; j += grp.NT) s = fmax(s, fabs(a[j]));
   return grp.max_nonneg(s);
 }
 
@@ -110,47 +110,125 @@ struct SolveStats {
   int nit, nfev, status;
 };
 
-// The whole fmin_l_bfgs_b run for one entity.
-// Synchronisation: element j of every p-vector is only ever touched by thread j mod NT, so the vector
-// updates need no barrier; the only cross-thread traffic is the x / rs gathers inside eval_fg.
+// Resumable state of one fmin_l_bfgs_b run (all values uniform across the cooperating threads). The
+// workgroup kernel keeps it in registers; the device-wide path for giant entities keeps it in HBM between
+// its kernels.
+struct LbfgsState {
+  LineSearch ls;
+  double f, fold, gdold, stp, theta, sbgnrm;
+  int col, head, nit, nfev, ifun, status, first, iter0;
+};
+
+__device__ __forceinline__ void lbfgs_init(LbfgsState& T) {
+  T.f = 0.0; T.fold = 0.0; T.gdold = 0.0; T.stp = 0.0; T.theta = 1.0; T.sbgnrm = 0.0;
+  T.col = 0; T.head = 0; T.nit = 0; T.nfev = 0; T.ifun = 0; T.status = -1; T.first = 1; T.iter0 = 1;
+}
+
+// One step of the driver: f_new and W.g are the objective and gradient at the trial point W.x. Advances the
+// algorithm until it needs another evaluation (next trial point left in W.x, T.status < 0) or stops
+// (T.status >= 0, result in W.x). Same rules as scipy's loop + L-BFGS-B's mainlb/lnsrlb.
+// Synchronisation: element j of every p-vector is only ever touched by thread j mod NT; W.x is synced before
+// returning because the evaluation gathers it across threads.
 template <class G>
-__device__ void lbfgs_solve(G& grp, const EntityView& P, const SolveParams& o, const Work& W, SolveStats& out) {
-  const int p = P.p, m = o.m;
+__device__ void lbfgs_advance(G& grp, int p, const SolveParams& o, const Work& W, LbfgsState& T, double f_new) {
+  const int m = o.m;
   double* alpha = W.alpha;
   double* rho = W.rho;
-  int col = 0, head = 0;
-  double theta = 1.0;
-  int nit = 0, nfev = 1, status = -1;
-  bool iter0 = true;
-  double f = eval_fg(grp, P, o, W);
-  double sbgnrm = maxabs(grp, W.g, p);
-  if (sbgnrm <= o.pgtol) status = 0;
-  while (status < 0) {
-    // ---- direction: two-loop recursion over the stored pairs, H0 = (1/theta) I ------------------
-    for (int j = grp.tid; j < p; j += G::NT) W.d[j] = -W.g[j];
-    if (col > 0) {
-      for (int a = col - 1; a >= 0; --a) {
-        int sl = head + a; if (sl >= m) sl -= m;
+  ++T.nfev;
+  bool need_dir = false, restart = false;
+  if (T.first) {
+    T.first = 0;
+    T.f = f_new;
+    T.sbgnrm = maxabs(grp, W.g, p);
+    if (T.sbgnrm <= o.pgtol) { T.status = 0; return; }
+    need_dir = true;
+  } else {
+    T.f = f_new;
+    const double gd = dot(grp, W.g, W.d, p);
+    double stp = T.stp;
+    const int task = dcsrch_step(T.ls, f_new, gd, stp);
+    T.stp = stp;
+    if (task == LS_FG) {
+      ++T.ifun;
+      if (T.ifun - 1 < o.maxls) {
+        for (int j = grp.tid; j < p; j += grp.NT) W.x[j] = stp * W.d[j] + W.t[j];   // stp == 1: exactly t + d
+        grp.sync();
+        return;
+      }
+      restart = true;   // iback >= maxls
+      need_dir = true;
+    } else {
+      // NEW_X: scipy's python loop first (nit / maxiter / maxfun), then mainlb's own tests
+      ++T.nit;
+      T.iter0 = 0;
+      T.sbgnrm = maxabs(grp, W.g, p);
+      if (T.nit >= o.max_iter) { T.status = 2; return; }
+      if (T.nfev > o.maxfun) { T.status = 3; return; }
+      if (T.sbgnrm <= o.pgtol) { T.status = 0; return; }
+      {
+        const double ddum = fmax(fabs(T.fold), fmax(fabs(T.f), 1.0));
+        if (T.fold - T.f <= o.ftol * ddum) { T.status = 1; return; }
+      }
+      // pair update: s = stp*d, y = g - g_old; skipped when s'y <= epsmch * (-g_old'd*stp)
+      double rrp = 0.0;
+      for (int j = grp.tid; j < p; j += grp.NT) {
+        const double yj = W.g[j] - W.r[j];
+        W.r[j] = yj;
+        rrp += yj * yj;
+      }
+      const double rr = grp.sum(rrp);
+      double dr, ddum;
+      if (stp == 1.0) { dr = gd - T.gdold; ddum = -T.gdold; }
+      else { dr = (gd - T.gdold) * stp; ddum = -T.gdold * stp; }
+      if (dr > EPSMCH * ddum) {
+        int sl;
+        if (T.col < m) { sl = T.head + T.col; if (sl >= m) sl -= m; ++T.col; }
+        else { sl = T.head; ++T.head; if (T.head >= m) T.head = 0; }
+        double* s = W.ws + (size_t)sl * p;
+        double* yv = W.wy + (size_t)sl * p;
+        for (int j = grp.tid; j < p; j += grp.NT) {
+          s[j] = stp * W.d[j];   // exact for stp == 1
+          yv[j] = W.r[j];
+        }
+        rho[sl] = 1.0 / dr;
+        T.theta = rr / dr;
+      }
+      need_dir = true;
+    }
+  }
+  while (need_dir) {
+    if (restart) {
+      for (int j = grp.tid; j < p; j += grp.NT) { W.x[j] = W.t[j]; W.g[j] = W.r[j]; }
+      T.f = T.fold;
+      restart = false;
+      if (T.col == 0) { T.status = 4; grp.sync(); return; }
+      T.col = 0; T.head = 0; T.theta = 1.0;
+    }
+    // direction: two-loop recursion over the stored pairs, H0 = (1/theta) I
+    for (int j = grp.tid; j < p; j += grp.NT) W.d[j] = -W.g[j];
+    if (T.col > 0) {
+      for (int a = T.col - 1; a >= 0; --a) {
+        int sl = T.head + a; if (sl >= m) sl -= m;
         const double* s = W.ws + (size_t)sl * p;
         const double* yv = W.wy + (size_t)sl * p;
         const double al = rho[sl] * dot(grp, s, W.d, p);
         alpha[a] = al;
-        for (int j = grp.tid; j < p; j += G::NT) W.d[j] -= al * yv[j];
+        for (int j = grp.tid; j < p; j += grp.NT) W.d[j] -= al * yv[j];
       }
-      const double h0 = 1.0 / theta;
-      for (int j = grp.tid; j < p; j += G::NT) W.d[j] *= h0;
-      for (int a = 0; a < col; ++a) {
-        int sl = head + a; if (sl >= m) sl -= m;
+      const double h0 = 1.0 / T.theta;
+      for (int j = grp.tid; j < p; j += grp.NT) W.d[j] *= h0;
+      for (int a = 0; a < T.col; ++a) {
+        int sl = T.head + a; if (sl >= m) sl -= m;
         const double* s = W.ws + (size_t)sl * p;
         const double* yv = W.wy + (size_t)sl * p;
         const double beta = rho[sl] * dot(grp, yv, W.d, p);
         const double c = alpha[a] - beta;
-        for (int j = grp.tid; j < p; j += G::NT) W.d[j] += c * s[j];
+        for (int j = grp.tid; j < p; j += grp.NT) W.d[j] += c * s[j];
       }
     }
     // z = x + d ; d = z - x  (mainlb re-derives d from the subspace point); save x, g
     double dd = 0.0, gdp = 0.0;
-    for (int j = grp.tid; j < p; j += G::NT) {
+    for (int j = grp.tid; j < p; j += grp.NT) {
       const double xj = W.x[j];
       const double z = xj + W.d[j];
       const double dj = z - xj;
@@ -162,80 +240,34 @@ __device__ void lbfgs_solve(G& grp, const EntityView& P, const SolveParams& o, c
       gdp += gj * dj;
     }
     const double dnorm = sqrt(grp.sum(dd));
-    double gd = grp.sum(gdp);
-    const double gdold = gd;
-    double stp = iter0 ? fmin(1.0 / dnorm, LS_STPMAX) : 1.0;
-    const double fold = f;
-    bool restart = false;
-    if (gd >= 0.0) {
-      restart = true;   // lnsrlb info = -4
-    } else {
-      LineSearch S;
-      dcsrch_start(S, f, gd, stp);
-      int ifun = 0;
-      for (;;) {
-        ++ifun;
-        if (ifun - 1 >= o.maxls) { restart = true; break; }
-        if (stp == 1.0) {
-          for (int j = grp.tid; j < p; j += G::NT) W.x[j] = W.t[j] + W.d[j];
-        } else {
-          for (int j = grp.tid; j < p; j += G::NT) W.x[j] = stp * W.d[j] + W.t[j];
-        }
-        grp.sync();
-        f = eval_fg(grp, P, o, W);
-        ++nfev;
-        gd = dot(grp, W.g, W.d, p);
-        if (dcsrch_step(S, f, gd, stp) != LS_FG) break;
-      }
-    }
-    if (restart) {
-      for (int j = grp.tid; j < p; j += G::NT) { W.x[j] = W.t[j]; W.g[j] = W.r[j]; }
-      grp.sync();
-      f = fold;
-      if (col == 0) { status = 4; break; }
-      col = 0; head = 0; theta = 1.0;
-      continue;
-    }
-    // ---- NEW_X: scipy's python loop first (nit / maxiter / maxfun), then mainlb's own tests ------
-    ++nit;
-    iter0 = false;
-    sbgnrm = maxabs(grp, W.g, p);
-    if (nit >= o.max_iter) { status = 2; break; }
-    if (nfev > o.maxfun) { status = 3; break; }
-    if (sbgnrm <= o.pgtol) { status = 0; break; }
-    {
-      const double ddum = fmax(fabs(fold), fmax(fabs(f), 1.0));
-      if (fold - f <= o.ftol * ddum) { status = 1; break; }
-    }
-    // ---- pair update: s = stp*d, y = g - g_old; skipped when s'y <= epsmch * (-g_old'd*stp) ------
-    double rrp = 0.0;
-    for (int j = grp.tid; j < p; j += G::NT) {
-      const double yj = W.g[j] - W.r[j];
-      W.r[j] = yj;
-      rrp += yj * yj;
-    }
-    const double rr = grp.sum(rrp);
-    double dr, ddum;
-    if (stp == 1.0) { dr = gd - gdold; ddum = -gdold; }
-    else { dr = (gd - gdold) * stp; ddum = -gdold * stp; }
-    if (dr <= EPSMCH * ddum) continue;
-    int sl;
-    if (col < m) { sl = head + col; if (sl >= m) sl -= m; ++col; }
-    else { sl = head; ++head; if (head >= m) head = 0; }
-    double* s = W.ws + (size_t)sl * p;
-    double* yv = W.wy + (size_t)sl * p;
-    for (int j = grp.tid; j < p; j += G::NT) {
-      s[j] = (stp == 1.0) ? W.d[j] : stp * W.d[j];
-      yv[j] = W.r[j];
-    }
-    rho[sl] = 1.0 / dr;
-    theta = rr / dr;
+    const double gd = grp.sum(gdp);
+    T.gdold = gd;
+    T.fold = T.f;
+    if (gd >= 0.0) { restart = true; continue; }   // lnsrlb info = -4
+    const double stp = T.iter0 ? fmin(1.0 / dnorm, LS_STPMAX) : 1.0;
+    T.stp = stp;
+    dcsrch_start(T.ls, T.f, gd, stp);
+    T.ifun = 1;
+    for (int j = grp.tid; j < p; j += grp.NT) W.x[j] = stp * W.d[j] + W.t[j];
+    grp.sync();
+    need_dir = false;
   }
-  out.f = f;
-  out.gnorm = sbgnrm;
-  out.nit = nit;
-  out.nfev = nfev;
-  out.status = status;
+}
+
+// The whole fmin_l_bfgs_b run for one entity (wave-per-entity LDS kernel, workgroup-per-entity kernel).
+template <class G>
+__device__ void lbfgs_solve(G& grp, const EntityView& P, const SolveParams& o, const Work& W, SolveStats& out) {
+  LbfgsState T;
+  lbfgs_init(T);
+  do {
+    const double f = eval_fg(grp, P, o, W);
+    lbfgs_advance(grp, P.p, o, W, T, f);
+  } while (T.status < 0);
+  out.f = T.f;
+  out.gnorm = T.sbgnrm;
+  out.nit = T.nit;
+  out.nfev = T.nfev;
+  out.status = T.status;
 }
 
 // _compute_variance, SIMPLE mode (binary_logistic_regression.py:175-180): 1/(sum_i X~_ij^2 D_i + l2*[j reg] + 1e-12),
@@ -248,7 +280,7 @@ __device__ __forceinline__ void variance_simple(G& grp, const EntityView& P, con
   const double* __restrict__ x = W.x;
   const double x0 = ic ? x[0] : 0.0;
   double dpart = 0.0;
-  for (int i = grp.tid; i < n; i += G::NT) {
+  for (int i = grp.tid; i < n; i += grp.NT) {
     double acc = x0;
     const int k1 = P.row_ptr[i + 1];
     for (int k = P.row_ptr[i]; k < k1; ++k) acc += (double)P.csr_val[k] * x[ic + P.csr_col[k]];
@@ -261,7 +293,7 @@ __device__ __forceinline__ void variance_simple(G& grp, const EntityView& P, con
   const double dsum = grp.sum(dpart);
   grp.sync();
   const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
-  for (int j = grp.tid; j < p; j += G::NT) {
+  for (int j = grp.tid; j < p; j += grp.NT) {
     double h;
     if (ic && j == 0) {
       h = dsum;

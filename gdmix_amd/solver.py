@@ -18,7 +18,7 @@ from .batch import RawBatch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgdmix_re.so")
 
-NUM_CLASSES = 40
+NUM_CLASSES = 42
 STATUS_NAMES = ("PGTOL", "FACTR", "MAXITER", "MAXFUN", "ABNORMAL")
 VAR_NONE, VAR_SIMPLE, VAR_FULL = 0, 1, 2
 VARIANCE_MODES = {None: VAR_NONE, "simple": VAR_SIMPLE, "SIMPLE": VAR_SIMPLE, "full": VAR_FULL, "FULL": VAR_FULL,
@@ -63,7 +63,7 @@ EXPORTED_SYMBOLS = (
     "gdmix_re_abi_version", "gdmix_re_last_error", "gdmix_re_default_opts", "gdmix_re_create",
     "gdmix_re_destroy", "gdmix_re_pack_workspace_bytes", "gdmix_re_pack", "gdmix_re_solve",
     "gdmix_re_solve_scratch_bytes", "gdmix_re_set_scratch", "gdmix_re_set_wave_lds_limit", "gdmix_re_score",
-    "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask",
+    "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz",
     "gdmix_re_class_kernel_name", "gdmix_java_string_hash", "gdmix_java_partition_id",
     "gdmix_java_partition_ids_i64")
 
@@ -102,6 +102,8 @@ def load_library():
     lib.gdmix_re_set_scratch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.gdmix_re_set_wave_lds_limit.argtypes = [C.c_void_p, C.c_int]
     lib.gdmix_re_set_kernel_mask.argtypes = [C.c_void_p, C.c_int]
+    lib.gdmix_re_set_giant_nnz.argtypes = [C.c_void_p, C.c_int64]
+    lib.gdmix_re_set_team_nnz.argtypes = [C.c_void_p, C.c_int64]
     lib.gdmix_re_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.gdmix_re_last_solve_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.gdmix_re_score.argtypes = [C.c_void_p, C.POINTER(_Packed), C.c_int, C.c_void_p, C.c_void_p,
@@ -269,6 +271,14 @@ class REDeviceSolver:
     def set_kernel_mask(self, mask: int):
         """bit0: register-resident wave kernel, bit1: LDS-resident wave kernel (block kernel always on)."""
         _check(self.lib.gdmix_re_set_kernel_mask(self._h, int(mask)), "set_kernel_mask")
+
+    def set_giant_nnz(self, nnz: int):
+        """Entities with >= nnz non-zeros are solved by the device-wide kernel (0 = never)."""
+        _check(self.lib.gdmix_re_set_giant_nnz(self._h, int(nnz)), "set_giant_nnz")
+
+    def set_team_nnz(self, nnz: int):
+        """Entities with >= nnz non-zeros (below the giant threshold) are solved by the 8-team kernel (0 = never)."""
+        _check(self.lib.gdmix_re_set_team_nnz(self._h, int(nnz)), "set_team_nnz")
 
     def set_timing(self, enabled: bool):
         _check(self.lib.gdmix_re_set_timing(self._h, int(bool(enabled))), "set_timing")

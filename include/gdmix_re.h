@@ -59,6 +59,7 @@ extern "C" {
 #define GDMIX_RE_ST_MAXITER   2   /* STOP: TOTAL NO. of ITERATIONS REACHED LIMIT             */
 #define GDMIX_RE_ST_MAXFUN    3   /* STOP: TOTAL NO. of f AND g EVALUATIONS EXCEEDS LIMIT    */
 #define GDMIX_RE_ST_ABNORMAL  4   /* ABNORMAL_TERMINATION_IN_LNSRCH                          */
+#define GDMIX_RE_ST_ABORTED   9   /* device-wide kernel gave up waiting at a barrier (never expected; the result is invalid) */
 /* "converged" for the entities/sec metric = status in {PGTOL, FACTR, MAXITER}: the reference treats
  * all three as a finished model (job_consumers.py:36-63 never looks at warnflag). */
 
@@ -120,7 +121,7 @@ typedef struct {
   int32_t        max_p, max_n, max_nnz;  /* per-entity maxima over the batch (host, after pack)     */
 } gdmix_re_packed;
 
-#define GDMIX_RE_NUM_CLASSES 40
+#define GDMIX_RE_NUM_CLASSES 42
 
 /* ---- solver options (defaults = REParams/LRParams defaults + scipy defaults) ----------------------
  * base_lr_params.py:22-27, binary_logistic_regression.py:223-231 (pgtol/maxfun/maxls are scipy's). */
@@ -196,6 +197,14 @@ GDMIX_API int gdmix_re_set_wave_lds_limit(gdmix_re_ctx* ctx, int bytes);
  * kernel, bit 1 = LDS-resident wavefront kernel, bit 2 = four-entities-per-wavefront kernel; the workgroup
  * kernel is always available. Default 7. */
 GDMIX_API int gdmix_re_set_kernel_mask(gdmix_re_ctx* ctx, int mask);
+
+/* The head of a Zipf-distributed partition: entities with at least `giant_nnz` non-zeros are solved one after
+ * another by a persistent kernel spanning the whole device; entities with at least `team_nnz` (and fewer than
+ * giant_nnz) by the same kernel split into 8 teams of CUs (one XCD each), 8 entities at a time; smaller ones
+ * by one workgroup each. Defaults 524288 and 16384; 0 disables a tier. Results do not depend on the
+ * thresholds beyond summation order. */
+GDMIX_API int gdmix_re_set_giant_nnz(gdmix_re_ctx* ctx, int64_t giant_nnz);
+GDMIX_API int gdmix_re_set_team_nnz(gdmix_re_ctx* ctx, int64_t team_nnz);
 
 /* Optional kernel timing: when enabled, gdmix_re_solve brackets each size class's kernel launch with
  * HIP events on the caller's stream; gdmix_re_last_solve_ms waits for them and returns the elapsed

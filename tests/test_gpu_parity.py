@@ -54,7 +54,7 @@ def _check_pack(packed, pk, val):
     assert np.array_equal(packed.csc_val().cpu().numpy(), csc_val)
 
 
-def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7):
+def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, giant_nnz=524288, team_nnz=16384):
     b, opts, exp, _ = load_fixture(name)
     kw = opts_kwargs(opts)
     pk = oracle.pack(b.ent_row_ptr, b.row_nnz_ptr, b.col_global)
@@ -63,11 +63,15 @@ def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7):
     th0 = exp["theta0"] if np.any(exp["theta0"]) else None
     device_solver.set_wave_lds_limit(lds_limit)
     device_solver.set_kernel_mask(kernel_mask)
+    device_solver.set_giant_nnz(giant_nnz)
+    device_solver.set_team_nnz(team_nnz)
     try:
         res = device_solver.solve(packed, SolverOptions(**kw), theta0=th0).to_host()
     finally:
         device_solver.set_wave_lds_limit(65536)
         device_solver.set_kernel_mask(7)
+        device_solver.set_giant_nnz(524288)
+        device_solver.set_team_nnz(16384)
     ref = oracle.solve(pk, b.val, b.y, b.offset, b.weight, oracle.make_opts(**kw), theta0=th0)
     coef_ptr = packed.coef_ptr_host()
     wp = well_posed_mask(b, opts)
@@ -132,6 +136,20 @@ def test_block_kernel_matches_reference_fixture(device_solver, name):
     _solve_and_compare(device_solver, name, lds_limit=0)
 
 
+@pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "ragged", "ml_per_user", "warm_stage2", "tiny_entities_regbias",
+                                  "c2_no_intercept", "ragged_variance_simple", "c2_m3"])
+def test_device_wide_kernel_matches_reference_fixture(device_solver, name):
+    # giant threshold 1 sends every entity, one after another, through the persistent device-wide kernel
+    _solve_and_compare(device_solver, name, giant_nnz=1)
+
+
+@pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "ragged", "ml_per_user", "warm_stage2", "c2_no_intercept",
+                                  "ragged_variance_simple"])
+def test_eight_team_kernel_matches_reference_fixture(device_solver, name):
+    # every entity through the persistent kernel split into 8 teams of CUs, 8 entities at a time
+    _solve_and_compare(device_solver, name, giant_nnz=0, team_nnz=1)
+
+
 def test_results_are_bitwise_reproducible(device_solver):
     b = synthetic.make_batch(2000, 16, 4, 1024, seed=5)
     packed = device_solver.pack(b)
@@ -173,13 +191,25 @@ def test_large_and_giant_entities_pack_and_solve(device_solver):
     packed = device_solver.pack(b)
     _check_pack(packed, pk, b.val)
     assert packed.max_nnz == int(b.ent_nnz().max()) and packed.max_n == int(b.ent_n().max())
-    res = device_solver.solve(packed, SolverOptions(**kw)).to_host()
     ref = oracle.solve(pk, b.val, b.y, b.offset, None, oracle.make_opts(**kw))
     coef_ptr = packed.coef_ptr_host()
     wp = well_posed_mask(b, dict(l2=1.0, regularize_bias=False, has_intercept=True))
-    err = per_entity_rel_err(res["theta"], ref["theta"], coef_ptr)
-    assert err[wp].max() <= REL_TOL_DEVICE, err[wp].max()
-    assert np.array_equal(res["nit"][wp], ref["nit"][wp])
+    # the two 48k-nnz entities through each tier: workgroup kernel, 8-team kernel (default), device-wide kernel
+    for giant_nnz, team_nnz, cls in ((0, 0, "re_solve_team_kernel workgroup"), (524288, 16384, "re_solve_team_kernel 8 teams"),
+                                     (40000, 0, "re_solve_team_kernel device-wide")):
+        device_solver.set_giant_nnz(giant_nnz)
+        device_solver.set_team_nnz(team_nnz)
+        try:
+            res = device_solver.solve(packed, SolverOptions(**kw)).to_host()
+        finally:
+            device_solver.set_giant_nnz(524288)
+            device_solver.set_team_nnz(16384)
+        counts = dict(device_solver.class_counts(packed))
+        assert counts[cls] >= 2
+        err = per_entity_rel_err(res["theta"], ref["theta"], coef_ptr)
+        assert err[wp].max() <= REL_TOL_DEVICE, err[wp].max()
+        assert np.array_equal(res["nit"][wp], ref["nit"][wp])
+        assert np.array_equal(res["status"][wp], ref["status"][wp])
 
 
 def test_score_matches_reference_inference(device_solver):
