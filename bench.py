@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="entities per pass of the CPU baseline (0 = 200k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--giant-nnz", type=int, default=-1, help="override the device-wide kernel threshold (exploration)")
-    ap.add_argument("--team-nnz", type=int, default=-1, help="override the 8-team kernel threshold (exploration)")
+    ap.add_argument("--team-nnz", type=int, default=-1, help="override the 16-team kernel threshold (exploration)")
     ap.add_argument("--solve-only", action="store_true", help="time gdmix_re_solve alone (batch packed once)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c5mean", "zipf", "ml_user", "ml_movie"],
                     help="c2 (default, the benchmarked configuration) or an exploration shape")

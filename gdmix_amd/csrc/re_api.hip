@@ -57,7 +57,7 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_WREG8, 65536, "re_solve_wreg_kernel<8> lds<=64K"},
     {KIND_WLDS, 24576, "re_solve_wave_kernel lds<=24K"},     {KIND_WLDS, 65536, "re_solve_wave_kernel lds<=64K"},
     {KIND_BLOCK, 0, "re_solve_team_kernel workgroup"},
-    {KIND_GRID, 0, "re_solve_team_kernel 8 teams"},
+    {KIND_GRID, 0, "re_solve_team_kernel 16 teams"},
     {KIND_GRID, 0, "re_solve_team_kernel device-wide"}};
 
 __global__ void class_base_kernel(int32_t* cc) {
@@ -373,7 +373,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     }
     // the team kernels run after the workgroup kernel on the same stream, so its slots are free again
     if (hc[XTEAM_CLASS] > 0) {
-      int teams = 8;
+      int teams = 16;   // 16 CUs per entity, 16 entities at a time
       if (const char* ev = getenv("GDMIX_RE_TEAMS")) teams = atoi(ev);   // exploration knob
       if (teams > TEAM_MAX_TEAMS) teams = TEAM_MAX_TEAMS;
       if (teams < 1 || slots < teams) teams = 1;

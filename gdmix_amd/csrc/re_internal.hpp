@@ -32,7 +32,7 @@ __host__ __device__ inline int group_epl(int kind) {
   return kind == KIND_QUAD2 ? 2 : ((kind == KIND_QUAD3 || kind == KIND_PAIR3 || kind == KIND_G64_3) ? 3 : (group_lanes(kind) > 0 ? 4 : 0));
 }
 constexpr int GIANT_CLASS = GDMIX_RE_NUM_CLASSES - 1;   // device-wide kernel, one entity at a time
-constexpr int XTEAM_CLASS = GDMIX_RE_NUM_CLASSES - 2;   // one XCD's worth of CUs per entity, 8 at a time
+constexpr int XTEAM_CLASS = GDMIX_RE_NUM_CLASSES - 2;   // 16 CUs per entity, 16 entities at a time
 constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 3;
 constexpr int BLOCK_NW = 4;   // wavefronts per workgroup of the block kernel
 #ifndef GDMIX_TEAM_BLOCK_NW
@@ -47,7 +47,7 @@ struct ClassTable {
   int ncap[GDMIX_RE_NUM_CLASSES];        // quad classes: sample / non-zero capacity of a row's LDS block
   int zcap[GDMIX_RE_NUM_CLASSES];
   int64_t giant_nnz;   // 0 = device-wide kernel off
-  int64_t team_nnz;    // 0 = 8-team kernel off
+  int64_t team_nnz;    // 0 = 16-team kernel off
 };
 
 // Device pointers of a packed batch, passed by value to kernels.
@@ -88,7 +88,7 @@ struct gdmix_ctx_impl {
   int kernel_mask;        // bit0 register wave kernel, bit1 LDS wave kernel, bit2 quad kernel
   int timing;             // bracket class launches with events
   int64_t giant_nnz;      // entities with >= this many non-zeros use the device-wide kernel (0 = never)
-  int64_t team_nnz;       // ... the 8-team kernel (0 = never)
+  int64_t team_nnz;       // ... the 16-team kernel (0 = never)
   void* grid_sync;        // device: TeamSync of the team kernels
   void* big_tmp;          // device: grow-only temporary of the big-entity pack path
   size_t big_tmp_bytes;
@@ -105,7 +105,7 @@ __host__ __device__ inline size_t wave_lds_bytes(int p, int n, int nnz, int d, i
 
 // doubles of global scratch one block-kernel slot needs
 inline size_t block_slot_doubles(int64_t max_p, int64_t max_n, int m) {
-  return (size_t)(5 + 2 * m) * max_p + max_n + 2 * m + 8;
+  return (size_t)(5 + 2 * m) * max_p + max_n + 2 * m + 8 + 256 * 64;   // + partial sums of split columns (team kernels)
 }
 
 hipError_t launch_classify(const gdmix_re_packed* b, int ic, int m, const ClassTable& tab, int32_t* cls_tmp,

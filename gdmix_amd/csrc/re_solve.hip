@@ -600,10 +600,47 @@ __global__ __launch_bounds__(WAVE* BLOCK_NW) void re_solve_block_kernel(BatchDev
 }
 
 // ---------------------------------------------------------------------------------------------------
+// order of a class by size, largest first (the persistent team kernel hands entities out in this order so
+// that the long solves start first). One workgroup, bitonic sort in LDS; ties by entity index, so the order
+// and with it the launch are reproducible. Lists longer than SORT_CAP stay in ticket order.
+// ---------------------------------------------------------------------------------------------------
+constexpr int SORT_CAP = 4096;
+__global__ __launch_bounds__(1024) void re_sort_class_kernel(int32_t* __restrict__ list, int count,
+                                                             const int64_t* __restrict__ ent_nnz_ptr) {
+  __shared__ unsigned long long key[SORT_CAP];
+  int np2 = 1;
+  while (np2 < count) np2 <<= 1;
+  for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+    unsigned long long k = ~0ull;
+    if (i < count) {
+      const int64_t e = list[i];
+      const unsigned long long z = (unsigned long long)(ent_nnz_ptr[e + 1] - ent_nnz_ptr[e]);
+      k = ((0xffffffffull - (z & 0xffffffffull)) << 32) | (unsigned long long)(uint32_t)e;
+    }
+    key[i] = k;
+  }
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < np2; t += blockDim.x) {
+        const int partner = t ^ j;
+        if (partner > t) {
+          const unsigned long long a = key[t], b = key[partner];
+          const bool up = (t & k) == 0;
+          if ((a > b) == up) { key[t] = b; key[partner] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < count; i += blockDim.x) list[i] = (int32_t)(uint32_t)key[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // team kernels (re_solve_team.hpp): compact-form L-BFGS with X and the state vectors in HBM.
 //   GRID = false  one workgroup per entity, entities strided over the grid, one scratch slot per workgroup
 //   GRID = true   a persistent grid of one workgroup per CU split into `teams` teams (workgroup b belongs to
-//                 team b % teams: with 8 teams that is one XCD each, which only matters for speed); every team
+//                 team b % teams; placement only matters for speed); every team
 //                 takes entities team, team + teams, ... of the class, one after another
 // ---------------------------------------------------------------------------------------------------
 template <int NW, bool GRID>
@@ -637,7 +674,15 @@ __global__ __launch_bounds__(WAVE* NW) void re_solve_team_kernel(BatchDev B, Out
   tm.epoch = 0;
   tm.phase = 0;
   double* slot = scratch + (size_t)(GRID ? team : (int)blockIdx.x) * slot_doubles;
-  for (int idx = GRID ? team : (int)blockIdx.x; idx < count; idx += GRID ? teams : (int)gridDim.x) {
+  for (int idx = (int)blockIdx.x;; idx += (int)gridDim.x) {
+    if (GRID) {
+      // teams take the next entity of the class (largest first, re_sort_class_kernel) as they become free
+      if (tm.bid == 0 && threadIdx.x == 0)
+        gs->cur = (int)__hip_atomic_fetch_add(&(gs - team)->next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tm.sync();
+      idx = gs->cur;
+    }
+    if (idx >= count) break;
     const int64_t e = B.order[begin + idx];
     const int64_t r0 = B.ent_row_ptr[e], z0 = B.ent_nnz_ptr[e], f0 = B.ent_feat_ptr[e];
     const int n = (int)(B.ent_row_ptr[e + 1] - r0);
@@ -655,6 +700,7 @@ __global__ __launch_bounds__(WAVE* NW) void re_solve_team_kernel(BatchDev B, Out
     W.wy = dp; dp += (size_t)m * max_p;
     W.alpha = dp; dp += m;
     W.rho = dp; dp += m;
+    W.part = dp; dp += TEAM_LONG_CAP * WAVE;
     W.rs = dp;
     for (int j = tm.tid; j < p; j += tm.NT) W.x[j] = theta0 ? theta0[c0 + j] : 0.0;
     EntityView P{n, d, p, ic, B.row_ptr + r0 + e, B.csr_col + z0, B.csr_val + z0, B.col_ptr + z0 + e,
@@ -709,6 +755,9 @@ hipError_t launch_solve_grid(const BatchDev& B, const OutDev& O, const SolvePara
     err = hipMemsetAsync(static_cast<TeamSync*>(sync_buf) + t, 0, 64, s);
     if (err != hipSuccess) return err;
   }
+  if (count > 1 && count <= SORT_CAP)
+    hipLaunchKernelGGL(re_sort_class_kernel, dim3(1), dim3(1024), 0, s, const_cast<int32_t*>(B.order) + begin, count,
+                       B.ent_nnz_ptr);
   hipLaunchKernelGGL((re_solve_team_kernel<TEAM_GRID_NW, true>), dim3(blocks), dim3(WAVE * TEAM_GRID_NW), 0, s, B, O, o,
                      theta0, begin, count, scratch, slot_doubles, max_p, static_cast<TeamSync*>(sync_buf), teams);
   return hipGetLastError();

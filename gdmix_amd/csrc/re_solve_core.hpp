@@ -41,6 +41,7 @@ struct Work {
   double* rs;   // [n] per-sample residual w*(sigma(z)-y)
   double* alpha;  // [m] two-loop coefficients (uniform; every thread stores the same value)
   double* rho;    // [m] 1/(s'y) per history slot (uniform)
+  double* part;   // team kernels: [TEAM_LONG_CAP * 64] partial sums of split columns
 };
 
 constexpr double EPSMCH = 2.220446049250313e-16;

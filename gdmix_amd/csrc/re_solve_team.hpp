@@ -22,19 +22,34 @@
 
 namespace gdmix {
 
+// -DGDMIX_TEAM_PROFILE: thread 0 of a team's first workgroup accumulates wall-clock ticks (100 MHz) per phase
+// and prints them per entity. Exploration only.
+#ifdef GDMIX_TEAM_PROFILE
+#define TEAM_PROF_DECL unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_last = wall_clock64();
+#define TEAM_PROF(i) do { const unsigned long long _n = wall_clock64(); prof_t[i] += _n - prof_last; prof_last = _n; } while (0)
+#else
+#define TEAM_PROF_DECL
+#define TEAM_PROF(i) do { } while (0)
+#endif
+
 constexpr int TEAM_MCAP = 10;                 // history pairs the compact path keeps accumulators for
 constexpr int TEAM_K = 2 * TEAM_MCAP + 6;     // fused reduction width: sq, gd, gg, rr, gr, S'g, Y'g, max|g|
 constexpr int TEAM_VEC = 32;                  // doubles per workgroup slot of the device-wide exchange buffer
 constexpr int TEAM_MAX_BLOCKS = 256;           // workgroups per team
 constexpr int TEAM_MAX_TEAMS = 32;
 constexpr int TEAM_SHORT_COL = 16;            // tiles whose columns are all this short: one lane per column
+constexpr int TEAM_CHUNK = 512;               // CSC entries a wavefront stages through LDS at a time
+constexpr int TEAM_LONGC = 2048;              // columns at least this long are split over the team in 64 slices
+constexpr int TEAM_LONG_CAP = 256;            // such columns per entity (more: none is split)
 
 // Exchange buffer of a multi-workgroup team (HBM).
 struct TeamSync {
   unsigned count;    // barrier arrivals, monotonic inside a launch (zeroed by a memset node before it)
   unsigned abort;    // a workgroup gave up waiting (never expected; keeps a lost workgroup from hanging the GPU)
-  unsigned pad[14];
-  double vec[2][TEAM_MAX_BLOCKS][TEAM_VEC];
+  unsigned next;     // team 0's copy: next entity of the class to hand out
+  int cur;           // entity this team is working on
+  unsigned pad[12];
+  double vec[2][TEAM_VEC][TEAM_MAX_BLOCKS];   // [phase][value][workgroup]
 };
 
 // LDS of one workgroup of a team.
@@ -48,6 +63,10 @@ struct TeamLds {
   double la[TEAM_MCAP], lb[TEAM_MCAP];
   double u[TEAM_MCAP], q[TEAM_MCAP];
   double sc[4];
+  double buf[NW][TEAM_CHUNK];     // per-wavefront staging of val * r products
+  int llist[TEAM_LONG_CAP];       // long columns of the entity, ascending
+  int lraw[TEAM_LONG_CAP];
+  int n_long, n_long_raw;
 };
 
 template <int NW>
@@ -125,19 +144,32 @@ struct Team {
         const double t = L->red[ph][ww][threadIdx.x];
         s = (threadIdx.x == K - 1) ? fmax(s, t) : s + t;
       }
-      if (nblocks > 1) gs->vec[ph][bid][threadIdx.x] = s;
+      if (nblocks > 1) gs->vec[ph][threadIdx.x][bid] = s;
       else L->out[ph][threadIdx.x] = s;
     }
     if (nblocks > 1) {
       device_barrier();
-      for (int k = w; k < K; k += NW) {
-        double s = 0.0;
-        for (unsigned b = lane; b < nblocks; b += WAVE) {
-          const double t = gs->vec[ph][b][k];
-          s = (k == K - 1) ? fmax(s, t) : s + t;
+      // wavefront w totals values w, w + NW, ...: every partial it needs is requested before the first is used
+      constexpr int KPW = (K + NW - 1) / NW;
+      constexpr int BPL = TEAM_MAX_BLOCKS / WAVE;
+      double t[KPW][BPL];
+#pragma unroll
+      for (int i = 0; i < KPW; ++i) {
+        const int k = w + i * NW;
+#pragma unroll
+        for (int j = 0; j < BPL; ++j) {
+          const unsigned b = lane + j * WAVE;
+          t[i][j] = (k < K && b < nblocks) ? gs->vec[ph][k][b] : 0.0;
         }
+      }
+#pragma unroll
+      for (int i = 0; i < KPW; ++i) {
+        const int k = w + i * NW;
+        double s = t[i][0];
+#pragma unroll
+        for (int j = 1; j < BPL; ++j) s = (k == K - 1) ? fmax(s, t[i][j]) : s + t[i][j];
         s = (k == K - 1) ? wave_max_nonneg(s) : wave_sum(s);
-        if (lane == 0) L->out[ph][k] = s;
+        if (k < K && lane == 0) L->out[ph][k] = s;
       }
     }
     __syncthreads();
@@ -176,7 +208,11 @@ __device__ __forceinline__ double gather_dot8(const float* __restrict__ val, con
 // 1 g'd, 2 g'g, 3 (g-r)'(g-r), 4 g'r, 5.. S_i'g, 5+MCAP.. Y_i'g (chronological i < col), K-1 max|g_j|.
 template <int NW>
 __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W,
-                                            int col, int head, double (&acc)[TEAM_K]) {
+                                            int col, int head, double (&acc)[TEAM_K]
+#ifdef GDMIX_TEAM_PROFILE
+                                            , unsigned long long (&prof_t)[8], unsigned long long& prof_last
+#endif
+                                            ) {
   const int n = P.n, p = P.p, ic = P.ic, m = o.m;
   const double* __restrict__ x = W.x;
   // ---- rows: logits, per-sample loss and residual
@@ -192,47 +228,135 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
     W.rs[i] = ri;
     pr[1] += ri;
   }
+  TEAM_PROF(0);
   tm.reduce(pr);   // also makes rs[] visible to the whole team
+  TEAM_PROF(1);
   const double loss = pr[0], rsum = pr[1];
   // ---- columns: X'r by tiles of 64 coefficients per wavefront, lane c of the tile ends up owning column c
   const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
   const double inv_n = 1.0 / (double)n;
+  TeamLds<NW>& L = *tm.L;
+  const int n_long = L.n_long;
+  if (n_long > 0) {
+    // long columns first: 64 slices each, slices strided over the wavefronts of the team, partial sums to HBM
+    for (int item = tm.wid; item < n_long * WAVE; item += tm.nwaves) {
+      const int c = L.llist[item >> 6], sl = item & (WAVE - 1);
+      const int b0 = P.col_ptr[c], e0 = P.col_ptr[c + 1];
+      const int ssz = (e0 - b0 + WAVE - 1) >> 6;
+      const int k0 = b0 + sl * ssz;
+      const int k1 = (k0 + ssz < e0) ? k0 + ssz : e0;
+      double s = 0.0;
+      for (int k = k0 + tm.lane; k < k1; k += 8 * WAVE) {
+        float v[8];
+        int r[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int kk = k + q * WAVE;
+          const bool ok = kk < k1;
+          v[q] = ok ? P.csc_val[kk] : 0.0f;
+          r[q] = ok ? P.csc_row[kk] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (k + q * WAVE < k1) s += (double)v[q] * W.rs[r[q]];
+      }
+      s = wave_sum(s);
+      if (tm.lane == 0) W.part[item] = s;
+    }
+    tm.sync();
+  }
 #pragma unroll
   for (int k = 0; k < TEAM_K; ++k) acc[k] = 0.0;
+  double* const buf = L.buf[threadIdx.x >> 6];
   for (int tile = tm.wid; tile * WAVE < p; tile += tm.nwaves) {
     const int j = tile * WAVE + tm.lane;
     const bool valid = j < p;
     const bool feat = valid && !(ic && j == 0);
     int cb = 0, ce = 0;
     if (feat) { cb = P.col_ptr[j - ic]; ce = P.col_ptr[j - ic + 1]; }
-    const int maxlen = (int)wave_max_nonneg((double)(ce - cb));
+    // split columns: their sum comes from the partials
+    int li = -1;
+    if (n_long > 0 && ce - cb >= TEAM_LONGC) {
+      int lo = 0, hi = n_long - 1;
+      const int c = j - ic;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (L.llist[mid] < c) lo = mid + 1; else hi = mid;
+      }
+      li = (L.llist[lo] == c) ? lo : -1;
+    }
+    const int cbx = (li >= 0) ? ce : cb;   // empty range in the flat pass
+    const int maxlen = (int)wave_max_nonneg((double)(ce - cbx));
     double mine = 0.0;
     if (maxlen <= TEAM_SHORT_COL) {
-      mine = gather_dot8(P.csc_val, P.csc_row, W.rs, cb, ce, 0.0);
+      mine = gather_dot8(P.csc_val, P.csc_row, W.rs, cbx, ce, 0.0);
     } else {
-      // eight columns at a time, lanes striding each of them: one dependent gather chain per step
-      const int ncol = (p - tile * WAVE) < WAVE ? (p - tile * WAVE) : WAVE;
-      for (int c = 0; c < ncol; c += 8) {
-        int b[8], len = 0;
-        double s[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          b[q] = readlane_i(cb, c + q);
-          const int l = readlane_i(ce, c + q) - b[q];
-          len = l > len ? l : len;
-          s[q] = 0.0;
-        }
-        for (int off = tm.lane; off < len; off += WAVE) {
+      // the tile's columns are one contiguous run of the CSC arrays: the wavefront streams it in chunks (coalesced
+      // loads, eight per lane in flight), parks the products in LDS, and every lane adds up its own column's part
+      const int first = (ic && tile == 0) ? 1 : 0;
+      const int fb = readlane_i(cb, first);
+      const int fe = (int)wave_max_nonneg((double)ce);
+      for (int s0 = fb; s0 < fe; s0 += TEAM_CHUNK) {
+        const int s1 = (s0 + TEAM_CHUNK < fe) ? s0 + TEAM_CHUNK : fe;
+        const int lo = cbx > s0 ? cbx : s0;
+        const int hi = ce < s1 ? ce : s1;
+        const unsigned long long owners = __ballot(lo < hi);
+        if (owners == 0) continue;   // the chunk lies inside a split column
+        double pr8[8];
+        {
+          float v[8];
+          int r[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
-            const int k = b[q] + off;
-            if (k < readlane_i(ce, c + q)) s[q] += (double)P.csc_val[k] * W.rs[P.csc_row[k]];
+            const int kk = s0 + tm.lane + q * WAVE;
+            const bool ok = kk < s1;
+            v[q] = ok ? P.csc_val[kk] : 0.0f;
+            r[q] = ok ? P.csc_row[kk] : 0;
           }
-        }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const double t = wave_sum(s[q]);
-          if (tm.lane == c + q) mine = t;
+          for (int q = 0; q < 8; ++q) pr8[q] = (s0 + tm.lane + q * WAVE < s1) ? (double)v[q] * W.rs[r[q]] : 0.0;
+        }
+        if (__popcll(owners) == 1) {
+          // one column owns the whole chunk (other entries, if any, belong to split columns and are masked out)
+          const int own = __ffsll((long long)owners) - 1;
+          const int olo = readlane_i(lo, own), ohi = readlane_i(hi, own);
+          double t = 0.0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int kk = s0 + tm.lane + q * WAVE;
+            if (kk >= olo && kk < ohi) t += pr8[q];
+          }
+          t = wave_sum(t);
+          if (tm.lane == own) mine += t;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) buf[tm.lane + q * WAVE] = pr8[q];
+          wave_lds_fence();
+          for (int k = lo; k < hi; ++k) mine += buf[k - s0];
+          wave_lds_fence();
+        }
+      }
+    }
+    // split columns of this tile: 64 partials each, eight columns in flight
+    unsigned long long lm = __ballot(li >= 0);
+    while (lm) {
+      int cl[8];
+      double t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        cl[q] = -1;
+        t[q] = 0.0;
+        if (lm) {
+          cl[q] = __ffsll((long long)lm) - 1;
+          lm &= lm - 1;
+          t[q] = W.part[(size_t)readlane_i(li, cl[q]) * WAVE + tm.lane];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (cl[q] >= 0) {
+          const double tt = wave_sum(t[q]);
+          if (tm.lane == cl[q]) mine = tt;
         }
       }
     }
@@ -260,25 +384,60 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
       }
     }
   }
+  TEAM_PROF(2);
   tm.reduce(acc);
+  TEAM_PROF(3);
   return inv_n * (loss + 0.5 * o.l2 * acc[0]);
 }
 
 // The whole fmin_l_bfgs_b run for one entity by a team. Requires 1 <= o.m <= TEAM_MCAP. W.x holds theta0 on
 // entry (visible to the team), theta on exit.
+// Which columns get split (TEAM_LONGC): every workgroup scans all column lengths and ends with the same ascending
+// list in its LDS. More than TEAM_LONG_CAP of them: none is split (they are then streamed by their tile's wavefront).
+template <int NW>
+__device__ __forceinline__ void team_long_setup(Team<NW>& tm, const EntityView& P) {
+  TeamLds<NW>& L = *tm.L;
+  if (threadIdx.x == 0) { L.n_long = 0; L.n_long_raw = 0; }
+  __syncthreads();
+  if (P.col_ptr[P.d] < TEAM_LONGC) return;   // uniform: fewer non-zeros than one long column
+  for (int c = threadIdx.x; c < P.d; c += blockDim.x) {
+    if (P.col_ptr[c + 1] - P.col_ptr[c] >= TEAM_LONGC) {
+      const int pos = atomicAdd(&L.n_long_raw, 1);
+      if (pos < TEAM_LONG_CAP) L.lraw[pos] = c;
+    }
+  }
+  __syncthreads();
+  const int cnt = L.n_long_raw;
+  if (cnt > TEAM_LONG_CAP) return;
+  if ((int)threadIdx.x < cnt) {
+    const int mine = L.lraw[threadIdx.x];
+    int rank = 0;
+    for (int k = 0; k < cnt; ++k) rank += (L.lraw[k] < mine) ? 1 : 0;
+    L.llist[rank] = mine;
+  }
+  if (threadIdx.x == 0) L.n_long = cnt;
+  __syncthreads();
+}
+
 template <int NW>
 __device__ void team_solve(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W, SolveStats& out) {
   const int p = P.p, m = o.m;
   TeamLds<NW>& L = *tm.L;
+  team_long_setup(tm, P);
   int col = 0, head = 0, nit = 0, nfev = 0, ifun = 0, status = -1;
   bool first = true, iter0 = true;
   double theta = 1.0, f = 0.0, fold = 0.0, gdold = 0.0, stp = 0.0, sbgnrm = 0.0, gg_k = 0.0;
   LineSearch ls;
   double acc[TEAM_K];
+  TEAM_PROF_DECL
   for (int j = tm.tid; j < p; j += tm.NT) { W.d[j] = 0.0; W.r[j] = 0.0; }
   tm.sync();
   for (;;) {
+#ifdef GDMIX_TEAM_PROFILE
+    const double f_new = team_eval(tm, P, o, W, col, head, acc, prof_t, prof_last);
+#else
     const double f_new = team_eval(tm, P, o, W, col, head, acc);
+#endif
     ++nfev;
     if (tm.aborted()) { status = GDMIX_RE_ST_ABORTED; break; }
     const double gd = acc[1], gg = acc[2], rr = acc[3], gr = acc[4];
@@ -339,57 +498,108 @@ __device__ void team_solve(Team<NW>& tm, const EntityView& P, const SolveParams&
       theta = rr / dr;
     }
     const int cnew = col - 1;   // chronological index of the stored pair
-    if (threadIdx.x == 0) {
-      if (store_pair) {
-        if (shift) {   // drop the oldest pair
-          for (int i = 0; i + 1 < m; ++i) {
-            for (int k = 0; k + 1 < m; ++k) {
-              L.SY[i * TEAM_MCAP + k] = L.SY[(i + 1) * TEAM_MCAP + k + 1];
-              L.YY[i * TEAM_MCAP + k] = L.YY[(i + 1) * TEAM_MCAP + k + 1];
-            }
-            L.ap[i] = L.ap[i + 1];
-            L.bp[i] = L.bp[i + 1];
-          }
+    // The small dense part, by the first wavefront of every workgroup (each workgroup keeps its own replica in
+    // LDS): lane i owns row i of the m x m matrices; the triangular solves broadcast one unknown per step.
+    if (threadIdx.x < WAVE) {
+      const int i = (int)threadIdx.x;
+      constexpr int MM = TEAM_MCAP * TEAM_MCAP;
+      if (store_pair && shift) {   // drop the oldest pair: (r, c) <- (r + 1, c + 1)
+        double sy[2], yy[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int idx = i + h * WAVE;
+          const int r = idx / TEAM_MCAP, c = idx - r * TEAM_MCAP;
+          const bool ok = idx < MM && r + 1 < m && c + 1 < m;
+          sy[h] = ok ? L.SY[(r + 1) * TEAM_MCAP + c + 1] : 0.0;
+          yy[h] = ok ? L.YY[(r + 1) * TEAM_MCAP + c + 1] : 0.0;
+        }
+        const double pa = (i + 1 < m) ? L.ap[i + 1] : 0.0, pb = (i + 1 < m) ? L.bp[i + 1] : 0.0;
+        wave_lds_fence();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int idx = i + h * WAVE;
+          const int r = idx / TEAM_MCAP, c = idx - r * TEAM_MCAP;
+          if (idx < MM && r + 1 < m && c + 1 < m) { L.SY[idx] = sy[h]; L.YY[idx] = yy[h]; }
+        }
+        if (i + 1 < m) { L.ap[i] = pa; L.bp[i] = pb; }
+        wave_lds_fence();
+      }
+      // S'g, Y'g of row i in chronological order after the shift; products with the new pair in closed form
+      double ai = 0.0, bi = 0.0;
+#pragma unroll
+      for (int k = 0; k < TEAM_MCAP; ++k) {
+        if (i == k) {
+          if (shift) { if (k + 1 < TEAM_MCAP) { ai = acc[5 + (k + 1 < TEAM_MCAP ? k + 1 : k)]; bi = acc[5 + TEAM_MCAP + (k + 1 < TEAM_MCAP ? k + 1 : k)]; } }
+          else { ai = acc[5 + k]; bi = acc[5 + TEAM_MCAP + k]; }
         }
       }
-      // current S'g, Y'g in chronological order after the shift; products with the new pair in closed form
-#pragma unroll
-      for (int i = 0; i < TEAM_MCAP; ++i) {
-        const int src = shift ? i + 1 : i;
-        if (src < TEAM_MCAP) { L.la[i] = acc[5 + src]; L.lb[i] = acc[5 + TEAM_MCAP + src]; }
-      }
       if (store_pair) {
-        for (int i = 0; i < cnew; ++i) {
-          L.SY[i * TEAM_MCAP + cnew] = L.la[i] - L.ap[i];          // s_i'(g - g_k)
-          const double yy = L.lb[i] - L.bp[i];                     // y_i'(g - g_k)
+        if (i < cnew) {
+          L.SY[i * TEAM_MCAP + cnew] = ai - L.ap[i];   // s_i'(g - g_k)
+          const double yy = bi - L.bp[i];              // y_i'(g - g_k)
           L.YY[i * TEAM_MCAP + cnew] = yy;
           L.YY[cnew * TEAM_MCAP + i] = yy;
+        } else if (i == cnew) {
+          L.SY[cnew * TEAM_MCAP + cnew] = dr;
+          L.YY[cnew * TEAM_MCAP + cnew] = rr;
+          ai = stp_prev * gd;   // s'g,  s = stp d
+          bi = gg - gr;         // y'g,  y = g - g_k
         }
-        L.SY[cnew * TEAM_MCAP + cnew] = dr;
-        L.YY[cnew * TEAM_MCAP + cnew] = rr;
-        L.la[cnew] = stp_prev * gd;      // s'g,  s = stp d
-        L.lb[cnew] = gg - gr;            // y'g,  y = g - g_k
+        wave_lds_fence();
       }
+      const bool row = i < col;
+      const int ir = row ? i : 0;
+      double Rrow[TEAM_MCAP], Rcol[TEAM_MCAP], Yrow[TEAM_MCAP];
+#pragma unroll
+      for (int k = 0; k < TEAM_MCAP; ++k) {
+        const bool ok = row && k < col;
+        Rrow[k] = ok ? L.SY[ir * TEAM_MCAP + k] : 0.0;
+        Rcol[k] = ok ? L.SY[k * TEAM_MCAP + ir] : 0.0;
+        Yrow[k] = ok ? L.YY[ir * TEAM_MCAP + k] : 0.0;
+      }
+      double diag = 1.0;
+#pragma unroll
+      for (int k = 0; k < TEAM_MCAP; ++k)
+        if (i == k && row) diag = Rrow[k];
+      const double rdiag = 1.0 / diag;
       const double gamma = 1.0 / theta;
-      // q = R^-1 a
-      for (int i = col - 1; i >= 0; --i) {
-        double s = L.la[i];
-        for (int k = i + 1; k < col; ++k) s -= L.SY[i * TEAM_MCAP + k] * L.q[k];
-        L.q[i] = s / L.SY[i * TEAM_MCAP + i];
+      // q = R^-1 a, last unknown first
+      double qk[TEAM_MCAP], uk[TEAM_MCAP];
+      double sv = row ? ai : 0.0, myq = 0.0, myu = 0.0;
+#pragma unroll
+      for (int k = TEAM_MCAP - 1; k >= 0; --k) {
+        qk[k] = 0.0;
+        if (k < col) {
+          const double cand = sv * rdiag;
+          qk[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cand), k),
+                                   __builtin_amdgcn_readlane(__double2loint(cand), k));
+          if (i == k) myq = qk[k];
+          if (i < k) sv -= Rrow[k] * qk[k];
+        }
       }
-      // u = R^-T ((D + gamma Y'Y) q - gamma b)
-      for (int i = 0; i < col; ++i) {
-        double s = L.SY[i * TEAM_MCAP + i] * L.q[i] - gamma * L.lb[i];
-        for (int k = 0; k < col; ++k) s += gamma * L.YY[i * TEAM_MCAP + k] * L.q[k];
-        for (int k = 0; k < i; ++k) s -= L.SY[k * TEAM_MCAP + i] * L.u[k];
-        L.u[i] = s / L.SY[i * TEAM_MCAP + i];
+      // u = R^-T ((D + gamma Y'Y) q - gamma b), first unknown first
+      double tv = diag * myq - gamma * bi;
+#pragma unroll
+      for (int k = 0; k < TEAM_MCAP; ++k) tv += gamma * Yrow[k] * qk[k];
+      if (!row) tv = 0.0;
+#pragma unroll
+      for (int k = 0; k < TEAM_MCAP; ++k) {
+        uk[k] = 0.0;
+        if (k < col) {
+          const double cand = tv * rdiag;
+          uk[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cand), k),
+                                   __builtin_amdgcn_readlane(__double2loint(cand), k));
+          if (i == k) myu = uk[k];
+          if (i > k) tv -= Rcol[k] * uk[k];
+        }
       }
-      double gdn = -gg_cur * (col > 0 ? gamma : 1.0);
-      for (int i = 0; i < col; ++i) gdn += gamma * L.lb[i] * L.q[i] - L.la[i] * L.u[i];
-      L.sc[0] = gdn;
-      for (int i = 0; i < col; ++i) { L.ap[i] = L.la[i]; L.bp[i] = L.lb[i]; }
+      const double term = row ? (gamma * bi * myq - ai * myu) : 0.0;
+      const double gdn0 = wave_sum(term) - gg_cur * (col > 0 ? gamma : 1.0);
+      if (row) { L.ap[i] = ai; L.bp[i] = bi; L.q[i] = myq; L.u[i] = myu; }
+      if (i == 0) L.sc[0] = gdn0;
     }
     tm.block_sync();
+    TEAM_PROF(4);
     double gdn = L.sc[0];
     if (gdn >= 0.0) {   // not a descent direction (lnsrlb info = -4): steepest descent without history
       if (col == 0) { status = 4; break; }
@@ -440,8 +650,16 @@ __device__ void team_solve(Team<NW>& tm, const EntityView& P, const SolveParams&
         W.x[j] = stp * dj + xj;
       }
     }
+    TEAM_PROF(5);
     tm.sync();
+    TEAM_PROF(6);
   }
+#ifdef GDMIX_TEAM_PROFILE
+  if (tm.tid == 0)
+    printf("team n=%d p=%d nfev=%d us/eval: rows %.1f red1 %.1f cols %.1f red2 %.1f solve %.1f upd %.1f sync %.1f\n", P.n, p, nfev,
+           prof_t[0] * 0.01 / nfev, prof_t[1] * 0.01 / nfev, prof_t[2] * 0.01 / nfev, prof_t[3] * 0.01 / nfev,
+           prof_t[4] * 0.01 / nfev, prof_t[5] * 0.01 / nfev, prof_t[6] * 0.01 / nfev);
+#endif
   out.f = f;
   out.gnorm = sbgnrm;
   out.nit = nit;

@@ -277,7 +277,7 @@ class REDeviceSolver:
         _check(self.lib.gdmix_re_set_giant_nnz(self._h, int(nnz)), "set_giant_nnz")
 
     def set_team_nnz(self, nnz: int):
-        """Entities with >= nnz non-zeros (below the giant threshold) are solved by the 8-team kernel (0 = never)."""
+        """Entities with >= nnz non-zeros (below the giant threshold) are solved by the 16-team kernel (0 = never)."""
         _check(self.lib.gdmix_re_set_team_nnz(self._h, int(nnz)), "set_team_nnz")
 
     def set_timing(self, enabled: bool):

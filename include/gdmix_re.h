@@ -200,7 +200,7 @@ GDMIX_API int gdmix_re_set_kernel_mask(gdmix_re_ctx* ctx, int mask);
 
 /* The head of a Zipf-distributed partition: entities with at least `giant_nnz` non-zeros are solved one after
  * another by a persistent kernel spanning the whole device; entities with at least `team_nnz` (and fewer than
- * giant_nnz) by the same kernel split into 8 teams of CUs (one XCD each), 8 entities at a time; smaller ones
+ * giant_nnz) by the same kernel split into 16 teams of CUs, 16 entities at a time, largest first; smaller ones
  * by one workgroup each. Defaults 524288 and 16384; 0 disables a tier. Results do not depend on the
  * thresholds beyond summation order. */
 GDMIX_API int gdmix_re_set_giant_nnz(gdmix_re_ctx* ctx, int64_t giant_nnz);

@@ -145,8 +145,8 @@ def test_device_wide_kernel_matches_reference_fixture(device_solver, name):
 
 @pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "ragged", "ml_per_user", "warm_stage2", "c2_no_intercept",
                                   "ragged_variance_simple"])
-def test_eight_team_kernel_matches_reference_fixture(device_solver, name):
-    # every entity through the persistent kernel split into 8 teams of CUs, 8 entities at a time
+def test_sixteen_team_kernel_matches_reference_fixture(device_solver, name):
+    # every entity through the persistent kernel split into 16 teams of CUs, 16 entities at a time
     _solve_and_compare(device_solver, name, giant_nnz=0, team_nnz=1)
 
 
@@ -194,8 +194,8 @@ def test_large_and_giant_entities_pack_and_solve(device_solver):
     ref = oracle.solve(pk, b.val, b.y, b.offset, None, oracle.make_opts(**kw))
     coef_ptr = packed.coef_ptr_host()
     wp = well_posed_mask(b, dict(l2=1.0, regularize_bias=False, has_intercept=True))
-    # the two 48k-nnz entities through each tier: workgroup kernel, 8-team kernel (default), device-wide kernel
-    for giant_nnz, team_nnz, cls in ((0, 0, "re_solve_team_kernel workgroup"), (524288, 16384, "re_solve_team_kernel 8 teams"),
+    # the two 48k-nnz entities through each tier: workgroup kernel, 16-team kernel (default), device-wide kernel
+    for giant_nnz, team_nnz, cls in ((0, 0, "re_solve_team_kernel workgroup"), (524288, 16384, "re_solve_team_kernel 16 teams"),
                                      (40000, 0, "re_solve_team_kernel device-wide")):
         device_solver.set_giant_nnz(giant_nnz)
         device_solver.set_team_nnz(team_nnz)

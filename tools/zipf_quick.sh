@@ -7,7 +7,7 @@ print('value %.0f ent/s  step %.2f ms  pack %.2f  solve %.2f  kernels %.2f' % (d
 print([(n,c,ms) for (n,c),ms in zip(d['detail']['classes'], d['detail']['class_ms']) if c and ms > 1.5])
 "
 }
-for t in 8 16; do for tn in 16384 8192; do
+for t in 8 16 32; do for tn in 16384 8192 4096; do
   echo "=== teams $t team_nnz $tn"
   GDMIX_RE_TEAMS=$t run "--team-nnz $tn"
 done; done
