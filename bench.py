@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--cpu-sample", type=int, default=0, help="entities per pass of the CPU baseline (0 = 200k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive hand-over measurement")
     ap.add_argument("--giant-nnz", type=int, default=-1, help="override the device-wide kernel threshold (exploration)")
     ap.add_argument("--team-nnz", type=int, default=-1, help="override the 16-team kernel threshold (exploration)")
     ap.add_argument("--solve-only", action="store_true", help="time gdmix_re_solve alone (batch packed once)")
@@ -181,20 +182,47 @@ def main():
         all_ms = float(cls_ms.sum())
         nfev = res.nfev.double().mean().item()
         nit = res.nit.double().mean().item()
-        traffic = None
+        traffic = traffic_detail = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
         if os.path.exists(tpath):   # PMC bytes of the same kernel from a separate rocprofv3 --pmc run
             with open(tpath) as fh:
                 tj = json.load(fh)
-            traffic = tj.get(classes[dom][0])
+            traffic_detail = tj.get(classes[dom][0])
+            traffic = traffic_detail["bytes"] if traffic_detail else None
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
                     "kernel": classes[dom][0], "entities_in_launch": int(classes[dom][1]),
                     "avg_launch_ms": dom_ms, "alg_bytes_per_launch": dom_bytes,
                     "alg_bytes_per_entity": alg_bytes / batch.E,
                     "all_solve_kernels": {"ms_per_step": all_ms, "alg_GBps": alg_bytes / (all_ms * 1e-3) / 1e9 if all_ms else 0.0},
                     "note": "LDS/register-resident L-BFGS: bound by fp64 VALU issue and latency, not by HBM "
                             "(SURVEY.md §8d honesty note); see DESIGN.md for the VALU-side accounting"}
+        # re-streamed figure (what a design that does not keep the entity resident would move), SURVEY.md §8(d)
+        nfev_e = res.nfev.cpu().numpy().astype(np.float64)
+        b_stream = float((nfev_e * (8.0 * z + 16.0 * n) + 8.0 * p + 32.0).sum())
+        # host hand-over: pinned host arrays -> H2D -> pack -> solve -> D2H of the thresholded coefficients
+        e2e = None
+        if world == 1 and not a.no_e2e:
+            names = ("ent_row_ptr", "row_nnz_ptr", "col_global", "val", "y", "offset")
+            pinned = {k: torch.from_numpy(getattr(batch, k)).pin_memory() for k in names}
+            theta_host = torch.empty(int(packed.P), dtype=torch.float64).pin_memory()
+            h2d_bytes = sum(v.numel() * v.element_size() for v in pinned.values())
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                rd = {k: v.to(solver.device, non_blocking=True) for k, v in pinned.items()}
+                rd["weight"] = None
+                rd["E"], rd["N"], rd["Z"] = batch.E, batch.N, batch.Z
+                pk = solver.pack(rd)
+                solver.solve(pk, opts, out=out)
+                theta_host.copy_(out["theta_thr"], non_blocking=True)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter() - t1
+                best = t2 if best is None else min(best, t2)
+            e2e = {"ms": best * 1e3, "entities_per_s": batch.E / best, "h2d_bytes": h2d_bytes,
+                   "d2h_bytes": theta_host.numel() * 8,
+                   "what": "pinned host raw batch -> H2D -> pack -> solve -> D2H thresholded theta, one stream, no overlap"}
         cpu = None
         if not a.no_cpu_baseline:
             sample = a.cpu_sample if a.cpu_sample > 0 else min(batch.E, 200_000)
@@ -218,7 +246,9 @@ def main():
                        "classes": classes, "class_ms": [round(float(x) / a.steps, 3) for x in kernel_ms],
                        "mean_nit": nit, "mean_nfev": nfev,
                        "converged_per_step": converged_all, "N": batch.N, "Z": batch.Z, "P": packed.P,
-                       "host_generate_s": t_gen},
+                       "host_generate_s": t_gen, "host_handover": e2e,
+                       "restreamed_bytes_per_step": b_stream,
+                       "restreamed_GBps": b_stream / (float(kernel_ms.sum()) / a.steps * 1e-3) / 1e9 if kernel_ms.sum() else None},
         }
         print(json.dumps(line))
     if world > 1:
