@@ -1,8 +1,10 @@
-"""In-tree build of libgdmix_re.so: hand-written HIP for gfx950 only, linked against the HIP runtime.
+"""In-tree build of libgdmix_re.so (hand-written HIP for gfx950 only, linked against the HIP runtime) and of
+libgdmix_io.so (host C++: native TFRecord reader).
 
-    python -m gdmix_amd.build            # build if sources are newer than the library
+    python -m gdmix_amd.build            # build what is older than its sources
     python -m gdmix_amd.build --force
 """
+import glob
 import os
 import subprocess
 import sys
@@ -11,7 +13,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgdmix_re.so")
 SOURCES = ["re_api.hip", "re_solve.hip", "re_pack.hip", "re_pack_big.hip"]
-HEADERS = ["re_device.hpp", "re_solve_core.hpp", "re_internal.hpp", os.path.join("..", "..", "include", "gdmix_re.h")]
+HEADERS = [os.path.basename(h) for h in glob.glob(os.path.join(CSRC, "*.hpp"))] + [os.path.join("..", "..", "include", "gdmix_re.h")]
+IO_LIB = os.path.join(HERE, "libgdmix_io.so")
+IO_SOURCES = ["io_reader.cpp", "io_avro.cpp"]
+IO_HEADERS = [os.path.join("..", "..", "include", "gdmix_io.h")]
+CXX = os.environ.get("CXX", "g++")
+IO_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-pthread"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -disable-machine-licm: MachineLICM hoists the ~35 fp64 polynomial constants of exp/log out of the solver's
 # main loop, where they stay live in VGPRs across the whole solve and cost a wave of occupancy.
@@ -37,5 +44,20 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
+def build_io_library(force=False, verbose=False):
+    if not force and os.path.exists(IO_LIB):
+        t = os.path.getmtime(IO_LIB)
+        if not any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in IO_SOURCES + IO_HEADERS):
+            return IO_LIB
+    cmd = [CXX] + IO_FLAGS + [os.path.join(CSRC, f) for f in IO_SOURCES] + ["-lz", "-o", IO_LIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return IO_LIB
+
+
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    force = "--force" in sys.argv
+    if "--io-only" not in sys.argv:
+        print(build_library(force=force, verbose=True))
+    print(build_io_library(force=force, verbose=True))

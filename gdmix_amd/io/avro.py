@@ -321,6 +321,13 @@ class Writer:
         self.close()
 
 
+def container_header(schema, codec="null", sync_marker=None):
+    """(header bytes, sync marker) of an object container file: what Writer.__init__ emits."""
+    sync = sync_marker or os.urandom(16)
+    meta = {"avro.schema": json.dumps(schema).encode("utf-8"), "avro.codec": codec.encode("ascii")}
+    return MAGIC + _META_CODEC.encode(meta) + sync, sync
+
+
 def write_file(path, schema, records, codec="null", block_records=1024):
     with Writer(path, schema, codec, block_records) as w:
         for r in records:

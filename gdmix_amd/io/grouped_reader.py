@@ -46,17 +46,26 @@ def _column(ctx, name, kinds, entity_label):
 
 def read_grouped_partition(input_path, metadata, entity_name, feature_bag, offset_column_name,
                            uid_column_name, label_column_name=None, weight_column_name=None,
-                           num_features=None, check_crc=False):
+                           num_features=None, check_crc=False, native=None, threads=0):
     """Read every record under input_path into one RawBatch (entity order = file order, then record order).
 
     feature_bag None => intercept-only model: one dummy zero feature per sample (job_consumers.py:213-218).
     label_column_name None (or absent from the records) => batch.has_label False (inference data).
+    native: True = libgdmix_io.so (multi-threaded C++), False = the Python decoder below, None = native when the
+    library has been built. Both follow the same rules (tests/test_native_io.py).
     """
     md = metadata if isinstance(metadata, DatasetMetadata) else DatasetMetadata(metadata)
     if entity_name not in md.get_feature_names():
         raise ValueError(f"entity name {entity_name} is not found among the features")
     has_weight_col = weight_column_name is not None and weight_column_name in md.get_feature_names()
     files = resolve_input_files(input_path)
+    from . import native_reader
+    if native is None:
+        native = native_reader.available()
+    if native:
+        return native_reader.read_grouped_files(files, entity_name, feature_bag, offset_column_name, uid_column_name,
+                                                label_column_name, weight_column_name if has_weight_col else None,
+                                                num_features, check_crc, threads)
     ent_n, row_k = [], []
     cols, vals, ys, offs, ws, uids, ids = [], [], [], [], [], [], []
     has_label = label_column_name is not None

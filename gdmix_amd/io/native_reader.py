@@ -1,0 +1,205 @@
+"""ctypes binding of libgdmix_io.so (include/gdmix_io.h): the native, multi-threaded reader of entity-grouped
+TFRecord partitions. Same rules and same errors as grouped_reader.read_grouped_partition (which stays as the
+statement of those rules in Python); tests/test_native_io.py compares the two array for array."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ..batch import RawBatch
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_HERE, "libgdmix_io.so")
+ABI_VERSION = 1
+EXPORTED_SYMBOLS = ("gdmix_io_abi_version", "gdmix_io_last_error", "gdmix_io_read_grouped", "gdmix_io_free",
+                    "gdmix_io_crc32c", "gdmix_io_masked_crc32c", "gdmix_io_avro_write_models", "gdmix_io_avro_write_scores")
+
+
+class GdmixIoError(RuntimeError):
+    pass
+
+
+class _Schema(C.Structure):
+    _fields_ = [("entity", C.c_char_p), ("feature_bag", C.c_char_p), ("offset", C.c_char_p), ("uid", C.c_char_p),
+                ("label", C.c_char_p), ("weight", C.c_char_p), ("num_features", C.c_int64), ("check_crc", C.c_int32),
+                ("threads", C.c_int32)]
+
+
+class _Batch(C.Structure):
+    _fields_ = [("E", C.c_int64), ("N", C.c_int64), ("Z", C.c_int64), ("ent_row_ptr", C.POINTER(C.c_int64)),
+                ("row_nnz_ptr", C.POINTER(C.c_int64)), ("col_global", C.POINTER(C.c_int64)), ("val", C.POINTER(C.c_float)),
+                ("y", C.POINTER(C.c_float)), ("offset", C.POINTER(C.c_float)), ("weight", C.POINTER(C.c_float)),
+                ("uid", C.POINTER(C.c_int64)), ("ent_id_ptr", C.POINTER(C.c_int64)), ("ent_id_bytes", C.POINTER(C.c_char)),
+                ("has_label", C.c_int32), ("bytes_read", C.c_int64)]
+
+
+class _ModelTable(C.Structure):
+    _fields_ = [("E", C.c_int64), ("id_ptr", C.c_void_p), ("id_bytes", C.c_char_p), ("coef_beg", C.c_void_p),
+                ("coef_cnt", C.c_void_p), ("var_beg", C.c_void_p), ("feat_beg", C.c_void_p), ("mean", C.c_void_p),
+                ("variance", C.c_void_p), ("feat_idx", C.c_void_p), ("prefix_ptr", C.c_void_p), ("prefix_bytes", C.c_char_p),
+                ("n_prefix", C.c_int64), ("icpt_enc", C.c_char_p), ("icpt_len", C.c_int64), ("class_enc", C.c_char_p),
+                ("class_len", C.c_int64), ("loss_enc", C.c_char_p), ("loss_len", C.c_int64), ("has_intercept", C.c_int32),
+                ("threshold", C.c_double)]
+
+
+_lib = None
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GdmixIoError(f"{LIB_PATH} is missing: run `python -m gdmix_amd.build`")
+    lib = C.CDLL(LIB_PATH)
+    for sym in EXPORTED_SYMBOLS:
+        if not hasattr(lib, sym):
+            raise GdmixIoError(f"{LIB_PATH} does not export {sym}")
+    lib.gdmix_io_abi_version.restype = C.c_int
+    lib.gdmix_io_last_error.restype = C.c_char_p
+    lib.gdmix_io_read_grouped.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.POINTER(_Schema), C.POINTER(C.POINTER(_Batch))]
+    lib.gdmix_io_free.argtypes = [C.POINTER(_Batch)]
+    lib.gdmix_io_free.restype = None
+    lib.gdmix_io_avro_write_models.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.POINTER(_ModelTable),
+                                               C.c_int32, C.c_int32, C.c_int32]
+    lib.gdmix_io_avro_write_scores.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.gdmix_io_crc32c.argtypes = [C.c_char_p, C.c_size_t]
+    lib.gdmix_io_crc32c.restype = C.c_uint32
+    lib.gdmix_io_masked_crc32c.argtypes = [C.c_char_p, C.c_size_t]
+    lib.gdmix_io_masked_crc32c.restype = C.c_uint32
+    if lib.gdmix_io_abi_version() != ABI_VERSION:
+        raise GdmixIoError(f"{LIB_PATH}: ABI version {lib.gdmix_io_abi_version()}, expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def crc32c(data: bytes) -> int:
+    return int(load_library().gdmix_io_crc32c(data, len(data)))
+
+
+def masked_crc32c(data: bytes) -> int:
+    return int(load_library().gdmix_io_masked_crc32c(data, len(data)))
+
+
+def _enc(s):
+    return None if s is None else s.encode("utf-8")
+
+
+def _copy(ptr, count, dtype):
+    if count == 0:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dtype, copy=True)
+
+
+def _split_ids(raw, ptr, E):
+    """E strings from concatenated UTF-8 bytes + offsets, without a Python-level loop when possible."""
+    if E == 0:
+        return []
+    lens = np.diff(ptr)
+    if lens.min() > 0 and b"\x00" not in raw:
+        # insert a NUL after every id, decode once, split once
+        out = np.zeros(len(raw) + E, np.uint8)
+        keep = np.ones(len(raw) + E, bool)
+        keep[ptr[1:] + np.arange(E)] = False
+        out[keep] = np.frombuffer(raw, np.uint8)
+        return out.tobytes().decode("utf-8").split("\x00")[:E]
+    return [raw[ptr[i]:ptr[i + 1]].decode("utf-8") for i in range(E)]
+
+
+def read_grouped_files(files, entity_name, feature_bag, offset_column_name, uid_column_name, label_column_name=None,
+                       weight_column_name=None, num_features=None, check_crc=False, threads=0, stats=None) -> RawBatch:
+    """files -> RawBatch; same arguments as grouped_reader.read_grouped_partition after file resolution and the
+    metadata checks. weight_column_name None => no weight array."""
+    lib = load_library()
+    sc = _Schema(_enc(entity_name), _enc(feature_bag), _enc(offset_column_name), _enc(uid_column_name),
+                 _enc(label_column_name), _enc(weight_column_name),
+                 -1 if num_features is None or feature_bag is None else int(num_features), int(bool(check_crc)), int(threads))
+    arr = (C.c_char_p * len(files))(*[f.encode("utf-8") for f in files])
+    out = C.POINTER(_Batch)()
+    rc = lib.gdmix_io_read_grouped(arr, len(files), C.byref(sc), C.byref(out))
+    if rc != 0:
+        msg = lib.gdmix_io_last_error().decode("utf-8", "replace")
+        # same exception types as the Python reader: schema problems are KeyError / ValueError / AssertionError there
+        raise (ValueError if rc in (-3, -4) else GdmixIoError)(f"gdmix_io_read_grouped: {msg}")
+    try:
+        b = out.contents
+        E, N, Z = int(b.E), int(b.N), int(b.Z)
+        idp = _copy(b.ent_id_ptr, E + 1, np.int64)
+        raw_ids = C.string_at(b.ent_id_bytes, int(idp[-1])) if E else b""
+        ids = _split_ids(raw_ids, idp, E)
+        if stats is not None:
+            stats["bytes_read"] = int(b.bytes_read)
+        return RawBatch(ent_row_ptr=_copy(b.ent_row_ptr, E + 1, np.int64), row_nnz_ptr=_copy(b.row_nnz_ptr, N + 1, np.int64),
+                        col_global=_copy(b.col_global, Z, np.int64), val=_copy(b.val, Z, np.float32),
+                        y=_copy(b.y, N, np.float32), offset=_copy(b.offset, N, np.float32),
+                        weight=_copy(b.weight, N, np.float32) if weight_column_name is not None else None,
+                        uid=_copy(b.uid, N, np.int64), entity_ids=ids, has_label=bool(b.has_label))
+    finally:
+        lib.gdmix_io_free(out)
+
+
+# ---- Avro writers ------------------------------------------------------------------------------------------
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _ids_to_bytes(ids):
+    enc = [str(x).encode("utf-8") for x in ids]
+    ptr = np.zeros(len(enc) + 1, np.int64)
+    if enc:
+        np.cumsum([len(x) for x in enc], out=ptr[1:])
+    return b"".join(enc), ptr
+
+
+def write_models_avro(path, header: bytes, sync: bytes, ids, coef_beg, coef_cnt, mean, feat_beg, feat_idx, prefix,
+                      icpt_enc: bytes, class_enc: bytes, loss_enc: bytes, has_intercept: bool, threshold: float,
+                      var_beg=None, variance=None, block_records=1024, deflate=False, threads=0):
+    """One BayesianLinearModelAvro per entity, in the order given. prefix: list of pre-encoded string(name)+string(term)
+    per global feature index, or None for an intercept-only model. Arrays are int64 / float64 numpy."""
+    lib = load_library()
+    d = os.path.dirname(path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    id_bytes, id_ptr = _ids_to_bytes(ids)
+    keep = [np.ascontiguousarray(coef_beg, np.int64), np.ascontiguousarray(coef_cnt, np.int64),
+            np.ascontiguousarray(feat_beg, np.int64), np.ascontiguousarray(mean, np.float64),
+            np.ascontiguousarray(feat_idx, np.int64),
+            None if var_beg is None else np.ascontiguousarray(var_beg, np.int64),
+            None if variance is None else np.ascontiguousarray(variance, np.float64)]
+    pre_bytes, pre_ptr = None, None
+    if prefix is not None:
+        pre_ptr = np.zeros(len(prefix) + 1, np.int64)
+        if prefix:
+            np.cumsum([len(x) for x in prefix], out=pre_ptr[1:])
+        pre_bytes = b"".join(prefix)
+    t = _ModelTable(len(ids), _ptr(id_ptr), id_bytes, _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[5]), _ptr(keep[2]), _ptr(keep[3]),
+                    _ptr(keep[6]), _ptr(keep[4]), _ptr(pre_ptr), pre_bytes, 0 if prefix is None else len(prefix),
+                    icpt_enc, len(icpt_enc), class_enc, len(class_enc), loss_enc, len(loss_enc), int(bool(has_intercept)),
+                    float(threshold))
+    rc = lib.gdmix_io_avro_write_models(path.encode("utf-8"), header, len(header), sync, C.byref(t), int(block_records),
+                                        int(bool(deflate)), int(threads))
+    if rc != 0:
+        raise GdmixIoError("gdmix_io_avro_write_models: " + lib.gdmix_io_last_error().decode("utf-8", "replace"))
+    return len(ids)
+
+
+def write_scores_avro(path, header: bytes, sync: bytes, uid, score, label, weight, per_coord, block_records=1024,
+                      deflate=False, threads=0):
+    lib = load_library()
+    d = os.path.dirname(path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    uid = np.ascontiguousarray(uid, np.int64)
+    f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+    score, label, weight, per_coord = f32(score), f32(label), f32(weight), f32(per_coord)
+    rc = lib.gdmix_io_avro_write_scores(path.encode("utf-8"), header, len(header), sync, len(uid), _ptr(uid), _ptr(score),
+                                        _ptr(label), _ptr(weight), _ptr(per_coord), int(block_records), int(bool(deflate)),
+                                        int(threads))
+    if rc != 0:
+        raise GdmixIoError("gdmix_io_avro_write_scores: " + lib.gdmix_io_last_error().decode("utf-8", "replace"))
+    return len(uid)

@@ -16,7 +16,7 @@ from collections import namedtuple
 import numpy as np
 
 from . import constants
-from .io import avro
+from .io import avro, native_reader
 from .io.features import get_feature_map, read_feature_list
 from .io.grouped_reader import read_grouped_partition
 from .io.metadata import DatasetMetadata, read_json_file
@@ -90,6 +90,38 @@ class ModelTable:
                 p = len(tr.theta)
                 d = len(tr.unique_global_indices)
                 self.add_chunk([k], tr.theta, [0, p], tr.unique_global_indices, [0, d], tr.variance)
+
+    def flatten(self):
+        """Flat arrays over the entities in dict order: (ids, coef_beg, coef_cnt, var_beg, feat_beg, mean, variance,
+        feat_idx); var_beg is -1 for an entity whose chunk carries no variance, variance None if no chunk does."""
+        ids = list(self._where.keys())
+        cr = np.array(list(self._where.values()), np.int64).reshape(-1, 2)
+        cbase, fbase, vbase = [], [], []
+        co = fo = vo = 0
+        any_var = any(ch["variance"] is not None for ch in self._chunks)
+        for ch in self._chunks:
+            cbase.append(co); fbase.append(fo)
+            vbase.append(vo if ch["variance"] is not None else -1)
+            co += len(ch["theta"]); fo += len(ch["idx"])
+            if ch["variance"] is not None:
+                vo += len(ch["variance"])
+        E = len(ids)
+        coef_beg = np.zeros(E, np.int64); coef_cnt = np.zeros(E, np.int64)
+        feat_beg = np.zeros(E, np.int64); var_beg = np.full(E, -1, np.int64)
+        for c, ch in enumerate(self._chunks):
+            sel = np.flatnonzero(cr[:, 0] == c) if E else np.zeros(0, np.int64)
+            if sel.size == 0:
+                continue
+            rows = cr[sel, 1]
+            coef_beg[sel] = cbase[c] + ch["coef_ptr"][rows]
+            coef_cnt[sel] = ch["coef_ptr"][rows + 1] - ch["coef_ptr"][rows]
+            feat_beg[sel] = fbase[c] + ch["feat_ptr"][rows]
+            if ch["variance"] is not None:
+                var_beg[sel] = vbase[c] + ch["coef_ptr"][rows]
+        mean = np.concatenate([ch["theta"] for ch in self._chunks]) if self._chunks else np.zeros(0)
+        idx = np.concatenate([ch["idx"] for ch in self._chunks]) if self._chunks else np.zeros(0, np.int64)
+        variance = np.concatenate([ch["variance"] for ch in self._chunks if ch["variance"] is not None]) if any_var else None
+        return ids, coef_beg, coef_cnt, var_beg, feat_beg, mean, variance, idx
 
     def lookup(self, ids):
         """Vectorised: for every id, (found mask, chunk index, row)."""
@@ -370,7 +402,8 @@ class RandomEffectLRLBFGSModel:
 
 
 # ---- Avro writers (record layout of util/io_utils.py:102-212 and :299-375) ----------------------------------
-def _export_models_to_avro(output_file, table, feature_list, has_intercept, with_variance, sparsity_threshold=1e-4):
+def _export_models_to_avro(output_file, table, feature_list, has_intercept, with_variance, sparsity_threshold=1e-4,
+                           native=None, sync_marker=None):
     """One BayesianLinearModelAvro per entity: intercept always, features with |value| > threshold
     (gen_one_avro_model, util/io_utils.py:102-160). The array payloads are assembled from pre-encoded
     name/term prefixes instead of per-field schema dispatch."""
@@ -381,10 +414,19 @@ def _export_models_to_avro(output_file, table, feature_list, has_intercept, with
     prefix = None
     if feature_list is not None:
         prefix = [avro.enc_string(n) + avro.enc_string(t) for (n, t) in feature_list]
+    if native is None:
+        native = native_reader.available() and isinstance(table, ModelTable)
+    if native:
+        ids, coef_beg, coef_cnt, var_beg, feat_beg, mean, variance, idx = table.flatten()
+        header, sync = avro.container_header(avro.BAYESIAN_LINEAR_MODEL_SCHEMA, "null", sync_marker)
+        use_var = with_variance and variance is not None
+        return native_reader.write_models_avro(output_file, header, sync, ids, coef_beg, coef_cnt, mean, feat_beg, idx, prefix,
+                                               icpt, head_class, loss, has_intercept, sparsity_threshold,
+                                               var_beg if use_var else None, variance if use_var else None)
     pack_d = struct.Struct("<d").pack
     ic = 1 if has_intercept else 0
     count = 0
-    with avro.Writer(output_file, avro.BAYESIAN_LINEAR_MODEL_SCHEMA) as w:
+    with avro.Writer(output_file, avro.BAYESIAN_LINEAR_MODEL_SCHEMA, sync_marker=sync_marker) as w:
         buf = bytearray()
         nbuf = 0
         for model_id, (mean, variance, uidx) in table.items():
@@ -418,12 +460,18 @@ def _export_models_to_avro(output_file, table, feature_list, has_intercept, with
     return count
 
 
-def _write_scores(output_file, schema, schema_params, uid, score, label, weight, per_coord):
+def _write_scores(output_file, schema, schema_params, uid, score, label, weight, per_coord, native=None, sync_marker=None):
     """Records {uid long, predictionScore float, label [null,float], weight float?, perCoordinate float} in
     blocks of 1024 (batched_write_avro, util/io_utils.py:299-334)."""
+    if native is None:
+        native = native_reader.available()
+    if native:
+        header, sync = avro.container_header(schema, "null", sync_marker)
+        native_reader.write_scores_avro(output_file, header, sync, uid, score, label, weight, per_coord)
+        return
     pack_f = struct.Struct("<f").pack
     n = len(uid)
-    with avro.Writer(output_file, schema) as w:
+    with avro.Writer(output_file, schema, sync_marker=sync_marker) as w:
         for b0 in range(0, n, 1024):
             b1 = min(n, b0 + 1024)
             buf = bytearray()

@@ -1,0 +1,130 @@
+/* gdmix_io.h — C ABI of libgdmix_io.so: native reader of entity-grouped TFRecord partitions.
+ *
+ * Replaces, for the random-effect path, what the reference does with the TensorFlow runtime before the
+ * solver sees any data (SURVEY.md §8 rows a9 + the slicing half of a8, next-row N3):
+ *   per_entity_grouped_input_fn      gdmix-trainer/src/gdmix/io/input_data_pipeline.py:223-332
+ *   dataset_reader                   gdmix-trainer/src/gdmix/util/io_utils.py:351-364
+ *   prepare_jobs (per-entity slices) gdmix-trainer/src/gdmix/models/custom/scipy/job_consumers.py:209-258
+ * One SequenceExample per entity: the entity id is a scalar in the context, every
+ * dense column a per-sample list in the context, the sparse bag two feature lists `<bag>_indices` /
+ * `<bag>_values` with one step per sample. Output: the entity-major ragged arrays gdmix_re_pack consumes
+ * (gdmix_re.h, gdmix_re_raw_batch), in host memory.
+ *
+ * Host code only (no HIP). Every function returns 0 or a negative code and never throws;
+ * gdmix_io_last_error() gives the message of the calling thread's last failure. Input files are untrusted:
+ * every length and offset is bounds-checked.
+ */
+#ifndef GDMIX_IO_H
+#define GDMIX_IO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define GDMIX_IO_API __attribute__((visibility("default")))
+#else
+#define GDMIX_IO_API
+#endif
+
+#define GDMIX_IO_OK        0
+#define GDMIX_IO_EINVAL   (-1)   /* bad argument */
+#define GDMIX_IO_EIO      (-2)   /* file cannot be opened / read / inflated */
+#define GDMIX_IO_EFORMAT  (-3)   /* framing, CRC or protobuf wire error */
+#define GDMIX_IO_ESCHEMA  (-4)   /* a record does not match the schema (missing column, length mismatch, ...) */
+#define GDMIX_IO_ENOMEM   (-5)
+
+#define GDMIX_IO_ABI_VERSION 1
+
+typedef struct gdmix_io_schema {
+  const char* entity;        /* context key of the entity id (int64 or bytes scalar)                       */
+  const char* feature_bag;   /* sparse bag name; NULL => intercept-only model: one dummy zero feature per
+                              * sample (job_consumers.py:213-218)                                          */
+  const char* offset;        /* context key, float list [n]                                                */
+  const char* uid;           /* context key, int64 list [n]                                                */
+  const char* label;         /* context key, int64 or float list [n]; NULL or absent from a record =>
+                              * has_label = 0 and y = 0 (inference data)                                   */
+  const char* weight;        /* context key, float list [n]; NULL => no weight array                        */
+  int64_t num_features;      /* > 0: feature indices must lie in [0, num_features); <= 0: unchecked         */
+  int32_t check_crc;         /* verify the masked CRC-32C of every record (length and data)                 */
+  int32_t threads;           /* decode threads; <= 0: one per online CPU                                    */
+} gdmix_io_schema;
+
+/* Arrays are owned by the library until gdmix_io_free. Entity order = file order, then record order. */
+typedef struct gdmix_io_batch {
+  int64_t E, N, Z;
+  int64_t* ent_row_ptr;   /* [E+1] sample offsets                                  */
+  int64_t* row_nnz_ptr;   /* [N+1] non-zero offsets                                */
+  int64_t* col_global;    /* [Z]   global feature index                            */
+  float*   val;           /* [Z]                                                   */
+  float*   y;             /* [N]   labels as float (0 when has_label == 0)         */
+  float*   offset;        /* [N]                                                   */
+  float*   weight;        /* [N] or NULL                                           */
+  int64_t* uid;           /* [N]                                                   */
+  int64_t* ent_id_ptr;    /* [E+1] offsets into ent_id_bytes                       */
+  char*    ent_id_bytes;  /* entity ids: UTF-8 bytes, or the decimal rendering of an int64 id
+                           * (job_consumers.py:235-239)                            */
+  int32_t  has_label;
+  int64_t  bytes_read;    /* decompressed bytes of TFRecord framing parsed         */
+} gdmix_io_batch;
+
+GDMIX_IO_API int gdmix_io_abi_version(void);
+GDMIX_IO_API const char* gdmix_io_last_error(void);
+
+/* Read every record of `files` (".gz" => gzip, ".deflate" => zlib, anything else raw: input_data_pipeline.py:63-85)
+ * into one batch. */
+GDMIX_IO_API int gdmix_io_read_grouped(const char* const* files, int32_t n_files, const gdmix_io_schema* schema,
+                                       gdmix_io_batch** out);
+GDMIX_IO_API void gdmix_io_free(gdmix_io_batch* batch);
+
+/* ---- Avro object container writers (model and score files) ----------------------------------------------
+ * The caller supplies the container header (magic "Obj\x01", the metadata map with avro.schema / avro.codec,
+ * the 16-byte sync marker) and the constant, pre-encoded pieces of a record; the library encodes the records in
+ * blocks of `block_records` (blocks in parallel, written in order). deflate_codec != 0: raw-deflate every block
+ * (avro.codec must then say "deflate"). */
+typedef struct gdmix_io_model_table {   /* one BayesianLinearModelAvro per entity, in array order */
+  int64_t E;
+  const int64_t* id_ptr;        /* [E+1] offsets into id_bytes                                              */
+  const char*    id_bytes;      /* modelId strings, UTF-8                                                   */
+  const int64_t* coef_beg;      /* [E] first coefficient of the entity in mean (intercept first)            */
+  const int64_t* coef_cnt;      /* [E] number of coefficients (features + has_intercept)                    */
+  const int64_t* var_beg;       /* [E] first variance in `variance`, < 0 => the entity has none; or NULL    */
+  const int64_t* feat_beg;      /* [E] first entry in feat_idx                                              */
+  const double*  mean;
+  const double*  variance;      /* or NULL                                                                  */
+  const int64_t* feat_idx;      /* global feature index of every non-intercept coefficient                  */
+  const int64_t* prefix_ptr;    /* [n_prefix+1] offsets into prefix_bytes; NULL => intercept-only file      */
+  const uint8_t* prefix_bytes;  /* per global feature: Avro string(name) + string(term)                     */
+  int64_t        n_prefix;
+  const uint8_t* icpt_enc;      /* string("(INTERCEPT)") + string("")                                       */
+  int64_t        icpt_len;
+  const uint8_t* class_enc;     /* modelClass union: branch + string                                        */
+  int64_t        class_len;
+  const uint8_t* loss_enc;      /* lossFunction union: branch + string                                      */
+  int64_t        loss_len;
+  int32_t        has_intercept;
+  double         threshold;     /* features with |value| <= threshold are not written (intercept always is) */
+} gdmix_io_model_table;
+
+GDMIX_IO_API int gdmix_io_avro_write_models(const char* path, const uint8_t* header, int64_t header_len, const uint8_t* sync,
+                                            const gdmix_io_model_table* table, int32_t block_records, int32_t deflate_codec,
+                                            int32_t threads);
+
+/* validation_result records: uid long, score float, label [null, float] (label NULL => null), weight float
+ * (weight NULL => the schema has no weight field), per-coordinate score float. */
+GDMIX_IO_API int gdmix_io_avro_write_scores(const char* path, const uint8_t* header, int64_t header_len, const uint8_t* sync,
+                                            int64_t n, const int64_t* uid, const float* score, const float* label,
+                                            const float* weight, const float* per_coord, int32_t block_records,
+                                            int32_t deflate_codec, int32_t threads);
+
+/* CRC-32C (Castagnoli) and TFRecord's masked form ((crc >> 15 | crc << 17) + 0xa282ead8). */
+GDMIX_IO_API uint32_t gdmix_io_crc32c(const void* data, size_t len);
+GDMIX_IO_API uint32_t gdmix_io_masked_crc32c(const void* data, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDMIX_IO_H */
