@@ -187,3 +187,163 @@ GDMIX_IO_API int gdmix_io_avro_write_scores(const char* path, const uint8_t* hea
 }
 
 }  // extern "C"
+
+// ---- entity-grouped TFRecord writer -----------------------------------------------------------------------------
+// One tf.train.SequenceExample per entity, the layout DataPartitioner writes through spark-tfrecord
+// (gdmix-data/src/main/scala/com/linkedin/gdmix/data/DataPartitioner.scala:313-316) and
+// gdmix_io_read_grouped reads: used to materialise synthetic partitions and by the partitioner tool
+// (gdmix_amd/partitioner.py). Field order and encodings (packed lists) are those of gdmix_amd/io/tfrecord.py, so
+// uncompressed files are byte-identical to the Python writer's.
+namespace {
+
+inline void put_varint(std::string& out, uint64_t u) {
+  while (u >= 0x80) { out.push_back((char)((u & 0x7F) | 0x80)); u >>= 7; }
+  out.push_back((char)u);
+}
+inline void put_ld(std::string& out, uint32_t fn, const std::string& payload) {
+  put_varint(out, ((uint64_t)fn << 3) | 2);
+  put_varint(out, payload.size());
+  out.append(payload);
+}
+inline void put_ld_raw(std::string& out, uint32_t fn, const void* p, size_t n) {
+  put_varint(out, ((uint64_t)fn << 3) | 2);
+  put_varint(out, n);
+  out.append((const char*)p, n);
+}
+
+// Feature{int64_list{packed}} / Feature{float_list{packed}} / Feature{bytes_list{value}}
+void feat_int64(std::string& out, const int64_t* v, int64_t n, std::string& t1, std::string& t2) {
+  t1.clear();
+  for (int64_t i = 0; i < n; ++i) put_varint(t1, (uint64_t)v[i]);
+  t2.clear();
+  if (n) put_ld(t2, 1, t1);
+  put_ld(out, 3, t2);
+}
+void feat_float(std::string& out, const float* v, int64_t n, std::string& t2) {
+  t2.clear();
+  if (n) put_ld_raw(t2, 1, v, (size_t)n * 4);
+  put_ld(out, 2, t2);
+}
+template <class F>
+void feat_float_as_int64(std::string& out, const float* v, int64_t n, std::string& t1, std::string& t2, F&& conv) {
+  t1.clear();
+  for (int64_t i = 0; i < n; ++i) put_varint(t1, (uint64_t)conv(v[i]));
+  t2.clear();
+  if (n) put_ld(t2, 1, t1);
+  put_ld(out, 3, t2);
+}
+void map_entry(std::string& out, const char* key, const std::string& feature, std::string& tmp) {
+  tmp.clear();
+  put_ld_raw(tmp, 1, key, strlen(key));
+  put_ld(tmp, 2, feature);
+  put_ld(out, 1, tmp);
+}
+
+}  // namespace
+
+extern "C" uint32_t gdmix_io_masked_crc32c(const void* data, size_t len);
+
+extern "C" GDMIX_IO_API int gdmix_io_write_grouped(const char* path, const gdmix_io_batch* b, const gdmix_io_schema* sc,
+                                                    int32_t int_entity_ids) {
+  if (!path || !b || !sc || !sc->entity || !sc->uid || !sc->offset) return set_error(GDMIX_IO_EINVAL, "NULL argument");
+  if (b->E > 0 && (!b->ent_row_ptr || !b->ent_id_ptr || !b->ent_id_bytes || !b->uid || !b->offset))
+    return set_error(GDMIX_IO_EINVAL, "batch has NULL arrays");
+  if (sc->feature_bag && b->N > 0 && (!b->row_nnz_ptr || (b->Z > 0 && (!b->col_global || !b->val))))
+    return set_error(GDMIX_IO_EINVAL, "batch has NULL feature arrays");
+  const std::string p(path);
+  const bool gz = p.size() >= 3 && p.compare(p.size() - 3, 3, ".gz") == 0;
+  const bool zl = p.size() >= 8 && p.compare(p.size() - 8, 8, ".deflate") == 0;
+  FILE* f = fopen(path, "wb");
+  if (!f) return set_error(GDMIX_IO_EIO, "%s: cannot open for writing", path);
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  std::vector<uint8_t> zbuf;
+  if (gz || zl) {
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, gz ? 15 + 16 : 15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+      fclose(f);
+      return set_error(GDMIX_IO_EIO, "%s: deflateInit2 failed", path);
+    }
+    zbuf.resize(1 << 20);
+  }
+  bool ok = true;
+  auto emit = [&](const std::string& chunk, bool finish) {
+    if (!(gz || zl)) { ok = ok && fwrite(chunk.data(), 1, chunk.size(), f) == chunk.size(); return; }
+    zs.next_in = (Bytef*)chunk.data();
+    zs.avail_in = (uInt)chunk.size();
+    int rc = Z_OK;
+    do {
+      zs.next_out = zbuf.data();
+      zs.avail_out = (uInt)zbuf.size();
+      rc = deflate(&zs, finish ? Z_FINISH : Z_NO_FLUSH);
+      const size_t have = zbuf.size() - zs.avail_out;
+      ok = ok && fwrite(zbuf.data(), 1, have, f) == have;
+    } while (ok && (zs.avail_out == 0 || (finish && rc != Z_STREAM_END)));
+  };
+  std::string rec, ctx, fls, feat, tmp, t1, t2, steps, entry, chunk;
+  const std::string bag_i = sc->feature_bag ? std::string(sc->feature_bag) + "_indices" : std::string();
+  const std::string bag_v = sc->feature_bag ? std::string(sc->feature_bag) + "_values" : std::string();
+  for (int64_t e = 0; e < b->E && ok; ++e) {
+    const int64_t r0 = b->ent_row_ptr[e], n = b->ent_row_ptr[e + 1] - r0;
+    ctx.clear();
+    // entity id
+    feat.clear();
+    const char* idp = b->ent_id_bytes + b->ent_id_ptr[e];
+    const size_t idn = (size_t)(b->ent_id_ptr[e + 1] - b->ent_id_ptr[e]);
+    if (int_entity_ids) {
+      const std::string s(idp, idn);
+      char* end = nullptr;
+      const long long v = strtoll(s.c_str(), &end, 10);
+      if (s.empty() || *end) { ok = false; set_error(GDMIX_IO_ESCHEMA, "%s: entity id '%s' is not an integer", path, s.c_str()); break; }
+      const int64_t v64 = (int64_t)v;
+      feat_int64(feat, &v64, 1, t1, t2);
+    } else {
+      t2.clear();
+      put_ld_raw(t2, 1, idp, idn);
+      put_ld(feat, 1, t2);
+    }
+    map_entry(ctx, sc->entity, feat, tmp);
+    feat.clear(); feat_int64(feat, b->uid + r0, n, t1, t2); map_entry(ctx, sc->uid, feat, tmp);
+    feat.clear(); feat_float(feat, b->offset + r0, n, t2); map_entry(ctx, sc->offset, feat, tmp);
+    if (sc->label && b->has_label && b->y) {
+      feat.clear();
+      feat_float_as_int64(feat, b->y + r0, n, t1, t2, [](float y) { return (int64_t)y; });
+      map_entry(ctx, sc->label, feat, tmp);
+    }
+    if (sc->weight && b->weight) { feat.clear(); feat_float(feat, b->weight + r0, n, t2); map_entry(ctx, sc->weight, feat, tmp); }
+    fls.clear();
+    if (sc->feature_bag) {
+      steps.clear();
+      for (int64_t i = r0; i < r0 + n; ++i) {
+        const int64_t z0 = b->row_nnz_ptr[i], k = b->row_nnz_ptr[i + 1] - z0;
+        feat.clear(); feat_int64(feat, b->col_global + z0, k, t1, t2);
+        put_ld(steps, 1, feat);
+      }
+      entry.clear(); put_ld_raw(entry, 1, bag_i.data(), bag_i.size()); put_ld(entry, 2, steps); put_ld(fls, 1, entry);
+      steps.clear();
+      for (int64_t i = r0; i < r0 + n; ++i) {
+        const int64_t z0 = b->row_nnz_ptr[i], k = b->row_nnz_ptr[i + 1] - z0;
+        feat.clear(); feat_float(feat, b->val + z0, k, t2);
+        put_ld(steps, 1, feat);
+      }
+      entry.clear(); put_ld_raw(entry, 1, bag_v.data(), bag_v.size()); put_ld(entry, 2, steps); put_ld(fls, 1, entry);
+    }
+    rec.clear();
+    put_ld(rec, 1, ctx);
+    put_ld(rec, 2, fls);
+    const uint64_t len = rec.size();
+    uint32_t c1 = gdmix_io_masked_crc32c(&len, 8), c2 = gdmix_io_masked_crc32c(rec.data(), rec.size());
+    chunk.append((const char*)&len, 8);
+    chunk.append((const char*)&c1, 4);
+    chunk.append(rec);
+    chunk.append((const char*)&c2, 4);
+    if (chunk.size() >= (8u << 20)) { emit(chunk, false); chunk.clear(); }
+  }
+  if (ok) emit(chunk, true);
+  if (gz || zl) deflateEnd(&zs);
+  if (fclose(f) != 0) ok = false;
+  if (!ok) {
+    if (!*gdmix_io_last_error()) set_error(GDMIX_IO_EIO, "%s: write failed", path);
+    return GDMIX_IO_EIO;
+  }
+  return GDMIX_IO_OK;
+}

@@ -142,9 +142,17 @@ def read_grouped_partition(input_path, metadata, entity_name, feature_bag, offse
 
 def write_grouped_partition(path, batch: RawBatch, entity_name, feature_bag, offset_column_name="offset",
                             uid_column_name="uid", label_column_name="response", weight_column_name="weight",
-                            int_entity_ids=False):
+                            int_entity_ids=False, native=None):
     """Write a RawBatch as one SequenceExample per entity (layout of DataPartitioner's output,
-    SURVEY.md Appendix A). Used by tests and to materialise synthetic partitions."""
+    SURVEY.md Appendix A). Used by tests, the partitioner tool and to materialise synthetic partitions.
+    native None => libgdmix_io.so when built (same bytes for uncompressed files)."""
+    from . import native_reader
+    if native is None:
+        native = native_reader.available()
+    if native:
+        native_reader.write_grouped_file(path, batch, entity_name, feature_bag, offset_column_name, uid_column_name,
+                                         label_column_name, weight_column_name, int_entity_ids)
+        return
     payloads = []
     n = batch.ent_n()
     for e in range(batch.E):

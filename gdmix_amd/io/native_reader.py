@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "libgdmix_io.so")
 ABI_VERSION = 1
 EXPORTED_SYMBOLS = ("gdmix_io_abi_version", "gdmix_io_last_error", "gdmix_io_read_grouped", "gdmix_io_free",
-                    "gdmix_io_crc32c", "gdmix_io_masked_crc32c", "gdmix_io_avro_write_models", "gdmix_io_avro_write_scores")
+                    "gdmix_io_crc32c", "gdmix_io_masked_crc32c", "gdmix_io_avro_write_models", "gdmix_io_avro_write_scores",
+                    "gdmix_io_write_grouped")
 
 
 class GdmixIoError(RuntimeError):
@@ -68,6 +69,7 @@ def load_library():
                                                C.c_int32, C.c_int32, C.c_int32]
     lib.gdmix_io_avro_write_scores.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.gdmix_io_write_grouped.argtypes = [C.c_char_p, C.POINTER(_Batch), C.POINTER(_Schema), C.c_int32]
     lib.gdmix_io_crc32c.argtypes = [C.c_char_p, C.c_size_t]
     lib.gdmix_io_crc32c.restype = C.c_uint32
     lib.gdmix_io_masked_crc32c.argtypes = [C.c_char_p, C.c_size_t]
@@ -203,3 +205,29 @@ def write_scores_avro(path, header: bytes, sync: bytes, uid, score, label, weigh
     if rc != 0:
         raise GdmixIoError("gdmix_io_avro_write_scores: " + lib.gdmix_io_last_error().decode("utf-8", "replace"))
     return len(uid)
+
+
+def write_grouped_file(path, batch: RawBatch, entity_name, feature_bag, offset_column_name="offset", uid_column_name="uid",
+                       label_column_name="response", weight_column_name="weight", int_entity_ids=False):
+    """One SequenceExample per entity of `batch` into `path` (suffix .gz / .deflate => compressed)."""
+    lib = load_library()
+    d = os.path.dirname(path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    id_bytes, id_ptr = _ids_to_bytes(batch.entity_ids)
+    keep = dict(erp=np.ascontiguousarray(batch.ent_row_ptr, np.int64), rnp=np.ascontiguousarray(batch.row_nnz_ptr, np.int64),
+                col=np.ascontiguousarray(batch.col_global, np.int64), val=np.ascontiguousarray(batch.val, np.float32),
+                y=np.ascontiguousarray(batch.y, np.float32), off=np.ascontiguousarray(batch.offset, np.float32),
+                w=None if batch.weight is None else np.ascontiguousarray(batch.weight, np.float32),
+                uid=np.ascontiguousarray(batch.uid, np.int64), idp=id_ptr)
+    idbuf = C.create_string_buffer(id_bytes, len(id_bytes) + 1)
+    cast = lambda a, t: None if a is None else C.cast(a.ctypes.data, C.POINTER(t))
+    b = _Batch(batch.E, batch.N, batch.Z, cast(keep["erp"], C.c_int64), cast(keep["rnp"], C.c_int64), cast(keep["col"], C.c_int64),
+               cast(keep["val"], C.c_float), cast(keep["y"], C.c_float), cast(keep["off"], C.c_float), cast(keep["w"], C.c_float),
+               cast(keep["uid"], C.c_int64), cast(keep["idp"], C.c_int64), C.cast(idbuf, C.POINTER(C.c_char)),
+               int(bool(batch.has_label)), 0)
+    sc = _Schema(_enc(entity_name), _enc(feature_bag), _enc(offset_column_name), _enc(uid_column_name),
+                 _enc(label_column_name), _enc(weight_column_name), -1, 0, 0)
+    rc = lib.gdmix_io_write_grouped(path.encode("utf-8"), C.byref(b), C.byref(sc), int(bool(int_entity_ids)))
+    if rc != 0:
+        raise GdmixIoError("gdmix_io_write_grouped: " + lib.gdmix_io_last_error().decode("utf-8", "replace"))

@@ -80,6 +80,14 @@ GDMIX_IO_API int gdmix_io_read_grouped(const char* const* files, int32_t n_files
                                        gdmix_io_batch** out);
 GDMIX_IO_API void gdmix_io_free(gdmix_io_batch* batch);
 
+/* Write a batch as one SequenceExample per entity (".gz" / ".deflate" suffix => compressed): the layout
+ * DataPartitioner produces (DataPartitioner.scala:313-316) and gdmix_io_read_grouped reads. int_entity_ids != 0:
+ * entity ids (decimal strings) are written as an int64 scalar instead of bytes. Labels are written as int64
+ * when batch->has_label; schema->weight NULL or batch->weight NULL => no weight column; num_features, check_crc
+ * and threads of the schema are ignored. */
+GDMIX_IO_API int gdmix_io_write_grouped(const char* path, const gdmix_io_batch* batch, const gdmix_io_schema* schema,
+                                        int32_t int_entity_ids);
+
 /* ---- Avro object container writers (model and score files) ----------------------------------------------
  * The caller supplies the container header (magic "Obj\x01", the metadata map with avro.schema / avro.codec,
  * the 16-byte sync marker) and the constant, pre-encoded pieces of a record; the library encodes the records in

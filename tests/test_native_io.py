@@ -282,3 +282,28 @@ def test_native_score_writer_is_byte_identical(tmp_path, has_label, has_weight):
     _write_scores(b, schema, sp, uid[:0], score[:0], None if label is None else label[:0],
                   None if weight is None else weight[:0], per[:0], native=True, sync_marker=sync)
     assert list(avro.read_file(b)) == []
+
+
+@pytest.mark.parametrize("int_ids", [False, True])
+@pytest.mark.parametrize("bag", ["bag", None])
+def test_native_tfrecord_writer_is_byte_identical_and_round_trips(tmp_path, int_ids, bag):
+    b = synthetic.make_ragged_batch(300, seed=5)
+    if int_ids:
+        b.entity_ids = [str(11 * i - 5) for i in range(b.E)]
+    a, n = str(tmp_path / "py.tfrecord"), str(tmp_path / "nat.tfrecord")
+    write_grouped_partition(a, b, "ent", bag, int_entity_ids=int_ids, native=False)
+    write_grouped_partition(n, b, "ent", bag, int_entity_ids=int_ids, native=True)
+    assert open(a, "rb").read() == open(n, "rb").read()
+    for suffix in (".gz", ".deflate"):
+        z = str(tmp_path / ("z" + suffix.replace(".", "_")) / ("part.tfrecord" + suffix))
+        write_grouped_partition(z, b, "ent", "bag", int_entity_ids=int_ids, native=True)
+        r = read_grouped_partition(z, MD, "ent", "bag", "offset", "uid", "response", "weight", num_features=4096,
+                                   check_crc=True, native=False)
+        for k in ARRAYS:
+            np.testing.assert_array_equal(getattr(r, k), getattr(b, k), err_msg=k)
+        assert r.entity_ids == b.entity_ids
+    # no label / no weight columns
+    nolab = RawBatch(**{**{k: getattr(b, k) for k in ARRAYS}, "weight": None, "entity_ids": b.entity_ids, "has_label": False})
+    write_grouped_partition(a, nolab, "ent", "bag", int_entity_ids=int_ids, native=False)
+    write_grouped_partition(n, nolab, "ent", "bag", int_entity_ids=int_ids, native=True)
+    assert open(a, "rb").read() == open(n, "rb").read()
