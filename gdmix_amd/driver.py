@@ -77,13 +77,28 @@ class RandomEffectDriver:
         logger.info(f"Execution context : {self.execution_context}")
         partition_index_list = self._get_partition_list()
         logger.info(f"This worker on work on the following list of partitions : {partition_index_list}")
-        for partition_index in partition_index_list:
+        # With entity re-balancing the workers train in lockstep, one partition each per round; a worker that has no
+        # partition (or an empty one) in a round still joins that round's collectives.
+        lockstep = bool(getattr(getattr(self.model, "model_params", None), "rebalance_entities", False))
+        rounds = len(partition_index_list)
+        if lockstep:
+            with open(self.base_training_params.partition_list_file) as f:
+                total = len(f.readline().split(","))
+            w = self.execution_context[constants.NUM_WORKERS]
+            rounds = (total + w - 1) // w
+        for k in range(rounds):
+            if k >= len(partition_index_list):
+                self.model.idle_round()
+                continue
+            partition_index = partition_index_list[k]
             checkpoint_path = self._anchor_directory(self.model.checkpoint_path, partition_index)
             training_data_dir = self._anchor_directory(self.model.training_data_dir, partition_index)
             validation_data_dir = self._anchor_directory(self.model.validation_data_dir, partition_index) \
                 if self.model.validation_data_dir else None
             if is_empty_directory(training_data_dir):
                 logger.info(f"{training_data_dir} is empty, no dataset to train on.")
+                if lockstep:
+                    self.model.idle_round()
                 continue
             self.execution_context[constants.PARTITION_INDEX] = partition_index
             self.model.train(training_data_dir=training_data_dir, validation_data_dir=validation_data_dir,

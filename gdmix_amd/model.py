@@ -290,22 +290,12 @@ class RandomEffectLRLBFGSModel:
         batch = self._read(input_path, tensor_metadata, schema_params, num_features, need_label=True)
         if not batch.has_label:
             raise KeyError(f"label column {schema_params.label_column_name!r} is missing from the training data")
-        solver = self._get_solver()
-        opts = self._solver_options()
-        packed = solver.pack(batch, has_intercept=self.has_intercept)
-        feat_ptr = packed.ent_feat_ptr().cpu().numpy()
-        uniq = packed.unique_global().cpu().numpy()
-        theta0 = None
-        if model_weights:
-            theta0, _ = _model_coefficients_for_batch(model_weights, batch.entity_ids, uniq, feat_ptr,
-                                                      self.has_intercept, num_features)
-        res = solver.solve(packed, opts, theta0=theta0).to_host()
+        theta_thr, variance, uniq, feat_ptr, stats = self._solve_batch(batch, model_weights, num_features)
         ic = 1 if self.has_intercept else 0
         coef_ptr = feat_ptr + np.arange(batch.E + 1, dtype=np.int64) * ic
-        self.last_training_stats = dict(entities=batch.E, samples=batch.N, nnz=batch.Z, nit=res["nit"], nfev=res["nfev"],
-                                        status=res["status"], fval=res["fval"], gnorm=res["gnorm"])
+        self.last_training_stats = dict(entities=batch.E, samples=batch.N, nnz=batch.Z, **stats)
         results = ModelTable()
-        results.add_chunk(batch.entity_ids, res["theta_thr"], coef_ptr, uniq, feat_ptr, res.get("variance"))
+        results.add_chunk(batch.entity_ids, theta_thr, coef_ptr, uniq, feat_ptr, variance)
         # The trained model is updated over the prior model: prior entities that are not in the current data
         # are carried over (random_effect_lr_lbfgs_model.py:155-162).
         model_weights.update(results)
@@ -313,6 +303,75 @@ class RandomEffectLRLBFGSModel:
         self._save_model(output_model_file, model_coefficients=model_weights, num_features=num_features,
                          feature_file=self.feature_file)
         return model_weights
+
+    _STAT_KEYS = ("nit", "nfev", "status", "fval", "gnorm")
+
+    def _rebalancing(self, model_weights):
+        """Entities travel between ranks only when asked for, in a multi-rank job, and for a cold start (a prior model
+        lives on the rank that owns the partition). Collective: every rank reaches the same decision."""
+        if not self.model_params.rebalance_entities:
+            return False
+        try:
+            import torch.distributed as dist
+        except ImportError:
+            return False
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return False
+        flags = [None] * dist.get_world_size()
+        dist.all_gather_object(flags, bool(model_weights))
+        if any(flags):
+            logger.info("a prior model is present on some worker: entities stay on the worker that owns their partition")
+            return False
+        return True
+
+    def _solve_batch(self, batch, model_weights, num_features):
+        """-> thresholded coefficients, variances|None, global feature index per coefficient, feat_ptr, solver statistics
+        for the entities of `batch`, in its order. With re-balancing part of the work is done on other ranks and
+        other ranks' entities here (rebalance.py); the arithmetic per entity is the same either way."""
+        solver = self._get_solver()
+        opts = self._solver_options()
+        rb = None
+        work = batch
+        if self._rebalancing(model_weights):
+            from .rebalance import Rebalancer
+            rb = Rebalancer(batch)
+            work = rb.exchange()
+            logger.info(f"re-balancing: loads {rb.loads.tolist()}, sent {[int(x.size) for x in rb.sent]}, "
+                        f"received {rb.recv_counts}, solving {work.E} entities here")
+        ic = 1 if self.has_intercept else 0
+        if work.E == 0:
+            theta_thr, variance, uniq = np.zeros(0), None, np.zeros(0, np.int64)
+            feat_ptr = np.zeros(1, np.int64)
+            stats = {k: np.zeros(0) for k in self._STAT_KEYS}
+        else:
+            packed = solver.pack(work, has_intercept=self.has_intercept)
+            feat_ptr = packed.ent_feat_ptr().cpu().numpy()
+            uniq = packed.unique_global().cpu().numpy()
+            theta0 = None
+            if model_weights:
+                theta0, _ = _model_coefficients_for_batch(model_weights, work.entity_ids, uniq, feat_ptr,
+                                                          self.has_intercept, num_features)
+            res = solver.solve(packed, opts, theta0=theta0).to_host()
+            theta_thr, variance = res["theta_thr"], res.get("variance")
+            stats = {k: res[k] for k in self._STAT_KEYS}
+        if rb is not None:
+            feat_cnt = np.diff(feat_ptr)
+            coef_cnt, theta_thr, variance, feat_cnt, uniq, st = rb.give_back(feat_cnt + ic, theta_thr, variance, feat_cnt, uniq, stats)
+            feat_ptr = np.concatenate([[0], np.cumsum(feat_cnt)]).astype(np.int64)
+            stats = {k: (st[k].astype(np.int32) if k in ("nit", "nfev", "status") else st[k]) for k in self._STAT_KEYS}
+        return theta_thr, variance, uniq, feat_ptr, stats
+
+    def idle_round(self, num_features=1):
+        """A rank without a partition in this round still takes part in the re-balancing collectives (and solves what
+        it is sent)."""
+        if not self.model_params.rebalance_entities:
+            return
+        from .batch import RawBatch
+        z = lambda dt: np.zeros(0, dt)
+        empty = RawBatch(ent_row_ptr=np.zeros(1, np.int64), row_nnz_ptr=np.zeros(1, np.int64), col_global=z(np.int64),
+                         val=z(np.float32), y=z(np.float32), offset=z(np.float32), weight=None, uid=z(np.int64),
+                         entity_ids=[], has_label=True)
+        self._solve_batch(empty, ModelTable(), num_features)
 
     def _predict(self, input_path, tensor_metadata, output_file, schema_params, num_features, model_weights):
         logger.info(f"Start inference for {input_path}.")

@@ -94,6 +94,8 @@ class REParams(LRParams):
     num_of_consumers: int = 2
     random_effect_variance_mode: Optional[str] = None
     disable_random_effect_scoring_after_training: bool = False
+    # not in the reference: move entities between the workers of a node when partitions are skewed (rebalance.py)
+    rebalance_entities: bool = False
 
     def __post_init__(self):
         super().__post_init__()

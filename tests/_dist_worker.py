@@ -24,6 +24,17 @@ def main():
     argv = json.load(open(os.path.join(base, "argv.json")))
     model = RandomEffectLRLBFGSModel(argv)
     model._solver = OracleSolverDouble()
+    # record what every re-balancing round did on this rank
+    rounds = []
+    from gdmix_amd import rebalance as rbm
+    orig_exchange = rbm.Rebalancer.exchange
+
+    def exchange(self):
+        work = orig_exchange(self)
+        rounds.append({"entities": int(self.batch.E), "sent": [int(x.size) for x in self.sent], "received": list(self.recv_counts),
+                       "solved": int(work.E)})
+        return work
+    rbm.Rebalancer.exchange = exchange
     driver = RandomEffectDriver(Params.__from_argv__(argv), model)
     assert driver.execution_context["task_index"] == rank and driver.execution_context["num_workers"] == world
     mine = driver._get_partition_list()
@@ -33,8 +44,11 @@ def main():
     # load totals: the only collective the RE path needs is this kind of tiny metadata exchange
     t = torch.tensor([len(mine)], dtype=torch.int64)
     dist.all_reduce(t)
+    all_rounds = [None] * world
+    dist.all_gather_object(all_rounds, rounds)
     if rank == 0:
-        json.dump({"per_rank": gathered, "total": int(t.item())}, open(os.path.join(base, "result.json"), "w"))
+        json.dump({"per_rank": gathered, "total": int(t.item()), "rebalance": all_rounds},
+                  open(os.path.join(base, "result.json"), "w"))
     dist.barrier()
     dist.destroy_process_group()
 
