@@ -45,7 +45,9 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_PAIR4, 1, "re_solve_grp_kernel<32,4> n<=256 nnz<=1024", 256, 1024},
     {KIND_G64_3, 1, "re_solve_grp_kernel<64,3> n<=64 nnz<=512", 64, 512},    {KIND_G64_3, 1, "re_solve_grp_kernel<64,3> n<=512 nnz<=2048", 512, 2048},
     {KIND_G64_4, 1, "re_solve_grp_kernel<64,4> n<=64 nnz<=512", 64, 512},    {KIND_G64_4, 1, "re_solve_grp_kernel<64,4> n<=512 nnz<=2048", 512, 2048},
+    {KIND_G128_3, 1, "re_solve_grp_kernel<128,3> n<=128 nnz<=1024", 128, 1024}, {KIND_G128_3, 1, "re_solve_grp_kernel<128,3> n<=1024 nnz<=3072", 1024, 3072},
     {KIND_G128_4, 1, "re_solve_grp_kernel<128,4> n<=128 nnz<=1024", 128, 1024}, {KIND_G128_4, 1, "re_solve_grp_kernel<128,4> n<=1024 nnz<=3072", 1024, 3072},
+    {KIND_G256_3, 1, "re_solve_grp_kernel<256,3> n<=256 nnz<=2048", 256, 2048}, {KIND_G256_3, 1, "re_solve_grp_kernel<256,3> n<=2048 nnz<=4096", 2048, 4096},
     {KIND_G256_4, 1, "re_solve_grp_kernel<256,4> n<=256 nnz<=2048", 256, 2048}, {KIND_G256_4, 1, "re_solve_grp_kernel<256,4> n<=2048 nnz<=4096", 2048, 4096},
     {KIND_G512_4, 1, "re_solve_grp_kernel<512,4> n<=512 nnz<=4096", 512, 4096},
     {KIND_WREG1, 3072, "re_solve_wreg_kernel<1> lds<=3K"},   {KIND_WREG1, 65536, "re_solve_wreg_kernel<1> lds<=64K"},
@@ -332,7 +334,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[c], s)); }
     switch (kClasses[c].kind) {
       case KIND_QUAD2: case KIND_QUAD3: case KIND_QUAD4: case KIND_PAIR3: case KIND_PAIR4:
-      case KIND_G64_3: case KIND_G64_4: case KIND_G128_4: case KIND_G256_4: case KIND_G512_4:
+      case KIND_G64_3: case KIND_G64_4: case KIND_G128_3: case KIND_G128_4: case KIND_G256_3: case KIND_G256_4: case KIND_G512_4:
         HIP_TRY(launch_solve_quad(group_lanes(kClasses[c].kind), group_epl(kClasses[c].kind), B, O, P, theta0, begin, hc[c],
                                   kClasses[c].ncap, kClasses[c].zcap, s));
         break;

@@ -21,15 +21,15 @@ namespace gdmix {
 //   KIND_BLOCK      workgroup-per-entity kernel working out of a global scratch slot (anything)
 // Each wavefront kind is split into LDS-footprint buckets so that small entities keep high occupancy.
 enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4, KIND_QUAD2 = 5, KIND_QUAD4 = 6, KIND_PAIR4 = 7, KIND_QUAD3 = 8, KIND_PAIR3 = 9, KIND_WREG8 = 10,
-       KIND_G64_3 = 11, KIND_G64_4 = 12, KIND_G128_4 = 13, KIND_G256_4 = 14, KIND_G512_4 = 15, KIND_GRID = 16 };
+       KIND_G64_3 = 11, KIND_G64_4 = 12, KIND_G128_4 = 13, KIND_G256_4 = 14, KIND_G512_4 = 15, KIND_GRID = 16, KIND_G128_3 = 17, KIND_G256_3 = 18 };
 
 // group kernels (several entities per wavefront): lanes per entity, coefficient slots per lane; 0 if not a group kind
 __host__ __device__ inline int group_lanes(int kind) {
   return (kind == KIND_QUAD2 || kind == KIND_QUAD3 || kind == KIND_QUAD4) ? 16 : ((kind == KIND_PAIR3 || kind == KIND_PAIR4) ? 32 :
-         ((kind == KIND_G64_3 || kind == KIND_G64_4) ? 64 : (kind == KIND_G128_4 ? 128 : (kind == KIND_G256_4 ? 256 : (kind == KIND_G512_4 ? 512 : 0)))));
+         ((kind == KIND_G64_3 || kind == KIND_G64_4) ? 64 : ((kind == KIND_G128_4 || kind == KIND_G128_3) ? 128 : ((kind == KIND_G256_4 || kind == KIND_G256_3) ? 256 : (kind == KIND_G512_4 ? 512 : 0)))));
 }
 __host__ __device__ inline int group_epl(int kind) {
-  return kind == KIND_QUAD2 ? 2 : ((kind == KIND_QUAD3 || kind == KIND_PAIR3 || kind == KIND_G64_3) ? 3 : (group_lanes(kind) > 0 ? 4 : 0));
+  return kind == KIND_QUAD2 ? 2 : ((kind == KIND_QUAD3 || kind == KIND_PAIR3 || kind == KIND_G64_3 || kind == KIND_G128_3 || kind == KIND_G256_3) ? 3 : (group_lanes(kind) > 0 ? 4 : 0));
 }
 constexpr int GIANT_CLASS = GDMIX_RE_NUM_CLASSES - 1;   // device-wide kernel, one entity at a time
 constexpr int XTEAM_CLASS = GDMIX_RE_NUM_CLASSES - 2;   // 16 CUs per entity, 16 entities at a time

@@ -467,8 +467,8 @@ hipError_t launch_solve_quad(int g, int epl, const BatchDev& B, const OutDev& O,
   GDMIX_GRP_CASE(32, 3, 32, 128) GDMIX_GRP_CASE(32, 3, 64, 256) GDMIX_GRP_CASE(32, 3, 256, 1024)
   GDMIX_GRP_CASE(32, 4, 32, 128) GDMIX_GRP_CASE(32, 4, 64, 256) GDMIX_GRP_CASE(32, 4, 256, 1024)
   GDMIX_GRP_CASE(64, 3, 64, 512) GDMIX_GRP_CASE(64, 3, 512, 2048) GDMIX_GRP_CASE(64, 4, 64, 512) GDMIX_GRP_CASE(64, 4, 512, 2048)
-  GDMIX_GRP_CASE(128, 4, 128, 1024) GDMIX_GRP_CASE(128, 4, 1024, 3072)
-  GDMIX_GRP_CASE(256, 4, 256, 2048) GDMIX_GRP_CASE(256, 4, 2048, 4096)
+  GDMIX_GRP_CASE(128, 3, 128, 1024) GDMIX_GRP_CASE(128, 3, 1024, 3072) GDMIX_GRP_CASE(128, 4, 128, 1024) GDMIX_GRP_CASE(128, 4, 1024, 3072)
+  GDMIX_GRP_CASE(256, 3, 256, 2048) GDMIX_GRP_CASE(256, 3, 2048, 4096) GDMIX_GRP_CASE(256, 4, 256, 2048) GDMIX_GRP_CASE(256, 4, 2048, 4096)
   GDMIX_GRP_CASE(512, 4, 512, 4096)
 #undef GDMIX_GRP_CASE
   return hipErrorInvalidValue;
