@@ -22,6 +22,7 @@ class RawBatch:
     uid: Optional[np.ndarray] = None     # int64 [N] sample ids (scoring output only)
     entity_ids: Optional[List[str]] = None  # [E] str(entity id) as job_consumers.py:235-239 renders it
     has_label: bool = True
+    binary_labels: bool = True              # False: real-valued labels (fixed-effect linear regression)
 
     def __post_init__(self):
         self.ent_row_ptr = np.ascontiguousarray(self.ent_row_ptr, np.int64)
@@ -70,7 +71,7 @@ class RawBatch:
         if self.entity_ids is not None and len(self.entity_ids) != E:
             raise ValueError("entity_ids must have E elements")
         # fit() asserts labels are 0/1 (binary_logistic_regression.py:208)
-        if self.has_label and N and np.count_nonzero((self.y != 0) & (self.y != 1)):
+        if self.has_label and self.binary_labels and N and np.count_nonzero((self.y != 0) & (self.y != 1)):
             raise AssertionError("labels must be 0 or 1")
 
     def ent_nnz(self):

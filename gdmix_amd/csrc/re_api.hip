@@ -98,6 +98,7 @@ GDMIX_API void gdmix_re_default_opts(gdmix_re_opts* o) {
   o->l2 = 1.0; o->regularize_bias = 1; o->has_intercept = 1; o->m = 10; o->max_iter = 100;
   o->maxfun = 15000; o->maxls = 20; o->ftol = 1e-12; o->pgtol = 1e-5;
   o->variance_mode = GDMIX_RE_VAR_NONE; o->threshold = 1e-4;
+  o->sum_loss = 0; o->linear = 0;
 }
 
 GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
@@ -308,6 +309,12 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   // the compact-form team kernels keep TEAM_MCAP history pairs
   tab.giant_nnz = opts->m <= TEAM_MCAP ? ctx->impl.giant_nnz : 0;
   tab.team_nnz = opts->m <= TEAM_MCAP ? ctx->impl.team_nnz : 0;
+  if (opts->sum_loss || opts->linear) {
+    // the fixed-effect objective lives in the team kernels only: every entity goes device-wide, one after another
+    if (opts->m > TEAM_MCAP) { set_error("sum_loss / linear need m <= %d", TEAM_MCAP); return GDMIX_RE_EINVAL; }
+    if (opts->variance_mode != GDMIX_RE_VAR_NONE) { set_error("variance is not available with sum_loss / linear"); return GDMIX_RE_EINVAL; }
+    tab.giant_nnz = 1;
+  }
 
   int32_t* cc = b->class_count;
   HIP_TRY(hipMemsetAsync(cc, 0, 3 * GDMIX_RE_NUM_CLASSES * sizeof(int32_t), s));
@@ -323,6 +330,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   P.l2 = opts->l2; P.ftol = opts->ftol; P.pgtol = opts->pgtol; P.threshold = opts->threshold;
   P.regularize_bias = opts->regularize_bias; P.has_intercept = ic; P.m = opts->m; P.max_iter = opts->max_iter;
   P.maxfun = opts->maxfun; P.maxls = opts->maxls; P.variance_mode = opts->variance_mode;
+  P.sum_loss = opts->sum_loss ? 1 : 0; P.linear = opts->linear ? 1 : 0;
   BatchDev B = make_batch_dev(b);
   OutDev O{out->theta, out->theta_thr, out->variance, out->fval, out->gnorm, out->nit, out->nfev, out->status};
 

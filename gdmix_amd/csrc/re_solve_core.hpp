@@ -13,6 +13,7 @@ namespace gdmix {
 struct SolveParams {
   double l2, ftol, pgtol, threshold;
   int regularize_bias, has_intercept, m, max_iter, maxfun, maxls, variance_mode;
+  int sum_loss, linear;   // fixed-effect objective (team kernels only)
 };
 
 // One entity's data, pointers into LDS (wave kernel) or HBM (block kernel).

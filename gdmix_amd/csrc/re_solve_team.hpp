@@ -224,7 +224,13 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
     const double yi = (double)P.y[i];
     const double wi = P.w ? (double)P.w[i] : 1.0;
     double ri;
-    pr[0] += logistic_terms(z, yi, wi, ri);
+    if (o.linear) {   // squared loss, fixed_effect_lr_lbfgs_model.py:356-358
+      const double e = z - yi;
+      pr[0] += wi * e * e;
+      ri = 2.0 * wi * e;
+    } else {
+      pr[0] += logistic_terms(z, yi, wi, ri);
+    }
     W.rs[i] = ri;
     pr[1] += ri;
   }
@@ -234,7 +240,7 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
   const double loss = pr[0], rsum = pr[1];
   // ---- columns: X'r by tiles of 64 coefficients per wavefront, lane c of the tile ends up owning column c
   const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
-  const double inv_n = 1.0 / (double)n;
+  const double inv_n = o.sum_loss ? 1.0 : 1.0 / (double)n;
   TeamLds<NW>& L = *tm.L;
   const int n_long = L.n_long;
   if (n_long > 0) {

@@ -50,7 +50,7 @@ class _Opts(C.Structure):
     _fields_ = [("l2", C.c_double), ("regularize_bias", C.c_int32), ("has_intercept", C.c_int32),
                 ("m", C.c_int32), ("max_iter", C.c_int32), ("maxfun", C.c_int32), ("maxls", C.c_int32),
                 ("ftol", C.c_double), ("pgtol", C.c_double), ("variance_mode", C.c_int32),
-                ("threshold", C.c_double)]
+                ("threshold", C.c_double), ("sum_loss", C.c_int32), ("linear", C.c_int32)]
 
 
 class _Result(C.Structure):
@@ -115,7 +115,7 @@ def load_library():
     lib.gdmix_java_partition_id.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     lib.gdmix_java_partition_id.restype = C.c_int32
     lib.gdmix_java_partition_ids_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
-    if lib.gdmix_re_abi_version() != 1:
+    if lib.gdmix_re_abi_version() != 2:
         raise GdmixReError("libgdmix_re.so ABI version mismatch")
     _lib = lib
     return lib
@@ -142,11 +142,14 @@ class SolverOptions:
     pgtol: float = 1e-5
     variance_mode: int = VAR_NONE
     threshold: float = 1e-4       # sparsity_threshold (base_lr_params.py:32)
+    sum_loss: bool = False        # fixed-effect objective: not divided by n (fixed_effect_lr_lbfgs_model.py:363-381)
+    linear: bool = False          # squared loss instead of the logistic loss (:356-358)
 
     def to_c(self):
         return _Opts(float(self.l2), int(bool(self.regularize_bias)), int(bool(self.has_intercept)),
                      int(self.m), int(self.max_iter), int(self.maxfun), int(self.maxls), float(self.ftol),
-                     float(self.pgtol), int(VARIANCE_MODES[self.variance_mode]), float(self.threshold))
+                     float(self.pgtol), int(VARIANCE_MODES[self.variance_mode]), float(self.threshold),
+                     int(bool(self.sum_loss)), int(bool(self.linear)))
 
 
 def java_string_hash(s: str) -> int:

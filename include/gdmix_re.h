@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GDMIX_RE_ABI_VERSION 1
+#define GDMIX_RE_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define GDMIX_API __attribute__((visibility("default")))
@@ -137,6 +137,11 @@ typedef struct {
   double  pgtol;            /* scipy default                          1e-5          */
   int32_t variance_mode;    /* GDMIX_RE_VAR_*                         default NONE  */
   double  threshold;        /* sparsity_threshold applied to theta_thr, default 1e-4 (model_utils.py:4-12) */
+  /* The two switches below turn the per-entity objective into the fixed-effect one
+   * (fixed_effect_lr_lbfgs_model.py:309-392): a batch with one "entity" = one worker's shard. Defaults 0.
+   * Non-default values route every entity to the team kernels. */
+  int32_t sum_loss;         /* 1: f = sum_i w_i l_i + (l2/2)|theta_reg|^2, not divided by n (:363-381)            */
+  int32_t linear;           /* 1: l_i = (y_i - z_i)^2 (linear regression, :356-358) instead of the logistic loss */
 } gdmix_re_opts;
 
 /* fills *o with the defaults above */

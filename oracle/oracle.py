@@ -19,14 +19,14 @@ class OracleOpts(C.Structure):
     _fields_ = [("l2", C.c_double), ("regularize_bias", C.c_int32), ("has_intercept", C.c_int32),
                 ("m", C.c_int32), ("max_iter", C.c_int32), ("maxfun", C.c_int32), ("maxls", C.c_int32),
                 ("ftol", C.c_double), ("pgtol", C.c_double), ("variance_mode", C.c_int32),
-                ("threshold", C.c_double)]
+                ("threshold", C.c_double), ("sum_loss", C.c_int32), ("linear", C.c_int32)]
 
 
 def make_opts(l2=1.0, regularize_bias=True, has_intercept=True, m=10, max_iter=100, maxfun=15000,
-              maxls=20, ftol=1e-12, pgtol=1e-5, variance_mode=0, threshold=1e-4):
+              maxls=20, ftol=1e-12, pgtol=1e-5, variance_mode=0, threshold=1e-4, sum_loss=False, linear=False):
     return OracleOpts(float(l2), int(bool(regularize_bias)), int(bool(has_intercept)), int(m),
                       int(max_iter), int(maxfun), int(maxls), float(ftol), float(pgtol),
-                      int(variance_mode), float(threshold))
+                      int(variance_mode), float(threshold), int(bool(sum_loss)), int(bool(linear)))
 
 
 def build(force=False):

@@ -78,6 +78,7 @@ typedef struct {
   const float *y, *o, *w;     /* w may be NULL */
   double l2;
   int reg_bias;
+  int sum_loss, linear;       /* fixed-effect objective: not divided by n / squared loss */
   double* z;                  /* [n] scratch */
   double* r;                  /* [n] scratch */
 } problem;
@@ -102,6 +103,12 @@ static double fg_(const problem* P, const double* th, double* g) {
   double cost = 0.0;
   for (int i = 0; i < n; ++i) {
     double zi = P->z[i], yi = (double)P->y[i], wi = P->w ? (double)P->w[i] : 1.0;
+    if (P->linear) {
+      /* squared_difference(labels, logits), fixed_effect_lr_lbfgs_model.py:356-358; d/dz = 2 (z - y) */
+      cost += wi * (yi - zi) * (yi - zi);
+      P->r[i] = 2.0 * wi * (zi - yi);
+      continue;
+    }
     /* max(x,0) - x*y + log(1 + exp(-|x|))   (:103) */
     double ce = fmax(zi, 0.0) - zi * yi + log(1.0 + exp(-fabs(zi)));
     cost += wi * ce;
@@ -111,7 +118,8 @@ static double fg_(const problem* P, const double* th, double* g) {
   int first_reg = (ic && !P->reg_bias) ? 1 : 0;
   double sq = 0.0;
   for (int j = first_reg; j < p; ++j) sq += th[j] * th[j];
-  double f = (1.0 / n) * (cost + (P->l2 / 2.0) * sq);                  /* (:108) */
+  const double inv_n = P->sum_loss ? 1.0 : 1.0 / n;   /* fixed effect: value = sum + regulariser, :363-381 */
+  double f = inv_n * (cost + (P->l2 / 2.0) * sq);                      /* (:108) */
   for (int j = 0; j < p; ++j) g[j] = 0.0;
   if (ic) for (int i = 0; i < n; ++i) g[0] += P->r[i];
   for (int i = 0; i < n; ++i)
@@ -120,7 +128,7 @@ static double fg_(const problem* P, const double* th, double* g) {
   for (int j = 0; j < p; ++j) {
     double reg = P->l2 * th[j];
     if (j < first_reg) reg = 0.0;
-    g[j] = (1.0 / n) * (g[j] + reg);                                   /* (:129) */
+    g[j] = inv_n * (g[j] + reg);                                       /* (:129) */
   }
   return f;
 }
@@ -481,7 +489,7 @@ static int variance_(const problem* P, const double* th, int mode, double* var, 
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
   double l2; int32_t regularize_bias, has_intercept, m, max_iter, maxfun, maxls;
-  double ftol, pgtol; int32_t variance_mode; double threshold;
+  double ftol, pgtol; int32_t variance_mode; double threshold; int32_t sum_loss, linear;
 } oracle_opts;  /* same field order as gdmix_re_opts */
 
 /* Solves entities [e_begin, e_end). Any output pointer may be NULL. Returns 0 or <0. */
@@ -506,6 +514,7 @@ int oracle_solve(int64_t e_begin, int64_t e_end, const int64_t* ent_row_ptr, con
     P.val = csr_val + z0;
     P.y = y + r0; P.o = offset + r0; P.w = weight ? weight + r0 : NULL;
     P.l2 = opt->l2; P.reg_bias = opt->regularize_bias;
+    P.sum_loss = opt->sum_loss; P.linear = opt->linear;
     const int p = P.p, m = O.m;
     size_t wsz = (size_t)4 * p + (size_t)2 * m * p + (size_t)2 * m + (size_t)2 * P.n + (size_t)p;
     double* work = (double*)malloc(sizeof(double) * wsz);
