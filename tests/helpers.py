@@ -17,6 +17,7 @@ REL_TOL_ORACLE = 1e-8      # CPU restatement vs reference scipy fixtures (well-p
 
 def fixture_names(solve_only=True):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+    names = [n for n in names if not n.startswith("fe_")]   # fixed-effect fixtures: tests/test_fixed_effect.py
     if solve_only:
         names = [n for n in names if not n.startswith("score_")]
     return names
