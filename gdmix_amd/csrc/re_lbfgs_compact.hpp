@@ -1,0 +1,270 @@
+// re_lbfgs_compact.hpp — the driver of fmin_l_bfgs_b in compact (Byrd-Nocedal-Schnabel) form, as a resumable step:
+// given the objective value and the fused products of one evaluation, decide what happens next (stop, another
+// line-search trial, a new search direction) and leave the coefficients of the elementwise update. Shared by the
+// team kernels (re_solve_team.hpp: state in registers, one kernel per solve) and the fixed-effect stepping kernels
+// (fe_solve.hip: state in HBM between kernels, an all-reduce in between). Rules: scipy's loop around setulb,
+// L-BFGS-B 3.0 mainlb / lnsrlb / matupd, MINPACK-2 dcsrch (re_device.hpp).
+#pragma once
+#include "re_solve_core.hpp"
+
+namespace gdmix {
+
+constexpr int TEAM_MCAP = 10;                 // history pairs the compact path keeps accumulators for
+constexpr int TEAM_K = 2 * TEAM_MCAP + 6;     // fused reduction width: sq, gd, gg, rr, gr, S'g, Y'g, max|g|
+// acc[] layout: 0 sum x_j^2 over regularised j, 1 g'd, 2 g'g, 3 (g-r)'(g-r), 4 g'r, 5.. S_i'g, 5+MCAP.. Y_i'g
+// (chronological i < col), K-1 max|g_j|.
+
+struct CompactState {   // uniform over the cooperating threads
+  LineSearch ls;
+  double theta, f, fold, gdold, stp, sbgnrm, gg_k;
+  int col, head, nit, nfev, ifun, status, first, iter0;
+};
+
+__device__ __forceinline__ void compact_init(CompactState& S) {
+  S.theta = 1.0; S.f = 0.0; S.fold = 0.0; S.gdold = 0.0; S.stp = 0.0; S.sbgnrm = 0.0; S.gg_k = 0.0;
+  S.col = 0; S.head = 0; S.nit = 0; S.nfev = 0; S.ifun = 0; S.status = -1; S.first = 1; S.iter0 = 1;
+}
+
+enum { CA_STOP = 0, CA_STOP_RESTORE = 1, CA_RETRY = 2, CA_DIRECTION = 3 };
+
+struct CompactPlan {    // what the elementwise pass over the p-vectors has to do
+  int action;           // CA_STOP: x is the result; CA_STOP_RESTORE: x := t first; CA_RETRY: x := t + stp d;
+                        // CA_DIRECTION: store the pair, build d, x := x + stp d
+  int store_pair, restore, slot, cnew, col, head;
+  double stp, stp_prev, gamma;
+};
+
+struct CompactMats {    // the m x m part (LDS; every workgroup keeps a replica)
+  double SY[TEAM_MCAP * TEAM_MCAP];   // s_i'y_k, chronological, i <= k used
+  double YY[TEAM_MCAP * TEAM_MCAP];   // y_i'y_k
+  double ap[TEAM_MCAP], bp[TEAM_MCAP];   // S'g_k, Y'g_k at the last accepted iterate
+  double u[TEAM_MCAP], q[TEAM_MCAP];
+  double sc[4];
+};
+
+// Called by every thread of a workgroup with identical arguments. Contains one __syncthreads() on the
+// CA_DIRECTION path.
+__device__ __forceinline__ void compact_advance(CompactState& S, const double (&acc)[TEAM_K], double f_new,
+                                                const SolveParams& o, CompactMats& L, CompactPlan& plan) {
+  const int m = o.m;
+  ++S.nfev;
+  const double gd = acc[1], gg = acc[2], rr = acc[3], gr = acc[4];
+  bool restore = false, store_pair = false, shift = false;
+  double dr = 0.0;
+  const double stp_prev = S.stp;
+  plan.store_pair = 0; plan.restore = 0; plan.slot = 0; plan.cnew = 0; plan.stp_prev = stp_prev;
+  if (S.first) {
+    S.first = 0;
+    S.f = f_new;
+    S.sbgnrm = acc[TEAM_K - 1];
+    if (S.sbgnrm <= o.pgtol) { S.status = 0; plan.action = CA_STOP; return; }
+  } else {
+    S.f = f_new;
+    double stp = S.stp;
+    const int task = dcsrch_step(S.ls, f_new, gd, stp);
+    S.stp = stp;
+    if (task == LS_FG) {
+      ++S.ifun;
+      if (S.ifun - 1 < o.maxls) { plan.action = CA_RETRY; plan.stp = stp; return; }
+      restore = true;   // iback >= maxls: back to the last iterate, forget the history
+    } else {
+      ++S.nit;
+      S.iter0 = 0;
+      S.sbgnrm = acc[TEAM_K - 1];
+      if (S.nit >= o.max_iter) { S.status = 2; plan.action = CA_STOP; return; }
+      if (S.nfev > o.maxfun) { S.status = 3; plan.action = CA_STOP; return; }
+      if (S.sbgnrm <= o.pgtol) { S.status = 0; plan.action = CA_STOP; return; }
+      {
+        const double ddum = fmax(fabs(S.fold), fmax(fabs(S.f), 1.0));
+        if (S.fold - S.f <= o.ftol * ddum) { S.status = 1; plan.action = CA_STOP; return; }
+      }
+      double ddum;
+      if (stp == 1.0) { dr = gd - S.gdold; ddum = -S.gdold; }
+      else { dr = (gd - S.gdold) * stp; ddum = -S.gdold * stp; }
+      store_pair = dr > EPSMCH * ddum;
+    }
+  }
+  // ---- new search direction
+  int slot = 0;          // history slot of the pair being stored
+  double gg_cur = gg;    // g'g of the gradient the direction is built from
+  if (restore) {
+    if (S.col == 0) { S.f = S.fold; S.status = 4; plan.action = CA_STOP_RESTORE; return; }
+    S.col = 0; S.head = 0; S.theta = 1.0;
+    S.f = S.fold;
+    gg_cur = S.gg_k;
+  }
+  int col = S.col, head = S.head;
+  double theta = S.theta;
+  if (store_pair) {
+    if (col < m) { slot = head + col; if (slot >= m) slot -= m; ++col; }
+    else { slot = head; ++head; if (head >= m) head = 0; shift = true; }
+    theta = rr / dr;
+  }
+  const int cnew = col - 1;   // chronological index of the stored pair
+  // The small dense part, by the first wavefront of every workgroup (each workgroup keeps its own replica in
+  // LDS): lane i owns row i of the m x m matrices; the triangular solves broadcast one unknown per step.
+  if (threadIdx.x < WAVE) {
+    const int i = (int)threadIdx.x;
+    constexpr int MM = TEAM_MCAP * TEAM_MCAP;
+    if (store_pair && shift) {   // drop the oldest pair: (r, c) <- (r + 1, c + 1)
+      double sy[2], yy[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int idx = i + h * WAVE;
+        const int r = idx / TEAM_MCAP, c = idx - r * TEAM_MCAP;
+        const bool ok = idx < MM && r + 1 < m && c + 1 < m;
+        sy[h] = ok ? L.SY[(r + 1) * TEAM_MCAP + c + 1] : 0.0;
+        yy[h] = ok ? L.YY[(r + 1) * TEAM_MCAP + c + 1] : 0.0;
+      }
+      const double pa = (i + 1 < m) ? L.ap[i + 1] : 0.0, pb = (i + 1 < m) ? L.bp[i + 1] : 0.0;
+      wave_lds_fence();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int idx = i + h * WAVE;
+        const int r = idx / TEAM_MCAP, c = idx - r * TEAM_MCAP;
+        if (idx < MM && r + 1 < m && c + 1 < m) { L.SY[idx] = sy[h]; L.YY[idx] = yy[h]; }
+      }
+      if (i + 1 < m) { L.ap[i] = pa; L.bp[i] = pb; }
+      wave_lds_fence();
+    }
+    // S'g, Y'g of row i in chronological order after the shift; products with the new pair in closed form
+    double ai = 0.0, bi = 0.0;
+#pragma unroll
+    for (int k = 0; k < TEAM_MCAP; ++k) {
+      if (i == k) {
+        if (shift) { if (k + 1 < TEAM_MCAP) { ai = acc[5 + (k + 1 < TEAM_MCAP ? k + 1 : k)]; bi = acc[5 + TEAM_MCAP + (k + 1 < TEAM_MCAP ? k + 1 : k)]; } }
+        else { ai = acc[5 + k]; bi = acc[5 + TEAM_MCAP + k]; }
+      }
+    }
+    if (store_pair) {
+      if (i < cnew) {
+        L.SY[i * TEAM_MCAP + cnew] = ai - L.ap[i];   // s_i'(g - g_k)
+        const double yy = bi - L.bp[i];              // y_i'(g - g_k)
+        L.YY[i * TEAM_MCAP + cnew] = yy;
+        L.YY[cnew * TEAM_MCAP + i] = yy;
+      } else if (i == cnew) {
+        L.SY[cnew * TEAM_MCAP + cnew] = dr;
+        L.YY[cnew * TEAM_MCAP + cnew] = rr;
+        ai = stp_prev * gd;   // s'g,  s = stp d
+        bi = gg - gr;         // y'g,  y = g - g_k
+      }
+      wave_lds_fence();
+    }
+    const bool row = i < col;
+    const int ir = row ? i : 0;
+    double Rrow[TEAM_MCAP], Rcol[TEAM_MCAP], Yrow[TEAM_MCAP];
+#pragma unroll
+    for (int k = 0; k < TEAM_MCAP; ++k) {
+      const bool ok = row && k < col;
+      Rrow[k] = ok ? L.SY[ir * TEAM_MCAP + k] : 0.0;
+      Rcol[k] = ok ? L.SY[k * TEAM_MCAP + ir] : 0.0;
+      Yrow[k] = ok ? L.YY[ir * TEAM_MCAP + k] : 0.0;
+    }
+    double diag = 1.0;
+#pragma unroll
+    for (int k = 0; k < TEAM_MCAP; ++k)
+      if (i == k && row) diag = Rrow[k];
+    const double rdiag = 1.0 / diag;
+    const double gamma = 1.0 / theta;
+    // q = R^-1 a, last unknown first
+    double qk[TEAM_MCAP], uk[TEAM_MCAP];
+    double sv = row ? ai : 0.0, myq = 0.0, myu = 0.0;
+#pragma unroll
+    for (int k = TEAM_MCAP - 1; k >= 0; --k) {
+      qk[k] = 0.0;
+      if (k < col) {
+        const double cand = sv * rdiag;
+        qk[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cand), k),
+                                 __builtin_amdgcn_readlane(__double2loint(cand), k));
+        if (i == k) myq = qk[k];
+        if (i < k) sv -= Rrow[k] * qk[k];
+      }
+    }
+    // u = R^-T ((D + gamma Y'Y) q - gamma b), first unknown first
+    double tv = diag * myq - gamma * bi;
+#pragma unroll
+    for (int k = 0; k < TEAM_MCAP; ++k) tv += gamma * Yrow[k] * qk[k];
+    if (!row) tv = 0.0;
+#pragma unroll
+    for (int k = 0; k < TEAM_MCAP; ++k) {
+      uk[k] = 0.0;
+      if (k < col) {
+        const double cand = tv * rdiag;
+        uk[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cand), k),
+                                 __builtin_amdgcn_readlane(__double2loint(cand), k));
+        if (i == k) myu = uk[k];
+        if (i > k) tv -= Rcol[k] * uk[k];
+      }
+    }
+    const double term = row ? (gamma * bi * myq - ai * myu) : 0.0;
+    const double gdn0 = wave_sum(term) - gg_cur * (col > 0 ? gamma : 1.0);
+    if (row) { L.ap[i] = ai; L.bp[i] = bi; L.q[i] = myq; L.u[i] = myu; }
+    if (i == 0) L.sc[0] = gdn0;
+  }
+  __syncthreads();
+  double gdn = L.sc[0];
+  if (gdn >= 0.0) {   // not a descent direction (lnsrlb info = -4): steepest descent without history
+    if (col == 0) { S.col = col; S.head = head; S.theta = theta; S.status = 4; plan.action = CA_STOP; return; }
+    col = 0; head = 0; theta = 1.0;
+    store_pair = false;
+    gdn = -gg_cur;
+  }
+  S.col = col; S.head = head; S.theta = theta;
+  S.gg_k = gg_cur;
+  S.gdold = gdn;
+  S.fold = S.f;
+  S.stp = S.iter0 ? fmin(1.0 / sqrt(gg_cur), LS_STPMAX) : 1.0;
+  dcsrch_start(S.ls, S.f, gdn, S.stp);
+  S.ifun = 1;
+  plan.action = CA_DIRECTION;
+  plan.store_pair = store_pair ? 1 : 0;
+  plan.restore = restore ? 1 : 0;
+  plan.slot = slot;
+  plan.cnew = cnew;
+  plan.col = col;
+  plan.head = head;
+  plan.stp = S.stp;
+  plan.gamma = 1.0 / theta;
+}
+
+// The elementwise part of a step for coefficient j (CA_RETRY / CA_DIRECTION). Vectors as in Work; u, q from L.
+__device__ __forceinline__ void compact_update(const CompactPlan& plan, const CompactMats& L, const Work& W, int p, int m, int j) {
+  if (plan.action == CA_RETRY) {
+    W.x[j] = plan.stp * W.d[j] + W.t[j];
+    return;
+  }
+  const double gj = plan.restore ? W.r[j] : W.g[j];
+  const double xj = plan.restore ? W.t[j] : W.x[j];
+  double sn = 0.0, yn = 0.0;
+  if (plan.store_pair) {
+    sn = plan.stp_prev * W.d[j];   // exact for stp == 1
+    yn = W.g[j] - W.r[j];
+    W.ws[(size_t)plan.slot * p + j] = sn;
+    W.wy[(size_t)plan.slot * p + j] = yn;
+  }
+  double dj = -gj;
+  if (plan.col > 0) {
+    double su = 0.0, yq = 0.0;
+#pragma unroll
+    for (int i = 0; i < TEAM_MCAP; ++i) {
+      if (i < plan.col) {
+        int sl = plan.head + i;
+        if (sl >= m) sl -= m;
+        const bool fresh = plan.store_pair && i == plan.cnew;
+        const double si = fresh ? sn : W.ws[(size_t)sl * p + j];
+        const double yi = fresh ? yn : W.wy[(size_t)sl * p + j];
+        su += L.u[i] * si;
+        yq += L.q[i] * yi;
+      }
+    }
+    dj = plan.gamma * (yq - gj) - su;
+  }
+  const double z = xj + dj;   // mainlb re-derives d from the subspace point
+  dj = z - xj;
+  W.d[j] = dj;
+  W.t[j] = xj;
+  W.r[j] = gj;
+  W.x[j] = plan.stp * dj + xj;
+}
+
+}  // namespace gdmix

@@ -18,7 +18,7 @@
 // agree with them to rounding (different summation order), which tests/test_gpu_parity.py pins against
 // the reference fixtures through the workgroup class.
 #pragma once
-#include "re_solve_core.hpp"
+#include "re_lbfgs_compact.hpp"
 
 namespace gdmix {
 
@@ -32,8 +32,6 @@ namespace gdmix {
 #define TEAM_PROF(i) do { } while (0)
 #endif
 
-constexpr int TEAM_MCAP = 10;                 // history pairs the compact path keeps accumulators for
-constexpr int TEAM_K = 2 * TEAM_MCAP + 6;     // fused reduction width: sq, gd, gg, rr, gr, S'g, Y'g, max|g|
 constexpr int TEAM_VEC = 32;                  // doubles per workgroup slot of the device-wide exchange buffer
 constexpr int TEAM_MAX_BLOCKS = 256;           // workgroups per team
 constexpr int TEAM_MAX_TEAMS = 32;
@@ -57,12 +55,7 @@ template <int NW>
 struct TeamLds {
   double red[2][NW][TEAM_VEC];
   double out[2][TEAM_VEC];
-  double SY[TEAM_MCAP * TEAM_MCAP];   // s_i'y_k, chronological, i <= k used
-  double YY[TEAM_MCAP * TEAM_MCAP];   // y_i'y_k
-  double ap[TEAM_MCAP], bp[TEAM_MCAP];   // S'g_k, Y'g_k at the last accepted iterate
-  double la[TEAM_MCAP], lb[TEAM_MCAP];
-  double u[TEAM_MCAP], q[TEAM_MCAP];
-  double sc[4];
+  CompactMats mats;
   double buf[NW][TEAM_CHUNK];     // per-wavefront staging of val * r products
   int llist[TEAM_LONG_CAP];       // long columns of the entity, ascending
   int lraw[TEAM_LONG_CAP];
@@ -430,247 +423,44 @@ __device__ void team_solve(Team<NW>& tm, const EntityView& P, const SolveParams&
   const int p = P.p, m = o.m;
   TeamLds<NW>& L = *tm.L;
   team_long_setup(tm, P);
-  int col = 0, head = 0, nit = 0, nfev = 0, ifun = 0, status = -1;
-  bool first = true, iter0 = true;
-  double theta = 1.0, f = 0.0, fold = 0.0, gdold = 0.0, stp = 0.0, sbgnrm = 0.0, gg_k = 0.0;
-  LineSearch ls;
+  CompactState S;
+  compact_init(S);
+  CompactPlan plan;
   double acc[TEAM_K];
   TEAM_PROF_DECL
   for (int j = tm.tid; j < p; j += tm.NT) { W.d[j] = 0.0; W.r[j] = 0.0; }
   tm.sync();
   for (;;) {
 #ifdef GDMIX_TEAM_PROFILE
-    const double f_new = team_eval(tm, P, o, W, col, head, acc, prof_t, prof_last);
+    const double f_new = team_eval(tm, P, o, W, S.col, S.head, acc, prof_t, prof_last);
 #else
-    const double f_new = team_eval(tm, P, o, W, col, head, acc);
+    const double f_new = team_eval(tm, P, o, W, S.col, S.head, acc);
 #endif
-    ++nfev;
-    if (tm.aborted()) { status = GDMIX_RE_ST_ABORTED; break; }
-    const double gd = acc[1], gg = acc[2], rr = acc[3], gr = acc[4];
-    bool restore = false, store_pair = false, shift = false;
-    double dr = 0.0;
-    const double stp_prev = stp;
-    if (first) {
-      first = false;
-      f = f_new;
-      sbgnrm = acc[TEAM_K - 1];
-      if (sbgnrm <= o.pgtol) { status = 0; break; }
-    } else {
-      f = f_new;
-      const int task = dcsrch_step(ls, f_new, gd, stp);
-      if (task == LS_FG) {
-        ++ifun;
-        if (ifun - 1 < o.maxls) {
-          for (int j = tm.tid; j < p; j += tm.NT) W.x[j] = stp * W.d[j] + W.t[j];
-          tm.sync();
-          continue;
-        }
-        restore = true;   // iback >= maxls: back to the last iterate, forget the history
-      } else {
-        ++nit;
-        iter0 = false;
-        sbgnrm = acc[TEAM_K - 1];
-        if (nit >= o.max_iter) { status = 2; break; }
-        if (nfev > o.maxfun) { status = 3; break; }
-        if (sbgnrm <= o.pgtol) { status = 0; break; }
-        {
-          const double ddum = fmax(fabs(fold), fmax(fabs(f), 1.0));
-          if (fold - f <= o.ftol * ddum) { status = 1; break; }
-        }
-        double ddum;
-        if (stp == 1.0) { dr = gd - gdold; ddum = -gdold; }
-        else { dr = (gd - gdold) * stp; ddum = -gdold * stp; }
-        store_pair = dr > EPSMCH * ddum;
-      }
-    }
-    // ---- new search direction
-    int slot = 0;          // history slot of the pair being stored
-    double gg_cur = gg;    // g'g of the gradient the direction is built from
-    if (restore) {
-      if (col == 0) {
-        for (int j = tm.tid; j < p; j += tm.NT) W.x[j] = W.t[j];
-        tm.sync();
-        f = fold;
-        status = 4;
-        break;
-      }
-      col = 0; head = 0; theta = 1.0;
-      f = fold;
-      gg_cur = gg_k;
-    }
-    if (store_pair) {
-      if (col < m) { slot = head + col; if (slot >= m) slot -= m; ++col; }
-      else { slot = head; ++head; if (head >= m) head = 0; shift = true; }
-      theta = rr / dr;
-    }
-    const int cnew = col - 1;   // chronological index of the stored pair
-    // The small dense part, by the first wavefront of every workgroup (each workgroup keeps its own replica in
-    // LDS): lane i owns row i of the m x m matrices; the triangular solves broadcast one unknown per step.
-    if (threadIdx.x < WAVE) {
-      const int i = (int)threadIdx.x;
-      constexpr int MM = TEAM_MCAP * TEAM_MCAP;
-      if (store_pair && shift) {   // drop the oldest pair: (r, c) <- (r + 1, c + 1)
-        double sy[2], yy[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int idx = i + h * WAVE;
-          const int r = idx / TEAM_MCAP, c = idx - r * TEAM_MCAP;
-          const bool ok = idx < MM && r + 1 < m && c + 1 < m;
-          sy[h] = ok ? L.SY[(r + 1) * TEAM_MCAP + c + 1] : 0.0;
-          yy[h] = ok ? L.YY[(r + 1) * TEAM_MCAP + c + 1] : 0.0;
-        }
-        const double pa = (i + 1 < m) ? L.ap[i + 1] : 0.0, pb = (i + 1 < m) ? L.bp[i + 1] : 0.0;
-        wave_lds_fence();
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int idx = i + h * WAVE;
-          const int r = idx / TEAM_MCAP, c = idx - r * TEAM_MCAP;
-          if (idx < MM && r + 1 < m && c + 1 < m) { L.SY[idx] = sy[h]; L.YY[idx] = yy[h]; }
-        }
-        if (i + 1 < m) { L.ap[i] = pa; L.bp[i] = pb; }
-        wave_lds_fence();
-      }
-      // S'g, Y'g of row i in chronological order after the shift; products with the new pair in closed form
-      double ai = 0.0, bi = 0.0;
-#pragma unroll
-      for (int k = 0; k < TEAM_MCAP; ++k) {
-        if (i == k) {
-          if (shift) { if (k + 1 < TEAM_MCAP) { ai = acc[5 + (k + 1 < TEAM_MCAP ? k + 1 : k)]; bi = acc[5 + TEAM_MCAP + (k + 1 < TEAM_MCAP ? k + 1 : k)]; } }
-          else { ai = acc[5 + k]; bi = acc[5 + TEAM_MCAP + k]; }
-        }
-      }
-      if (store_pair) {
-        if (i < cnew) {
-          L.SY[i * TEAM_MCAP + cnew] = ai - L.ap[i];   // s_i'(g - g_k)
-          const double yy = bi - L.bp[i];              // y_i'(g - g_k)
-          L.YY[i * TEAM_MCAP + cnew] = yy;
-          L.YY[cnew * TEAM_MCAP + i] = yy;
-        } else if (i == cnew) {
-          L.SY[cnew * TEAM_MCAP + cnew] = dr;
-          L.YY[cnew * TEAM_MCAP + cnew] = rr;
-          ai = stp_prev * gd;   // s'g,  s = stp d
-          bi = gg - gr;         // y'g,  y = g - g_k
-        }
-        wave_lds_fence();
-      }
-      const bool row = i < col;
-      const int ir = row ? i : 0;
-      double Rrow[TEAM_MCAP], Rcol[TEAM_MCAP], Yrow[TEAM_MCAP];
-#pragma unroll
-      for (int k = 0; k < TEAM_MCAP; ++k) {
-        const bool ok = row && k < col;
-        Rrow[k] = ok ? L.SY[ir * TEAM_MCAP + k] : 0.0;
-        Rcol[k] = ok ? L.SY[k * TEAM_MCAP + ir] : 0.0;
-        Yrow[k] = ok ? L.YY[ir * TEAM_MCAP + k] : 0.0;
-      }
-      double diag = 1.0;
-#pragma unroll
-      for (int k = 0; k < TEAM_MCAP; ++k)
-        if (i == k && row) diag = Rrow[k];
-      const double rdiag = 1.0 / diag;
-      const double gamma = 1.0 / theta;
-      // q = R^-1 a, last unknown first
-      double qk[TEAM_MCAP], uk[TEAM_MCAP];
-      double sv = row ? ai : 0.0, myq = 0.0, myu = 0.0;
-#pragma unroll
-      for (int k = TEAM_MCAP - 1; k >= 0; --k) {
-        qk[k] = 0.0;
-        if (k < col) {
-          const double cand = sv * rdiag;
-          qk[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cand), k),
-                                   __builtin_amdgcn_readlane(__double2loint(cand), k));
-          if (i == k) myq = qk[k];
-          if (i < k) sv -= Rrow[k] * qk[k];
-        }
-      }
-      // u = R^-T ((D + gamma Y'Y) q - gamma b), first unknown first
-      double tv = diag * myq - gamma * bi;
-#pragma unroll
-      for (int k = 0; k < TEAM_MCAP; ++k) tv += gamma * Yrow[k] * qk[k];
-      if (!row) tv = 0.0;
-#pragma unroll
-      for (int k = 0; k < TEAM_MCAP; ++k) {
-        uk[k] = 0.0;
-        if (k < col) {
-          const double cand = tv * rdiag;
-          uk[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cand), k),
-                                   __builtin_amdgcn_readlane(__double2loint(cand), k));
-          if (i == k) myu = uk[k];
-          if (i > k) tv -= Rcol[k] * uk[k];
-        }
-      }
-      const double term = row ? (gamma * bi * myq - ai * myu) : 0.0;
-      const double gdn0 = wave_sum(term) - gg_cur * (col > 0 ? gamma : 1.0);
-      if (row) { L.ap[i] = ai; L.bp[i] = bi; L.q[i] = myq; L.u[i] = myu; }
-      if (i == 0) L.sc[0] = gdn0;
-    }
-    tm.block_sync();
+    if (tm.aborted()) { ++S.nfev; S.status = GDMIX_RE_ST_ABORTED; break; }
+    compact_advance(S, acc, f_new, o, L.mats, plan);
     TEAM_PROF(4);
-    double gdn = L.sc[0];
-    if (gdn >= 0.0) {   // not a descent direction (lnsrlb info = -4): steepest descent without history
-      if (col == 0) { status = 4; break; }
-      col = 0; head = 0; theta = 1.0;
-      store_pair = false;
-      gdn = -gg_cur;
+    if (plan.action == CA_STOP) break;
+    if (plan.action == CA_STOP_RESTORE) {
+      for (int j = tm.tid; j < p; j += tm.NT) W.x[j] = W.t[j];
+      tm.sync();
+      break;
     }
-    gg_k = gg_cur;
-    gdold = gdn;
-    fold = f;
-    stp = iter0 ? fmin(1.0 / sqrt(gg_cur), LS_STPMAX) : 1.0;
-    dcsrch_start(ls, f, gdn, stp);
-    ifun = 1;
-    {
-      const double gamma = 1.0 / theta;
-      for (int j = tm.tid; j < p; j += tm.NT) {
-        const double gj = restore ? W.r[j] : W.g[j];
-        const double xj = restore ? W.t[j] : W.x[j];
-        double sn = 0.0, yn = 0.0;
-        if (store_pair) {
-          sn = stp_prev * W.d[j];   // exact for stp == 1
-          yn = W.g[j] - W.r[j];
-          W.ws[(size_t)slot * p + j] = sn;
-          W.wy[(size_t)slot * p + j] = yn;
-        }
-        double dj = -gj;
-        if (col > 0) {
-          double su = 0.0, yq = 0.0;
-#pragma unroll
-          for (int i = 0; i < TEAM_MCAP; ++i) {
-            if (i < col) {
-              int sl = head + i;
-              if (sl >= m) sl -= m;
-              const bool fresh = store_pair && i == cnew;
-              const double si = fresh ? sn : W.ws[(size_t)sl * p + j];
-              const double yi = fresh ? yn : W.wy[(size_t)sl * p + j];
-              su += L.u[i] * si;
-              yq += L.q[i] * yi;
-            }
-          }
-          dj = gamma * (yq - gj) - su;
-        }
-        const double z = xj + dj;   // mainlb re-derives d from the subspace point
-        dj = z - xj;
-        W.d[j] = dj;
-        W.t[j] = xj;
-        W.r[j] = gj;
-        W.x[j] = stp * dj + xj;
-      }
-    }
+    for (int j = tm.tid; j < p; j += tm.NT) compact_update(plan, L.mats, W, p, m, j);
     TEAM_PROF(5);
     tm.sync();
     TEAM_PROF(6);
   }
 #ifdef GDMIX_TEAM_PROFILE
   if (tm.tid == 0)
-    printf("team n=%d p=%d nfev=%d us/eval: rows %.1f red1 %.1f cols %.1f red2 %.1f solve %.1f upd %.1f sync %.1f\n", P.n, p, nfev,
-           prof_t[0] * 0.01 / nfev, prof_t[1] * 0.01 / nfev, prof_t[2] * 0.01 / nfev, prof_t[3] * 0.01 / nfev,
-           prof_t[4] * 0.01 / nfev, prof_t[5] * 0.01 / nfev, prof_t[6] * 0.01 / nfev);
+    printf("team n=%d p=%d nfev=%d us/eval: rows %.1f red1 %.1f cols %.1f red2 %.1f solve %.1f upd %.1f sync %.1f\n", P.n, p, S.nfev,
+           prof_t[0] * 0.01 / S.nfev, prof_t[1] * 0.01 / S.nfev, prof_t[2] * 0.01 / S.nfev, prof_t[3] * 0.01 / S.nfev,
+           prof_t[4] * 0.01 / S.nfev, prof_t[5] * 0.01 / S.nfev, prof_t[6] * 0.01 / S.nfev);
 #endif
-  out.f = f;
-  out.gnorm = sbgnrm;
-  out.nit = nit;
-  out.nfev = nfev;
-  out.status = status;
+  out.f = S.f;
+  out.gnorm = S.sbgnrm;
+  out.nit = S.nit;
+  out.nfev = S.nfev;
+  out.status = S.status;
 }
 
 // The team seen through the thread-group interface of re_solve_core.hpp (variance_simple, result epilogue).
