@@ -83,9 +83,6 @@ static BatchDev make_batch_dev(const gdmix_re_packed* b) {
 
 using namespace gdmix;
 
-struct gdmix_re_ctx {
-  gdmix_ctx_impl impl;
-};
 
 extern "C" {
 

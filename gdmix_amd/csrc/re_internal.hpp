@@ -96,6 +96,15 @@ struct gdmix_ctx_impl {
   bool ev_used[GDMIX_RE_NUM_CLASSES];
 };
 
+}  // namespace gdmix
+
+// the opaque context of the C ABI
+struct gdmix_re_ctx {
+  gdmix::gdmix_ctx_impl impl;
+};
+
+namespace gdmix {
+
 // LDS bytes the wave kernel needs for an entity of this shape (must match the kernel's carve-up).
 __host__ __device__ inline size_t wave_lds_bytes(int p, int n, int nnz, int d, int m, bool has_w) {
   size_t dbl = (size_t)(5 + 2 * m) * p + n + 2 * m;

@@ -15,9 +15,15 @@ streaming from HBM twice per evaluation (CSR for the logits, the CSC copy for th
 between the reference's coefficient layout (global feature index, intercept last) and the solver's (features
 present in the shard, intercept first).
 
-Multi-worker training (the reference all-reduces value and gradient across workers, :375-381) is not built: one
-MI355X holds 288 GB, i.e. shards the reference needs many CPU workers for.
+Two device paths, same arithmetic rules:
+  * fit()           the whole solve inside the device-wide team kernel (one launch; single worker only);
+  * fit_stepping()  include/gdmix_fe.h: streaming kernels for the two passes over the shard and the L-BFGS step as
+                    separate launches, with ONE all-reduce of [gradient, value] across workers in between (the
+                    reference does two, :375-381) — RCCL through torch.distributed on the GPU box. Every worker holds
+                    its shard and runs the replicated step on the reduced buffer, like the reference's workers run scipy.
 """
+import ctypes as C
+
 import numpy as np
 
 from .batch import RawBatch
@@ -97,3 +103,136 @@ class FixedEffectDeviceSolver:
         theta = to_global(res["theta"], uniq, num_features, has_intercept, dummy)
         info = {k: res[k][0] for k in ("fval", "nit", "nfev", "status", "gnorm")}
         return theta, info
+
+
+class _SteppingProblem:
+    """gdmix_fe_problem handle; the packed shard and theta0 are kept alive with it."""
+
+    def __init__(self, solver, packed, num_features, opts, theta0_dev):
+        from .solver import GdmixReError
+        self.solver, self.packed, self.theta0 = solver, packed, theta0_dev
+        self.lib = solver.lib
+        self._h = C.c_void_p()
+        c_opts = opts.to_c()
+        rc = self.lib.gdmix_fe_create(solver._h, C.byref(packed.c), int(num_features), C.byref(c_opts),
+                                      None if theta0_dev is None else theta0_dev.data_ptr(), C.byref(self._h), solver._stream())
+        if rc != 0:
+            raise GdmixReError("gdmix_fe_create: " + self.lib.gdmix_re_last_error().decode())
+        cnt = C.c_int64()
+        ptr = self.lib.gdmix_fe_reduce_buffer(self._h, C.byref(cnt))
+        self.count = int(cnt.value)
+        self.buffer_ptr = ptr
+
+    def _check(self, rc, what):
+        from .solver import GdmixReError
+        if rc != 0:
+            raise GdmixReError(f"{what}: " + self.lib.gdmix_re_last_error().decode())
+
+    def reduce_tensor(self):
+        """The [gradient, value] buffer as a torch tensor view (no copy), for torch.distributed.all_reduce."""
+        t = self.solver.torch
+        return _device_view(t, self.buffer_ptr, self.count, self.solver.device)
+
+    def eval(self):
+        self._check(self.lib.gdmix_fe_eval(self._h, self.solver._stream()), "gdmix_fe_eval")
+
+    def step(self):
+        st = C.c_int32(-1)
+        self._check(self.lib.gdmix_fe_step(self._h, self.solver._stream(), C.byref(st)), "gdmix_fe_step")
+        return int(st.value)
+
+    def result(self):
+        t = self.solver.torch
+        theta = t.empty(self.count - 1, dtype=t.float64, device=self.solver.device)
+        f, g, nit, nfev = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()
+        self._check(self.lib.gdmix_fe_result(self._h, theta.data_ptr(), C.byref(f), C.byref(g), C.byref(nit), C.byref(nfev),
+                                             self.solver._stream()), "gdmix_fe_result")
+        return theta.cpu().numpy(), dict(fval=f.value, gnorm=g.value, nit=int(nit.value), nfev=int(nfev.value))
+
+    def last_eval_ms(self):
+        a, b = C.c_float(), C.c_float()
+        self._check(self.lib.gdmix_fe_last_eval_ms(self._h, C.byref(a), C.byref(b)), "gdmix_fe_last_eval_ms")
+        return float(a.value), float(b.value)
+
+    def close(self):
+        if self._h:
+            self.lib.gdmix_fe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _device_view(torch, ptr, count, device):
+    """float64 tensor over `count` doubles of device memory owned by the library."""
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(h, device=device)
+
+
+def run_stepping_loop(problem, all_reduce=None, max_evals=100000):
+    """do { eval; all_reduce; } while (step() < 0)  — the loop gdmix_fe.h describes. all_reduce(tensor) sums in place
+    across workers (None: single worker)."""
+    buf = problem.reduce_tensor() if all_reduce is not None else None
+    status = -1
+    for _ in range(max_evals):
+        problem.eval()
+        if all_reduce is not None:
+            all_reduce(buf)
+        status = problem.step()
+        if status >= 0:
+            break
+    return status
+
+
+def _fit_stepping(self, row_nnz_ptr, col_global, val, y, num_features, offset=None, weight=None, has_intercept=True, l2=1.0,
+                  regularize_bias=True, model_type=LOGISTIC_REGRESSION, theta0=None, max_iter=100, m=10, tolerance=1e-12,
+                  group=None, return_problem=False):
+    """Same contract as fit(), through include/gdmix_fe.h. With torch.distributed initialised (or `group` given) every
+    worker calls this with its own shard; the coefficients returned are identical on all workers."""
+    if model_type not in (LOGISTIC_REGRESSION, LINEAR_REGRESSION):
+        raise ValueError(f"unknown model type {model_type!r}")
+    batch, dummy = shard_as_batch(row_nnz_ptr, col_global, val, y, offset, weight, has_intercept,
+                                  binary_labels=(model_type == LOGISTIC_REGRESSION))
+    D = 1 if dummy else int(num_features)   # the dummy zero feature of an intercept-only model occupies global index 0
+    if not dummy and batch.col_global.size and (batch.col_global.min() < 0 or batch.col_global.max() >= D):
+        raise ValueError(f"feature index outside [0, {D})")
+    s = self.solver
+    packed = s.pack(batch, has_intercept=has_intercept)
+    opts = SolverOptions(l2=l2, regularize_bias=bool(regularize_bias) and bool(has_intercept), has_intercept=has_intercept, m=m,
+                         max_iter=max_iter, ftol=tolerance, threshold=0.0, sum_loss=True, linear=(model_type == LINEAR_REGRESSION))
+    ic = 1 if has_intercept else 0
+    t0 = None
+    if theta0 is not None:
+        full = np.zeros(D + ic)
+        th = np.asarray(theta0, np.float64)
+        if dummy:
+            full[D:] = th[-ic:] if ic else []
+        else:
+            full[:] = th
+        t0 = s.torch.from_numpy(full).to(s.device)
+    prob = _SteppingProblem(s, packed, D, opts, t0)
+    all_reduce = None
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            all_reduce = lambda t: dist.all_reduce(t, group=group)
+    except ImportError:
+        pass
+    status = run_stepping_loop(prob, all_reduce)
+    theta, info = prob.result()
+    info["status"] = status
+    if dummy:
+        theta = theta[D:]
+    if return_problem:
+        return theta, info, prob
+    prob.close()
+    return theta, info
+
+
+FixedEffectDeviceSolver.fit_stepping = _fit_stepping

@@ -1,0 +1,66 @@
+/* gdmix_fe.h — C ABI of the fixed-effect trainer in libgdmix_re.so.
+ *
+ * Replaces the body of FixedEffectLRModelLBFGS's training step
+ *   _train_model_fn / _compute_loss_and_gradients / fmin_l_bfgs_b call
+ *   gdmix-trainer/src/gdmix/models/custom/fixed_effect_lr_lbfgs_model.py:309-392, 394-430, 635-643
+ * for one worker's shard resident in HBM:
+ *
+ *   f(theta) = sum_i w_i loss(y_i, x_i.w + b + offset_i) + (l2/2) |theta_reg|^2     theta = [w (num_features), b]
+ *
+ * (intercept LAST, :340-342; not divided by n; theta_reg excludes b unless regularize_bias, :367-369). The
+ * reference evaluates value and gradient with TensorFlow on every worker, all-reduces both across workers
+ * (two collectives, keys 0/1, each worker adding l2 |theta|^2 / (2 R), :375-381) and hands them to scipy's
+ * fmin_l_bfgs_b, which runs replicated on every worker. Here one evaluation is
+ *
+ *   gdmix_fe_eval    local part of [gradient (num_features + 1), value] into one device buffer
+ *   <caller>         ONE all-reduce (sum) of that buffer across workers (RCCL through torch.distributed);
+ *                    nothing to do for a single worker
+ *   gdmix_fe_step    adds the regulariser once, advances L-BFGS (replicated: every worker computes the same
+ *                    step from the same reduced buffer), returns the solver status (-1 = evaluate again)
+ *
+ * so the host loop is `do { eval; all_reduce; } while (step() < 0)`. All arithmetic fp64 on fp32 data. The shard is
+ * a one-entity batch packed by gdmix_re_pack (CSR + CSC copy, local feature ids + unique_global map); the
+ * L-BFGS vectors live in the global coefficient space, which is common to all workers.
+ *
+ * Same conventions as gdmix_re.h: 0 / negative return codes, gdmix_re_last_error(), no exceptions, caller-owned
+ * input buffers (which must stay alive until gdmix_fe_destroy), one context per device, calls serialised.
+ */
+#ifndef GDMIX_FE_H
+#define GDMIX_FE_H
+
+#include "gdmix_re.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gdmix_fe_problem gdmix_fe_problem;
+
+/* shard: a packed batch with E == 1 (gdmix_re_pack; has_intercept of the pack must equal opts->has_intercept).
+ * num_features: size of the global feature space D; coefficients are [D + has_intercept], intercept last.
+ * opts: l2, regularize_bias, has_intercept, m (<= 10), max_iter, maxfun, maxls, ftol, pgtol, linear are used.
+ * theta0: device pointer [D + has_intercept] or NULL (zeros). */
+GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* shard, int64_t num_features,
+                              const gdmix_re_opts* opts, const double* theta0, gdmix_fe_problem** out, void* stream);
+GDMIX_API void gdmix_fe_destroy(gdmix_fe_problem* p);
+
+/* Local [gradient of the data term (D + has_intercept), value of the data term] at the current trial point. */
+GDMIX_API int gdmix_fe_eval(gdmix_fe_problem* p, void* stream);
+
+/* The buffer gdmix_fe_eval fills and gdmix_fe_step consumes: *count = D + has_intercept + 1 doubles. */
+GDMIX_API double* gdmix_fe_reduce_buffer(gdmix_fe_problem* p, int64_t* count);
+
+/* Consumes the (all-reduced) buffer. *status: -1 = evaluate again, else GDMIX_RE_ST_*. Synchronises the stream. */
+GDMIX_API int gdmix_fe_step(gdmix_fe_problem* p, void* stream, int32_t* status);
+
+/* Result after status >= 0: theta [D + has_intercept] (device pointer, may be NULL) and scalars (host, may be NULL). */
+GDMIX_API int gdmix_fe_result(gdmix_fe_problem* p, double* theta, double* fval, double* gnorm, int32_t* nit,
+                              int32_t* nfev, void* stream);
+
+/* Optional timing of the last gdmix_fe_eval (HIP events on the launch stream): ms of the CSR pass, the CSC pass. */
+GDMIX_API int gdmix_fe_last_eval_ms(gdmix_fe_problem* p, float* rows_ms, float* cols_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDMIX_FE_H */

@@ -19,7 +19,7 @@ def lib():
 
 
 def test_header_symbols_exported(lib):
-    hdr = open(os.path.join(ROOT, "include", "gdmix_re.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "gdmix_re.h")).read() + open(os.path.join(ROOT, "include", "gdmix_fe.h")).read()
     declared = set(re.findall(r"GDMIX_API[^;(]*?\b(gdmix_\w+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     assert declared == set(solver.EXPORTED_SYMBOLS)

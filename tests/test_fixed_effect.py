@@ -92,6 +92,56 @@ def test_device_matches_reference_ground_truth_and_oracle(device_solver, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_stepping_kernels_match_reference_ground_truth_and_oracle(device_solver, name):
+    """include/gdmix_fe.h: streaming passes + replicated L-BFGS step (single worker: no all-reduce)."""
+    c = load(name)
+    ic = bool(c["has_intercept"])
+    s = fe.FixedEffectDeviceSolver(solver=device_solver)
+    theta, info = s.fit_stepping(c["row_nnz_ptr"], c["col_global"], c["val"], c["y"], int(c["num_features"]), offset=c["offset"],
+                                 has_intercept=ic, l2=float(c["l2"]), regularize_bias=True,
+                                 model_type=fe.LINEAR_REGRESSION if c["linear"] else fe.LOGISTIC_REGRESSION,
+                                 theta0=c["theta0"] if c["theta0"].size else None, max_iter=int(c["max_iter"]))
+    assert info["status"] in (0, 1, 2)
+    assert rel_err(theta, c["theta"]) <= tol(info["status"]), rel_err(theta, c["theta"])
+    th_o, res = oracle_fit(c)
+    assert info["status"] == res["status"][0]
+    if info["status"] != 1:
+        assert info["nit"] == res["nit"][0] and info["nfev"] == res["nfev"][0]
+
+
+@pytest.mark.gpu
+def test_stepping_kernels_on_ragged_rows_long_columns_and_weights(device_solver):
+    """Row lengths from 0 to several blocks of the streaming kernel, a handful of very long columns, empty rows at both
+    ends, weights, unregularised intercept: device-wide team kernel, stepping kernels and oracle agree."""
+    rng = np.random.default_rng(5)
+    n, D = 3000, 700
+    k = rng.integers(0, 40, n)
+    k[rng.integers(0, n, 5)] = rng.integers(5000, 12000, 5)      # rows longer than one 4096-entry block
+    k[:3] = 0
+    k[-2:] = 0
+    rp = np.concatenate([[0], np.cumsum(k)]).astype(np.int64)
+    cols = rng.integers(0, D, rp[-1])
+    cols[rng.random(rp[-1]) < 0.5] = rng.integers(0, 3, int((rng.random(rp[-1]) < 0.5).sum()) or 1)[0]   # one dominant column
+    vals = (rng.standard_normal(rp[-1]) * 0.1).astype(np.float32)
+    y = (rng.random(n) < 0.4).astype(np.float32)
+    off = (0.2 * rng.standard_normal(n)).astype(np.float32)
+    wt = (0.5 + rng.random(n)).astype(np.float32)
+    s = fe.FixedEffectDeviceSolver(solver=device_solver)
+    kw = dict(offset=off, weight=wt, l2=2.0, regularize_bias=False, max_iter=60)
+    th_team, info_team = s.fit(rp, cols, vals, y, D, **kw)
+    th_step, info_step = s.fit_stepping(rp, cols, vals, y, D, **kw)
+    batch, dummy = fe.shard_as_batch(rp, cols, vals, y, off, wt, True)
+    pk = oracle.pack(batch.ent_row_ptr, batch.row_nnz_ptr, batch.col_global)
+    o = oracle.make_opts(l2=2.0, regularize_bias=False, has_intercept=True, max_iter=60, threshold=0.0, sum_loss=True)
+    res = oracle.solve(pk, batch.val, batch.y, batch.offset, batch.weight, o)
+    th_o = fe.to_global(res["theta"], pk["unique_global"], D, True, dummy)
+    for th, info in ((th_team, info_team), (th_step, info_step)):
+        assert info["status"] == res["status"][0]
+        assert rel_err(th, th_o) <= tol(info["status"]), rel_err(th, th_o)
+
+
+@pytest.mark.gpu
 def test_device_fixed_effect_at_scale_against_oracle(device_solver):
     """200k samples x 20 non-zeros over 5000 features, weights, unregularised intercept, both model types."""
     rng = np.random.default_rng(0)
@@ -115,3 +165,7 @@ def test_device_fixed_effect_at_scale_against_oracle(device_solver):
         th_o = fe.to_global(res["theta"], pk["unique_global"], D, True, dummy)
         assert info["status"] in (0, 1) and res["status"][0] == info["status"]
         assert rel_err(theta, th_o) <= 1e-5, rel_err(theta, th_o)
+        th2, info2 = s.fit_stepping(rp, cols.ravel(), vals.ravel(), y, D, offset=off, weight=wt, l2=10.0, regularize_bias=False,
+                                    model_type=fe.LINEAR_REGRESSION if linear else fe.LOGISTIC_REGRESSION, max_iter=200)
+        assert info2["status"] == info["status"]
+        assert rel_err(th2, th_o) <= 1e-5, rel_err(th2, th_o)

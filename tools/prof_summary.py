@@ -31,7 +31,7 @@ def pmc(db):
     cur = sqlite3.connect(db).cursor()
     print(f"# PMC pass: {db}")
     rows = list(cur.execute("select kernel_name, counter_name, count(*), sum(value), avg(value) from counters_collection "
-                            "where kernel_name like 'gdmix::%' group by kernel_name, counter_name order by sum(value) desc"))
+                            "where kernel_name like '%gdmix::%' group by kernel_name, counter_name order by sum(value) desc"))
     print(f"{'kernel':60s} {'counter':18s} {'dispatches':>10s} {'sum':>16s} {'avg/dispatch':>16s}")
     for k, c, n, s, a in rows:
         print(f"{short(k, 60):60s} {c:18s} {n:10d} {s:16.1f} {a:16.2f}")
