@@ -11,6 +11,11 @@
 // (rows / columns) that intersect the block are summed out of LDS — one thread per segment when they are short,
 // one wavefront per segment when they are long — in entry order, so the result does not depend on the launch.
 // A segment that crosses block boundaries leaves partial sums that a small second kernel adds up in block order.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
 #include "re_internal.hpp"
 #include "re_lbfgs_compact.hpp"
 #include "../../include/gdmix_fe.h"
@@ -19,8 +24,14 @@
 
 namespace gdmix {
 
-constexpr int FE_BLK = 4096;       // entries per workgroup of a streaming pass
+#ifndef GDMIX_FE_BLK
+#define GDMIX_FE_BLK 2048
+#endif
+constexpr int FE_BLK = GDMIX_FE_BLK;   // entries per workgroup of a streaming pass
 constexpr int FE_THREADS = 256;
+constexpr int FE_TILE_ROWS = 1 << 18;  // rows per tile of the CSC copy: 2 MiB of residuals, resident in an XCD's L2
+// LDS index of product k: one pad double per 32 so that equal-length rows do not land on one bank
+__device__ __forceinline__ int fe_slot(int k) { return k + (k >> 5); }
 constexpr int FE_WAVES = FE_THREADS / WAVE;
 constexpr int FE_DOT_BLOCKS = 512;
 
@@ -30,17 +41,19 @@ struct FeDev {
   const int32_t* row_ptr;   // [n+1]
   const int32_t* csr_col;   // [z] local feature id
   const float* csr_val;
-  const int32_t* col_ptr;   // [d+1]
-  const int32_t* csc_row;   // [z]
+  const int32_t* col_ptr;   // [ntile*d+1] column copy cut into row tiles: segment t*d + c = column c, rows of tile t
+  const int32_t* csc_row;   // [z] sorted by (tile, column, row)
   const float* csc_val;
+  int ntile, nseg_c;        // row tiles, ntile * d
   const float *y, *o, *w;   // w may be NULL
   const int64_t* umap;      // [d] local -> global feature id
   double* xl;               // [d] x of the features present in this shard
   double* rs;               // [n] per-sample residual
-  double* gl;               // [d] data gradient, local ids
+  double* gl;               // [ntile*d] data gradient per (tile, local column)
   double* fg;               // [P + 1] global data gradient (intercept last), then the data value
   int32_t* own_r;           // [nblk+1] first row owned by a block of the CSR pass
   int32_t* own_c;           // [nblk+1] first column owned by a block of the CSC pass
+  uint8_t *carry_r, *carry_c;   // [nblk]
   double *pf_r, *pl_r, *pf_c, *pl_c;                        // [nblk] partial sums of the first / last segment of a block
   double *loss_part, *rsum_part, *loss_fix, *rsum_fix;      // [nblk]
   double* acc_part;         // [FE_DOT_BLOCKS][TEAM_K]
@@ -60,9 +73,16 @@ __device__ __forceinline__ int seg_lower_bound(const int32_t* __restrict__ ptr, 
   return lo;
 }
 
-__global__ void fe_own_kernel(const int32_t* __restrict__ ptr, int nseg, int nblk, int32_t* __restrict__ own) {
-  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b <= nblk; b += gridDim.x * blockDim.x)
-    own[b] = (b == nblk) ? nseg : seg_lower_bound(ptr, nseg, (int64_t)b * FE_BLK);
+// own[b] = first segment that starts in block b or later; carry[b] = the block begins inside a segment that
+// started in an earlier block
+__global__ void fe_own_kernel(const int32_t* __restrict__ ptr, int nseg, int nblk, int64_t z, int32_t* __restrict__ own,
+                              uint8_t* __restrict__ carry) {
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b <= nblk; b += gridDim.x * blockDim.x) {
+    const int64_t k0 = (int64_t)b * FE_BLK;
+    const int o0 = (b == nblk) ? nseg : seg_lower_bound(ptr, nseg, k0);
+    own[b] = o0;
+    if (b < nblk) carry[b] = (b > 0 && k0 < z && (o0 >= nseg || (int64_t)ptr[o0] > k0)) ? 1 : 0;
+  }
 }
 
 __global__ void fe_prepare_kernel(FeDev F) {
@@ -71,11 +91,12 @@ __global__ void fe_prepare_kernel(FeDev F) {
 
 // what is done with a finished segment sum
 template <bool ROWS>
-__device__ __forceinline__ void fe_emit(const FeDev& F, const SolveParams& o, int s, double sum, double xb, double& loss, double& rsum) {
+__device__ __forceinline__ void fe_emit(const FeDev& F, const SolveParams& o, int s, double sum, double xb, float fo, float fy, float fw,
+                                        double& loss, double& rsum) {
   if (ROWS) {
-    const double zi = sum + xb + (double)F.o[s];
-    const double yi = (double)F.y[s];
-    const double wi = F.w ? (double)F.w[s] : 1.0;
+    const double zi = sum + xb + (double)fo;
+    const double yi = (double)fy;
+    const double wi = (double)fw;
     double ri;
     if (o.linear) {
       const double e = zi - yi;
@@ -93,7 +114,7 @@ __device__ __forceinline__ void fe_emit(const FeDev& F, const SolveParams& o, in
 
 template <bool ROWS>
 __global__ __launch_bounds__(FE_THREADS) void fe_stream_kernel(FeDev F, SolveParams o) {
-  __shared__ double prod[FE_BLK];
+  __shared__ double prod[FE_BLK + FE_BLK / 32];
   __shared__ double red[2][FE_WAVES];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
   const int b = blockIdx.x;
@@ -104,52 +125,68 @@ __global__ __launch_bounds__(FE_THREADS) void fe_stream_kernel(FeDev F, SolvePar
   const int32_t* __restrict__ own = ROWS ? F.own_r : F.own_c;
   double* const pf = ROWS ? F.pf_r : F.pf_c;
   double* const pl = ROWS ? F.pl_r : F.pl_c;
+  const uint8_t* __restrict__ cflag = ROWS ? F.carry_r : F.carry_c;
   const int64_t k0 = (int64_t)b * FE_BLK;
   const int64_t k1 = (k0 + FE_BLK < F.z) ? k0 + FE_BLK : F.z;
   const int cnt = (int)(k1 - k0);
-  {
-    float v[FE_BLK / FE_THREADS];
-    int c[FE_BLK / FE_THREADS];
-#pragma unroll
-    for (int q = 0; q < FE_BLK / FE_THREADS; ++q) {
-      const int k = tid + q * FE_THREADS;
-      const bool ok = k < cnt;
-      v[q] = ok ? val[k0 + k] : 0.0f;
-      c[q] = ok ? idx[k0 + k] : 0;
-    }
-#pragma unroll
-    for (int q = 0; q < FE_BLK / FE_THREADS; ++q) {
-      const int k = tid + q * FE_THREADS;
-      if (k < cnt) prod[k] = (double)v[q] * vec[c[q]];
-    }
-  }
-  __syncthreads();
+  // Requests in dependency order, none waited for before it is needed: the block's descriptor, the streaming loads,
+  // then (from the descriptor) what the first segment of this thread will need at the very end. A block costs three
+  // memory round trips (descriptor | entries + segment data | gathers) instead of six in program order.
   const int o0 = own[b], o1 = own[b + 1];
-  // entries before the first owned segment belong to a segment that started in an earlier block
-  const bool carry = b > 0 && ((o0 < o1) ? (int64_t)ptr[o0] > k0 : true) && k0 < k1;
-  const int nwork = (o1 - o0) + (carry ? 1 : 0);
+  const bool carry = cflag[b] != 0;
   const double xb = (ROWS && F.ic) ? F.W.x[F.D] : 0.0;
-  double loss = 0.0, rsum = 0.0;
+  float v[FE_BLK / FE_THREADS];
+  int c[FE_BLK / FE_THREADS];
+#pragma unroll
+  for (int q = 0; q < FE_BLK / FE_THREADS; ++q) {
+    const int k = tid + q * FE_THREADS;
+    const bool ok = k < cnt;
+    v[q] = ok ? val[k0 + k] : 0.0f;
+    c[q] = ok ? idx[k0 + k] : 0;
+  }
+  const int nwork = (o1 - o0) + (carry ? 1 : 0);
   const bool by_wave = nwork * 48 <= cnt;   // long segments: one wavefront each
   const int step = by_wave ? FE_WAVES : FE_THREADS;
-  for (int t = by_wave ? wv : tid; t < nwork; t += step) {
+  const int tfirst = by_wave ? wv : tid;
+  int p0 = 0, p1 = 0;
+  float fo = 0.0f, fy = 0.0f, fw = 1.0f;
+  if (tfirst < nwork) {
+    const bool is_carry = carry && tfirst == 0;
+    const int s = is_carry ? o0 - 1 : o0 + tfirst - (carry ? 1 : 0);
+    p0 = ptr[s];
+    p1 = ptr[s + 1];
+    if (ROWS) { fo = F.o[s]; fy = F.y[s]; if (F.w) fw = F.w[s]; }
+  }
+#pragma unroll
+  for (int q = 0; q < FE_BLK / FE_THREADS; ++q) {
+    const int k = tid + q * FE_THREADS;
+    if (k < cnt) prod[fe_slot(k)] = (double)v[q] * vec[c[q]];
+  }
+  __syncthreads();
+  double loss = 0.0, rsum = 0.0;
+  for (int t = tfirst; t < nwork; t += step) {
     const bool is_carry = carry && t == 0;
     const int s = is_carry ? o0 - 1 : o0 + t - (carry ? 1 : 0);
-    const int64_t a0 = is_carry ? k0 : (int64_t)ptr[s];
-    const int64_t a1full = (int64_t)ptr[s + 1];
+    if (t != tfirst) {
+      p0 = ptr[s];
+      p1 = ptr[s + 1];
+      if (ROWS) { fo = F.o[s]; fy = F.y[s]; fw = F.w ? F.w[s] : 1.0f; }
+    }
+    const int64_t a0 = is_carry ? k0 : (int64_t)p0;
+    const int64_t a1full = (int64_t)p1;
     const int64_t a1 = a1full < k1 ? a1full : k1;
     const int lo = (int)(a0 - k0), hi = (int)(a1 - k0);
     double sum = 0.0;
     if (by_wave) {
-      for (int k = lo + lane; k < hi; k += WAVE) sum += prod[k];
+      for (int k = lo + lane; k < hi; k += WAVE) sum += prod[fe_slot(k)];
       sum = wave_sum(sum);
     } else {
-      for (int k = lo; k < hi; ++k) sum += prod[k];
+      for (int k = lo; k < hi; ++k) sum += prod[fe_slot(k)];
     }
     if (!by_wave || lane == 0) {
       if (is_carry) pf[b] = sum;                       // completed (or passed on) by fe_fix_kernel
       else if (a1full > k1) pl[b] = sum;               // continues in the next block
-      else fe_emit<ROWS>(F, o, s, sum, xb, loss, rsum);
+      else fe_emit<ROWS>(F, o, s, sum, xb, fo, fy, fw, loss, rsum);
     }
   }
   if (ROWS) {
@@ -179,15 +216,15 @@ __global__ void fe_fix_kernel(FeDev F, SolveParams o) {
     double loss = 0.0, rsum = 0.0;
     const int64_t k0 = (int64_t)b * FE_BLK;
     const int64_t k1 = (k0 + FE_BLK < F.z) ? k0 + FE_BLK : F.z;
-    const int o0 = own[b], o1 = own[b + 1];
-    const bool carry = b > 0 && ((o0 < o1) ? (int64_t)ptr[o0] > k0 : true) && k0 < k1;
+    const int o0 = own[b];
+    const bool carry = (ROWS ? F.carry_r : F.carry_c)[b] != 0;
     if (carry) {
       const int s = o0 - 1;
       if ((int64_t)ptr[s + 1] <= k1) {   // ends here
         const int ob = (int)((int64_t)ptr[s] / FE_BLK);
         double t = pl[ob];
         for (int bb = ob + 1; bb <= b; ++bb) t += pf[bb];
-        fe_emit<ROWS>(F, o, s, t, xb, loss, rsum);
+        fe_emit<ROWS>(F, o, s, t, xb, ROWS ? F.o[s] : 0.0f, ROWS ? F.y[s] : 0.0f, (ROWS && F.w) ? F.w[s] : 1.0f, loss, rsum);
       }
     }
     if (ROWS) { F.loss_fix[b] = loss; F.rsum_fix[b] = rsum; }
@@ -197,7 +234,11 @@ __global__ void fe_fix_kernel(FeDev F, SolveParams o) {
 // local gradient into the global coefficient space; workgroup 0 also adds up the value and the intercept gradient
 __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
   __shared__ double red[2][FE_WAVES];
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < F.d; j += gridDim.x * blockDim.x) F.fg[F.umap[j]] = F.gl[j];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < F.d; j += gridDim.x * blockDim.x) {
+    double g = F.gl[j];
+    for (int t = 1; t < F.ntile; ++t) g += F.gl[(size_t)t * F.d + j];   // tiles in row order
+    F.fg[F.umap[j]] = g;
+  }
   if (blockIdx.x != 0) return;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
   double a = 0.0, r = 0.0;
@@ -270,13 +311,25 @@ __global__ __launch_bounds__(FE_THREADS) void fe_step_kernel(FeDev F, SolveParam
   __shared__ double tot[TEAM_K];
   __shared__ CompactMats mats;
   const int tid = threadIdx.x;
-  if (tid < TEAM_K) {
-    double s = F.acc_part[tid];
-    for (int b = 1; b < dot_blocks; ++b) {
-      const double t = F.acc_part[(size_t)b * TEAM_K + tid];
-      s = (tid == TEAM_K - 1) ? fmax(s, t) : s + t;
+  {
+    // value v of block b by thread (b % 8) * 32 + v, eight partial totals per value, combined in order
+    __shared__ double part8[8][32];
+    const int v = tid & 31, g = tid >> 5;
+    if (v < TEAM_K) {
+      double s = 0.0;
+      for (int b = g; b < dot_blocks; b += 8) {
+        const double t = F.acc_part[(size_t)b * TEAM_K + v];
+        s = (v == TEAM_K - 1) ? fmax(s, t) : s + t;
+      }
+      part8[g][v] = s;
     }
-    tot[tid] = s;
+    __syncthreads();
+    if (tid < TEAM_K) {
+      double s = part8[0][tid];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) s = (tid == TEAM_K - 1) ? fmax(s, part8[k][tid]) : s + part8[k][tid];
+      tot[tid] = s;
+    }
   }
   {
     const double* src = reinterpret_cast<const double*>(F.mats);
@@ -329,6 +382,37 @@ __global__ void fe_init_kernel(FeDev F, const double* __restrict__ theta0) {
   }
 }
 
+// ---- row-tiled copy of the CSC arrays -----------------------------------------------------------------------------
+// The column pass gathers the residual of every entry's row. With the columns stored whole, consecutive entries
+// of a column are rows far apart and the residual vector (8 B x samples) does not fit an XCD's 4 MiB L2: every
+// gather pulls a full line from the fabric (measured: 7.5 GB fetched for 1 GB of entries). Cutting the columns into
+// row tiles of FE_TILE_ROWS and storing the entries tile-major (tile, column, row) keeps the residuals a pass touches
+// at any time within 2 MiB; the per-(tile, column) sums are added up in tile order afterwards.
+__global__ void fe_tile_count_kernel(const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ csc_row, int d,
+                                     uint32_t* __restrict__ key, uint32_t* __restrict__ perm, int32_t* __restrict__ cnt) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int nw = (gridDim.x * blockDim.x) >> 6;
+  for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < d; c += nw) {
+    const int k1 = col_ptr[c + 1];
+    for (int k = col_ptr[c] + lane; k < k1; k += WAVE) {
+      const int t = csc_row[k] / FE_TILE_ROWS;
+      key[k] = (uint32_t)t;
+      perm[k] = (uint32_t)k;
+      atomicAdd(&cnt[(size_t)t * d + c], 1);
+    }
+  }
+}
+
+__global__ void fe_tile_gather_kernel(const uint32_t* __restrict__ perm, const int32_t* __restrict__ csc_row,
+                                      const float* __restrict__ csc_val, int64_t z, int32_t* __restrict__ trow,
+                                      float* __restrict__ tval) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < z; k += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t src = perm[k];
+    trow[k] = csc_row[src];
+    tval[k] = csc_val[src];
+  }
+}
+
 }  // namespace gdmix
 
 using namespace gdmix;
@@ -338,6 +422,7 @@ struct gdmix_fe_problem {
   FeDev F;
   SolveParams o;
   void* pool;            // one device allocation carved into the arrays above
+  void* tiled;           // row-tiled CSC copy (NULL when the shard has a single row tile)
   int32_t* status_dev;
   hipEvent_t ev[3];
   bool timed;
@@ -373,11 +458,16 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   if (!p) { set_error("out of host memory"); return GDMIX_RE_ENOMEM; }
   p->ctx = ctx;
   p->pool = nullptr;
+  p->tiled = nullptr;
   p->timed = false;
   for (auto& e : p->ev) e = nullptr;
   FeDev& F = p->F;
   const int ic = opts->has_intercept ? 1 : 0;
   F.n = (int)b->N; F.z = b->Z; F.d = (int)b->D; F.ic = ic; F.D = num_features; F.P = (int)num_features + ic; F.m = opts->m;
+  F.ntile = (F.n + FE_TILE_ROWS - 1) / FE_TILE_ROWS;
+  if (F.ntile < 1) F.ntile = 1;
+  if ((int64_t)F.ntile * F.d > 0x7ffffff0ll) { set_error("row tiles x features exceeds 2^31"); delete p; return GDMIX_RE_ERANGE; }
+  F.nseg_c = F.ntile * F.d;
   F.nblk = (int)((F.z + FE_BLK - 1) / FE_BLK);
   if (F.nblk < 1) F.nblk = 1;
   F.row_ptr = b->row_ptr; F.csr_col = b->csr_col; F.csr_val = b->csr_val; F.col_ptr = b->col_ptr; F.csc_row = b->csc_row;
@@ -389,8 +479,8 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   const size_t P = (size_t)F.P, nb = (size_t)F.nblk;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t r = off; off = up256(off + bytes); return r; };
-  const size_t o_xl = take((size_t)(F.d + 1) * 8), o_rs = take((size_t)(F.n + 1) * 8), o_gl = take((size_t)(F.d + 1) * 8);
-  const size_t o_fg = take((P + 1) * 8), o_ownr = take((nb + 1) * 4), o_ownc = take((nb + 1) * 4);
+  const size_t o_xl = take((size_t)(F.d + 1) * 8), o_rs = take((size_t)(F.n + 1) * 8), o_gl = take(((size_t)F.nseg_c + 1) * 8);
+  const size_t o_fg = take((P + 1) * 8), o_ownr = take((nb + 1) * 4), o_ownc = take((nb + 1) * 4), o_cr = take(nb + 1), o_cc = take(nb + 1);
   const size_t o_part = take(nb * 8 * 8), o_acc = take((size_t)FE_DOT_BLOCKS * TEAM_K * 8);
   const size_t o_state = take(sizeof(CompactState)), o_plan = take(sizeof(CompactPlan)), o_mats = take(sizeof(CompactMats));
   const size_t o_vec = take((size_t)(5 + 2 * opts->m) * P * 8), o_status = take(64);
@@ -402,6 +492,7 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   F.xl = reinterpret_cast<double*>(base + o_xl); F.rs = reinterpret_cast<double*>(base + o_rs);
   F.gl = reinterpret_cast<double*>(base + o_gl); F.fg = reinterpret_cast<double*>(base + o_fg);
   F.own_r = reinterpret_cast<int32_t*>(base + o_ownr); F.own_c = reinterpret_cast<int32_t*>(base + o_ownc);
+  F.carry_r = reinterpret_cast<uint8_t*>(base + o_cr); F.carry_c = reinterpret_cast<uint8_t*>(base + o_cc);
   double* part = reinterpret_cast<double*>(base + o_part);
   F.pf_r = part; F.pl_r = part + nb; F.pf_c = part + 2 * nb; F.pl_c = part + 3 * nb;
   F.loss_part = part + 4 * nb; F.rsum_part = part + 5 * nb; F.loss_fix = part + 6 * nb; F.rsum_fix = part + 7 * nb;
@@ -415,8 +506,51 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   F.W.rs = F.rs; F.W.alpha = nullptr; F.W.rho = nullptr; F.W.part = nullptr;
   p->status_dev = reinterpret_cast<int32_t*>(base + o_status);
   const int g = (int)((nb + 1 + 255) / 256);
-  hipLaunchKernelGGL(fe_own_kernel, dim3(g), dim3(256), 0, s, F.row_ptr, F.n, F.nblk, F.own_r);
-  hipLaunchKernelGGL(fe_own_kernel, dim3(g), dim3(256), 0, s, F.col_ptr, F.d, F.nblk, F.own_c);
+  hipLaunchKernelGGL(fe_own_kernel, dim3(g), dim3(256), 0, s, F.row_ptr, F.n, F.nblk, F.z, F.own_r, F.carry_r);
+  if (F.ntile > 1) {
+    // build the row-tiled CSC copy: stable sort of the packed (column, row) order by tile, segment table by histogram + scan
+    const size_t z = (size_t)F.z, ns = (size_t)F.nseg_c;
+    size_t toff = 0;
+    auto ttake = [&](size_t bytes) { size_t r = toff; toff = up256(toff + bytes); return r; };
+    const size_t t_ptr = ttake((ns + 1) * 4), t_row = ttake(z * 4), t_val = ttake(z * 4);
+    rc = hipMalloc(&p->tiled, toff);
+    if (rc != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", toff, hipGetErrorString(rc)); (void)hipFree(p->pool); delete p; return GDMIX_RE_ENOMEM; }
+    char* tb = static_cast<char*>(p->tiled);
+    int32_t* tptr = reinterpret_cast<int32_t*>(tb + t_ptr);
+    int32_t* trow = reinterpret_cast<int32_t*>(tb + t_row);
+    float* tval = reinterpret_cast<float*>(tb + t_val);
+    unsigned bits = 1;
+    while ((1 << bits) < F.ntile) ++bits;
+    size_t sort_tmp = 0, scan_tmp = 0;
+    rc = rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                   z, 0u, bits, s);
+    if (rc == hipSuccess) rc = rocprim::exclusive_scan(nullptr, scan_tmp, (int32_t*)nullptr, (int32_t*)nullptr, 0, ns + 1, rocprim::plus<int32_t>(), s);
+    void* tmp = nullptr;
+    size_t woff = 0;
+    auto wtake = [&](size_t bytes) { size_t r = woff; woff = up256(woff + bytes); return r; };
+    const size_t w_key = wtake(z * 4), w_perm = wtake(z * 4), w_key2 = wtake(z * 4), w_perm2 = wtake(z * 4), w_cnt = wtake((ns + 1) * 4);
+    const size_t w_lib = wtake(sort_tmp > scan_tmp ? sort_tmp : scan_tmp);
+    if (rc == hipSuccess) rc = hipMalloc(&tmp, woff);
+    if (rc != hipSuccess) { set_error("tiled column copy: %s", hipGetErrorString(rc)); (void)hipFree(p->tiled); (void)hipFree(p->pool); delete p; return GDMIX_RE_ENOMEM; }
+    char* wb = static_cast<char*>(tmp);
+    uint32_t* key = reinterpret_cast<uint32_t*>(wb + w_key);
+    uint32_t* perm = reinterpret_cast<uint32_t*>(wb + w_perm);
+    uint32_t* key2 = reinterpret_cast<uint32_t*>(wb + w_key2);
+    uint32_t* perm2 = reinterpret_cast<uint32_t*>(wb + w_perm2);
+    int32_t* cnt = reinterpret_cast<int32_t*>(wb + w_cnt);
+    (void)hipMemsetAsync(cnt, 0, (ns + 1) * 4, s);
+    hipLaunchKernelGGL(fe_tile_count_kernel, dim3(ci->num_cus * 8), dim3(256), 0, s, b->col_ptr, b->csc_row, F.d, key, perm, cnt);
+    size_t lt = scan_tmp;
+    rc = rocprim::exclusive_scan(wb + w_lib, lt, cnt, tptr, 0, ns + 1, rocprim::plus<int32_t>(), s);
+    lt = sort_tmp;
+    if (rc == hipSuccess) rc = rocprim::radix_sort_pairs(wb + w_lib, lt, key, key2, perm, perm2, z, 0u, bits, s);
+    hipLaunchKernelGGL(fe_tile_gather_kernel, dim3(ci->num_cus * 16), dim3(256), 0, s, perm2, b->csc_row, b->csc_val, (int64_t)z, trow, tval);
+    if (rc == hipSuccess) rc = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    if (rc != hipSuccess) { set_error("tiled column copy: %s", hipGetErrorString(rc)); (void)hipFree(p->tiled); (void)hipFree(p->pool); delete p; return GDMIX_RE_EHIP; }
+    F.col_ptr = tptr; F.csc_row = trow; F.csc_val = tval;
+  }
+  hipLaunchKernelGGL(fe_own_kernel, dim3(g), dim3(256), 0, s, F.col_ptr, F.nseg_c, F.nblk, F.z, F.own_c, F.carry_c);
   int gp = (int)((P + 255) / 256);
   if (gp > 1024) gp = 1024;
   hipLaunchKernelGGL(fe_init_kernel, dim3(gp), dim3(256), 0, s, F, theta0);
@@ -430,6 +564,7 @@ GDMIX_API void gdmix_fe_destroy(gdmix_fe_problem* p) {
   if (!p) return;
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
   if (p->pool) (void)hipFree(p->pool);
+  if (p->tiled) (void)hipFree(p->tiled);
   delete p;
 }
 

@@ -221,7 +221,13 @@ def _fit_stepping(self, row_nnz_ptr, col_global, val, y, num_features, offset=No
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            all_reduce = lambda t: dist.all_reduce(t, group=group)
+            if dist.get_backend(group) == "nccl":          # RCCL, in place on the device buffer
+                all_reduce = lambda t: dist.all_reduce(t, group=group)
+            else:                                          # e.g. gloo: staged through the host
+                def all_reduce(t):
+                    h = t.cpu()
+                    dist.all_reduce(h, group=group)
+                    t.copy_(h)
     except ImportError:
         pass
     status = run_stepping_loop(prob, all_reduce)

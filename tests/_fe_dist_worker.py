@@ -1,0 +1,44 @@
+"""Worker of the two-process fixed-effect test: each rank holds every other sample of a fixture as its shard on the
+(shared) GPU and runs the product path fit_stepping(); the all-reduce goes through gloo."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch.distributed as dist
+
+from gdmix_amd import fixed_effect as fe
+
+
+def main():
+    base, names = sys.argv[1], sys.argv[2].split(",")
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    out = {}
+    s = fe.FixedEffectDeviceSolver(0)
+    for name in names:
+        z = np.load(os.path.join(ROOT, "tests", "golden", f"fe_{name}.npz"))
+        rp, col, val = z["row_nnz_ptr"], z["col_global"], z["val"]
+        rows = np.arange(rank, rp.size - 1, world)
+        k = np.diff(rp)[rows]
+        nz = np.concatenate([np.arange(rp[i], rp[i + 1]) for i in rows]) if rows.size else np.zeros(0, np.int64)
+        theta, info = s.fit_stepping(np.concatenate([[0], np.cumsum(k)]), col[nz], val[nz], z["y"][rows], int(z["num_features"]),
+                                     offset=z["offset"][rows], has_intercept=bool(z["has_intercept"]), l2=float(z["l2"]),
+                                     regularize_bias=True,
+                                     model_type=fe.LINEAR_REGRESSION if z["linear"] else fe.LOGISTIC_REGRESSION,
+                                     theta0=z["theta0"] if z["theta0"].size else None, max_iter=int(z["max_iter"]))
+        out[name] = {"theta": theta.tolist(), "status": int(info["status"]), "nit": int(info["nit"]), "nfev": int(info["nfev"])}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, out)
+    if rank == 0:
+        json.dump(gathered, open(os.path.join(base, "result.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

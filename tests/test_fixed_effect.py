@@ -142,10 +142,33 @@ def test_stepping_kernels_on_ragged_rows_long_columns_and_weights(device_solver)
 
 
 @pytest.mark.gpu
+def test_two_workers_all_reduce_gradient_and_value(tmp_path):
+    """Two processes, each with every other sample as its shard (both on GPU 0, collectives over gloo): the replicated
+    L-BFGS step on the all-reduced [gradient, value] gives every worker the coefficients of the whole data set."""
+    import json
+    import subprocess
+    import sys
+    names = ["logistic_offset", "linear_offset", "logistic_wide", "logistic_no_intercept", "logistic_warm_one_iteration"]
+    root = os.path.dirname(HERE)
+    env = dict(os.environ)
+    env.pop("TF_CONFIG", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(root, "tests", "_fe_dist_worker.py"), str(tmp_path), ",".join(names)]
+    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=root)
+    res = json.load(open(tmp_path / "result.json"))
+    assert len(res) == 2
+    for name in names:
+        c = load(name)
+        a, b = res[0][name], res[1][name]
+        assert a["theta"] == b["theta"] and a["status"] == b["status"] and a["nit"] == b["nit"]     # replicated step: bitwise equal
+        assert rel_err(np.array(a["theta"]), c["theta"]) <= tol(a["status"]) * 10, (name, rel_err(np.array(a["theta"]), c["theta"]))
+
+
+@pytest.mark.gpu
 def test_device_fixed_effect_at_scale_against_oracle(device_solver):
-    """200k samples x 20 non-zeros over 5000 features, weights, unregularised intercept, both model types."""
+    """600k samples x 8 non-zeros over 5000 features, weights, unregularised intercept, both model types."""
     rng = np.random.default_rng(0)
-    n, k, D = 200_000, 20, 5000
+    n, k, D = 600_000, 8, 5000   # three row tiles of the column copy
     cols = rng.integers(0, D, (n, k))
     vals = rng.standard_normal((n, k)).astype(np.float32)
     w_true = rng.standard_normal(D) * 0.3
