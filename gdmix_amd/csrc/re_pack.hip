@@ -252,13 +252,25 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t* __restr
   if (threadIdx.x == 0) block_sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
-__global__ void scan_blocksums_kernel(long long* __restrict__ block_sums, int nb, PackStats* __restrict__ stats) {
-  // single thread: nb = ceil(E / 2048) is at most a few tens of thousands
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    long long run = 0;
-    for (int b = 0; b < nb; ++b) { const long long v = block_sums[b]; block_sums[b] = run; run += v; }
-    stats->D = (unsigned long long)run;
+// exclusive scan of the per-chunk sums by one workgroup: every thread takes a contiguous run of chunks
+__global__ __launch_bounds__(1024) void scan_blocksums_kernel(long long* __restrict__ block_sums, int nb, PackStats* __restrict__ stats) {
+  __shared__ long long tsum[1024];
+  const int tid = threadIdx.x;
+  const int per = (nb + 1023) / 1024;
+  const int b0 = tid * per, b1 = (b0 + per < nb) ? b0 + per : nb;
+  long long mine = 0;
+  for (int b = b0; b < b1; ++b) mine += block_sums[b];
+  tsum[tid] = mine;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+    const long long v = (tid >= off) ? tsum[tid - off] : 0;
+    __syncthreads();
+    tsum[tid] += v;
+    __syncthreads();
   }
+  long long run = tsum[tid] - mine;
+  for (int b = b0; b < b1; ++b) { const long long v = block_sums[b]; block_sums[b] = run; run += v; }
+  if (tid == 1023) stats->D = (unsigned long long)tsum[1023];
 }
 
 __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ in, int64_t count,
@@ -427,7 +439,7 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
   DBG_STAGE("pack_big_entities");
   const int nb = (int)((E + SCAN_CHUNK - 1) / SCAN_CHUNK);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, s, d_cnt, E, block_sums);
-  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1), 0, s, block_sums, nb, stats);
+  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb, stats);
   hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, s, d_cnt, E, block_sums, out->ent_feat_ptr);
   DBG_STAGE("scan kernels");
   {
