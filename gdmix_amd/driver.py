@@ -142,3 +142,66 @@ class RandomEffectDriver:
             self._anchor_directory(p.validation_score_dir, partition_index), f"part-{task:05d}.avro") \
             if p.validation_score_dir else None
         return ctx
+
+
+class FixedEffectDriver:
+    """drivers/fixed_effect_driver.py:12-75 + drivers/driver.py:85-216: one model over all the data; worker w of W reads
+    files[w::W]; the partition index is the task index and directories are not anchored."""
+
+    def __init__(self, base_training_params, model):
+        self.base_training_params = base_training_params
+        self.model = model
+        self.execution_context = self._setup_cluster()
+        self.effect_name = constants.FIXED_EFFECT
+
+    def _setup_cluster(self):
+        tf_config = os.environ.get(constants.TF_CONFIG)
+        if not tf_config:
+            rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+            return {constants.TASK_TYPE: "worker", constants.TASK_INDEX: rank, constants.CLUSTER_SPEC: None,
+                    constants.NUM_WORKERS: world, constants.NUM_SHARDS: world, constants.SHARD_INDEX: rank,
+                    constants.IS_CHIEF: rank == 0}
+        cfg = json.loads(tf_config)
+        cluster = cfg.get("cluster") or {}
+        task = cfg.get("task", {})
+        n = len(cluster.get(constants.WORKER, []))
+        ctx = {constants.TASK_TYPE: task.get("type"), constants.TASK_INDEX: task.get("index"), constants.CLUSTER_SPEC: None,
+               constants.NUM_WORKERS: n, constants.NUM_SHARDS: n, constants.SHARD_INDEX: task.get("index"),
+               constants.IS_CHIEF: task.get("index") == 0}
+        if ctx[constants.TASK_TYPE] is None or ctx[constants.TASK_INDEX] is None:
+            raise Exception("No job name found")
+        if n < 1:
+            raise Exception("No worker found")
+        return ctx
+
+    def _get_partition_list(self):
+        return [self.execution_context[constants.TASK_INDEX]]
+
+    def _init_collectives(self):
+        """W > 1 workers all-reduce gradient and value: RCCL when launched one process per GPU by torch.distributed.run."""
+        if self.execution_context[constants.NUM_WORKERS] <= 1:
+            return
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            backend = "nccl" if torch.cuda.is_available() and torch.cuda.device_count() >= int(os.environ.get("LOCAL_WORLD_SIZE", "1")) else "gloo"
+            dist.init_process_group(os.environ.get("GDMIX_DIST_BACKEND", backend))
+
+    def run_training(self, schema_params, export_model=False, output_model_dir=None):
+        logger.info(f"Commencing {self.effect_name} training")
+        self._init_collectives()
+        ctx = dict(self.execution_context)
+        ctx[constants.PARTITION_INDEX] = ctx[constants.TASK_INDEX]
+        self.model.train(training_data_dir=self.model.training_data_dir, validation_data_dir=self.model.validation_data_dir,
+                         metadata_file=self.model.metadata_file, checkpoint_path=self.model.checkpoint_path,
+                         execution_context=ctx, schema_params=schema_params)
+        if export_model and ctx[constants.IS_CHIEF]:
+            self.model.export(output_model_dir=output_model_dir)
+
+    def run_inference(self, schema_params):
+        logger.info(f"Commencing {self.effect_name} inference")
+        ctx = dict(self.execution_context)
+        ctx[constants.PARTITION_INDEX] = ctx[constants.TASK_INDEX]
+        self.model.predict(output_dir=self.base_training_params.validation_score_dir,
+                           input_data_path=self.model.validation_data_dir, metadata_file=self.model.metadata_file,
+                           checkpoint_path=self.model.checkpoint_path, execution_context=ctx, schema_params=schema_params)

@@ -5,13 +5,13 @@ shared by Params, SchemaParams and REParams, unknown flags are ignored, any fail
     python -m gdmix_amd.gdmix --stage=random_effect --action=train --model_type=logistic_regression \\
         --partition_list_file=... --training_data_dir=... --metadata_file=... --output_model_dir=... ...
 
-Only --stage=random_effect is implemented (the fixed-effect and DeText stages are out of scope).
+--stage=fixed_effect runs the linear / logistic fixed-effect model (fe_model.py); the DeText stage is out of scope.
 """
 import logging
 import sys
 
 from . import constants
-from .driver import RandomEffectDriver
+from .driver import FixedEffectDriver, RandomEffectDriver
 from .model import RandomEffectLRLBFGSModel
 from .params import Params, SchemaParams
 
@@ -23,11 +23,17 @@ def run(args):
     params = Params.__from_argv__(args, error_on_unknown=False)
     schema_params = SchemaParams.__from_argv__(args, error_on_unknown=False)
     logger.info(f"Parsed schema params amd gdmix args (params): {params}")
-    if params.stage != constants.RANDOM_EFFECT:
-        raise NotImplementedError(f"stage {params.stage!r}: only the random-effect stage runs on this library")
-    if params.model_type != constants.LOGISTIC_REGRESSION:
-        raise ValueError("Random effect supports logistic_regression only")
-    driver = RandomEffectDriver(base_training_params=params, model=RandomEffectLRLBFGSModel(raw_model_params=args))
+    if params.stage == constants.FIXED_EFFECT:
+        if params.model_type not in (constants.LOGISTIC_REGRESSION, constants.LINEAR_REGRESSION):
+            raise NotImplementedError(f"model type {params.model_type!r}: the fixed effect runs logistic_regression and linear_regression")
+        from .fe_model import FixedEffectLRModelLBFGS
+        driver = FixedEffectDriver(base_training_params=params, model=FixedEffectLRModelLBFGS(raw_model_params=args, base_training_params=params))
+    elif params.stage == constants.RANDOM_EFFECT:
+        if params.model_type != constants.LOGISTIC_REGRESSION:
+            raise ValueError("Random effect supports logistic_regression only")
+        driver = RandomEffectDriver(base_training_params=params, model=RandomEffectLRLBFGSModel(raw_model_params=args))
+    else:
+        raise NotImplementedError(f"stage {params.stage!r} does not run on this library")
     if params.action == constants.ACTION_TRAIN:
         driver.run_training(schema_params=schema_params, export_model=True)
     elif params.action == constants.ACTION_INFERENCE:

@@ -462,11 +462,11 @@ class RandomEffectLRLBFGSModel:
 
 # ---- Avro writers (record layout of util/io_utils.py:102-212 and :299-375) ----------------------------------
 def _export_models_to_avro(output_file, table, feature_list, has_intercept, with_variance, sparsity_threshold=1e-4,
-                           native=None, sync_marker=None):
+                           native=None, sync_marker=None, model_class=None):
     """One BayesianLinearModelAvro per entity: intercept always, features with |value| > threshold
     (gen_one_avro_model, util/io_utils.py:102-160). The array payloads are assembled from pre-encoded
     name/term prefixes instead of per-field schema dispatch."""
-    model_class = constants.PHOTON_LR_MODEL_CLASS
+    model_class = model_class or constants.PHOTON_LR_MODEL_CLASS
     head_class = avro.enc_long(1) + avro.enc_string(model_class)       # union branch 1 (string)
     loss = avro.enc_long(1) + avro.enc_string("")                      # lossFunction = "" (not null)
     icpt = avro.enc_string(constants.INTERCEPT) + avro.enc_string("")

@@ -63,7 +63,8 @@ def one_case(name, seed, has_offset, has_intercept, intercept_only, model_type, 
     # the reference's own generator gives data and its expected coefficients for this seed
     if n is not None:
         ref._NUM_SAMPLES, ref._NUM_FEATURES = n, d
-    exp = ref._create_expected_data(has_offset, seed, use_previous_model, intercept_only, has_intercept, model_type)["training"]
+    both = ref._create_expected_data(has_offset, seed, use_previous_model, intercept_only, has_intercept, model_type)
+    exp, vexp = both["training"], both["validation"]
     ref._NUM_SAMPLES, ref._NUM_FEATURES = 100, 10
     y = np.asarray(exp.labels, np.float64)
     off = np.asarray(exp.offsets, np.float32)
@@ -85,7 +86,22 @@ def one_case(name, seed, has_offset, has_intercept, intercept_only, model_type, 
     order = np.lexsort((colsi, rows))
     rows, colsi = rows[order], colsi[order]
     row_ptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=y.size))]).astype(np.int64)
-    out = dict(row_nnz_ptr=row_ptr, col_global=colsi.astype(np.int64), val=X32[rows, colsi].astype(np.float32),
+    # validation set of the same seed and the scores the reference's _predict gives for theta on float32-valued inputs
+    voff = np.asarray(vexp.offsets, np.float32)
+    VX32 = np.zeros((voff.size, 0), np.float32) if intercept_only else np.asarray(vexp.features, np.float32)
+    vcols = [VX32.astype(np.float64)]
+    if has_intercept or intercept_only:
+        vcols.append(np.ones((voff.size, 1)))
+    per_t, tot_t = ref._predict(theta, Xp, off.astype(np.float64))
+    per_v, tot_v = ref._predict(theta, np.hstack(vcols), voff.astype(np.float64))
+    vr, vc = np.nonzero(VX32)
+    vo = np.lexsort((vc, vr))
+    vr, vc = vr[vo], vc[vo]
+    vrp = np.concatenate([[0], np.cumsum(np.bincount(vr, minlength=voff.size))]).astype(np.int64)
+    val_out = dict(v_row_nnz_ptr=vrp, v_col_global=vc.astype(np.int64), v_val=VX32[vr, vc].astype(np.float32),
+                   v_y=np.asarray(vexp.labels, np.float32), v_offset=voff, train_per_coord=per_t, train_score=tot_t,
+                   valid_per_coord=per_v, valid_score=tot_v)
+    out = dict(**val_out, row_nnz_ptr=row_ptr, col_global=colsi.astype(np.int64), val=X32[rows, colsi].astype(np.float32),
                y=y.astype(np.float32), offset=off, num_features=np.int64(X32.shape[1]),
                has_intercept=np.int64(1 if (has_intercept or intercept_only) else 0), l2=np.float64(l2),
                linear=np.int64(model_type == constants.LINEAR_REGRESSION), max_iter=np.int64(max_iter if not use_previous_model else 1),

@@ -130,3 +130,40 @@ class OracleSolverDouble:
         b = packed.batch
         lo, pc = oracle.score(packed.pk, b.val, b.offset, theta, packed.has_intercept, has_model)
         return _Arr(lo), _Arr(pc)
+
+
+class OracleFeDouble:
+    """Stands in for gdmix_amd.fixed_effect.FixedEffectDeviceSolver in CPU-only tests of the fixed-effect model class:
+    same fit_stepping() contract, solved by the oracle; `.solver` is the OracleSolverDouble (pack / score)."""
+
+    def __init__(self):
+        self.solver = OracleSolverDouble()
+
+    def fit_stepping(self, row_nnz_ptr, col_global, val, y, num_features, offset=None, weight=None, has_intercept=True, l2=1.0,
+                     regularize_bias=True, model_type="logistic_regression", theta0=None, max_iter=100, m=10, tolerance=1e-12,
+                     group=None):
+        from gdmix_amd import fixed_effect as fe
+        from oracle import oracle
+        linear = model_type == fe.LINEAR_REGRESSION
+        batch, dummy = fe.shard_as_batch(row_nnz_ptr, col_global, val, y, offset, weight, has_intercept, binary_labels=not linear)
+        D = 1 if dummy else int(num_features)
+        pk = oracle.pack(batch.ent_row_ptr, batch.row_nnz_ptr, batch.col_global)
+        uniq = pk["unique_global"]
+        ic = 1 if has_intercept else 0
+        t0 = None
+        if theta0 is not None:
+            full = np.zeros(D + ic)
+            th = np.asarray(theta0, np.float64)
+            if dummy:
+                full[D:] = th[-ic:] if ic else []
+            else:
+                full[:] = th
+            t0 = fe.to_local(full, uniq, D, has_intercept, False)
+        o = oracle.make_opts(l2=l2, regularize_bias=bool(regularize_bias) and has_intercept, has_intercept=has_intercept, m=m,
+                             max_iter=max_iter, ftol=tolerance, threshold=0.0, sum_loss=True, linear=linear)
+        res = oracle.solve(pk, batch.val, batch.y, batch.offset, batch.weight, o, theta0=t0)
+        theta = fe.to_global(res["theta"], uniq, D, has_intercept, False)
+        if dummy:
+            theta = theta[D:]
+        return theta, dict(fval=res["fval"][0], gnorm=res["gnorm"][0], nit=int(res["nit"][0]), nfev=int(res["nfev"][0]),
+                           status=int(res["status"][0]))
