@@ -796,4 +796,157 @@ GDMIX_IO_API int gdmix_io_read_grouped(const char* const* files, int32_t n_files
   return GDMIX_IO_OK;
 }
 
+// ---- per-record (tf.train.Example) files: the fixed-effect stage's input -------------------------------------------
+// One Example per sample (per_record_input_fn, gdmix-trainer/src/gdmix/io/input_data_pipeline.py:129-221): dense
+// columns are one-element lists, the sparse bag two lists `<bag>_indices` / `<bag>_values`. schema->entity is unused;
+// schema->offset / label / weight may be NULL (column not in the metadata: offset 0, label 0, weight 1, as
+// fixed_effect_lr_lbfgs_model.py:255-258 defaults them). The batch comes back with E = 0 and no entity arrays.
+GDMIX_IO_API int gdmix_io_read_examples(const char* const* files, int32_t n_files, const gdmix_io_schema* sc,
+                                        gdmix_io_batch** out) {
+  if (!out) return fail(GDMIX_IO_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (!sc || n_files < 0 || (n_files > 0 && !files) || !sc->uid) return fail(GDMIX_IO_EINVAL, "NULL argument");
+  int threads = sc->threads;
+  if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads <= 0) threads = 1; }
+  Ctx c;
+  c.sc = sc;
+  for (int f = 0; f < n_files; ++f) {
+    if (!files[f]) return fail(GDMIX_IO_EINVAL, "files[%d] is NULL", f);
+    c.files.emplace_back(files[f]);
+  }
+  std::vector<FileBuf> bufs((size_t)n_files);
+  std::vector<std::vector<RecInfo>> file_recs((size_t)n_files);
+  {
+    std::atomic<int> nextf{0}, rc{GDMIX_IO_OK}, err_set{0};
+    std::string err;
+    auto work = [&]() {
+      for (;;) {
+        const int f = nextf.fetch_add(1);
+        if (f >= n_files) return;
+        int r = load_file(c.files[f], bufs[f]);
+        if (r == GDMIX_IO_OK) r = index_records(c.files[f], bufs[f], f, sc->check_crc != 0, file_recs[f]);
+        if (r != GDMIX_IO_OK) { int e = 0; if (err_set.compare_exchange_strong(e, 1)) { err = g_err; rc.store(r); } }
+      }
+    };
+    const int nt = threads < n_files ? threads : n_files;
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+    if (rc.load() != GDMIX_IO_OK) { snprintf(g_err, sizeof(g_err), "%s", err.c_str()); return rc.load(); }
+  }
+  std::vector<RecInfo> recs;
+  int64_t bytes = 0;
+  for (int f = 0; f < n_files; ++f) {
+    recs.insert(recs.end(), file_recs[f].begin(), file_recs[f].end());
+    std::vector<RecInfo>().swap(file_recs[f]);
+    bytes += (int64_t)bufs[f].size;
+  }
+  const int64_t N = (int64_t)recs.size();
+  const std::string bag_i = sc->feature_bag ? std::string(sc->feature_bag) + "_indices" : std::string();
+  const std::string bag_v = sc->feature_bag ? std::string(sc->feature_bag) + "_values" : std::string();
+  const size_t l_uid = strlen(sc->uid), l_off = sc->offset ? strlen(sc->offset) : 0, l_lab = sc->label ? strlen(sc->label) : 0,
+               l_w = sc->weight ? strlen(sc->weight) : 0;
+  // pass 1: locate the columns of every record (f_uid / f_offset / f_label / f_weight / fl_idx / fl_val hold Feature messages)
+  int rc = parallel_for(N, threads, [&](int64_t i) {
+    RecInfo& r = recs[i];
+    if (sc->check_crc) {
+      uint32_t want;
+      memcpy(&want, r.rec.e, 4);
+      if (want != masked(crc32c(r.rec.p, r.rec.size()))) return rec_error(c, r, GDMIX_IO_EFORMAT, "corrupt data CRC");
+    }
+    Span msg = r.rec, feats;
+    Field f;
+    while (!msg.empty()) {
+      if (!next_field(msg, f)) return rec_error(c, r, GDMIX_IO_EFORMAT, "bad Example");
+      if (f.fn == 1 && f.wt == 2) feats = f.payload;
+    }
+    bool have_uid = false, have_off = false, have_lab = false, have_w = false;
+    while (!feats.empty()) {
+      if (!next_field(feats, f)) return rec_error(c, r, GDMIX_IO_EFORMAT, "bad Features");
+      if (f.fn != 1 || f.wt != 2) continue;
+      Span entry = f.payload, key, val;
+      bool has_key = false;
+      Field g;
+      while (!entry.empty()) {
+        if (!next_field(entry, g)) return rec_error(c, r, GDMIX_IO_EFORMAT, "bad Features entry");
+        if (g.wt != 2) continue;
+        if (g.fn == 1) { key = g.payload; has_key = true; }
+        else if (g.fn == 2) val = g.payload;
+      }
+      if (!has_key) continue;
+      if (key_is(key, sc->uid, l_uid)) { r.f_uid = val; have_uid = true; }
+      else if (key_is(key, sc->offset, l_off)) { r.f_offset = val; have_off = true; }
+      else if (key_is(key, sc->label, l_lab)) { r.f_label = val; have_lab = true; }
+      else if (key_is(key, sc->weight, l_w)) { r.f_weight = val; have_w = true; }
+      else if (sc->feature_bag && key_is(key, bag_i.c_str(), bag_i.size())) r.fl_idx = val;
+      else if (sc->feature_bag && key_is(key, bag_v.c_str(), bag_v.size())) r.fl_val = val;
+    }
+    if (!have_uid) return rec_error(c, r, GDMIX_IO_ESCHEMA, "uid column is missing");
+    if (sc->offset && !have_off) return rec_error(c, r, GDMIX_IO_ESCHEMA, "offset column is missing");
+    if (sc->label && !have_lab) return rec_error(c, r, GDMIX_IO_ESCHEMA, "label column is missing");
+    if (sc->weight && !have_w) return rec_error(c, r, GDMIX_IO_ESCHEMA, "weight column is missing");
+    int64_t m;
+    int e;
+    if ((e = column_len(c, r, r.f_uid, true, false, "uid column must hold one int64", m))) return e;
+    if (m != 1) return rec_error(c, r, GDMIX_IO_ESCHEMA, "uid column must hold one value per record");
+    if (sc->offset) { if ((e = column_len(c, r, r.f_offset, true, true, "bad offset column", m))) return e; if (m != 1) return rec_error(c, r, GDMIX_IO_ESCHEMA, "offset column must hold one value per record"); }
+    if (sc->label) { if ((e = column_len(c, r, r.f_label, true, true, "bad label column", m))) return e; if (m != 1) return rec_error(c, r, GDMIX_IO_ESCHEMA, "label column must hold one value per record"); }
+    if (sc->weight) { if ((e = column_len(c, r, r.f_weight, true, true, "bad weight column", m))) return e; if (m != 1) return rec_error(c, r, GDMIX_IO_ESCHEMA, "weight column must hold one value per record"); }
+    int64_t a = 0, b = 0;
+    if (sc->feature_bag) {
+      if ((e = column_len(c, r, r.fl_idx, true, false, "feature indices must be an int64 list", a))) return e;
+      if ((e = column_len(c, r, r.fl_val, false, true, "feature values must be a float list", b))) return e;
+      if (a != b) return rec_error(c, r, GDMIX_IO_ESCHEMA, "indices and values of a sample differ in length");
+    }
+    r.n = 1;
+    r.nnz = a;
+    return (int)GDMIX_IO_OK;
+  });
+  if (rc != GDMIX_IO_OK) return rc;
+  gdmix_io_batch* b = (gdmix_io_batch*)calloc(1, sizeof(gdmix_io_batch));
+  if (!b) return fail(GDMIX_IO_ENOMEM, "out of memory");
+  b->E = 0; b->N = N; b->has_label = sc->label ? 1 : 0; b->bytes_read = bytes;
+  bool ok = alloc(b->row_nnz_ptr, N + 1);
+  int64_t Z = 0;
+  if (ok) { for (int64_t i = 0; i < N; ++i) { b->row_nnz_ptr[i] = Z; Z += recs[i].nnz; } b->row_nnz_ptr[N] = Z; b->Z = Z; }
+  ok = ok && alloc(b->col_global, Z) && alloc(b->val, Z) && alloc(b->y, N) && alloc(b->offset, N) && alloc(b->uid, N) &&
+       alloc(b->weight, N);
+  if (!ok) { gdmix_io_free(b); return fail(GDMIX_IO_ENOMEM, "out of memory"); }
+  auto one_float = [&](Span feat, float& outv) {   // int64 or float scalar -> float
+    Kind kind;
+    Span list;
+    if (!feature_kind(feat, kind, list)) return false;
+    if (kind == K_FLOAT) return read_floats(list, &outv, 1);
+    if (kind == K_INT64) { int64_t v = 0; if (!read_int64s(list, &v, 1)) return false; outv = (float)v; return true; }
+    return false;
+  };
+  rc = parallel_for(N, threads, [&](int64_t i) {
+    const RecInfo& r = recs[i];
+    Kind kind;
+    Span list;
+    feature_kind(r.f_uid, kind, list);
+    if (!read_int64s(list, b->uid + i, 1)) return rec_error(c, r, GDMIX_IO_EFORMAT, "bad uid");
+    b->offset[i] = 0.0f; b->y[i] = 0.0f; b->weight[i] = 1.0f;
+    if (sc->offset && !one_float(r.f_offset, b->offset[i])) return rec_error(c, r, GDMIX_IO_EFORMAT, "bad offset");
+    if (sc->label && !one_float(r.f_label, b->y[i])) return rec_error(c, r, GDMIX_IO_EFORMAT, "bad label");
+    if (sc->weight && !one_float(r.f_weight, b->weight[i])) return rec_error(c, r, GDMIX_IO_EFORMAT, "bad weight");
+    if (sc->feature_bag && r.nnz) {
+      const int64_t z0 = b->row_nnz_ptr[i];
+      feature_kind(r.fl_idx, kind, list);
+      if (!read_int64s(list, b->col_global + z0, r.nnz)) return rec_error(c, r, GDMIX_IO_EFORMAT, "bad index list");
+      if (sc->num_features > 0)
+        for (int64_t k = 0; k < r.nnz; ++k)
+          if (b->col_global[z0 + k] < 0 || b->col_global[z0 + k] >= sc->num_features)
+            return rec_error(c, r, GDMIX_IO_ESCHEMA, "feature index outside [0, num_features)");
+      feature_kind(r.fl_val, kind, list);
+      if (!read_floats(list, b->val + z0, r.nnz)) return rec_error(c, r, GDMIX_IO_EFORMAT, "bad value list");
+    }
+    return (int)GDMIX_IO_OK;
+  });
+  if (rc != GDMIX_IO_OK) { gdmix_io_free(b); return rc; }
+  *out = b;
+  return GDMIX_IO_OK;
+}
+
 }  // extern "C"

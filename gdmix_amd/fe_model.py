@@ -66,12 +66,20 @@ def shard_input_files(input_path, num_shards, shard_index):
 
 
 def read_per_record_files(files, metadata: DatasetMetadata, feature_bag, num_features, uid_name, label_name, offset_name,
-                          weight_name):
+                          weight_name, native=None):
     """tf.train.Example records -> flat sample arrays (CSR over samples). Columns that the metadata does not list are
-    defaults: offset 0, weight 1, label 0 (fixed_effect_lr_lbfgs_model.py:255-258,345-346)."""
+    defaults: offset 0, weight 1, label 0 (fixed_effect_lr_lbfgs_model.py:255-258,345-346). native None: libgdmix_io.so
+    when built (same rules; tests/test_fe_model.py compares the two)."""
     names = set(metadata.get_feature_names()) | set(metadata.get_label_names())
     has = lambda n: n is not None and n in names
     has_label, has_offset, has_weight = has(label_name), has(offset_name), has(weight_name)
+    if native is None:
+        native = native_reader.available()
+    if native:
+        d = native_reader.read_example_files(files, feature_bag, num_features, uid_name, label_name if has_label else None,
+                                             offset_name if has_offset else None, weight_name if has_weight else None)
+        d["has_label"], d["has_weight"] = has_label, has_weight
+        return d
     uid, y, off, w, k, cols, vals = [], [], [], [], [], [], []
     ikey, vkey = (f"{feature_bag}_indices", f"{feature_bag}_values") if feature_bag else (None, None)
 

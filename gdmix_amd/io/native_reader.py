@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libgdmix_io.so")
 ABI_VERSION = 1
 EXPORTED_SYMBOLS = ("gdmix_io_abi_version", "gdmix_io_last_error", "gdmix_io_read_grouped", "gdmix_io_free",
                     "gdmix_io_crc32c", "gdmix_io_masked_crc32c", "gdmix_io_avro_write_models", "gdmix_io_avro_write_scores",
-                    "gdmix_io_write_grouped")
+                    "gdmix_io_write_grouped", "gdmix_io_read_examples")
 
 
 class GdmixIoError(RuntimeError):
@@ -63,6 +63,7 @@ def load_library():
     lib.gdmix_io_abi_version.restype = C.c_int
     lib.gdmix_io_last_error.restype = C.c_char_p
     lib.gdmix_io_read_grouped.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.POINTER(_Schema), C.POINTER(C.POINTER(_Batch))]
+    lib.gdmix_io_read_examples.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.POINTER(_Schema), C.POINTER(C.POINTER(_Batch))]
     lib.gdmix_io_free.argtypes = [C.POINTER(_Batch)]
     lib.gdmix_io_free.restype = None
     lib.gdmix_io_avro_write_models.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.POINTER(_ModelTable),
@@ -231,3 +232,25 @@ def write_grouped_file(path, batch: RawBatch, entity_name, feature_bag, offset_c
     rc = lib.gdmix_io_write_grouped(path.encode("utf-8"), C.byref(b), C.byref(sc), int(bool(int_entity_ids)))
     if rc != 0:
         raise GdmixIoError("gdmix_io_write_grouped: " + lib.gdmix_io_last_error().decode("utf-8", "replace"))
+
+
+def read_example_files(files, feature_bag, num_features, uid_name, label_name=None, offset_name=None, weight_name=None,
+                       check_crc=False, threads=0):
+    """Per-record (tf.train.Example) files -> dict of flat sample arrays (the fixed-effect stage's input)."""
+    lib = load_library()
+    sc = _Schema(None, _enc(feature_bag), _enc(offset_name), _enc(uid_name), _enc(label_name), _enc(weight_name),
+                 -1 if num_features is None or feature_bag is None else int(num_features), int(bool(check_crc)), int(threads))
+    arr = (C.c_char_p * len(files))(*[f.encode("utf-8") for f in files])
+    out = C.POINTER(_Batch)()
+    rc = lib.gdmix_io_read_examples(arr, len(files), C.byref(sc), C.byref(out))
+    if rc != 0:
+        msg = lib.gdmix_io_last_error().decode("utf-8", "replace")
+        raise (ValueError if rc in (-3, -4) else GdmixIoError)(f"gdmix_io_read_examples: {msg}")
+    try:
+        b = out.contents
+        N, Z = int(b.N), int(b.Z)
+        return dict(n=N, row_nnz_ptr=_copy(b.row_nnz_ptr, N + 1, np.int64), col=_copy(b.col_global, Z, np.int64),
+                    val=_copy(b.val, Z, np.float32), y=_copy(b.y, N, np.float32), offset=_copy(b.offset, N, np.float32),
+                    weight=_copy(b.weight, N, np.float32), uid=_copy(b.uid, N, np.int64))
+    finally:
+        lib.gdmix_io_free(out)

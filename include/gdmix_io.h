@@ -80,6 +80,13 @@ GDMIX_IO_API int gdmix_io_read_grouped(const char* const* files, int32_t n_files
                                        gdmix_io_batch** out);
 GDMIX_IO_API void gdmix_io_free(gdmix_io_batch* batch);
 
+/* Per-record files of the fixed-effect stage: one tf.train.Example per sample (per_record_input_fn,
+ * io/input_data_pipeline.py:129-221); dense columns hold one value, the sparse bag is `<bag>_indices` / `<bag>_values`.
+ * schema->entity is ignored; offset / label / weight may be NULL (defaults 0 / 0 / 1). Returns a batch with E = 0:
+ * row_nnz_ptr [N+1], col_global, val, y, offset, weight, uid. */
+GDMIX_IO_API int gdmix_io_read_examples(const char* const* files, int32_t n_files, const gdmix_io_schema* schema,
+                                        gdmix_io_batch** out);
+
 /* Write a batch as one SequenceExample per entity (".gz" / ".deflate" suffix => compressed): the layout
  * DataPartitioner produces (DataPartitioner.scala:313-316) and gdmix_io_read_grouped reads. int_entity_ids != 0:
  * entity ids (decimal strings) are written as an int64 scalar instead of bytes. Labels are written as int64

@@ -153,6 +153,34 @@ def test_weights_truncate_in_the_score_file_as_in_the_reference(tmp_path):
     assert all(r["weight"] == 2.0 for r in rows)                  # int(2.5), fixed_effect_lr_lbfgs_model.py:427-428
 
 
+def test_native_example_reader_matches_python_decoder(tmp_path):
+    from gdmix_amd.fe_model import read_per_record_files
+    from gdmix_amd.io.metadata import DatasetMetadata
+    c = load("logistic_wide")
+    setup_case(tmp_path, c, with_weight=True)
+    md = DatasetMetadata(str(tmp_path / "meta.json"))
+    files = sorted(str(p) for p in (tmp_path / "train").iterdir())
+    args = (files, md, "global", int(c["num_features"]), "uid", "response", "offset", "weight")
+    a = read_per_record_files(*args, native=False)
+    b = read_per_record_files(*args, native=True)
+    assert a["n"] == b["n"] == c["y"].size and a["has_label"] == b["has_label"] and a["has_weight"] == b["has_weight"]
+    for k in ("row_nnz_ptr", "col", "val", "y", "offset", "weight", "uid"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    np.testing.assert_array_equal(b["col"], c["col_global"])
+    # columns the metadata does not list fall back to defaults in both
+    md2 = json.load(open(tmp_path / "meta.json"))
+    md2["features"] = [f for f in md2["features"] if f["name"] not in ("offset", "weight")]
+    json.dump(md2, open(tmp_path / "meta2.json", "w"))
+    for native in (False, True):
+        r = read_per_record_files(files, DatasetMetadata(str(tmp_path / "meta2.json")), "global", int(c["num_features"]), "uid",
+                                  "response", "offset", "weight", native=native)
+        assert not r["offset"].any() and (r["weight"] == 1).all() and not r["has_weight"]
+    # a feature index outside the bag fails in both
+    for native in (False, True):
+        with pytest.raises(ValueError):
+            read_per_record_files(files, md, "global", 5, "uid", "response", "offset", "weight", native=native)
+
+
 def test_file_sharding_rules(tmp_path):
     for i in range(5):
         open(tmp_path / f"part-{i}.tfrecord", "wb").close()
