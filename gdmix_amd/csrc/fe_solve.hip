@@ -34,6 +34,7 @@ constexpr int FE_TILE_ROWS = 1 << 18;  // rows per tile of the CSC copy: 2 MiB o
 __device__ __forceinline__ int fe_slot(int k) { return k + (k >> 5); }
 constexpr int FE_WAVES = FE_THREADS / WAVE;
 constexpr int FE_DOT_BLOCKS = 512;
+constexpr int FE_FIN_BLOCKS = 64;   // workgroups (= lanes of the final wavefront) that add up the per-block partial sums
 
 struct FeDev {
   int n, d, ic, P, nblk, m;
@@ -57,6 +58,7 @@ struct FeDev {
   double *pf_r, *pl_r, *pf_c, *pl_c;                        // [nblk] partial sums of the first / last segment of a block
   double *loss_part, *rsum_part, *loss_fix, *rsum_fix;      // [nblk]
   double* acc_part;         // [FE_DOT_BLOCKS][TEAM_K]
+  double* fin_part;         // [FE_FIN_BLOCKS][2]
   CompactState* state;
   CompactPlan* plan;
   CompactMats* mats;
@@ -239,10 +241,14 @@ __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
     for (int t = 1; t < F.ntile; ++t) g += F.gl[(size_t)t * F.d + j];   // tiles in row order
     F.fg[F.umap[j]] = g;
   }
-  if (blockIdx.x != 0) return;
+  // the first FE_FIN_BLOCKS workgroups also add up a contiguous range of the per-block value / residual sums each
+  if (blockIdx.x >= FE_FIN_BLOCKS) return;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+  const int chunk = (F.nblk + FE_FIN_BLOCKS - 1) / FE_FIN_BLOCKS;
+  const int b0 = blockIdx.x * chunk;
+  const int b1 = (b0 + chunk < F.nblk) ? b0 + chunk : F.nblk;
   double a = 0.0, r = 0.0;
-  for (int b = tid; b < F.nblk; b += FE_THREADS) {
+  for (int b = b0 + tid; b < b1; b += FE_THREADS) {
     a += F.loss_part[b]; a += F.loss_fix[b];
     r += F.rsum_part[b]; r += F.rsum_fix[b];
   }
@@ -254,8 +260,19 @@ __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
     double sa = red[0][0], sr = red[1][0];
 #pragma unroll
     for (int w = 1; w < FE_WAVES; ++w) { sa += red[0][w]; sr += red[1][w]; }
-    if (F.ic) F.fg[F.D] = sr;
-    F.fg[F.P] = sa;
+    F.fin_part[2 * blockIdx.x] = sa;
+    F.fin_part[2 * blockIdx.x + 1] = sr;
+  }
+}
+
+// one wavefront: the FE_FIN_BLOCKS range sums -> data value and intercept gradient
+__global__ __launch_bounds__(WAVE) void fe_finish2_kernel(FeDev F) {
+  const int lane = threadIdx.x;
+  const double a = wave_sum(lane < FE_FIN_BLOCKS ? F.fin_part[2 * lane] : 0.0);
+  const double r = wave_sum(lane < FE_FIN_BLOCKS ? F.fin_part[2 * lane + 1] : 0.0);
+  if (lane == 0) {
+    if (F.ic) F.fg[F.D] = r;
+    F.fg[F.P] = a;
   }
 }
 
@@ -481,7 +498,7 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   auto take = [&](size_t bytes) { size_t r = off; off = up256(off + bytes); return r; };
   const size_t o_xl = take((size_t)(F.d + 1) * 8), o_rs = take((size_t)(F.n + 1) * 8), o_gl = take(((size_t)F.nseg_c + 1) * 8);
   const size_t o_fg = take((P + 1) * 8), o_ownr = take((nb + 1) * 4), o_ownc = take((nb + 1) * 4), o_cr = take(nb + 1), o_cc = take(nb + 1);
-  const size_t o_part = take(nb * 8 * 8), o_acc = take((size_t)FE_DOT_BLOCKS * TEAM_K * 8);
+  const size_t o_part = take(nb * 8 * 8), o_acc = take((size_t)FE_DOT_BLOCKS * TEAM_K * 8), o_fin = take((size_t)FE_FIN_BLOCKS * 2 * 8);
   const size_t o_state = take(sizeof(CompactState)), o_plan = take(sizeof(CompactPlan)), o_mats = take(sizeof(CompactMats));
   const size_t o_vec = take((size_t)(5 + 2 * opts->m) * P * 8), o_status = take(64);
   hipError_t rc = hipMalloc(&p->pool, off);
@@ -497,6 +514,7 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   F.pf_r = part; F.pl_r = part + nb; F.pf_c = part + 2 * nb; F.pl_c = part + 3 * nb;
   F.loss_part = part + 4 * nb; F.rsum_part = part + 5 * nb; F.loss_fix = part + 6 * nb; F.rsum_fix = part + 7 * nb;
   F.acc_part = reinterpret_cast<double*>(base + o_acc);
+  F.fin_part = reinterpret_cast<double*>(base + o_fin);
   F.state = reinterpret_cast<CompactState*>(base + o_state);
   F.plan = reinterpret_cast<CompactPlan*>(base + o_plan);
   F.mats = reinterpret_cast<CompactMats*>(base + o_mats);
@@ -592,7 +610,8 @@ GDMIX_API int gdmix_fe_eval(gdmix_fe_problem* p, void* stream) {
   hipLaunchKernelGGL((fe_stream_kernel<false>), dim3(F.nblk), dim3(FE_THREADS), 0, s, F, p->o);
   hipLaunchKernelGGL((fe_fix_kernel<false>), dim3(gf), dim3(256), 0, s, F, p->o);
   HIP_TRY(hipEventRecord(p->ev[2], s));
-  hipLaunchKernelGGL(fe_finish_kernel, dim3(gd), dim3(FE_THREADS), 0, s, F);
+  hipLaunchKernelGGL(fe_finish_kernel, dim3(gd < FE_FIN_BLOCKS ? FE_FIN_BLOCKS : gd), dim3(FE_THREADS), 0, s, F);
+  hipLaunchKernelGGL(fe_finish2_kernel, dim3(1), dim3(WAVE), 0, s, F);
   HIP_TRY(hipGetLastError());
   p->timed = true;
   return GDMIX_RE_OK;

@@ -8,5 +8,5 @@ rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_IN
 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE -d $O/sq2 -o q2 -- python tools/fe_bench.py > $O/sq2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o f -- python tools/fe_bench.py > $O/fetch.log 2>&1
 python tools/prof_summary.py --stats $(ls $O/stats/*.db | head -1) --pmc $(ls $O/sq/*.db | head -1) $(ls $O/sq2/*.db | head -1) $(ls $O/fetch/*.db | head -1) > $O/summary.txt 2>&1
-grep -E "fe_stream" $O/summary.txt | head -60
+grep -E "fe_stream|fe_step|fe_dots|fe_finish|fe_fix" $O/summary.txt | head -40
 find $O -name "*.db" -delete
