@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive hand-over measurement")
     ap.add_argument("--giant-nnz", type=int, default=-1, help="override the device-wide kernel threshold (exploration)")
-    ap.add_argument("--team-nnz", type=int, default=-1, help="override the 16-team kernel threshold (exploration)")
+    ap.add_argument("--team-nnz", type=int, default=-1, help="override the lowest team-tier threshold (exploration)")
     ap.add_argument("--solve-only", action="store_true", help="time gdmix_re_solve alone (batch packed once)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c5mean", "zipf", "ml_user", "ml_movie"],
                     help="c2 (default, the benchmarked configuration) or an exploration shape")

@@ -628,7 +628,7 @@ GDMIX_API int gdmix_fe_step(gdmix_fe_problem* p, void* stream, int32_t* status) 
   if (gp > 1024) gp = 1024;
   hipLaunchKernelGGL(fe_update_kernel, dim3(gp), dim3(256), 0, s, F, p->o.m);
   HIP_TRY(hipGetLastError());
-  int32_t* hp = p->ctx->impl.host_pinned + 512;
+  int32_t* hp = p->ctx->impl.host_pinned + 960;
   HIP_TRY(hipMemcpyAsync(hp, p->status_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   *status = *hp;

@@ -59,7 +59,9 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_WREG8, 65536, "re_solve_wreg_kernel<8> lds<=64K"},
     {KIND_WLDS, 24576, "re_solve_wave_kernel lds<=24K"},     {KIND_WLDS, 65536, "re_solve_wave_kernel lds<=64K"},
     {KIND_BLOCK, 0, "re_solve_team_kernel workgroup"},
-    {KIND_GRID, 0, "re_solve_team_kernel 16 teams"},
+    {KIND_GRID, 0, "re_solve_team_kernel 128 teams"},
+    {KIND_GRID, 0, "re_solve_team_kernel 32 teams"},
+    {KIND_GRID, 0, "re_solve_team_kernel 8 teams"},
     {KIND_GRID, 0, "re_solve_team_kernel device-wide"}};
 
 __global__ void class_base_kernel(int32_t* cc) {
@@ -124,7 +126,7 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   c->impl.wave_lds_limit = 65536;
   c->impl.kernel_mask = 7;
   c->impl.timing = 0;
-  c->impl.giant_nnz = 524288;
+  c->impl.giant_nnz = 16777216;
   c->impl.team_nnz = 16384;
   c->impl.grid_sync = nullptr;
   c->impl.big_tmp = nullptr;
@@ -314,13 +316,13 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   }
 
   int32_t* cc = b->class_count;
-  HIP_TRY(hipMemsetAsync(cc, 0, 3 * GDMIX_RE_NUM_CLASSES * sizeof(int32_t), s));
+  HIP_TRY(hipMemsetAsync(cc, 0, 6 * GDMIX_RE_NUM_CLASSES * sizeof(int32_t), s));
   HIP_TRY(launch_classify(b, ic, opts->m, tab, b->cls_tmp, cc, s));
   hipLaunchKernelGGL(class_base_kernel, dim3(1), dim3(1), 0, s, cc);
   HIP_TRY(hipGetLastError());
   HIP_TRY(launch_order(b, b->cls_tmp, cc + GDMIX_RE_NUM_CLASSES, cc + 2 * GDMIX_RE_NUM_CLASSES, s));
   int32_t* hc = ctx->impl.host_pinned + 256;
-  HIP_TRY(hipMemcpyAsync(hc, cc, GDMIX_RE_NUM_CLASSES * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(hc, cc, 6 * GDMIX_RE_NUM_CLASSES * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
 
   SolveParams P;
@@ -352,7 +354,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[c], s)); ctx->impl.ev_used[c] = true; }
     begin += hc[c];
   }
-  if (hc[BLOCK_CLASS] > 0 || hc[XTEAM_CLASS] > 0 || hc[GIANT_CLASS] > 0) {
+  if (hc[BLOCK_CLASS] > 0 || hc[TEAM128_CLASS] > 0 || hc[TEAM32_CLASS] > 0 || hc[TEAM8_CLASS] > 0 || hc[GIANT_CLASS] > 0) {
     size_t slot_doubles;
     int slots = slots_for(b, opts, &slot_doubles);
     size_t need = (size_t)slots * slot_doubles * 8;
@@ -366,7 +368,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
       if (b->scratch_bytes > avail) { avail = b->scratch_bytes; base = b->scratch; }
       slots = (int)(avail / (slot_doubles * 8));
       if (slots < 1) {
-        set_error("%d entities need the workgroup kernel: provide >= %zu bytes via gdmix_re_set_scratch", hc[BLOCK_CLASS] + hc[XTEAM_CLASS] + hc[GIANT_CLASS],
+        set_error("%d entities need the workgroup kernel: provide >= %zu bytes via gdmix_re_set_scratch", hc[BLOCK_CLASS] + hc[TEAM128_CLASS] + hc[TEAM32_CLASS] + hc[TEAM8_CLASS] + hc[GIANT_CLASS],
                   slot_doubles * 8);
         return GDMIX_RE_ENOMEM;
       }
@@ -379,16 +381,27 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
       begin += hc[BLOCK_CLASS];
     }
     // the team kernels run after the workgroup kernel on the same stream, so its slots are free again
-    if (hc[XTEAM_CLASS] > 0) {
-      int teams = 16;   // 16 CUs per entity, 16 entities at a time
+    for (int tier = 0; tier < 3; ++tier) {
+      const int cls = tier == 0 ? TEAM128_CLASS : (tier == 1 ? TEAM32_CLASS : TEAM8_CLASS);
+      if (hc[cls] <= 0) continue;
+      // Team count: the longest solve on its team should take about as long as the whole tier on the device, i.e.
+      // teams ~ total work / largest entity's work (non-zeros as the measure), within what the tier allows: few large
+      // entities get large teams (the critical path matters), many small ones small teams (the barriers do).
+      const int tier_max = tier == 0 ? 128 : (tier == 1 ? 32 : 8);
+      const unsigned long long tot = reinterpret_cast<const unsigned long long*>(hc + 4 * GDMIX_RE_NUM_CLASSES)[cls];
+      const unsigned long long big = (unsigned long long)hc[3 * GDMIX_RE_NUM_CLASSES + cls];
+      const unsigned long long ratio = big ? tot / big : 1;
+      int teams = 1;
+      while (teams * 2 <= tier_max && (unsigned long long)(teams * 2) <= ratio) teams *= 2;
       if (const char* ev = getenv("GDMIX_RE_TEAMS")) teams = atoi(ev);   // exploration knob
       if (teams > TEAM_MAX_TEAMS) teams = TEAM_MAX_TEAMS;
-      if (teams < 1 || slots < teams) teams = 1;
-      if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[XTEAM_CLASS], s)); }
-      HIP_TRY(launch_solve_grid(B, O, P, theta0, begin, hc[XTEAM_CLASS], scratch, slot_doubles, b->max_p,
-                                ctx->impl.grid_sync, ctx->impl.num_cus, teams, s));
-      if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[XTEAM_CLASS], s)); ctx->impl.ev_used[XTEAM_CLASS] = true; }
-      begin += hc[XTEAM_CLASS];
+      while (teams > 1 && (slots < teams || ctx->impl.num_cus % teams)) teams >>= 1;
+      if (teams < 1) teams = 1;
+      if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[cls], s)); }
+      HIP_TRY(launch_solve_grid(B, O, P, theta0, begin, hc[cls], scratch, slot_doubles, b->max_p, ctx->impl.grid_sync,
+                                ctx->impl.num_cus, teams, s));
+      if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[cls], s)); ctx->impl.ev_used[cls] = true; }
+      begin += hc[cls];
     }
     if (hc[GIANT_CLASS] > 0) {
       if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[GIANT_CLASS], s)); }

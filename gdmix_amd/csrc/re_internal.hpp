@@ -32,8 +32,10 @@ __host__ __device__ inline int group_epl(int kind) {
   return kind == KIND_QUAD2 ? 2 : ((kind == KIND_QUAD3 || kind == KIND_PAIR3 || kind == KIND_G64_3 || kind == KIND_G128_3 || kind == KIND_G256_3) ? 3 : (group_lanes(kind) > 0 ? 4 : 0));
 }
 constexpr int GIANT_CLASS = GDMIX_RE_NUM_CLASSES - 1;   // device-wide kernel, one entity at a time
-constexpr int XTEAM_CLASS = GDMIX_RE_NUM_CLASSES - 2;   // 16 CUs per entity, 16 entities at a time
-constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 3;
+constexpr int TEAM8_CLASS = GDMIX_RE_NUM_CLASSES - 2;    // 8 teams of 32 CUs
+constexpr int TEAM32_CLASS = GDMIX_RE_NUM_CLASSES - 3;   // 32 teams of 8 CUs
+constexpr int TEAM128_CLASS = GDMIX_RE_NUM_CLASSES - 4;  // 128 teams of 2 CUs
+constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 5;
 constexpr int BLOCK_NW = 4;   // wavefronts per workgroup of the block kernel
 #ifndef GDMIX_TEAM_BLOCK_NW
 #define GDMIX_TEAM_BLOCK_NW 8
@@ -47,7 +49,7 @@ struct ClassTable {
   int ncap[GDMIX_RE_NUM_CLASSES];        // quad classes: sample / non-zero capacity of a row's LDS block
   int zcap[GDMIX_RE_NUM_CLASSES];
   int64_t giant_nnz;   // 0 = device-wide kernel off
-  int64_t team_nnz;    // 0 = 16-team kernel off
+  int64_t team_nnz;    // 0 = team tiers off
 };
 
 // Device pointers of a packed batch, passed by value to kernels.
@@ -88,7 +90,7 @@ struct gdmix_ctx_impl {
   int kernel_mask;        // bit0 register wave kernel, bit1 LDS wave kernel, bit2 quad kernel
   int timing;             // bracket class launches with events
   int64_t giant_nnz;      // entities with >= this many non-zeros use the device-wide kernel (0 = never)
-  int64_t team_nnz;       // ... the 16-team kernel (0 = never)
+  int64_t team_nnz;       // lowest tier of the team kernel (0 = never)
   void* grid_sync;        // device: TeamSync of the team kernels
   void* big_tmp;          // device: grow-only temporary of the big-entity pack path
   size_t big_tmp_bytes;

@@ -321,7 +321,7 @@ static PackLayout pack_layout(int64_t E, int64_t N, int64_t Z) {
   L.order = take((size_t)(E + 1) * 4);
   L.cls_tmp = take((size_t)(E + 1) * 4);
   L.d_cnt = take((size_t)(E + 1) * 4);
-  L.class_count = take(3 * GDMIX_RE_NUM_CLASSES * 4);
+  L.class_count = take(6 * GDMIX_RE_NUM_CLASSES * 4);
   L.block_sums = take((size_t)((E + 1) / SCAN_CHUNK + 2) * 8);
   L.stats = take(sizeof(PackStats));
   L.sort_key = take((size_t)(Z + 1) * 8);

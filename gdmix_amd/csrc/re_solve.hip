@@ -46,9 +46,15 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
       }
     }
     if (tab.giant_nnz > 0 && z >= tab.giant_nnz) c = GIANT_CLASS;
-    else if (tab.team_nnz > 0 && z >= tab.team_nnz) c = XTEAM_CLASS;
+    else if (tab.team_nnz > 0 && z >= tab.team_nnz)
+      c = (z >= 128 * tab.team_nnz) ? TEAM8_CLASS : ((z >= 8 * tab.team_nnz) ? TEAM32_CLASS : TEAM128_CLASS);
     cls_out[e] = c;
     atomicAdd(&local[c], 1);
+    if (c >= TEAM128_CLASS && c <= TEAM8_CLASS) {
+      // work of the team tiers (non-zeros: total and largest entity), for the choice of the team size; rare entities
+      atomicAdd(reinterpret_cast<unsigned long long*>(counts + 4 * GDMIX_RE_NUM_CLASSES) + c, (unsigned long long)z);
+      atomicMax(counts + 3 * GDMIX_RE_NUM_CLASSES + c, z);
+    }
   }
   __syncthreads();
   if (threadIdx.x < GDMIX_RE_NUM_CLASSES && local[threadIdx.x]) atomicAdd(&counts[threadIdx.x], local[threadIdx.x]);

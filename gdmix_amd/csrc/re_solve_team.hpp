@@ -34,7 +34,7 @@ namespace gdmix {
 
 constexpr int TEAM_VEC = 32;                  // doubles per workgroup slot of the device-wide exchange buffer
 constexpr int TEAM_MAX_BLOCKS = 256;           // workgroups per team
-constexpr int TEAM_MAX_TEAMS = 32;
+constexpr int TEAM_MAX_TEAMS = 128;
 constexpr int TEAM_SHORT_COL = 16;            // tiles whose columns are all this short: one lane per column
 constexpr int TEAM_CHUNK = 512;               // CSC entries a wavefront stages through LDS at a time
 constexpr int TEAM_LONGC = 2048;              // columns at least this long are split over the team in 64 slices

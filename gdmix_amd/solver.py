@@ -18,7 +18,7 @@ from .batch import RawBatch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgdmix_re.so")
 
-NUM_CLASSES = 46
+NUM_CLASSES = 48
 STATUS_NAMES = ("PGTOL", "FACTR", "MAXITER", "MAXFUN", "ABNORMAL")
 VAR_NONE, VAR_SIMPLE, VAR_FULL = 0, 1, 2
 VARIANCE_MODES = {None: VAR_NONE, "simple": VAR_SIMPLE, "SIMPLE": VAR_SIMPLE, "full": VAR_FULL, "FULL": VAR_FULL,
@@ -293,7 +293,7 @@ class REDeviceSolver:
         _check(self.lib.gdmix_re_set_giant_nnz(self._h, int(nnz)), "set_giant_nnz")
 
     def set_team_nnz(self, nnz: int):
-        """Entities with >= nnz non-zeros (below the giant threshold) are solved by the 16-team kernel (0 = never)."""
+        """Entities with >= nnz non-zeros (below the giant threshold) are solved by the team tiers of the persistent kernel (0 = never)."""
         _check(self.lib.gdmix_re_set_team_nnz(self._h, int(nnz)), "set_team_nnz")
 
     def set_timing(self, enabled: bool):

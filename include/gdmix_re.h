@@ -115,13 +115,13 @@ typedef struct {
   /* solver-owned scratch inside the workspace (written by gdmix_re_solve) */
   int32_t*       order;         /* [E]   entity ids grouped by size class (solver launch order)     */
   int32_t*       cls_tmp;       /* [E]   size class of each entity                                  */
-  int32_t*       class_count;   /* [3*NUM_CLASSES] per-class counts / bases / cursors (device)     */
+  int32_t*       class_count;   /* [6*NUM_CLASSES] per-class counts / bases / cursors / largest nnz / total nnz (u64) (device) */
   void*          scratch;       /* pack-time sort scratch, free for reuse once pack has returned    */
   size_t         scratch_bytes;
   int32_t        max_p, max_n, max_nnz;  /* per-entity maxima over the batch (host, after pack)     */
 } gdmix_re_packed;
 
-#define GDMIX_RE_NUM_CLASSES 46
+#define GDMIX_RE_NUM_CLASSES 48
 
 /* ---- solver options (defaults = REParams/LRParams defaults + scipy defaults) ----------------------
  * base_lr_params.py:22-27, binary_logistic_regression.py:223-231 (pgtol/maxfun/maxls are scipy's). */
@@ -203,11 +203,15 @@ GDMIX_API int gdmix_re_set_wave_lds_limit(gdmix_re_ctx* ctx, int bytes);
  * kernel is always available. Default 7. */
 GDMIX_API int gdmix_re_set_kernel_mask(gdmix_re_ctx* ctx, int mask);
 
-/* The head of a Zipf-distributed partition: entities with at least `giant_nnz` non-zeros are solved one after
- * another by a persistent kernel spanning the whole device; entities with at least `team_nnz` (and fewer than
- * giant_nnz) by the same kernel split into 16 teams of CUs, 16 entities at a time, largest first; smaller ones
- * by one workgroup each. Defaults 524288 and 16384; 0 disables a tier. Results do not depend on the
- * thresholds beyond summation order. */
+/* The head of a Zipf-distributed partition is solved by a persistent kernel (one workgroup per CU) split into teams
+ * of CUs, every team taking the next entity of its tier as it becomes free, largest first. Tiers by non-zeros:
+ *   [team_nnz, 8 team_nnz)        128 teams of 2 CUs
+ *   [8 team_nnz, 128 team_nnz)     32 teams of 8 CUs
+ *   [128 team_nnz, giant_nnz)       8 teams of 32 CUs
+ *   >= giant_nnz                    the whole device, one entity after another
+ * (these entities are bound by synchronisation and memory latency, not by throughput: small teams, many at a time).
+ * Smaller entities: one workgroup each. Defaults team_nnz 16384, giant_nnz 16777216; 0 disables the tiers above /
+ * the device-wide tier. Results do not depend on the thresholds beyond summation order. */
 GDMIX_API int gdmix_re_set_giant_nnz(gdmix_re_ctx* ctx, int64_t giant_nnz);
 GDMIX_API int gdmix_re_set_team_nnz(gdmix_re_ctx* ctx, int64_t team_nnz);
 

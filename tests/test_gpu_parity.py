@@ -54,7 +54,7 @@ def _check_pack(packed, pk, val):
     assert np.array_equal(packed.csc_val().cpu().numpy(), csc_val)
 
 
-def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, giant_nnz=524288, team_nnz=16384):
+def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, giant_nnz=16777216, team_nnz=16384):
     b, opts, exp, _ = load_fixture(name)
     kw = opts_kwargs(opts)
     pk = oracle.pack(b.ent_row_ptr, b.row_nnz_ptr, b.col_global)
@@ -70,7 +70,7 @@ def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, gian
     finally:
         device_solver.set_wave_lds_limit(65536)
         device_solver.set_kernel_mask(7)
-        device_solver.set_giant_nnz(524288)
+        device_solver.set_giant_nnz(16777216)
         device_solver.set_team_nnz(16384)
     ref = oracle.solve(pk, b.val, b.y, b.offset, b.weight, oracle.make_opts(**kw), theta0=th0)
     coef_ptr = packed.coef_ptr_host()
@@ -145,8 +145,8 @@ def test_device_wide_kernel_matches_reference_fixture(device_solver, name):
 
 @pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "ragged", "ml_per_user", "warm_stage2", "c2_no_intercept",
                                   "ragged_variance_simple"])
-def test_sixteen_team_kernel_matches_reference_fixture(device_solver, name):
-    # every entity through the persistent kernel split into 16 teams of CUs, 16 entities at a time
+def test_team_tiers_match_reference_fixture(device_solver, name):
+    # every entity through the persistent kernel split into teams of CUs (tier by size: 128, 32 or 8 teams)
     _solve_and_compare(device_solver, name, giant_nnz=0, team_nnz=1)
 
 
@@ -194,15 +194,16 @@ def test_large_and_giant_entities_pack_and_solve(device_solver):
     ref = oracle.solve(pk, b.val, b.y, b.offset, None, oracle.make_opts(**kw))
     coef_ptr = packed.coef_ptr_host()
     wp = well_posed_mask(b, dict(l2=1.0, regularize_bias=False, has_intercept=True))
-    # the two 48k-nnz entities through each tier: workgroup kernel, 16-team kernel (default), device-wide kernel
-    for giant_nnz, team_nnz, cls in ((0, 0, "re_solve_team_kernel workgroup"), (524288, 16384, "re_solve_team_kernel 16 teams"),
+    # the two 48k-nnz entities through each tier: workgroup kernel, 128 / 32 / 8 teams, device-wide kernel
+    for giant_nnz, team_nnz, cls in ((0, 0, "re_solve_team_kernel workgroup"), (16777216, 16384, "re_solve_team_kernel 128 teams"),
+                                     (16777216, 4096, "re_solve_team_kernel 32 teams"), (16777216, 256, "re_solve_team_kernel 8 teams"),
                                      (40000, 0, "re_solve_team_kernel device-wide")):
         device_solver.set_giant_nnz(giant_nnz)
         device_solver.set_team_nnz(team_nnz)
         try:
             res = device_solver.solve(packed, SolverOptions(**kw)).to_host()
         finally:
-            device_solver.set_giant_nnz(524288)
+            device_solver.set_giant_nnz(16777216)
             device_solver.set_team_nnz(16384)
         counts = dict(device_solver.class_counts(packed))
         assert counts[cls] >= 2
