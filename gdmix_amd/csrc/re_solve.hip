@@ -649,8 +649,11 @@ __global__ __launch_bounds__(1024) void re_sort_class_kernel(int32_t* __restrict
 //                 team b % teams; placement only matters for speed); every team
 //                 takes entities team, team + teams, ... of the class, one after another
 // ---------------------------------------------------------------------------------------------------
+#ifndef GDMIX_TEAM_WAVES_PER_EU
+#define GDMIX_TEAM_WAVES_PER_EU 2
+#endif
 template <int NW, bool GRID>
-__global__ __launch_bounds__(WAVE* NW) void re_solve_team_kernel(BatchDev B, OutDev O, SolveParams o,
+__global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(GDMIX_TEAM_WAVES_PER_EU))) void re_solve_team_kernel(BatchDev B, OutDev O, SolveParams o,
                                                                  const double* __restrict__ theta0, int begin, int count,
                                                                  double* scratch, size_t slot_doubles, int64_t max_p,
                                                                  TeamSync* gs, int teams) {

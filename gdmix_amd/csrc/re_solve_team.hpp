@@ -264,8 +264,6 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
     }
     tm.sync();
   }
-#pragma unroll
-  for (int k = 0; k < TEAM_K; ++k) acc[k] = 0.0;
   double* const buf = L.buf[threadIdx.x >> 6];
   for (int tile = tm.wid; tile * WAVE < p; tile += tm.nwaves) {
     const int j = tile * WAVE + tm.lane;
@@ -361,9 +359,18 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
     }
     if (valid) {
       const double a = (ic && j == 0) ? rsum : mine;
+      W.g[j] = inv_n * (a + ((j < first_reg) ? 0.0 : o.l2 * x[j]));
+    }
+  }
+  // Products with the gradient in a second sweep over the same coefficients (the thread that stored g[j] reads it
+  // back: no synchronisation), so that the accumulators and the tile staging above are not live at the same time.
+#pragma unroll
+  for (int k = 0; k < TEAM_K; ++k) acc[k] = 0.0;
+  for (int tile = tm.wid; tile * WAVE < p; tile += tm.nwaves) {
+    const int j = tile * WAVE + tm.lane;
+    if (j < p) {
       const double xj = x[j];
-      const double gj = inv_n * (a + ((j < first_reg) ? 0.0 : o.l2 * xj));
-      W.g[j] = gj;
+      const double gj = W.g[j];
       const double dj = W.d[j], rj = W.r[j];
       if (j >= first_reg) acc[0] += xj * xj;
       acc[1] += gj * dj;
