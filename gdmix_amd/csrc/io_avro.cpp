@@ -347,3 +347,292 @@ extern "C" GDMIX_IO_API int gdmix_io_write_grouped(const char* path, const gdmix
   }
   return GDMIX_IO_OK;
 }
+
+// ---- model file reader ------------------------------------------------------------------------------------------
+// The prior model of a warm start and the model of an inference run: every BayesianLinearModelAvro record of an object
+// container file into flat arrays (what RandomEffectLRLBFGSModel._load_weights /
+// _convert_avro_model_record_to_sparse_coefficients build record by record,
+// gdmix-trainer/src/gdmix/models/custom/random_effect_lr_lbfgs_model.py:256-309). The caller has parsed the container
+// header (gdmix_amd/io/avro.py) and checked that the writer schema is the canonical field order
+// (modelId, modelClass, means, variances, lossFunction); this file walks the blocks (in parallel) and maps every
+// (name, term) to its global feature index through the pre-encoded feature list, the last of equal pairs winning as in
+// the reference's dict.
+#include <string_view>
+#include <unordered_map>
+
+namespace {
+
+struct Cursor {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool ok = true;
+  int64_t get_long() {
+    uint64_t u = 0;
+    int shift = 0;
+    for (;;) {
+      if (p >= end || shift > 63) { ok = false; return 0; }
+      const uint8_t b = *p++;
+      u |= (uint64_t)(b & 0x7F) << shift;
+      if (!(b & 0x80)) break;
+      shift += 7;
+    }
+    return (int64_t)(u >> 1) ^ -(int64_t)(u & 1);
+  }
+  std::string_view get_bytes() {
+    const int64_t n = get_long();
+    if (!ok || n < 0 || n > end - p) { ok = false; return {}; }
+    std::string_view s((const char*)p, (size_t)n);
+    p += n;
+    return s;
+  }
+  double get_double() {
+    if (end - p < 8) { ok = false; return 0.0; }
+    double v;
+    memcpy(&v, p, 8);
+    p += 8;
+    return v;
+  }
+};
+
+struct ModelBlock {   // one container block, decoded
+  std::vector<int64_t> id_len, coef_cnt, idx;
+  std::vector<uint8_t> has_var;
+  std::vector<double> mean, var;
+  std::string ids;
+  int err = 0;        // 1 malformed, 2 unknown feature, 3 intercept not first, 4 variances do not line up
+  std::string what;
+};
+
+bool raw_inflate(const uint8_t* in, size_t n, std::string& out) {
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  if (inflateInit2(&zs, -15) != Z_OK) return false;
+  out.resize(n * 4 + 1024);
+  zs.next_in = (Bytef*)in;
+  zs.avail_in = (uInt)n;
+  size_t have = 0;
+  int rc;
+  for (;;) {
+    zs.next_out = (Bytef*)&out[have];
+    zs.avail_out = (uInt)(out.size() - have);
+    rc = inflate(&zs, Z_NO_FLUSH);
+    have = out.size() - zs.avail_out;
+    if (rc == Z_STREAM_END) break;
+    if (rc != Z_OK) { inflateEnd(&zs); return false; }
+    if (zs.avail_out == 0) out.resize(out.size() * 2);
+  }
+  out.resize(have);
+  inflateEnd(&zs);
+  return true;
+}
+
+using FeatureMap = std::unordered_map<std::string_view, int64_t>;
+
+// name, term, value triples of one array; key = the raw bytes of string(name) + string(term) as they stand in the file
+template <class F>
+bool read_ntv_array(Cursor& c, F&& item) {
+  for (;;) {
+    int64_t n = c.get_long();
+    if (!c.ok) return false;
+    if (n == 0) return true;
+    if (n < 0) { n = -n; c.get_long(); }   // block with a byte size
+    for (int64_t i = 0; i < n; ++i) {
+      const uint8_t* k0 = c.p;
+      c.get_bytes();
+      c.get_bytes();
+      if (!c.ok) return false;
+      const std::string_view key((const char*)k0, (size_t)(c.p - k0));
+      const double v = c.get_double();
+      if (!c.ok) return false;
+      if (!item(key, v)) return false;
+    }
+  }
+}
+
+void decode_model_block(const uint8_t* data, size_t size, int64_t count, const FeatureMap& fmap, std::string_view icpt,
+                        bool has_intercept, ModelBlock& B) {
+  Cursor c{data, data + size};
+  std::vector<int64_t> vidx;
+  for (int64_t r = 0; r < count; ++r) {
+    const std::string_view id = c.get_bytes();
+    if (!c.ok) { B.err = 1; return; }
+    B.ids.append(id);
+    B.id_len.push_back((int64_t)id.size());
+    const int64_t cls = c.get_long();
+    if (cls == 1) c.get_bytes(); else if (cls != 0) c.ok = false;
+    if (!c.ok) { B.err = 1; return; }
+    const size_t first = B.mean.size();
+    bool good = read_ntv_array(c, [&](std::string_view key, double v) {
+      int64_t g;
+      if (has_intercept && B.mean.size() == first) {
+        if (key != icpt) { B.err = 3; B.what.assign(id); return false; }
+        g = -1;
+      } else {
+        auto it = fmap.find(key);
+        if (it == fmap.end()) { B.err = 2; B.what.assign(key); return false; }
+        g = it->second;
+      }
+      B.mean.push_back(v);
+      B.idx.push_back(g);
+      return true;
+    });
+    if (!good) { if (!B.err) B.err = 1; return; }
+    const size_t cnt = B.mean.size() - first;
+    B.coef_cnt.push_back((int64_t)cnt);
+    const int64_t vb = c.get_long();
+    if (!c.ok || (vb != 0 && vb != 1)) { B.err = 1; return; }
+    size_t nv = 0;
+    B.var.resize(B.mean.size(), 0.0);
+    if (vb == 1) {
+      good = read_ntv_array(c, [&](std::string_view key, double v) {
+        if (nv >= cnt) { B.err = 4; B.what.assign(id); return false; }
+        int64_t g = -2;
+        if (has_intercept && nv == 0) { if (key == icpt) g = -1; }
+        else { auto it = fmap.find(key); if (it != fmap.end()) g = it->second; }
+        if (g != B.idx[first + nv]) { B.err = 4; B.what.assign(id); return false; }
+        B.var[first + nv] = v;
+        ++nv;
+        return true;
+      });
+      if (!good) { if (!B.err) B.err = 1; return; }
+      if (nv != 0 && nv != cnt) { B.err = 4; B.what.assign(id); return; }
+    }
+    B.has_var.push_back(nv ? 1 : 0);   // an empty variances array counts as none (`if model_record.get("variances")`)
+    const int64_t lb = c.get_long();
+    if (lb == 1) c.get_bytes(); else if (lb != 0) c.ok = false;
+    if (!c.ok) { B.err = 1; return; }
+  }
+  if (c.p != c.end) B.err = 1;
+}
+
+template <class T>
+T* dup_array(const std::vector<T>& v) {
+  T* p = (T*)malloc((v.size() ? v.size() : 1) * sizeof(T));
+  if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+GDMIX_IO_API void gdmix_io_free_models(gdmix_io_models* m) {
+  if (!m) return;
+  free(m->id_ptr); free(m->id_bytes); free(m->coef_ptr); free(m->mean); free(m->variance); free(m->feat_idx); free(m->has_variance);
+  free(m);
+}
+
+GDMIX_IO_API int gdmix_io_avro_read_models(const char* path, int64_t data_offset, const uint8_t* sync, int32_t deflate_codec,
+                                           const int64_t* prefix_ptr, const uint8_t* prefix_bytes, int64_t n_prefix,
+                                           const uint8_t* icpt_enc, int64_t icpt_len, int32_t has_intercept, int32_t threads,
+                                           gdmix_io_models** out) {
+  if (!path || !sync || !out || data_offset < 0 || n_prefix < 0 || (n_prefix > 0 && (!prefix_ptr || !prefix_bytes)) || !icpt_enc)
+    return set_error(GDMIX_IO_EINVAL, "bad argument");
+  *out = nullptr;
+  FILE* f = fopen(path, "rb");
+  if (!f) return set_error(GDMIX_IO_EIO, "%s: cannot open", path);
+  std::string file;
+  {
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz < 0) { fclose(f); return set_error(GDMIX_IO_EIO, "%s: cannot size", path); }
+    file.resize((size_t)sz);
+    const bool ok = fread(&file[0], 1, (size_t)sz, f) == (size_t)sz;
+    fclose(f);
+    if (!ok) return set_error(GDMIX_IO_EIO, "%s: read failed", path);
+  }
+  if ((size_t)data_offset > file.size()) return set_error(GDMIX_IO_EFORMAT, "%s: header is longer than the file", path);
+  // container blocks: count, size, payload, sync
+  struct Span { int64_t count; const uint8_t* p; size_t n; };
+  std::vector<Span> spans;
+  {
+    Cursor c{(const uint8_t*)file.data() + data_offset, (const uint8_t*)file.data() + file.size()};
+    while (c.p < c.end) {
+      const int64_t count = c.get_long();
+      const int64_t size = c.get_long();
+      if (!c.ok || count < 0 || size < 0 || size + 16 > c.end - c.p) return set_error(GDMIX_IO_EFORMAT, "%s: truncated block", path);
+      if (memcmp(c.p + size, sync, 16) != 0) return set_error(GDMIX_IO_EFORMAT, "%s: sync marker mismatch", path);
+      spans.push_back({count, c.p, (size_t)size});
+      c.p += size + 16;
+    }
+  }
+  FeatureMap fmap;
+  fmap.reserve((size_t)n_prefix * 2);
+  for (int64_t g = 0; g < n_prefix; ++g)
+    fmap[std::string_view((const char*)prefix_bytes + prefix_ptr[g], (size_t)(prefix_ptr[g + 1] - prefix_ptr[g]))] = g;
+  const std::string_view icpt((const char*)icpt_enc, (size_t)icpt_len);
+  std::vector<ModelBlock> blocks(spans.size());
+  if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads <= 0) threads = 1; }
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    std::string plain;
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= spans.size()) return;
+      const uint8_t* p = spans[k].p;
+      size_t n = spans[k].n;
+      if (deflate_codec) {
+        if (!raw_inflate(p, n, plain)) { blocks[k].err = 1; continue; }
+        p = (const uint8_t*)plain.data();
+        n = plain.size();
+      }
+      decode_model_block(p, n, spans[k].count, fmap, icpt, has_intercept != 0, blocks[k]);
+    }
+  };
+  {
+    const int nt = (size_t)threads < spans.size() ? threads : (int)(spans.size() ? spans.size() : 1);
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+  }
+  int64_t E = 0, Cn = 0, idb = 0;
+  for (const ModelBlock& B : blocks) {
+    if (B.err == 1) return set_error(GDMIX_IO_EFORMAT, "%s: malformed model record", path);
+    if (B.err == 2) return set_error(GDMIX_IO_ESCHEMA, "%s: a coefficient's (name, term) is not in the feature file", path);
+    if (B.err == 3) return set_error(GDMIX_IO_ESCHEMA, "%s: model %s does not start with the intercept", path, B.what.c_str());
+    if (B.err == 4) return set_error(GDMIX_IO_ESCHEMA, "%s: variances of model %s do not line up with its means", path, B.what.c_str());
+    E += (int64_t)B.coef_cnt.size();
+    Cn += (int64_t)B.mean.size();
+    idb += (int64_t)B.ids.size();
+  }
+  gdmix_io_models* m = (gdmix_io_models*)calloc(1, sizeof(gdmix_io_models));
+  if (!m) return set_error(GDMIX_IO_ENOMEM, "out of memory");
+  m->E = E;
+  m->C = Cn;
+  m->id_ptr = (int64_t*)malloc((size_t)(E + 1) * 8);
+  m->id_bytes = (char*)malloc((size_t)(idb ? idb : 1));
+  m->coef_ptr = (int64_t*)malloc((size_t)(E + 1) * 8);
+  m->mean = (double*)malloc((size_t)(Cn ? Cn : 1) * 8);
+  m->variance = (double*)malloc((size_t)(Cn ? Cn : 1) * 8);
+  m->feat_idx = (int64_t*)malloc((size_t)(Cn ? Cn : 1) * 8);
+  m->has_variance = (uint8_t*)malloc((size_t)(E ? E : 1));
+  if (!m->id_ptr || !m->id_bytes || !m->coef_ptr || !m->mean || !m->variance || !m->feat_idx || !m->has_variance) {
+    gdmix_io_free_models(m);
+    return set_error(GDMIX_IO_ENOMEM, "out of memory");
+  }
+  int64_t e = 0, cpos = 0, ipos = 0;
+  m->id_ptr[0] = 0;
+  m->coef_ptr[0] = 0;
+  for (const ModelBlock& B : blocks) {
+    if (!B.ids.empty()) memcpy(m->id_bytes + ipos, B.ids.data(), B.ids.size());
+    if (!B.mean.empty()) {
+      memcpy(m->mean + cpos, B.mean.data(), B.mean.size() * 8);
+      memcpy(m->variance + cpos, B.var.data(), B.mean.size() * 8);
+      memcpy(m->feat_idx + cpos, B.idx.data(), B.mean.size() * 8);
+    }
+    for (size_t r = 0; r < B.coef_cnt.size(); ++r, ++e) {
+      ipos += B.id_len[r];
+      cpos += B.coef_cnt[r];
+      m->id_ptr[e + 1] = ipos;
+      m->coef_ptr[e + 1] = cpos;
+      m->has_variance[e] = B.has_var[r];
+      if (B.has_var[r]) m->any_variance = 1;
+    }
+  }
+  *out = m;
+  return GDMIX_IO_OK;
+}
+
+}  // extern "C"

@@ -458,7 +458,7 @@ __device__ void team_solve(Team<NW>& tm, const EntityView& P, const SolveParams&
     TEAM_PROF(6);
   }
 #ifdef GDMIX_TEAM_PROFILE
-  if (tm.tid == 0)
+  if (tm.tid == 0 && blockIdx.x % 64 == 0)   // a few lines only: device printf perturbs the other workgroups
     printf("team n=%d p=%d nfev=%d us/eval: rows %.1f red1 %.1f cols %.1f red2 %.1f solve %.1f upd %.1f sync %.1f\n", P.n, p, S.nfev,
            prof_t[0] * 0.01 / S.nfev, prof_t[1] * 0.01 / S.nfev, prof_t[2] * 0.01 / S.nfev, prof_t[3] * 0.01 / S.nfev,
            prof_t[4] * 0.01 / S.nfev, prof_t[5] * 0.01 / S.nfev, prof_t[6] * 0.01 / S.nfev);

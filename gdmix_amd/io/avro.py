@@ -367,6 +367,47 @@ def read_file(path):
             yield rec
 
 
+def read_header(path, limit=1 << 22):
+    """(schema, codec name, sync marker, offset of the first block) of an object container file."""
+    with open(path, "rb") as f:
+        data = f.read(limit)
+    if data[:4] != MAGIC:
+        raise ValueError(f"{path}: not an Avro object container file")
+    meta, pos = _META_CODEC.decode(memoryview(data), 4)
+    if pos + 16 > len(data):
+        raise ValueError(f"{path}: truncated header")
+    return (json.loads(meta["avro.schema"].decode("utf-8")), meta.get("avro.codec", b"null").decode("ascii"),
+            bytes(data[pos:pos + 16]), pos + 16)
+
+
+def is_model_schema(schema):
+    """True when a writer schema has exactly the field order and types of BAYESIAN_LINEAR_MODEL_SCHEMA (docs, defaults
+    and namespaces aside): the layout the native model reader walks."""
+    def ntv(t):
+        return (isinstance(t, dict) and t.get("type") == "record" and
+                [(f.get("name"), f.get("type")) for f in t.get("fields", [])] == [("name", "string"), ("term", "string"), ("value", "double")])
+    try:
+        if schema.get("type") != "record":
+            return False
+        f = schema["fields"]
+        if [x["name"] for x in f] != ["modelId", "modelClass", "means", "variances", "lossFunction"]:
+            return False
+        if f[0]["type"] != "string" or f[1]["type"] != ["null", "string"] or f[4]["type"] != ["null", "string"]:
+            return False
+        m = f[2]["type"]
+        if not (isinstance(m, dict) and m.get("type") == "array" and ntv(m["items"])):
+            return False
+        name = m["items"]["name"]
+        full = (m["items"].get("namespace") or schema.get("namespace") or "")
+        v = f[3]["type"]
+        if not (isinstance(v, list) and len(v) == 2 and v[0] == "null" and isinstance(v[1], dict) and v[1].get("type") == "array"):
+            return False
+        it = v[1]["items"]
+        return it == name or it == (full + "." + name if full else name) or ntv(it)
+    except (KeyError, TypeError, AttributeError, IndexError):
+        return False
+
+
 def read_schema(path):
     with open(path, "rb") as f:
         data = f.read(1 << 16)

@@ -10,10 +10,10 @@ from ..batch import RawBatch
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "libgdmix_io.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 EXPORTED_SYMBOLS = ("gdmix_io_abi_version", "gdmix_io_last_error", "gdmix_io_read_grouped", "gdmix_io_free",
                     "gdmix_io_crc32c", "gdmix_io_masked_crc32c", "gdmix_io_avro_write_models", "gdmix_io_avro_write_scores",
-                    "gdmix_io_write_grouped", "gdmix_io_read_examples")
+                    "gdmix_io_write_grouped", "gdmix_io_read_examples", "gdmix_io_avro_read_models", "gdmix_io_free_models")
 
 
 class GdmixIoError(RuntimeError):
@@ -43,6 +43,12 @@ class _ModelTable(C.Structure):
                 ("threshold", C.c_double)]
 
 
+class _Models(C.Structure):
+    _fields_ = [("E", C.c_int64), ("C", C.c_int64), ("id_ptr", C.POINTER(C.c_int64)), ("id_bytes", C.POINTER(C.c_char)),
+                ("coef_ptr", C.POINTER(C.c_int64)), ("mean", C.POINTER(C.c_double)), ("variance", C.POINTER(C.c_double)),
+                ("feat_idx", C.POINTER(C.c_int64)), ("has_variance", C.POINTER(C.c_uint8)), ("any_variance", C.c_int32)]
+
+
 _lib = None
 
 
@@ -70,6 +76,10 @@ def load_library():
                                                C.c_int32, C.c_int32, C.c_int32]
     lib.gdmix_io_avro_write_scores.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.gdmix_io_avro_read_models.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int32, C.c_void_p, C.c_char_p, C.c_int64,
+                                              C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.POINTER(_Models))]
+    lib.gdmix_io_free_models.argtypes = [C.POINTER(_Models)]
+    lib.gdmix_io_free_models.restype = None
     lib.gdmix_io_write_grouped.argtypes = [C.c_char_p, C.POINTER(_Batch), C.POINTER(_Schema), C.c_int32]
     lib.gdmix_io_crc32c.argtypes = [C.c_char_p, C.c_size_t]
     lib.gdmix_io_crc32c.restype = C.c_uint32
@@ -254,3 +264,32 @@ def read_example_files(files, feature_bag, num_features, uid_name, label_name=No
                     weight=_copy(b.weight, N, np.float32), uid=_copy(b.uid, N, np.int64))
     finally:
         lib.gdmix_io_free(out)
+
+
+def read_models_avro(path, data_offset: int, sync: bytes, deflate: bool, prefix, icpt_enc: bytes, has_intercept: bool, threads=0):
+    """Every model record of an Avro container file -> dict(ids, coef_ptr, mean, variance|None, feat_idx (-1 = the
+    intercept), has_variance). prefix: pre-encoded string(name)+string(term) per global feature index. Raises KeyError for
+    a coefficient that is not in the feature list, AssertionError for a misplaced intercept (the reference's errors)."""
+    lib = load_library()
+    pre_ptr = np.zeros(len(prefix) + 1, np.int64)
+    if prefix:
+        np.cumsum([len(x) for x in prefix], out=pre_ptr[1:])
+    pre_bytes = b"".join(prefix)
+    out = C.POINTER(_Models)()
+    rc = lib.gdmix_io_avro_read_models(path.encode("utf-8"), int(data_offset), sync, int(bool(deflate)), _ptr(pre_ptr), pre_bytes,
+                                       len(prefix), icpt_enc, len(icpt_enc), int(bool(has_intercept)), int(threads), C.byref(out))
+    if rc != 0:
+        msg = lib.gdmix_io_last_error().decode("utf-8", "replace")
+        if rc == -4:
+            raise (KeyError if "feature file" in msg else AssertionError)(msg)
+        raise (ValueError if rc == -3 else GdmixIoError)(f"gdmix_io_avro_read_models: {msg}")
+    try:
+        m = out.contents
+        E, Cn = int(m.E), int(m.C)
+        id_ptr = _copy(m.id_ptr, E + 1, np.int64)
+        raw = C.string_at(m.id_bytes, int(id_ptr[-1])) if E else b""
+        return dict(ids=_split_ids(raw, id_ptr, E), coef_ptr=_copy(m.coef_ptr, E + 1, np.int64), mean=_copy(m.mean, Cn, np.float64),
+                    variance=_copy(m.variance, Cn, np.float64) if m.any_variance else None,
+                    feat_idx=_copy(m.feat_idx, Cn, np.int64), has_variance=_copy(m.has_variance, E, np.uint8))
+    finally:
+        lib.gdmix_io_free_models(out)

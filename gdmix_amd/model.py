@@ -410,8 +410,12 @@ class RandomEffectLRLBFGSModel:
                 logger.info(f"No model found at {model_file}.")
                 return ModelTable()
             raise FileNotFoundError(f"Model file {model_file} does not exist")
-        feature2global_id = None if self.feature_file is None else get_feature_map(self.feature_file)
         table = ModelTable()
+        if self.feature_file is not None and native_reader.available():
+            loaded = self._load_weights_native(model_file, table)
+            if loaded:
+                return table
+        feature2global_id = None if self.feature_file is None else get_feature_map(self.feature_file)
         ids, theta, var, idx, coef_ptr, feat_ptr = [], [], [], [], [0], [0]
         any_var = False
         for record in avro.read_file(model_file):
@@ -430,6 +434,24 @@ class RandomEffectLRLBFGSModel:
             table.add_chunk(ids, np.concatenate(theta), coef_ptr, np.concatenate(idx) if idx else np.zeros(0, np.int64),
                             feat_ptr, np.concatenate(var) if any_var else None)
         return table
+
+    def _load_weights_native(self, model_file, table):
+        """The same table through libgdmix_io.so (blocks decoded in parallel); False when the file's writer schema is not
+        the canonical layout, in which case the schema-driven Python decoder reads it."""
+        schema, codec, sync, data_offset = avro.read_header(model_file)
+        if codec not in ("null", "deflate") or not avro.is_model_schema(schema):
+            return False
+        prefix = [avro.enc_string(n) + avro.enc_string(t) for (n, t) in read_feature_list(self.feature_file)]
+        icpt = avro.enc_string(constants.INTERCEPT) + avro.enc_string("")
+        m = native_reader.read_models_avro(model_file, data_offset, sync, codec == "deflate", prefix, icpt, self.has_intercept)
+        if m["ids"]:
+            ic = 1 if self.has_intercept else 0
+            coef_ptr = m["coef_ptr"]
+            feat = m["feat_idx"]
+            idx = feat[feat >= 0] if ic else feat
+            feat_ptr = coef_ptr - np.arange(coef_ptr.size, dtype=np.int64) * ic
+            table.add_chunk(m["ids"], m["mean"], coef_ptr, idx, feat_ptr, m["variance"])
+        return True
 
     @staticmethod
     def _convert_avro_model_record_to_sparse_coefficients(has_intercept, model_record, feature2global_id):

@@ -37,7 +37,7 @@ extern "C" {
 #define GDMIX_IO_ESCHEMA  (-4)   /* a record does not match the schema (missing column, length mismatch, ...) */
 #define GDMIX_IO_ENOMEM   (-5)
 
-#define GDMIX_IO_ABI_VERSION 1
+#define GDMIX_IO_ABI_VERSION 2
 
 typedef struct gdmix_io_schema {
   const char* entity;        /* context key of the entity id (int64 or bytes scalar)                       */
@@ -134,6 +134,35 @@ GDMIX_IO_API int gdmix_io_avro_write_scores(const char* path, const uint8_t* hea
                                             int64_t n, const int64_t* uid, const float* score, const float* label,
                                             const float* weight, const float* per_coord, int32_t block_records,
                                             int32_t deflate_codec, int32_t threads);
+
+/* ---- Avro model file reader ---------------------------------------------------------------------------------
+ * Every BayesianLinearModelAvro record of an object container file as flat arrays: replaces the record-by-record
+ * loop of RandomEffectLRLBFGSModel._load_weights / _convert_avro_model_record_to_sparse_coefficients
+ * (gdmix-trainer/src/gdmix/models/custom/random_effect_lr_lbfgs_model.py:256-309) for the prior model of a warm
+ * start and the model of an inference run. The caller parses the container header (data_offset = first byte after
+ * the header's sync marker) and checks that the writer schema has the canonical field order; prefix_* is the feature
+ * list as pre-encoded string(name) + string(term) (as for gdmix_io_avro_write_models; of equal pairs the last wins,
+ * like the reference's dict). has_intercept: the first coefficient of every record must be the intercept
+ * (feat_idx -1), everything else must be in the feature list (GDMIX_IO_ESCHEMA otherwise = the reference's
+ * AssertionError / KeyError). A variances array must be empty or line up with means. Blocks are decoded in parallel. */
+typedef struct gdmix_io_models {
+  int64_t  E;             /* records, in file order                                            */
+  int64_t  C;             /* coefficients over all records                                     */
+  int64_t* id_ptr;        /* [E+1] offsets into id_bytes                                       */
+  char*    id_bytes;      /* modelId strings                                                   */
+  int64_t* coef_ptr;      /* [E+1] offsets into mean / variance / feat_idx                     */
+  double*  mean;          /* [C]                                                               */
+  double*  variance;      /* [C] 0 where the record has none                                   */
+  int64_t* feat_idx;      /* [C] global feature index, -1 = the intercept                      */
+  uint8_t* has_variance;  /* [E]                                                               */
+  int32_t  any_variance;
+} gdmix_io_models;
+
+GDMIX_IO_API int gdmix_io_avro_read_models(const char* path, int64_t data_offset, const uint8_t* sync, int32_t deflate_codec,
+                                           const int64_t* prefix_ptr, const uint8_t* prefix_bytes, int64_t n_prefix,
+                                           const uint8_t* icpt_enc, int64_t icpt_len, int32_t has_intercept, int32_t threads,
+                                           gdmix_io_models** out);
+GDMIX_IO_API void gdmix_io_free_models(gdmix_io_models* models);
 
 /* CRC-32C (Castagnoli) and TFRecord's masked form ((crc >> 15 | crc << 17) + 0xa282ead8). */
 GDMIX_IO_API uint32_t gdmix_io_crc32c(const void* data, size_t len);

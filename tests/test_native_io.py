@@ -307,3 +307,127 @@ def test_native_tfrecord_writer_is_byte_identical_and_round_trips(tmp_path, int_
     write_grouped_partition(a, nolab, "ent", "bag", int_entity_ids=int_ids, native=False)
     write_grouped_partition(n, nolab, "ent", "bag", int_entity_ids=int_ids, native=True)
     assert open(a, "rb").read() == open(n, "rb").read()
+
+
+# ---- Avro model reader: the same table the record-by-record Python loader builds ---------------------------------
+def _model_for(tmp_path, D, has_intercept=True, feature_list=None):
+    from gdmix_amd.model import RandomEffectLRLBFGSModel
+    fl = feature_list or [(f"name{j}", "" if j % 4 else f"term{j}") for j in range(D)]
+    with open(tmp_path / "features.csv", "w") as f:
+        f.write("".join(f"{n},{t}\n" for n, t in fl))
+    argv = ["--output_model_dir", str(tmp_path / "m"), "--feature_bag", "bag", "--feature_file", str(tmp_path / "features.csv"),
+            "--partition_entity", "ent", "--has_intercept", "true" if has_intercept else "false",
+            "--metadata_file", str(tmp_path / "md.json")]
+    if not has_intercept:
+        argv += ["--regularize_bias", "false"]
+    return RandomEffectLRLBFGSModel(argv), fl
+
+
+def _load_both(model, path, monkeypatch):
+    nat = model._load_weights(path)
+    monkeypatch.setattr(native_reader, "available", lambda: False)
+    py = model._load_weights(path)
+    monkeypatch.undo()
+    return nat, py
+
+
+def _assert_same_table(a, b):
+    assert list(a.keys()) == list(b.keys())
+    fa, fb = a.flatten(), b.flatten()
+    for x, y in zip(fa[1:], fb[1:]):
+        if x is None or y is None:
+            assert x is None and y is None
+        else:
+            assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("with_variance", [False, True])
+@pytest.mark.parametrize("codec", ["null", "deflate"])
+def test_native_model_reader_matches_python_loader(tmp_path, monkeypatch, with_variance, codec):
+    from gdmix_amd.io import avro
+    from gdmix_amd.model import _export_models_to_avro
+    D = 50
+    model, fl = _model_for(tmp_path, D)
+    table = _table(11, 2600, D, with_variance)
+    path = str(tmp_path / "models.avro")
+    _export_models_to_avro(path, table, fl, True, with_variance, native=False)
+    if codec == "deflate":   # the same records through the generic writer with the deflate codec
+        recs = list(avro.read_file(path))
+        avro.write_file(path, avro.BAYESIAN_LINEAR_MODEL_SCHEMA, recs, codec="deflate", block_records=100)
+    nat, py = _load_both(model, path, monkeypatch)
+    assert len(nat) == 2600
+    _assert_same_table(nat, py)
+    # what was exported and thresholded is what comes back
+    k = "id1"
+    want = table[k]
+    keep = np.abs(want.theta[1:]) > 1e-4
+    assert np.array_equal(nat[k].theta, np.concatenate([want.theta[:1], want.theta[1:][keep]]))
+    assert np.array_equal(nat[k].unique_global_indices, want.unique_global_indices[keep])
+    assert (nat[k].variance is not None) == with_variance
+
+
+def test_native_model_reader_errors_and_fallbacks(tmp_path, monkeypatch):
+    from gdmix_amd.io import avro
+    from gdmix_amd.model import ModelTable, _export_models_to_avro
+    D = 6
+    model, fl = _model_for(tmp_path, D)
+    t = ModelTable()
+    t.add_chunk(["a", "b"], np.array([0.5, 1.0, -2.0, 0.25, 3.0]), [0, 3, 5], np.array([1, 4, 5]), [0, 2, 3])
+    path = str(tmp_path / "m.avro")
+    # a feature that is not in this model's feature file -> KeyError, from both loaders
+    wider = fl + [("extra", "")]
+    t2 = ModelTable()
+    t2.add_chunk(["a"], np.array([0.5, 1.0]), [0, 2], np.array([6]), [0, 1])
+    _export_models_to_avro(path, t2, wider, True, False, native=False)
+    with pytest.raises(KeyError):
+        model._load_weights(path)
+    monkeypatch.setattr(native_reader, "available", lambda: False)
+    with pytest.raises(KeyError):
+        model._load_weights(path)
+    monkeypatch.undo()
+    # a model written without an intercept read by a model that expects one -> AssertionError, from both
+    t3 = ModelTable()
+    t3.add_chunk(["a", "b"], np.array([1.0, -2.0, 3.0]), [0, 2, 3], np.array([1, 4, 5]), [0, 2, 3])
+    _export_models_to_avro(path, t3, fl, False, False, native=False)
+    with pytest.raises(AssertionError):
+        model._load_weights(path)
+    monkeypatch.setattr(native_reader, "available", lambda: False)
+    with pytest.raises(AssertionError):
+        model._load_weights(path)
+    monkeypatch.undo()
+    # a writer schema with another field order is left to the schema-driven decoder
+    _export_models_to_avro(path, t, fl, True, False, native=False)
+    recs = list(avro.read_file(path))
+    schema = dict(avro.BAYESIAN_LINEAR_MODEL_SCHEMA)
+    f = list(schema["fields"])
+    schema["fields"] = [f[0], f[1], f[4], f[2], f[3]]
+    assert not avro.is_model_schema(schema) and avro.is_model_schema(avro.BAYESIAN_LINEAR_MODEL_SCHEMA)
+    avro.write_file(path, schema, recs)
+    called = []
+    real = native_reader.read_models_avro
+    monkeypatch.setattr(native_reader, "read_models_avro", lambda *a, **k: called.append(1) or real(*a, **k))
+    got = model._load_weights(path)
+    assert not called and list(got.keys()) == ["a", "b"]
+    assert np.array_equal(got["b"].theta, [0.25, 3.0]) and np.array_equal(got["b"].unique_global_indices, [5])
+    # truncated file -> ValueError
+    _export_models_to_avro(path, t, fl, True, False, native=False)
+    data = open(path, "rb").read()
+    open(path, "wb").write(data[:-5])
+    with pytest.raises(ValueError):
+        model._load_weights(path)
+    # empty container
+    avro.write_file(path, avro.BAYESIAN_LINEAR_MODEL_SCHEMA, [])
+    assert len(model._load_weights(path)) == 0
+
+
+def test_native_model_reader_without_intercept_and_duplicate_features(tmp_path, monkeypatch):
+    from gdmix_amd.model import ModelTable, _export_models_to_avro
+    fl = [("f0", ""), ("f1", "t"), ("f0", "")]      # the later of equal (name, term) pairs wins, as in the reference's dict
+    model, _ = _model_for(tmp_path, 3, has_intercept=False, feature_list=fl)
+    t = ModelTable()
+    t.add_chunk(["x", "y"], np.array([0.5, -2.0, 3.0]), [0, 2, 3], np.array([1, 0, 1]), [0, 2, 3])
+    path = str(tmp_path / "m.avro")
+    _export_models_to_avro(path, t, fl, False, False, native=False)
+    nat, py = _load_both(model, path, monkeypatch)
+    _assert_same_table(nat, py)
+    assert np.array_equal(nat["x"].unique_global_indices, [1, 2])

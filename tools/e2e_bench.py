@@ -1,0 +1,86 @@
+"""End to end through the drop-in CLI on one MI355X: TFRecord partitions on disk -> python -m gdmix_amd.gdmix
+--stage=random_effect --action=train -> photon-ml model Avro + score Avro, with the time of each phase.
+
+    PYTHONPATH=. python tools/e2e_bench.py [entities] [partitions]
+
+C2-shaped entities (n ~ Poisson(16), k = 4, D = 1024). The phases are timed by wrapping the model's own methods;
+nothing is skipped: the active training data is read a second time for scoring, as the reference does.
+"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+from gdmix_amd import gdmix as cli
+from gdmix_amd import model as model_mod
+from gdmix_amd import synthetic
+from gdmix_amd.io.grouped_reader import write_grouped_partition
+
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+parts = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+md = {"features": [{"name": "bag", "dtype": "float", "shape": [1024], "isSparse": True},
+                   {"name": "offset", "dtype": "float", "shape": [], "isSparse": False},
+                   {"name": "uid", "dtype": "long", "shape": [], "isSparse": False},
+                   {"name": "ent", "dtype": "string", "shape": [], "isSparse": False}],
+      "labels": [{"name": "response", "dtype": "int", "shape": [], "isSparse": False}]}
+
+phases = {}
+
+
+def timed(cls, name, label):
+    fn = getattr(cls, name)
+
+    def wrapper(*a, **k):
+        t = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            phases[label] = phases.get(label, 0.0) + time.perf_counter() - t
+    setattr(cls, name, wrapper)
+
+
+M = model_mod.RandomEffectLRLBFGSModel
+timed(M, "_read", "read TFRecord (train + scoring passes)")
+timed(M, "_solve_batch", "pack + solve + D2H")
+timed(M, "_save_model", "model Avro")
+timed(M, "_predict", "scoring pass total (read + score + score Avro)")
+timed(model_mod, "_write_scores", "score Avro")
+
+with tempfile.TemporaryDirectory() as d:
+    t = time.perf_counter()
+    b = synthetic.make_batch(E, 16, 4, 1024, seed=1)
+    per = (E + parts - 1) // parts
+    for k in range(parts):
+        sub = b.select(np.arange(k * per, min(E, (k + 1) * per)))
+        write_grouped_partition(os.path.join(d, "train", "active", f"partitionId={k}", "part-0.tfrecord"), sub, "ent", "bag",
+                                weight_column_name=None)
+    json.dump(md, open(os.path.join(d, "meta.json"), "w"))
+    with open(os.path.join(d, "features.csv"), "w") as f:
+        f.write("".join(f"f{i},\n" for i in range(1024)))
+    open(os.path.join(d, "plist.txt"), "w").write(",".join(str(k) for k in range(parts)))
+    size = sum(os.path.getsize(os.path.join(r, x)) for r, _, fs in os.walk(os.path.join(d, "train")) for x in fs)
+    print(f"{E} entities, {b.N} samples, {b.Z} nnz in {parts} partitions, {size / 1e6:.0f} MB of TFRecord "
+          f"(generated + written in {time.perf_counter() - t:.1f} s)", flush=True)
+    argv = ["gdmix", "--stage=random_effect", "--model_type=logistic_regression", "--uid_column_name=uid",
+            "--label_column_name=response", "--prediction_score_column_name=predictionScore",
+            f"--partition_list_file={d}/plist.txt", f"--training_data_dir={d}/train", f"--metadata_file={d}/meta.json",
+            f"--output_model_dir={d}/models", "--feature_bag=bag", f"--feature_file={d}/features.csv",
+            "--partition_entity=ent", "--regularize_bias=False", "--l2_reg_weight=1.0", f"--training_score_dir={d}/ts",
+            "--action=train"]
+    os.environ.pop("TF_CONFIG", None)
+    import shutil
+    timed(M, "_load_weights", "prior model Avro")
+    for rep, label in enumerate(("cold start (pays for the HIP context and library load)", "cold start", "warm start from the model above")):
+        if rep == 1:
+            shutil.rmtree(os.path.join(d, "models"))
+        phases.clear()
+        t = time.perf_counter()
+        cli.run(argv)
+        dt = time.perf_counter() - t
+        out = sum(os.path.getsize(os.path.join(r, x)) for r, _, fs in os.walk(d) for x in fs if x.endswith(".avro"))
+        print(f"{label}: {dt:.2f} s  {E / dt:,.0f} entities/s end to end ({out / 1e6:.0f} MB of Avro written)")
+        for k, v in phases.items():
+            print(f"    {k:52s} {v:7.2f} s")
