@@ -636,3 +636,75 @@ GDMIX_IO_API int gdmix_io_avro_read_models(const char* path, int64_t data_offset
 }
 
 }  // extern "C"
+
+// ---- prior / trained coefficients in a batch's index space ----------------------------------------------------------
+// For every entity of a packed batch that has a model: the model's intercept, and for every feature present in the
+// batch's data the model's coefficient if it has one, else 0 — the warm start of prepare_jobs
+// (gdmix-trainer/src/gdmix/models/custom/scipy/job_consumers.py:262-288) and the coefficient vector of
+// InferenceJobConsumer, for all entities at once. Entities in parallel; an entity whose model lists its features in
+// ascending order (what this trainer and photon-ml write) is merged in one pass, any other order goes through a
+// stable sort (of equal indices the first listed wins).
+#include <algorithm>
+
+extern "C" GDMIX_IO_API int gdmix_io_map_coefficients(int64_t E, const int64_t* cur_ptr, const int64_t* cur_idx,
+                                                      const int64_t* src_row, const int64_t* prior_coef_ptr,
+                                                      const int64_t* prior_feat_ptr, const double* prior_theta,
+                                                      const int64_t* prior_idx, int32_t has_intercept, double* theta,
+                                                      int32_t threads) {
+  if (E < 0 || (E > 0 && (!cur_ptr || !src_row || !prior_coef_ptr || !prior_feat_ptr || !theta)))
+    return set_error(GDMIX_IO_EINVAL, "bad argument");
+  const int64_t ic = has_intercept ? 1 : 0;
+  if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads <= 0) threads = 1; }
+  const int64_t chunk = 4096;
+  const int64_t n_chunks = (E + chunk - 1) / chunk;
+  std::atomic<int64_t> next{0};
+  std::atomic<int> bad{0};
+  auto work = [&]() {
+    std::vector<std::pair<int64_t, int64_t>> order;
+    for (;;) {
+      const int64_t c = next.fetch_add(1);
+      if (c >= n_chunks) return;
+      const int64_t e1 = std::min(E, (c + 1) * chunk);
+      for (int64_t e = c * chunk; e < e1; ++e) {
+        const int64_t r = src_row[e];
+        if (r < 0) continue;
+        const int64_t pc0 = prior_coef_ptr[r], pc1 = prior_coef_ptr[r + 1];
+        const int64_t pf0 = prior_feat_ptr[r], pf1 = prior_feat_ptr[r + 1];
+        if (pc1 - pc0 != pf1 - pf0 + ic) { bad.store(1); continue; }
+        double* out = theta + cur_ptr[e] + e * ic;
+        if (ic) out[0] = prior_theta[pc0];
+        const int64_t* cur = cur_idx + cur_ptr[e];
+        const int64_t nc = cur_ptr[e + 1] - cur_ptr[e], np_ = pf1 - pf0;
+        if (nc == 0 || np_ == 0) continue;
+        const int64_t* pi = prior_idx + pf0;
+        const double* pv = prior_theta + pc0 + ic;
+        bool asc = true, cur_asc = true;
+        for (int64_t k = 1; k < np_ && asc; ++k) asc = pi[k - 1] < pi[k];
+        for (int64_t k = 1; k < nc && cur_asc; ++k) cur_asc = cur[k - 1] < cur[k];
+        if (asc && cur_asc) {
+          int64_t a = 0, b = 0;
+          while (a < nc && b < np_) {
+            if (cur[a] < pi[b]) ++a;
+            else if (cur[a] > pi[b]) ++b;
+            else { out[ic + a] = pv[b]; ++a; ++b; }
+          }
+        } else {
+          order.clear();
+          for (int64_t k = 0; k < np_; ++k) order.emplace_back(pi[k], k);
+          std::stable_sort(order.begin(), order.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+          for (int64_t a = 0; a < nc; ++a) {
+            auto it = std::lower_bound(order.begin(), order.end(), cur[a], [](const auto& x, int64_t key) { return x.first < key; });
+            if (it != order.end() && it->first == cur[a]) out[ic + a] = pv[it->second];
+          }
+        }
+      }
+    }
+  };
+  const int nt = (int64_t)threads < n_chunks ? threads : (int)(n_chunks ? n_chunks : 1);
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+  work();
+  for (auto& th : pool) th.join();
+  if (bad.load()) return set_error(GDMIX_IO_ESCHEMA, "a model's coefficient and feature counts do not agree");
+  return GDMIX_IO_OK;
+}

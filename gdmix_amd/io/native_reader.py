@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libgdmix_io.so")
 ABI_VERSION = 2
 EXPORTED_SYMBOLS = ("gdmix_io_abi_version", "gdmix_io_last_error", "gdmix_io_read_grouped", "gdmix_io_free",
                     "gdmix_io_crc32c", "gdmix_io_masked_crc32c", "gdmix_io_avro_write_models", "gdmix_io_avro_write_scores",
-                    "gdmix_io_write_grouped", "gdmix_io_read_examples", "gdmix_io_avro_read_models", "gdmix_io_free_models")
+                    "gdmix_io_write_grouped", "gdmix_io_read_examples", "gdmix_io_avro_read_models", "gdmix_io_free_models", "gdmix_io_map_coefficients")
 
 
 class GdmixIoError(RuntimeError):
@@ -79,6 +79,7 @@ def load_library():
     lib.gdmix_io_avro_read_models.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int32, C.c_void_p, C.c_char_p, C.c_int64,
                                               C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.POINTER(_Models))]
     lib.gdmix_io_free_models.argtypes = [C.POINTER(_Models)]
+    lib.gdmix_io_map_coefficients.argtypes = [C.c_int64] + [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_int32]
     lib.gdmix_io_free_models.restype = None
     lib.gdmix_io_write_grouped.argtypes = [C.c_char_p, C.POINTER(_Batch), C.POINTER(_Schema), C.c_int32]
     lib.gdmix_io_crc32c.argtypes = [C.c_char_p, C.c_size_t]
@@ -293,3 +294,17 @@ def read_models_avro(path, data_offset: int, sync: bytes, deflate: bool, prefix,
                     feat_idx=_copy(m.feat_idx, Cn, np.int64), has_variance=_copy(m.has_variance, E, np.uint8))
     finally:
         lib.gdmix_io_free_models(out)
+
+
+def map_coefficients(theta, cur_ptr, cur_idx, src_row, prior_coef_ptr, prior_feat_ptr, prior_theta, prior_idx, has_intercept, threads=0):
+    """theta (float64, zero where nothing is known, laid out [intercept,] features per entity) gets the coefficients of the
+    models in rows src_row (>= 0) of one table chunk; see gdmix_io_map_coefficients."""
+    lib = load_library()
+    i64 = lambda a: np.ascontiguousarray(a, np.int64)
+    cur_ptr, cur_idx, src_row, pcp, pfp, pidx = i64(cur_ptr), i64(cur_idx), i64(src_row), i64(prior_coef_ptr), i64(prior_feat_ptr), i64(prior_idx)
+    pth = np.ascontiguousarray(prior_theta, np.float64)
+    assert theta.dtype == np.float64 and theta.flags.c_contiguous
+    rc = lib.gdmix_io_map_coefficients(len(src_row), _ptr(cur_ptr), _ptr(cur_idx), _ptr(src_row), _ptr(pcp), _ptr(pfp), _ptr(pth),
+                                       _ptr(pidx), int(bool(has_intercept)), _ptr(theta), int(threads))
+    if rc != 0:
+        raise GdmixIoError("gdmix_io_map_coefficients: " + lib.gdmix_io_last_error().decode("utf-8", "replace"))

@@ -136,7 +136,7 @@ class ModelTable:
         return found, chunk, row
 
 
-def _model_coefficients_for_batch(table, entity_ids, unique_global, ent_feat_ptr, has_intercept, num_features):
+def _model_coefficients_for_batch(table, entity_ids, unique_global, ent_feat_ptr, has_intercept, num_features, native=None):
     """Coefficients of the prior / trained models in the packed batch's local index space.
 
     For every entity that has a model: intercept from the model (always), and for every feature present in
@@ -150,6 +150,15 @@ def _model_coefficients_for_batch(table, entity_ids, unique_global, ent_feat_ptr
     found, chunk, row = table.lookup(entity_ids)
     has_model = found.astype(np.uint8)
     if not found.any():
+        return theta, has_model
+    if native is None:
+        native = native_reader.available()
+    if native:
+        for c in np.unique(chunk[found]):
+            ch = table._chunks[int(c)]
+            src_row = np.where(found & (chunk == c), row, -1)
+            native_reader.map_coefficients(theta, ent_feat_ptr, unique_global, src_row, ch["coef_ptr"], ch["feat_ptr"], ch["theta"],
+                                           ch["idx"], has_intercept)
         return theta, has_model
     F = int(num_features) + 1
     ent_of_feat = np.repeat(np.arange(E, dtype=np.int64), d)

@@ -164,6 +164,20 @@ GDMIX_IO_API int gdmix_io_avro_read_models(const char* path, int64_t data_offset
                                            gdmix_io_models** out);
 GDMIX_IO_API void gdmix_io_free_models(gdmix_io_models* models);
 
+/* ---- model coefficients in a batch's index space ---------------------------------------------------------------
+ * The warm start of prepare_jobs (gdmix-trainer/src/gdmix/models/custom/scipy/job_consumers.py:262-288) and the
+ * coefficient vector InferenceJobConsumer scores with, for all entities of a packed batch at once. Entity e of the
+ * batch has features cur_idx[cur_ptr[e] .. cur_ptr[e+1]) (global indices) and, when src_row[e] >= 0, a model in row
+ * src_row[e] of a table (coefficients prior_theta[prior_coef_ptr[r] ..), intercept first when has_intercept; global
+ * feature indices prior_idx[prior_feat_ptr[r] ..)). Writes into theta (laid out [intercept,] features per entity, i.e.
+ * entity e starts at cur_ptr[e] + e * has_intercept; the caller zero-fills it): the model's intercept and, for every
+ * batch feature the model has, its coefficient (of equal indices in a model the first listed). Entities without a model
+ * are left untouched. */
+GDMIX_IO_API int gdmix_io_map_coefficients(int64_t E, const int64_t* cur_ptr, const int64_t* cur_idx, const int64_t* src_row,
+                                           const int64_t* prior_coef_ptr, const int64_t* prior_feat_ptr,
+                                           const double* prior_theta, const int64_t* prior_idx, int32_t has_intercept,
+                                           double* theta, int32_t threads);
+
 /* CRC-32C (Castagnoli) and TFRecord's masked form ((crc >> 15 | crc << 17) + 0xa282ead8). */
 GDMIX_IO_API uint32_t gdmix_io_crc32c(const void* data, size_t len);
 GDMIX_IO_API uint32_t gdmix_io_masked_crc32c(const void* data, size_t len);

@@ -407,6 +407,33 @@ def test_warm_start_mapping_matches_naive_dictionary_logic():
     E = b.E
     coef_ptr = pptr + np.arange(E + 1)
     table.add_chunk(b.entity_ids, extra["prior_theta"], coef_ptr, extra["prior_unique_global"], pptr)
-    theta0, has_model = _model_coefficients_for_batch(table, b.entity_ids, pk["unique_global"], pk["ent_feat_ptr"], True, 1024)
-    assert has_model.all()
-    np.testing.assert_array_equal(theta0, exp["theta0"])          # what the reference fed fmin_l_bfgs_b
+    for native in (False, True):
+        theta0, has_model = _model_coefficients_for_batch(table, b.entity_ids, pk["unique_global"], pk["ent_feat_ptr"], True, 1024,
+                                                          native=native)
+        assert has_model.all()
+        np.testing.assert_array_equal(theta0, exp["theta0"])          # what the reference fed fmin_l_bfgs_b
+
+
+@pytest.mark.parametrize("has_intercept", [True, False])
+def test_native_coefficient_mapping_equals_the_numpy_one(has_intercept):
+    """Several table chunks, entities without a model, models listing their features in any order (and twice)."""
+    rng = np.random.default_rng(4)
+    E, D = 500, 40
+    ic = 1 if has_intercept else 0
+    d = rng.integers(0, 12, E)
+    feat_ptr = np.concatenate([[0], np.cumsum(d)]).astype(np.int64)
+    uniq = np.concatenate([np.sort(rng.choice(D, k, replace=False)) for k in d] + [np.zeros(0, np.int64)]).astype(np.int64)
+    ids = [f"e{i}" for i in range(E)]
+    table = ModelTable()
+    for c in range(3):
+        own = [i for i in range(E) if i % 4 == c]              # i % 4 == 3: no model
+        pd = rng.integers(0, 10, len(own))
+        pf = np.concatenate([[0], np.cumsum(pd)]).astype(np.int64)
+        pidx = rng.integers(0, D, pf[-1]) if c == 2 else np.concatenate(
+            [np.sort(rng.choice(D, k, replace=False)) for k in pd] + [np.zeros(0, np.int64)]).astype(np.int64)
+        table.add_chunk([ids[i] for i in own], rng.standard_normal(pf[-1] + len(own) * ic), pf + np.arange(len(own) + 1) * ic, pidx, pf)
+    a, ha = _model_coefficients_for_batch(table, ids, uniq, feat_ptr, has_intercept, D, native=False)
+    b, hb = _model_coefficients_for_batch(table, ids, uniq, feat_ptr, has_intercept, D, native=True)
+    assert np.array_equal(ha, hb) and ha.sum() == sum(1 for i in range(E) if i % 4 != 3)
+    np.testing.assert_array_equal(a, b)
+    assert np.count_nonzero(a) > 100
