@@ -110,6 +110,30 @@ def _copy(ptr, count, dtype):
     return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dtype, copy=True)
 
 
+class _BatchOwner:
+    """Keeps a gdmix_io_batch alive for as long as a numpy view of one of its arrays is; frees it afterwards."""
+
+    def __init__(self, lib, handle):
+        self._lib, self._handle = lib, handle
+
+    def __del__(self):
+        if self._handle is not None:
+            self._lib.gdmix_io_free(self._handle)
+            self._handle = None
+
+
+_CTYPE = {np.dtype(np.int64): C.c_int64, np.dtype(np.float32): C.c_float}
+
+
+def _view(owner, ptr, count, dtype):
+    """The library's array as a numpy array without a copy (hundreds of MB per partition); the array holds the owner."""
+    if count == 0:
+        return np.zeros(0, dtype)
+    buf = (_CTYPE[np.dtype(dtype)] * count).from_address(C.addressof(ptr.contents))
+    buf._owner = owner
+    return np.frombuffer(buf, dtype=dtype)
+
+
 def _split_ids(raw, ptr, E):
     """E strings from concatenated UTF-8 bytes + offsets, without a Python-level loop when possible."""
     if E == 0:
@@ -140,21 +164,20 @@ def read_grouped_files(files, entity_name, feature_bag, offset_column_name, uid_
         msg = lib.gdmix_io_last_error().decode("utf-8", "replace")
         # same exception types as the Python reader: schema problems are KeyError / ValueError / AssertionError there
         raise (ValueError if rc in (-3, -4) else GdmixIoError)(f"gdmix_io_read_grouped: {msg}")
-    try:
-        b = out.contents
-        E, N, Z = int(b.E), int(b.N), int(b.Z)
-        idp = _copy(b.ent_id_ptr, E + 1, np.int64)
-        raw_ids = C.string_at(b.ent_id_bytes, int(idp[-1])) if E else b""
-        ids = _split_ids(raw_ids, idp, E)
-        if stats is not None:
-            stats["bytes_read"] = int(b.bytes_read)
-        return RawBatch(ent_row_ptr=_copy(b.ent_row_ptr, E + 1, np.int64), row_nnz_ptr=_copy(b.row_nnz_ptr, N + 1, np.int64),
-                        col_global=_copy(b.col_global, Z, np.int64), val=_copy(b.val, Z, np.float32),
-                        y=_copy(b.y, N, np.float32), offset=_copy(b.offset, N, np.float32),
-                        weight=_copy(b.weight, N, np.float32) if weight_column_name is not None else None,
-                        uid=_copy(b.uid, N, np.int64), entity_ids=ids, has_label=bool(b.has_label))
-    finally:
-        lib.gdmix_io_free(out)
+    owner = _BatchOwner(lib, out)     # freed when the last array view goes away
+    b = out.contents
+    E, N, Z = int(b.E), int(b.N), int(b.Z)
+    idp = _copy(b.ent_id_ptr, E + 1, np.int64)
+    raw_ids = C.string_at(b.ent_id_bytes, int(idp[-1])) if E else b""
+    ids = _split_ids(raw_ids, idp, E)
+    if stats is not None:
+        stats["bytes_read"] = int(b.bytes_read)
+    v = lambda ptr, n, dt: _view(owner, ptr, n, dt)
+    return RawBatch(ent_row_ptr=v(b.ent_row_ptr, E + 1, np.int64), row_nnz_ptr=v(b.row_nnz_ptr, N + 1, np.int64),
+                    col_global=v(b.col_global, Z, np.int64), val=v(b.val, Z, np.float32),
+                    y=v(b.y, N, np.float32), offset=v(b.offset, N, np.float32),
+                    weight=v(b.weight, N, np.float32) if weight_column_name is not None else None,
+                    uid=v(b.uid, N, np.int64), entity_ids=ids, has_label=bool(b.has_label))
 
 
 # ---- Avro writers ------------------------------------------------------------------------------------------

@@ -210,6 +210,7 @@ class RandomEffectLRLBFGSModel:
         self.disable_random_effect_scoring_after_training = self.model_params.disable_random_effect_scoring_after_training
         self._device_index = device
         self._solver = None
+        self._read_cache = None     # (key, batch) of the partition _train decoded last
         self.last_training_stats = None
 
     # ---- Model API (models/api.py) ---------------------------------------------------------------------
@@ -281,11 +282,24 @@ class RandomEffectLRLBFGSModel:
                 i, o = execution_context.get(constants.PASSIVE_TRAINING_DATA_DIR, None), \
                     execution_context.get(constants.PASSIVE_TRAINING_OUTPUT_FILE, None)
                 i and o and predict(i, o)
+            self._read_cache = None
         else:
             raise ValueError(f"Invalid action {action!r}.")
 
     def _read(self, input_path, tensor_metadata, schema_params, num_features, need_label):
         assert self.model_params.data_format == constants.TFRECORD
+        # The active training data is scored right after it was trained on (_action): the partition is decoded once.
+        key = (os.path.abspath(input_path), self.model_params.partition_entity, self.feature_bag_name, num_features)
+        if self._read_cache is not None and self._read_cache[0] == key:
+            batch = self._read_cache[1]
+            self._read_cache = None
+            return batch
+        batch = self._read_files(input_path, tensor_metadata, schema_params, num_features)
+        if need_label:
+            self._read_cache = (key, batch)
+        return batch
+
+    def _read_files(self, input_path, tensor_metadata, schema_params, num_features):
         return read_grouped_partition(
             input_path, tensor_metadata, entity_name=self.model_params.partition_entity,
             feature_bag=self.feature_bag_name, offset_column_name=self.model_params.offset_column_name,
