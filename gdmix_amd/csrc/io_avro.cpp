@@ -20,7 +20,7 @@
 #include <vector>
 
 extern "C" const char* gdmix_io_last_error(void);
-namespace gdmix_io_detail { int set_error(int code, const char* fmt, ...); }
+namespace gdmix_io_detail { int set_error(int code, const char* fmt, ...); int default_threads(); }
 using gdmix_io_detail::set_error;
 
 namespace {
@@ -59,7 +59,7 @@ int write_blocks(const char* path, const uint8_t* header, int64_t header_len, co
   if (!f) return set_error(GDMIX_IO_EIO, "%s: cannot open for writing", path);
   bool ok = fwrite(header, 1, (size_t)header_len, f) == (size_t)header_len;
   const int64_t n_blocks = (total + block_records - 1) / block_records;
-  if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads <= 0) threads = 1; }
+  if (threads <= 0) threads = gdmix_io_detail::default_threads();
   const int64_t round = (int64_t)threads * 4;
   std::vector<std::string> out((size_t)round);
   std::atomic<int> failed{0};
@@ -563,7 +563,7 @@ GDMIX_IO_API int gdmix_io_avro_read_models(const char* path, int64_t data_offset
     fmap[std::string_view((const char*)prefix_bytes + prefix_ptr[g], (size_t)(prefix_ptr[g + 1] - prefix_ptr[g]))] = g;
   const std::string_view icpt((const char*)icpt_enc, (size_t)icpt_len);
   std::vector<ModelBlock> blocks(spans.size());
-  if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads <= 0) threads = 1; }
+  if (threads <= 0) threads = gdmix_io_detail::default_threads();
   std::atomic<size_t> next{0};
   auto work = [&]() {
     std::string plain;
@@ -606,13 +606,15 @@ GDMIX_IO_API int gdmix_io_avro_read_models(const char* path, int64_t data_offset
   m->coef_ptr = (int64_t*)malloc((size_t)(E + 1) * 8);
   m->mean = (double*)malloc((size_t)(Cn ? Cn : 1) * 8);
   m->variance = (double*)malloc((size_t)(Cn ? Cn : 1) * 8);
-  m->feat_idx = (int64_t*)malloc((size_t)(Cn ? Cn : 1) * 8);
+  const int64_t Fn = Cn - (has_intercept ? E : 0);   // every record starts with exactly one intercept
+  m->F = Fn;
+  m->feat_idx = (int64_t*)malloc((size_t)(Fn > 0 ? Fn : 1) * 8);
   m->has_variance = (uint8_t*)malloc((size_t)(E ? E : 1));
   if (!m->id_ptr || !m->id_bytes || !m->coef_ptr || !m->mean || !m->variance || !m->feat_idx || !m->has_variance) {
     gdmix_io_free_models(m);
     return set_error(GDMIX_IO_ENOMEM, "out of memory");
   }
-  int64_t e = 0, cpos = 0, ipos = 0;
+  int64_t e = 0, cpos = 0, ipos = 0, fpos = 0;
   m->id_ptr[0] = 0;
   m->coef_ptr[0] = 0;
   for (const ModelBlock& B : blocks) {
@@ -620,7 +622,8 @@ GDMIX_IO_API int gdmix_io_avro_read_models(const char* path, int64_t data_offset
     if (!B.mean.empty()) {
       memcpy(m->mean + cpos, B.mean.data(), B.mean.size() * 8);
       memcpy(m->variance + cpos, B.var.data(), B.mean.size() * 8);
-      memcpy(m->feat_idx + cpos, B.idx.data(), B.mean.size() * 8);
+      for (const int64_t g : B.idx)
+        if (g >= 0) m->feat_idx[fpos++] = g;
     }
     for (size_t r = 0; r < B.coef_cnt.size(); ++r, ++e) {
       ipos += B.id_len[r];
@@ -654,7 +657,7 @@ extern "C" GDMIX_IO_API int gdmix_io_map_coefficients(int64_t E, const int64_t* 
   if (E < 0 || (E > 0 && (!cur_ptr || !src_row || !prior_coef_ptr || !prior_feat_ptr || !theta)))
     return set_error(GDMIX_IO_EINVAL, "bad argument");
   const int64_t ic = has_intercept ? 1 : 0;
-  if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads <= 0) threads = 1; }
+  if (threads <= 0) threads = gdmix_io_detail::default_threads();
   const int64_t chunk = 4096;
   const int64_t n_chunks = (E + chunk - 1) / chunk;
   std::atomic<int64_t> next{0};

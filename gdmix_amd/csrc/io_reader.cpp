@@ -51,6 +51,17 @@ int set_error(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+// threads <= 0 in the API: the host's cores, at most 32 (one trainer process per GPU shares the host with seven
+// others, and the decode phases stop scaling before that: tools/io_bench.py); GDMIX_IO_THREADS overrides.
+int default_threads() {
+  if (const char* e = getenv("GDMIX_IO_THREADS")) {
+    const int t = atoi(e);
+    if (t > 0) return t;
+  }
+  int t = (int)std::thread::hardware_concurrency();
+  if (t <= 0) t = 1;
+  return t < 32 ? t : 32;
+}
 }  // namespace gdmix_io_detail
 
 namespace {
@@ -690,7 +701,7 @@ GDMIX_IO_API int gdmix_io_read_grouped(const char* const* files, int32_t n_files
   nm.has_bag = sc->feature_bag != nullptr;
   if (nm.has_bag) { nm.bag_idx = std::string(sc->feature_bag) + "_indices"; nm.bag_val = std::string(sc->feature_bag) + "_values"; }
   int threads = sc->threads;
-  if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads <= 0) threads = 1; }
+  if (threads <= 0) threads = gdmix_io_detail::default_threads();
 
   const bool timing = getenv("GDMIX_IO_TIMING") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
@@ -807,7 +818,7 @@ GDMIX_IO_API int gdmix_io_read_examples(const char* const* files, int32_t n_file
   *out = nullptr;
   if (!sc || n_files < 0 || (n_files > 0 && !files) || !sc->uid) return fail(GDMIX_IO_EINVAL, "NULL argument");
   int threads = sc->threads;
-  if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads <= 0) threads = 1; }
+  if (threads <= 0) threads = gdmix_io_detail::default_threads();
   Ctx c;
   c.sc = sc;
   for (int f = 0; f < n_files; ++f) {

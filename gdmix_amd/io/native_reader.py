@@ -46,7 +46,7 @@ class _ModelTable(C.Structure):
 class _Models(C.Structure):
     _fields_ = [("E", C.c_int64), ("C", C.c_int64), ("id_ptr", C.POINTER(C.c_int64)), ("id_bytes", C.POINTER(C.c_char)),
                 ("coef_ptr", C.POINTER(C.c_int64)), ("mean", C.POINTER(C.c_double)), ("variance", C.POINTER(C.c_double)),
-                ("feat_idx", C.POINTER(C.c_int64)), ("has_variance", C.POINTER(C.c_uint8)), ("any_variance", C.c_int32)]
+                ("F", C.c_int64), ("feat_idx", C.POINTER(C.c_int64)), ("has_variance", C.POINTER(C.c_uint8)), ("any_variance", C.c_int32)]
 
 
 _lib = None
@@ -113,16 +113,16 @@ def _copy(ptr, count, dtype):
 class _BatchOwner:
     """Keeps a gdmix_io_batch alive for as long as a numpy view of one of its arrays is; frees it afterwards."""
 
-    def __init__(self, lib, handle):
-        self._lib, self._handle = lib, handle
+    def __init__(self, lib, handle, free=None):
+        self._free, self._handle = free or lib.gdmix_io_free, handle
 
     def __del__(self):
         if self._handle is not None:
-            self._lib.gdmix_io_free(self._handle)
+            self._free(self._handle)
             self._handle = None
 
 
-_CTYPE = {np.dtype(np.int64): C.c_int64, np.dtype(np.float32): C.c_float}
+_CTYPE = {np.dtype(np.int64): C.c_int64, np.dtype(np.float32): C.c_float, np.dtype(np.float64): C.c_double}
 
 
 def _view(owner, ptr, count, dtype):
@@ -291,8 +291,8 @@ def read_example_files(files, feature_bag, num_features, uid_name, label_name=No
 
 
 def read_models_avro(path, data_offset: int, sync: bytes, deflate: bool, prefix, icpt_enc: bytes, has_intercept: bool, threads=0):
-    """Every model record of an Avro container file -> dict(ids, coef_ptr, mean, variance|None, feat_idx (-1 = the
-    intercept), has_variance). prefix: pre-encoded string(name)+string(term) per global feature index. Raises KeyError for
+    """Every model record of an Avro container file -> dict(ids, coef_ptr, mean, variance|None, feat_idx (the
+    non-intercept coefficients' global indices, in order), has_variance). prefix: pre-encoded string(name)+string(term) per global feature index. Raises KeyError for
     a coefficient that is not in the feature list, AssertionError for a misplaced intercept (the reference's errors)."""
     lib = load_library()
     pre_ptr = np.zeros(len(prefix) + 1, np.int64)
@@ -307,16 +307,15 @@ def read_models_avro(path, data_offset: int, sync: bytes, deflate: bool, prefix,
         if rc == -4:
             raise (KeyError if "feature file" in msg else AssertionError)(msg)
         raise (ValueError if rc == -3 else GdmixIoError)(f"gdmix_io_avro_read_models: {msg}")
-    try:
-        m = out.contents
-        E, Cn = int(m.E), int(m.C)
-        id_ptr = _copy(m.id_ptr, E + 1, np.int64)
-        raw = C.string_at(m.id_bytes, int(id_ptr[-1])) if E else b""
-        return dict(ids=_split_ids(raw, id_ptr, E), coef_ptr=_copy(m.coef_ptr, E + 1, np.int64), mean=_copy(m.mean, Cn, np.float64),
-                    variance=_copy(m.variance, Cn, np.float64) if m.any_variance else None,
-                    feat_idx=_copy(m.feat_idx, Cn, np.int64), has_variance=_copy(m.has_variance, E, np.uint8))
-    finally:
-        lib.gdmix_io_free_models(out)
+    owner = _BatchOwner(lib, out, lib.gdmix_io_free_models)
+    m = out.contents
+    E, Cn, Fn = int(m.E), int(m.C), int(m.F)
+    id_ptr = _copy(m.id_ptr, E + 1, np.int64)
+    raw = C.string_at(m.id_bytes, int(id_ptr[-1])) if E else b""
+    v = lambda ptr, n, dt: _view(owner, ptr, n, dt)
+    return dict(ids=_split_ids(raw, id_ptr, E), coef_ptr=v(m.coef_ptr, E + 1, np.int64), mean=v(m.mean, Cn, np.float64),
+                variance=v(m.variance, Cn, np.float64) if m.any_variance else None,
+                feat_idx=v(m.feat_idx, Fn, np.int64), has_variance=_copy(m.has_variance, E, np.uint8))
 
 
 def map_coefficients(theta, cur_ptr, cur_idx, src_row, prior_coef_ptr, prior_feat_ptr, prior_theta, prior_idx, has_intercept, threads=0):

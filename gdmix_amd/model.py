@@ -470,10 +470,8 @@ class RandomEffectLRLBFGSModel:
         if m["ids"]:
             ic = 1 if self.has_intercept else 0
             coef_ptr = m["coef_ptr"]
-            feat = m["feat_idx"]
-            idx = feat[feat >= 0] if ic else feat
             feat_ptr = coef_ptr - np.arange(coef_ptr.size, dtype=np.int64) * ic
-            table.add_chunk(m["ids"], m["mean"], coef_ptr, idx, feat_ptr, m["variance"])
+            table.add_chunk(m["ids"], m["mean"], coef_ptr, m["feat_idx"], feat_ptr, m["variance"])
         return True
 
     @staticmethod

@@ -50,7 +50,8 @@ typedef struct gdmix_io_schema {
   const char* weight;        /* context key, float list [n]; NULL => no weight array                        */
   int64_t num_features;      /* > 0: feature indices must lie in [0, num_features); <= 0: unchecked         */
   int32_t check_crc;         /* verify the masked CRC-32C of every record (length and data)                 */
-  int32_t threads;           /* decode threads; <= 0: one per online CPU                                    */
+  int32_t threads;           /* decode threads; <= 0 (here and in every call below): one per online CPU, at most 32;
+                              * the environment variable GDMIX_IO_THREADS overrides that default            */
 } gdmix_io_schema;
 
 /* Arrays are owned by the library until gdmix_io_free. Entity order = file order, then record order. */
@@ -143,7 +144,7 @@ GDMIX_IO_API int gdmix_io_avro_write_scores(const char* path, const uint8_t* hea
  * the header's sync marker) and checks that the writer schema has the canonical field order; prefix_* is the feature
  * list as pre-encoded string(name) + string(term) (as for gdmix_io_avro_write_models; of equal pairs the last wins,
  * like the reference's dict). has_intercept: the first coefficient of every record must be the intercept
- * (feat_idx -1), everything else must be in the feature list (GDMIX_IO_ESCHEMA otherwise = the reference's
+ * (it carries no feature index), everything else must be in the feature list (GDMIX_IO_ESCHEMA otherwise = the reference's
  * AssertionError / KeyError). A variances array must be empty or line up with means. Blocks are decoded in parallel. */
 typedef struct gdmix_io_models {
   int64_t  E;             /* records, in file order                                            */
@@ -153,7 +154,9 @@ typedef struct gdmix_io_models {
   int64_t* coef_ptr;      /* [E+1] offsets into mean / variance / feat_idx                     */
   double*  mean;          /* [C]                                                               */
   double*  variance;      /* [C] 0 where the record has none                                   */
-  int64_t* feat_idx;      /* [C] global feature index, -1 = the intercept                      */
+  int64_t  F;             /* C - E * has_intercept                                             */
+  int64_t* feat_idx;      /* [F] global feature index of every non-intercept coefficient, in order: record e
+                           * owns feat_idx[coef_ptr[e] - e * has_intercept .. )                            */
   uint8_t* has_variance;  /* [E]                                                               */
   int32_t  any_variance;
 } gdmix_io_models;
