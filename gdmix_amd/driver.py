@@ -86,11 +86,24 @@ class RandomEffectDriver:
                 total = len(f.readline().split(","))
             w = self.execution_context[constants.NUM_WORKERS]
             rounds = (total + w - 1) // w
+        pipelined = hasattr(self.model, "begin_pipeline")
+        if pipelined:
+            self.model.begin_pipeline()
+        try:
+            self._train_rounds(rounds, partition_index_list, lockstep, schema_params, export_model, output_model_dir, pipelined)
+        finally:
+            if pipelined:
+                self.model.end_pipeline()
+
+    def _train_rounds(self, rounds, partition_index_list, lockstep, schema_params, export_model, output_model_dir, pipelined):
         for k in range(rounds):
             if k >= len(partition_index_list):
                 self.model.idle_round()
                 continue
             partition_index = partition_index_list[k]
+            if pipelined and k + 1 < len(partition_index_list):   # decode the next partition while this one is solved
+                self.model.prefetch(self._anchor_directory(self.model.training_data_dir, partition_index_list[k + 1]),
+                                    self.model.metadata_file, schema_params)
             checkpoint_path = self._anchor_directory(self.model.checkpoint_path, partition_index)
             training_data_dir = self._anchor_directory(self.model.training_data_dir, partition_index)
             validation_data_dir = self._anchor_directory(self.model.validation_data_dir, partition_index) \
@@ -101,6 +114,8 @@ class RandomEffectDriver:
                     self.model.idle_round()
                 continue
             self.execution_context[constants.PARTITION_INDEX] = partition_index
+            if pipelined and validation_data_dir:   # decoded while the training data is solved
+                self.model.prefetch(validation_data_dir, self.model.metadata_file, schema_params)
             self.model.train(training_data_dir=training_data_dir, validation_data_dir=validation_data_dir,
                              metadata_file=self.model.metadata_file, checkpoint_path=checkpoint_path,
                              execution_context=self._prepare_training_context(partition_index),

@@ -211,6 +211,9 @@ class RandomEffectLRLBFGSModel:
         self._device_index = device
         self._solver = None
         self._read_cache = None     # (key, batch) of the partition _train decoded last
+        self._io_pool = None        # begin_pipeline(): files are read ahead and written behind the device work
+        self._prefetched = {}       # read key -> Future[RawBatch]
+        self._pending_writes = []
         self.last_training_stats = None
 
     # ---- Model API (models/api.py) ---------------------------------------------------------------------
@@ -286,15 +289,60 @@ class RandomEffectLRLBFGSModel:
         else:
             raise ValueError(f"Invalid action {action!r}.")
 
+    # ---- host pipeline: the driver reads partition k+1 and writes partition k's files while the device works -------
+    def begin_pipeline(self):
+        """From here on prefetch() decodes input in a background thread and the Avro files are written by one; flush()
+        waits for them (and raises what they raised). The native reader / writers release the GIL."""
+        if self._io_pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._io_pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix="gdmix-io")
+
+    def _read_key(self, input_path, num_features):
+        return (os.path.abspath(input_path), self.model_params.partition_entity, self.feature_bag_name, num_features)
+
+    def prefetch(self, input_path, metadata_file, schema_params):
+        """Start decoding the partition a later train() / predict() call will ask for."""
+        if self._io_pool is None or not os.path.isdir(input_path):
+            return
+        tensor_metadata = DatasetMetadata(read_json_file(metadata_file))
+        num_features = 1 if self.feature_bag_name is None else tensor_metadata.get_feature_shape(self.feature_bag_name)[0]
+        key = self._read_key(input_path, num_features)
+        if key not in self._prefetched:
+            self._prefetched[key] = self._io_pool.submit(self._read_files, input_path, tensor_metadata, schema_params, num_features)
+
+    def _write_behind(self, fn, *args, **kwargs):
+        if self._io_pool is None:
+            return fn(*args, **kwargs)
+        self._pending_writes = [f for f in self._pending_writes if not (f.done() and f.exception() is None)]
+        self._pending_writes.append(self._io_pool.submit(fn, *args, **kwargs))
+
+    def flush(self):
+        """Wait for the files still being written; the first failure is raised here."""
+        pending, self._pending_writes = self._pending_writes, []
+        for f in pending:
+            f.result()
+
+    def end_pipeline(self):
+        try:
+            self.flush()
+        finally:
+            for f in self._prefetched.values():
+                f.cancel()
+            self._prefetched = {}
+            if self._io_pool is not None:
+                self._io_pool.shutdown(wait=True)
+                self._io_pool = None
+
     def _read(self, input_path, tensor_metadata, schema_params, num_features, need_label):
         assert self.model_params.data_format == constants.TFRECORD
         # The active training data is scored right after it was trained on (_action): the partition is decoded once.
-        key = (os.path.abspath(input_path), self.model_params.partition_entity, self.feature_bag_name, num_features)
+        key = self._read_key(input_path, num_features)
         if self._read_cache is not None and self._read_cache[0] == key:
             batch = self._read_cache[1]
             self._read_cache = None
             return batch
-        batch = self._read_files(input_path, tensor_metadata, schema_params, num_features)
+        ahead = self._prefetched.pop(key, None)
+        batch = ahead.result() if ahead is not None else self._read_files(input_path, tensor_metadata, schema_params, num_features)
         if need_label:
             self._read_cache = (key, batch)
         return batch
@@ -323,8 +371,8 @@ class RandomEffectLRLBFGSModel:
         # are carried over (random_effect_lr_lbfgs_model.py:155-162).
         model_weights.update(results)
         logger.info(f"{len(model_weights)} models in total after training/refreshing.")
-        self._save_model(output_model_file, model_coefficients=model_weights, num_features=num_features,
-                         feature_file=self.feature_file)
+        self._write_behind(self._save_model, output_model_file, model_coefficients=model_weights, num_features=num_features,
+                           feature_file=self.feature_file)
         return model_weights
 
     _STAT_KEYS = ("nit", "nfev", "status", "fval", "gnorm")
@@ -413,8 +461,8 @@ class RandomEffectLRLBFGSModel:
         logit, per_coord = solver.score(packed, theta, has_model)
         logit, per_coord = logit.cpu().numpy(), per_coord.cpu().numpy()
         weights = batch.weight if batch.weight is not None else np.ones(batch.N, np.float32)
-        _write_scores(output_file, schema, schema_params, batch.uid, logit, batch.y if batch.has_label else None,
-                      weights if has_weight else None, per_coord)
+        self._write_behind(_write_scores, output_file, schema, schema_params, batch.uid, logit, batch.y if batch.has_label else None,
+                           weights if has_weight else None, per_coord)
         logger.info(f"Inference complete: {input_path}.")
 
     def _save_model(self, output_file, model_coefficients, num_features, feature_file):
@@ -428,6 +476,7 @@ class RandomEffectLRLBFGSModel:
 
     def _load_weights(self, model_file, catch_exception=False):
         logger.info(f"Loading model from {model_file}")
+        self.flush()    # the file may be one this process is still writing
         if not os.path.exists(model_file):
             if catch_exception:
                 logger.info(f"No model found at {model_file}.")

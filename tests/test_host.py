@@ -437,3 +437,61 @@ def test_native_coefficient_mapping_equals_the_numpy_one(has_intercept):
     assert np.array_equal(ha, hb) and ha.sum() == sum(1 for i in range(E) if i % 4 != 3)
     np.testing.assert_array_equal(a, b)
     assert np.count_nonzero(a) > 100
+
+
+# ---- host pipeline: read ahead, write behind ------------------------------------------------------------------------
+def _pipeline_job(tmp_path, parts=(0, 1, 2)):
+    import shutil
+    from gdmix_amd.params import Params
+    plist = tmp_path / "plist.txt"
+    plist.write_text(",".join(str(k) for k in parts))
+    for k in parts:
+        for sub in ("data/active", "valid"):
+            d = tmp_path / sub / f"partitionId={k}"
+            os.makedirs(d)
+            shutil.copy(os.path.join(RES, "data.tfrecord"), d / "data.tfrecord")
+    base = Params(uid_column_name="uid", weight_column_name="weight", label_column_name="response",
+                  prediction_score_column_name="predictionScore", action="train", stage="random_effect",
+                  training_score_dir=str(tmp_path / "ts"), validation_score_dir=str(tmp_path / "vs"),
+                  partition_list_file=str(plist))
+    return base, _make_model(tmp_path)
+
+
+def test_driver_pipeline_reads_each_partition_once_and_writes_the_same_files(tmp_path, monkeypatch):
+    monkeypatch.delenv("TF_CONFIG", raising=False)
+    base, model = _pipeline_job(tmp_path)
+    reads = []
+    real = model._read_files
+    monkeypatch.setattr(model, "_read_files", lambda path, *a: reads.append(path) or real(path, *a))
+    RandomEffectDriver(base, model).run_training(SCHEMA)
+    assert model._io_pool is None and not model._pending_writes and not model._prefetched      # pipeline closed, nothing left
+    # training data decoded once per partition (the scoring pass reuses it), validation data once
+    assert sorted(reads) == sorted([str(tmp_path / "data" / "active" / f"partitionId={k}") for k in range(3)] +
+                                   [str(tmp_path / "valid" / f"partitionId={k}") for k in range(3)])
+    # the same job one partition at a time through the synchronous API
+    ref = _make_model(tmp_path)
+    ref.checkpoint_path = str(tmp_path / "models_ref")
+    ref.model_params = ref.model_params.__class__(**{**ref.model_params.__dict__, "output_model_dir": str(tmp_path / "models_ref")})
+    for k in range(3):
+        ctx = {"partition_index": k, "validation_output_file": str(tmp_path / "vs_ref" / f"{k}.avro"),
+               "active_training_output_file": str(tmp_path / "ts_ref" / f"{k}.avro")}
+        ref.train(str(tmp_path / "data" / "active" / f"partitionId={k}"), str(tmp_path / "valid" / f"partitionId={k}"),
+                  ref.metadata_file, None, ctx, SCHEMA)
+        got = list(avro.read_file(str(tmp_path / "models" / f"part-{k:05d}.avro")))
+        assert got == list(avro.read_file(str(tmp_path / "models_ref" / f"part-{k:05d}.avro"))) and len(got) > 0
+        assert list(avro.read_file(str(tmp_path / "ts" / f"partitionId={k}" / "part-00000-active.avro"))) == \
+            list(avro.read_file(str(tmp_path / "ts_ref" / f"{k}.avro")))
+        assert list(avro.read_file(str(tmp_path / "vs" / f"partitionId={k}" / "part-00000.avro"))) == \
+            list(avro.read_file(str(tmp_path / "vs_ref" / f"{k}.avro")))
+
+
+def test_driver_pipeline_raises_what_a_background_write_raised(tmp_path, monkeypatch):
+    monkeypatch.delenv("TF_CONFIG", raising=False)
+    base, model = _pipeline_job(tmp_path, parts=(0, 1))
+
+    def boom(*a, **k):
+        raise OSError("disk full")
+    monkeypatch.setattr(model, "_save_model", boom)
+    with pytest.raises(OSError, match="disk full"):
+        RandomEffectDriver(base, model).run_training(SCHEMA)
+    assert model._io_pool is None
