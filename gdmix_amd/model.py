@@ -310,16 +310,18 @@ class RandomEffectLRLBFGSModel:
         if key not in self._prefetched:
             self._prefetched[key] = self._io_pool.submit(self._read_files, input_path, tensor_metadata, schema_params, num_features)
 
-    def _write_behind(self, fn, *args, **kwargs):
+    def _write_behind(self, path, fn, *args, **kwargs):
         if self._io_pool is None:
             return fn(*args, **kwargs)
-        self._pending_writes = [f for f in self._pending_writes if not (f.done() and f.exception() is None)]
-        self._pending_writes.append(self._io_pool.submit(fn, *args, **kwargs))
+        self._pending_writes = [(p, f) for p, f in self._pending_writes if not (f.done() and f.exception() is None)]
+        self._pending_writes.append((os.path.abspath(path), self._io_pool.submit(fn, *args, **kwargs)))
 
-    def flush(self):
-        """Wait for the files still being written; the first failure is raised here."""
-        pending, self._pending_writes = self._pending_writes, []
-        for f in pending:
+    def flush(self, path=None):
+        """Wait for the files still being written (only `path` if given); the first failure is raised here."""
+        path = None if path is None else os.path.abspath(path)
+        wait = [(p, f) for p, f in self._pending_writes if path is None or p == path]
+        self._pending_writes = [(p, f) for p, f in self._pending_writes if not (path is None or p == path)]
+        for _, f in wait:
             f.result()
 
     def end_pipeline(self):
@@ -344,7 +346,7 @@ class RandomEffectLRLBFGSModel:
         ahead = self._prefetched.pop(key, None)
         batch = ahead.result() if ahead is not None else self._read_files(input_path, tensor_metadata, schema_params, num_features)
         if need_label:
-            self._read_cache = (key, batch)
+            self._read_cache = [key, batch, None, None]   # _train adds the packed batch and the coefficients it found
         return batch
 
     def _read_files(self, input_path, tensor_metadata, schema_params, num_features):
@@ -361,17 +363,19 @@ class RandomEffectLRLBFGSModel:
         batch = self._read(input_path, tensor_metadata, schema_params, num_features, need_label=True)
         if not batch.has_label:
             raise KeyError(f"label column {schema_params.label_column_name!r} is missing from the training data")
-        theta_thr, variance, uniq, feat_ptr, stats = self._solve_batch(batch, model_weights, num_features)
+        theta_thr, variance, uniq, feat_ptr, stats, packed = self._solve_batch(batch, model_weights, num_features)
         ic = 1 if self.has_intercept else 0
         coef_ptr = feat_ptr + np.arange(batch.E + 1, dtype=np.int64) * ic
         self.last_training_stats = dict(entities=batch.E, samples=batch.N, nnz=batch.Z, **stats)
         results = ModelTable()
         results.add_chunk(batch.entity_ids, theta_thr, coef_ptr, uniq, feat_ptr, variance)
+        if self._read_cache is not None and self._read_cache[1] is batch and packed is not None and len(results) == batch.E:
+            self._read_cache[2:] = [packed, theta_thr]     # (an entity id listed twice is scored with its later model: no shortcut)
         # The trained model is updated over the prior model: prior entities that are not in the current data
         # are carried over (random_effect_lr_lbfgs_model.py:155-162).
         model_weights.update(results)
         logger.info(f"{len(model_weights)} models in total after training/refreshing.")
-        self._write_behind(self._save_model, output_model_file, model_coefficients=model_weights, num_features=num_features,
+        self._write_behind(output_model_file, self._save_model, output_model_file, model_coefficients=model_weights, num_features=num_features,
                            feature_file=self.feature_file)
         return model_weights
 
@@ -403,6 +407,7 @@ class RandomEffectLRLBFGSModel:
         opts = self._solver_options()
         rb = None
         work = batch
+        packed = None
         if self._rebalancing(model_weights):
             from .rebalance import Rebalancer
             rb = Rebalancer(batch)
@@ -430,7 +435,7 @@ class RandomEffectLRLBFGSModel:
             coef_cnt, theta_thr, variance, feat_cnt, uniq, st = rb.give_back(feat_cnt + ic, theta_thr, variance, feat_cnt, uniq, stats)
             feat_ptr = np.concatenate([[0], np.cumsum(feat_cnt)]).astype(np.int64)
             stats = {k: (st[k].astype(np.int32) if k in ("nit", "nfev", "status") else st[k]) for k in self._STAT_KEYS}
-        return theta_thr, variance, uniq, feat_ptr, stats
+        return theta_thr, variance, uniq, feat_ptr, stats, (packed if rb is None else None)
 
     def idle_round(self, num_features=1):
         """A rank without a partition in this round still takes part in the re-balancing collectives (and solves what
@@ -446,22 +451,31 @@ class RandomEffectLRLBFGSModel:
 
     def _predict(self, input_path, tensor_metadata, output_file, schema_params, num_features, model_weights):
         logger.info(f"Start inference for {input_path}.")
-        batch = self._read(input_path, tensor_metadata, schema_params, num_features, need_label=False)
+        packed = theta = has_model = None
+        cache = self._read_cache
+        if cache is not None and cache[0] == self._read_key(input_path, num_features) and cache[2] is not None:
+            # The partition that was just trained on: still packed on the device, and every entity's model is the one the
+            # solve returned (thresholded, as saved) - what the table lookup below would reproduce coefficient by coefficient.
+            _, batch, packed, theta = cache
+            self._read_cache = None
+        else:
+            batch = self._read(input_path, tensor_metadata, schema_params, num_features, need_label=False)
         has_weight = any(schema_params.weight_column_name == f.name for f in tensor_metadata.get_features())
         schema = avro.inference_output_schema(schema_params, has_weight=has_weight)
         if batch.E == 0:
             avro.write_file(output_file, schema, [])
             return
         solver = self._get_solver()
-        packed = solver.pack(batch, has_intercept=self.has_intercept)
-        feat_ptr = packed.ent_feat_ptr().cpu().numpy()
-        uniq = packed.unique_global().cpu().numpy()
-        theta, has_model = _model_coefficients_for_batch(model_weights, batch.entity_ids, uniq, feat_ptr,
-                                                         self.has_intercept, num_features)
+        if packed is None:
+            packed = solver.pack(batch, has_intercept=self.has_intercept)
+            feat_ptr = packed.ent_feat_ptr().cpu().numpy()
+            uniq = packed.unique_global().cpu().numpy()
+            theta, has_model = _model_coefficients_for_batch(model_weights, batch.entity_ids, uniq, feat_ptr,
+                                                             self.has_intercept, num_features)
         logit, per_coord = solver.score(packed, theta, has_model)
         logit, per_coord = logit.cpu().numpy(), per_coord.cpu().numpy()
         weights = batch.weight if batch.weight is not None else np.ones(batch.N, np.float32)
-        self._write_behind(_write_scores, output_file, schema, schema_params, batch.uid, logit, batch.y if batch.has_label else None,
+        self._write_behind(output_file, _write_scores, output_file, schema, schema_params, batch.uid, logit, batch.y if batch.has_label else None,
                            weights if has_weight else None, per_coord)
         logger.info(f"Inference complete: {input_path}.")
 
@@ -476,7 +490,7 @@ class RandomEffectLRLBFGSModel:
 
     def _load_weights(self, model_file, catch_exception=False):
         logger.info(f"Loading model from {model_file}")
-        self.flush()    # the file may be one this process is still writing
+        self.flush(model_file)    # it may be a file this process is still writing
         if not os.path.exists(model_file):
             if catch_exception:
                 logger.info(f"No model found at {model_file}.")
