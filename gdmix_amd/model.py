@@ -213,6 +213,7 @@ class RandomEffectLRLBFGSModel:
         self._read_cache = None     # (key, batch) of the partition _train decoded last
         self._io_pool = None        # begin_pipeline(): files are read ahead and written behind the device work
         self._prefetched = {}       # read key -> Future[RawBatch]
+        self._prefetched_models = {}   # model file -> Future[ModelTable]
         self._pending_writes = []
         self.last_training_stats = None
 
@@ -295,7 +296,7 @@ class RandomEffectLRLBFGSModel:
         waits for them (and raises what they raised). The native reader / writers release the GIL."""
         if self._io_pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            self._io_pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix="gdmix-io")
+            self._io_pool = ThreadPoolExecutor(max_workers=3, thread_name_prefix="gdmix-io")
 
     def _read_key(self, input_path, num_features):
         return (os.path.abspath(input_path), self.model_params.partition_entity, self.feature_bag_name, num_features)
@@ -309,6 +310,14 @@ class RandomEffectLRLBFGSModel:
         key = self._read_key(input_path, num_features)
         if key not in self._prefetched:
             self._prefetched[key] = self._io_pool.submit(self._read_files, input_path, tensor_metadata, schema_params, num_features)
+
+    def prefetch_prior_model(self, partition_index):
+        """Start loading the model file train() will warm-start partition `partition_index` from, if there is one."""
+        model_file = os.path.abspath(os.path.join(self.model_params.output_model_dir, f"part-{partition_index:05d}.avro"))
+        if self._io_pool is None or not os.path.exists(model_file) or model_file in self._prefetched_models:
+            return
+        self.flush(model_file)
+        self._prefetched_models[model_file] = self._io_pool.submit(self._load_weights_from, model_file)
 
     def _write_behind(self, path, fn, *args, **kwargs):
         if self._io_pool is None:
@@ -328,9 +337,9 @@ class RandomEffectLRLBFGSModel:
         try:
             self.flush()
         finally:
-            for f in self._prefetched.values():
+            for f in list(self._prefetched.values()) + list(self._prefetched_models.values()):
                 f.cancel()
-            self._prefetched = {}
+            self._prefetched, self._prefetched_models = {}, {}
             if self._io_pool is not None:
                 self._io_pool.shutdown(wait=True)
                 self._io_pool = None
@@ -490,12 +499,18 @@ class RandomEffectLRLBFGSModel:
 
     def _load_weights(self, model_file, catch_exception=False):
         logger.info(f"Loading model from {model_file}")
+        ahead = self._prefetched_models.pop(os.path.abspath(model_file), None)
+        if ahead is not None:
+            return ahead.result()
         self.flush(model_file)    # it may be a file this process is still writing
         if not os.path.exists(model_file):
             if catch_exception:
                 logger.info(f"No model found at {model_file}.")
                 return ModelTable()
             raise FileNotFoundError(f"Model file {model_file} does not exist")
+        return self._load_weights_from(model_file)
+
+    def _load_weights_from(self, model_file):
         table = ModelTable()
         if self.feature_file is not None and native_reader.available():
             loaded = self._load_weights_native(model_file, table)

@@ -485,6 +485,27 @@ def test_driver_pipeline_reads_each_partition_once_and_writes_the_same_files(tmp
             list(avro.read_file(str(tmp_path / "vs_ref" / f"{k}.avro")))
 
 
+def test_driver_pipeline_warm_start_loads_the_next_prior_model_ahead(tmp_path, monkeypatch):
+    monkeypatch.delenv("TF_CONFIG", raising=False)
+    base, model = _pipeline_job(tmp_path)
+    RandomEffectDriver(base, model).run_training(SCHEMA)
+    first = {k: list(avro.read_file(str(tmp_path / "models" / f"part-{k:05d}.avro"))) for k in range(3)}
+    ahead = []
+    real = model.prefetch_prior_model
+    monkeypatch.setattr(model, "prefetch_prior_model", lambda k: ahead.append(k) or real(k))
+    loads = []
+    real_load = model._load_weights_from
+    monkeypatch.setattr(model, "_load_weights_from", lambda f: loads.append(os.path.basename(f)) or real_load(f))
+    RandomEffectDriver(base, model).run_training(SCHEMA)
+    assert ahead == [1, 2] and sorted(loads) == [f"part-{k:05d}.avro" for k in range(3)]      # each prior model read once
+    assert model.last_training_stats["nit"].max() <= 1                                          # warm start at the optimum
+    for k in range(3):
+        again = list(avro.read_file(str(tmp_path / "models" / f"part-{k:05d}.avro")))
+        assert [r["modelId"] for r in again] == [r["modelId"] for r in first[k]]
+        for a, b in zip(again, first[k]):
+            np.testing.assert_allclose([c["value"] for c in a["means"]], [c["value"] for c in b["means"]], rtol=1e-6)
+
+
 def test_driver_pipeline_raises_what_a_background_write_raised(tmp_path, monkeypatch):
     monkeypatch.delenv("TF_CONFIG", raising=False)
     base, model = _pipeline_job(tmp_path, parts=(0, 1))
