@@ -432,7 +432,7 @@ GDMIX_API int gdmix_re_score(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int ha
   if (!theta && !has_model) { set_error("theta is NULL"); return GDMIX_RE_EINVAL; }
   HIP_TRY(hipSetDevice(ctx->impl.device));
   BatchDev B = make_batch_dev(b);
-  HIP_TRY(launch_score(B, b->E, has_intercept ? 1 : 0, theta, has_model, logit, logit_per_coord,
+  HIP_TRY(launch_score(B, b->E, b->N, has_intercept ? 1 : 0, theta, has_model, logit, logit_per_coord,
                        static_cast<hipStream_t>(stream)));
   return GDMIX_RE_OK;
 }

@@ -139,7 +139,7 @@ hipError_t launch_variance_full(const BatchDev& B, int64_t E, const SolveParams&
                                 double* scratch, size_t slot_doubles, int slots, int64_t max_p, hipStream_t s);
 constexpr int64_t VAR_FULL_MAX_P = 2048;   // FULL variance densifies p x p (as the reference does)
 inline size_t var_full_slot_doubles(int64_t max_p) { return (size_t)2 * max_p * max_p + max_p + 8; }
-hipError_t launch_score(const BatchDev& B, int64_t E, int ic, const double* theta, const uint8_t* has_model,
+hipError_t launch_score(const BatchDev& B, int64_t E, int64_t N, int ic, const double* theta, const uint8_t* has_model,
                         float* logit, float* per_coord, hipStream_t s);
 
 // pack (re_pack.hip)

@@ -6,7 +6,7 @@
 //   re_solve_block_kernel                  one 256-thread workgroup per entity for blocks that do not
 //                                          fit the LDS budget: X streams from HBM/L2 every evaluation,
 //                                          L-BFGS state lives in a per-workgroup global scratch slot
-//   re_score_kernel                        logits X~theta + offset
+//   re_score_kernel                        logits X~theta + offset, one thread per sample
 #include "re_internal.hpp"
 #include "re_solve_team.hpp"
 
@@ -880,43 +880,87 @@ hipError_t launch_variance_full(const BatchDev& B, int64_t E, const SolveParams&
 }
 
 // ---------------------------------------------------------------------------------------------------
-// scoring: one wavefront per entity, lane per sample  (job_consumers.py:138-152)
+// scoring: logits of every sample of the batch  (job_consumers.py:138-152, binary_logistic_regression.py:241-262)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void re_score_kernel(BatchDev B, int64_t E, int ic, const double* __restrict__ theta,
+// One thread per sample over the whole batch, whatever the entity sizes are (a Zipf partition has entities of one
+// sample and of a million): a pure streaming pass, bound by HBM. The entity of a sample is found by bisection of
+// ent_row_ptr — the wavefront's first and last sample by a 64-way search of the whole wavefront, each lane then within
+// that range, which is a handful of entities or a single one. Adjacent lanes read adjacent rows, so the (value, column)
+// loads of a wavefront fall on consecutive cache lines; the coefficient gathers of an entity stay in L1/L2.
+
+// largest e in [lo, hi] with ptr[e] <= g (ptr[lo] <= g)
+__device__ __forceinline__ int64_t entity_of_sample(const int64_t* __restrict__ ptr, int64_t lo, int64_t hi, int64_t g) {
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if (ptr[mid] <= g) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// The same by a whole wavefront (uniform arguments, all lanes active): 64 probes per step instead of one, so a
+// million entities take four dependent loads instead of twenty.
+__device__ __forceinline__ int64_t wave_entity_of_sample(const int64_t* __restrict__ ptr, int64_t lo, int64_t hi, int64_t g, int lane) {
+  while (lo < hi) {
+    const int64_t step = (hi - lo + WAVE - 1) / WAVE;
+    const int64_t probe = lo + (int64_t)(lane + 1) * step;
+    const bool le = ptr[probe < hi ? probe : hi] <= g;     // non-decreasing in the lane index
+    const int c = __popcll(__ballot(le));
+    const int64_t below = lo + (int64_t)c * step;           // last probe that is <= g (lo itself when c == 0)
+    const int64_t above = lo + (int64_t)(c + 1) * step;     // first probe that is > g
+    const int64_t nhi = (c < WAVE && above <= hi) ? above - 1 : hi;
+    lo = below < hi ? below : hi;
+    hi = (c == WAVE) ? lo : nhi;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void re_score_kernel(BatchDev B, int64_t E, int64_t N, int ic, const double* __restrict__ theta,
                                                        const uint8_t* __restrict__ has_model,
                                                        float* __restrict__ logit, float* __restrict__ per_coord) {
   const int lane = threadIdx.x & (WAVE - 1);
-  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t e = wave0; e < E; e += nwaves) {
-    const int64_t r0 = B.ent_row_ptr[e], z0 = B.ent_nnz_ptr[e];
-    const int n = (int)(B.ent_row_ptr[e + 1] - r0);
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t gf = g - lane;
+  if (gf >= N) return;
+  const int64_t gl = (gf + WAVE - 1 < N) ? gf + WAVE - 1 : N - 1;
+  const int64_t e_lo = wave_entity_of_sample(B.ent_row_ptr, 0, E - 1, gf, lane);
+  const int64_t w_hi = (e_lo + WAVE < E) ? e_lo + WAVE : E - 1;   // 64 samples span at most 64 non-empty entities
+  const int64_t e_hi = wave_entity_of_sample(B.ent_row_ptr, e_lo, (B.ent_row_ptr[w_hi] > gl) ? w_hi : E - 1, gl, lane);
+  if (g >= N) return;
+  const int64_t e = entity_of_sample(B.ent_row_ptr, e_lo, e_hi, g);
+  const int64_t r0 = B.ent_row_ptr[e], z0 = B.ent_nnz_ptr[e];
+  const double off = (double)B.offset[g];
+  const bool model = has_model ? has_model[e] != 0 : true;
+  double z = off;
+  if (model) {
     const int64_t c0 = B.ent_feat_ptr[e] + e * ic;
-    const bool model = has_model ? has_model[e] != 0 : true;
-    const int32_t* rp = B.row_ptr + r0 + e;
-    const double x0 = (ic && model) ? theta[c0] : 0.0;
-    for (int i = lane; i < n; i += WAVE) {
-      const double off = (double)B.offset[r0 + i];
-      double z;
-      if (model) {
-        double acc = x0;
-        for (int k = rp[i]; k < rp[i + 1]; ++k) acc += (double)B.csr_val[z0 + k] * theta[c0 + ic + B.csr_col[z0 + k]];
-        z = acc + off;
-      } else {
-        z = off;
-      }
-      logit[r0 + i] = (float)z;
-      per_coord[r0 + i] = (float)(z - off);
+    const int32_t* rp = B.row_ptr + r0 + e + (g - r0);
+    const int k0 = rp[0], k1 = rp[1];
+    const float* __restrict__ val = B.csr_val + z0;
+    const int32_t* __restrict__ col = B.csr_col + z0;
+    const double* __restrict__ th = theta + c0 + ic;
+    double acc = ic ? theta[c0] : 0.0;
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {   // four gathers in flight; the sum keeps the row's order
+      const float v0 = val[k], v1 = val[k + 1], v2 = val[k + 2], v3 = val[k + 3];
+      const double t0 = th[col[k]], t1 = th[col[k + 1]], t2 = th[col[k + 2]], t3 = th[col[k + 3]];
+      acc += (double)v0 * t0;
+      acc += (double)v1 * t1;
+      acc += (double)v2 * t2;
+      acc += (double)v3 * t3;
     }
+    for (; k < k1; ++k) acc += (double)val[k] * th[col[k]];
+    z = acc + off;
   }
+  logit[g] = (float)z;
+  per_coord[g] = (float)(z - off);
 }
 
-hipError_t launch_score(const BatchDev& B, int64_t E, int ic, const double* theta, const uint8_t* has_model,
+hipError_t launch_score(const BatchDev& B, int64_t E, int64_t N, int ic, const double* theta, const uint8_t* has_model,
                         float* logit, float* per_coord, hipStream_t s) {
-  if (E <= 0) return hipSuccess;
-  int64_t blocks = (E + 3) / 4;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(re_score_kernel, dim3((int)blocks), dim3(256), 0, s, B, E, ic, theta, has_model, logit, per_coord);
+  if (E <= 0 || N <= 0) return hipSuccess;
+  const int64_t blocks = (N + 255) / 256;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(re_score_kernel, dim3((unsigned)blocks), dim3(256), 0, s, B, E, N, ic, theta, has_model, logit, per_coord);
   return hipGetLastError();
 }
 

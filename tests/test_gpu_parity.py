@@ -233,6 +233,32 @@ def test_score_matches_reference_inference(device_solver):
     np.testing.assert_allclose(logit, lo, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", ["ragged", "zipf", "single_giant", "tiny"])
+@pytest.mark.parametrize("has_intercept", [True, False])
+def test_score_any_entity_sizes_matches_oracle(device_solver, shape, has_intercept):
+    """The scoring pass is one thread per sample over the whole batch: entities of one sample next to entities of a
+    hundred thousand, empty rows, entities without a model — against the CPU restatement, to float rounding."""
+    from gdmix_amd import synthetic
+    if shape == "ragged":
+        b = synthetic.make_ragged_batch(5000, seed=21)
+    elif shape == "zipf":
+        b = synthetic.make_batch(3000, 32, 8, 65536, seed=5, size_dist="zipf", with_uid=False)
+    elif shape == "single_giant":
+        b = synthetic.make_batch(1, 100001, 8, 4096, seed=6, size_dist="const")
+    else:
+        b = synthetic.make_batch(3, 1, 2, 16, seed=7, size_dist="const")
+    packed = device_solver.pack(b, has_intercept=has_intercept)
+    pk = oracle.pack(b.ent_row_ptr, b.row_nnz_ptr, b.col_global)
+    rng = np.random.default_rng(8)
+    theta = rng.standard_normal(int(packed.P))
+    has_model = (rng.random(b.E) < 0.8).astype(np.uint8)
+    for hm in (None, has_model):
+        logit, per = device_solver.score(packed, theta, hm)
+        lo, po = oracle.score(pk, b.val, b.offset, theta, has_intercept, hm)
+        np.testing.assert_allclose(logit.cpu().numpy(), lo.astype(np.float32), rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(per.cpu().numpy(), po.astype(np.float32), rtol=2e-5, atol=2e-5)
+
+
 def test_partition_ids_bit_exact(device_solver):
     rng = np.random.default_rng(0)
     ids = np.concatenate([rng.integers(-2**62, 2**62, size=5000), np.arange(-50, 2000),
