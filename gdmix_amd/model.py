@@ -123,6 +123,39 @@ class ModelTable:
         variance = np.concatenate([ch["variance"] for ch in self._chunks if ch["variance"] is not None]) if any_var else None
         return ids, coef_beg, coef_cnt, var_beg, feat_beg, mean, variance, idx
 
+    def rows_for(self, ids):
+        """The models of `ids` as flat arrays in that order: dict(has [E] bool, coef_ptr [E+1], theta, feat_ptr [E+1], idx);
+        an id without a model has empty slices."""
+        from .batch import _ranges
+        E = len(ids)
+        found, chunk, row = self.lookup(ids)
+        cc = np.zeros(E, np.int64); fc = np.zeros(E, np.int64)
+        cs = np.zeros(E, np.int64); fs = np.zeros(E, np.int64)
+        co = fo = 0
+        for c, ch in enumerate(self._chunks):
+            sel = np.flatnonzero(found & (chunk == c))
+            if sel.size:
+                r = row[sel]
+                cc[sel] = ch["coef_ptr"][r + 1] - ch["coef_ptr"][r]
+                fc[sel] = ch["feat_ptr"][r + 1] - ch["feat_ptr"][r]
+                cs[sel] = co + ch["coef_ptr"][r]
+                fs[sel] = fo + ch["feat_ptr"][r]
+            co += len(ch["theta"]); fo += len(ch["idx"])
+        theta = np.concatenate([ch["theta"] for ch in self._chunks]) if self._chunks else np.zeros(0)
+        idx = np.concatenate([ch["idx"] for ch in self._chunks]) if self._chunks else np.zeros(0, np.int64)
+        return dict(has=found, coef_ptr=np.concatenate([[0], np.cumsum(cc)]).astype(np.int64), theta=theta[_ranges(cs, cc)],
+                    feat_ptr=np.concatenate([[0], np.cumsum(fc)]).astype(np.int64), idx=idx[_ranges(fs, fc)])
+
+    @classmethod
+    def from_rows(cls, ids, rows):
+        """Inverse of rows_for: a table of the ids that have a model."""
+        t = cls()
+        t._chunks.append(dict(theta=np.asarray(rows["theta"], np.float64), variance=None, idx=np.asarray(rows["idx"], np.int64),
+                              coef_ptr=np.asarray(rows["coef_ptr"], np.int64), feat_ptr=np.asarray(rows["feat_ptr"], np.int64)))
+        for r in np.flatnonzero(rows["has"]):
+            t._where[ids[int(r)]] = (0, int(r))
+        return t
+
     def lookup(self, ids):
         """Vectorised: for every id, (found mask, chunk index, row)."""
         found = np.zeros(len(ids), bool)
@@ -391,22 +424,20 @@ class RandomEffectLRLBFGSModel:
     _STAT_KEYS = ("nit", "nfev", "status", "fval", "gnorm")
 
     def _rebalancing(self, model_weights):
-        """Entities travel between ranks only when asked for, in a multi-rank job, and for a cold start (a prior model
-        lives on the rank that owns the partition). Collective: every rank reaches the same decision."""
+        """-> (entities travel between ranks this round, prior models travel with them). Only when asked for and in a
+        multi-rank job. Collective: every rank reaches the same decision; a prior model on any rank makes all ranks
+        exchange prior models (a warm start needs the coefficients where the entity is solved)."""
         if not self.model_params.rebalance_entities:
-            return False
+            return False, False
         try:
             import torch.distributed as dist
         except ImportError:
-            return False
+            return False, False
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-            return False
+            return False, False
         flags = [None] * dist.get_world_size()
         dist.all_gather_object(flags, bool(model_weights))
-        if any(flags):
-            logger.info("a prior model is present on some worker: entities stay on the worker that owns their partition")
-            return False
-        return True
+        return True, any(flags)
 
     def _solve_batch(self, batch, model_weights, num_features):
         """-> thresholded coefficients, variances|None, global feature index per coefficient, feat_ptr, solver statistics
@@ -417,10 +448,14 @@ class RandomEffectLRLBFGSModel:
         rb = None
         work = batch
         packed = None
-        if self._rebalancing(model_weights):
+        rebalance, with_prior = self._rebalancing(model_weights)
+        if rebalance:
             from .rebalance import Rebalancer
             rb = Rebalancer(batch)
-            work = rb.exchange()
+            prior = model_weights.rows_for(batch.entity_ids) if (with_prior and model_weights) else None
+            work = rb.exchange(prior=prior, with_prior=with_prior)
+            if with_prior:   # the models of the entities solved here, wherever they came from
+                model_weights = ModelTable.from_rows(work.entity_ids, rb.work_prior)
             logger.info(f"re-balancing: loads {rb.loads.tolist()}, sent {[int(x.size) for x in rb.sent]}, "
                         f"received {rb.recv_counts}, solving {work.E} entities here")
         ic = 1 if self.has_intercept else 0

@@ -12,6 +12,8 @@ partition, which writes the model file. One round per partition step, all ranks 
   3. one all_to_all of the raw ragged arrays of the travelling entities (three flat buffers: int64, float32, id
      bytes); on the GPU box the tensors live in HBM and the collective is RCCL over xGMI (direct, non-ring
      all-to-all: 7 links per GPU), in the tests it is gloo on CPU;
+     with a warm start the prior models of the travelling entities go with them (coefficient counts, global
+     feature indices, coefficients: one more int64 and one float64 all_to_all);
   4. every rank solves its kept + received entities as one batch;
   5. one all_to_all back: coefficient counts, coefficients, variances, feature indices, solver statistics of the
      foreign entities; the owner splices them into its results in the original entity order.
@@ -164,7 +166,10 @@ class Rebalancer:
         self.kept = None
         self.recv_counts = None
 
-    def exchange(self) -> RawBatch:
+    def exchange(self, prior=None, with_prior=False) -> RawBatch:
+        """with_prior (the same on every rank): prior models travel too. prior = dict(has [E] bool, coef_ptr [E+1],
+        theta, feat_ptr [E+1], idx) for this rank's batch in entity order (None = no entity has one); afterwards
+        self.work_prior is the same structure for the returned batch."""
         c = self.comm
         loads = c.all_gather_floats(self.cost.sum())
         self.loads = loads
@@ -195,10 +200,48 @@ class Rebalancer:
             for p in parts:
                 if p.weight is None:
                     p.weight = np.ones(p.N, np.float32)
+        self.work_prior = None
+        if with_prior:
+            self.work_prior = self._exchange_prior(prior)
         parts = [p for p in parts if p.E] or [parts[0]]
         self.work = concat(parts) if len(parts) > 1 else parts[0]
         self.work_has_label = all(p.has_label for p in parts)
         return self.work
+
+    def _exchange_prior(self, prior):
+        """Prior models of the kept entities followed by those received, origin ranks in rank order (= the entity order
+        of the batch exchange() returns)."""
+        from .batch import _ranges
+        c = self.comm
+        E = self.batch.E
+        if prior is None:
+            prior = dict(has=np.zeros(E, bool), coef_ptr=np.zeros(E + 1, np.int64), theta=np.zeros(0), feat_ptr=np.zeros(E + 1, np.int64),
+                         idx=np.zeros(0, np.int64))
+        has = np.asarray(prior["has"], bool)
+        cp, fp = np.asarray(prior["coef_ptr"], np.int64), np.asarray(prior["feat_ptr"], np.int64)
+        th, ix = np.asarray(prior["theta"], np.float64), np.asarray(prior["idx"], np.int64)
+
+        def rows(sel):
+            cc, fc = np.diff(cp)[sel], np.diff(fp)[sel]
+            return has[sel].astype(np.int64), cc, fc, th[_ranges(cp[sel], cc)], ix[_ranges(fp[sel], fc)]
+        i_parts, f_parts = [], []
+        for sel in self.sent:
+            h, cc, fc, t, i = rows(sel)
+            i_parts.append(np.concatenate([h, cc, fc, i]) if sel.size else np.zeros(0, np.int64))
+            f_parts.append(t if sel.size else np.zeros(0, np.float64))
+        ri = c.all_to_all(i_parts, np.int64)
+        rf = c.all_to_all(f_parts, np.float64)
+        hs, ccs, fcs, ths, ixs = [[x] for x in rows(self.kept)]
+        for j in range(c.world):
+            n = self.recv_counts[j]
+            if n == 0:
+                continue
+            ii = ri[j]
+            hs.append(ii[:n]); ccs.append(ii[n:2 * n]); fcs.append(ii[2 * n:3 * n]); ixs.append(ii[3 * n:]); ths.append(rf[j])
+        cc, fc = np.concatenate(ccs), np.concatenate(fcs)
+        return dict(has=np.concatenate(hs).astype(bool), coef_ptr=np.concatenate([[0], np.cumsum(cc)]).astype(np.int64),
+                    theta=np.concatenate(ths).astype(np.float64), feat_ptr=np.concatenate([[0], np.cumsum(fc)]).astype(np.int64),
+                    idx=np.concatenate(ixs).astype(np.int64))
 
     def give_back(self, coef_cnt, theta, variance, feat_cnt, feat_idx, stats=None):
         """Per-entity results of the batch returned by exchange(), in its entity order:
@@ -238,15 +281,26 @@ class Rebalancer:
             f64_parts.append(np.concatenate(flts))
         ri = c.all_to_all(i64_parts, np.int64)
         rf = c.all_to_all(f64_parts, np.float64)
-        # assemble my batch's results in original entity order
+        # assemble my batch's results in original entity order: every source (kept here, returned by rank j) is appended
+        # to a pool, every entity remembers where its slice of the pool starts
+        from .batch import _ranges
         E = self.batch.E
+        theta = np.asarray(theta, np.float64)
+        feat_idx = np.asarray(feat_idx, np.int64)
         my_coef = np.zeros(E, np.int64)
         my_feat = np.zeros(E, np.int64)
-        pieces = {}   # entity index -> (theta, var, idx, stats...)
-        for pos, e in enumerate(self.kept):
-            pieces[int(e)] = (theta[cptr[pos]:cptr[pos + 1]], None if variance is None else variance[cptr[pos]:cptr[pos + 1]],
-                              np.asarray(feat_idx)[fptr[pos]:fptr[pos + 1]], {k: stats[k][pos] for k in skeys})
+        c_start = np.zeros(E, np.int64)
+        f_start = np.zeros(E, np.int64)
         any_var = variance is not None
+        th_pool, fi_pool, va_pool = [theta[:cptr[nk]]], [feat_idx[:fptr[nk]]], [None if variance is None else np.asarray(variance, np.float64)[:cptr[nk]]]
+        st_out = {k: np.zeros(E, np.float64) for k in skeys}
+        my_coef[self.kept] = coef_cnt[:nk]
+        my_feat[self.kept] = feat_cnt[:nk]
+        c_start[self.kept] = cptr[:nk]
+        f_start[self.kept] = fptr[:nk]
+        for k in skeys:
+            st_out[k][self.kept] = np.asarray(stats[k], np.float64)[:nk]
+        c_base, f_base = int(cptr[nk]), int(fptr[nk])
         for j in range(c.world):
             ix = self.sent[j]
             if ix.size == 0:
@@ -256,32 +310,25 @@ class Rebalancer:
             assert n == ix.size, "result count differs from the entities sent"
             cc = ii[2:2 + n]; fc = ii[2 + n:2 + 2 * n]; fi = ii[2 + 2 * n:]
             tot = int(cc.sum())
-            th = ff[:tot]
             q = tot
             va = None
             if hv:
                 va = ff[q:q + tot]; q += tot
                 any_var = True
-            st = {}
             for k in skeys:
-                st[k] = ff[q:q + n]; q += n
-            cp = np.concatenate([[0], np.cumsum(cc)])
-            fp = np.concatenate([[0], np.cumsum(fc)])
-            for t_, e in enumerate(ix):
-                pieces[int(e)] = (th[cp[t_]:cp[t_ + 1]], None if va is None else va[cp[t_]:cp[t_ + 1]], fi[fp[t_]:fp[t_ + 1]],
-                                  {k: st[k][t_] for k in skeys})
-        th_out, va_out, fi_out = [], [], []
-        st_out = {k: np.zeros(E, np.float64) for k in skeys}
-        for e in range(E):
-            th, va, fi, st = pieces[e]
-            my_coef[e] = len(th)
-            my_feat[e] = len(fi)
-            th_out.append(th)
-            fi_out.append(fi)
-            if any_var:
-                va_out.append(va if va is not None else np.zeros(len(th)))
-            for k in skeys:
-                st_out[k][e] = st[k]
-        cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
-        return (my_coef, cat(th_out, np.float64), cat(va_out, np.float64) if any_var else None, my_feat, cat(fi_out, np.int64),
-                st_out)
+                st_out[k][ix] = ff[q:q + n]; q += n
+            my_coef[ix] = cc
+            my_feat[ix] = fc
+            c_start[ix] = c_base + np.cumsum(cc) - cc
+            f_start[ix] = f_base + np.cumsum(fc) - fc
+            th_pool.append(ff[:tot]); fi_pool.append(fi); va_pool.append(va)
+            c_base += tot
+            f_base += int(fc.sum())
+        cg = _ranges(c_start, my_coef)
+        th_all = np.concatenate(th_pool).astype(np.float64)
+        fi_all = np.concatenate(fi_pool).astype(np.int64)
+        va_out = None
+        if any_var:
+            va_all = np.concatenate([v if v is not None else np.zeros(t.size) for v, t in zip(va_pool, th_pool)]).astype(np.float64)
+            va_out = va_all[cg]
+        return my_coef, th_all[cg], va_out, my_feat, fi_all[_ranges(f_start, my_feat)], st_out

@@ -29,10 +29,11 @@ def main():
     from gdmix_amd import rebalance as rbm
     orig_exchange = rbm.Rebalancer.exchange
 
-    def exchange(self):
-        work = orig_exchange(self)
+    def exchange(self, *a, **k):
+        work = orig_exchange(self, *a, **k)
         rounds.append({"entities": int(self.batch.E), "sent": [int(x.size) for x in self.sent], "received": list(self.recv_counts),
-                       "solved": int(work.E)})
+                       "solved": int(work.E), "with_prior": bool(k.get("with_prior", False)),
+                       "prior_models": int(self.work_prior["has"].sum()) if self.work_prior is not None else 0})
         return work
     rbm.Rebalancer.exchange = exchange
     driver = RandomEffectDriver(Params.__from_argv__(argv), model)

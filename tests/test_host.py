@@ -516,3 +516,21 @@ def test_driver_pipeline_raises_what_a_background_write_raised(tmp_path, monkeyp
     with pytest.raises(OSError, match="disk full"):
         RandomEffectDriver(base, model).run_training(SCHEMA)
     assert model._io_pool is None
+
+
+def test_model_table_rows_round_trip():
+    """rows_for / from_rows (what travels with a re-balanced entity): several chunks, an overridden id, ids without a model."""
+    t = ModelTable()
+    t.add_chunk(["a", "b", "c"], np.arange(6.0), [0, 3, 4, 6], np.array([5, 7, 2]), [0, 2, 2, 3])
+    t.add_chunk(["b", "d"], np.array([10.0, 11.0, 12.0]), [0, 2, 3], np.array([9]), [0, 1, 1])
+    ids = ["d", "zz", "b", "a"]
+    rows = t.rows_for(ids)
+    assert rows["has"].tolist() == [True, False, True, True]
+    assert rows["coef_ptr"].tolist() == [0, 1, 1, 3, 6] and rows["feat_ptr"].tolist() == [0, 0, 0, 1, 3]
+    assert rows["theta"].tolist() == [12.0, 10.0, 11.0, 0.0, 1.0, 2.0] and rows["idx"].tolist() == [9, 5, 7]
+    back = ModelTable.from_rows(ids, rows)
+    assert sorted(back.keys()) == ["a", "b", "d"] and "zz" not in back
+    for k in ("a", "b", "d"):
+        assert np.array_equal(back[k].theta, t[k].theta) and np.array_equal(back[k].unique_global_indices, t[k].unique_global_indices)
+    empty = ModelTable().rows_for(["x"])
+    assert not empty["has"].any() and empty["theta"].size == 0

@@ -45,11 +45,11 @@ def test_wire_format_round_trip():
     assert r.entity_ids == b.entity_ids and r.has_label == b.has_label
 
 
-def _run(tmp_path, tag, rebalance):
+def _run(tmp_path, tag, rebalance, extra=()):
     out = tmp_path / tag
     argv = json.load(open(tmp_path / "argv.json"))
     argv = [a for a in argv if not a.startswith("--output_model_dir")] + [f"--output_model_dir={out / 'models'}",
-                                                                         f"--rebalance_entities={rebalance}"]
+                                                                         f"--rebalance_entities={rebalance}"] + list(extra)
     os.makedirs(out, exist_ok=True)
     json.dump(argv, open(out / "argv.json", "w"))
     env = dict(os.environ)
@@ -97,3 +97,16 @@ def test_two_ranks_rebalance_skewed_partitions_and_write_the_same_models(tmp_pat
     # round 1: rank 0 gives away entities of the heavy partition; round 2: rank 1 has no partition and takes half
     assert rounds[0][0]["sent"][1] > 0 and rounds[1][0]["received"][0] > 0
     assert rounds[0][1]["sent"][1] > 0 and rounds[1][1]["entities"] == 0 and rounds[1][1]["received"][0] > 0
+    assert not rounds[0][0]["with_prior"]
+    # second pass over the same directories with another regularisation weight: a warm start from the models above. The
+    # prior models of the travelling entities travel with them, so the result is again bit-identical to the plain run.
+    plain = _run(tmp_path, "plain", False, ["--l2_reg_weight=3.0"])
+    moved = _run(tmp_path, "rebalanced", True, ["--l2_reg_weight=3.0"])
+    for k, b in enumerate((heavy, light, third)):
+        a = list(avro.read_file(str(plain / "models" / f"part-{k:05d}.avro")))
+        r = list(avro.read_file(str(moved / "models" / f"part-{k:05d}.avro")))
+        assert len(a) == b.E and a == r
+    rounds = json.load(open(moved / "result.json"))["rebalance"]
+    assert rounds[0][0]["with_prior"] and rounds[0][0]["sent"][1] > 0
+    r1 = rounds[1][0]    # rank 1, first round: its own light partition plus what rank 0 gave away
+    assert r1["prior_models"] == r1["solved"] > r1["entities"]     # every entity came with its model
