@@ -223,6 +223,23 @@ def main():
             e2e = {"ms": best * 1e3, "entities_per_s": batch.E / best, "h2d_bytes": h2d_bytes,
                    "d2h_bytes": theta_host.numel() * 8,
                    "what": "pinned host raw batch -> H2D -> pack -> solve -> D2H thresholded theta, one stream, no overlap"}
+        # the scoring pass over the same resident batch (the path's HBM-bound stream; not part of `value`)
+        score = None
+        if not a.no_e2e:
+            th = out["theta_thr"]
+            for _ in range(2):
+                solver.score(packed, th)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            for _ in range(10):
+                solver.score(packed, th)
+            ev[1].record()
+            torch.cuda.synchronize()
+            sms = ev[0].elapsed_time(ev[1]) / 10
+            sbytes = 8.0 * batch.Z + 16.0 * batch.N + 4.0 * (batch.N + batch.E) + 8.0 * float(packed.P) + 24.0 * batch.E
+            score = {"ms": sms, "samples_per_s": batch.N / (sms * 1e-3), "alg_bytes": sbytes, "GBps": sbytes / (sms * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": sbytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "what": "gdmix_re_score: logits of every sample, 8 B/nnz + 16 B/sample + 8 B/coefficient + pointers"}
         cpu = None
         if not a.no_cpu_baseline:
             sample = a.cpu_sample if a.cpu_sample > 0 else min(batch.E, 200_000)
@@ -246,7 +263,7 @@ def main():
                        "classes": classes, "class_ms": [round(float(x) / a.steps, 3) for x in kernel_ms],
                        "mean_nit": nit, "mean_nfev": nfev,
                        "converged_per_step": converged_all, "N": batch.N, "Z": batch.Z, "P": packed.P,
-                       "host_generate_s": t_gen, "host_handover": e2e,
+                       "host_generate_s": t_gen, "host_handover": e2e, "score_pass": score,
                        "restreamed_bytes_per_step": b_stream,
                        "restreamed_GBps": b_stream / (float(kernel_ms.sum()) / a.steps * 1e-3) / 1e9 if kernel_ms.sum() else None},
         }
