@@ -69,6 +69,23 @@ class RandomEffectDriver:
                     self.execution_context[constants.NUM_WORKERS])
         return [all_partitions[i] for i in idx]
 
+    def _init_collectives(self):
+        """Entity re-balancing exchanges entities between the workers: RCCL when launched one process per GPU by
+        torch.distributed.run (which provides the rendezvous variables; TF_CONFIG alone does not)."""
+        if self.execution_context[constants.NUM_WORKERS] <= 1:
+            return
+        import torch
+        import torch.distributed as dist
+        if dist.is_initialized():
+            return
+        if "RANK" not in os.environ or "MASTER_ADDR" not in os.environ:
+            raise RuntimeError("--rebalance_entities needs the workers to be started by torch.distributed.run "
+                               "(RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT): they exchange entities over RCCL")
+        backend = "nccl" if torch.cuda.is_available() and torch.cuda.device_count() >= int(os.environ.get("LOCAL_WORLD_SIZE", "1")) else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(os.environ.get("GDMIX_DIST_BACKEND", backend))
+
     def _anchor_directory(self, directory_path, partition_index):
         return os.path.join(directory_path, self._RANDOM_EFFECT_PARTITION_DIR_PREFIX + str(partition_index))
 
@@ -82,6 +99,7 @@ class RandomEffectDriver:
         lockstep = bool(getattr(getattr(self.model, "model_params", None), "rebalance_entities", False))
         rounds = len(partition_index_list)
         if lockstep:
+            self._init_collectives()
             with open(self.base_training_params.partition_list_file) as f:
                 total = len(f.readline().split(","))
             w = self.execution_context[constants.NUM_WORKERS]

@@ -19,8 +19,7 @@ from gdmix_amd.params import Params, SchemaParams
 
 def main():
     base = sys.argv[1]
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])   # the driver opens the process group when it needs one
     argv = json.load(open(os.path.join(base, "argv.json")))
     model = RandomEffectLRLBFGSModel(argv)
     model._solver = OracleSolverDouble()
@@ -40,6 +39,8 @@ def main():
     assert driver.execution_context["task_index"] == rank and driver.execution_context["num_workers"] == world
     mine = driver._get_partition_list()
     driver.run_training(SchemaParams.__from_argv__(argv), export_model=True)
+    if not dist.is_initialized():
+        dist.init_process_group("gloo")
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
     # load totals: the only collective the RE path needs is this kind of tiny metadata exchange
