@@ -471,7 +471,7 @@ class RandomEffectLRLBFGSModel:
             if model_weights:
                 theta0, _ = _model_coefficients_for_batch(model_weights, work.entity_ids, uniq, feat_ptr,
                                                           self.has_intercept, num_features)
-            res = solver.solve(packed, opts, theta0=theta0).to_host()
+            res = solver.solve(packed, opts, theta0=theta0).to_host(("theta_thr", "variance") + self._STAT_KEYS)
             theta_thr, variance = res["theta_thr"], res.get("variance")
             stats = {k: res[k] for k in self._STAT_KEYS}
         if rb is not None:

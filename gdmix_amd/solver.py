@@ -246,8 +246,10 @@ class SolveResult:
             return t[k]
         raise AttributeError(k)
 
-    def to_host(self):
-        return {k: (v.cpu().numpy() if v is not None else None) for k, v in self._t.items()}
+    def to_host(self, keys=None):
+        """numpy copies of the result arrays (all of them, or only `keys`: the unthresholded coefficients are as large as
+        the thresholded ones and the model path never reads them)."""
+        return {k: (v.cpu().numpy() if v is not None else None) for k, v in self._t.items() if keys is None or k in keys}
 
 
 class REDeviceSolver:

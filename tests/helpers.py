@@ -105,8 +105,8 @@ class _Res:
     def __init__(self, d):
         self.d = d
 
-    def to_host(self):
-        return self.d
+    def to_host(self, keys=None):
+        return self.d if keys is None else {k: v for k, v in self.d.items() if k in keys}
 
 
 class OracleSolverDouble:

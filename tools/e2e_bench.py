@@ -49,6 +49,30 @@ timed(M, "_save_model", "model Avro")
 timed(M, "_predict", "scoring pass total (read + score + score Avro)")
 timed(model_mod, "_write_scores", "score Avro")
 
+from gdmix_amd import solver as solver_mod
+
+
+def timed_sync(cls, name, label):
+    import torch
+    fn = getattr(cls, name)
+
+    def wrapper(*a, **k):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            torch.cuda.synchronize()
+            phases[label] = phases.get(label, 0.0) + time.perf_counter() - t
+    setattr(cls, name, wrapper)
+
+
+if os.environ.get("E2E_DETAIL"):     # attribute the device-side calls (adds synchronisation: totals get slightly worse)
+    timed_sync(solver_mod.REDeviceSolver, "pack", "  . upload + pack")
+    timed_sync(solver_mod.REDeviceSolver, "solve", "  . solve")
+    timed_sync(solver_mod.REDeviceSolver, "score", "  . score")
+    timed_sync(solver_mod.SolveResult, "to_host", "  . results D2H")
+
 with tempfile.TemporaryDirectory() as d:
     t = time.perf_counter()
     b = synthetic.make_batch(E, 16, 4, 1024, seed=1)
