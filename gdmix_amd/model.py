@@ -30,6 +30,10 @@ logger.setLevel(logging.INFO)
 TrainingResult = namedtuple("TrainingResult", ("theta", "variance", "unique_global_indices"))
 
 
+_ROW_BITS = 40
+_ROW_MASK = (1 << _ROW_BITS) - 1
+
+
 class ModelTable:
     """entity id -> TrainingResult, stored as flat arrays per chunk so that a million models do not become
     a million Python objects. Iteration order follows dict.update semantics: existing ids keep their place,
@@ -37,7 +41,7 @@ class ModelTable:
 
     def __init__(self):
         self._chunks = []      # dict(theta, variance|None, idx, coef_ptr, feat_ptr)
-        self._where = {}       # id -> (chunk index, row)
+        self._where = {}       # id -> chunk index << 40 | row
 
     def __len__(self):
         return len(self._where)
@@ -53,14 +57,17 @@ class ModelTable:
         self._chunks.append(dict(theta=np.asarray(theta, np.float64), variance=None if variance is None else np.asarray(variance, np.float64),
                                  idx=np.asarray(idx, np.int64), coef_ptr=np.asarray(coef_ptr, np.int64),
                                  feat_ptr=np.asarray(feat_ptr, np.int64)))
-        for r, k in enumerate(ids):
-            self._where[k] = (c, r)    # an existing key keeps its position in the dict, only the value changes
+        base = c << _ROW_BITS
+        if not self._where:
+            self._where = dict(zip(ids, range(base, base + len(ids))))
+        else:
+            self._where.update(zip(ids, range(base, base + len(ids))))   # an existing key keeps its position, only the value changes
 
     def get(self, k, default=None):
         w = self._where.get(k)
         if w is None:
             return default
-        c, r = w
+        c, r = w >> _ROW_BITS, w & _ROW_MASK
         ch = self._chunks[c]
         a, b = ch["coef_ptr"][r], ch["coef_ptr"][r + 1]
         fa, fb = ch["feat_ptr"][r], ch["feat_ptr"][r + 1]
@@ -83,8 +90,8 @@ class ModelTable:
         if isinstance(other, ModelTable):
             base = len(self._chunks)
             self._chunks.extend(other._chunks)
-            for k, (c, r) in other._where.items():
-                self._where[k] = (base + c, r)
+            shift = base << _ROW_BITS
+            self._where.update((k, w + shift) for k, w in other._where.items())
         else:
             for k, tr in dict(other).items():
                 p = len(tr.theta)
@@ -95,7 +102,8 @@ class ModelTable:
         """Flat arrays over the entities in dict order: (ids, coef_beg, coef_cnt, var_beg, feat_beg, mean, variance,
         feat_idx); var_beg is -1 for an entity whose chunk carries no variance, variance None if no chunk does."""
         ids = list(self._where.keys())
-        cr = np.array(list(self._where.values()), np.int64).reshape(-1, 2)
+        w = np.fromiter(self._where.values(), np.int64, count=len(ids))
+        cr = np.stack([w >> _ROW_BITS, w & _ROW_MASK], axis=1) if len(ids) else np.zeros((0, 2), np.int64)
         cbase, fbase, vbase = [], [], []
         co = fo = vo = 0
         any_var = any(ch["variance"] is not None for ch in self._chunks)
@@ -153,7 +161,7 @@ class ModelTable:
         t._chunks.append(dict(theta=np.asarray(rows["theta"], np.float64), variance=None, idx=np.asarray(rows["idx"], np.int64),
                               coef_ptr=np.asarray(rows["coef_ptr"], np.int64), feat_ptr=np.asarray(rows["feat_ptr"], np.int64)))
         for r in np.flatnonzero(rows["has"]):
-            t._where[ids[int(r)]] = (0, int(r))
+            t._where[ids[int(r)]] = int(r)
         return t
 
     def lookup(self, ids):
@@ -161,11 +169,11 @@ class ModelTable:
         found = np.zeros(len(ids), bool)
         chunk = np.zeros(len(ids), np.int64)
         row = np.zeros(len(ids), np.int64)
-        for i, k in enumerate(ids):
-            w = self._where.get(k)
-            if w is not None:
-                found[i] = True
-                chunk[i], row[i] = w
+        get = self._where.get
+        w = np.fromiter((get(k, -1) for k in ids), np.int64, count=len(ids))
+        found = w >= 0
+        chunk = np.where(found, w >> _ROW_BITS, 0)
+        row = np.where(found, w & _ROW_MASK, 0)
         return found, chunk, row
 
 
@@ -329,7 +337,7 @@ class RandomEffectLRLBFGSModel:
         waits for them (and raises what they raised). The native reader / writers release the GIL."""
         if self._io_pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            self._io_pool = ThreadPoolExecutor(max_workers=3, thread_name_prefix="gdmix-io")
+            self._io_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="gdmix-io")
 
     def _read_key(self, input_path, num_features):
         return (os.path.abspath(input_path), self.model_params.partition_entity, self.feature_bag_name, num_features)
@@ -405,14 +413,14 @@ class RandomEffectLRLBFGSModel:
         batch = self._read(input_path, tensor_metadata, schema_params, num_features, need_label=True)
         if not batch.has_label:
             raise KeyError(f"label column {schema_params.label_column_name!r} is missing from the training data")
-        theta_thr, variance, uniq, feat_ptr, stats, packed = self._solve_batch(batch, model_weights, num_features)
+        theta_thr, variance, uniq, feat_ptr, stats, resident = self._solve_batch(batch, model_weights, num_features)
         ic = 1 if self.has_intercept else 0
         coef_ptr = feat_ptr + np.arange(batch.E + 1, dtype=np.int64) * ic
         self.last_training_stats = dict(entities=batch.E, samples=batch.N, nnz=batch.Z, **stats)
         results = ModelTable()
         results.add_chunk(batch.entity_ids, theta_thr, coef_ptr, uniq, feat_ptr, variance)
-        if self._read_cache is not None and self._read_cache[1] is batch and packed is not None and len(results) == batch.E:
-            self._read_cache[2:] = [packed, theta_thr]     # (an entity id listed twice is scored with its later model: no shortcut)
+        if self._read_cache is not None and self._read_cache[1] is batch and resident is not None and len(results) == batch.E:
+            self._read_cache[2:] = list(resident)     # (an entity id listed twice is scored with its later model: no shortcut)
         # The trained model is updated over the prior model: prior entities that are not in the current data
         # are carried over (random_effect_lr_lbfgs_model.py:155-162).
         model_weights.update(results)
@@ -447,7 +455,7 @@ class RandomEffectLRLBFGSModel:
         opts = self._solver_options()
         rb = None
         work = batch
-        packed = None
+        packed = theta_dev = None
         rebalance, with_prior = self._rebalancing(model_weights)
         if rebalance:
             from .rebalance import Rebalancer
@@ -471,15 +479,18 @@ class RandomEffectLRLBFGSModel:
             if model_weights:
                 theta0, _ = _model_coefficients_for_batch(model_weights, work.entity_ids, uniq, feat_ptr,
                                                           self.has_intercept, num_features)
-            res = solver.solve(packed, opts, theta0=theta0).to_host(("theta_thr", "variance") + self._STAT_KEYS)
+            solved = solver.solve(packed, opts, theta0=theta0)
+            res = solved.to_host(("theta_thr", "variance") + self._STAT_KEYS)
             theta_thr, variance = res["theta_thr"], res.get("variance")
+            theta_dev = getattr(solved, "theta_thr", None)    # still in HBM: what the scoring pass of this partition reads
             stats = {k: res[k] for k in self._STAT_KEYS}
         if rb is not None:
             feat_cnt = np.diff(feat_ptr)
             coef_cnt, theta_thr, variance, feat_cnt, uniq, st = rb.give_back(feat_cnt + ic, theta_thr, variance, feat_cnt, uniq, stats)
             feat_ptr = np.concatenate([[0], np.cumsum(feat_cnt)]).astype(np.int64)
             stats = {k: (st[k].astype(np.int32) if k in ("nit", "nfev", "status") else st[k]) for k in self._STAT_KEYS}
-        return theta_thr, variance, uniq, feat_ptr, stats, (packed if rb is None else None)
+        resident = None if (rb is not None or packed is None) else (packed, theta_dev if theta_dev is not None else theta_thr)
+        return theta_thr, variance, uniq, feat_ptr, stats, resident
 
     def idle_round(self, num_features=1):
         """A rank without a partition in this round still takes part in the re-balancing collectives (and solves what
