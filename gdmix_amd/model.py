@@ -335,7 +335,6 @@ class RandomEffectLRLBFGSModel:
     def begin_pipeline(self):
         """From here on prefetch() decodes input in a background thread and the Avro files are written by one; flush()
         waits for them (and raises what they raised). The native reader / writers release the GIL."""
-        self._get_solver()     # the read-ahead thread uploads to the device: it has to exist (and fails here if it cannot)
         if self._io_pool is None:
             from concurrent.futures import ThreadPoolExecutor
             self._io_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="gdmix-io")
@@ -351,16 +350,7 @@ class RandomEffectLRLBFGSModel:
         num_features = 1 if self.feature_bag_name is None else tensor_metadata.get_feature_shape(self.feature_bag_name)[0]
         key = self._read_key(input_path, num_features)
         if key not in self._prefetched:
-            self._prefetched[key] = self._io_pool.submit(self._read_ahead, input_path, tensor_metadata, schema_params, num_features)
-
-    def _read_ahead(self, input_path, tensor_metadata, schema_params, num_features):
-        """Background thread: decode the partition and, once this process has a device solver, start its upload on the
-        copy stream (pack() orders it before the kernels)."""
-        batch = self._read_files(input_path, tensor_metadata, schema_params, num_features)
-        solver = self._solver
-        if batch.E and solver is not None and hasattr(solver, "upload") and not self.model_params.rebalance_entities:
-            batch.on_device = solver.upload(batch, ahead=True)
-        return batch
+            self._prefetched[key] = self._io_pool.submit(self._read_files, input_path, tensor_metadata, schema_params, num_features)
 
     def prefetch_prior_model(self, partition_index):
         """Start loading the model file train() will warm-start partition `partition_index` from, if there is one."""
@@ -369,15 +359,6 @@ class RandomEffectLRLBFGSModel:
             return
         self.flush(model_file)
         self._prefetched_models[model_file] = self._io_pool.submit(self._load_weights_from, model_file)
-
-    @staticmethod
-    def _uploaded(batch):
-        """The device copy _read_ahead started, once; else the host batch (pack uploads it)."""
-        dev = getattr(batch, "on_device", None)
-        if dev is None:
-            return batch
-        batch.on_device = None
-        return dev
 
     def _write_behind(self, path, fn, *args, **kwargs):
         if self._io_pool is None:
@@ -491,7 +472,7 @@ class RandomEffectLRLBFGSModel:
             feat_ptr = np.zeros(1, np.int64)
             stats = {k: np.zeros(0) for k in self._STAT_KEYS}
         else:
-            packed = solver.pack(self._uploaded(work), has_intercept=self.has_intercept)
+            packed = solver.pack(work, has_intercept=self.has_intercept)
             feat_ptr = packed.ent_feat_ptr().cpu().numpy()
             uniq = packed.unique_global().cpu().numpy()
             theta0 = None
@@ -541,7 +522,7 @@ class RandomEffectLRLBFGSModel:
             return
         solver = self._get_solver()
         if packed is None:
-            packed = solver.pack(self._uploaded(batch), has_intercept=self.has_intercept)
+            packed = solver.pack(batch, has_intercept=self.has_intercept)
             feat_ptr = packed.ent_feat_ptr().cpu().numpy()
             uniq = packed.unique_global().cpu().numpy()
             theta, has_model = _model_coefficients_for_batch(model_weights, batch.entity_ids, uniq, feat_ptr,

@@ -270,7 +270,6 @@ class REDeviceSolver:
         _check(self.lib.gdmix_re_create(self.device_index, C.byref(h)), "gdmix_re_create")
         self._h = h
         self._scratch = None
-        self._copy_stream = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -312,25 +311,14 @@ class REDeviceSolver:
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- upload + pack -------------------------------------------------------------------------
-    def upload(self, raw: RawBatch, ahead=False):
-        """Copy the raw ragged arrays to HBM. Returns dict of device tensors. ahead=True (from a background thread): the
-        copies go on a side stream so that they overlap the kernels of the partition being solved; pack() waits for them."""
+    def upload(self, raw: RawBatch):
+        """Copy the raw ragged arrays to HBM (pinned-free simple path). Returns dict of device tensors."""
         t = self.torch
         dev = self.device
-
-        def copy():
-            return dict(ent_row_ptr=t.from_numpy(raw.ent_row_ptr).to(dev), row_nnz_ptr=t.from_numpy(raw.row_nnz_ptr).to(dev),
-                        col_global=t.from_numpy(raw.col_global).to(dev), val=t.from_numpy(raw.val).to(dev),
-                        y=t.from_numpy(raw.y).to(dev), offset=t.from_numpy(raw.offset).to(dev),
-                        weight=None if raw.weight is None else t.from_numpy(raw.weight).to(dev))
-        if ahead:
-            if self._copy_stream is None:
-                self._copy_stream = t.cuda.Stream(device=dev)
-            with t.cuda.stream(self._copy_stream):
-                d = copy()
-                d["ready"] = self._copy_stream.record_event()
-        else:
-            d = copy()
+        d = dict(ent_row_ptr=t.from_numpy(raw.ent_row_ptr).to(dev), row_nnz_ptr=t.from_numpy(raw.row_nnz_ptr).to(dev),
+                 col_global=t.from_numpy(raw.col_global).to(dev), val=t.from_numpy(raw.val).to(dev),
+                 y=t.from_numpy(raw.y).to(dev), offset=t.from_numpy(raw.offset).to(dev),
+                 weight=None if raw.weight is None else t.from_numpy(raw.weight).to(dev))
         d["E"], d["N"], d["Z"] = raw.E, raw.N, raw.Z
         return d
 
@@ -339,13 +327,6 @@ class REDeviceSolver:
         t = self.torch
         rd = self.upload(raw) if isinstance(raw, RawBatch) else raw
         E, N, Z = rd["E"], rd["N"], rd["Z"]
-        ready = rd.pop("ready", None)
-        if ready is not None:    # uploaded ahead on the copy stream: order it before this stream's work
-            cur = t.cuda.current_stream(self.device)
-            cur.wait_event(ready)
-            for v in rd.values():
-                if isinstance(v, t.Tensor):
-                    v.record_stream(cur)
         ptr = lambda x: None if x is None or x.numel() == 0 else x.data_ptr()
         c_raw = _RawBatch(E, N, Z, rd["ent_row_ptr"].data_ptr(), rd["row_nnz_ptr"].data_ptr(), ptr(rd["col_global"]),
                           ptr(rd["val"]), ptr(rd["y"]), ptr(rd["offset"]), ptr(rd["weight"]))
