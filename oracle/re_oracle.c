@@ -96,8 +96,51 @@ static void logits_(const problem* P, const double* th, double* z) {
   }
 }
 
+/* The fixed-effect objective sums over a whole shard (10^5 .. 10^7 samples). The reference adds those up with
+ * TensorFlow's / numpy's blocked (pairwise) reductions, whose rounding error does not grow with n; a plain running sum in
+ * fp64 loses ~1e-11 of the value at n = 4e5, the line search's interpolation turns that into ~1e-9 of the first step and
+ * three L-BFGS iterations into 7e-6 of the coefficients (measured against scipy on the same objective,
+ * tools/fuzz_fe.py case 5). So the sums over samples and over coefficients of the sum_loss objective are accumulated
+ * in long double here: 11 more mantissa bits stand in for the blocked reductions. The random-effect objective
+ * (n ~ 10^1 .. 10^3, pinned bit-tight against the reference's fixtures) keeps its plain fp64 sums. */
+static double fg_wide_(const problem* P, const double* th, double* g) {
+  const int n = P->n, p = P->p, ic = P->ic;
+  logits_(P, th, P->z);
+  long double cost = 0.0L, rsum = 0.0L;
+  for (int i = 0; i < n; ++i) {
+    double zi = P->z[i], yi = (double)P->y[i], wi = P->w ? (double)P->w[i] : 1.0;
+    if (P->linear) {
+      cost += (long double)(wi * (yi - zi) * (yi - zi));
+      P->r[i] = 2.0 * wi * (zi - yi);
+    } else {
+      double ce = fmax(zi, 0.0) - zi * yi + log(1.0 + exp(-fabs(zi)));
+      cost += (long double)(wi * ce);
+      P->r[i] = wi * (expit_(zi) - yi);
+    }
+    rsum += (long double)P->r[i];
+  }
+  int first_reg = (ic && !P->reg_bias) ? 1 : 0;
+  long double sq = 0.0L;
+  for (int j = first_reg; j < p; ++j) sq += (long double)(th[j] * th[j]);
+  double f = (double)(cost + (long double)(P->l2 / 2.0) * sq);
+  long double* gw = (long double*)malloc((size_t)(p > 0 ? p : 1) * sizeof(long double));
+  for (int j = 0; j < p; ++j) gw[j] = 0.0L;
+  if (ic) gw[0] = rsum;
+  for (int i = 0; i < n; ++i)
+    for (int k = P->row_ptr[i]; k < P->row_ptr[i + 1]; ++k)
+      gw[ic + P->col[k]] += (long double)((double)P->val[k] * P->r[i]);
+  for (int j = 0; j < p; ++j) {
+    double reg = P->l2 * th[j];
+    if (j < first_reg) reg = 0.0;
+    g[j] = (double)(gw[j] + (long double)reg);
+  }
+  free(gw);
+  return f;
+}
+
 /* _loss (:84-110) and _gradient (:121-131), fused: f and g at theta. */
 static double fg_(const problem* P, const double* th, double* g) {
+  if (P->sum_loss) return fg_wide_(P, th, g);
   const int n = P->n, p = P->p, ic = P->ic;
   logits_(P, th, P->z);
   double cost = 0.0;
@@ -294,7 +337,13 @@ typedef struct {
   int regularize_bias, has_intercept, m, max_iter, maxfun, maxls;
 } solve_opts;
 
+static __thread int g_wide_dots = 0;   /* set per solve: the fixed-effect coefficient space has 10^4 .. 10^6 dimensions (see fg_wide_) */
 static double dot_(const double* a, const double* b, int n) {
+  if (g_wide_dots) {
+    long double s = 0.0L;
+    for (int i = 0; i < n; ++i) s += (long double)(a[i] * b[i]);
+    return (double)s;
+  }
   double s = 0.0;
   for (int i = 0; i < n; ++i) s += a[i] * b[i];
   return s;
@@ -309,6 +358,7 @@ static double maxabs_(const double* a, int n) {
 /* Returns status 0..4 (PGTOL, FACTR, MAXITER, MAXFUN, ABNORMAL); x holds theta0 on entry. */
 static int lbfgs_solve_entity(const problem* P, const solve_opts* O, double* x, double* f_out,
                               double* gnorm_out, int* nit_out, int* nfev_out, double* work) {
+  g_wide_dots = P->sum_loss;
   const int p = P->p, m = O->m;
   double* g = work;
   double* d = g + p;

@@ -1,0 +1,96 @@
+"""Randomised parity sweep of the fixed-effect solver: stepping kernels (include/gdmix_fe.h) and the device-wide team
+kernel against the CPU oracle on seeded random shards. A tool for the GPU box, not a test.
+
+    PYTHONPATH=.:tests python tools/fuzz_fe.py [cases] [first_seed]
+"""
+import sys
+import time
+
+import numpy as np
+
+from gdmix_amd import fixed_effect as fe
+from gdmix_amd.solver import REDeviceSolver
+from oracle import oracle
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+dev = REDeviceSolver(0)
+s = fe.FixedEffectDeviceSolver(solver=dev)
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+bad = 0
+t0 = time.time()
+worst = 0.0
+for case in range(cases):
+    rng = np.random.default_rng(seed0 + case)
+    n = int(rng.choice([50, 3000, 40000, 300000, 700000]))
+    n = int(n * (0.5 + rng.random()))
+    D = int(rng.choice([5, 300, 20000, 150000]))
+    kmax = int(rng.choice([1, 4, 12, 40]))
+    k = rng.integers(0, kmax + 1, n)
+    if rng.random() < 0.3:    # a few very long rows
+        k[rng.integers(0, n, 3)] = rng.integers(3000, 9000, 3)
+    rp = np.concatenate([[0], np.cumsum(k)]).astype(np.int64)
+    Z = int(rp[-1])
+    cols = rng.integers(0, D, Z)
+    if rng.random() < 0.4 and Z:   # dominant columns
+        hot = rng.random(Z) < 0.3
+        cols[hot] = rng.integers(0, min(D, 3), int(hot.sum()))
+    vals = (rng.standard_normal(Z) * float(rng.choice([0.1, 1.0]))).astype(np.float32)
+    linear = bool(rng.random() < 0.35)
+    ic = bool(rng.random() < 0.8)
+    w_true = rng.standard_normal(D) * 0.3
+    z = np.zeros(n)
+    np.add.at(z, np.repeat(np.arange(n), k), vals.astype(np.float64) * w_true[cols])
+    off = (0.2 * rng.standard_normal(n)).astype(np.float32) if rng.random() < 0.7 else None
+    wt = (0.5 + rng.random(n)).astype(np.float32) if rng.random() < 0.5 else None
+    y = (z + 0.1 * rng.standard_normal(n)).astype(np.float32) if linear else (rng.random(n) < 1 / (1 + np.exp(-z))).astype(np.float32)
+    l2 = float(rng.choice([0.1, 1.0, 10.0, 100.0]))
+    regb = bool(rng.random() < 0.5)
+    max_iter = int(rng.choice([3, 30, 200]))
+    m = int(rng.choice([3, 10]))
+    th0 = 0.05 * rng.standard_normal(D + (1 if ic else 0)) if rng.random() < 0.3 else None
+    if th0 is not None:   # the oracle works in the space of the features present in the shard: start the absent ones at 0
+        absent = np.ones(D, bool)
+        absent[cols] = False
+        th0[:D][absent] = 0.0
+    mt = fe.LINEAR_REGRESSION if linear else fe.LOGISTIC_REGRESSION
+    kw = dict(offset=off, weight=wt, has_intercept=ic, l2=l2, regularize_bias=regb, model_type=mt, theta0=th0, max_iter=max_iter, m=m)
+    th_step, info_step = s.fit_stepping(rp, cols, vals, y, D, **kw)
+    th_team, info_team = s.fit(rp, cols, vals, y, D, **kw) if Z < 4_000_000 else (None, None)
+    batch, dummy = fe.shard_as_batch(rp, cols, vals, y, off, wt, ic, binary_labels=not linear)
+    pk = oracle.pack(batch.ent_row_ptr, batch.row_nnz_ptr, batch.col_global)
+    Dg = 1 if dummy else D
+    o = oracle.make_opts(l2=l2, regularize_bias=regb and ic, has_intercept=ic, m=m, max_iter=max_iter, threshold=0.0, sum_loss=True, linear=linear)
+    t0l = None
+    if th0 is not None:
+        t0l = fe.to_local(th0 if not dummy else np.concatenate([np.zeros(Dg), th0[D:]]), pk["unique_global"], Dg, ic, False)
+    res = oracle.solve(pk, batch.val, batch.y, batch.offset, batch.weight, o, theta0=t0l)
+    th_o = fe.to_global(res["theta"], pk["unique_global"], Dg, ic, False)
+    if dummy:
+        th_o = th_o[Dg:]
+    problems = []
+    for name, th, info in (("stepping", th_step, info_step), ("team", th_team, info_team)):
+        if th is None:
+            continue
+        e = rel_err(th, th_o)
+        st = int(info["status"])
+        tol = 1e-5 if (st == 1 or res["status"][0] == 1) else 1e-7
+        if st != int(res["status"][0]) and not (st in (0, 1) and res["status"][0] in (0, 1)):
+            problems.append(f"{name}: status {st} vs oracle {int(res['status'][0])}")
+        if st not in (1,) and res["status"][0] != 1 and int(info["nit"]) != int(res["nit"][0]):
+            problems.append(f"{name}: nit {info['nit']} vs oracle {int(res['nit'][0])}")
+        if e > tol:
+            problems.append(f"{name}: theta rel err {e:.2e} (status {st}, nit {info['nit']} / oracle {int(res['nit'][0])})")
+        worst = max(worst, e)
+    if problems:
+        bad += 1
+    if problems or case % 5 == 0:
+        print(f"{'BAD' if problems else 'ok '} case {seed0 + case} n={n} D={D} Z={Z} linear={linear} ic={ic} l2={l2} regb={regb} max_iter={max_iter} m={m} "
+              f"warm={th0 is not None} off={off is not None} wt={wt is not None} dummy={dummy}" + "".join("\n      " + p for p in problems), flush=True)
+print(f"{cases} cases, {bad} with disagreements, worst theta rel err {worst:.2e}, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
