@@ -73,24 +73,39 @@ for case in range(cases):
     th_o = fe.to_global(res["theta"], pk["unique_global"], Dg, ic, False)
     if dummy:
         th_o = th_o[Dg:]
+    # How reproducible is the oracle's own answer? Long runs amplify rounding (see tools/fuzz_parity.py): the same solve
+    # from a start moved by ~1e-15, three times.
+    sens, stable = 0.0, True
+    P_loc = int(res["theta"].size)
+    for j in range(3):
+        jig = 1e-15 * np.random.default_rng(j + 1).standard_normal(P_loc)
+        pert = oracle.solve(pk, batch.val, batch.y, batch.offset, batch.weight, o, theta0=jig if t0l is None else t0l * (1.0 + jig))
+        sens = max(sens, rel_err(pert["theta"], res["theta"]))
+        stable = stable and int(pert["nit"][0]) == int(res["nit"][0]) and int(pert["status"][0]) == int(res["status"][0])
+    stable = stable and sens < 1e-9
     problems = []
     for name, th, info in (("stepping", th_step, info_step), ("team", th_team, info_team)):
         if th is None:
             continue
         e = rel_err(th, th_o)
         st = int(info["status"])
-        tol = 1e-5 if (st == 1 or res["status"][0] == 1) else 1e-7
-        if st != int(res["status"][0]) and not (st in (0, 1) and res["status"][0] in (0, 1)):
-            problems.append(f"{name}: status {st} vs oracle {int(res['status'][0])}")
-        if st not in (1,) and res["status"][0] != 1 and int(info["nit"]) != int(res["nit"][0]):
-            problems.append(f"{name}: nit {info['nit']} vs oracle {int(res['nit'][0])}")
+        if stable:
+            tol = 1e-5 if (st == 1 or res["status"][0] == 1) else 1e-7
+            if st != int(res["status"][0]) and not (st in (0, 1) and res["status"][0] in (0, 1)):
+                problems.append(f"{name}: status {st} vs oracle {int(res['status'][0])}")
+            # (a stop test met within rounding of its threshold may fall on the next iteration: then the coefficients agree)
+            if st not in (1,) and res["status"][0] != 1 and int(info["nit"]) != int(res["nit"][0]) and e > 1e-9:
+                problems.append(f"{name}: nit {info['nit']} vs oracle {int(res['nit'][0])}")
+            worst = max(worst, e)
+        else:
+            tol = max(1e-6, 1000.0 * sens)
         if e > tol:
-            problems.append(f"{name}: theta rel err {e:.2e} (status {st}, nit {info['nit']} / oracle {int(res['nit'][0])})")
-        worst = max(worst, e)
+            problems.append(f"{name}: theta rel err {e:.2e} (status {st}, nit {info['nit']} / oracle {int(res['nit'][0])}; "
+                            f"oracle sensitivity {sens:.1e}, {'reproducible' if stable else 'rounding-sensitive'})")
     if problems:
         bad += 1
     if problems or case % 5 == 0:
         print(f"{'BAD' if problems else 'ok '} case {seed0 + case} n={n} D={D} Z={Z} linear={linear} ic={ic} l2={l2} regb={regb} max_iter={max_iter} m={m} "
-              f"warm={th0 is not None} off={off is not None} wt={wt is not None} dummy={dummy}" + "".join("\n      " + p for p in problems), flush=True)
-print(f"{cases} cases, {bad} with disagreements, worst theta rel err {worst:.2e}, {time.time() - t0:.0f} s")
+              f"warm={th0 is not None} off={off is not None} wt={wt is not None} dummy={dummy} {'reproducible' if stable else 'sensitive %.0e' % sens}" + "".join("\n      " + p for p in problems), flush=True)
+print(f"{cases} cases, {bad} with disagreements, worst theta rel err on reproducible cases {worst:.2e}, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
