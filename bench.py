@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--giant-nnz", type=int, default=-1, help="override the device-wide kernel threshold (exploration)")
     ap.add_argument("--team-nnz", type=int, default=-1, help="override the lowest team-tier threshold (exploration)")
     ap.add_argument("--solve-only", action="store_true", help="time gdmix_re_solve alone (batch packed once)")
+    ap.add_argument("--ranks-share-device", action="store_true",
+                    help="test hook for a 1-GPU box: every rank uses cuda:0 and the collectives go over gloo (numbers are meaningless)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c5mean", "zipf", "ml_user", "ml_movie"],
                     help="c2 (default, the benchmarked configuration) or an exploration shape")
     return ap.parse_args()
@@ -87,10 +89,16 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback path)")
+    if a.ranks_share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_dev = "cpu" if a.ranks_share_device else "cuda"    # where the two scalars of the collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.ranks_share_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from gdmix_amd import build, synthetic
     if rank == 0:
         build.build_library()
@@ -151,14 +159,14 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     status = res.status
     converged = int(((status >= 0) & (status <= 2)).sum().item())
     if world > 1:
-        ct = torch.tensor([converged], dtype=torch.int64, device="cuda")
+        ct = torch.tensor([converged], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(ct)
         converged_all = int(ct.item())
     else:
@@ -184,7 +192,8 @@ def main():
         nit = res.nit.double().mean().item()
         traffic = traffic_detail = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        if os.path.exists(tpath):   # PMC bytes of the same kernel from a separate rocprofv3 --pmc run
+        # PMC bytes of the same kernel from a separate rocprofv3 --pmc run of this configuration (tools/profile_round.sh)
+        if os.path.exists(tpath) and a.workload == "c2" and a.entities == 1_000_000 and (a.mean_n, a.k, a.dim) == (16, 4, 1024):
             with open(tpath) as fh:
                 tj = json.load(fh)
             traffic_detail = tj.get(classes[dom][0])
