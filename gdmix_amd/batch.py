@@ -4,7 +4,7 @@ A RawBatch is the flattened form of what the reference's prepare_jobs slices one
 of the TF sparse tensors (gdmix-trainer/src/gdmix/models/custom/scipy/job_consumers.py:176-258):
 entity-major, then sample-major, then non-zero-major ragged arrays.
 """
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional
 
 import numpy as np

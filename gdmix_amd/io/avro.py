@@ -11,7 +11,6 @@ Container: magic 'Obj\\x01' | file metadata map {avro.schema, avro.codec} | 16-b
 little endian; string/bytes = long length + data; array/map = blocks of [long count][items] ending with 0;
 union = long branch index + value; record = fields in schema order. Codecs: null and deflate.
 """
-import io
 import json
 import os
 import struct

@@ -23,6 +23,7 @@ Nothing here touches the arithmetic: results are bit-identical to the unbalanced
 import numpy as np
 
 from .batch import RawBatch, concat
+from .io.native_reader import _ids_to_bytes, _split_ids   # vectorised id <-> bytes (pure numpy; no library call)
 
 
 # ---- planning (pure numpy, identical on every rank) -----------------------------------------------------------------
@@ -71,13 +72,13 @@ def choose_entities(cost, amounts):
 # ---- wire format of a RawBatch slice ----------------------------------------------------------------------------------
 def _pack(b: RawBatch):
     """RawBatch -> (int64 array, float32 array, uint8 array)."""
-    ids = [s.encode("utf-8") for s in b.entity_ids]
-    id_len = np.array([len(x) for x in ids], np.int64)
+    id_bytes, id_ptr = _ids_to_bytes(b.entity_ids)
+    id_len = np.diff(id_ptr)
     has_w = b.weight is not None
     i64 = np.concatenate([np.array([b.E, b.N, b.Z, int(has_w), int(b.has_label)], np.int64), np.diff(b.ent_row_ptr),
                           np.diff(b.row_nnz_ptr), b.col_global, b.uid if b.uid is not None else np.zeros(b.N, np.int64), id_len])
     f32 = np.concatenate([b.val, b.y, b.offset] + ([b.weight] if has_w else []))
-    u8 = np.frombuffer(b"".join(ids), np.uint8)
+    u8 = np.frombuffer(id_bytes, np.uint8)
     return i64.astype(np.int64), f32.astype(np.float32), u8
 
 
@@ -95,8 +96,7 @@ def _unpack(i64, f32, u8):
     off = f32[q:q + N]; q += N
     w = f32[q:q + N] if has_w else None
     idp = np.concatenate([[0], np.cumsum(id_len)]).astype(np.int64)
-    raw = u8.tobytes()
-    ids = [raw[idp[i]:idp[i + 1]].decode("utf-8") for i in range(E)]
+    ids = _split_ids(u8.tobytes(), idp, E)
     return RawBatch(ent_row_ptr=np.concatenate([[0], np.cumsum(n)]).astype(np.int64),
                     row_nnz_ptr=np.concatenate([[0], np.cumsum(k)]).astype(np.int64), col_global=col.copy(), val=val.copy(),
                     y=y.copy(), offset=off.copy(), weight=None if w is None else w.copy(), uid=uid.copy(), entity_ids=ids,

@@ -1,5 +1,4 @@
 """Per-phase timing of the team kernels (library built with -DGDMIX_TEAM_PROFILE prints from the device)."""
-import numpy as np
 import torch
 from gdmix_amd import synthetic
 from gdmix_amd.solver import REDeviceSolver, SolverOptions

@@ -8,7 +8,7 @@ import tempfile
 import time
 
 from gdmix_amd import synthetic
-from gdmix_amd.io import native_reader
+
 from gdmix_amd.io.grouped_reader import read_grouped_partition, write_grouped_partition
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 50000

@@ -4,7 +4,6 @@
 """
 import sys
 
-import numpy as np
 import torch
 
 from gdmix_amd import synthetic

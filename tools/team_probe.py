@@ -1,7 +1,6 @@
 """Per-phase timing of the workgroup-class team kernel under full occupancy (library built with
 GDMIX_EXTRA_FLAGS=-DGDMIX_TEAM_PROFILE prints one line per entity from the device)."""
 import sys
-import numpy as np
 import torch
 from gdmix_amd import synthetic
 from gdmix_amd.solver import REDeviceSolver, SolverOptions
