@@ -56,16 +56,17 @@ def choose_entities(cost, amounts):
     empty); every entity appears at most once; the rest stays."""
     cost = np.asarray(cost, np.float64)
     order = np.argsort(cost, kind="stable")
+    csum = np.concatenate([[0.0], np.cumsum(cost[order])])   # costs are non-zero counts: the sums are exact
     out = []
     pos = 0
     for amt in amounts:
-        take = []
-        acc = 0.0
-        while pos < order.size and amt > 0 and acc + cost[order[pos]] <= amt * 1.0000001:
-            take.append(order[pos])
-            acc += cost[order[pos]]
-            pos += 1
-        out.append(np.sort(np.array(take, np.int64)))
+        end = pos
+        if amt > 0 and pos < order.size:
+            # the longest run order[pos:end] whose total stays within the amount
+            end = int(np.searchsorted(csum, csum[pos] + amt * 1.0000001, side="right")) - 1
+            end = min(max(end, pos), order.size)
+        out.append(np.sort(order[pos:end].astype(np.int64)))
+        pos = end
     return out
 
 
