@@ -102,6 +102,8 @@ class FixedEffectDeviceSolver:
         res = self.solver.solve(packed, opts, theta0=t0).to_host()
         theta = to_global(res["theta"], uniq, num_features, has_intercept, dummy)
         info = {k: res[k][0] for k in ("fval", "nit", "nfev", "status", "gnorm")}
+        if not 0 <= int(info["status"]) <= 4:
+            raise RuntimeError(f"the fixed-effect solve did not finish (device status {int(info['status'])}: 9 = a device barrier timed out)")
         return theta, info
 
 
@@ -186,8 +188,8 @@ def run_stepping_loop(problem, all_reduce=None, max_evals=100000):
             all_reduce(buf)
         status = problem.step()
         if status >= 0:
-            break
-    return status
+            return status
+    raise RuntimeError(f"the fixed-effect L-BFGS loop did not stop within {max_evals} evaluations")
 
 
 def _fit_stepping(self, row_nnz_ptr, col_global, val, y, num_features, offset=None, weight=None, has_intercept=True, l2=1.0,

@@ -482,6 +482,10 @@ class RandomEffectLRLBFGSModel:
             solved = solver.solve(packed, opts, theta0=theta0)
             res = solved.to_host(("theta_thr", "variance") + self._STAT_KEYS)
             theta_thr, variance = res["theta_thr"], res.get("variance")
+            bad = (res["status"] < 0) | (res["status"] > 4)      # 0..4 are fmin_l_bfgs_b's own outcomes
+            if bad.any():
+                raise RuntimeError(f"{int(bad.sum())} of {work.E} entities were not solved (device status "
+                                   f"{sorted(set(res['status'][bad].tolist()))}: 9 = a team barrier timed out, -1 = never reached)")
             theta_dev = getattr(solved, "theta_thr", None)    # still in HBM: what the scoring pass of this partition reads
             stats = {k: res[k] for k in self._STAT_KEYS}
         if rb is not None:
