@@ -534,3 +534,42 @@ def test_model_table_rows_round_trip():
         assert np.array_equal(back[k].theta, t[k].theta) and np.array_equal(back[k].unique_global_indices, t[k].unique_global_indices)
     empty = ModelTable().rows_for(["x"])
     assert not empty["has"].any() and empty["theta"].size == 0
+
+
+def test_entity_id_listed_twice_is_scored_with_its_later_model(tmp_path):
+    """The reference keeps one model per id (dict.update: the later record wins) and scores every record of that id with
+    it. The scoring pass of the partition just trained on normally reuses the solve's own coefficients; with a repeated id
+    it has to go through the model table instead — the scores must equal a cold prediction from the saved model file."""
+    from gdmix_amd import synthetic
+    b = synthetic.make_batch(6, 12, 4, 64, seed=3)
+    b.entity_ids = ["a", "b", "a", "c", "b", "d"]
+    md = {"features": [{"name": "bag", "dtype": "float", "shape": [64], "isSparse": True},
+                       {"name": "offset", "dtype": "float", "shape": [], "isSparse": False},
+                       {"name": "uid", "dtype": "long", "shape": [], "isSparse": False},
+                       {"name": "ent", "dtype": "string", "shape": [], "isSparse": False}],
+          "labels": [{"name": "response", "dtype": "int", "shape": [], "isSparse": False}]}
+    json.dump(md, open(tmp_path / "meta.json", "w"))
+    with open(tmp_path / "features.csv", "w") as f:
+        f.write("".join(f"f{i},\n" for i in range(64)))
+    d = tmp_path / "train" / "partitionId=0"
+    write_grouped_partition(str(d / "part-0.tfrecord"), b, "ent", "bag", weight_column_name=None)
+    argv = ["--uid_column_name", "uid", "--label_column_name", "response", "--output_model_dir", str(tmp_path / "models"),
+            "--metadata_file", str(tmp_path / "meta.json"), "--feature_bag", "bag", "--feature_file", str(tmp_path / "features.csv"),
+            "--partition_entity", "ent", "--regularize_bias", "False"]
+    schema = SchemaParams(uid_column_name="uid", label_column_name="response", prediction_score_column_name="predictionScore")
+    m = RandomEffectLRLBFGSModel(argv)
+    m._solver = OracleSolverDouble()
+    m.train(str(d), None, m.metadata_file, None, {"partition_index": 0, "active_training_output_file": str(tmp_path / "ts.avro")}, schema)
+    models = list(avro.read_file(str(tmp_path / "models" / "part-00000.avro")))
+    assert [r["modelId"] for r in models] == ["a", "b", "c", "d"]               # first position kept, later values
+    m2 = RandomEffectLRLBFGSModel(argv)
+    m2._solver = OracleSolverDouble()
+    m2.predict(str(tmp_path / "cold"), str(d), m2.metadata_file, str(tmp_path / "models"), {"partition_index": 0}, schema)
+    cold = list(avro.read_file(str(tmp_path / "cold" / "part-00000.avro")))
+    assert list(avro.read_file(str(tmp_path / "ts.avro"))) == cold and len(cold) == b.N
+    # the first record of "a" is scored with the model trained on the second one
+    n0 = int(b.ent_row_ptr[1])
+    mean_a = {c["name"]: c["value"] for c in models[0]["means"]}
+    k0, k1 = int(b.row_nnz_ptr[0]), int(b.row_nnz_ptr[1])
+    z = mean_a["(INTERCEPT)"] + sum(float(b.val[k]) * mean_a.get(f"f{int(b.col_global[k])}", 0.0) for k in range(k0, k1)) + float(b.offset[0])
+    assert abs(cold[0]["predictionScore"] - z) < 1e-5 and n0 > 0
