@@ -295,15 +295,15 @@ __global__ __launch_bounds__(FE_THREADS) void fe_dots_kernel(FeDev F, SolveParam
     acc[2] += gj * gj;
     const double yj = gj - rj;
     acc[3] += yj * yj;
-    acc[4] += gj * rj;
+    acc[4] += yj * gj;
     acc[TEAM_K - 1] = fmax(acc[TEAM_K - 1], fabs(gj));
 #pragma unroll
     for (int i = 0; i < TEAM_MCAP; ++i) {
       if (i < col) {
         int sl = head + i;
         if (sl >= m) sl -= m;
-        acc[5 + i] += F.W.ws[(size_t)sl * P + j] * gj;
-        acc[5 + TEAM_MCAP + i] += F.W.wy[(size_t)sl * P + j] * gj;
+        acc[5 + i] += F.W.ws[(size_t)sl * P + j] * yj;
+        acc[5 + TEAM_MCAP + i] += F.W.wy[(size_t)sl * P + j] * yj;
       }
     }
   }

@@ -10,9 +10,12 @@
 namespace gdmix {
 
 constexpr int TEAM_MCAP = 10;                 // history pairs the compact path keeps accumulators for
-constexpr int TEAM_K = 2 * TEAM_MCAP + 6;     // fused reduction width: sq, gd, gg, rr, gr, S'g, Y'g, max|g|
-// acc[] layout: 0 sum x_j^2 over regularised j, 1 g'd, 2 g'g, 3 (g-r)'(g-r), 4 g'r, 5.. S_i'g, 5+MCAP.. Y_i'g
-// (chronological i < col), K-1 max|g_j|.
+constexpr int TEAM_K = 2 * TEAM_MCAP + 6;     // fused reduction width: sq, gd, gg, yy, yg, S'y, Y'y, max|g|
+// acc[] layout, with y = g - r (r = the gradient at the last accepted iterate): 0 sum x_j^2 over regularised j, 1 g'd,
+// 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (chronological i < col), K-1 max|g_j|.
+// The products are taken with y, not with g: S'g and Y'g at the new gradient are the stored ones plus these, and the new
+// column of S'Y / Y'Y is these — sums, where products with g would need differences of nearly equal numbers once the
+// gradient changes little between iterates.
 
 struct CompactState {   // uniform over the cooperating threads
   LineSearch ls;
@@ -48,7 +51,7 @@ __device__ __forceinline__ void compact_advance(CompactState& S, const double (&
                                                 const SolveParams& o, CompactMats& L, CompactPlan& plan) {
   const int m = o.m;
   ++S.nfev;
-  const double gd = acc[1], gg = acc[2], rr = acc[3], gr = acc[4];
+  const double gd = acc[1], gg = acc[2], rr = acc[3], yg = acc[4];
   bool restore = false, store_pair = false, shift = false;
   double dr = 0.0;
   const double stp_prev = S.stp;
@@ -127,26 +130,29 @@ __device__ __forceinline__ void compact_advance(CompactState& S, const double (&
       if (i + 1 < m) { L.ap[i] = pa; L.bp[i] = pb; }
       wave_lds_fence();
     }
-    // S'g, Y'g of row i in chronological order after the shift; products with the new pair in closed form
-    double ai = 0.0, bi = 0.0;
+    // s_i'y, y_i'y of row i in chronological order after the shift (y = g - g_k)
+    double sy_i = 0.0, yy_i = 0.0;
 #pragma unroll
     for (int k = 0; k < TEAM_MCAP; ++k) {
       if (i == k) {
-        if (shift) { if (k + 1 < TEAM_MCAP) { ai = acc[5 + (k + 1 < TEAM_MCAP ? k + 1 : k)]; bi = acc[5 + TEAM_MCAP + (k + 1 < TEAM_MCAP ? k + 1 : k)]; } }
-        else { ai = acc[5 + k]; bi = acc[5 + TEAM_MCAP + k]; }
+        if (shift) { if (k + 1 < TEAM_MCAP) { sy_i = acc[5 + (k + 1 < TEAM_MCAP ? k + 1 : k)]; yy_i = acc[5 + TEAM_MCAP + (k + 1 < TEAM_MCAP ? k + 1 : k)]; } }
+        else { sy_i = acc[5 + k]; yy_i = acc[5 + TEAM_MCAP + k]; }
       }
     }
+    // S'g, Y'g at the new gradient: the stored products at g_k plus the products with y; the new pair in closed form
+    const int old_rows = store_pair ? cnew : col;
+    double ai = 0.0, bi = 0.0;
+    if (i < old_rows && !restore) { ai = L.ap[i] + sy_i; bi = L.bp[i] + yy_i; }
     if (store_pair) {
       if (i < cnew) {
-        L.SY[i * TEAM_MCAP + cnew] = ai - L.ap[i];   // s_i'(g - g_k)
-        const double yy = bi - L.bp[i];              // y_i'(g - g_k)
-        L.YY[i * TEAM_MCAP + cnew] = yy;
-        L.YY[cnew * TEAM_MCAP + i] = yy;
+        L.SY[i * TEAM_MCAP + cnew] = sy_i;
+        L.YY[i * TEAM_MCAP + cnew] = yy_i;
+        L.YY[cnew * TEAM_MCAP + i] = yy_i;
       } else if (i == cnew) {
         L.SY[cnew * TEAM_MCAP + cnew] = dr;
         L.YY[cnew * TEAM_MCAP + cnew] = rr;
         ai = stp_prev * gd;   // s'g,  s = stp d
-        bi = gg - gr;         // y'g,  y = g - g_k
+        bi = yg;              // y'g
       }
       wave_lds_fence();
     }

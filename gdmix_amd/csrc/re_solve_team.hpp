@@ -198,7 +198,7 @@ __device__ __forceinline__ double gather_dot8(const float* __restrict__ val, con
 }
 
 // f, g and every dot product the driver needs, at W.x. acc[] layout: 0 sum x_j^2 over regularised j,
-// 1 g'd, 2 g'g, 3 (g-r)'(g-r), 4 g'r, 5.. S_i'g, 5+MCAP.. Y_i'g (chronological i < col), K-1 max|g_j|.
+// 1 g'd, 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (y = g - r; chronological i < col), K-1 max|g_j|.
 template <int NW>
 __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W,
                                             int col, int head, double (&acc)[TEAM_K]
@@ -377,15 +377,15 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
       acc[2] += gj * gj;
       const double yj = gj - rj;
       acc[3] += yj * yj;
-      acc[4] += gj * rj;
+      acc[4] += yj * gj;
       acc[TEAM_K - 1] = fmax(acc[TEAM_K - 1], fabs(gj));
 #pragma unroll
       for (int i = 0; i < TEAM_MCAP; ++i) {
         if (i < col) {
           int sl = head + i;
           if (sl >= m) sl -= m;
-          acc[5 + i] += W.ws[(size_t)sl * p + j] * gj;
-          acc[5 + TEAM_MCAP + i] += W.wy[(size_t)sl * p + j] * gj;
+          acc[5 + i] += W.ws[(size_t)sl * p + j] * yj;
+          acc[5 + TEAM_MCAP + i] += W.wy[(size_t)sl * p + j] * yj;
         }
       }
     }

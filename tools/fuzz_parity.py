@@ -70,8 +70,9 @@ for case in range(cases):
     # stops up to 1e-3 away. Those entities are compared against that sensitivity, the stable ones strictly.
     sens = np.zeros(b.E)
     stable = np.ones(b.E, bool)
-    for j in range(3):   # the divergence is chaotic: a few samples of it
-        jig = 1e-15 * np.random.default_rng(j + 1).standard_normal(int(packed.P))
+    for j, mag in enumerate((1e-15, 1e-14, 1e-13)):   # the divergence is chaotic: a few samples of it, up to the size of the
+        # difference between two summation orders over 1e4 .. 1e5 samples (which is what the device and the oracle differ by)
+        jig = mag * np.random.default_rng(j + 1).standard_normal(int(packed.P))
         pert = oracle.solve(pk, b.val, b.y, b.offset, b.weight, oracle.make_opts(**kw), theta0=jig if th0 is None else th0 * (1.0 + jig))
         sj = per_entity_rel_err(pert["theta"], ref["theta"], coef_ptr)
         sens = np.maximum(sens, sj)
