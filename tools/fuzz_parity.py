@@ -108,6 +108,13 @@ for case in range(cases):
         k = np.flatnonzero(unstable_bad)
         problems.append(f"{k.size} rounding-sensitive entities are further off than the oracle's own sensitivity explains, e.g. {k[:3]}: "
                         f"err {err[k[:3]]} sensitivity {sens[k[:3]]}")
+    # scoring pass with the oracle's coefficients and a random set of entities without a model
+    hm = (rng.random(b.E) < 0.85).astype(np.uint8) if rng.random() < 0.5 else None
+    lo_d, pc_d = solver.score(packed, ref["theta"], hm)
+    lo_o, pc_o = oracle.score(pk, b.val, b.offset, ref["theta"], has_intercept, hm)
+    fin = np.isfinite(lo_o)
+    if not np.allclose(lo_d.cpu().numpy()[fin], lo_o[fin], rtol=3e-6, atol=3e-6) or not np.allclose(pc_d.cpu().numpy()[fin], pc_o[fin], rtol=3e-5, atol=3e-5):
+        problems.append("scores differ")
     worst = max(worst, float(err[wp].max()) if wp.any() else 0.0)
     tag = "ok " if not problems else "BAD"
     if problems:
