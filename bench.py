@@ -234,7 +234,7 @@ def main():
                    "what": "pinned host raw batch -> H2D -> pack -> solve -> D2H thresholded theta, one stream, no overlap"}
         # the scoring pass over the same resident batch (the path's HBM-bound stream; not part of `value`)
         score = None
-        if not a.no_e2e:
+        if not a.no_e2e and world == 1:
             th = out["theta_thr"]
             for _ in range(2):
                 solver.score(packed, th)
@@ -250,7 +250,7 @@ def main():
                      "frac_of_hbm_peak": sbytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "what": "gdmix_re_score: logits of every sample, 8 B/nnz + 16 B/sample + 8 B/coefficient + pointers"}
         cpu = None
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             sample = a.cpu_sample if a.cpu_sample > 0 else min(batch.E, 200_000)
             v, cores, es, d, passes = cpu_baseline(batch, opts_kw, sample)
             cpu = {"value": round(v, 1), "unit": "entities/s", "cores": cores, "kind": "port",
