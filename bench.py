@@ -180,6 +180,10 @@ def main():
         p = np.diff(packed.coef_ptr_host())
         b_e = 8.0 * z + 16.0 * n + 8.0 * p + 32.0                    # B(e), SURVEY.md §8(d)
         alg_bytes = float(b_e.sum())
+        # parity classes of SURVEY.md §8(d): W = both labels present (a finite optimum exists with the unregularised intercept),
+        # D = all labels equal (the solver runs until the gradient test passes; only invariants are comparable)
+        n1 = np.add.reduceat(batch.y.astype(np.float64), batch.ent_row_ptr[:-1]) if batch.N else np.zeros(batch.E)
+        well_posed = int(((n1 > 0) & (n1 < n)).sum())
         classes = solver.class_counts(packed)
         cls = packed._view(packed.c.cls_tmp, packed.E, torch.int32).cpu().numpy()
         cls_ms = kernel_ms / a.steps
@@ -271,7 +275,7 @@ def main():
                        "solve_kernel_ms_per_step": float(kernel_ms.sum()) / a.steps,
                        "classes": classes, "class_ms": [round(float(x) / a.steps, 3) for x in kernel_ms],
                        "mean_nit": nit, "mean_nfev": nfev,
-                       "converged_per_step": converged_all, "N": batch.N, "Z": batch.Z, "P": packed.P,
+                       "converged_per_step": converged_all, "parity_classes": {"W": well_posed, "D": int(batch.E - well_posed)}, "N": batch.N, "Z": batch.Z, "P": packed.P,
                        "host_generate_s": t_gen, "host_handover": e2e, "score_pass": score,
                        "restreamed_bytes_per_step": b_stream,
                        "restreamed_GBps": b_stream / (float(kernel_ms.sum()) / a.steps * 1e-3) / 1e9 if kernel_ms.sum() else None},

@@ -23,7 +23,7 @@ import os
 
 import numpy as np
 
-from .batch import RawBatch
+from .batch import RawBatch, _ranges
 from .io.grouped_reader import write_grouped_partition
 
 ACTIVE, PASSIVE = "active", "passive"
@@ -155,11 +155,10 @@ def build_batches(entity, uid, label, offset, weight, row_nnz_ptr, col_global, v
             continue
         for p in np.unique(pid[sub == s]):
             recs = np.flatnonzero((sub == s) & (pid == p))
-            rows = np.concatenate([order[ptr[r]:ptr[r + 1]] for r in recs]) if recs.size else np.zeros(0, np.int64)
             n = (ptr[recs + 1] - ptr[recs]).astype(np.int64)
+            rows = order[_ranges(ptr[recs], n)]
             kk = k[rows]
-            starts = rnp[rows]
-            nz = np.concatenate([np.arange(a, a + c) for a, c in zip(starts, kk)]) if rows.size else np.zeros(0, np.int64)
+            nz = _ranges(rnp[rows], kk)
             out[(name, int(p))] = RawBatch(
                 ent_row_ptr=np.concatenate([[0], np.cumsum(n)]).astype(np.int64),
                 row_nnz_ptr=np.concatenate([[0], np.cumsum(kk)]).astype(np.int64),
