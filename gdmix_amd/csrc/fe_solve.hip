@@ -434,6 +434,36 @@ __global__ void fe_tile_gather_kernel(const uint32_t* __restrict__ perm, const i
 
 using namespace gdmix;
 
+// ---- scoring ----------------------------------------------------------------------------------------------------------
+// logits of every sample of a raw shard under a global coefficient vector (intercept last): one thread per sample straight
+// off the sample-major arrays the reader produced — no pack, no column copy; the coefficient vector (8 B x features) is
+// gathered from L2. Sums in row order, starting from the intercept, as the packed scoring pass does.
+__global__ __launch_bounds__(256) void fe_score_kernel(int64_t n, const int64_t* __restrict__ row_nnz_ptr,
+                                                       const int64_t* __restrict__ col_global, const float* __restrict__ val,
+                                                       const float* __restrict__ offset, const double* __restrict__ theta,
+                                                       int64_t D, int ic, float* __restrict__ score, float* __restrict__ per_coord) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double acc = ic ? theta[D] : 0.0;
+  if (row_nnz_ptr) {
+    int64_t k = row_nnz_ptr[i];
+    const int64_t k1 = row_nnz_ptr[i + 1];
+    for (; k + 4 <= k1; k += 4) {
+      const float v0 = val[k], v1 = val[k + 1], v2 = val[k + 2], v3 = val[k + 3];
+      const double t0 = theta[col_global[k]], t1 = theta[col_global[k + 1]], t2 = theta[col_global[k + 2]], t3 = theta[col_global[k + 3]];
+      acc += (double)v0 * t0;
+      acc += (double)v1 * t1;
+      acc += (double)v2 * t2;
+      acc += (double)v3 * t3;
+    }
+    for (; k < k1; ++k) acc += (double)val[k] * theta[col_global[k]];
+  }
+  const double off = offset ? (double)offset[i] : 0.0;
+  const double z = acc + off;
+  score[i] = (float)z;
+  per_coord[i] = (float)(z - off);
+}
+
 struct gdmix_fe_problem {
   gdmix_re_ctx* ctx;
   FeDev F;
@@ -647,6 +677,21 @@ GDMIX_API int gdmix_fe_result(gdmix_fe_problem* p, double* theta, double* fval, 
   if (gnorm) *gnorm = S.sbgnrm;
   if (nit) *nit = S.nit;
   if (nfev) *nfev = S.nfev;
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_fe_score(gdmix_re_ctx* ctx, int64_t n, const int64_t* row_nnz_ptr, const int64_t* col_global, const float* val,
+                             const float* offset, const double* theta, int64_t num_features, int has_intercept, float* score,
+                             float* per_coord, void* stream) {
+  if (!ctx || n < 0 || !theta || !score || !per_coord || num_features < 0) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
+  if (row_nnz_ptr && (!col_global || !val)) { set_error("row_nnz_ptr without col_global / val"); return GDMIX_RE_EINVAL; }
+  if (n == 0) return GDMIX_RE_OK;
+  HIP_TRY(hipSetDevice(ctx->impl.device));
+  const int64_t blocks = (n + 255) / 256;
+  if (blocks > 0x7fffffffLL) { set_error("too many samples for one launch"); return GDMIX_RE_ERANGE; }
+  hipLaunchKernelGGL(fe_score_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), n, row_nnz_ptr,
+                     col_global, val, offset, theta, num_features, has_intercept ? 1 : 0, score, per_coord);
+  HIP_TRY(hipGetLastError());
   return GDMIX_RE_OK;
 }
 

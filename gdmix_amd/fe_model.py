@@ -225,14 +225,18 @@ class FixedEffectLRModelLBFGS:
             per_coord = np.zeros(0, np.float32)
         else:
             fe = self._solver()
-            batch, dummy = shard_as_batch(data["row_nnz_ptr"] if bag else np.zeros(n + 1, np.int64), data["col"] if bag else [],
-                                          data["val"] if bag else [], np.zeros(n, np.float32), data["offset"], None, self.has_intercept)
-            packed = fe.solver.pack(batch, has_intercept=self.has_intercept)
-            uniq = packed.unique_global().cpu().numpy()
-            th = theta if bag else theta[1:]
-            local = to_local(th, uniq, self.num_features if bag else 0, self.has_intercept, dummy)
-            logit, per = fe.solver.score(packed, local)
-            per_coord = per.cpu().numpy()
+            if hasattr(fe, "score"):      # the device path: one pass over the sample-major arrays, no pack
+                _, per_coord = fe.score(data["row_nnz_ptr"] if bag else None, data["col"] if bag else None, data["val"] if bag else None,
+                                        data["offset"], theta if bag else theta[1:], self.num_features if bag else 0, self.has_intercept)
+            else:
+                batch, dummy = shard_as_batch(data["row_nnz_ptr"] if bag else np.zeros(n + 1, np.int64), data["col"] if bag else [],
+                                              data["val"] if bag else [], np.zeros(n, np.float32), data["offset"], None, self.has_intercept)
+                packed = fe.solver.pack(batch, has_intercept=self.has_intercept)
+                uniq = packed.unique_global().cpu().numpy()
+                th = theta if bag else theta[1:]
+                local = to_local(th, uniq, self.num_features if bag else 0, self.has_intercept, dummy)
+                logit, per = fe.solver.score(packed, local)
+                per_coord = per.cpu().numpy()
         score = (per_coord.astype(np.float64) + data["offset"].astype(np.float64)).astype(np.float32)
         self._write_inference_result(data["uid"], data["y"] if data["has_label"] else None,
                                      data["weight"] if data["has_weight"] else None, score, per_coord, task_index, schema_params,

@@ -82,6 +82,10 @@ class FixedEffectDeviceSolver:
     def __init__(self, device=0, solver=None):
         self.solver = solver or REDeviceSolver(device)
 
+    def score(self, row_nnz_ptr, col_global, val, offset, theta, num_features, has_intercept=True):
+        """-> (score, per-coordinate score) of every sample under theta (intercept last); see device_score."""
+        return device_score(self.solver, row_nnz_ptr, col_global, val, offset, theta, num_features, has_intercept)
+
     def fit(self, row_nnz_ptr, col_global, val, y, num_features, offset=None, weight=None, has_intercept=True, l2=1.0,
             regularize_bias=True, model_type=LOGISTIC_REGRESSION, theta0=None, max_iter=100, m=10, tolerance=1e-12):
         """-> (theta [num_features + has_intercept], intercept last; info dict with f, nit, nfev, status, gnorm)."""
@@ -105,6 +109,30 @@ class FixedEffectDeviceSolver:
         if not 0 <= int(info["status"]) <= 4:
             raise RuntimeError(f"the fixed-effect solve did not finish (device status {int(info['status'])}: 9 = a device barrier timed out)")
         return theta, info
+
+
+def device_score(solver, row_nnz_ptr, col_global, val, offset, theta, num_features, has_intercept):
+    """(score, per-coordinate score) float32 numpy arrays of every sample: x . w + b (+ offset). theta: [num_features +
+    has_intercept], intercept last. The shard is read once off its sample-major arrays (gdmix_fe_score): no pack."""
+    t = solver.torch
+    n = (len(row_nnz_ptr) - 1) if row_nnz_ptr is not None else len(offset)
+    dev = solver.device
+    up = lambda a, dt: None if a is None else t.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
+    rp, cg, vl = up(row_nnz_ptr, np.int64), up(col_global, np.int64), up(val, np.float32)
+    if cg is not None and cg.numel() and (int(cg.min()) < 0 or int(cg.max()) >= num_features):
+        raise ValueError(f"feature index outside [0, {num_features})")
+    of = up(offset, np.float32)
+    th = up(theta, np.float64)
+    assert th.numel() == num_features + (1 if has_intercept else 0)
+    score = t.empty(n, dtype=t.float32, device=dev)
+    per = t.empty(n, dtype=t.float32, device=dev)
+    ptr = lambda x: None if x is None or x.numel() == 0 else x.data_ptr()
+    rc = solver.lib.gdmix_fe_score(solver._h, n, None if cg is None or cg.numel() == 0 else rp.data_ptr(), ptr(cg), ptr(vl), ptr(of),
+                                   th.data_ptr(), int(num_features), int(bool(has_intercept)), ptr(score), ptr(per), solver._stream())
+    if rc != 0:
+        from .solver import GdmixReError
+        raise GdmixReError("gdmix_fe_score: " + solver.lib.gdmix_re_last_error().decode())
+    return score.cpu().numpy(), per.cpu().numpy()
 
 
 class _SteppingProblem:

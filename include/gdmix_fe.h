@@ -57,6 +57,16 @@ GDMIX_API int gdmix_fe_step(gdmix_fe_problem* p, void* stream, int32_t* status);
 GDMIX_API int gdmix_fe_result(gdmix_fe_problem* p, double* theta, double* fval, double* gnorm, int32_t* nit,
                               int32_t* nfev, void* stream);
 
+/* Scores of a raw shard under a global coefficient vector: replaces _predict / the scoring after training
+ *   gdmix-trainer/src/gdmix/models/custom/fixed_effect_lr_lbfgs_model.py:214-306,406-440
+ * score_i = x_i . w + b + offset_i, per_coord_i = score_i - offset_i, stored as float (the reference's Avro `float`). All
+ * pointers are device pointers: row_nnz_ptr [n+1] / col_global / val are the sample-major arrays of the reader (NULL,
+ * NULL, NULL for a model without a feature bag), offset [n] or NULL, theta [num_features + has_intercept] with the
+ * intercept last. No pack is needed: the pass reads the shard once. Feature indices must lie in [0, num_features). */
+GDMIX_API int gdmix_fe_score(gdmix_re_ctx* ctx, int64_t n, const int64_t* row_nnz_ptr, const int64_t* col_global, const float* val,
+                             const float* offset, const double* theta, int64_t num_features, int has_intercept, float* score,
+                             float* per_coord, void* stream);
+
 /* Optional timing of the last gdmix_fe_eval (HIP events on the launch stream): ms of the CSR pass, the CSC pass. */
 GDMIX_API int gdmix_fe_last_eval_ms(gdmix_fe_problem* p, float* rows_ms, float* cols_ms);
 

@@ -192,3 +192,42 @@ def test_device_fixed_effect_at_scale_against_oracle(device_solver):
                                     model_type=fe.LINEAR_REGRESSION if linear else fe.LOGISTIC_REGRESSION, max_iter=200)
         assert info2["status"] == info["status"]
         assert rel_err(th2, th_o) <= 1e-5, rel_err(th2, th_o)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("has_intercept", [True, False])
+def test_device_scoring_of_a_raw_shard(device_solver, has_intercept):
+    """gdmix_fe_score: one pass over the sample-major arrays (ragged rows, empty rows, no pack) equals the host sum, and the
+    packed scoring pass it replaced, to float rounding."""
+    rng = np.random.default_rng(9)
+    n, D = 5000, 3000
+    k = rng.integers(0, 30, n)
+    k[:2] = 0
+    k[-1] = 0
+    k[7] = 2500
+    rp = np.concatenate([[0], np.cumsum(k)]).astype(np.int64)
+    cols = rng.integers(0, D, rp[-1])
+    vals = rng.standard_normal(rp[-1]).astype(np.float32)
+    off = rng.standard_normal(n).astype(np.float32)
+    theta = rng.standard_normal(D + (1 if has_intercept else 0))
+    s = fe.FixedEffectDeviceSolver(solver=device_solver)
+    score, per = s.score(rp, cols, vals, off, theta, D, has_intercept)
+    want = np.zeros(n)
+    np.add.at(want, np.repeat(np.arange(n), k), vals.astype(np.float64) * theta[cols])
+    if has_intercept:
+        want += theta[D]
+    np.testing.assert_allclose(per, want.astype(np.float32), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(score, (want + off).astype(np.float32), rtol=2e-5, atol=2e-5)
+    # the path it replaced: pack the shard as one entity and score in the local index space
+    batch, dummy = fe.shard_as_batch(rp, cols, vals, np.zeros(n, np.float32), off, None, has_intercept)
+    packed = device_solver.pack(batch, has_intercept=has_intercept)
+    local = fe.to_local(theta, packed.unique_global().cpu().numpy(), D, has_intercept, dummy)
+    lo, pc = device_solver.score(packed, local)
+    np.testing.assert_array_equal(score, lo.cpu().numpy())
+    np.testing.assert_array_equal(per, pc.cpu().numpy())
+    # no feature bag (intercept-only model), no offset
+    if has_intercept:
+        sc, pe = s.score(None, None, None, off, theta[D:], 0, True)
+        np.testing.assert_allclose(pe, np.full(n, theta[D], np.float32), rtol=1e-7)
+    with pytest.raises(ValueError):
+        s.score(rp, np.where(cols == cols[0], D, cols), vals, off, theta, D, has_intercept)
