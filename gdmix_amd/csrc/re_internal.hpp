@@ -150,10 +150,11 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
 struct BigPackArgs {
   const int64_t* ent_row_ptr;
   const int64_t* ent_nnz_ptr;
+  const int64_t* row_nnz_ptr;
   const int64_t* col_global;
   const float* val;
   int ic;
-  const int32_t* row_ptr;
+  int32_t* row_ptr;
   int32_t* csr_col;
   int32_t* col_ptr;
   int32_t* csc_row;

@@ -169,15 +169,25 @@ __global__ __launch_bounds__(WAVE* NWAVES) void pack_entity_kernel(
     }
     const int n = (int)n64, nnz = (int)nnz64;
     const bool small = nnz <= CAP && n <= CAP;
+    if (!small) {
+      // too large for this kernel's LDS staging: deferred to the next pack stage, which also writes its row pointers (one
+      // wavefront walking the rows of a 4 M-sample entity here cost 27 ms; the last stage does it one thread per row)
+      if (lane == 0) {
+        out_list[atomicAdd(out_count, 1)] = (int32_t)e;
+        if (out_nnz) atomicAdd(out_nnz, (unsigned long long)nnz);
+      }
+      mx_n = max(mx_n, n); mx_z = max(mx_z, nnz);
+      continue;
+    }
     int32_t* const rp_out = row_ptr + r0 + e;
     for (int i = lane; i <= n; i += WAVE) {
       const int32_t v = (int32_t)(row_nnz_ptr[r0 + i] - z0);
       rp_out[i] = v;
-      if (small) lds_rp[wv][i] = v;
+      lds_rp[wv][i] = v;
     }
     bool bad = false;
     int d;
-    if (small) {
+    {
       // explicit LDS instantiation (ds_* accesses; a generic pointer selecting between LDS and HBM compiles
       // to flat_* accesses whose base+offset folding faults at the LDS aperture edge)
       for (int k = lane; k < nnz; k += WAVE) {
@@ -196,14 +206,6 @@ __global__ __launch_bounds__(WAVE* NWAVES) void pack_entity_kernel(
         d = emit_entity(lds_keys[wv], lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0, col_ptr + z0 + e,
                         csc_row + z0, csc_val + z0, uniq_sparse + z0);
       }
-    } else {
-      // too large for this kernel's LDS staging: deferred to the next pack kernel
-      if (lane == 0) {
-        out_list[atomicAdd(out_count, 1)] = (int32_t)e;
-        if (out_nnz) atomicAdd(out_nnz, (unsigned long long)nnz);
-      }
-      mx_n = max(mx_n, n); mx_z = max(mx_z, nnz);
-      continue;
     }
     if (__ballot(bad) && lane == 0) atomicExch(&stats->err, GDMIX_RE_ERANGE);
     if (lane == 0) d_cnt[e] = d;
@@ -429,7 +431,7 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
     HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(PackStats), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (hs->n_big > 0) {
-      BigPackArgs A{raw->ent_row_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, ic, out->row_ptr, out->csr_col,
+      BigPackArgs A{raw->ent_row_ptr, out->ent_nnz_ptr, raw->row_nnz_ptr, raw->col_global, raw->val, ic, out->row_ptr, out->csr_col,
                     out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, big_list, hs->n_big,
                     (int64_t)hs->big_nnz, &stats->max_p, &stats->err};
       const int rc = pack_big_entities(ctx, A, s);

@@ -62,6 +62,38 @@ __global__ __launch_bounds__(256) void big_fill_kernel(const int64_t* __restrict
   if (bad) atomicExch(err, GDMIX_RE_ERANGE);
 }
 
+// rows[b] = samples of big entity b + 1 (its row-pointer entries)
+__global__ void big_rowcount_kernel(const int64_t* __restrict__ ent_row_ptr, const int32_t* __restrict__ big_list, int n_big,
+                                    int64_t* __restrict__ rows) {
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < n_big; b += gridDim.x * blockDim.x) {
+    const int64_t e = big_list[b];
+    rows[b] = ent_row_ptr[e + 1] - ent_row_ptr[e] + 1;
+  }
+}
+
+// One thread per row-pointer entry of the big entities: the entity-relative row pointers (which the wavefront pack kernels
+// write for their own entities) and, for the emit pass, the row of every raw position.
+__global__ __launch_bounds__(256) void big_rows_kernel(BigPackArgs a, const int64_t* __restrict__ offs,
+                                                       const int64_t* __restrict__ row_offs, const int64_t* __restrict__ rows,
+                                                       uint32_t* __restrict__ row_of) {
+  const int nb = a.n_big;
+  const int64_t total = row_offs[nb - 1] + rows[nb - 1];
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < total; r += (int64_t)gridDim.x * blockDim.x) {
+    const int b = big_find(row_offs, nb, r);
+    const int64_t i = r - row_offs[b];
+    const int64_t e = a.big_list[b];
+    const int64_t r0 = a.ent_row_ptr[e], z0 = a.ent_nnz_ptr[e];
+    const int64_t n = a.ent_row_ptr[e + 1] - r0;
+    const int64_t k0 = a.row_nnz_ptr[r0 + i] - z0;
+    a.row_ptr[r0 + e + i] = (int32_t)k0;
+    if (i < n) {
+      const int64_t k1 = a.row_nnz_ptr[r0 + i + 1] - z0;
+      uint32_t* const dst = row_of + offs[b];
+      for (int64_t k = k0; k < k1; ++k) dst[k] = (uint32_t)i;
+    }
+  }
+}
+
 // head[i] = 1 where a new (entity, column) run starts in the sorted keys
 __global__ __launch_bounds__(256) void big_heads_kernel(const unsigned long long* __restrict__ keys, int64_t total,
                                                         int32_t* __restrict__ head) {
@@ -72,14 +104,13 @@ __global__ __launch_bounds__(256) void big_heads_kernel(const unsigned long long
 __global__ __launch_bounds__(256) void big_emit_kernel(BigPackArgs a, const int64_t* __restrict__ offs, int64_t total,
                                                        const unsigned long long* __restrict__ keys,
                                                        const uint32_t* __restrict__ vals, const int32_t* __restrict__ head,
-                                                       const int64_t* __restrict__ scan) {
+                                                       const int64_t* __restrict__ scan, const uint32_t* __restrict__ row_of) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const unsigned long long key = keys[i];
     const int b = (int)(key >> 32);
     const int64_t e = a.big_list[b];
-    const int64_t z0 = a.ent_nnz_ptr[e], r0 = a.ent_row_ptr[e];
+    const int64_t z0 = a.ent_nnz_ptr[e];
     const int nnz = (int)(a.ent_nnz_ptr[e + 1] - z0);
-    const int n = (int)(a.ent_row_ptr[e + 1] - r0);
     const int64_t o = offs[b];
     const int k = (int)(i - o);             // position in the entity's CSC order
     const int pos = (int)vals[i];           // position in the entity's CSR (raw) order
@@ -89,13 +120,7 @@ __global__ __launch_bounds__(256) void big_emit_kernel(BigPackArgs a, const int6
     if (h) { a.uniq_sparse[z0 + lid] = (int32_t)(uint32_t)key; cp[lid] = k; }
     a.csr_col[z0 + pos] = lid;
     a.csc_val[z0 + k] = a.val[z0 + pos];
-    const int32_t* rp = a.row_ptr + r0 + e;
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (rp[mid] <= pos) lo = mid; else hi = mid - 1;
-    }
-    a.csc_row[z0 + k] = lo;
+    a.csc_row[z0 + k] = (int32_t)row_of[o + pos];   // filled by big_rows_kernel (a bisection of the row pointers per entry before)
     if (k == nnz - 1) {
       const int d = lid + 1;
       cp[d] = nnz;
@@ -131,6 +156,7 @@ int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s) 
   const size_t o_vals_a = take((size_t)T * 4), o_vals_b = take((size_t)T * 4);
   const size_t o_head = take((size_t)T * 4), o_scan = take((size_t)T * 8);
   const size_t o_sizes = take((size_t)(nb + 1) * 8), o_offs = take((size_t)(nb + 1) * 8);
+  const size_t o_rows = take((size_t)(nb + 1) * 8), o_row_offs = take((size_t)(nb + 1) * 8);
   const size_t o_lib = take(lib_tmp);
   if (ctx->big_tmp_bytes < off) {
     HIP_TRY(hipStreamSynchronize(s));
@@ -153,6 +179,8 @@ int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s) 
   int64_t* scan = reinterpret_cast<int64_t*>(base + o_scan);
   int64_t* sizes = reinterpret_cast<int64_t*>(base + o_sizes);
   int64_t* offs = reinterpret_cast<int64_t*>(base + o_offs);
+  int64_t* rows = reinterpret_cast<int64_t*>(base + o_rows);
+  int64_t* row_offs = reinterpret_cast<int64_t*>(base + o_row_offs);
   void* lib = base + o_lib;
 
   int grid = (nb + 255) / 256;
@@ -168,7 +196,13 @@ int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s) 
   hipLaunchKernelGGL(big_heads_kernel, dim3(grid), dim3(256), 0, s, keys_b, T, head);
   tmp = lib_tmp;
   HIP_TRY((rocprim::exclusive_scan(lib, tmp, head, scan, (int64_t)0, (size_t)T, rocprim::plus<int64_t>(), s)));
-  hipLaunchKernelGGL(big_emit_kernel, dim3(grid), dim3(256), 0, s, a, offs, T, keys_b, vals_b, head, scan);
+  // row pointers of these entities and the row of every raw position; the sort's input values are free again
+  uint32_t* row_of = vals_a;
+  hipLaunchKernelGGL(big_rowcount_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, a.ent_row_ptr, a.big_list, nb, rows);
+  tmp = lib_tmp;
+  HIP_TRY((rocprim::exclusive_scan(lib, tmp, rows, row_offs, (int64_t)0, (size_t)nb, rocprim::plus<int64_t>(), s)));
+  hipLaunchKernelGGL(big_rows_kernel, dim3(ctx->num_cus * 32), dim3(256), 0, s, a, offs, row_offs, rows, row_of);
+  hipLaunchKernelGGL(big_emit_kernel, dim3(grid), dim3(256), 0, s, a, offs, T, keys_b, vals_b, head, scan, row_of);
   HIP_TRY(hipGetLastError());
   return GDMIX_RE_OK;
 }
