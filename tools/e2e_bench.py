@@ -1,7 +1,7 @@
 """End to end through the drop-in CLI on one MI355X: TFRecord partitions on disk -> python -m gdmix_amd.gdmix
 --stage=random_effect --action=train -> photon-ml model Avro + score Avro, with the time of each phase.
 
-    PYTHONPATH=. python tools/e2e_bench.py [entities] [partitions]
+    PYTHONPATH=. python tools/e2e_bench.py [entities] [partitions] [c2|zipf]
 
 C2-shaped entities (n ~ Poisson(16), k = 4, D = 1024). The phases are timed by wrapping the model's own methods;
 nothing is skipped: the active training data is read a second time for scoring, as the reference does.
@@ -21,7 +21,9 @@ from gdmix_amd.io.grouped_reader import write_grouped_partition
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 parts = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-md = {"features": [{"name": "bag", "dtype": "float", "shape": [1024], "isSparse": True},
+SHAPE = sys.argv[3] if len(sys.argv) > 3 else "c2"      # c2 | zipf (C5-shaped: Zipf sizes, k = 8, D = 65536)
+DIM = 1024 if SHAPE == "c2" else 65536
+md = {"features": [{"name": "bag", "dtype": "float", "shape": [DIM], "isSparse": True},
                    {"name": "offset", "dtype": "float", "shape": [], "isSparse": False},
                    {"name": "uid", "dtype": "long", "shape": [], "isSparse": False},
                    {"name": "ent", "dtype": "string", "shape": [], "isSparse": False}],
@@ -75,7 +77,7 @@ if os.environ.get("E2E_DETAIL"):     # attribute the device-side calls (adds syn
 
 with tempfile.TemporaryDirectory() as d:
     t = time.perf_counter()
-    b = synthetic.make_batch(E, 16, 4, 1024, seed=1)
+    b = synthetic.make_batch(E, 16, 4, 1024, seed=1) if SHAPE == "c2" else synthetic.make_batch(E, 32, 8, DIM, seed=synthetic.C5_SEED, size_dist="zipf")
     per = (E + parts - 1) // parts
     for k in range(parts):
         sub = b.select(np.arange(k * per, min(E, (k + 1) * per)))
@@ -83,7 +85,7 @@ with tempfile.TemporaryDirectory() as d:
                                 weight_column_name=None)
     json.dump(md, open(os.path.join(d, "meta.json"), "w"))
     with open(os.path.join(d, "features.csv"), "w") as f:
-        f.write("".join(f"f{i},\n" for i in range(1024)))
+        f.write("".join(f"f{i},\n" for i in range(DIM)))
     open(os.path.join(d, "plist.txt"), "w").write(",".join(str(k) for k in range(parts)))
     size = sum(os.path.getsize(os.path.join(r, x)) for r, _, fs in os.walk(os.path.join(d, "train")) for x in fs)
     print(f"{E} entities, {b.N} samples, {b.Z} nnz in {parts} partitions, {size / 1e6:.0f} MB of TFRecord "
