@@ -728,6 +728,11 @@ static hipError_t launch_team_block(const BatchDev& B, const OutDev& O, const So
                                     int begin, int count, double* scratch, size_t slot_doubles, int slots,
                                     int64_t max_p, hipStream_t s) {
   int grid = count < slots ? count : slots;
+  // largest first (workgroups start in index order and take the next entity as they finish): a big entity started last
+  // would be the tail of the launch
+  if (count > 1 && count <= SORT_CAP)
+    hipLaunchKernelGGL(re_sort_class_kernel, dim3(1), dim3(1024), 0, s, const_cast<int32_t*>(B.order) + begin, count,
+                       B.ent_nnz_ptr);
   hipLaunchKernelGGL((re_solve_team_kernel<NW, false>), dim3(grid), dim3(WAVE * NW), 0, s, B, O, o, theta0, begin,
                      count, scratch, slot_doubles, max_p, static_cast<TeamSync*>(nullptr), 1);
   return hipGetLastError();
@@ -760,10 +765,9 @@ hipError_t launch_solve_grid(const BatchDev& B, const OutDev& O, const SolvePara
                                                                WAVE * TEAM_GRID_NW, 0);
   if (err != hipSuccess) return err;
   if (per_cu < 1) return hipErrorLaunchOutOfResources;
-  for (int t = 0; t < teams; ++t) {
-    err = hipMemsetAsync(static_cast<TeamSync*>(sync_buf) + t, 0, 64, s);
-    if (err != hipSuccess) return err;
-  }
+  // the counters at the head of every team's TeamSync, in one call (a memset per team was 128 launches per tier)
+  err = hipMemset2DAsync(sync_buf, sizeof(TeamSync), 0, 64, (size_t)teams, s);
+  if (err != hipSuccess) return err;
   if (count > 1 && count <= SORT_CAP)
     hipLaunchKernelGGL(re_sort_class_kernel, dim3(1), dim3(1024), 0, s, const_cast<int32_t*>(B.order) + begin, count,
                        B.ent_nnz_ptr);
