@@ -390,9 +390,18 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
       const int tier_max = tier == 0 ? 128 : (tier == 1 ? 32 : 8);
       const unsigned long long tot = reinterpret_cast<const unsigned long long*>(hc + 4 * GDMIX_RE_NUM_CLASSES)[cls];
       const unsigned long long big = (unsigned long long)hc[3 * GDMIX_RE_NUM_CLASSES + cls];
+      // teams ~ total work / largest entity's work, as a power of two: rounded down when the tier has many entities (the
+      // barriers of many small teams are the cost); a tier of a handful of entities gets about one team per entity (5
+      // entities of 0.2 .. 0.9 M non-zeros: 9.4 ms on one team of 256 CUs, 6.5 ms on four of 64; a makespan model with
+      // fixed per-CU constants did worse than these two rules on the larger tiers)
       const unsigned long long ratio = big ? tot / big : 1;
       int teams = 1;
       while (teams * 2 <= tier_max && (unsigned long long)(teams * 2) <= ratio) teams *= 2;
+      if (hc[cls] <= 16) {   // a handful: one team per entity, as far as a power of two, the tier and 4x the rule above allow
+        int want = 1;
+        while (want * 2 <= hc[cls] && want * 2 <= tier_max && want * 2 <= teams * 4) want *= 2;
+        if (want > teams) teams = want;
+      }
       if (const char* ev = getenv("GDMIX_RE_TEAMS")) teams = atoi(ev);   // exploration knob
       if (teams > TEAM_MAX_TEAMS) teams = TEAM_MAX_TEAMS;
       while (teams > 1 && (slots < teams || ctx->impl.num_cus % teams)) teams >>= 1;
