@@ -21,7 +21,7 @@ from .io.features import get_feature_map, read_feature_list
 from .io.grouped_reader import read_grouped_partition
 from .io.metadata import DatasetMetadata, read_json_file
 from .params import REParams
-from .solver import REDeviceSolver, SolverOptions, VARIANCE_MODES
+from .solver import REDeviceSolver, SolverOptions, VARIANCE_MODES, host_array
 
 logger = logging.getLogger(__name__)
 logger.setLevel(logging.INFO)
@@ -473,8 +473,8 @@ class RandomEffectLRLBFGSModel:
             stats = {k: np.zeros(0) for k in self._STAT_KEYS}
         else:
             packed = solver.pack(work, has_intercept=self.has_intercept)
-            feat_ptr = packed.ent_feat_ptr().cpu().numpy()
-            uniq = packed.unique_global().cpu().numpy()
+            feat_ptr = host_array(packed.ent_feat_ptr())
+            uniq = host_array(packed.unique_global())
             theta0 = None
             if model_weights:
                 theta0, _ = _model_coefficients_for_batch(model_weights, work.entity_ids, uniq, feat_ptr,
@@ -527,12 +527,12 @@ class RandomEffectLRLBFGSModel:
         solver = self._get_solver()
         if packed is None:
             packed = solver.pack(batch, has_intercept=self.has_intercept)
-            feat_ptr = packed.ent_feat_ptr().cpu().numpy()
-            uniq = packed.unique_global().cpu().numpy()
+            feat_ptr = host_array(packed.ent_feat_ptr())
+            uniq = host_array(packed.unique_global())
             theta, has_model = _model_coefficients_for_batch(model_weights, batch.entity_ids, uniq, feat_ptr,
                                                              self.has_intercept, num_features)
         logit, per_coord = solver.score(packed, theta, has_model)
-        logit, per_coord = logit.cpu().numpy(), per_coord.cpu().numpy()
+        logit, per_coord = host_array(logit), host_array(per_coord)
         weights = batch.weight if batch.weight is not None else np.ones(batch.N, np.float32)
         self._write_behind(output_file, _write_scores, output_file, schema, schema_params, batch.uid, logit, batch.y if batch.has_label else None,
                            weights if has_weight else None, per_coord)

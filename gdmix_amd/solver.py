@@ -237,6 +237,20 @@ class PackedBatch:
         return fp + (np.arange(self.E + 1, dtype=np.int64) if self.has_intercept else 0)
 
 
+def host_array(t):
+    """Device tensor -> numpy array. Large tensors are copied through page-locked memory (torch caches the blocks; the array
+    keeps its block alive): about twice the rate of a copy into pageable memory."""
+    if not getattr(t, "is_cuda", False):
+        return t.cpu().numpy()
+    if t.numel() * t.element_size() < (1 << 20):
+        return t.cpu().numpy()
+    import torch
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return h.numpy()
+
+
 class SolveResult:
     def __init__(self, tensors, E, P):
         self._t = tensors
@@ -251,7 +265,27 @@ class SolveResult:
     def to_host(self, keys=None):
         """numpy copies of the result arrays (all of them, or only `keys`: the unthresholded coefficients are as large as
         the thresholded ones and the model path never reads them)."""
-        return {k: (v.cpu().numpy() if v is not None else None) for k, v in self._t.items() if keys is None or k in keys}
+        out, staged = {}, []
+        for k, v in self._t.items():
+            if keys is not None and k not in keys:
+                continue
+            if v is None:
+                out[k] = None
+            elif v.is_cuda and v.numel() * v.element_size() >= (1 << 20):
+                # large arrays go through page-locked memory (torch caches the blocks): about twice the rate of a copy
+                # into pageable memory, and the copies of one result overlap
+                import torch
+                h = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                h.copy_(v, non_blocking=True)
+                staged.append((k, h))
+            else:
+                out[k] = v.cpu().numpy()
+        if staged:
+            import torch
+            torch.cuda.current_stream().synchronize()
+            for k, h in staged:
+                out[k] = h.numpy()    # the array keeps the pinned block alive
+        return out
 
 
 class REDeviceSolver:
