@@ -209,3 +209,30 @@ def test_cli_fixed_effect_stage_on_the_device(tmp_path, name):
     os.remove(tmp_path / "vs" / "part-00000.avro")
     gdmix.run(inf)
     assert len(list(avro.read_file(str(tmp_path / "vs" / "part-00000.avro")))) == c["v_y"].size
+
+
+def test_model_file_loads_the_same_through_the_native_reader_and_the_python_decoder(tmp_path, monkeypatch):
+    from gdmix_amd.io import avro, native_reader
+    c = load("logistic_offset")
+    argv = setup_case(tmp_path, c)
+    params = Params.__from_argv__(argv, error_on_unknown=False)
+    sp = SchemaParams.__from_argv__(argv, error_on_unknown=False)
+    m = FixedEffectLRModelLBFGS(argv, params)
+    m._fe = OracleFeDouble()
+    FixedEffectDriver(params, m).run_training(sp)
+    called = []
+    real = native_reader.read_models_avro
+    monkeypatch.setattr(native_reader, "read_models_avro", lambda *a, **k: called.append(1) or real(*a, **k))
+    nat = m._load_model()
+    assert called
+    monkeypatch.setattr(native_reader, "available", lambda: False)
+    py = m._load_model()
+    monkeypatch.undo()
+    np.testing.assert_array_equal(nat, py)
+    assert np.count_nonzero(nat) > 3 and nat[-1] != 0.0           # intercept last
+    # a model naming a feature this job does not know: the reference skips it; the native reader declines, the decoder reads on
+    path = [p for p in os.listdir(m.checkpoint_path) if p.endswith(".avro")][0]
+    recs = list(avro.read_file(os.path.join(m.checkpoint_path, path)))
+    recs[0]["means"].append({"name": "not_in_the_feature_file", "term": "", "value": 3.0})
+    avro.write_file(os.path.join(m.checkpoint_path, path), avro.BAYESIAN_LINEAR_MODEL_SCHEMA, recs)
+    np.testing.assert_array_equal(m._load_model(), py)
