@@ -294,14 +294,13 @@ def read_example_files(files, feature_bag, num_features, uid_name, label_name=No
     if rc != 0:
         msg = lib.gdmix_io_last_error().decode("utf-8", "replace")
         raise (ValueError if rc in (-3, -4) else GdmixIoError)(f"gdmix_io_read_examples: {msg}")
-    try:
-        b = out.contents
-        N, Z = int(b.N), int(b.Z)
-        return dict(n=N, row_nnz_ptr=_copy(b.row_nnz_ptr, N + 1, np.int64), col=_copy(b.col_global, Z, np.int64),
-                    val=_copy(b.val, Z, np.float32), y=_copy(b.y, N, np.float32), offset=_copy(b.offset, N, np.float32),
-                    weight=_copy(b.weight, N, np.float32), uid=_copy(b.uid, N, np.int64))
-    finally:
-        lib.gdmix_io_free(out)
+    owner = _BatchOwner(lib, out)     # the arrays are views of the library's buffers, freed with the last of them
+    b = out.contents
+    N, Z = int(b.N), int(b.Z)
+    v = lambda ptr, n, dt: _view(owner, ptr, n, dt)
+    return dict(n=N, row_nnz_ptr=v(b.row_nnz_ptr, N + 1, np.int64), col=v(b.col_global, Z, np.int64),
+                val=v(b.val, Z, np.float32), y=v(b.y, N, np.float32), offset=v(b.offset, N, np.float32),
+                weight=v(b.weight, N, np.float32), uid=v(b.uid, N, np.int64))
 
 
 def read_models_avro(path, data_offset: int, sync: bytes, deflate: bool, prefix, icpt_enc: bytes, has_intercept: bool, threads=0):
