@@ -271,11 +271,8 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
                    const gdmix_re_result* out, void* stream) {
   if (!ctx || !b || !opts || !out) { set_error("NULL argument"); return GDMIX_RE_EINVAL; }
   if (opts->m < 1 || opts->max_iter < 0 || opts->maxls < 1) { set_error("bad solver options (m, max_iter, maxls)"); return GDMIX_RE_EINVAL; }
-  if (opts->regularize_bias && !opts->has_intercept) {
-    // LRParams.__post_init__: "Intercept must be used when it is regularized" (base_lr_params.py:40-41)
-    set_error("regularize_bias requires has_intercept");
-    return GDMIX_RE_EINVAL;
-  }
+  // regularize_bias without an intercept is legal for the random effect (REParams skips LRParams' check,
+  // random_effect_lr_lbfgs_model.py:48-53): the whole theta is regularised (binary_logistic_regression.py:72-82)
   if (opts->variance_mode == GDMIX_RE_VAR_FULL) {
     if (!out->theta) { set_error("variance_mode FULL needs out->theta"); return GDMIX_RE_EINVAL; }
     if (b->max_p > VAR_FULL_MAX_P) {

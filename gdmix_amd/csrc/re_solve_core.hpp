@@ -71,9 +71,10 @@ __device__ __forceinline__ double eval_fg(G& grp, const EntityView& P, const Sol
   const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
   double sq = 0.0;
   for (int j = first_reg + grp.tid; j < p; j += grp.NT) sq += x[j] * x[j];
-  part += 0.5 * o.l2 * sq;
   const double inv_n = 1.0 / (double)n;
-  const double f = inv_n * grp.sum(part);
+  // cost.sum() + regulariser, added once (binary_logistic_regression.py:105-108)
+  const double cost = grp.sum(part);
+  const double f = inv_n * (cost + 0.5 * o.l2 * grp.sum(sq));
   const double rsum = grp.sum(rpart);   // also orders the rs[] writes before the reads below (block)
   grp.sync();
   for (int j = grp.tid; j < p; j += grp.NT) {

@@ -142,6 +142,56 @@ __device__ __forceinline__ void grp_sum2(double& a, double& b, XWave& X) {
   }
 }
 
+__device__ __forceinline__ void row_sum3(double& a, double& b, double& c) {
+#define GDMIX_RSTEP3S(CTRL)             \
+  {                                     \
+    const double ta = dpp_row<CTRL>(a); \
+    const double tb = dpp_row<CTRL>(b); \
+    const double tc = dpp_row<CTRL>(c); \
+    a += ta;                            \
+    b += tb;                            \
+    c += tc;                            \
+  }
+  GDMIX_RSTEP3S(0xB1) GDMIX_RSTEP3S(0x4E) GDMIX_RSTEP3S(0x141) GDMIX_RSTEP3S(0x140)
+#undef GDMIX_RSTEP3S
+}
+
+// three sums over the G lanes of an entity in one pass
+template <int G>
+__device__ __forceinline__ void grp_sum3(double& a, double& b, double& c, XWave& X) {
+  row_sum3(a, b, c);
+  if (G >= 32) {
+    double a0, a1, b0, b1, c0, c1;
+    rowpair_split(a, a0, a1);
+    rowpair_split(b, b0, b1);
+    rowpair_split(c, c0, c1);
+    a = a0 + a1;
+    b = b0 + b1;
+    c = c0 + c1;
+  }
+  if (G >= 64) {
+    double a0, a1, b0, b1, c0, c1;
+    half_split(a, a0, a1);
+    half_split(b, b0, b1);
+    half_split(c, c0, c1);
+    a = a0 + a1;
+    b = b0 + b1;
+    c = c0 + c1;
+  }
+  if (G > 64) {
+    constexpr int NW = G / WAVE;
+    double* pa = X.buf + (X.phase * 3 + 0) * NW;
+    double* pb = X.buf + (X.phase * 3 + 1) * NW;
+    double* pc = X.buf + (X.phase * 3 + 2) * NW;
+    if ((threadIdx.x & (WAVE - 1)) == 0) { pa[threadIdx.x >> 6] = a; pb[threadIdx.x >> 6] = b; pc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    a = pa[0]; b = pb[0]; c = pc[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { a += pa[w]; b += pb[w]; c += pc[w]; }
+    X.phase ^= 1;
+  }
+}
+
 __device__ __forceinline__ void row_sum2_max(double& a, double& b, double& c) {
 #define GDMIX_RSTEP3(CTRL)              \
   {                                     \
@@ -310,8 +360,11 @@ __device__ __forceinline__ double quad_eval(const QuadLds& L, const SolveParams&
     const int j = gl + G * s;
     if (j >= first_reg && j < p) sq += xt[s] * xt[s];
   }
+  // cost.sum() and the regulariser are summed separately and added once, as the reference writes it
+  // (binary_logistic_regression.py:105-108): spreading (l2/2) x_j^2 over the lanes' loss partials rounds differently, which
+  // decides line searches on entities whose loss is ~1e13 (tests/golden exit_extreme_02)
+  grp_sum3<G>(part, rpart, sq, X);
   part += 0.5 * o.l2 * sq;
-  grp_sum2<G>(part, rpart, X);
   grp_fence<G>();
   const double inv_n = 1.0 / (double)n;
 #pragma unroll

@@ -117,8 +117,8 @@ __device__ __forceinline__ double wreg_eval(const WregLds& L, const SolveParams&
     const int j = lane + WAVE * s;
     if (j >= first_reg && j < p) sq += xt[s] * xt[s];
   }
-  part += 0.5 * o.l2 * sq;
   wave_sum2(part, rpart);
+  part += 0.5 * o.l2 * wave_sum(sq);   // cost.sum() + regulariser, added once (binary_logistic_regression.py:105-108)
   wave_lds_fence();
   const double inv_n = 1.0 / (double)n;
 #pragma unroll

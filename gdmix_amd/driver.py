@@ -120,9 +120,10 @@ class RandomEffectDriver:
                 continue
             partition_index = partition_index_list[k]
             if pipelined and k + 1 < len(partition_index_list):   # decode the next partition while this one is solved
-                self.model.prefetch(self._anchor_directory(self.model.training_data_dir, partition_index_list[k + 1]),
-                                    self.model.metadata_file, schema_params)
-                self.model.prefetch_prior_model(partition_index_list[k + 1])
+                next_dir = self._anchor_directory(self.model.training_data_dir, partition_index_list[k + 1])
+                if not is_empty_directory(next_dir):   # a partition that will be skipped is not decoded (nor kept) at all
+                    self.model.prefetch(next_dir, self.model.metadata_file, schema_params)
+                    self.model.prefetch_prior_model(partition_index_list[k + 1])
             checkpoint_path = self._anchor_directory(self.model.checkpoint_path, partition_index)
             training_data_dir = self._anchor_directory(self.model.training_data_dir, partition_index)
             validation_data_dir = self._anchor_directory(self.model.validation_data_dir, partition_index) \

@@ -55,10 +55,13 @@ class FixedLRParams(LRParams):
 
 
 def shard_input_files(input_path, num_shards, shard_index):
-    """util/distribution_utils.py:11-47: sorted files, strided over the workers; with fewer files than workers, worker
-    w gets file w (or nothing)."""
+    """util/distribution_utils.py:11-47: every entry of the directory (glob '*': whatever its suffix, dot-files
+    excluded), sorted, strided over the workers; with fewer files than workers, worker w gets file w (or nothing).
+    Entries that are not record files (Spark's zero-byte `_SUCCESS` marker) take part in the striding exactly as they
+    do upstream and then contribute no records."""
     assert 0 <= shard_index < num_shards and num_shards >= 1
-    files = resolve_input_files(input_path) if os.path.isdir(input_path) else sorted(glob.glob(input_path))
+    pattern = os.path.join(input_path, "*") if os.path.isdir(input_path) else input_path
+    files = sorted(f for f in glob.glob(pattern) if not os.path.isdir(f))
     assert len(files) > 0, f"{input_path} is empty"
     if len(files) < num_shards:
         return [files[shard_index]] if shard_index < len(files) else []
@@ -70,6 +73,7 @@ def read_per_record_files(files, metadata: DatasetMetadata, feature_bag, num_fea
     """tf.train.Example records -> flat sample arrays (CSR over samples). Columns that the metadata does not list are
     defaults: offset 0, weight 1, label 0 (fixed_effect_lr_lbfgs_model.py:255-258,345-346). native None: libgdmix_io.so
     when built (same rules; tests/test_fe_model.py compares the two)."""
+    files = [f for f in files if os.path.getsize(f) > 0]   # zero-byte entries (`_SUCCESS`) hold no records
     names = set(metadata.get_feature_names()) | set(metadata.get_label_names())
     has = lambda n: n is not None and n in names
     has_label, has_offset, has_weight = has(label_name), has(offset_name), has(weight_name)
@@ -196,7 +200,7 @@ class FixedEffectLRModelLBFGS:
             data["y"], D, offset=data["offset"], weight=data["weight"] if data["has_weight"] else None,
             has_intercept=self.has_intercept, l2=self.l2_reg_weight, regularize_bias=self.is_regularize_bias,
             model_type=self.model_type, theta0=self._strip_dummy(x0) if not bag else x0, max_iter=self.max_iteration,
-            m=self.num_correction_pairs, tolerance=self.model_params.lbfgs_tolerance)
+            m=self.num_correction_pairs, tolerance=self.model_params.lbfgs_tolerance, dummy=not bag)
         if not bag:
             theta = np.concatenate([[0.0], theta])   # the dummy weight of an intercept-only model (add_dummy_weight)
         self.last_training_info = info
@@ -230,7 +234,8 @@ class FixedEffectLRModelLBFGS:
                                         data["offset"], theta if bag else theta[1:], self.num_features if bag else 0, self.has_intercept)
             else:
                 batch, dummy = shard_as_batch(data["row_nnz_ptr"] if bag else np.zeros(n + 1, np.int64), data["col"] if bag else [],
-                                              data["val"] if bag else [], np.zeros(n, np.float32), data["offset"], None, self.has_intercept)
+                                              data["val"] if bag else [], np.zeros(n, np.float32), data["offset"], None, self.has_intercept,
+                                              dummy=not bag)
                 packed = fe.solver.pack(batch, has_intercept=self.has_intercept)
                 uniq = packed.unique_global().cpu().numpy()
                 th = theta if bag else theta[1:]

@@ -33,23 +33,44 @@ LOGISTIC_REGRESSION = "logistic_regression"
 LINEAR_REGRESSION = "linear_regression"
 
 
-def shard_as_batch(row_nnz_ptr, col_global, val, y, offset=None, weight=None, has_intercept=True, binary_labels=True):
-    """The shard as a one-entity RawBatch. An intercept-only model (no features at all) gets one dummy zero
-    feature per sample, as the random-effect path does (job_consumers.py:213-218)."""
+def shard_as_batch(row_nnz_ptr, col_global, val, y, offset=None, weight=None, has_intercept=True, binary_labels=True,
+                   dummy=None):
+    """The shard as a one-entity RawBatch.
+
+    dummy=True: an intercept-only model (no feature bag configured) gets one dummy zero feature per sample, as the
+    random-effect path does (job_consumers.py:213-218). dummy=None infers it from "no non-zeros at all", which is
+    only right for callers that have no notion of a feature bag; the model class passes `feature_bag is None`.
+
+    A bagged worker whose shard holds no non-zero (no samples at all — shard_input_files hands out [] when there are
+    fewer files than workers, util/distribution_utils.py:41-44 — or only empty rows) still owns the full
+    coefficient space: it gets one extra sample of weight 0 carrying a 0.0 at feature 0, which adds exactly 0 to the
+    value and to every gradient entry, so it joins the all-reduce with a full-size buffer of zeros like the
+    reference's empty worker does."""
     row_nnz_ptr = np.asarray(row_nnz_ptr, np.int64)
     n = row_nnz_ptr.size - 1
     col = np.asarray(col_global, np.int64)
     v = np.asarray(val, np.float32)
-    dummy = col.size == 0
+    y = np.asarray(y, np.float32)
+    offset = np.zeros(n, np.float32) if offset is None else np.asarray(offset, np.float32)
+    weight = None if weight is None else np.asarray(weight, np.float32)
+    if dummy is None:
+        dummy = col.size == 0
     if dummy:
         if not has_intercept:
             raise ValueError("a model without features needs an intercept")
         row_nnz_ptr = np.arange(n + 1, dtype=np.int64)
         col = np.zeros(n, np.int64)
         v = np.zeros(n, np.float32)
+    if col.size == 0:   # bagged shard without a single non-zero (or a dummy shard without samples): the weight-0 sample
+        row_nnz_ptr = np.concatenate([row_nnz_ptr, [row_nnz_ptr[-1] + 1]]).astype(np.int64)
+        col = np.zeros(1, np.int64)
+        v = np.zeros(1, np.float32)
+        y = np.concatenate([y, np.zeros(1, np.float32)])
+        offset = np.concatenate([offset, np.zeros(1, np.float32)])
+        weight = np.concatenate([np.ones(n, np.float32) if weight is None else weight, np.zeros(1, np.float32)])
+        n += 1
     b = RawBatch(ent_row_ptr=np.array([0, n], np.int64), row_nnz_ptr=row_nnz_ptr, col_global=col, val=v,
-                 y=np.asarray(y, np.float32), offset=np.zeros(n, np.float32) if offset is None else np.asarray(offset, np.float32),
-                 weight=None if weight is None else np.asarray(weight, np.float32), uid=np.arange(n, dtype=np.int64),
+                 y=y, offset=offset, weight=weight, uid=np.arange(n, dtype=np.int64),
                  entity_ids=["fixed_effect"], has_label=True, binary_labels=binary_labels)
     return b, dummy
 
@@ -87,12 +108,12 @@ class FixedEffectDeviceSolver:
         return device_score(self.solver, row_nnz_ptr, col_global, val, offset, theta, num_features, has_intercept)
 
     def fit(self, row_nnz_ptr, col_global, val, y, num_features, offset=None, weight=None, has_intercept=True, l2=1.0,
-            regularize_bias=True, model_type=LOGISTIC_REGRESSION, theta0=None, max_iter=100, m=10, tolerance=1e-12):
+            regularize_bias=True, model_type=LOGISTIC_REGRESSION, theta0=None, max_iter=100, m=10, tolerance=1e-12, dummy=None):
         """-> (theta [num_features + has_intercept], intercept last; info dict with f, nit, nfev, status, gnorm)."""
         if model_type not in (LOGISTIC_REGRESSION, LINEAR_REGRESSION):
             raise ValueError(f"unknown model type {model_type!r}")
         batch, dummy = shard_as_batch(row_nnz_ptr, col_global, val, y, offset, weight, has_intercept,
-                                      binary_labels=(model_type == LOGISTIC_REGRESSION))
+                                      binary_labels=(model_type == LOGISTIC_REGRESSION), dummy=dummy)
         if not dummy and batch.col_global.size and (batch.col_global.min() < 0 or batch.col_global.max() >= num_features):
             raise ValueError(f"feature index outside [0, {num_features})")
         packed = self.solver.pack(batch, has_intercept=has_intercept)
@@ -222,13 +243,15 @@ def run_stepping_loop(problem, all_reduce=None, max_evals=100000):
 
 def _fit_stepping(self, row_nnz_ptr, col_global, val, y, num_features, offset=None, weight=None, has_intercept=True, l2=1.0,
                   regularize_bias=True, model_type=LOGISTIC_REGRESSION, theta0=None, max_iter=100, m=10, tolerance=1e-12,
-                  group=None, return_problem=False):
+                  group=None, return_problem=False, dummy=None):
     """Same contract as fit(), through include/gdmix_fe.h. With torch.distributed initialised (or `group` given) every
-    worker calls this with its own shard; the coefficients returned are identical on all workers."""
+    worker calls this with its own shard; the coefficients returned are identical on all workers. dummy: True for a
+    model without a feature bag (intercept only), False for a bagged model — also when this worker's shard happens to
+    hold no non-zero, so that its all-reduce buffer has the same num_features + 2 entries as everyone else's."""
     if model_type not in (LOGISTIC_REGRESSION, LINEAR_REGRESSION):
         raise ValueError(f"unknown model type {model_type!r}")
     batch, dummy = shard_as_batch(row_nnz_ptr, col_global, val, y, offset, weight, has_intercept,
-                                  binary_labels=(model_type == LOGISTIC_REGRESSION))
+                                  binary_labels=(model_type == LOGISTIC_REGRESSION), dummy=dummy)
     D = 1 if dummy else int(num_features)   # the dummy zero feature of an intercept-only model occupies global index 0
     if not dummy and batch.col_global.size and (batch.col_global.min() < 0 or batch.col_global.max() >= D):
         raise ValueError(f"feature index outside [0, {D})")

@@ -85,7 +85,8 @@ def read_grouped_partition(input_path, metadata, entity_name, feature_bag, offse
             if len(off) != n:
                 raise ValueError(f"entity {eid}: {len(off)} offsets for {n} uids")
             if feature_bag is None:
-                assert num_features in (None, 1)
+                if num_features not in (None, 1):
+                    raise AssertionError(f"an intercept-only model has one dummy feature, not {num_features}")
                 k = np.ones(n, np.int64)
                 c = np.zeros(n, np.int64)
                 v = np.zeros(n, np.float32)
@@ -102,8 +103,8 @@ def read_grouped_partition(input_path, metadata, entity_name, feature_bag, offse
                 # asserts it equals the uid count (job_consumers.py:229-232)
                 nz = np.flatnonzero(k)
                 sample_count = int(nz[-1]) + 1 if nz.size else 0
-                assert sample_count == n, \
-                    f"entity {eid}: {sample_count} feature rows (last non-empty) vs {n} uids"
+                if sample_count != n:   # an explicit raise: `python -O` must not turn this data check off
+                    raise AssertionError(f"entity {eid}: {sample_count} feature rows (last non-empty) vs {n} uids")
                 k = k[:n]
                 c = np.concatenate([np.asarray(s[1], np.int64) for s in istep[:n]]) if n else np.zeros(0, np.int64)
                 v = np.concatenate([np.asarray(s[1], np.float32) for s in vstep[:n]]) if n else np.zeros(0, np.float32)

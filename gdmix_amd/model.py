@@ -288,7 +288,9 @@ class RandomEffectLRLBFGSModel:
 
     def _solver_options(self):
         mp = self.model_params
-        return SolverOptions(l2=mp.l2_reg_weight, regularize_bias=mp.regularize_bias, has_intercept=self.has_intercept,
+        # without an intercept the whole theta is regularised whatever regularize_bias says (binary_logistic_regression.py:72-82)
+        return SolverOptions(l2=mp.l2_reg_weight, regularize_bias=bool(mp.regularize_bias) and bool(self.has_intercept),
+                             has_intercept=self.has_intercept,
                              m=mp.num_of_lbfgs_curvature_pairs, max_iter=mp.num_of_lbfgs_iterations,
                              ftol=mp.lbfgs_tolerance, variance_mode=VARIANCE_MODES[mp.random_effect_variance_mode],
                              threshold=mp.sparsity_threshold)
@@ -363,7 +365,11 @@ class RandomEffectLRLBFGSModel:
     def _write_behind(self, path, fn, *args, **kwargs):
         if self._io_pool is None:
             return fn(*args, **kwargs)
-        self._pending_writes = [(p, f) for p, f in self._pending_writes if not (f.done() and f.exception() is None)]
+        # a write that already failed is raised now, before more partitions are trained on top of a missing file
+        done = [(p, f) for p, f in self._pending_writes if f.done()]
+        self._pending_writes = [(p, f) for p, f in self._pending_writes if not f.done()]
+        for _, f in done:
+            f.result()
         self._pending_writes.append((os.path.abspath(path), self._io_pool.submit(fn, *args, **kwargs)))
 
     def flush(self, path=None):

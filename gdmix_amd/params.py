@@ -98,7 +98,9 @@ class REParams(LRParams):
     rebalance_entities: bool = False
 
     def __post_init__(self):
-        super().__post_init__()
+        # the reference's REParams.__post_init__ does NOT chain to LRParams.__post_init__ (random_effect_lr_lbfgs_model.py:
+        # 48-53): `--has_intercept False` with regularize_bias left at its default True is a valid random-effect
+        # configuration upstream (test_random_effect_lr_lbfgs_model.py: warm start without intercept)
         assert self.max_training_queue_size > self.num_of_consumers, \
             "queue size limit must be larger than the number of consumers"
         assert self.random_effect_variance_mode is None or self.random_effect_variance_mode in _VARIANCE_MODE, \

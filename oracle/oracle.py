@@ -45,6 +45,7 @@ def lib():
         _lib = C.CDLL(_LIB_PATH)
         _lib.oracle_pack.restype = C.c_int64
         _lib.oracle_solve.restype = C.c_int
+        _lib.oracle_solve2.restype = C.c_int
         _lib.oracle_score.restype = C.c_int
         _lib.oracle_java_string_hash.restype = C.c_int32
         _lib.oracle_java_partition_id.restype = C.c_int32
@@ -82,7 +83,9 @@ def pack(ent_row_ptr, row_nnz_ptr, col_global):
 
 
 def solve(packed, val, y, offset, weight=None, opts=None, theta0=None, e_begin=0, e_end=None):
-    """Run the fp64 L-BFGS restatement on entities [e_begin, e_end) of a packed batch."""
+    """Run the fp64 L-BFGS restatement on entities [e_begin, e_end) of a packed batch. `nfev` is scipy's funcalls (a trial
+    point equal to the previously evaluated one is served from ScalarFunction's cache and not counted); `neval` counts every
+    evaluation performed, which is what the device reports — the two differ only when a step is too small to move x."""
     opts = opts or make_opts()
     E = packed["E"]
     e_end = E if e_end is None else e_end
@@ -96,16 +99,24 @@ def solve(packed, val, y, offset, weight=None, opts=None, theta0=None, e_begin=0
     out = dict(theta=np.zeros(P), theta_thr=np.zeros(P),
                variance=np.zeros(P) if opts.variance_mode else None,
                fval=np.zeros(E), gnorm=np.zeros(E), nit=np.zeros(E, np.int32),
-               nfev=np.zeros(E, np.int32), status=np.full(E, -1, np.int32))
-    rc = lib().oracle_solve(C.c_int64(e_begin), C.c_int64(e_end), _p(packed["ent_row_ptr"]),
+               nfev=np.zeros(E, np.int32), status=np.full(E, -1, np.int32), neval=np.zeros(E, np.int32))
+    rc = lib().oracle_solve2(C.c_int64(e_begin), C.c_int64(e_end), _p(packed["ent_row_ptr"]),
                             _p(packed["ent_nnz_ptr"]), _p(packed["ent_feat_ptr"]), _p(packed["row_ptr"]),
                             _p(packed["csr_col"]), _p(val), _p(y), _p(offset), _p(weight),
                             C.byref(opts), _p(theta0), _p(out["theta"]), _p(out["theta_thr"]),
                             _p(out["variance"]), _p(out["fval"]), _p(out["gnorm"]), _p(out["nit"]),
-                            _p(out["nfev"]), _p(out["status"]))
+                            _p(out["nfev"]), _p(out["status"]), _p(out["neval"]))
     if rc:
         raise RuntimeError(f"oracle_solve failed: {rc}")
     return out
+
+
+def branch_counts(reset=True):
+    """Which L-BFGS-B branches the solves of this thread went through since the last reset:
+    dict(skipped_pairs, gd_restarts, maxls_aborts, max_evals_in_one_search, memory_wraps)."""
+    out = (C.c_longlong * 5)()
+    lib().oracle_branch_counts(out, int(bool(reset)))
+    return dict(zip(("skipped_pairs", "gd_restarts", "maxls_aborts", "max_evals_in_one_search", "memory_wraps"), [int(v) for v in out]))
 
 
 def score(packed, val, offset, theta, has_intercept=True, has_model=None):

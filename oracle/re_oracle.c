@@ -16,6 +16,7 @@
  * gdmix-trainer/src/gdmix/...).
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -139,7 +140,19 @@ static double fg_wide_(const problem* P, const double* th, double* g) {
 }
 
 /* _loss (:84-110) and _gradient (:121-131), fused: f and g at theta. */
+static double fg_impl_(const problem* P, const double* th, double* g);
 static double fg_(const problem* P, const double* th, double* g) {
+  const double f = fg_impl_(P, th, g);
+  static int trace = -1;   /* ORACLE_TRACE=1: every evaluation to stderr (debugging aid for the fixture generators) */
+  if (trace < 0) trace = getenv("ORACLE_TRACE") != NULL;
+  if (trace) {
+    fprintf(stderr, "FG f=%.17g x=", f);
+    for (int j = 0; j < P->p; ++j) fprintf(stderr, " %.17g", th[j]);
+    fprintf(stderr, "\n");
+  }
+  return f;
+}
+static double fg_impl_(const problem* P, const double* th, double* g) {
   if (P->sum_loss) return fg_wide_(P, th, g);
   const int n = P->n, p = P->p, ic = P->ic;
   logits_(P, th, P->z);
@@ -337,6 +350,14 @@ typedef struct {
   int regularize_bias, has_intercept, m, max_iter, maxfun, maxls;
 } solve_opts;
 
+/* Branch counters of the calling thread's solves (test bookkeeping: which L-BFGS-B branches a fixture exercises):
+ * 0 curvature pairs skipped (dr <= epsmch*ddum), 1 restarts because g'd >= 0, 2 line searches aborted at maxls,
+ * 3 largest number of evaluations inside one line search, 4 memory wraps (col == m pushes). */
+static __thread long long g_branch[5] = {0, 0, 0, 0, 0};
+void oracle_branch_counts(long long* out, int reset) {
+  for (int i = 0; i < 5; ++i) { out[i] = g_branch[i]; if (reset) g_branch[i] = 0; }
+}
+
 static __thread int g_wide_dots = 0;   /* set per solve: the fixed-effect coefficient space has 10^4 .. 10^6 dimensions (see fg_wide_) */
 static double dot_(const double* a, const double* b, int n) {
   if (g_wide_dots) {
@@ -356,6 +377,7 @@ static double maxabs_(const double* a, int n) {
 }
 
 /* Returns status 0..4 (PGTOL, FACTR, MAXITER, MAXFUN, ABNORMAL); x holds theta0 on entry. */
+static __thread int g_last_neval = 0;   /* evaluations the last solve performed, repeated points included (see nfev below) */
 static int lbfgs_solve_entity(const problem* P, const solve_opts* O, double* x, double* f_out,
                               double* gnorm_out, int* nit_out, int* nfev_out, double* work) {
   g_wide_dots = P->sum_loss;
@@ -368,11 +390,13 @@ static int lbfgs_solve_entity(const problem* P, const solve_opts* O, double* x, 
   double* wy = ws + (size_t)m * p;
   double* alpha = wy + (size_t)m * p;   /* m */
   double* rho = alpha + m;              /* m: 1/(s'y) of slot */
+  double* xe = rho + m;                 /* p: the last point f and g were evaluated at */
   int col = 0, head = 0;                /* stored pairs; oldest slot */
   double theta = 1.0;
-  int nit = 0, nfev = 0, status = -1, iter0 = 1;
+  int nit = 0, nfev = 0, neval = 1, status = -1, iter0 = 1;
   double f = fg_(P, x, g);
   nfev = 1;
+  memcpy(xe, x, sizeof(double) * (size_t)p);
   double sbgnrm = maxabs_(g, p);
   if (sbgnrm <= O->pgtol) { status = 0; goto done; }
   for (;;) {
@@ -403,17 +427,27 @@ static int lbfgs_solve_entity(const problem* P, const solve_opts* O, double* x, 
     int restart = 0;
     if (gd >= 0.0) {
       restart = 1; /* info = -4 */
+      g_branch[1]++;
     } else {
       ls_state S;
       dcsrch_start(&S, f, gd, stp);
       int ifun = 0;
       for (;;) {
         ifun++;
-        if (ifun - 1 >= O->maxls) { restart = 1; break; }   /* iback >= maxls */
+        if (ifun - 1 >= O->maxls) { restart = 1; g_branch[2]++; break; }   /* iback >= maxls */
+        if (ifun > g_branch[3]) g_branch[3] = ifun;
         if (stp == 1.0) for (int j = 0; j < p; ++j) x[j] = t[j] + d[j];
         else for (int j = 0; j < p; ++j) x[j] = stp * d[j] + t[j];
         f = fg_(P, x, g);
-        nfev++;
+        /* funcalls is scipy's ScalarFunction.nfev: fun_and_grad(x) re-uses f, g (and does not count) when x equals the point of
+         * the previous evaluation (np.array_equal: -0.0 == 0.0), scipy/optimize/_differentiable_functions.py — same values,
+         * one count less; it happens when a step is too small to move x */
+        {
+          int same = 1;
+          for (int j = 0; j < p; ++j) same &= (x[j] == xe[j]);
+          if (!same) { nfev++; memcpy(xe, x, sizeof(double) * (size_t)p); }
+          neval++;
+        }
         gd = dot_(g, d, p);
         if (dcsrch_step(&S, f, gd, &stp) != LS_FG) break;
       }
@@ -442,10 +476,10 @@ static int lbfgs_solve_entity(const problem* P, const solve_opts* O, double* x, 
     double rr = dot_(r, r, p), dr, ddum;
     if (stp == 1.0) { dr = gd - gdold; ddum = -gdold; }
     else { dr = (gd - gdold) * stp; for (int j = 0; j < p; ++j) d[j] *= stp; ddum = -gdold * stp; }
-    if (dr <= EPSMCH * ddum) continue;
+    if (dr <= EPSMCH * ddum) { g_branch[0]++; continue; }
     int sl;
     if (col < m) { sl = (head + col) % m; col++; }
-    else { sl = head; head = (head + 1) % m; }
+    else { sl = head; head = (head + 1) % m; g_branch[4]++; }
     memcpy(ws + (size_t)sl * p, d, sizeof(double) * (size_t)p);
     memcpy(wy + (size_t)sl * p, r, sizeof(double) * (size_t)p);
     rho[sl] = 1.0 / dr;
@@ -456,6 +490,7 @@ done:
   *gnorm_out = sbgnrm;
   *nit_out = nit;
   *nfev_out = nfev;
+  g_last_neval = neval;
   return status;
 }
 
@@ -542,7 +577,15 @@ typedef struct {
   double ftol, pgtol; int32_t variance_mode; double threshold; int32_t sum_loss, linear;
 } oracle_opts;  /* same field order as gdmix_re_opts */
 
-/* Solves entities [e_begin, e_end). Any output pointer may be NULL. Returns 0 or <0. */
+/* Solves entities [e_begin, e_end). Any output pointer may be NULL. Returns 0 or <0.
+ * nfev = scipy's funcalls (a point equal to the previously evaluated one is not counted); neval = evaluations performed. */
+int oracle_solve2(int64_t e_begin, int64_t e_end, const int64_t* ent_row_ptr, const int64_t* ent_nnz_ptr,
+                  const int64_t* ent_feat_ptr, const int32_t* row_ptr, const int32_t* csr_col,
+                  const float* csr_val, const float* y, const float* offset, const float* weight,
+                  const void* opt, const double* theta0, double* theta, double* theta_thr,
+                  double* variance, double* fval, double* gnorm, int32_t* nit, int32_t* nfev,
+                  int32_t* status, int32_t* neval);
+static __thread int32_t* g_neval_out = NULL;
 int oracle_solve(int64_t e_begin, int64_t e_end, const int64_t* ent_row_ptr, const int64_t* ent_nnz_ptr,
                  const int64_t* ent_feat_ptr, const int32_t* row_ptr, const int32_t* csr_col,
                  const float* csr_val, const float* y, const float* offset, const float* weight,
@@ -566,10 +609,10 @@ int oracle_solve(int64_t e_begin, int64_t e_end, const int64_t* ent_row_ptr, con
     P.l2 = opt->l2; P.reg_bias = opt->regularize_bias;
     P.sum_loss = opt->sum_loss; P.linear = opt->linear;
     const int p = P.p, m = O.m;
-    size_t wsz = (size_t)4 * p + (size_t)2 * m * p + (size_t)2 * m + (size_t)2 * P.n + (size_t)p;
+    size_t wsz = (size_t)5 * p + (size_t)2 * m * p + (size_t)2 * m + (size_t)2 * P.n + (size_t)p;
     double* work = (double*)malloc(sizeof(double) * wsz);
     if (!work) return -1;
-    P.z = work + (size_t)4 * p + (size_t)2 * m * p + (size_t)2 * m;
+    P.z = work + (size_t)5 * p + (size_t)2 * m * p + (size_t)2 * m;   /* g d t r | ws wy | alpha rho | xe */
     P.r = P.z + P.n;
     double* x = P.r + P.n;
     for (int j = 0; j < p; ++j) x[j] = theta0 ? theta0[c0 + j] : 0.0;
@@ -589,10 +632,24 @@ int oracle_solve(int64_t e_begin, int64_t e_end, const int64_t* ent_row_ptr, con
     if (gnorm) gnorm[e] = gn;
     if (nit) nit[e] = it;
     if (nfev) nfev[e] = fe;
+    if (g_neval_out) g_neval_out[e] = g_last_neval;
     if (status) status[e] = st;
     free(work);
   }
   return 0;
+}
+
+int oracle_solve2(int64_t e_begin, int64_t e_end, const int64_t* ent_row_ptr, const int64_t* ent_nnz_ptr,
+                  const int64_t* ent_feat_ptr, const int32_t* row_ptr, const int32_t* csr_col,
+                  const float* csr_val, const float* y, const float* offset, const float* weight,
+                  const void* opt, const double* theta0, double* theta, double* theta_thr,
+                  double* variance, double* fval, double* gnorm, int32_t* nit, int32_t* nfev,
+                  int32_t* status, int32_t* neval) {
+  g_neval_out = neval;
+  const int rc = oracle_solve(e_begin, e_end, ent_row_ptr, ent_nnz_ptr, ent_feat_ptr, row_ptr, csr_col, csr_val, y, offset, weight,
+                              (const oracle_opts*)opt, theta0, theta, theta_thr, variance, fval, gnorm, nit, nfev, status);
+  g_neval_out = NULL;
+  return rc;
 }
 
 /* predict_proba(return_logits=True) + InferenceJobConsumer (binary_logistic_regression.py:241-262,

@@ -60,6 +60,63 @@ def well_posed_mask(batch, opts):
     return mixed
 
 
+def parity_mask(batch, opts, exp):
+    """Entities compared iteration for iteration. Fixtures of tests/golden/generate_exit_fixtures.py carry `strict`: the
+    reference reproduced its own answer there under rounding-sized noise (start +-1e-14, weights +-1 ulp); the others of
+    those sets are long runs on extreme inputs whose reference answer depends on scipy's build. Older fixtures: class W."""
+    if "strict" in exp:
+        return exp["strict"].astype(bool)
+    return well_posed_mask(batch, opts)
+
+
+def entity_logits(batch, e, uniq_e, theta_e, ic):
+    """x_i . theta + offset_i for the samples of entity e; theta_e in local index space (intercept first)."""
+    r0, r1 = int(batch.ent_row_ptr[e]), int(batch.ent_row_ptr[e + 1])
+    z = batch.offset[r0:r1].astype(np.float64) + (theta_e[0] if ic else 0.0)
+    for i in range(r0, r1):
+        k0, k1 = int(batch.row_nnz_ptr[i]), int(batch.row_nnz_ptr[i + 1])
+        loc = np.searchsorted(uniq_e, batch.col_global[k0:k1])
+        z[i - r0] += float(np.dot(batch.val[k0:k1].astype(np.float64), theta_e[ic + loc]))
+    return z
+
+
+def d_class_contract(batch, opts, feat_ptr, uniq, theta, theta_thr, gnorm, status, entities):
+    """SURVEY.md §8(d) class D (all labels equal, intercept unregularised: no finite optimum): per entity, which of the four
+    invariants hold — (0) returned max|g| <= 1e-5, (1) sign(theta_0) matches the label, (2) every non-intercept
+    |theta_j| <= 1e-4, i.e. thresholded to 0, (3) sigmoid(logit) within 1e-4 of the label on the entity's own samples.
+    Returns a bool array [len(entities), 4]."""
+    ic = 1 if opts["has_intercept"] else 0
+    out = np.zeros((len(entities), 4), bool)
+    for r, e in enumerate(entities):
+        f0, f1 = int(feat_ptr[e]), int(feat_ptr[e + 1])
+        c0 = f0 + e * ic
+        th = theta[c0:c0 + (f1 - f0) + ic]
+        label = float(batch.y[int(batch.ent_row_ptr[e])])
+        out[r, 0] = status[e] == 0 and gnorm[e] <= 1e-5
+        out[r, 1] = bool(ic) and ((th[0] > 0) == (label > 0.5)) and th[0] != 0
+        out[r, 2] = bool(np.all(np.abs(th[ic:]) <= 1e-4)) and bool(np.all(theta_thr[c0 + ic:c0 + (f1 - f0) + ic] == 0))
+        z = entity_logits(batch, e, uniq[f0:f1], th, ic)
+        with np.errstate(over="ignore"):
+            out[r, 3] = bool(np.all(np.abs(1.0 / (1.0 + np.exp(-z)) - label) <= 1e-4))
+    return out
+
+
+def check_d_class(batch, opts, exp, res, name=""):
+    """Device / oracle result `res` (dict of host arrays) on the class-D entities of a fixture: every invariant the
+    reference's own answer satisfies must hold for ours too, and the thresholded zero pattern must be the fixture's
+    whenever the non-intercept coefficients are all thresholded away. Returns (#D entities, #with the full contract)."""
+    dg = np.flatnonzero(~well_posed_mask(batch, opts))
+    if dg.size == 0 or not opts["has_intercept"]:
+        return 0, 0
+    fp, uq = exp["ent_feat_ptr"], exp["unique_global"]
+    want = d_class_contract(batch, opts, fp, uq, exp["theta"], exp["theta_thr"], exp["gnorm"], exp["status"], dg)
+    got = d_class_contract(batch, opts, fp, uq, res["theta"], res["theta_thr"], res["gnorm"], res["status"], dg)
+    bad = want & ~got
+    assert not bad.any(), f"{name}: class-D invariants lost on entities {dg[bad.any(axis=1)][:8].tolist()} (columns {np.flatnonzero(bad.any(axis=0)).tolist()})"
+    assert np.all(res["status"][dg] >= 0)
+    return int(dg.size), int(want.all(axis=1).sum())
+
+
 def per_entity_rel_err(a, b, coef_ptr):
     """max-norm relative error per entity: max|a-b| / max(max|b|, tiny)."""
     E = coef_ptr.size - 1
@@ -141,11 +198,12 @@ class OracleFeDouble:
 
     def fit_stepping(self, row_nnz_ptr, col_global, val, y, num_features, offset=None, weight=None, has_intercept=True, l2=1.0,
                      regularize_bias=True, model_type="logistic_regression", theta0=None, max_iter=100, m=10, tolerance=1e-12,
-                     group=None):
+                     group=None, dummy=None):
         from gdmix_amd import fixed_effect as fe
         from oracle import oracle
         linear = model_type == fe.LINEAR_REGRESSION
-        batch, dummy = fe.shard_as_batch(row_nnz_ptr, col_global, val, y, offset, weight, has_intercept, binary_labels=not linear)
+        batch, dummy = fe.shard_as_batch(row_nnz_ptr, col_global, val, y, offset, weight, has_intercept, binary_labels=not linear,
+                                         dummy=dummy)
         D = 1 if dummy else int(num_features)
         pk = oracle.pack(batch.ent_row_ptr, batch.row_nnz_ptr, batch.col_global)
         uniq = pk["unique_global"]

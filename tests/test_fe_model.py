@@ -188,6 +188,11 @@ def test_file_sharding_rules(tmp_path):
     assert shard_input_files(str(tmp_path), 2, 0) == files[0::2] and shard_input_files(str(tmp_path), 2, 1) == files[1::2]
     assert shard_input_files(str(tmp_path), 8, 3) == [files[3]] and shard_input_files(str(tmp_path), 8, 6) == []
     assert shard_input_files(str(tmp_path / "*.tfrecord"), 1, 0) == files
+    # the reference shards over every entry of the directory (glob '*'), whatever its suffix (distribution_utils.py:31-36)
+    open(tmp_path / "_SUCCESS", "wb").close()
+    open(tmp_path / "part-9.tfrecords", "wb").close()
+    allf = sorted(str(p) for p in tmp_path.iterdir())
+    assert len(allf) == 7 and shard_input_files(str(tmp_path), 2, 0) == allf[0::2] and shard_input_files(str(tmp_path), 2, 1) == allf[1::2]
 
 
 def test_variance_mode_is_rejected(tmp_path):

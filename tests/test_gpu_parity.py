@@ -8,7 +8,7 @@ result on well-posed entities — asserted here two orders tighter (1e-7) — an
 import numpy as np
 import pytest
 
-from helpers import (fixture_names, load_fixture, opts_kwargs, per_entity_rel_err, well_posed_mask)
+from helpers import (check_d_class, fixture_names, load_fixture, opts_kwargs, parity_mask, per_entity_rel_err, well_posed_mask)
 from gdmix_amd import synthetic
 from gdmix_amd.solver import SolverOptions
 from oracle import oracle
@@ -74,15 +74,22 @@ def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, gian
         device_solver.set_team_nnz(16384)
     ref = oracle.solve(pk, b.val, b.y, b.offset, b.weight, oracle.make_opts(**kw), theta0=th0)
     coef_ptr = packed.coef_ptr_host()
-    wp = well_posed_mask(b, opts)
+    wp = parity_mask(b, opts, exp)
     assert np.all(res["status"] >= 0)
     # (1) against the reference's own numbers
     err = per_entity_rel_err(res["theta"], exp["theta"], coef_ptr)
     assert err[wp].max() <= REL_TOL_DEVICE, f"{name}: theta rel err vs reference {err[wp].max():.3e}"
     assert np.array_equal(res["nit"][wp], exp["nit"][wp]), name
-    assert np.array_equal(res["nfev"][wp], exp["nfev"][wp]), name
+    # the device counts the evaluations it performs; scipy's funcalls leaves out a trial point equal to the previous one
+    # (served from ScalarFunction's cache: a step too small to move x, only on the extreme entities of the exit_* sets).
+    # The oracle reports both (nfev pinned to the reference in test_oracle_golden.py, neval = evaluations performed).
+    assert np.array_equal(res["nfev"][wp], ref["neval"][wp]), name
+    same_count = wp & (ref["neval"] == ref["nfev"])
+    assert np.array_equal(res["nfev"][same_count], exp["nfev"][same_count]), name
     assert np.array_equal(res["status"][wp], exp["status"][wp]), name
-    np.testing.assert_allclose(res["fval"][wp], exp["fval"][wp], rtol=1e-9, atol=1e-13)
+    fv = wp & (exp["status"] != 4)   # f after ABNORMAL: scipy's driver reports the last trial's, see test_oracle_golden.py
+    np.testing.assert_allclose(res["fval"][fv], exp["fval"][fv], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(res["fval"][wp], ref["fval"][wp], rtol=1e-9, atol=1e-13)
     # thresholded coefficients: same zero pattern, same values
     m = np.zeros(coef_ptr[-1], bool)
     for e in np.flatnonzero(wp):
@@ -93,11 +100,12 @@ def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, gian
     assert err_o[wp].max() <= REL_TOL_DEVICE
     if kw["variance_mode"] in (1, 2):   # SIMPLE: same sums; FULL: Cholesky here vs LU (np.linalg.inv) there
         np.testing.assert_allclose(res["variance"], exp["variance"], rtol=1e-7)
-    # degenerate entities: invariants only
+    # degenerate entities: invariants only — the whole class-D contract of SURVEY.md §8(d)
     dg = ~wp
     if dg.any():
         conv = dg & (res["status"] == 0)
         assert np.all(res["gnorm"][conv] <= 1e-5)
+    check_d_class(b, opts, exp, res, name)
     return err[wp].max()
 
 
@@ -110,7 +118,9 @@ def test_default_routing_matches_reference_fixture(device_solver, name):
 VARIANT_FIXTURES = ["ref_fixture_l2_0.1", "ref_dataset1", "ref_dataset2", "c2_shipped_cfg", "c2_defaults", "c2_l2_1e-3",
                     "c2_large_offsets", "c2_weights", "c2_no_intercept", "c2_maxiter1", "c2_maxiter3_m2", "c2_m3",
                     "ragged", "ragged_variance_simple", "ragged_variance_full", "ref_dataset1_variance_full", "ml_per_user", "ml_per_movie", "c5_mean_shape", "zipf_tail",
-                    "tiny_entities_regbias", "tiny_entities_shipped_cfg", "warm_stage2"]
+                    "tiny_entities_regbias", "tiny_entities_shipped_cfg", "warm_stage2",
+                    "exit_factr_1e-7", "exit_factr_1e-4_m3_weights", "exit_hard_02", "exit_hard_04", "exit_extreme_00", "exit_extreme_01",
+                    "exit_extreme_02", "exit_extreme_03"]
 
 
 @pytest.mark.parametrize("name", VARIANT_FIXTURES)
@@ -130,21 +140,21 @@ def test_quad_kernel_matches_reference_fixture(device_solver, name):
 
 @pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "c2_shipped_cfg", "c2_l2_1e-3", "ragged", "ml_per_user",
                                   "c5_mean_shape", "warm_stage2", "tiny_entities_regbias", "c2_no_intercept",
-                                  "ragged_variance_simple", "c2_m3"])
+                                  "ragged_variance_simple", "c2_m3", "exit_factr_1e-4", "exit_hard_03"])
 def test_block_kernel_matches_reference_fixture(device_solver, name):
     # lds limit 0 sends every entity through the workgroup-per-entity kernel
     _solve_and_compare(device_solver, name, lds_limit=0)
 
 
 @pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "ragged", "ml_per_user", "warm_stage2", "tiny_entities_regbias",
-                                  "c2_no_intercept", "ragged_variance_simple", "c2_m3"])
+                                  "c2_no_intercept", "ragged_variance_simple", "c2_m3", "exit_factr_1e-4_m3_weights"])
 def test_device_wide_kernel_matches_reference_fixture(device_solver, name):
     # giant threshold 1 sends every entity, one after another, through the persistent device-wide kernel
     _solve_and_compare(device_solver, name, giant_nnz=1)
 
 
 @pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "ragged", "ml_per_user", "warm_stage2", "c2_no_intercept",
-                                  "ragged_variance_simple"])
+                                  "ragged_variance_simple", "exit_factr_1e-7"])
 def test_team_tiers_match_reference_fixture(device_solver, name):
     # every entity through the persistent kernel split into teams of CUs (tier by size: 128, 32 or 8 teams)
     _solve_and_compare(device_solver, name, giant_nnz=0, team_nnz=1)
