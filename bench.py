@@ -8,7 +8,8 @@
 A "step" is one pass of the device hot path over one resident batch: gdmix_re_pack (per-entity
 unique/local-index/CSC build) followed by gdmix_re_solve (the whole per-entity L-BFGS on the device),
 on the configuration BASELINE.json's metric is quoted on for one GPU: configs[1], synthetic 1M
-entities x avg 64 nnz (n ~ max(1, Poisson(16)), k = 4, D = 1024, seed 20240601), solver options of the
+entities x avg 64 nnz (n ~ max(1, Poisson(16)), k = 4 distinct uniform columns of D = 1024, seed 20240601: the generator of
+SURVEY.md §8(d), gdmix_amd.synthetic.make_survey_batch), solver options of the
 shipped MovieLens config (l2 = 1, regularize_bias = false, m = 10, max_iter = 100, tol = 1e-12).
 Inputs are resident in HBM before the timed region; outputs stay in HBM. With N > 1 every rank owns
 its own shard of 1M entities (weak scaling; entities are independent, no data-path collective).
@@ -80,6 +81,75 @@ def cpu_baseline(batch, opts_kw, sample, min_seconds=10.0):
     return conv / dt, cores, E, dt, passes
 
 
+def host_handover(batch, opts, device_index, P, partitions=24, workers=3):
+    """Partitions handed over from host memory, pipelined: `workers` threads, each with its own context, HIP stream and
+    page-locked staging, take partitions round robin — upload k+1 || widen + pack + solve k || download k-1. The batch
+    crosses PCIe in the 32-bit wire form (gdmix_re_wire_batch: counts, int32 feature ids, byte labels); the thresholded
+    coefficients come back as float64. Every partition is the same C2 batch (its wire arrays sit in page-locked memory, where
+    the native reader would have decoded them). Also timed: one partition alone on one stream (no overlap)."""
+    import threading
+    import torch
+    from gdmix_amd.solver import REDeviceSolver
+    wire = batch.to_wire()
+    keys = [k for k in REDeviceSolver.WIRE_ARRAYS if wire[k] is not None]
+    h2d = sum(wire[k].nbytes for k in keys)
+
+    class Worker:
+        def __init__(self):
+            self.solver = REDeviceSolver(device_index)
+            self.stream = torch.cuda.Stream(device=self.solver.device)
+            self.wire = dict(wire)
+            for k in keys:   # this worker's page-locked copy of the partition
+                self.wire[k] = torch.from_numpy(wire[k]).pin_memory()
+            self.theta_host = torch.empty(P, dtype=torch.float64).pin_memory()
+            self.status_host = torch.empty(batch.E, dtype=torch.int32).pin_memory()
+            self.converged = 0
+
+        def one(self):
+            s = self.solver
+            with torch.cuda.stream(self.stream):
+                rd = s.widen(s.upload_wire(self.wire))
+                pk = s.pack(rd)
+                res = s.solve(pk, opts)
+                self.theta_host[:pk.P].copy_(res.theta_thr, non_blocking=True)
+                self.status_host.copy_(res.status, non_blocking=True)
+                self.stream.synchronize()
+            st = self.status_host.numpy()
+            self.converged += int(((st >= 0) & (st <= 2)).sum())
+
+    ws = [Worker() for _ in range(workers)]
+    for w in ws:
+        w.one()          # warm-up: allocator, kernels
+        w.converged = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ws[0].one()
+    serial = time.perf_counter() - t0
+    ws[0].converged = 0
+    start = threading.Barrier(workers + 1)
+
+    def run(i):
+        start.wait()
+        for _ in range(i, partitions, workers):
+            ws[i].one()
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(workers)]
+    for th in threads:
+        th.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for th in threads:
+        th.join()
+    dt = time.perf_counter() - t0
+    conv = sum(w.converged for w in ws)
+    for w in ws:
+        w.solver.close()
+    return {"ms_per_partition": dt / partitions * 1e3, "entities_per_s": conv / dt, "partitions": partitions, "streams": workers,
+            "h2d_bytes_per_partition": h2d, "d2h_bytes_per_partition": P * 8 + batch.E * 4,
+            "serial_one_stream": {"ms": serial * 1e3, "entities_per_s": batch.E / serial},
+            "what": "page-locked 32-bit wire batch -> H2D -> gdmix_re_widen -> pack -> solve -> D2H thresholded theta (f64) + status, "
+                    f"{workers} streams, partitions round robin; serial_one_stream = the same for one partition without overlap"}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -110,8 +180,8 @@ def main():
     opts = SolverOptions(**opts_kw)
     t_gen = time.perf_counter()
     if a.workload == "c2":
-        batch = synthetic.make_batch(a.entities, a.mean_n, a.k, a.dim, seed=synthetic.C2_SEED + rank,
-                                     entity_id_base=rank * a.entities, with_uid=False)
+        batch = synthetic.make_survey_batch(a.entities, a.mean_n, a.k, a.dim, seed=synthetic.C2_SEED + rank,
+                                            entity_id_base=rank * a.entities)
     elif a.workload == "c5mean":
         batch = synthetic.make_batch(a.entities, 32, 8, 65536, seed=synthetic.C5_SEED + rank, with_uid=False)
     elif a.workload == "zipf":
@@ -213,29 +283,10 @@ def main():
         # re-streamed figure (what a design that does not keep the entity resident would move), SURVEY.md §8(d)
         nfev_e = res.nfev.cpu().numpy().astype(np.float64)
         b_stream = float((nfev_e * (8.0 * z + 16.0 * n) + 8.0 * p + 32.0).sum())
-        # host hand-over: pinned host arrays -> H2D -> pack -> solve -> D2H of the thresholded coefficients
+        # host hand-over (SURVEY.md §8(d) metric (ii)): packed host batch -> H2D -> solve -> D2H -> thresholded theta on the host
         e2e = None
         if world == 1 and not a.no_e2e:
-            names = ("ent_row_ptr", "row_nnz_ptr", "col_global", "val", "y", "offset")
-            pinned = {k: torch.from_numpy(getattr(batch, k)).pin_memory() for k in names}
-            theta_host = torch.empty(int(packed.P), dtype=torch.float64).pin_memory()
-            h2d_bytes = sum(v.numel() * v.element_size() for v in pinned.values())
-            best = None
-            for _ in range(3):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                rd = {k: v.to(solver.device, non_blocking=True) for k, v in pinned.items()}
-                rd["weight"] = None
-                rd["E"], rd["N"], rd["Z"] = batch.E, batch.N, batch.Z
-                pk = solver.pack(rd)
-                solver.solve(pk, opts, out=out)
-                theta_host.copy_(out["theta_thr"], non_blocking=True)
-                torch.cuda.synchronize()
-                t2 = time.perf_counter() - t1
-                best = t2 if best is None else min(best, t2)
-            e2e = {"ms": best * 1e3, "entities_per_s": batch.E / best, "h2d_bytes": h2d_bytes,
-                   "d2h_bytes": theta_host.numel() * 8,
-                   "what": "pinned host raw batch -> H2D -> pack -> solve -> D2H thresholded theta, one stream, no overlap"}
+            e2e = host_handover(batch, opts, local_rank, int(packed.P))
         # the scoring pass over the same resident batch (the path's HBM-bound stream; not part of `value`)
         score = None
         if not a.no_e2e and world == 1:
@@ -266,7 +317,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": (f"C2: synthetic {a.entities} entities/GPU x avg {a.mean_n * a.k} nnz "
-                                    f"(n~Poisson({a.mean_n}), k={a.k}, D={a.dim}), per-entity L2 LR, L-BFGS m=10")
+                                    f"(n~max(1,Poisson({a.mean_n})), k={a.k} distinct uniform columns of D={a.dim}, SURVEY 8(d) generator), "
+                                    f"per-entity L2 LR, L-BFGS m=10")
                        if a.workload == "c2" else f"exploration shape {a.workload}, {a.entities} entities/GPU",
                        "entities_per_gpu": a.entities, "step": "solve" if a.solve_only else "pack+solve",
                        "l2": 1.0, "regularize_bias": False, "max_iter": 100, "parallelism": f"entity-shard x{world}"},

@@ -80,6 +80,25 @@ class RawBatch:
     def ent_n(self):
         return np.diff(self.ent_row_ptr)
 
+    def to_wire(self):
+        """The 32-bit hand-over form (include/gdmix_re.h, gdmix_re_wire_batch): counts instead of int64 pointers, int32 feature
+        ids, byte labels. dict of contiguous numpy arrays + the two widths; 0.6 of the raw form's bytes for C2."""
+        if self.Z and (self.col_global.min() < 0 or self.col_global.max() > 0x7fffffff):
+            raise ValueError("feature index outside [0, 2^31)")
+        ent_n = np.diff(self.ent_row_ptr)
+        if self.E and ent_n.max() > 0x7fffffff:
+            raise ValueError("an entity has more than 2^31 samples")
+        k = np.diff(self.row_nnz_ptr)
+        kmax = int(k.max()) if k.size else 0
+        kdt = np.uint8 if kmax <= 0xff else (np.uint16 if kmax <= 0xffff else np.uint32)
+        binary = self.binary_labels and self.has_label
+        cdt = np.uint16 if (self.Z == 0 or self.col_global.max() <= 0xffff) else np.int32
+        return dict(E=self.E, N=self.N, Z=self.Z, ent_n=ent_n.astype(np.int32), row_nnz=k.astype(kdt),
+                    row_nnz_width=np.dtype(kdt).itemsize, col_global=self.col_global.astype(cdt), col_width=np.dtype(cdt).itemsize,
+                    val=self.val,
+                    y=self.y.astype(np.uint8) if binary else self.y, y_width=1 if binary else 4, offset=self.offset,
+                    weight=self.weight)
+
     def select(self, ents):
         """Sub-batch of the given entity indices (ascending order not required)."""
         ents = np.asarray(ents, np.int64)

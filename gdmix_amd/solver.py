@@ -35,6 +35,13 @@ class _RawBatch(C.Structure):
                 ("val", C.c_void_p), ("y", C.c_void_p), ("offset", C.c_void_p), ("weight", C.c_void_p)]
 
 
+class _WireBatch(C.Structure):
+    _fields_ = [("E", C.c_int64), ("N", C.c_int64), ("Z", C.c_int64), ("ent_n", C.c_void_p), ("row_nnz", C.c_void_p),
+                ("row_nnz_width", C.c_int32), ("y_width", C.c_int32), ("col_width", C.c_int32), ("reserved", C.c_int32),
+                ("col_global", C.c_void_p), ("val", C.c_void_p),
+                ("y", C.c_void_p), ("offset", C.c_void_p), ("weight", C.c_void_p)]
+
+
 class _Packed(C.Structure):
     _fields_ = [("E", C.c_int64), ("N", C.c_int64), ("Z", C.c_int64), ("D", C.c_int64),
                 ("ent_row_ptr", C.c_void_p), ("ent_nnz_ptr", C.c_void_p), ("ent_feat_ptr", C.c_void_p),
@@ -63,7 +70,7 @@ EXPORTED_SYMBOLS = (
     "gdmix_re_abi_version", "gdmix_re_last_error", "gdmix_re_default_opts", "gdmix_re_create",
     "gdmix_re_destroy", "gdmix_re_pack_workspace_bytes", "gdmix_re_pack", "gdmix_re_solve",
     "gdmix_re_solve_scratch_bytes", "gdmix_re_set_scratch", "gdmix_re_set_wave_lds_limit", "gdmix_re_score",
-    "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz",
+    "gdmix_re_widen_workspace_bytes", "gdmix_re_widen", "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz",
     "gdmix_fe_create", "gdmix_fe_destroy", "gdmix_fe_eval", "gdmix_fe_reduce_buffer", "gdmix_fe_step", "gdmix_fe_result",
     "gdmix_fe_last_eval_ms", "gdmix_fe_score",
     "gdmix_re_class_kernel_name", "gdmix_java_string_hash", "gdmix_java_partition_id",
@@ -97,6 +104,9 @@ def load_library():
     lib.gdmix_re_pack_workspace_bytes.restype = C.c_size_t
     lib.gdmix_re_pack.argtypes = [C.c_void_p, C.POINTER(_RawBatch), C.c_int, C.c_void_p, C.c_size_t,
                                   C.POINTER(_Packed), C.c_void_p]
+    lib.gdmix_re_widen_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64]
+    lib.gdmix_re_widen_workspace_bytes.restype = C.c_size_t
+    lib.gdmix_re_widen.argtypes = [C.c_void_p, C.POINTER(_WireBatch), C.c_void_p, C.c_size_t, C.POINTER(_RawBatch), C.c_void_p]
     lib.gdmix_re_solve.argtypes = [C.c_void_p, C.POINTER(_Packed), C.POINTER(_Opts), C.c_void_p,
                                    C.POINTER(_Result), C.c_void_p]
     lib.gdmix_re_solve_scratch_bytes.argtypes = [C.POINTER(_Packed), C.POINTER(_Opts)]
@@ -130,7 +140,7 @@ def load_library():
     lib.gdmix_java_partition_id.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     lib.gdmix_java_partition_id.restype = C.c_int32
     lib.gdmix_java_partition_ids_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
-    if lib.gdmix_re_abi_version() != 2:
+    if lib.gdmix_re_abi_version() != 3:
         raise GdmixReError("libgdmix_re.so ABI version mismatch")
     _lib = lib
     return lib
@@ -357,6 +367,53 @@ class REDeviceSolver:
                  weight=None if raw.weight is None else t.from_numpy(raw.weight).to(dev))
         d["E"], d["N"], d["Z"] = raw.E, raw.N, raw.Z
         return d
+
+    WIRE_ARRAYS = ("ent_n", "row_nnz", "col_global", "val", "y", "offset", "weight")
+
+    def upload_wire(self, wire, pinned=None):
+        """wire: RawBatch.to_wire() (host numpy). Copies the arrays to HBM on the current stream — through the page-locked
+        tensors of `pinned` (same keys, at least as large; reused from partition to partition) when given, so that the
+        copies are asynchronous. Returns the dict of device tensors gdmix_re_widen takes."""
+        t = self.torch
+        d = {k: wire[k] for k in ("E", "N", "Z", "row_nnz_width", "y_width", "col_width")}
+        for k in self.WIRE_ARRAYS:
+            a = wire[k]
+            if a is None:
+                d[k] = None
+                continue
+            if isinstance(a, t.Tensor):      # already a (page-locked) host tensor: the reader decoded into it
+                d[k] = a.to(self.device, non_blocking=True)
+                continue
+            if pinned is not None:
+                h = pinned[k][:a.size]
+                h.numpy()[...] = a
+                d[k] = h.to(self.device, non_blocking=True)
+            else:
+                d[k] = t.from_numpy(a).to(self.device)
+        return d
+
+    def widen(self, wd):
+        """gdmix_re_widen: wire form (device tensors from upload_wire) -> the raw form gdmix_re_pack takes, on the device."""
+        t = self.torch
+        E, N, Z = wd["E"], wd["N"], wd["Z"]
+        ptr = lambda x: None if x is None or x.numel() == 0 else x.data_ptr()
+        c_wire = _WireBatch(E, N, Z, ptr(wd["ent_n"]), ptr(wd["row_nnz"]), wd["row_nnz_width"], wd["y_width"], wd["col_width"], 0, ptr(wd["col_global"]),
+                            ptr(wd["val"]), ptr(wd["y"]), ptr(wd["offset"]), ptr(wd["weight"]))
+        nbytes = self.lib.gdmix_re_widen_workspace_bytes(E, N, Z)
+        ws = t.empty(nbytes, dtype=t.uint8, device=self.device)
+        c_raw = _RawBatch()
+        _check(self.lib.gdmix_re_widen(self._h, C.byref(c_wire), ws.data_ptr(), nbytes, C.byref(c_raw), self._stream()), "gdmix_re_widen")
+
+        def view(p, count, dtype):
+            if not p or count == 0:
+                return t.empty(0, dtype=dtype, device=self.device)
+            off = p - ws.data_ptr()
+            return ws[off:off + count * t.empty(0, dtype=dtype).element_size()].view(dtype)
+        y = wd["y"] if wd["y_width"] == 4 else view(c_raw.y, N, t.float32)
+        rd = dict(E=E, N=N, Z=Z, ent_row_ptr=view(c_raw.ent_row_ptr, E + 1, t.int64), row_nnz_ptr=view(c_raw.row_nnz_ptr, N + 1, t.int64),
+                  col_global=view(c_raw.col_global, Z, t.int64), val=wd["val"], y=y, offset=wd["offset"], weight=wd["weight"],
+                  _keep=(ws, wd))
+        return rd
 
     def pack(self, raw, has_intercept=True) -> PackedBatch:
         """raw: RawBatch (host) or the dict returned by upload() (device)."""

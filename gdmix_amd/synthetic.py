@@ -60,6 +60,37 @@ def make_batch(E, mean_n=16, k=4, D=1024, seed=C2_SEED, size_dist="poisson", l_o
         entity_ids=[str(i) for i in range(entity_id_base, entity_id_base + E)])
 
 
+def make_survey_batch(E, mean_n=16, k=4, D=1024, seed=C2_SEED, size_dist="poisson", entity_id_base=0, with_uid=False):
+    """The generator SURVEY.md §8(d) states for the measured configurations, to the letter: n_e = max(1, Poisson(mean_n)); per
+    sample k DISTINCT columns drawn uniformly from [0, D) (in draw order, not sorted); values ~ N(0,1) fp32; offset ~ N(0,1)
+    fp32; hidden w* ~ 0.5 N(0,1); y ~ Bernoulli(sigmoid(x . w* + offset)) — no per-entity bias; weight = 1.
+    (make_batch above — one column per stratum of the feature space plus a hidden entity bias — is what the committed
+    parity fixtures were generated from and stays as it is.)"""
+    rng = np.random.default_rng(seed)
+    n = _entity_sizes(rng, E, size_dist, mean_n)
+    N = int(n.sum())
+    cols = rng.integers(0, D, size=(N, k), dtype=np.int64)
+    while k > 1:   # re-draw the samples that drew a column twice (k = 4, D = 1024: 0.6 % of them)
+        dup = np.zeros(N, bool)
+        for a in range(k):
+            for b in range(a + 1, k):
+                dup |= cols[:, a] == cols[:, b]
+        bad = np.flatnonzero(dup)
+        if bad.size == 0:
+            break
+        cols[bad] = rng.integers(0, D, size=(bad.size, k), dtype=np.int64)
+    vals = rng.standard_normal(size=(N, k)).astype(np.float32)
+    offset = rng.standard_normal(N).astype(np.float32)
+    w_star = 0.5 * rng.standard_normal(D)
+    logit = (vals.astype(np.float64) * w_star[cols]).sum(axis=1) + offset
+    y = (rng.random(N) < 1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
+    return RawBatch(
+        ent_row_ptr=np.concatenate([[0], np.cumsum(n)]), row_nnz_ptr=np.arange(N + 1, dtype=np.int64) * k,
+        col_global=cols.reshape(-1), val=vals.reshape(-1), y=y, offset=offset, weight=None,
+        uid=np.arange(N, dtype=np.int64) if with_uid else None,
+        entity_ids=[str(i) for i in range(entity_id_base, entity_id_base + E)])
+
+
 def make_ragged_batch(E, seed=7, D=200, max_n=40, max_k=9, empty_row_prob=0.15, dup_prob=0.1,
                       random_weights=True):
     """Adversarially ragged entities: empty samples, duplicate (row, col) pairs, n from 1, k from 0."""

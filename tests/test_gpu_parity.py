@@ -288,3 +288,47 @@ def test_empty_and_single_entity_batches(device_solver):
     ref = oracle.solve(pk, one.val, one.y, one.offset, None, oracle.make_opts())
     np.testing.assert_allclose(res["theta"], ref["theta"], rtol=1e-9)
     assert res["nit"][0] == ref["nit"][0]
+
+
+@pytest.mark.parametrize("shape", ["ragged", "c2", "wide_rows", "tiny", "float_labels"])
+def test_wire_form_widens_to_the_raw_batch(device_solver, shape):
+    """gdmix_re_wire_batch (counts, int32 feature ids, byte labels) -> gdmix_re_widen gives bit for bit the raw arrays a
+    direct upload would, for every count width; the pack that follows is the same pack."""
+    import torch
+    if shape == "ragged":
+        b = synthetic.make_ragged_batch(3000, seed=31)          # empty samples, duplicates, weights
+    elif shape == "c2":
+        b = synthetic.make_batch(50000, 16, 4, 1024, seed=32)
+    elif shape == "wide_rows":                                  # more than 255 (and 65535) non-zeros in a sample
+        from gdmix_amd.batch import RawBatch
+        rng = np.random.default_rng(33)
+        k = np.array([3, 300, 0, 70000, 1, 0, 2], np.int64)
+        rp = np.concatenate([[0], np.cumsum(k)])
+        b = RawBatch(ent_row_ptr=[0, 2, 2, 5, 7], row_nnz_ptr=rp, col_global=rng.integers(0, 2**31 - 1, rp[-1]),
+                     val=rng.standard_normal(rp[-1]), y=[0, 1, 1, 0, 1, 0, 0], offset=rng.standard_normal(7))
+    elif shape == "tiny":
+        from gdmix_amd.batch import RawBatch
+        b = RawBatch(ent_row_ptr=[0, 1], row_nnz_ptr=[0, 1], col_global=[3], val=[2.0], y=[1], offset=[0.0])
+    else:
+        b = synthetic.make_batch(2000, 16, 4, 1024, seed=34)
+        b.y = (b.y * 0.25 + 0.1).astype(np.float32)
+        b.binary_labels = False
+    w = b.to_wire()
+    assert w["row_nnz_width"] == {"ragged": 1, "c2": 1, "wide_rows": 4, "tiny": 1, "float_labels": 1}[shape]
+    assert w["col_width"] == (4 if shape == "wide_rows" else 2)
+    rd = device_solver.widen(device_solver.upload_wire(w))
+    for k in ("ent_row_ptr", "row_nnz_ptr", "col_global", "val", "y", "offset"):
+        assert np.array_equal(rd[k].cpu().numpy(), getattr(b, k)), k
+    assert (rd["weight"] is None) == (b.weight is None)
+    if b.weight is not None:
+        assert np.array_equal(rd["weight"].cpu().numpy(), b.weight)
+    if shape in ("ragged", "c2"):
+        pk = oracle.pack(b.ent_row_ptr, b.row_nnz_ptr, b.col_global)
+        _check_pack(device_solver.pack(rd), pk, b.val)
+    # through page-locked staging blocks, as the pipelined hand-over does
+    pinned = {k: torch.empty(max(1, 0 if w[k] is None else w[k].size), dtype=torch.from_numpy(w[k]).dtype).pin_memory()
+              for k in device_solver.WIRE_ARRAYS if w[k] is not None}
+    rd2 = device_solver.widen(device_solver.upload_wire(w, pinned=pinned))
+    torch.cuda.synchronize()
+    for k in ("ent_row_ptr", "row_nnz_ptr", "col_global", "y"):
+        assert np.array_equal(rd2[k].cpu().numpy(), getattr(b, k)), k
