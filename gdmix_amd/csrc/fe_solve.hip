@@ -296,6 +296,7 @@ __global__ __launch_bounds__(FE_THREADS) void fe_dots_kernel(FeDev F, SolveParam
     const double yj = gj - rj;
     acc[3] += yj * yj;
     acc[4] += yj * gj;
+    acc[TEAM_RD] += rj * dj;
     acc[TEAM_K - 1] = fmax(acc[TEAM_K - 1], fabs(gj));
 #pragma unroll
     for (int i = 0; i < TEAM_MCAP; ++i) {

@@ -10,9 +10,14 @@
 namespace gdmix {
 
 constexpr int TEAM_MCAP = 10;                 // history pairs the compact path keeps accumulators for
-constexpr int TEAM_K = 2 * TEAM_MCAP + 6;     // fused reduction width: sq, gd, gg, yy, yg, S'y, Y'y, max|g|
+constexpr int TEAM_K = 2 * TEAM_MCAP + 7;     // fused reduction width: sq, gd, gg, yy, yg, S'y, Y'y, r'd, max|g|
+constexpr int TEAM_RD = 2 * TEAM_MCAP + 5;    // acc index of r'd
 // acc[] layout, with y = g - r (r = the gradient at the last accepted iterate): 0 sum x_j^2 over regularised j, 1 g'd,
-// 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (chronological i < col), K-1 max|g_j|.
+// 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (chronological i < col), K-2 r'd, K-1 max|g_j|.
+// r'd is the slope of the line search at its start, taken from the direction as it is actually used (after mainlb's
+// d = (x + d) - x): the small solve also yields g'd = -g'Hg algebraically, but the two differ once x dwarfs d (badly scaled
+// entities; tests/golden exit_hard_*, exit_extreme_*), and L-BFGS-B's line search runs on the former (lnsrlb: gd = ddot(g, d)).
+// It arrives with the first trial's products and replaces the algebraic value before the search takes its first decision.
 // The products are taken with y, not with g: S'g and Y'g at the new gradient are the stored ones plus these, and the new
 // column of S'Y / Y'Y is these — sums, where products with g would need differences of nearly equal numbers once the
 // gradient changes little between iterates.
@@ -52,7 +57,7 @@ __device__ __forceinline__ void compact_advance(CompactState& S, const double (&
   const int m = o.m;
   ++S.nfev;
   const double gd = acc[1], gg = acc[2], rr = acc[3], yg = acc[4];
-  bool restore = false, store_pair = false, shift = false;
+  bool restore = false, store_pair = false, shift = false, descent_lost = false;
   double dr = 0.0;
   const double stp_prev = S.stp;
   plan.store_pair = 0; plan.restore = 0; plan.slot = 0; plan.cnew = 0; plan.stp_prev = stp_prev;
@@ -64,9 +69,20 @@ __device__ __forceinline__ void compact_advance(CompactState& S, const double (&
   } else {
     S.f = f_new;
     double stp = S.stp;
-    const int task = dcsrch_step(S.ls, f_new, gd, stp);
+    if (S.ifun == 1) {   // first trial of this search: the slope at its start, exactly
+      const double g0 = acc[TEAM_RD];
+      S.ls.ginit = g0; S.ls.gtest = LS_FTOL * g0; S.ls.gx = g0; S.ls.gy = g0;
+      S.gdold = g0;
+      if (g0 >= 0.0) {   // not a descent direction after all (lnsrlb info = -4; it would not have evaluated this trial)
+        --S.nfev;
+        descent_lost = true;
+      }
+    }
+    const int task = descent_lost ? LS_FG : dcsrch_step(S.ls, f_new, gd, stp);
     S.stp = stp;
-    if (task == LS_FG) {
+    if (descent_lost) {
+      restore = true;
+    } else if (task == LS_FG) {
       ++S.ifun;
       if (S.ifun - 1 < o.maxls) { plan.action = CA_RETRY; plan.stp = stp; return; }
       restore = true;   // iback >= maxls: back to the last iterate, forget the history
@@ -208,13 +224,8 @@ __device__ __forceinline__ void compact_advance(CompactState& S, const double (&
     if (i == 0) L.sc[0] = gdn0;
   }
   __syncthreads();
-  double gdn = L.sc[0];
-  if (gdn >= 0.0) {   // not a descent direction (lnsrlb info = -4): steepest descent without history
-    if (col == 0) { S.col = col; S.head = head; S.theta = theta; S.status = 4; plan.action = CA_STOP; return; }
-    col = 0; head = 0; theta = 1.0;
-    store_pair = false;
-    gdn = -gg_cur;
-  }
+  const double gdn = L.sc[0];   // algebraic -g'Hg: a stand-in until r'd arrives with the first trial (see TEAM_RD above), which
+                                // also takes the "not a descent direction" decision (lnsrlb info = -4)
   S.col = col; S.head = head; S.theta = theta;
   S.gg_k = gg_cur;
   S.gdold = gdn;

@@ -198,7 +198,7 @@ __device__ __forceinline__ double gather_dot8(const float* __restrict__ val, con
 }
 
 // f, g and every dot product the driver needs, at W.x. acc[] layout: 0 sum x_j^2 over regularised j,
-// 1 g'd, 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (y = g - r; chronological i < col), K-1 max|g_j|.
+// 1 g'd, 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (y = g - r; chronological i < col), K-2 r'd, K-1 max|g_j|.
 template <int NW>
 __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W,
                                             int col, int head, double (&acc)[TEAM_K]
@@ -378,6 +378,7 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
       const double yj = gj - rj;
       acc[3] += yj * yj;
       acc[4] += yj * gj;
+      acc[TEAM_RD] += rj * dj;
       acc[TEAM_K - 1] = fmax(acc[TEAM_K - 1], fabs(gj));
 #pragma unroll
       for (int i = 0; i < TEAM_MCAP; ++i) {

@@ -140,21 +140,23 @@ def test_quad_kernel_matches_reference_fixture(device_solver, name):
 
 @pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "c2_shipped_cfg", "c2_l2_1e-3", "ragged", "ml_per_user",
                                   "c5_mean_shape", "warm_stage2", "tiny_entities_regbias", "c2_no_intercept",
-                                  "ragged_variance_simple", "c2_m3", "exit_factr_1e-4", "exit_hard_03"])
+                                  "ragged_variance_simple", "c2_m3", "exit_factr_1e-4", "exit_hard_02", "exit_hard_03", "exit_extreme_00",
+                                  "exit_extreme_01", "exit_extreme_02", "exit_extreme_03"])
 def test_block_kernel_matches_reference_fixture(device_solver, name):
     # lds limit 0 sends every entity through the workgroup-per-entity kernel
     _solve_and_compare(device_solver, name, lds_limit=0)
 
 
 @pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "ragged", "ml_per_user", "warm_stage2", "tiny_entities_regbias",
-                                  "c2_no_intercept", "ragged_variance_simple", "c2_m3", "exit_factr_1e-4_m3_weights"])
+                                  "c2_no_intercept", "ragged_variance_simple", "c2_m3", "exit_factr_1e-4_m3_weights", "exit_extreme_00",
+                                  "exit_extreme_02"])
 def test_device_wide_kernel_matches_reference_fixture(device_solver, name):
     # giant threshold 1 sends every entity, one after another, through the persistent device-wide kernel
     _solve_and_compare(device_solver, name, giant_nnz=1)
 
 
 @pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "ragged", "ml_per_user", "warm_stage2", "c2_no_intercept",
-                                  "ragged_variance_simple", "exit_factr_1e-7"])
+                                  "ragged_variance_simple", "exit_factr_1e-7", "exit_hard_02", "exit_extreme_01", "exit_extreme_03"])
 def test_team_tiers_match_reference_fixture(device_solver, name):
     # every entity through the persistent kernel split into teams of CUs (tier by size: 128, 32 or 8 teams)
     _solve_and_compare(device_solver, name, giant_nnz=0, team_nnz=1)
