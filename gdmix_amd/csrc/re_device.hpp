@@ -76,6 +76,26 @@ __device__ __forceinline__ void wave_mem_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Loads / stores of the vectors the workgroups of a team exchange (x, the per-sample residuals, partial sums). SC1 = true:
+// relaxed agent-scope accesses (global_load / global_store ... sc1): the store is written through to the memory side, the
+// load bypasses this CU's L1, so the hand-off needs no cache write-back / invalidate, only a drained store queue
+// (s_waitcnt vmcnt(0)) ahead of the barrier arrival (MI355X_MICROARCH.md, "valid forms": sc1 stores and loads on both sides).
+template <bool SC1>
+__device__ __forceinline__ double ld_x(const double* p) {
+  if (SC1)
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(const_cast<double*>(p)),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  return *p;
+}
+template <bool SC1>
+__device__ __forceinline__ void st_x(double* p, double v) {
+  if (SC1)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  else
+    *p = v;
+}
+
 // ---- thread groups ------------------------------------------------------------------------------
 // One wavefront cooperating on one entity.
 struct WaveGroup {

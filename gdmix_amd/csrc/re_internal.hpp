@@ -21,7 +21,8 @@ namespace gdmix {
 //   KIND_BLOCK      workgroup-per-entity kernel working out of a global scratch slot (anything)
 // Each wavefront kind is split into LDS-footprint buckets so that small entities keep high occupancy.
 enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4, KIND_QUAD2 = 5, KIND_QUAD4 = 6, KIND_PAIR4 = 7, KIND_QUAD3 = 8, KIND_PAIR3 = 9, KIND_WREG8 = 10,
-       KIND_G64_3 = 11, KIND_G64_4 = 12, KIND_G128_4 = 13, KIND_G256_4 = 14, KIND_G512_4 = 15, KIND_GRID = 16, KIND_G128_3 = 17, KIND_G256_3 = 18 };
+       KIND_G64_3 = 11, KIND_G64_4 = 12, KIND_G128_4 = 13, KIND_G256_4 = 14, KIND_G512_4 = 15, KIND_GRID = 16, KIND_G128_3 = 17, KIND_G256_3 = 18,
+       KIND_TREG = 19 };
 
 // group kernels (several entities per wavefront): lanes per entity, coefficient slots per lane; 0 if not a group kind
 __host__ __device__ inline int group_lanes(int kind) {
@@ -36,6 +37,15 @@ constexpr int TEAM8_CLASS = GDMIX_RE_NUM_CLASSES - 2;    // 8 teams of 32 CUs
 constexpr int TEAM32_CLASS = GDMIX_RE_NUM_CLASSES - 3;   // 32 teams of 8 CUs
 constexpr int TEAM128_CLASS = GDMIX_RE_NUM_CLASSES - 4;  // 128 teams of 2 CUs
 constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 5;
+// Team kernels with the L-BFGS vectors in registers (re_solve_team.hpp, team_solve_reg): one class per team size, in
+// workgroups (= CUs); a team of s workgroups holds entities of up to s * TREG_COEFS coefficients.
+constexpr int TREG_NUM = 12;
+constexpr int TREG_CLASS0 = BLOCK_CLASS - TREG_NUM;
+constexpr int TREG_NW = 4, TREG_EPL = 4;
+constexpr int TREG_COEFS = TREG_NW * TREG_EPL * 64;   // per workgroup
+__host__ __device__ inline int treg_size(int k) {
+  return k == 0 ? 1 : (k == 1 ? 2 : (k == 2 ? 3 : (k == 3 ? 4 : (k == 4 ? 6 : (k == 5 ? 8 : (k == 6 ? 12 : (k == 7 ? 16 : (k == 8 ? 24 : (k == 9 ? 32 : (k == 10 ? 48 : 64))))))))));
+}
 constexpr int BLOCK_NW = 4;   // wavefronts per workgroup of the block kernel
 #ifndef GDMIX_TEAM_BLOCK_NW
 #define GDMIX_TEAM_BLOCK_NW 8
@@ -50,6 +60,7 @@ struct ClassTable {
   int zcap[GDMIX_RE_NUM_CLASSES];
   int64_t giant_nnz;   // 0 = device-wide kernel off
   int64_t team_nnz;    // 0 = team tiers off
+  int treg;            // register team kernels on
 };
 
 // Device pointers of a packed batch, passed by value to kernels.
@@ -135,6 +146,9 @@ hipError_t launch_solve_block(const BatchDev& B, const OutDev& O, const SolvePar
 hipError_t launch_solve_grid(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
                              int begin, int count, double* scratch, size_t slot_doubles, int64_t max_p,
                              void* sync_buf, int blocks, int teams, hipStream_t s);
+hipError_t launch_solve_treg(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0, int begin, int count,
+                             double* scratch, int64_t max_p, int64_t max_n, void* sync_buf, int blocks, int size, hipStream_t s);
+inline size_t treg_slot_doubles(int64_t max_p, int64_t max_n) { return (size_t)2 * max_p + (size_t)256 * 64 + (size_t)max_n + 64; }
 hipError_t launch_variance_full(const BatchDev& B, int64_t E, const SolveParams& o, const double* theta, double* variance,
                                 double* scratch, size_t slot_doubles, int slots, int64_t max_p, hipStream_t s);
 constexpr int64_t VAR_FULL_MAX_P = 2048;   // FULL variance densifies p x p (as the reference does)

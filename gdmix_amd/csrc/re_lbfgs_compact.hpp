@@ -38,7 +38,7 @@ enum { CA_STOP = 0, CA_STOP_RESTORE = 1, CA_RETRY = 2, CA_DIRECTION = 3 };
 struct CompactPlan {    // what the elementwise pass over the p-vectors has to do
   int action;           // CA_STOP: x is the result; CA_STOP_RESTORE: x := t first; CA_RETRY: x := t + stp d;
                         // CA_DIRECTION: store the pair, build d, x := x + stp d
-  int store_pair, restore, slot, cnew, col, head;
+  int store_pair, restore, slot, cnew, col, head, shift;   // shift: the oldest pair was dropped to make room (col == m)
   double stp, stp_prev, gamma;
 };
 
@@ -52,7 +52,7 @@ struct CompactMats {    // the m x m part (LDS; every workgroup keeps a replica)
 
 // Called by every thread of a workgroup with identical arguments. Contains one __syncthreads() on the
 // CA_DIRECTION path.
-__device__ __forceinline__ void compact_advance(CompactState& S, const double (&acc)[TEAM_K], double f_new,
+__device__ __forceinline__ void compact_advance(CompactState& S, const double* acc /* [TEAM_K], registers or LDS */, double f_new,
                                                 const SolveParams& o, CompactMats& L, CompactPlan& plan) {
   const int m = o.m;
   ++S.nfev;
@@ -60,7 +60,7 @@ __device__ __forceinline__ void compact_advance(CompactState& S, const double (&
   bool restore = false, store_pair = false, shift = false, descent_lost = false;
   double dr = 0.0;
   const double stp_prev = S.stp;
-  plan.store_pair = 0; plan.restore = 0; plan.slot = 0; plan.cnew = 0; plan.stp_prev = stp_prev;
+  plan.store_pair = 0; plan.restore = 0; plan.slot = 0; plan.cnew = 0; plan.shift = 0; plan.stp_prev = stp_prev;
   if (S.first) {
     S.first = 0;
     S.f = f_new;
@@ -238,6 +238,7 @@ __device__ __forceinline__ void compact_advance(CompactState& S, const double (&
   plan.restore = restore ? 1 : 0;
   plan.slot = slot;
   plan.cnew = cnew;
+  plan.shift = (store_pair && shift) ? 1 : 0;
   plan.col = col;
   plan.head = head;
   plan.stp = S.stp;

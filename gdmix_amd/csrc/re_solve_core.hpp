@@ -276,21 +276,22 @@ __device__ void lbfgs_solve(G& grp, const EntityView& P, const SolveParams& o, c
 // _compute_variance, SIMPLE mode (binary_logistic_regression.py:175-180): 1/(sum_i X~_ij^2 D_i + l2*[j reg] + 1e-12),
 // D_i = rho_i (1-rho_i) w_i. Duplicate (row, col) entries are summed before squaring, as the reference's
 // toarray() does. W.rs is reused for D.
-template <class G>
+// SC1: the team's exchanged vectors (W.x, W.rs) are accessed through sc1 loads / stores (re_device.hpp, ld_x / st_x)
+template <bool SC1 = false, class G>
 __device__ __forceinline__ void variance_simple(G& grp, const EntityView& P, const SolveParams& o, const Work& W,
                                                 double* var_out) {
   const int n = P.n, p = P.p, ic = P.ic;
   const double* __restrict__ x = W.x;
-  const double x0 = ic ? x[0] : 0.0;
+  const double x0 = ic ? ld_x<SC1>(x) : 0.0;
   double dpart = 0.0;
   for (int i = grp.tid; i < n; i += grp.NT) {
     double acc = x0;
     const int k1 = P.row_ptr[i + 1];
-    for (int k = P.row_ptr[i]; k < k1; ++k) acc += (double)P.csr_val[k] * x[ic + P.csr_col[k]];
+    for (int k = P.row_ptr[i]; k < k1; ++k) acc += (double)P.csr_val[k] * ld_x<SC1>(x + ic + P.csr_col[k]);
     const double z = acc + (double)P.o[i];
     const double rho = 1.0 / (1.0 + exp(-z));
     const double di = rho * (1.0 - rho) * (P.w ? (double)P.w[i] : 1.0);
-    W.rs[i] = di;
+    st_x<SC1>(W.rs + i, di);
     dpart += di;
   }
   const double dsum = grp.sum(dpart);
@@ -310,7 +311,7 @@ __device__ __forceinline__ void variance_simple(G& grp, const EntityView& P, con
         double v = (double)P.csc_val[k];
         ++k;
         while (k < k1 && P.csc_row[k] == row) { v += (double)P.csc_val[k]; ++k; }
-        h += v * v * W.rs[row];
+        h += v * v * ld_x<SC1>(W.rs + row);
       }
     }
     h += (j < first_reg) ? 0.0 : o.l2;

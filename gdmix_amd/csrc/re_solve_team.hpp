@@ -34,7 +34,7 @@ namespace gdmix {
 
 constexpr int TEAM_VEC = 32;                  // doubles per workgroup slot of the device-wide exchange buffer
 constexpr int TEAM_MAX_BLOCKS = 256;           // workgroups per team
-constexpr int TEAM_MAX_TEAMS = 128;
+constexpr int TEAM_MAX_TEAMS = 256;
 constexpr int TEAM_SHORT_COL = 16;            // tiles whose columns are all this short: one lane per column
 constexpr int TEAM_CHUNK = 512;               // CSC entries a wavefront stages through LDS at a time
 constexpr int TEAM_LONGC = 2048;              // columns at least this long are split over the team in 64 slices
@@ -71,6 +71,8 @@ struct Team {
   TeamLds<NW>* L;
   unsigned epoch;
   int phase;
+  bool cheap;             // every vector the workgroups exchange goes through sc1 accesses (ld_x / st_x below): the barrier
+                          // needs no L2 write-back and no L1 invalidate, only drained stores
 
   __device__ __forceinline__ void block_sync() const { __syncthreads(); }
 
@@ -82,8 +84,10 @@ struct Team {
     __syncthreads();
     ++epoch;
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!cheap) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __hip_atomic_fetch_add(&gs->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned target = epoch * nblocks;
       unsigned spins = 0;
@@ -100,7 +104,7 @@ struct Team {
           }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (!cheap) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
   }
@@ -118,15 +122,24 @@ struct Team {
   // memory operations of the team like sync().
   template <int K>
   __device__ __forceinline__ void reduce(double (&v)[K]) {
-    static_assert(K <= TEAM_VEC, "reduction wider than the exchange slot");
-    const int ph = phase;
-    phase ^= 1;
     double mine = 0.0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const double t = (k == K - 1) ? wave_max_nonneg(v[k]) : wave_sum(v[k]);
       if (lane == k) mine = t;
     }
+    const double* tot = reduce_placed<K>(mine);
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = tot[k];
+  }
+
+  // The same with the wavefront's totals already in place: lane k of every wavefront holds that wavefront's total of value
+  // k. Returns the team totals (LDS, valid until the reduction after the next one).
+  template <int K>
+  __device__ __forceinline__ const double* reduce_placed(double mine) {
+    static_assert(K <= TEAM_VEC, "reduction wider than the exchange slot");
+    const int ph = phase;
+    phase ^= 1;
     const int w = threadIdx.x >> 6;
     if (lane < K) L->red[ph][w][lane] = mine;
     __syncthreads();
@@ -137,8 +150,12 @@ struct Team {
         const double t = L->red[ph][ww][threadIdx.x];
         s = (threadIdx.x == K - 1) ? fmax(s, t) : s + t;
       }
-      if (nblocks > 1) gs->vec[ph][threadIdx.x][bid] = s;
-      else L->out[ph][threadIdx.x] = s;
+      if (nblocks > 1) {
+        if (cheap) st_x<true>(&gs->vec[ph][threadIdx.x][bid], s);
+        else gs->vec[ph][threadIdx.x][bid] = s;
+      } else {
+        L->out[ph][threadIdx.x] = s;
+      }
     }
     if (nblocks > 1) {
       device_barrier();
@@ -152,7 +169,7 @@ struct Team {
 #pragma unroll
         for (int j = 0; j < BPL; ++j) {
           const unsigned b = lane + j * WAVE;
-          t[i][j] = (k < K && b < nblocks) ? gs->vec[ph][k][b] : 0.0;
+          t[i][j] = (k < K && b < nblocks) ? (cheap ? ld_x<true>(&gs->vec[ph][k][b]) : gs->vec[ph][k][b]) : 0.0;
         }
       }
 #pragma unroll
@@ -166,8 +183,7 @@ struct Team {
       }
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = L->out[ph][k];
+    return L->out[ph];
   }
 };
 
@@ -176,6 +192,7 @@ __device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgc
 // acc + sum_{k in [k0,k1)} val[k] * vec[idx[k]], added in index order. These entities stream from HBM/L2, where
 // a dependent (index -> gather) chain costs two memory latencies: eight entries are loaded, then gathered, at a
 // time, so a typical row (or short column) costs two latencies instead of two per entry.
+template <bool SC1 = false>
 __device__ __forceinline__ double gather_dot8(const float* __restrict__ val, const int32_t* __restrict__ idx,
                                               const double* __restrict__ vec, int k0, int k1, double acc) {
   for (int k = k0; k < k1; k += 8) {
@@ -189,7 +206,7 @@ __device__ __forceinline__ double gather_dot8(const float* __restrict__ val, con
       v[q] = ok ? val[k + q] : 0.0f;
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) xv[q] = (k + q < k1) ? vec[c[q]] : 0.0;
+    for (int q = 0; q < 8; ++q) xv[q] = (k + q < k1) ? ld_x<SC1>(vec + c[q]) : 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q)
       if (k + q < k1) acc += (double)v[q] * xv[q];
@@ -197,22 +214,23 @@ __device__ __forceinline__ double gather_dot8(const float* __restrict__ val, con
   return acc;
 }
 
-// f, g and every dot product the driver needs, at W.x. acc[] layout: 0 sum x_j^2 over regularised j,
-// 1 g'd, 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (y = g - r; chronological i < col), K-2 r'd, K-1 max|g_j|.
-template <int NW>
-__device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W,
-                                            int col, int head, double (&acc)[TEAM_K]
+// The two passes over the entity's matrix at W.x: logits, per-sample loss and residuals (CSR copy), then X'r by tiles of 64
+// coefficients per wavefront (CSC copy). Leaves g in W.g — every coefficient written by the thread that owns it (tile =
+// wavefront index + k * wavefronts of the team, lane = coefficient inside the tile) — and returns the loss sum.
+// SC1: x, the residuals and the partial sums of split columns are exchanged through sc1 accesses (ld_x / st_x above).
+template <int NW, bool SC1>
+__device__ __forceinline__ double team_fg(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W
 #ifdef GDMIX_TEAM_PROFILE
-                                            , unsigned long long (&prof_t)[8], unsigned long long& prof_last
+                                          , unsigned long long (&prof_t)[8], unsigned long long& prof_last
 #endif
-                                            ) {
-  const int n = P.n, p = P.p, ic = P.ic, m = o.m;
+                                          ) {
+  const int n = P.n, p = P.p, ic = P.ic;
   const double* __restrict__ x = W.x;
   // ---- rows: logits, per-sample loss and residual
   double pr[3] = {0.0, 0.0, 0.0};
-  const double x0 = ic ? x[0] : 0.0;
+  const double x0 = ic ? ld_x<SC1>(x) : 0.0;
   for (int i = tm.tid; i < n; i += tm.NT) {
-    const double a = gather_dot8(P.csr_val, P.csr_col, x + ic, P.row_ptr[i], P.row_ptr[i + 1], x0);
+    const double a = gather_dot8<SC1>(P.csr_val, P.csr_col, x + ic, P.row_ptr[i], P.row_ptr[i + 1], x0);
     const double z = a + (double)P.o[i];
     const double yi = (double)P.y[i];
     const double wi = P.w ? (double)P.w[i] : 1.0;
@@ -224,7 +242,7 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
     } else {
       pr[0] += logistic_terms(z, yi, wi, ri);
     }
-    W.rs[i] = ri;
+    st_x<SC1>(W.rs + i, ri);
     pr[1] += ri;
   }
   TEAM_PROF(0);
@@ -257,10 +275,10 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-          if (k + q * WAVE < k1) s += (double)v[q] * W.rs[r[q]];
+          if (k + q * WAVE < k1) s += (double)v[q] * ld_x<SC1>(W.rs + r[q]);
       }
       s = wave_sum(s);
-      if (tm.lane == 0) W.part[item] = s;
+      if (tm.lane == 0) st_x<SC1>(W.part + item, s);
     }
     tm.sync();
   }
@@ -286,7 +304,7 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
     const int maxlen = (int)wave_max_nonneg((double)(ce - cbx));
     double mine = 0.0;
     if (maxlen <= TEAM_SHORT_COL) {
-      mine = gather_dot8(P.csc_val, P.csc_row, W.rs, cbx, ce, 0.0);
+      mine = gather_dot8<SC1>(P.csc_val, P.csc_row, W.rs, cbx, ce, 0.0);
     } else {
       // the tile's columns are one contiguous run of the CSC arrays: the wavefront streams it in chunks (coalesced
       // loads, eight per lane in flight), parks the products in LDS, and every lane adds up its own column's part
@@ -311,7 +329,7 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
             r[q] = ok ? P.csc_row[kk] : 0;
           }
 #pragma unroll
-          for (int q = 0; q < 8; ++q) pr8[q] = (s0 + tm.lane + q * WAVE < s1) ? (double)v[q] * W.rs[r[q]] : 0.0;
+          for (int q = 0; q < 8; ++q) pr8[q] = (s0 + tm.lane + q * WAVE < s1) ? (double)v[q] * ld_x<SC1>(W.rs + r[q]) : 0.0;
         }
         if (__popcll(owners) == 1) {
           // one column owns the whole chunk (other entries, if any, belong to split columns and are masked out)
@@ -346,7 +364,7 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
         if (lm) {
           cl[q] = __ffsll((long long)lm) - 1;
           lm &= lm - 1;
-          t[q] = W.part[(size_t)readlane_i(li, cl[q]) * WAVE + tm.lane];
+          t[q] = ld_x<SC1>(W.part + (size_t)readlane_i(li, cl[q]) * WAVE + tm.lane);
         }
       }
 #pragma unroll
@@ -359,9 +377,31 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
     }
     if (valid) {
       const double a = (ic && j == 0) ? rsum : mine;
-      W.g[j] = inv_n * (a + ((j < first_reg) ? 0.0 : o.l2 * x[j]));
+      W.g[j] = inv_n * (a + ((j < first_reg) ? 0.0 : o.l2 * ld_x<SC1>(x + j)));
     }
   }
+  TEAM_PROF(2);
+  return loss;
+}
+
+// f, g and every dot product the driver needs, at W.x, all vectors in HBM. acc[] layout: 0 sum x_j^2 over regularised j,
+// 1 g'd, 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (y = g - r; chronological i < col), K-2 r'd, K-1 max|g_j|.
+template <int NW>
+__device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W,
+                                            int col, int head, double (&acc)[TEAM_K]
+#ifdef GDMIX_TEAM_PROFILE
+                                            , unsigned long long (&prof_t)[8], unsigned long long& prof_last
+#endif
+                                            ) {
+  const int n = P.n, p = P.p, ic = P.ic, m = o.m;
+  const double* __restrict__ x = W.x;
+  const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
+  const double inv_n = o.sum_loss ? 1.0 : 1.0 / (double)n;
+#ifdef GDMIX_TEAM_PROFILE
+  const double loss = team_fg<NW, false>(tm, P, o, W, prof_t, prof_last);
+#else
+  const double loss = team_fg<NW, false>(tm, P, o, W);
+#endif
   // Products with the gradient in a second sweep over the same coefficients (the thread that stored g[j] reads it
   // back: no synchronisation), so that the accumulators and the tile staging above are not live at the same time.
 #pragma unroll
@@ -464,6 +504,181 @@ __device__ void team_solve(Team<NW>& tm, const EntityView& P, const SolveParams&
            prof_t[0] * 0.01 / S.nfev, prof_t[1] * 0.01 / S.nfev, prof_t[2] * 0.01 / S.nfev, prof_t[3] * 0.01 / S.nfev,
            prof_t[4] * 0.01 / S.nfev, prof_t[5] * 0.01 / S.nfev, prof_t[6] * 0.01 / S.nfev);
 #endif
+  out.f = S.f;
+  out.gnorm = S.sbgnrm;
+  out.nit = S.nit;
+  out.nfev = S.nfev;
+  out.status = S.status;
+}
+
+// ---- the same solve with the L-BFGS vectors on chip ------------------------------------------------------------------
+// What an evaluation of a large entity moves is not its matrix but the L-BFGS history: 2 m p doubles read by the pass that
+// forms the products and again by the pass that forms the direction (p = 4.4 k: 1.4 MB against 88 KB of matrix). Every
+// coefficient already belongs to one thread for the whole solve (tile = wavefront + k * wavefronts of the team), so with a
+// team sized by p — at most EPL tiles per wavefront — that thread keeps its coefficients' x, g, d, x_old, g_old and all 2 m
+// history entries in registers (25 EPL doubles), the history as a shift register in chronological order (static indices).
+// Only x (for the row gathers) and the residuals (for the column gathers) still go through memory, as sc1 accesses, and the
+// barriers of an evaluation carry no cache maintenance (Team::cheap).
+template <int EPL>
+struct TeamRegs {
+  double x[EPL], g[EPL], d[EPL], t[EPL], r[EPL];
+  double S[TEAM_MCAP][EPL], Y[TEAM_MCAP][EPL];
+};
+
+template <int NW, int EPL>
+__device__ __forceinline__ double team_eval_reg(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W,
+                                                TeamRegs<EPL>& R, int col, const double*& acc) {
+  const int n = P.n, p = P.p, ic = P.ic;
+  const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
+  const double inv_n = o.sum_loss ? 1.0 : 1.0 / (double)n;
+#ifdef GDMIX_TEAM_PROFILE
+  unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = wall_clock64();
+  const double loss = team_fg<NW, true>(tm, P, o, W, prof_t, prof_last);
+#else
+  const double loss = team_fg<NW, true>(tm, P, o, W);
+#endif
+  // the products, one value at a time: its sum over this thread's coefficients, then over the wavefront, kept by lane k
+  // (an accumulator per value, as the HBM form has them, would be 54 more live registers next to the history)
+  double yv[EPL];
+  bool ok[EPL];
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) {
+    const int j = (tm.wid + i * tm.nwaves) * WAVE + tm.lane;
+    ok[i] = j < p;
+    R.g[i] = ok[i] ? W.g[j] : 0.0;   // this thread's own store of team_fg
+    yv[i] = R.g[i] - R.r[i];
+  }
+  double mine = 0.0;
+#define GDMIX_TREG_VALUE(K_, EXPR_, MAX_)                                   \
+  {                                                                         \
+    double t_ = 0.0;                                                        \
+    _Pragma("unroll") for (int i = 0; i < EPL; ++i) {                       \
+      const int j = (tm.wid + i * tm.nwaves) * WAVE + tm.lane;              \
+      (void)j;                                                              \
+      if (ok[i]) t_ = (MAX_) ? fmax(t_, (EXPR_)) : t_ + (EXPR_);            \
+    }                                                                       \
+    t_ = (MAX_) ? wave_max_nonneg(t_) : wave_sum(t_);                       \
+    if (tm.lane == (K_)) mine = t_;                                         \
+  }
+  GDMIX_TREG_VALUE(0, (j >= first_reg ? R.x[i] * R.x[i] : 0.0), false)
+  GDMIX_TREG_VALUE(1, R.g[i] * R.d[i], false)
+  GDMIX_TREG_VALUE(2, R.g[i] * R.g[i], false)
+  GDMIX_TREG_VALUE(3, yv[i] * yv[i], false)
+  GDMIX_TREG_VALUE(4, yv[i] * R.g[i], false)
+#pragma unroll
+  for (int a = 0; a < TEAM_MCAP; ++a) {
+    if (a < col) {   // uniform
+      GDMIX_TREG_VALUE(5 + a, R.S[a][i] * yv[i], false)
+      GDMIX_TREG_VALUE(5 + TEAM_MCAP + a, R.Y[a][i] * yv[i], false)
+    }
+  }
+  GDMIX_TREG_VALUE(TEAM_RD, R.r[i] * R.d[i], false)
+  GDMIX_TREG_VALUE(TEAM_K - 1, fabs(R.g[i]), true)
+#undef GDMIX_TREG_VALUE
+  acc = tm.template reduce_placed<TEAM_K>(mine);
+  return inv_n * (loss + 0.5 * o.l2 * acc[0]);
+}
+
+// The elementwise part of a step for the coefficient in register slot i (compact_update of re_lbfgs_compact.hpp with the
+// vectors in registers). Returns the new x_j.
+template <int EPL>
+__device__ __forceinline__ double compact_update_reg(const CompactPlan& plan, const CompactMats& L, TeamRegs<EPL>& R, int i, int m) {
+  if (plan.action == CA_RETRY) {
+    R.x[i] = plan.stp * R.d[i] + R.t[i];
+    return R.x[i];
+  }
+  const double gj = plan.restore ? R.r[i] : R.g[i];
+  const double xj = plan.restore ? R.t[i] : R.x[i];
+  if (plan.store_pair) {
+    const double sn = plan.stp_prev * R.d[i];   // exact for stp == 1
+    const double yn = R.g[i] - R.r[i];
+    if (plan.shift) {
+#pragma unroll
+      for (int a = 0; a + 1 < TEAM_MCAP; ++a) {
+        if (a + 1 < m) { R.S[a][i] = R.S[a + 1][i]; R.Y[a][i] = R.Y[a + 1][i]; }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < TEAM_MCAP; ++a) {
+      if (a == plan.cnew) { R.S[a][i] = sn; R.Y[a][i] = yn; }
+    }
+  }
+  double dj = -gj;
+  if (plan.col > 0) {
+    double su = 0.0, yq = 0.0;
+#pragma unroll
+    for (int a = 0; a < TEAM_MCAP; ++a) {
+      if (a < plan.col) {
+        su += L.u[a] * R.S[a][i];
+        yq += L.q[a] * R.Y[a][i];
+      }
+    }
+    dj = plan.gamma * (yq - gj) - su;
+  }
+  const double z = xj + dj;   // mainlb re-derives d from the subspace point
+  dj = z - xj;
+  R.d[i] = dj;
+  R.t[i] = xj;
+  R.r[i] = gj;
+  R.x[i] = plan.stp * dj + xj;
+  return R.x[i];
+}
+
+// Requires 1 <= o.m <= TEAM_MCAP and p <= EPL * 64 * wavefronts of the team. theta0 may be NULL (zeros). The coefficients
+// are written straight from the owners' registers (theta_out / thr_out: the entity's slices, either may be NULL); W.x holds
+// theta on exit for sc1 readers (variance_simple<true>).
+template <int NW, int EPL>
+__device__ void team_solve_reg(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W, const double* theta0,
+                               double* theta_out, double* thr_out, SolveStats& out) {
+  const int p = P.p, m = o.m;
+  TeamLds<NW>& L = *tm.L;
+  team_long_setup(tm, P);
+  CompactState S;
+  compact_init(S);
+  CompactPlan plan;
+  const double* acc = nullptr;
+  TeamRegs<EPL> R;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) {
+    const int j = (tm.wid + i * tm.nwaves) * WAVE + tm.lane;
+    R.x[i] = (theta0 && j < p) ? theta0[j] : 0.0;
+    R.g[i] = 0.0; R.d[i] = 0.0; R.t[i] = 0.0; R.r[i] = 0.0;
+#pragma unroll
+    for (int a = 0; a < TEAM_MCAP; ++a) { R.S[a][i] = 0.0; R.Y[a][i] = 0.0; }
+    if (j < p) st_x<true>(W.x + j, R.x[i]);
+  }
+  tm.sync();
+  for (;;) {
+    const double f_new = team_eval_reg<NW, EPL>(tm, P, o, W, R, S.col, acc);
+    if (tm.aborted()) { ++S.nfev; S.status = GDMIX_RE_ST_ABORTED; break; }
+    compact_advance(S, acc, f_new, o, L.mats, plan);
+    if (plan.action == CA_STOP) break;
+    if (plan.action == CA_STOP_RESTORE) {
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) {
+        const int j = (tm.wid + i * tm.nwaves) * WAVE + tm.lane;
+        if (j < p) st_x<true>(W.x + j, R.t[i]);
+      }
+      tm.sync();
+      break;
+    }
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      const int j = (tm.wid + i * tm.nwaves) * WAVE + tm.lane;
+      if (j < p) st_x<true>(W.x + j, compact_update_reg<EPL>(plan, L.mats, R, i, m));
+    }
+    tm.sync();
+  }
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) {
+    const int j = (tm.wid + i * tm.nwaves) * WAVE + tm.lane;
+    if (j < p) {
+      const double v = (plan.action == CA_STOP_RESTORE) ? R.t[i] : R.x[i];
+      if (theta_out) theta_out[j] = v;
+      // threshold_coefficients: |x| <= threshold -> 0.0, intercept included (util/model_utils.py:4-12)
+      if (thr_out) thr_out[j] = (fabs(v) <= o.threshold) ? 0.0 : v;
+    }
+  }
   out.f = S.f;
   out.gnorm = S.sbgnrm;
   out.nit = S.nit;
