@@ -23,6 +23,7 @@ class RawBatch:
     entity_ids: Optional[List[str]] = None  # [E] str(entity id) as job_consumers.py:235-239 renders it
     has_label: bool = True
     binary_labels: bool = True              # False: real-valued labels (fixed-effect linear regression)
+    trusted: bool = False                   # built by the native reader, which checked all of validate() while decoding
 
     def __post_init__(self):
         self.ent_row_ptr = np.ascontiguousarray(self.ent_row_ptr, np.int64)
@@ -35,7 +36,8 @@ class RawBatch:
             self.weight = np.ascontiguousarray(self.weight, np.float32)
         if self.uid is not None:
             self.uid = np.ascontiguousarray(self.uid, np.int64)
-        self.validate()
+        if not self.trusted:
+            self.validate()
 
     @property
     def E(self):

@@ -10,7 +10,7 @@ from ..batch import RawBatch
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "libgdmix_io.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 EXPORTED_SYMBOLS = ("gdmix_io_abi_version", "gdmix_io_last_error", "gdmix_io_read_grouped", "gdmix_io_free",
                     "gdmix_io_crc32c", "gdmix_io_masked_crc32c", "gdmix_io_avro_write_models", "gdmix_io_avro_write_scores",
                     "gdmix_io_write_grouped", "gdmix_io_read_examples", "gdmix_io_avro_read_models", "gdmix_io_free_models", "gdmix_io_map_coefficients")
@@ -31,7 +31,7 @@ class _Batch(C.Structure):
                 ("row_nnz_ptr", C.POINTER(C.c_int64)), ("col_global", C.POINTER(C.c_int64)), ("val", C.POINTER(C.c_float)),
                 ("y", C.POINTER(C.c_float)), ("offset", C.POINTER(C.c_float)), ("weight", C.POINTER(C.c_float)),
                 ("uid", C.POINTER(C.c_int64)), ("ent_id_ptr", C.POINTER(C.c_int64)), ("ent_id_bytes", C.POINTER(C.c_char)),
-                ("has_label", C.c_int32), ("bytes_read", C.c_int64)]
+                ("has_label", C.c_int32), ("bytes_read", C.c_int64), ("labels_binary", C.c_int32)]
 
 
 class _ModelTable(C.Structure):
@@ -173,11 +173,15 @@ def read_grouped_files(files, entity_name, feature_bag, offset_column_name, uid_
     if stats is not None:
         stats["bytes_read"] = int(b.bytes_read)
     v = lambda ptr, n, dt: _view(owner, ptr, n, dt)
+    if bool(b.has_label) and not int(b.labels_binary):
+        raise AssertionError("labels must be 0 or 1")   # fit() asserts it (binary_logistic_regression.py:208)
+    # the library built these arrays itself (monotone pointers, matching lengths, labels checked while decoding): the
+    # passes RawBatch.validate would make over them are skipped
     return RawBatch(ent_row_ptr=v(b.ent_row_ptr, E + 1, np.int64), row_nnz_ptr=v(b.row_nnz_ptr, N + 1, np.int64),
                     col_global=v(b.col_global, Z, np.int64), val=v(b.val, Z, np.float32),
                     y=v(b.y, N, np.float32), offset=v(b.offset, N, np.float32),
                     weight=v(b.weight, N, np.float32) if weight_column_name is not None else None,
-                    uid=v(b.uid, N, np.int64), entity_ids=ids, has_label=bool(b.has_label))
+                    uid=v(b.uid, N, np.int64), entity_ids=ids, has_label=bool(b.has_label), trusted=True)
 
 
 # ---- Avro writers ------------------------------------------------------------------------------------------

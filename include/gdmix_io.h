@@ -37,7 +37,7 @@ extern "C" {
 #define GDMIX_IO_ESCHEMA  (-4)   /* a record does not match the schema (missing column, length mismatch, ...) */
 #define GDMIX_IO_ENOMEM   (-5)
 
-#define GDMIX_IO_ABI_VERSION 2
+#define GDMIX_IO_ABI_VERSION 3
 
 typedef struct gdmix_io_schema {
   const char* entity;        /* context key of the entity id (int64 or bytes scalar)                       */
@@ -70,6 +70,8 @@ typedef struct gdmix_io_batch {
                            * (job_consumers.py:235-239)                            */
   int32_t  has_label;
   int64_t  bytes_read;    /* decompressed bytes of TFRecord framing parsed         */
+  int32_t  labels_binary; /* every label read is exactly 0 or 1 (what fit() asserts, binary_logistic_regression.py:208);
+                           * checked while decoding, so that the caller need not pass over y again */
 } gdmix_io_batch;
 
 GDMIX_IO_API int gdmix_io_abi_version(void);
