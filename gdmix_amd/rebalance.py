@@ -119,6 +119,16 @@ class _Comm:
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
         self.device = device
+        self._pinned = {}     # (direction, dtype) -> page-locked staging tensor, grown as needed and reused from round to round
+
+    def _stage(self, key, count, tdt):
+        """A page-locked host tensor of at least `count` elements (RCCL path: the device copies run at PCIe rate and without a
+        pageable bounce buffer)."""
+        buf = self._pinned.get((key, tdt))
+        if buf is None or buf.numel() < count:
+            buf = self.t.empty(max(count, 1) + max(count, 1) // 4, dtype=tdt).pin_memory()
+            self._pinned[(key, tdt)] = buf
+        return buf[:count]
 
     def all_gather_floats(self, x):
         t = self.t
@@ -136,11 +146,23 @@ class _Comm:
         self.dist.all_to_all_single(rsizes, sizes, group=self.group)
         rs = [int(x) for x in rsizes.tolist()]
         flat = np.concatenate([np.asarray(p, dtype) for p in parts]) if parts else np.zeros(0, dtype)
-        send = t.from_numpy(np.ascontiguousarray(flat)).to(self.device)
+        on_device = self.device.type != "cpu"
+        if on_device:   # host arrays -> page-locked staging -> HBM; the exchange itself is device to device (RCCL over xGMI)
+            hs = self._stage("send", flat.size, tdt)
+            hs.numpy()[...] = flat
+            send = hs.to(self.device, non_blocking=True)
+        else:
+            send = t.from_numpy(np.ascontiguousarray(flat))
         recv = t.zeros(sum(rs), dtype=tdt, device=self.device)
         self.dist.all_to_all_single(recv, send, output_split_sizes=rs, input_split_sizes=[int(p.size) for p in parts],
                                     group=self.group)
-        r = recv.cpu().numpy()
+        if on_device:
+            hr = self._stage("recv", recv.numel(), tdt)
+            hr.copy_(recv, non_blocking=True)
+            t.cuda.current_stream(self.device).synchronize()
+            r = hr.numpy().copy()
+        else:
+            r = recv.numpy()
         out, p = [], 0
         for n in rs:
             out.append(r[p:p + n])

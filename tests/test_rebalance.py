@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from gdmix_amd import synthetic
 from gdmix_amd.io import avro
@@ -110,3 +111,17 @@ def test_two_ranks_rebalance_skewed_partitions_and_write_the_same_models(tmp_pat
     assert rounds[0][0]["with_prior"] and rounds[0][0]["sent"][1] > 0
     r1 = rounds[1][0]    # rank 1, first round: its own light partition plus what rank 0 gave away
     assert r1["prior_models"] == r1["solved"] > r1["entities"]     # every entity came with its model
+
+
+@pytest.mark.gpu
+def test_rccl_branch_of_the_exchange_runs_on_device_memory():
+    """The `nccl` (= RCCL) branch of rebalance._Comm has only one GPU to run on here: a single-rank process group, device
+    tensors, payloads of every dtype the exchange uses travelling rank 0 -> rank 0 through RCCL, page-locked staging on
+    both sides, and a whole exchange / give_back round (tests/_nccl_worker.py)."""
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TF_CONFIG", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_nccl_worker.py")], env=env, timeout=600, cwd=ROOT,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "nccl single-rank exchange ok" in r.stdout
