@@ -92,7 +92,9 @@ __global__ void fe_prepare_kernel(FeDev F) {
 }
 
 // what is done with a finished segment sum
-template <bool ROWS>
+// HESS: the pass computes the diagonal of X~' D X~ instead of the gradient (fixed_effect_lr_lbfgs_model.py:271-296): the row pass
+// leaves d_i = w_i rho_i (1 - rho_i), rho = sigmoid(logit), the column pass sums val^2 d_i
+template <bool ROWS, bool HESS = false>
 __device__ __forceinline__ void fe_emit(const FeDev& F, const SolveParams& o, int s, double sum, double xb, float fo, float fy, float fw,
                                         double& loss, double& rsum) {
   if (ROWS) {
@@ -100,7 +102,10 @@ __device__ __forceinline__ void fe_emit(const FeDev& F, const SolveParams& o, in
     const double yi = (double)fy;
     const double wi = (double)fw;
     double ri;
-    if (o.linear) {
+    if (HESS) {
+      const double rho = sigmoid_full(zi);
+      ri = wi * rho * (1.0 - rho);
+    } else if (o.linear) {
       const double e = zi - yi;
       loss += wi * e * e;
       ri = 2.0 * wi * e;
@@ -114,7 +119,7 @@ __device__ __forceinline__ void fe_emit(const FeDev& F, const SolveParams& o, in
   }
 }
 
-template <bool ROWS>
+template <bool ROWS, bool HESS = false>
 __global__ __launch_bounds__(FE_THREADS) void fe_stream_kernel(FeDev F, SolveParams o) {
   __shared__ double prod[FE_BLK + FE_BLK / 32];
   __shared__ double red[2][FE_WAVES];
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(FE_THREADS) void fe_stream_kernel(FeDev F, SolvePar
 #pragma unroll
   for (int q = 0; q < FE_BLK / FE_THREADS; ++q) {
     const int k = tid + q * FE_THREADS;
-    if (k < cnt) prod[fe_slot(k)] = (double)v[q] * vec[c[q]];
+    if (k < cnt) prod[fe_slot(k)] = (HESS && !ROWS) ? (double)v[q] * (double)v[q] * vec[c[q]] : (double)v[q] * vec[c[q]];
   }
   __syncthreads();
   double loss = 0.0, rsum = 0.0;
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(FE_THREADS) void fe_stream_kernel(FeDev F, SolvePar
     if (!by_wave || lane == 0) {
       if (is_carry) pf[b] = sum;                       // completed (or passed on) by fe_fix_kernel
       else if (a1full > k1) pl[b] = sum;               // continues in the next block
-      else fe_emit<ROWS>(F, o, s, sum, xb, fo, fy, fw, loss, rsum);
+      else fe_emit<ROWS, HESS>(F, o, s, sum, xb, fo, fy, fw, loss, rsum);
     }
   }
   if (ROWS) {
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(FE_THREADS) void fe_stream_kernel(FeDev F, SolvePar
 }
 
 // segments that cross block boundaries: the block in which such a segment ends adds up its parts in block order
-template <bool ROWS>
+template <bool ROWS, bool HESS = false>
 __global__ void fe_fix_kernel(FeDev F, SolveParams o) {
   const int32_t* __restrict__ ptr = ROWS ? F.row_ptr : F.col_ptr;
   const int32_t* __restrict__ own = ROWS ? F.own_r : F.own_c;
@@ -226,7 +231,7 @@ __global__ void fe_fix_kernel(FeDev F, SolveParams o) {
         const int ob = (int)((int64_t)ptr[s] / FE_BLK);
         double t = pl[ob];
         for (int bb = ob + 1; bb <= b; ++bb) t += pf[bb];
-        fe_emit<ROWS>(F, o, s, t, xb, ROWS ? F.o[s] : 0.0f, ROWS ? F.y[s] : 0.0f, (ROWS && F.w) ? F.w[s] : 1.0f, loss, rsum);
+        fe_emit<ROWS, HESS>(F, o, s, t, xb, ROWS ? F.o[s] : 0.0f, ROWS ? F.y[s] : 0.0f, (ROWS && F.w) ? F.w[s] : 1.0f, loss, rsum);
       }
     }
     if (ROWS) { F.loss_fix[b] = loss; F.rsum_fix[b] = rsum; }
@@ -656,6 +661,27 @@ GDMIX_API int gdmix_fe_eval(gdmix_fe_problem* p, void* stream) {
   hipLaunchKernelGGL(fe_finish2_kernel, dim3(1), dim3(WAVE), 0, s, F);
   HIP_TRY(hipGetLastError());
   p->timed = true;
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_fe_hessian_diag(gdmix_fe_problem* p, const double* theta, void* stream) {
+  if (!p) { set_error("problem is NULL"); return GDMIX_RE_EINVAL; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  FeDev F = p->F;
+  if (theta) F.W.x = const_cast<double*>(theta);   // the passes only read x
+  HIP_TRY(hipMemsetAsync(F.fg, 0, ((size_t)F.P + 1) * 8, s));
+  int gd = (F.d + 255) / 256;
+  if (gd > 2048) gd = 2048;
+  if (gd < 1) gd = 1;
+  int gf = (F.nblk + 255) / 256;
+  hipLaunchKernelGGL(fe_prepare_kernel, dim3(gd), dim3(256), 0, s, F);
+  hipLaunchKernelGGL((fe_stream_kernel<true, true>), dim3(F.nblk), dim3(FE_THREADS), 0, s, F, p->o);
+  hipLaunchKernelGGL((fe_fix_kernel<true, true>), dim3(gf), dim3(256), 0, s, F, p->o);
+  hipLaunchKernelGGL((fe_stream_kernel<false, true>), dim3(F.nblk), dim3(FE_THREADS), 0, s, F, p->o);
+  hipLaunchKernelGGL((fe_fix_kernel<false, true>), dim3(gf), dim3(256), 0, s, F, p->o);
+  hipLaunchKernelGGL(fe_finish_kernel, dim3(gd < FE_FIN_BLOCKS ? FE_FIN_BLOCKS : gd), dim3(FE_THREADS), 0, s, F);
+  hipLaunchKernelGGL(fe_finish2_kernel, dim3(1), dim3(WAVE), 0, s, F);   // fg[D] = sum_i d_i (the intercept's entry), fg[P] unused
+  HIP_TRY(hipGetLastError());
   return GDMIX_RE_OK;
 }
 

@@ -128,8 +128,8 @@ class FixedEffectLRModelLBFGS:
     def __init__(self, raw_model_params, base_training_params, device=None):
         self.model_params: FixedLRParams = self._parse_parameters(raw_model_params)
         p = self.model_params
-        if p.fixed_effect_variance_mode is not None:
-            raise NotImplementedError("fixed_effect_variance_mode is not available on this library")
+        self.fixed_effect_variance_mode = p.fixed_effect_variance_mode
+        self.variances = None
         self.training_output_dir = base_training_params.training_score_dir
         self.validation_output_dir = base_training_params.validation_score_dir
         self.model_type = base_training_params.model_type
@@ -200,14 +200,20 @@ class FixedEffectLRModelLBFGS:
             data["y"], D, offset=data["offset"], weight=data["weight"] if data["has_weight"] else None,
             has_intercept=self.has_intercept, l2=self.l2_reg_weight, regularize_bias=self.is_regularize_bias,
             model_type=self.model_type, theta0=self._strip_dummy(x0) if not bag else x0, max_iter=self.max_iteration,
-            m=self.num_correction_pairs, tolerance=self.model_params.lbfgs_tolerance, dummy=not bag)
+            m=self.num_correction_pairs, tolerance=self.model_params.lbfgs_tolerance, dummy=not bag,
+            variance_mode=self.fixed_effect_variance_mode, threshold=self.sparsity_threshold)
+        self.variances = info.pop("variances", None)
         if not bag:
             theta = np.concatenate([[0.0], theta])   # the dummy weight of an intercept-only model (add_dummy_weight)
+            if self.variances is not None:
+                self.variances = np.concatenate([[0.0], self.variances])
         self.last_training_info = info
         logger.info(f"f_min: {info['fval']} num of funcalls: {info['nfev']} status: {info['status']}")
         theta = np.where(np.abs(theta) <= self.sparsity_threshold, 0.0, theta)   # threshold_coefficients (:648-649)
         self.model_coefficients = theta
-        if not self.disable_fixed_effect_scoring_after_training:
+        # the reference's variance computation rides on the scoring pass over the training data, which therefore runs (and writes
+        # its scores) whenever a variance mode is set (:650-661)
+        if not self.disable_fixed_effect_scoring_after_training or self.fixed_effect_variance_mode is not None:
             self._score_and_write(theta, data, task_index, schema_params, self.training_output_dir)
         if validation_data_dir:
             vdata = self._read(validation_data_dir, num_workers, task_index, schema_params)
@@ -274,11 +280,15 @@ class FixedEffectLRModelLBFGS:
         bag = self.feature_bag_name is not None
         weights = theta[:D] if bag else np.zeros(0)
         local = np.concatenate([theta[D:D + ic], weights])   # intercept first, as the export helper expects
+        var_local = None
+        if self.variances is not None:
+            var_local = np.concatenate([self.variances[D:D + ic], self.variances[:D] if bag else np.zeros(0)])
         table = ModelTable()
-        table.add_chunk([GLOBAL_MODEL_ID], local, [0, local.size], np.arange(weights.size, dtype=np.int64), [0, weights.size])
+        table.add_chunk([GLOBAL_MODEL_ID], local, [0, local.size], np.arange(weights.size, dtype=np.int64), [0, weights.size],
+                        variance=var_local)
         feature_list = read_feature_list(self.feature_file) if self.feature_file else None
         output_file = os.path.join(self.checkpoint_path, "part-00000.avro")
-        _export_models_to_avro(output_file, table, feature_list, self.has_intercept, False, self.sparsity_threshold,
+        _export_models_to_avro(output_file, table, feature_list, self.has_intercept, self.variances is not None, self.sparsity_threshold,
                                model_class=MODEL_CLASS[self.model_type])
         logger.info(f"dumped the global model to {output_file}")
 

@@ -200,6 +200,12 @@ class _SteppingProblem:
                                              self.solver._stream()), "gdmix_fe_result")
         return theta.cpu().numpy(), dict(fval=f.value, gnorm=g.value, nit=int(nit.value), nfev=int(nfev.value))
 
+    def hessian_diag(self, theta_dev=None):
+        """diag(X~' D X~) of the shard at theta (device tensor [D + has_intercept], None = the current point) into the reduce
+        buffer (gdmix_fe_hessian_diag)."""
+        self._check(self.lib.gdmix_fe_hessian_diag(self._h, None if theta_dev is None else theta_dev.data_ptr(), self.solver._stream()),
+                    "gdmix_fe_hessian_diag")
+
     def last_eval_ms(self):
         a, b = C.c_float(), C.c_float()
         self._check(self.lib.gdmix_fe_last_eval_ms(self._h, C.byref(a), C.byref(b)), "gdmix_fe_last_eval_ms")
@@ -243,7 +249,7 @@ def run_stepping_loop(problem, all_reduce=None, max_evals=100000):
 
 def _fit_stepping(self, row_nnz_ptr, col_global, val, y, num_features, offset=None, weight=None, has_intercept=True, l2=1.0,
                   regularize_bias=True, model_type=LOGISTIC_REGRESSION, theta0=None, max_iter=100, m=10, tolerance=1e-12,
-                  group=None, return_problem=False, dummy=None):
+                  group=None, return_problem=False, dummy=None, variance_mode=None, threshold=0.0):
     """Same contract as fit(), through include/gdmix_fe.h. With torch.distributed initialised (or `group` given) every
     worker calls this with its own shard; the coefficients returned are identical on all workers. dummy: True for a
     model without a feature bag (intercept only), False for a bagged model — also when this worker's shard happens to
@@ -286,12 +292,75 @@ def _fit_stepping(self, row_nnz_ptr, col_global, val, y, num_features, offset=No
     status = run_stepping_loop(prob, all_reduce)
     theta, info = prob.result()
     info["status"] = status
+    if variance_mode is not None:
+        # the variances of the thresholded model on the training data, as the reference's scoring pass after training computes
+        # them (fixed_effect_lr_lbfgs_model.py:648-661, 271-305, 451-463)
+        th = np.where(np.abs(theta) <= threshold, 0.0, theta)
+        info["variances"] = _variances(s, prob, batch, th, D, has_intercept, float(l2), bool(regularize_bias) and bool(has_intercept),
+                                       str(variance_mode).upper(), all_reduce, group)
+        if dummy:
+            info["variances"] = info["variances"][D:]
     if dummy:
         theta = theta[D:]
     if return_problem:
         return theta, info, prob
     prob.close()
     return theta, info
+
+
+FULL_VARIANCE_MAX_FEATURES = 4096   # FULL densifies a (D + 1) x (D + 1) Hessian, as the reference does
+
+
+def _variances(solver, prob, batch, theta, D, has_intercept, l2, regularize_bias, mode, all_reduce, group):
+    """variance of every coefficient (intercept last). SIMPLE: 1 / (diag(X~' D X~) + l2 [regularised] + 1e-12), the diagonal by two
+    more streaming passes on the device and the same all-reduce as an evaluation. FULL: diag((X~' D X~ + (l2 + 1e-12) I - l2
+    [intercept unregularised])^-1): the dense matrix is built on the host from the shard (scipy), summed over the workers and
+    inverted with numpy, exactly as the reference does (:296-305, 457-463) — only sensible for small feature spaces."""
+    eps = 1.0e-12
+    ic = 1 if has_intercept else 0
+    P = D + ic
+    if mode == "SIMPLE":
+        t = solver.torch
+        prob.hessian_diag(t.from_numpy(np.ascontiguousarray(theta, np.float64)).to(solver.device))
+        buf = prob.reduce_tensor()
+        if all_reduce is not None:
+            all_reduce(buf)
+        H = buf[:P].cpu().numpy().copy()
+        H += l2
+        if ic and not regularize_bias:
+            H[-1] -= l2
+        return 1.0 / (H + eps)
+    if mode != "FULL":
+        raise ValueError(f"unknown variance mode {mode!r}")
+    if P > FULL_VARIANCE_MAX_FEATURES:
+        raise ValueError(f"fixed_effect_variance_mode FULL inverts a dense {P} x {P} matrix; at most {FULL_VARIANCE_MAX_FEATURES} features")
+    import scipy.sparse as sp
+    n = batch.N
+    X = sp.csr_matrix((batch.val.astype(np.float64), batch.col_global, batch.row_nnz_ptr), shape=(n, max(D, 1)))[:, :D]
+    if ic:
+        X = sp.hstack([X, sp.csr_matrix(np.ones((n, 1)))], format="csr")
+    z = X @ theta + batch.offset.astype(np.float64)
+    rho = 1.0 / (1.0 + np.exp(-z))
+    d = rho * (1.0 - rho) * (1.0 if batch.weight is None else batch.weight.astype(np.float64))
+    H = np.asarray((X.T @ X.multiply(d[:, None])).todense(), np.float64)
+    try:
+        import torch
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            ht = torch.from_numpy(H)
+            if dist.get_backend(group) == "nccl":
+                hd = ht.to(solver.device)
+                dist.all_reduce(hd, group=group)
+                H = hd.cpu().numpy()
+            else:
+                dist.all_reduce(ht, group=group)
+                H = ht.numpy()
+    except ImportError:
+        pass
+    H = H + np.diag([l2 + eps] * P)
+    if ic and not regularize_bias:
+        H[-1, -1] -= l2
+    return np.diagonal(np.linalg.inv(H)).copy()
 
 
 FixedEffectDeviceSolver.fit_stepping = _fit_stepping

@@ -50,6 +50,14 @@ GDMIX_API int gdmix_fe_eval(gdmix_fe_problem* p, void* stream);
 /* The buffer gdmix_fe_eval fills and gdmix_fe_step consumes: *count = D + has_intercept + 1 doubles. */
 GDMIX_API double* gdmix_fe_reduce_buffer(gdmix_fe_problem* p, int64_t* count);
 
+/* Diagonal of the data term's Hessian X~' D X~ of the shard at theta (device pointer [D + has_intercept], intercept last;
+ * NULL = the current point), D_i = w_i rho_i (1 - rho_i), rho = sigmoid(x_i . w + b + offset_i) — what
+ * fixed_effect_lr_lbfgs_model.py:271-296 accumulates batch by batch for fixed_effect_variance_mode = SIMPLE. Written to the
+ * reduce buffer in place of the gradient (entries [0, D + has_intercept); the last entry is unused): the same all-reduce as
+ * an evaluation makes it the whole data set's, and variance_j = 1 / (H_j + l2 [j regularised] + 1e-12) (:451-456). The
+ * reference does this arithmetic in float32, this library in float64. Two more streaming passes over the shard. */
+GDMIX_API int gdmix_fe_hessian_diag(gdmix_fe_problem* p, const double* theta, void* stream);
+
 /* Consumes the (all-reduced) buffer. *status: -1 = evaluate again, else GDMIX_RE_ST_*. Synchronises the stream. */
 GDMIX_API int gdmix_fe_step(gdmix_fe_problem* p, void* stream, int32_t* status);
 

@@ -198,7 +198,7 @@ class OracleFeDouble:
 
     def fit_stepping(self, row_nnz_ptr, col_global, val, y, num_features, offset=None, weight=None, has_intercept=True, l2=1.0,
                      regularize_bias=True, model_type="logistic_regression", theta0=None, max_iter=100, m=10, tolerance=1e-12,
-                     group=None, dummy=None):
+                     group=None, dummy=None, variance_mode=None, threshold=0.0):
         from gdmix_amd import fixed_effect as fe
         from oracle import oracle
         linear = model_type == fe.LINEAR_REGRESSION
@@ -221,7 +221,33 @@ class OracleFeDouble:
                              max_iter=max_iter, ftol=tolerance, threshold=0.0, sum_loss=True, linear=linear)
         res = oracle.solve(pk, batch.val, batch.y, batch.offset, batch.weight, o, theta0=t0)
         theta = fe.to_global(res["theta"], uniq, D, has_intercept, False)
+        variances = None
+        if variance_mode is not None:
+            class _NoDevice:    # FULL runs on the host; SIMPLE stated here in numpy (the device pass is tested on the GPU)
+                pass
+            th = np.where(np.abs(theta) <= threshold, 0.0, theta)
+            rb = bool(regularize_bias) and has_intercept
+            if str(variance_mode).upper() == "FULL":
+                variances = fe._variances(_NoDevice(), None, batch, th, D, has_intercept, float(l2), rb, "FULL", None, None)
+            else:
+                k = np.diff(batch.row_nnz_ptr)
+                rows = np.repeat(np.arange(batch.N), k)
+                z = np.bincount(rows, weights=batch.val.astype(np.float64) * th[batch.col_global], minlength=batch.N) + batch.offset
+                if has_intercept:
+                    z = z + th[D]
+                rho = 1.0 / (1.0 + np.exp(-z))
+                d = rho * (1 - rho) * (1.0 if batch.weight is None else batch.weight)
+                H = np.bincount(batch.col_global, weights=batch.val.astype(np.float64) ** 2 * d[rows], minlength=D)
+                if has_intercept:
+                    H = np.concatenate([H, [d.sum()]])
+                H = H + l2
+                if has_intercept and not rb:
+                    H[-1] -= l2
+                variances = 1.0 / (H + 1e-12)
         if dummy:
             theta = theta[D:]
-        return theta, dict(fval=res["fval"][0], gnorm=res["gnorm"][0], nit=int(res["nit"][0]), nfev=int(res["nfev"][0]),
+            if variances is not None:
+                variances = variances[D:]
+        extra = {} if variances is None else {"variances": variances}
+        return theta, dict(**extra, fval=res["fval"][0], gnorm=res["gnorm"][0], nit=int(res["nit"][0]), nfev=int(res["nfev"][0]),
                            status=int(res["status"][0]))

@@ -195,11 +195,53 @@ def test_file_sharding_rules(tmp_path):
     assert len(allf) == 7 and shard_input_files(str(tmp_path), 2, 0) == allf[0::2] and shard_input_files(str(tmp_path), 2, 1) == allf[1::2]
 
 
-def test_variance_mode_is_rejected(tmp_path):
+def _dense_variances(c, theta, mode, l2, regularize_bias):
+    """The statement the reference's own test checks against (test_optimizer_helper.compute_coefficients_and_variance:
+    -1 / diag(Hessian) resp. -diag(Hessian^-1) of the log-likelihood), in dense numpy, plus the l2 terms of :451-463."""
+    D = int(c["num_features"])
+    rp, col, val = c["row_nnz_ptr"], c["col_global"], c["val"].astype(np.float64)
+    n = rp.size - 1
+    X = np.zeros((n, D + 1))
+    X[np.repeat(np.arange(n), np.diff(rp)), col] = val
+    X[:, D] = 1.0
+    z = X @ theta + c["offset"].astype(np.float64)
+    rho = 1 / (1 + np.exp(-z))
+    H = X.T @ (X * (rho * (1 - rho))[:, None])
+    if mode == "simple":
+        h = np.diagonal(H) + l2
+        if not regularize_bias:
+            h[-1] -= l2
+        return 1.0 / (h + 1e-12)
+    H = H + np.diag([l2 + 1e-12] * (D + 1))
+    if not regularize_bias:
+        H[-1, -1] -= l2
+    return np.diagonal(np.linalg.inv(H))
+
+
+@pytest.mark.parametrize("mode", ["simple", "full"])
+def test_variance_modes_write_the_variances_of_the_thresholded_model(tmp_path, mode):
+    """fixed_effect_variance_mode (fixed_effect_lr_lbfgs_model.py:271-305,451-463): variances of the saved (thresholded)
+    coefficients on the training data, next to the means in the model file; the training scores are written even with
+    scoring after training disabled, as upstream's variance pass rides on that scoring pass."""
     c = load("logistic_offset")
-    argv = setup_case(tmp_path, c) + ["--fixed_effect_variance_mode=simple"]
-    with pytest.raises(NotImplementedError):
-        FixedEffectLRModelLBFGS(argv, Params.__from_argv__(argv, error_on_unknown=False))
+    argv = setup_case(tmp_path, c) + [f"--fixed_effect_variance_mode={mode}", "--disable_fixed_effect_scoring_after_training=True"]
+    params = Params.__from_argv__(argv, error_on_unknown=False)
+    model = FixedEffectLRModelLBFGS(argv, params)
+    model._fe = OracleFeDouble()
+    FixedEffectDriver(params, model).run_training(SchemaParams.__from_argv__(argv, error_on_unknown=False), export_model=True)
+    assert (tmp_path / "ts" / "part-00000.avro").exists()
+    D = int(c["num_features"])
+    theta = model.model_coefficients
+    want = _dense_variances(c, theta, mode, float(c["l2"]), bool(c["has_intercept"]))
+    np.testing.assert_allclose(model.variances, want, rtol=1e-8)
+    rec = list(avro.read_file(str(tmp_path / "model" / "part-00000.avro")))[0]
+    means = {(m["name"], m["term"]): m["value"] for m in rec["means"]}
+    var = {(m["name"], m["term"]): m["value"] for m in rec["variances"]}
+    assert set(var) == set(means)                       # a variance for every coefficient written (gen_one_avro_model)
+    np.testing.assert_allclose(var[(constants.INTERCEPT, "")], want[D], rtol=1e-8)
+    for j in range(D):
+        if abs(theta[j]) > 1e-4:
+            np.testing.assert_allclose(var[(f"f{j}", f"t{j % 3}")], want[j], rtol=1e-8)
 
 
 @pytest.mark.gpu

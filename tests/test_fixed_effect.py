@@ -231,3 +231,34 @@ def test_device_scoring_of_a_raw_shard(device_solver, has_intercept):
         np.testing.assert_allclose(pe, np.full(n, theta[D], np.float32), rtol=1e-7)
     with pytest.raises(ValueError):
         s.score(rp, np.where(cols == cols[0], D, cols), vals, off, theta, D, has_intercept)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("regularize_bias", [False, True])
+def test_device_hessian_diagonal_and_simple_variance(device_solver, regularize_bias):
+    """gdmix_fe_hessian_diag: two streaming passes (rows -> w rho (1 - rho), columns -> sum val^2 d) against dense numpy, ragged
+    rows, weights, three row tiles of the column copy; then the SIMPLE variances through fit_stepping."""
+    rng = np.random.default_rng(17)
+    n, D = 600_000, 700
+    k = rng.integers(0, 9, n)
+    k[:3] = 0
+    rp = np.concatenate([[0], np.cumsum(k)]).astype(np.int64)
+    cols = np.concatenate([rng.choice(D, kk, replace=False) for kk in k[:2000]] + [rng.integers(0, D, int(k[2000:].sum()))]) if True else None
+    # (distinct columns inside a row for the first rows; the bulk may repeat a column in a row: both sides then add val^2 per entry)
+    vals = rng.standard_normal(rp[-1]).astype(np.float32)
+    y = (rng.random(n) < 0.5).astype(np.float32)
+    off = (0.3 * rng.standard_normal(n)).astype(np.float32)
+    wt = (0.5 + rng.random(n)).astype(np.float32)
+    s = fe.FixedEffectDeviceSolver(solver=device_solver)
+    l2 = 3.0
+    theta, info = s.fit_stepping(rp, cols, vals, y, D, offset=off, weight=wt, l2=l2, regularize_bias=regularize_bias, max_iter=30,
+                                 variance_mode="simple", threshold=1e-4)
+    th = np.where(np.abs(theta) <= 1e-4, 0.0, theta)
+    rows = np.repeat(np.arange(n), k)
+    z = np.bincount(rows, weights=vals.astype(np.float64) * th[cols], minlength=n) + th[D] + off
+    rho = 1 / (1 + np.exp(-z))
+    d = rho * (1 - rho) * wt
+    H = np.concatenate([np.bincount(cols, weights=vals.astype(np.float64) ** 2 * d[rows], minlength=D), [d.sum()]]) + l2
+    if not regularize_bias:
+        H[-1] -= l2
+    np.testing.assert_allclose(info["variances"], 1.0 / (H + 1e-12), rtol=1e-10)
