@@ -264,16 +264,37 @@ def main():
         all_ms = float(cls_ms.sum())
         nfev = res.nfev.double().mean().item()
         nit = res.nit.double().mean().item()
-        traffic = traffic_detail = None
+        traffic = traffic_detail = valu = None
+        traffic_note = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        # PMC bytes of the same kernel from a separate rocprofv3 --pmc run of this configuration (tools/profile_round.sh)
-        if os.path.exists(tpath) and a.workload == "c2" and a.entities == 1_000_000 and (a.mean_n, a.k, a.dim) == (16, 4, 1024):
+        workload_id = f"{a.workload} E={a.entities} n~{a.mean_n} k={a.k} D={a.dim} survey-generator"
+        # PMC counters of the same kernel from separate rocprofv3 --pmc runs of this configuration (tools/profile_round.sh);
+        # they are per launch of a size class and only valid for the workload they were collected on
+        if not os.path.exists(tpath):
+            traffic_note = "profiles/latest_traffic.json is missing: run tools/profile_round.sh on the GPU box"
+        else:
             with open(tpath) as fh:
                 tj = json.load(fh)
-            traffic_detail = tj.get(classes[dom][0])
-            traffic = traffic_detail["bytes"] if traffic_detail else None
+            if tj.get("_workload") != workload_id:
+                traffic_note = f"PMC passes were collected on workload {tj.get('_workload')!r}, this run is {workload_id!r}"
+            elif classes[dom][0] not in tj:
+                traffic_note = f"no PMC pass holds the dominant class {classes[dom][0]!r}"
+            else:
+                traffic_detail = tj[classes[dom][0]]
+                traffic = traffic_detail["bytes"]
+                if traffic_detail.get("valu_insts"):
+                    # the binding resource: VALU issue. Peak = CUs x 4 SIMDs x clock / 4 cycles per wave64
+                    # fp64-path instruction.
+                    insts = float(traffic_detail["valu_insts"])
+                    peak = 256 * 4 * 2.4e9 / 4.0
+                    valu = {"insts_per_launch": insts, "insts_per_entity": insts / max(1, int(classes[dom][1])),
+                            "issue_rate_Ginst_s": insts / (dom_ms * 1e-3) / 1e9 if dom_ms else None,
+                            "issue_frac": insts / (dom_ms * 1e-3) / peak if dom_ms else None,
+                            "peak_Ginst_s": peak / 1e9,
+                            "source": "SQ_INSTS_VALU (rocprofv3 --pmc, separate pass) / live launch duration; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles"}
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "traffic_detail": traffic_detail,
+                    "valu": valu,
                     "kernel": classes[dom][0], "entities_in_launch": int(classes[dom][1]),
                     "avg_launch_ms": dom_ms, "alg_bytes_per_launch": dom_bytes,
                     "alg_bytes_per_entity": alg_bytes / batch.E,

@@ -1,6 +1,13 @@
 #!/usr/bin/env python3
-"""FETCH_SIZE + WRITE_SIZE (KB, rocprofv3 --pmc, separate passes) per dispatch of the solve kernels ->
-profiles/latest_traffic.json keyed by bench.py's class names (bytes per launch)."""
+"""PMC passes of the bench command (rocprofv3 --pmc, one counter group per pass, tools/profile_round.sh) ->
+profiles/latest_traffic.json, keyed by bench.py's size-class names:
+
+    bytes / fetch_bytes / write_bytes   FETCH_SIZE + WRITE_SIZE (KB) per dispatch
+    valu_insts                          SQ_INSTS_VALU per dispatch (wave-instructions)
+    valu_busy_cycles / wave_cycles      SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES per dispatch (quad-cycles) when collected
+
+    python tools/make_traffic_json.py FETCH.db WRITE.db OUT.json [SQ.db ...] [--workload "text"]
+"""
 import json
 import re
 import sqlite3
@@ -24,9 +31,21 @@ def class_name(kernel):
     return None
 
 
-fetch, write, out_path = sys.argv[1], sys.argv[2], sys.argv[3]
+args = sys.argv[1:]
+workload = None
+if "--workload" in args:
+    i = args.index("--workload")
+    workload = args[i + 1]
+    del args[i:i + 2]
+fetch, write, out_path, sq = args[0], args[1], args[2], args[3:]
 f = per_dispatch(fetch, "FETCH_SIZE")
 w = per_dispatch(write, "WRITE_SIZE")
+extra = {}
+for db in sq:
+    for counter, key in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_ACTIVE_INST_VALU", "valu_busy_cycles"), ("SQ_WAVE_CYCLES", "wave_cycles"),
+                         ("SQ_BUSY_CYCLES", "sq_busy_cycles")):
+        for k, (n, s) in per_dispatch(db, counter).items():
+            extra.setdefault(k, {})[key] = s / n
 res = {}
 for k, (n, s) in f.items():
     cn = class_name(k)
@@ -37,5 +56,8 @@ for k, (n, s) in f.items():
     res[cn] = {"fetch_bytes": s / n * 1024.0, "write_bytes": (ws / wn * 1024.0) if wn else None,
                "bytes": (s / n + (ws / wn if wn else 0.0)) * 1024.0, "dispatches": n,
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB), separate passes; 4-byte-per-lane reads, no x2 correction (calibrated, DESIGN.md section 5)"}
+    res[cn].update(extra.get(k, {}))
+if workload:
+    res["_workload"] = workload
 json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
