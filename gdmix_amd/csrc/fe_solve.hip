@@ -303,14 +303,18 @@ __global__ __launch_bounds__(FE_THREADS) void fe_dots_kernel(FeDev F, SolveParam
     acc[4] += yj * gj;
     acc[TEAM_RD] += rj * dj;
     acc[TEAM_K - 1] = fmax(acc[TEAM_K - 1], fabs(gj));
+    double2 h[TEAM_MCAP];   // all pairs requested before the first is used (see team_eval)
 #pragma unroll
     for (int i = 0; i < TEAM_MCAP; ++i) {
-      if (i < col) {
-        int sl = head + i;
-        if (sl >= m) sl -= m;
-        acc[5 + i] += F.W.ws[(size_t)sl * P + j] * yj;
-        acc[5 + TEAM_MCAP + i] += F.W.wy[(size_t)sl * P + j] * yj;
-      }
+      int sl = head + i;
+      if (sl >= m) sl -= m;
+      if (i >= m) sl = 0;
+      h[i] = compact_hist(F.W, m, j)[sl * COMPACT_HIST_STRIDE];
+    }
+#pragma unroll
+    for (int i = 0; i < TEAM_MCAP; ++i) {
+      acc[5 + i] += (i < col ? h[i].x : 0.0) * yj;
+      acc[5 + TEAM_MCAP + i] += (i < col ? h[i].y : 0.0) * yj;
     }
   }
   double mine = 0.0;
@@ -547,7 +551,7 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   const size_t o_fg = take((P + 1) * 8), o_ownr = take((nb + 1) * 4), o_ownc = take((nb + 1) * 4), o_cr = take(nb + 1), o_cc = take(nb + 1);
   const size_t o_part = take(nb * 8 * 8), o_acc = take((size_t)FE_DOT_BLOCKS * TEAM_K * 8), o_fin = take((size_t)FE_FIN_BLOCKS * 2 * 8);
   const size_t o_state = take(sizeof(CompactState)), o_plan = take(sizeof(CompactPlan)), o_mats = take(sizeof(CompactMats));
-  const size_t o_vec = take((size_t)(5 + 2 * opts->m) * P * 8), o_status = take(64);
+  const size_t o_vec = take(((size_t)5 * P + compact_hist_doubles((int64_t)P, opts->m)) * 8 + 16), o_status = take(64);
   hipError_t rc = hipMalloc(&p->pool, off);
   if (rc != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(rc)); delete p; return GDMIX_RE_ENOMEM; }
   char* base = static_cast<char*>(p->pool);
@@ -567,7 +571,8 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   F.mats = reinterpret_cast<CompactMats*>(base + o_mats);
   double* v = reinterpret_cast<double*>(base + o_vec);
   F.W.x = v; F.W.g = v + P; F.W.d = v + 2 * P; F.W.t = v + 3 * P; F.W.r = v + 4 * P;
-  F.W.ws = v + 5 * P; F.W.wy = v + (5 + (size_t)opts->m) * P;
+  F.W.ws = v + 5 * P + ((5 * P) & 1);   // 16-byte aligned: the interleaved history (re_lbfgs_compact.hpp) is read with 16-byte loads
+  F.W.wy = F.W.ws + (size_t)opts->m * P;
   F.W.rs = F.rs; F.W.alpha = nullptr; F.W.rho = nullptr; F.W.part = nullptr;
   p->status_dev = reinterpret_cast<int32_t*>(base + o_status);
   const int g = (int)((nb + 1 + 255) / 256);

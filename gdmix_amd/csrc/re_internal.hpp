@@ -127,7 +127,8 @@ __host__ __device__ inline size_t wave_lds_bytes(int p, int n, int nnz, int d, i
 
 // doubles of global scratch one block-kernel slot needs
 inline size_t block_slot_doubles(int64_t max_p, int64_t max_n, int m) {
-  return (size_t)(5 + 2 * m) * max_p + max_n + 2 * m + 8 + 256 * 64;   // + partial sums of split columns (team kernels)
+  // x g d t r | history (tiles of 64 coefficients, re_lbfgs_compact.hpp) | alpha rho | partial sums of split columns | residuals
+  return (size_t)5 * max_p + (size_t)2 * m * ((max_p + 63) & ~(int64_t)63) + max_n + 2 * m + 8 + 256 * 64;
 }
 
 hipError_t launch_classify(const gdmix_re_packed* b, int ic, int m, const ClassTable& tab, int32_t* cls_tmp,

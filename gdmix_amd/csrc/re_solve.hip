@@ -719,8 +719,9 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(GDMIX_
     W.d = dp; dp += max_p;
     W.t = dp; dp += max_p;
     W.r = dp; dp += max_p;
-    W.ws = dp; dp += (size_t)m * max_p;
-    W.wy = dp; dp += (size_t)m * max_p;
+    dp += (reinterpret_cast<uintptr_t>(dp) >> 3) & 1;   // the history is read with 16-byte loads
+    W.ws = dp; dp += (size_t)2 * m * ((max_p + 63) & ~(int64_t)63);   // tiles of 64 coefficients (re_lbfgs_compact.hpp)
+    W.wy = nullptr;
     W.alpha = dp; dp += m;
     W.rho = dp; dp += m;
     W.part = dp; dp += TEAM_LONG_CAP * WAVE;

@@ -406,27 +406,40 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
   // back: no synchronisation), so that the accumulators and the tile staging above are not live at the same time.
 #pragma unroll
   for (int k = 0; k < TEAM_K; ++k) acc[k] = 0.0;
-  for (int tile = tm.wid; tile * WAVE < p; tile += tm.nwaves) {
-    const int j = tile * WAVE + tm.lane;
-    if (j < p) {
-      const double xj = x[j];
-      const double gj = W.g[j];
-      const double dj = W.d[j], rj = W.r[j];
-      if (j >= first_reg) acc[0] += xj * xj;
-      acc[1] += gj * dj;
-      acc[2] += gj * gj;
-      const double yj = gj - rj;
-      acc[3] += yj * yj;
-      acc[4] += yj * gj;
-      acc[TEAM_RD] += rj * dj;
-      acc[TEAM_K - 1] = fmax(acc[TEAM_K - 1], fabs(gj));
+  // two tiles per trip: all 2 x (4 + m) loads of the trip are in flight before the first product (the passes over the history
+  // are bound by how many bytes a CU keeps in flight, not by arithmetic)
+  for (int tile = tm.wid; tile * WAVE < p; tile += 2 * tm.nwaves) {
+    const int jv[2] = {tile * WAVE + tm.lane, (tile + tm.nwaves) * WAVE + tm.lane};
+    const bool ok[2] = {jv[0] < p, jv[1] < p};
+    double xj[2], gj[2], dj[2], rj[2];
+    double2 h[2][TEAM_MCAP];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = ok[u] ? jv[u] : tm.lane;   // tile 0 always exists: a safe address for the lanes past the end
+      xj[u] = x[j]; gj[u] = W.g[j]; dj[u] = W.d[j]; rj[u] = W.r[j];
 #pragma unroll
       for (int i = 0; i < TEAM_MCAP; ++i) {
-        if (i < col) {
-          int sl = head + i;
-          if (sl >= m) sl -= m;
-          acc[5 + i] += W.ws[(size_t)sl * p + j] * yj;
-          acc[5 + TEAM_MCAP + i] += W.wy[(size_t)sl * p + j] * yj;
+        int sl = head + i;
+        if (sl >= m) sl -= m;
+        if (i >= m) sl = 0;
+        h[u][i] = compact_hist(W, m, j)[sl * COMPACT_HIST_STRIDE];   // slots without a pair yet are read and discarded
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (ok[u]) {
+        if (jv[u] >= first_reg) acc[0] += xj[u] * xj[u];
+        acc[1] += gj[u] * dj[u];
+        acc[2] += gj[u] * gj[u];
+        const double yj = gj[u] - rj[u];
+        acc[3] += yj * yj;
+        acc[4] += yj * gj[u];
+        acc[TEAM_RD] += rj[u] * dj[u];
+        acc[TEAM_K - 1] = fmax(acc[TEAM_K - 1], fabs(gj[u]));
+#pragma unroll
+        for (int i = 0; i < TEAM_MCAP; ++i) {
+          acc[5 + i] += (i < col ? h[u][i].x : 0.0) * yj;
+          acc[5 + TEAM_MCAP + i] += (i < col ? h[u][i].y : 0.0) * yj;
         }
       }
     }
