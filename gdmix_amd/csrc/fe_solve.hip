@@ -4,13 +4,15 @@
 // that the caller can all-reduce [gradient, value] across workers in between
 // (fixed_effect_lr_lbfgs_model.py:309-392: _train_model_fn; :394-430 _compute_loss_and_gradients; :635-643).
 //
-// The streaming passes (fe_stream_kernel) are HBM-bound and written for that: the non-zeros are cut into
-// fixed blocks of FE_BLK consecutive entries whatever the row / column lengths are (the CSR arrays for
-// X theta, the CSC copy for X'r), one workgroup per block; every lane loads 16 entries 256 apart (coalesced, all in
-// flight at once), multiplies by the gathered vector element and parks the product in LDS; then the segments
-// (rows / columns) that intersect the block are summed out of LDS — one thread per segment when they are short,
-// one wavefront per segment when they are long — in entry order, so the result does not depend on the launch.
-// A segment that crosses block boundaries leaves partial sums that a small second kernel adds up in block order.
+// The two passes (fe_scatter_kernel) are written for HBM: no gather may cost an L2 request per entry, and no sum may
+// depend on the launch. Each pass has its own copy of the non-zeros, grouped by block of FE_B consecutive *outputs* (rows
+// for X theta, columns for X'r) and, inside a block, in the order of the *gathered* vector (columns for X theta, rows for
+// X'r): one wavefront owns a block's FE_B accumulators in LDS, streams the block's entries (index of the gathered
+// element, value, 16-bit accumulator index: 10 B per entry, every byte once), reads the gathered vector almost
+// sequentially (a 128-byte line serves all the entries that fall into it, ~20 here, instead of one) and adds the
+// products into LDS with ds_add_f64. A block with many entries is cut into chunks of equal entry count, one wavefront
+// each, whose partial sums a second small kernel adds in chunk order. One wavefront per accumulator set and in-order
+// LDS atomics: a row's terms are added one by one in column order, a column's in row order, whatever the launch.
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -21,42 +23,49 @@
 #include "../../include/gdmix_fe.h"
 
 #include <new>
+#include <vector>
 
 namespace gdmix {
 
-#ifndef GDMIX_FE_BLK
-#define GDMIX_FE_BLK 2048
+#ifndef GDMIX_FE_B
+#define GDMIX_FE_B 2048
 #endif
-constexpr int FE_BLK = GDMIX_FE_BLK;   // entries per workgroup of a streaming pass
+#ifndef GDMIX_FE_UNROLL
+#define GDMIX_FE_UNROLL 8
+#endif
+constexpr int FE_B = GDMIX_FE_B;        // accumulators (rows / columns) per block: 16 KiB of LDS per wavefront
+constexpr int FE_U = GDMIX_FE_UNROLL;   // entries per lane in flight
 constexpr int FE_THREADS = 256;
-constexpr int FE_TILE_ROWS = 1 << 18;  // rows per tile of the CSC copy: 2 MiB of residuals, resident in an XCD's L2
-// LDS index of product k: one pad double per 32 so that equal-length rows do not land on one bank
-__device__ __forceinline__ int fe_slot(int k) { return k + (k >> 5); }
 constexpr int FE_WAVES = FE_THREADS / WAVE;
 constexpr int FE_DOT_BLOCKS = 512;
-constexpr int FE_FIN_BLOCKS = 64;   // workgroups (= lanes of the final wavefront) that add up the per-block partial sums
+constexpr int FE_FIN_BLOCKS = 64;   // workgroups (= lanes of the final wavefront) that add up the per-unit partial sums
+constexpr int FE_FIX_PER_BLOCK = FE_B / FE_THREADS;   // workgroups of fe_rows_fix_kernel per block
+static_assert(FE_B <= 65536 && FE_B % FE_THREADS == 0, "16-bit accumulator index");
+
+// one pass's copy of the non-zeros
+struct FeCopy {
+  const int32_t* key;      // [z] element of the gathered vector: local column (row pass) / row (column pass)
+  const float* val;        // [z]
+  const uint16_t* loc;     // [z] accumulator within the block
+  const int32_t* ustart;   // [nunit+1] unit -> first entry; units tile the copy
+  const int32_t* ublock;   // [nunit]
+  const int32_t* ufirst;   // [nblock+1] block -> first unit
+  double* part;            // [nunit][FE_B] partial sums of the blocks that have several units (column pass: of all)
+  int nunit, nblock;
+};
 
 struct FeDev {
-  int n, d, ic, P, nblk, m;
+  int n, d, ic, P, m;
   int64_t z, D;
-  const int32_t* row_ptr;   // [n+1]
-  const int32_t* csr_col;   // [z] local feature id
-  const float* csr_val;
-  const int32_t* col_ptr;   // [ntile*d+1] column copy cut into row tiles: segment t*d + c = column c, rows of tile t
-  const int32_t* csc_row;   // [z] sorted by (tile, column, row)
-  const float* csc_val;
-  int ntile, nseg_c;        // row tiles, ntile * d
+  FeCopy rc, cc;            // row pass, column pass
+  const int32_t* multi;     // [nmulti] row blocks cut into several units
+  int nmulti, nred;         // nred = rc.nunit + nmulti * FE_FIX_PER_BLOCK entries of loss_part / rsum_part
   const float *y, *o, *w;   // w may be NULL
   const int64_t* umap;      // [d] local -> global feature id
   double* xl;               // [d] x of the features present in this shard
   double* rs;               // [n] per-sample residual
-  double* gl;               // [ntile*d] data gradient per (tile, local column)
   double* fg;               // [P + 1] global data gradient (intercept last), then the data value
-  int32_t* own_r;           // [nblk+1] first row owned by a block of the CSR pass
-  int32_t* own_c;           // [nblk+1] first column owned by a block of the CSC pass
-  uint8_t *carry_r, *carry_c;   // [nblk]
-  double *pf_r, *pl_r, *pf_c, *pl_c;                        // [nblk] partial sums of the first / last segment of a block
-  double *loss_part, *rsum_part, *loss_fix, *rsum_fix;      // [nblk]
+  double *loss_part, *rsum_part;   // [nred]
   double* acc_part;         // [FE_DOT_BLOCKS][TEAM_K]
   double* fin_part;         // [FE_FIN_BLOCKS][2]
   CompactState* state;
@@ -65,197 +74,162 @@ struct FeDev {
   Work W;                   // global coefficient space, P each; ws / wy m*P
 };
 
-// first segment whose start position is >= pos (ptr non-decreasing, ptr[nseg] = z)
-__device__ __forceinline__ int seg_lower_bound(const int32_t* __restrict__ ptr, int nseg, int64_t pos) {
-  int lo = 0, hi = nseg;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if ((int64_t)ptr[mid] < pos) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
-
-// own[b] = first segment that starts in block b or later; carry[b] = the block begins inside a segment that
-// started in an earlier block
-__global__ void fe_own_kernel(const int32_t* __restrict__ ptr, int nseg, int nblk, int64_t z, int32_t* __restrict__ own,
-                              uint8_t* __restrict__ carry) {
-  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b <= nblk; b += gridDim.x * blockDim.x) {
-    const int64_t k0 = (int64_t)b * FE_BLK;
-    const int o0 = (b == nblk) ? nseg : seg_lower_bound(ptr, nseg, k0);
-    own[b] = o0;
-    if (b < nblk) carry[b] = (b > 0 && k0 < z && (o0 >= nseg || (int64_t)ptr[o0] > k0)) ? 1 : 0;
-  }
-}
-
 __global__ void fe_prepare_kernel(FeDev F) {
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < F.d; j += gridDim.x * blockDim.x) F.xl[j] = F.W.x[F.umap[j]];
 }
 
-// what is done with a finished segment sum
+// what becomes of a finished row sum
 // HESS: the pass computes the diagonal of X~' D X~ instead of the gradient (fixed_effect_lr_lbfgs_model.py:271-296): the row pass
 // leaves d_i = w_i rho_i (1 - rho_i), rho = sigmoid(logit), the column pass sums val^2 d_i
-template <bool ROWS, bool HESS = false>
-__device__ __forceinline__ void fe_emit(const FeDev& F, const SolveParams& o, int s, double sum, double xb, float fo, float fy, float fw,
-                                        double& loss, double& rsum) {
-  if (ROWS) {
-    const double zi = sum + xb + (double)fo;
-    const double yi = (double)fy;
-    const double wi = (double)fw;
-    double ri;
-    if (HESS) {
-      const double rho = sigmoid_full(zi);
-      ri = wi * rho * (1.0 - rho);
-    } else if (o.linear) {
-      const double e = zi - yi;
-      loss += wi * e * e;
-      ri = 2.0 * wi * e;
-    } else {
-      loss += logistic_terms(zi, yi, wi, ri);
-    }
-    F.rs[s] = ri;
-    rsum += ri;
+template <bool HESS>
+__device__ __forceinline__ void fe_emit_row(const FeDev& F, const SolveParams& o, int s, double sum, double xb, double& loss, double& rsum) {
+  const double zi = sum + xb + (double)F.o[s];
+  const double yi = (double)F.y[s];
+  const double wi = F.w ? (double)F.w[s] : 1.0;
+  double ri;
+  if (HESS) {
+    const double rho = sigmoid_full(zi);
+    ri = wi * rho * (1.0 - rho);
+  } else if (o.linear) {
+    const double e = zi - yi;
+    loss += wi * e * e;
+    ri = 2.0 * wi * e;
   } else {
-    F.gl[s] = sum;
+    loss += logistic_terms(zi, yi, wi, ri);
   }
+  F.rs[s] = ri;
+  rsum += ri;
+}
+
+// acc[loc] += term, in LDS, nothing returned
+__device__ __forceinline__ void lds_add(double* acc, int loc, double term) {
+  __hip_atomic_fetch_add(acc + loc, term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 template <bool ROWS, bool HESS = false>
-__global__ __launch_bounds__(FE_THREADS) void fe_stream_kernel(FeDev F, SolveParams o) {
-  __shared__ double prod[FE_BLK + FE_BLK / 32];
-  __shared__ double red[2][FE_WAVES];
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
-  const int b = blockIdx.x;
-  const int32_t* __restrict__ ptr = ROWS ? F.row_ptr : F.col_ptr;
-  const int32_t* __restrict__ idx = ROWS ? F.csr_col : F.csc_row;
-  const float* __restrict__ val = ROWS ? F.csr_val : F.csc_val;
-  const double* __restrict__ vec = ROWS ? F.xl : F.rs;
-  const int32_t* __restrict__ own = ROWS ? F.own_r : F.own_c;
-  double* const pf = ROWS ? F.pf_r : F.pf_c;
-  double* const pl = ROWS ? F.pl_r : F.pl_c;
-  const uint8_t* __restrict__ cflag = ROWS ? F.carry_r : F.carry_c;
-  const int64_t k0 = (int64_t)b * FE_BLK;
-  const int64_t k1 = (k0 + FE_BLK < F.z) ? k0 + FE_BLK : F.z;
-  const int cnt = (int)(k1 - k0);
-  // Requests in dependency order, none waited for before it is needed: the block's descriptor, the streaming loads,
-  // then (from the descriptor) what the first segment of this thread will need at the very end. A block costs three
-  // memory round trips (descriptor | entries + segment data | gathers) instead of six in program order.
-  const int o0 = own[b], o1 = own[b + 1];
-  const bool carry = cflag[b] != 0;
+__global__ __launch_bounds__(WAVE) void fe_scatter_kernel(FeDev F, SolveParams o) {
+  __shared__ double acc[FE_B + 2];   // + a spare one for the lanes beyond the end of the last trip
+  const int lane = threadIdx.x, u = blockIdx.x;
+  const FeCopy& C = ROWS ? F.rc : F.cc;
+  const int k0 = C.ustart[u], k1 = C.ustart[u + 1], b = C.ublock[u];
+  const bool whole = ROWS && (C.ufirst[b + 1] - C.ufirst[b] == 1);
   const double xb = (ROWS && F.ic) ? F.W.x[F.D] : 0.0;
-  float v[FE_BLK / FE_THREADS];
-  int c[FE_BLK / FE_THREADS];
+  const int32_t* __restrict__ key = C.key;
+  const float* __restrict__ val = C.val;
+  const uint16_t* __restrict__ loc = C.loc;
+  const double* __restrict__ vec = ROWS ? F.xl : F.rs;
 #pragma unroll
-  for (int q = 0; q < FE_BLK / FE_THREADS; ++q) {
-    const int k = tid + q * FE_THREADS;
-    const bool ok = k < cnt;
-    v[q] = ok ? val[k0 + k] : 0.0f;
-    c[q] = ok ? idx[k0 + k] : 0;
-  }
-  const int nwork = (o1 - o0) + (carry ? 1 : 0);
-  const bool by_wave = nwork * 48 <= cnt;   // long segments: one wavefront each
-  const int step = by_wave ? FE_WAVES : FE_THREADS;
-  const int tfirst = by_wave ? wv : tid;
-  int p0 = 0, p1 = 0;
-  float fo = 0.0f, fy = 0.0f, fw = 1.0f;
-  if (tfirst < nwork) {
-    const bool is_carry = carry && tfirst == 0;
-    const int s = is_carry ? o0 - 1 : o0 + tfirst - (carry ? 1 : 0);
-    p0 = ptr[s];
-    p1 = ptr[s + 1];
-    if (ROWS) { fo = F.o[s]; fy = F.y[s]; if (F.w) fw = F.w[s]; }
-  }
+  for (int i = 0; i < FE_B / WAVE; i += 2) *reinterpret_cast<double2*>(acc + (i * WAVE + 2 * lane)) = make_double2(0.0, 0.0);
+  // full trips without a guard in sight (a load under a branch is waited for inside the branch); the last, partial trip
+  // reads clamped addresses and sends what is beyond the end to a spare accumulator
+  int base = k0;
+  for (; base + WAVE * FE_U <= k1; base += WAVE * FE_U) {
+    int kq[FE_U], lq[FE_U];
+    float vq[FE_U];
+    double xq[FE_U];
 #pragma unroll
-  for (int q = 0; q < FE_BLK / FE_THREADS; ++q) {
-    const int k = tid + q * FE_THREADS;
-    if (k < cnt) prod[fe_slot(k)] = (HESS && !ROWS) ? (double)v[q] * (double)v[q] * vec[c[q]] : (double)v[q] * vec[c[q]];
-  }
-  __syncthreads();
-  double loss = 0.0, rsum = 0.0;
-  for (int t = tfirst; t < nwork; t += step) {
-    const bool is_carry = carry && t == 0;
-    const int s = is_carry ? o0 - 1 : o0 + t - (carry ? 1 : 0);
-    if (t != tfirst) {
-      p0 = ptr[s];
-      p1 = ptr[s + 1];
-      if (ROWS) { fo = F.o[s]; fy = F.y[s]; fw = F.w ? F.w[s] : 1.0f; }
+    for (int q = 0; q < FE_U; ++q) {
+      const int k = base + q * WAVE + lane;
+      kq[q] = key[k];
+      vq[q] = val[k];
+      lq[q] = (int)loc[k];
     }
-    const int64_t a0 = is_carry ? k0 : (int64_t)p0;
-    const int64_t a1full = (int64_t)p1;
-    const int64_t a1 = a1full < k1 ? a1full : k1;
-    const int lo = (int)(a0 - k0), hi = (int)(a1 - k0);
-    double sum = 0.0;
-    if (by_wave) {
-      for (int k = lo + lane; k < hi; k += WAVE) sum += prod[fe_slot(k)];
-      sum = wave_sum(sum);
-    } else {
-      for (int k = lo; k < hi; ++k) sum += prod[fe_slot(k)];
-    }
-    if (!by_wave || lane == 0) {
-      if (is_carry) pf[b] = sum;                       // completed (or passed on) by fe_fix_kernel
-      else if (a1full > k1) pl[b] = sum;               // continues in the next block
-      else fe_emit<ROWS, HESS>(F, o, s, sum, xb, fo, fy, fw, loss, rsum);
+#pragma unroll
+    for (int q = 0; q < FE_U; ++q) xq[q] = vec[kq[q]];
+#pragma unroll
+    for (int q = 0; q < FE_U; ++q) {
+      const double v = (double)vq[q];
+      lds_add(acc, lq[q], (HESS && !ROWS) ? v * v * xq[q] : v * xq[q]);
     }
   }
-  if (ROWS) {
+  if (base < k1) {
+    int kq[FE_U], lq[FE_U];
+    float vq[FE_U];
+    double xq[FE_U];
+#pragma unroll
+    for (int q = 0; q < FE_U; ++q) {
+      const int k = base + q * WAVE + lane;
+      const int kc = k < k1 ? k : k1 - 1;
+      kq[q] = key[kc];
+      vq[q] = val[kc];
+      lq[q] = k < k1 ? (int)loc[kc] : FE_B;
+    }
+#pragma unroll
+    for (int q = 0; q < FE_U; ++q) xq[q] = vec[kq[q]];
+#pragma unroll
+    for (int q = 0; q < FE_U; ++q) {
+      const double v = (double)vq[q];
+      lds_add(acc, lq[q], (HESS && !ROWS) ? v * v * xq[q] : v * xq[q]);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the adds have landed
+  __builtin_amdgcn_wave_barrier();
+  if (whole) {
+    double loss = 0.0, rsum = 0.0;
+    const int r0 = b * FE_B;
+    const int nr = (F.n - r0 < FE_B) ? F.n - r0 : FE_B;
+    for (int i = lane; i < nr; i += WAVE) fe_emit_row<HESS>(F, o, r0 + i, acc[i], xb, loss, rsum);
     loss = wave_sum(loss);
     rsum = wave_sum(rsum);
-    if (lane == 0) { red[0][wv] = loss; red[1][wv] = rsum; }
-    __syncthreads();
-    if (tid == 0) {
-      double a = red[0][0], r = red[1][0];
+    if (lane == 0) { F.loss_part[u] = loss; F.rsum_part[u] = rsum; }
+  } else {
+    double* __restrict__ out = C.part + (size_t)u * FE_B;
 #pragma unroll
-      for (int w = 1; w < FE_WAVES; ++w) { a += red[0][w]; r += red[1][w]; }
-      F.loss_part[b] = a;
-      F.rsum_part[b] = r;
-    }
+    for (int i = 0; i < FE_B / WAVE; i += 2)
+      *reinterpret_cast<double2*>(out + (i * WAVE + 2 * lane)) = *reinterpret_cast<const double2*>(acc + (i * WAVE + 2 * lane));
+    if (ROWS && lane == 0) { F.loss_part[u] = 0.0; F.rsum_part[u] = 0.0; }
   }
 }
 
-// segments that cross block boundaries: the block in which such a segment ends adds up its parts in block order
-template <bool ROWS, bool HESS = false>
-__global__ void fe_fix_kernel(FeDev F, SolveParams o) {
-  const int32_t* __restrict__ ptr = ROWS ? F.row_ptr : F.col_ptr;
-  const int32_t* __restrict__ own = ROWS ? F.own_r : F.own_c;
-  const double* pf = ROWS ? F.pf_r : F.pf_c;
-  const double* pl = ROWS ? F.pl_r : F.pl_c;
-  const double xb = (ROWS && F.ic) ? F.W.x[F.D] : 0.0;
-  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < F.nblk; b += gridDim.x * blockDim.x) {
-    double loss = 0.0, rsum = 0.0;
-    const int64_t k0 = (int64_t)b * FE_BLK;
-    const int64_t k1 = (k0 + FE_BLK < F.z) ? k0 + FE_BLK : F.z;
-    const int o0 = own[b];
-    const bool carry = (ROWS ? F.carry_r : F.carry_c)[b] != 0;
-    if (carry) {
-      const int s = o0 - 1;
-      if ((int64_t)ptr[s + 1] <= k1) {   // ends here
-        const int ob = (int)((int64_t)ptr[s] / FE_BLK);
-        double t = pl[ob];
-        for (int bb = ob + 1; bb <= b; ++bb) t += pf[bb];
-        fe_emit<ROWS, HESS>(F, o, s, t, xb, ROWS ? F.o[s] : 0.0f, ROWS ? F.y[s] : 0.0f, (ROWS && F.w) ? F.w[s] : 1.0f, loss, rsum);
-      }
-    }
-    if (ROWS) { F.loss_fix[b] = loss; F.rsum_fix[b] = rsum; }
+// rows of the blocks that were cut into several units: partial sums in unit order, then as above
+template <bool HESS = false>
+__global__ __launch_bounds__(FE_THREADS) void fe_rows_fix_kernel(FeDev F, SolveParams o) {
+  __shared__ double red[2][FE_WAVES];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+  const int b = F.multi[blockIdx.x / FE_FIX_PER_BLOCK];
+  const int i = (blockIdx.x % FE_FIX_PER_BLOCK) * FE_THREADS + tid;
+  const int row = b * FE_B + i;
+  const double xb = F.ic ? F.W.x[F.D] : 0.0;
+  double loss = 0.0, rsum = 0.0;
+  if (row < F.n) {
+    const int u0 = F.rc.ufirst[b], u1 = F.rc.ufirst[b + 1];
+    double t = F.rc.part[(size_t)u0 * FE_B + i];
+    for (int u = u0 + 1; u < u1; ++u) t += F.rc.part[(size_t)u * FE_B + i];
+    fe_emit_row<HESS>(F, o, row, t, xb, loss, rsum);
+  }
+  loss = wave_sum(loss);
+  rsum = wave_sum(rsum);
+  if (lane == 0) { red[0][wv] = loss; red[1][wv] = rsum; }
+  __syncthreads();
+  if (tid == 0) {
+    double a = red[0][0], r = red[1][0];
+#pragma unroll
+    for (int w = 1; w < FE_WAVES; ++w) { a += red[0][w]; r += red[1][w]; }
+    F.loss_part[F.rc.nunit + blockIdx.x] = a;
+    F.rsum_part[F.rc.nunit + blockIdx.x] = r;
   }
 }
 
-// local gradient into the global coefficient space; workgroup 0 also adds up the value and the intercept gradient
+// local gradient (the column blocks' partial sums in unit order) into the global coefficient space; the first
+// FE_FIN_BLOCKS workgroups also add up a contiguous range of the per-unit value / residual sums each
 __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
   __shared__ double red[2][FE_WAVES];
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < F.d; j += gridDim.x * blockDim.x) {
-    double g = F.gl[j];
-    for (int t = 1; t < F.ntile; ++t) g += F.gl[(size_t)t * F.d + j];   // tiles in row order
+    const int b = j / FE_B, i = j % FE_B;
+    const int u0 = F.cc.ufirst[b], u1 = F.cc.ufirst[b + 1];
+    double g = F.cc.part[(size_t)u0 * FE_B + i];
+    for (int u = u0 + 1; u < u1; ++u) g += F.cc.part[(size_t)u * FE_B + i];
     F.fg[F.umap[j]] = g;
   }
-  // the first FE_FIN_BLOCKS workgroups also add up a contiguous range of the per-block value / residual sums each
   if (blockIdx.x >= FE_FIN_BLOCKS) return;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
-  const int chunk = (F.nblk + FE_FIN_BLOCKS - 1) / FE_FIN_BLOCKS;
+  const int chunk = (F.nred + FE_FIN_BLOCKS - 1) / FE_FIN_BLOCKS;
   const int b0 = blockIdx.x * chunk;
-  const int b1 = (b0 + chunk < F.nblk) ? b0 + chunk : F.nblk;
+  const int b1 = (b0 + chunk < F.nred) ? b0 + chunk : F.nred;
   double a = 0.0, r = 0.0;
   for (int b = b0 + tid; b < b1; b += FE_THREADS) {
-    a += F.loss_part[b]; a += F.loss_fix[b];
-    r += F.rsum_part[b]; r += F.rsum_fix[b];
+    a += F.loss_part[b];
+    r += F.rsum_part[b];
   }
   a = wave_sum(a);
   r = wave_sum(r);
@@ -409,45 +383,64 @@ __global__ void fe_init_kernel(FeDev F, const double* __restrict__ theta0) {
   }
 }
 
-// ---- row-tiled copy of the CSC arrays -----------------------------------------------------------------------------
-// The column pass gathers the residual of every entry's row. With the columns stored whole, consecutive entries
-// of a column are rows far apart and the residual vector (8 B x samples) does not fit an XCD's 4 MiB L2: every
-// gather pulls a full line from the fabric (measured: 7.5 GB fetched for 1 GB of entries). Cutting the columns into
-// row tiles of FE_TILE_ROWS and storing the entries tile-major (tile, column, row) keeps the residuals a pass touches
-// at any time within 2 MiB; the per-(tile, column) sums are added up in tile order afterwards.
-__global__ void fe_tile_count_kernel(const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ csc_row, int d,
-                                     uint32_t* __restrict__ key, uint32_t* __restrict__ perm, int32_t* __restrict__ cnt) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int nw = (gridDim.x * blockDim.x) >> 6;
-  for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < d; c += nw) {
-    const int k0 = col_ptr[c], k1 = col_ptr[c + 1];
-    for (int kb = k0; kb < k1; kb += WAVE) {   // wave-uniform trip count
-      const int k = kb + lane;
-      const bool in = k < k1;
-      const int t = in ? csc_row[k] / FE_TILE_ROWS : -1;
-      if (in) { key[k] = (uint32_t)t; perm[k] = (uint32_t)k; }
-      // a column's entries are in row order, so equal tiles are runs of lanes: one atomic per run instead of one per entry
-      // (same-address atomics serialise in L2: 8 ms of the 10 ms this build took)
-      const int tp = __shfl_up(t, 1);
-      const bool head = in && (lane == 0 || t != tp);
-      const unsigned long long heads = __ballot(head);
-      const unsigned long long valid = __ballot(in);
-      if (head) {
-        const unsigned long long above = (lane == WAVE - 1) ? 0ull : (heads >> (lane + 1)) << (lane + 1);
-        const int end = above ? __ffsll((long long)above) - 1 : __popcll(valid);   // lanes in use are 0 .. popc(valid)-1
-        atomicAdd(&cnt[(size_t)t * d + c], end - lane);
-      }
-    }
+// ---- the passes' copies of the non-zeros ---------------------------------------------------------------------------------
+// From the packed shard's CSR (for the column pass) and CSC (for the row pass) arrays: segment of every entry (flag + scan),
+// stable sort by block of the entry's index (rocPRIM radix sort on the block number alone, so the source order — the order of
+// the gathered vector — survives inside a block), units = the blocks' runs cut every `chunk` entries.
+__global__ void fe_flag_kernel(const int32_t* __restrict__ ptr, int nseg, int64_t z, int32_t* __restrict__ flag) {
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x + 1; s < nseg; s += gridDim.x * blockDim.x) {
+    const int p = ptr[s];
+    if (p < z) atomicAdd(&flag[p], 1);   // empty segments pile up on the next entry
   }
 }
 
-__global__ void fe_tile_gather_kernel(const uint32_t* __restrict__ perm, const int32_t* __restrict__ csc_row,
-                                      const float* __restrict__ csc_val, int64_t z, int32_t* __restrict__ trow,
-                                      float* __restrict__ tval) {
+__global__ void fe_key_kernel(const int32_t* __restrict__ idx, int64_t z, uint32_t* __restrict__ skey, uint32_t* __restrict__ perm) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < z; k += (int64_t)gridDim.x * blockDim.x) {
+    skey[k] = (uint32_t)(idx[k] / FE_B);
+    perm[k] = (uint32_t)k;
+  }
+}
+
+__global__ void fe_copy_gather_kernel(const uint32_t* __restrict__ perm, const int32_t* __restrict__ seg, const int32_t* __restrict__ idx,
+                                      const float* __restrict__ val, int64_t z, int32_t* __restrict__ ckey, float* __restrict__ cval,
+                                      uint16_t* __restrict__ cloc) {
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < z; k += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t src = perm[k];
-    trow[k] = csc_row[src];
-    tval[k] = csc_val[src];
+    ckey[k] = seg[src];
+    cval[k] = val[src];
+    cloc[k] = (uint16_t)(idx[src] % FE_B);
+  }
+}
+
+// bp[b] = first sorted entry of a block >= b
+__global__ void fe_block_kernel(const uint32_t* __restrict__ sorted, int64_t z, int nblock, int32_t* __restrict__ bp) {
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b <= nblock; b += gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = z;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (sorted[mid] < (uint32_t)b) lo = mid + 1; else hi = mid;
+    }
+    bp[b] = (int32_t)lo;
+  }
+}
+
+// units of block b (an empty block keeps one: its outputs are still due)
+__global__ void fe_chunks_kernel(const int32_t* __restrict__ bp, int nblock, int chunk, int32_t* __restrict__ nch) {
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b <= nblock; b += gridDim.x * blockDim.x) {
+    const int len = b < nblock ? bp[b + 1] - bp[b] : 0;
+    nch[b] = b < nblock ? (len <= chunk ? 1 : (len + chunk - 1) / chunk) : 0;
+  }
+}
+
+__global__ void fe_units_kernel(const int32_t* __restrict__ bp, const int32_t* __restrict__ ufirst, int nblock, int chunk, int64_t z,
+                                int32_t* __restrict__ ustart, int32_t* __restrict__ ublock) {
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblock; b += gridDim.x * blockDim.x) {
+    const int u0 = ufirst[b], u1 = ufirst[b + 1];
+    for (int u = u0; u < u1; ++u) {
+      ustart[u] = bp[b] + (u - u0) * chunk;
+      ublock[u] = b;
+    }
+    if (b == nblock - 1) ustart[u1] = (int32_t)z;
   }
 }
 
@@ -489,8 +482,8 @@ struct gdmix_fe_problem {
   gdmix_re_ctx* ctx;
   FeDev F;
   SolveParams o;
-  void* pool;            // one device allocation carved into the arrays above
-  void* tiled;           // row-tiled CSC copy (NULL when the shard has a single row tile)
+  void* pool;            // one device allocation carved into the vectors and partial sums
+  void* copies[2];       // the row pass's and the column pass's copy of the non-zeros, with their unit tables
   int32_t* status_dev;
   hipEvent_t ev[3];
   bool timed;
@@ -506,6 +499,129 @@ struct gdmix_fe_problem {
   } while (0)
 
 static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Entries per unit. Blocks stay whole (a row block then finishes its rows itself) when that still gives the device enough
+// units; otherwise every block is cut so that there are about eight wavefronts per CU.
+static int fe_chunk_len(int64_t z, int nblock, int num_cus) {
+  const int64_t target = (z + (int64_t)num_cus * 8 - 1) / ((int64_t)num_cus * 8);
+  const int64_t avg = (z + nblock - 1) / nblock;
+  int64_t c = (avg <= 2 * target) ? 2 * avg : target;
+  if (c < 8192) c = 8192;
+  if (c > (1 << 28)) c = 1 << 28;
+  return (int)c;
+}
+
+// Build one pass's copy from segment-major source arrays (ptr [nseg+1], idx / val [z]); `len` = extent of idx (outputs of the
+// pass). Device memory of the result in *owned; the unit table is also returned on the host (ufirst) for the caller.
+static int fe_build_copy(hipStream_t s, int num_cus, const int32_t* ptr, int nseg, const int32_t* idx, const float* val, int64_t z,
+                         int len, FeCopy* out, void** owned, std::vector<int32_t>* ufirst_host) {
+  *owned = nullptr;
+  const int nblock = len > 0 ? (len + FE_B - 1) / FE_B : 1;
+  const int chunk = fe_chunk_len(z, nblock, num_cus);
+  const size_t zz = (size_t)(z > 0 ? z : 1);
+  unsigned bits = 1;
+  while ((1u << bits) < (unsigned)nblock) ++bits;
+  size_t sort_tmp = 0, scan_tmp = 0, scan2_tmp = 0;
+  hipError_t rc = rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                            (uint32_t*)nullptr, zz, 0u, bits, s);
+  if (rc == hipSuccess) rc = rocprim::inclusive_scan(nullptr, scan_tmp, (int32_t*)nullptr, (int32_t*)nullptr, zz, rocprim::plus<int32_t>(), s);
+  if (rc == hipSuccess) rc = rocprim::exclusive_scan(nullptr, scan2_tmp, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)nblock + 1, rocprim::plus<int32_t>(), s);
+  if (rc != hipSuccess) { set_error("rocPRIM sizing failed: %s", hipGetErrorString(rc)); return GDMIX_RE_EHIP; }
+  size_t lib = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
+  if (scan2_tmp > lib) lib = scan2_tmp;
+  size_t woff = 0;
+  auto wtake = [&](size_t bytes) { size_t r = woff; woff = up256(woff + bytes); return r; };
+  const size_t w_a = wtake(zz * 4), w_seg = wtake(zz * 4), w_key = wtake(zz * 4), w_perm = wtake(zz * 4), w_perm2 = wtake(zz * 4);
+  const size_t w_bp = wtake(((size_t)nblock + 1) * 4), w_nch = wtake(((size_t)nblock + 1) * 4), w_lib = wtake(lib);
+  void* tmp = nullptr;
+  rc = hipMalloc(&tmp, woff);
+  if (rc != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", woff, hipGetErrorString(rc)); return GDMIX_RE_ENOMEM; }
+  char* wb = static_cast<char*>(tmp);
+  int32_t* flag = reinterpret_cast<int32_t*>(wb + w_a);      // later: the sorted block numbers
+  int32_t* seg = reinterpret_cast<int32_t*>(wb + w_seg);
+  uint32_t* skey = reinterpret_cast<uint32_t*>(wb + w_key);
+  uint32_t* perm = reinterpret_cast<uint32_t*>(wb + w_perm);
+  uint32_t* skey2 = reinterpret_cast<uint32_t*>(wb + w_a);
+  uint32_t* perm2 = reinterpret_cast<uint32_t*>(wb + w_perm2);
+  int32_t* bp = reinterpret_cast<int32_t*>(wb + w_bp);
+  int32_t* nch = reinterpret_cast<int32_t*>(wb + w_nch);
+  // the copy itself and the block -> unit table; the unit arrays follow once their number is known
+  size_t coff = 0;
+  auto ctake = [&](size_t bytes) { size_t r = coff; coff = up256(coff + bytes); return r; };
+  const size_t c_key = ctake(zz * 4), c_val = ctake(zz * 4), c_loc = ctake(zz * 2), c_uf = ctake(((size_t)nblock + 1) * 4);
+  // upper bound of the unit count: a block of len entries has at most len / chunk + 1 units
+  const size_t max_units = (size_t)nblock + (size_t)(z / chunk) + 1;
+  const size_t c_us = ctake((max_units + 1) * 4), c_ub = ctake(max_units * 4);
+  void* mem = nullptr;
+  rc = hipMalloc(&mem, coff);
+  if (rc != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", coff, hipGetErrorString(rc)); (void)hipFree(tmp); return GDMIX_RE_ENOMEM; }
+  char* cb = static_cast<char*>(mem);
+  int32_t* ckey = reinterpret_cast<int32_t*>(cb + c_key);
+  float* cval = reinterpret_cast<float*>(cb + c_val);
+  uint16_t* cloc = reinterpret_cast<uint16_t*>(cb + c_loc);
+  int32_t* ufirst = reinterpret_cast<int32_t*>(cb + c_uf);
+  int32_t* ustart = reinterpret_cast<int32_t*>(cb + c_us);
+  int32_t* ublock = reinterpret_cast<int32_t*>(cb + c_ub);
+  const int ge = num_cus * 16;
+  int gb = (nblock + 1 + 255) / 256;
+  if (gb > 4096) gb = 4096;
+  if (z > 0) {
+    (void)hipMemsetAsync(flag, 0, zz * 4, s);
+    int gs = (nseg + 255) / 256;
+    if (gs > 4096) gs = 4096;
+    if (gs < 1) gs = 1;
+    hipLaunchKernelGGL(fe_flag_kernel, dim3(gs), dim3(256), 0, s, ptr, nseg, z, flag);
+    size_t lt = scan_tmp;
+    rc = rocprim::inclusive_scan(wb + w_lib, lt, flag, seg, (size_t)z, rocprim::plus<int32_t>(), s);
+    hipLaunchKernelGGL(fe_key_kernel, dim3(ge), dim3(256), 0, s, idx, z, skey, perm);
+    lt = sort_tmp;
+    if (rc == hipSuccess) rc = rocprim::radix_sort_pairs(wb + w_lib, lt, skey, skey2, perm, perm2, (size_t)z, 0u, bits, s);
+    hipLaunchKernelGGL(fe_copy_gather_kernel, dim3(ge), dim3(256), 0, s, perm2, seg, idx, val, z, ckey, cval, cloc);
+  }
+  hipLaunchKernelGGL(fe_block_kernel, dim3(gb), dim3(256), 0, s, skey2, z, nblock, bp);
+  hipLaunchKernelGGL(fe_chunks_kernel, dim3(gb), dim3(256), 0, s, bp, nblock, chunk, nch);
+  size_t lt = scan2_tmp;
+  if (rc == hipSuccess) rc = rocprim::exclusive_scan(wb + w_lib, lt, nch, ufirst, 0, (size_t)nblock + 1, rocprim::plus<int32_t>(), s);
+  hipLaunchKernelGGL(fe_units_kernel, dim3(gb), dim3(256), 0, s, bp, ufirst, nblock, chunk, z, ustart, ublock);
+  ufirst_host->resize((size_t)nblock + 1);
+  if (rc == hipSuccess) rc = hipMemcpyAsync(ufirst_host->data(), ufirst, ((size_t)nblock + 1) * 4, hipMemcpyDeviceToHost, s);
+  if (rc == hipSuccess) rc = hipStreamSynchronize(s);
+  if (rc == hipSuccess) rc = hipGetLastError();
+  (void)hipFree(tmp);
+  if (rc != hipSuccess) { set_error("building a pass's copy failed: %s", hipGetErrorString(rc)); (void)hipFree(mem); return GDMIX_RE_EHIP; }
+  out->key = ckey; out->val = cval; out->loc = cloc; out->ustart = ustart; out->ublock = ublock; out->ufirst = ufirst;
+  out->part = nullptr;
+  out->nblock = nblock;
+  out->nunit = (*ufirst_host)[(size_t)nblock];
+  *owned = mem;
+  return GDMIX_RE_OK;
+}
+
+static void fe_free(gdmix_fe_problem* p) {
+  for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
+  if (p->pool) (void)hipFree(p->pool);
+  for (auto& c : p->copies) if (c) (void)hipFree(c);
+  delete p;
+}
+
+template <bool HESS>
+static int fe_passes(gdmix_fe_problem* p, const FeDev& F, hipStream_t s, bool timed) {
+  HIP_TRY(hipMemsetAsync(F.fg, 0, ((size_t)F.P + 1) * 8, s));
+  int gd = (F.d + 255) / 256;
+  if (gd > 2048) gd = 2048;
+  if (gd < 1) gd = 1;
+  hipLaunchKernelGGL(fe_prepare_kernel, dim3(gd), dim3(256), 0, s, F);
+  if (timed) HIP_TRY(hipEventRecord(p->ev[0], s));
+  hipLaunchKernelGGL((fe_scatter_kernel<true, HESS>), dim3(F.rc.nunit), dim3(WAVE), 0, s, F, p->o);
+  if (F.nmulti) hipLaunchKernelGGL((fe_rows_fix_kernel<HESS>), dim3(F.nmulti * FE_FIX_PER_BLOCK), dim3(FE_THREADS), 0, s, F, p->o);
+  if (timed) HIP_TRY(hipEventRecord(p->ev[1], s));
+  hipLaunchKernelGGL((fe_scatter_kernel<false, HESS>), dim3(F.cc.nunit), dim3(WAVE), 0, s, F, p->o);
+  if (timed) HIP_TRY(hipEventRecord(p->ev[2], s));
+  hipLaunchKernelGGL(fe_finish_kernel, dim3(gd < FE_FIN_BLOCKS ? FE_FIN_BLOCKS : gd), dim3(FE_THREADS), 0, s, F);
+  hipLaunchKernelGGL(fe_finish2_kernel, dim3(1), dim3(WAVE), 0, s, F);   // HESS: fg[D] = sum_i d_i (the intercept's entry), fg[P] unused
+  HIP_TRY(hipGetLastError());
+  return GDMIX_RE_OK;
+}
 
 extern "C" {
 
@@ -526,44 +642,49 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   if (!p) { set_error("out of host memory"); return GDMIX_RE_ENOMEM; }
   p->ctx = ctx;
   p->pool = nullptr;
-  p->tiled = nullptr;
+  p->copies[0] = p->copies[1] = nullptr;
   p->timed = false;
   for (auto& e : p->ev) e = nullptr;
   FeDev& F = p->F;
   const int ic = opts->has_intercept ? 1 : 0;
   F.n = (int)b->N; F.z = b->Z; F.d = (int)b->D; F.ic = ic; F.D = num_features; F.P = (int)num_features + ic; F.m = opts->m;
-  F.ntile = (F.n + FE_TILE_ROWS - 1) / FE_TILE_ROWS;
-  if (F.ntile < 1) F.ntile = 1;
-  if ((int64_t)F.ntile * F.d > 0x7ffffff0ll) { set_error("row tiles x features exceeds 2^31"); delete p; return GDMIX_RE_ERANGE; }
-  F.nseg_c = F.ntile * F.d;
-  F.nblk = (int)((F.z + FE_BLK - 1) / FE_BLK);
-  if (F.nblk < 1) F.nblk = 1;
-  F.row_ptr = b->row_ptr; F.csr_col = b->csr_col; F.csr_val = b->csr_val; F.col_ptr = b->col_ptr; F.csc_row = b->csc_row;
-  F.csc_val = b->csc_val; F.y = b->y; F.o = b->offset; F.w = b->weight; F.umap = b->unique_global;
+  F.y = b->y; F.o = b->offset; F.w = b->weight; F.umap = b->unique_global;
   SolveParams& o = p->o;
   o.l2 = opts->l2; o.ftol = opts->ftol; o.pgtol = opts->pgtol; o.threshold = 0.0; o.regularize_bias = opts->regularize_bias;
   o.has_intercept = ic; o.m = opts->m; o.max_iter = opts->max_iter; o.maxfun = opts->maxfun; o.maxls = opts->maxls;
   o.variance_mode = 0; o.sum_loss = 1; o.linear = opts->linear ? 1 : 0;
-  const size_t P = (size_t)F.P, nb = (size_t)F.nblk;
+  // row pass: outputs = rows, gathered = x by local column: from the column-major arrays. Column pass: the other way round.
+  std::vector<int32_t> uf_r, uf_c;
+  int rc2 = fe_build_copy(s, ci->num_cus, b->col_ptr, F.d, b->csc_row, b->csc_val, F.z, F.n, &F.rc, &p->copies[0], &uf_r);
+  if (rc2 == GDMIX_RE_OK) rc2 = fe_build_copy(s, ci->num_cus, b->row_ptr, F.n, b->csr_col, b->csr_val, F.z, F.d, &F.cc, &p->copies[1], &uf_c);
+  if (rc2 != GDMIX_RE_OK) { fe_free(p); return rc2; }
+  std::vector<int32_t> multi;
+  for (int rb = 0; rb < F.rc.nblock; ++rb) if (uf_r[(size_t)rb + 1] - uf_r[(size_t)rb] > 1) multi.push_back(rb);
+  F.nmulti = (int)multi.size();
+  F.nred = F.rc.nunit + F.nmulti * FE_FIX_PER_BLOCK;
+  const size_t P = (size_t)F.P;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t r = off; off = up256(off + bytes); return r; };
-  const size_t o_xl = take((size_t)(F.d + 1) * 8), o_rs = take((size_t)(F.n + 1) * 8), o_gl = take(((size_t)F.nseg_c + 1) * 8);
-  const size_t o_fg = take((P + 1) * 8), o_ownr = take((nb + 1) * 4), o_ownc = take((nb + 1) * 4), o_cr = take(nb + 1), o_cc = take(nb + 1);
-  const size_t o_part = take(nb * 8 * 8), o_acc = take((size_t)FE_DOT_BLOCKS * TEAM_K * 8), o_fin = take((size_t)FE_FIN_BLOCKS * 2 * 8);
+  const size_t o_xl = take((size_t)(F.d + 1) * 8), o_rs = take((size_t)(F.n + 1) * 8), o_fg = take((P + 1) * 8);
+  const size_t o_pr = take((size_t)F.rc.nunit * FE_B * 8), o_pc = take((size_t)F.cc.nunit * FE_B * 8);
+  const size_t o_multi = take((multi.size() + 1) * 4), o_red = take((size_t)F.nred * 2 * 8 + 16);
+  const size_t o_acc = take((size_t)FE_DOT_BLOCKS * TEAM_K * 8), o_fin = take((size_t)FE_FIN_BLOCKS * 2 * 8);
   const size_t o_state = take(sizeof(CompactState)), o_plan = take(sizeof(CompactPlan)), o_mats = take(sizeof(CompactMats));
   const size_t o_vec = take(((size_t)5 * P + compact_hist_doubles((int64_t)P, opts->m)) * 8 + 16), o_status = take(64);
   hipError_t rc = hipMalloc(&p->pool, off);
-  if (rc != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(rc)); delete p; return GDMIX_RE_ENOMEM; }
+  if (rc != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(rc)); fe_free(p); return GDMIX_RE_ENOMEM; }
   char* base = static_cast<char*>(p->pool);
   rc = hipMemsetAsync(base, 0, off, s);
-  if (rc != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(rc)); (void)hipFree(p->pool); delete p; return GDMIX_RE_EHIP; }
+  if (rc == hipSuccess && !multi.empty()) {
+    rc = hipMemcpyAsync(base + o_multi, multi.data(), multi.size() * 4, hipMemcpyHostToDevice, s);
+    if (rc == hipSuccess) rc = hipStreamSynchronize(s);   // `multi` goes out of scope
+  }
+  if (rc != hipSuccess) { set_error("initialising the problem failed: %s", hipGetErrorString(rc)); fe_free(p); return GDMIX_RE_EHIP; }
   F.xl = reinterpret_cast<double*>(base + o_xl); F.rs = reinterpret_cast<double*>(base + o_rs);
-  F.gl = reinterpret_cast<double*>(base + o_gl); F.fg = reinterpret_cast<double*>(base + o_fg);
-  F.own_r = reinterpret_cast<int32_t*>(base + o_ownr); F.own_c = reinterpret_cast<int32_t*>(base + o_ownc);
-  F.carry_r = reinterpret_cast<uint8_t*>(base + o_cr); F.carry_c = reinterpret_cast<uint8_t*>(base + o_cc);
-  double* part = reinterpret_cast<double*>(base + o_part);
-  F.pf_r = part; F.pl_r = part + nb; F.pf_c = part + 2 * nb; F.pl_c = part + 3 * nb;
-  F.loss_part = part + 4 * nb; F.rsum_part = part + 5 * nb; F.loss_fix = part + 6 * nb; F.rsum_fix = part + 7 * nb;
+  F.fg = reinterpret_cast<double*>(base + o_fg);
+  F.rc.part = reinterpret_cast<double*>(base + o_pr); F.cc.part = reinterpret_cast<double*>(base + o_pc);
+  F.multi = reinterpret_cast<const int32_t*>(base + o_multi);
+  F.loss_part = reinterpret_cast<double*>(base + o_red); F.rsum_part = F.loss_part + F.nred;
   F.acc_part = reinterpret_cast<double*>(base + o_acc);
   F.fin_part = reinterpret_cast<double*>(base + o_fin);
   F.state = reinterpret_cast<CompactState*>(base + o_state);
@@ -575,67 +696,17 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   F.W.wy = F.W.ws + (size_t)opts->m * P;
   F.W.rs = F.rs; F.W.alpha = nullptr; F.W.rho = nullptr; F.W.part = nullptr;
   p->status_dev = reinterpret_cast<int32_t*>(base + o_status);
-  const int g = (int)((nb + 1 + 255) / 256);
-  hipLaunchKernelGGL(fe_own_kernel, dim3(g), dim3(256), 0, s, F.row_ptr, F.n, F.nblk, F.z, F.own_r, F.carry_r);
-  if (F.ntile > 1) {
-    // build the row-tiled CSC copy: stable sort of the packed (column, row) order by tile, segment table by histogram + scan
-    const size_t z = (size_t)F.z, ns = (size_t)F.nseg_c;
-    size_t toff = 0;
-    auto ttake = [&](size_t bytes) { size_t r = toff; toff = up256(toff + bytes); return r; };
-    const size_t t_ptr = ttake((ns + 1) * 4), t_row = ttake(z * 4), t_val = ttake(z * 4);
-    rc = hipMalloc(&p->tiled, toff);
-    if (rc != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", toff, hipGetErrorString(rc)); (void)hipFree(p->pool); delete p; return GDMIX_RE_ENOMEM; }
-    char* tb = static_cast<char*>(p->tiled);
-    int32_t* tptr = reinterpret_cast<int32_t*>(tb + t_ptr);
-    int32_t* trow = reinterpret_cast<int32_t*>(tb + t_row);
-    float* tval = reinterpret_cast<float*>(tb + t_val);
-    unsigned bits = 1;
-    while ((1 << bits) < F.ntile) ++bits;
-    size_t sort_tmp = 0, scan_tmp = 0;
-    rc = rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                   z, 0u, bits, s);
-    if (rc == hipSuccess) rc = rocprim::exclusive_scan(nullptr, scan_tmp, (int32_t*)nullptr, (int32_t*)nullptr, 0, ns + 1, rocprim::plus<int32_t>(), s);
-    void* tmp = nullptr;
-    size_t woff = 0;
-    auto wtake = [&](size_t bytes) { size_t r = woff; woff = up256(woff + bytes); return r; };
-    const size_t w_key = wtake(z * 4), w_perm = wtake(z * 4), w_key2 = wtake(z * 4), w_perm2 = wtake(z * 4), w_cnt = wtake((ns + 1) * 4);
-    const size_t w_lib = wtake(sort_tmp > scan_tmp ? sort_tmp : scan_tmp);
-    if (rc == hipSuccess) rc = hipMalloc(&tmp, woff);
-    if (rc != hipSuccess) { set_error("tiled column copy: %s", hipGetErrorString(rc)); (void)hipFree(p->tiled); (void)hipFree(p->pool); delete p; return GDMIX_RE_ENOMEM; }
-    char* wb = static_cast<char*>(tmp);
-    uint32_t* key = reinterpret_cast<uint32_t*>(wb + w_key);
-    uint32_t* perm = reinterpret_cast<uint32_t*>(wb + w_perm);
-    uint32_t* key2 = reinterpret_cast<uint32_t*>(wb + w_key2);
-    uint32_t* perm2 = reinterpret_cast<uint32_t*>(wb + w_perm2);
-    int32_t* cnt = reinterpret_cast<int32_t*>(wb + w_cnt);
-    (void)hipMemsetAsync(cnt, 0, (ns + 1) * 4, s);
-    hipLaunchKernelGGL(fe_tile_count_kernel, dim3(ci->num_cus * 8), dim3(256), 0, s, b->col_ptr, b->csc_row, F.d, key, perm, cnt);
-    size_t lt = scan_tmp;
-    rc = rocprim::exclusive_scan(wb + w_lib, lt, cnt, tptr, 0, ns + 1, rocprim::plus<int32_t>(), s);
-    lt = sort_tmp;
-    if (rc == hipSuccess) rc = rocprim::radix_sort_pairs(wb + w_lib, lt, key, key2, perm, perm2, z, 0u, bits, s);
-    hipLaunchKernelGGL(fe_tile_gather_kernel, dim3(ci->num_cus * 16), dim3(256), 0, s, perm2, b->csc_row, b->csc_val, (int64_t)z, trow, tval);
-    if (rc == hipSuccess) rc = hipStreamSynchronize(s);
-    (void)hipFree(tmp);
-    if (rc != hipSuccess) { set_error("tiled column copy: %s", hipGetErrorString(rc)); (void)hipFree(p->tiled); (void)hipFree(p->pool); delete p; return GDMIX_RE_EHIP; }
-    F.col_ptr = tptr; F.csc_row = trow; F.csc_val = tval;
-  }
-  hipLaunchKernelGGL(fe_own_kernel, dim3(g), dim3(256), 0, s, F.col_ptr, F.nseg_c, F.nblk, F.z, F.own_c, F.carry_c);
   int gp = (int)((P + 255) / 256);
   if (gp > 1024) gp = 1024;
   hipLaunchKernelGGL(fe_init_kernel, dim3(gp), dim3(256), 0, s, F, theta0);
   rc = hipGetLastError();
-  if (rc != hipSuccess) { set_error("launch failed: %s", hipGetErrorString(rc)); (void)hipFree(p->pool); delete p; return GDMIX_RE_EHIP; }
+  if (rc != hipSuccess) { set_error("launch failed: %s", hipGetErrorString(rc)); fe_free(p); return GDMIX_RE_EHIP; }
   *out = p;
   return GDMIX_RE_OK;
 }
 
 GDMIX_API void gdmix_fe_destroy(gdmix_fe_problem* p) {
-  if (!p) return;
-  for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
-  if (p->pool) (void)hipFree(p->pool);
-  if (p->tiled) (void)hipFree(p->tiled);
-  delete p;
+  if (p) fe_free(p);
 }
 
 GDMIX_API double* gdmix_fe_reduce_buffer(gdmix_fe_problem* p, int64_t* count) {
@@ -646,48 +717,17 @@ GDMIX_API double* gdmix_fe_reduce_buffer(gdmix_fe_problem* p, int64_t* count) {
 
 GDMIX_API int gdmix_fe_eval(gdmix_fe_problem* p, void* stream) {
   if (!p) { set_error("problem is NULL"); return GDMIX_RE_EINVAL; }
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const FeDev& F = p->F;
   if (!p->ev[0]) for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
-  HIP_TRY(hipMemsetAsync(F.fg, 0, ((size_t)F.P + 1) * 8, s));
-  int gd = (F.d + 255) / 256;
-  if (gd > 2048) gd = 2048;
-  if (gd < 1) gd = 1;
-  int gf = (F.nblk + 255) / 256;
-  hipLaunchKernelGGL(fe_prepare_kernel, dim3(gd), dim3(256), 0, s, F);
-  HIP_TRY(hipEventRecord(p->ev[0], s));
-  hipLaunchKernelGGL((fe_stream_kernel<true>), dim3(F.nblk), dim3(FE_THREADS), 0, s, F, p->o);
-  hipLaunchKernelGGL((fe_fix_kernel<true>), dim3(gf), dim3(256), 0, s, F, p->o);
-  HIP_TRY(hipEventRecord(p->ev[1], s));
-  hipLaunchKernelGGL((fe_stream_kernel<false>), dim3(F.nblk), dim3(FE_THREADS), 0, s, F, p->o);
-  hipLaunchKernelGGL((fe_fix_kernel<false>), dim3(gf), dim3(256), 0, s, F, p->o);
-  HIP_TRY(hipEventRecord(p->ev[2], s));
-  hipLaunchKernelGGL(fe_finish_kernel, dim3(gd < FE_FIN_BLOCKS ? FE_FIN_BLOCKS : gd), dim3(FE_THREADS), 0, s, F);
-  hipLaunchKernelGGL(fe_finish2_kernel, dim3(1), dim3(WAVE), 0, s, F);
-  HIP_TRY(hipGetLastError());
-  p->timed = true;
-  return GDMIX_RE_OK;
+  const int rc = fe_passes<false>(p, p->F, static_cast<hipStream_t>(stream), true);
+  if (rc == GDMIX_RE_OK) p->timed = true;
+  return rc;
 }
 
 GDMIX_API int gdmix_fe_hessian_diag(gdmix_fe_problem* p, const double* theta, void* stream) {
   if (!p) { set_error("problem is NULL"); return GDMIX_RE_EINVAL; }
-  hipStream_t s = static_cast<hipStream_t>(stream);
   FeDev F = p->F;
   if (theta) F.W.x = const_cast<double*>(theta);   // the passes only read x
-  HIP_TRY(hipMemsetAsync(F.fg, 0, ((size_t)F.P + 1) * 8, s));
-  int gd = (F.d + 255) / 256;
-  if (gd > 2048) gd = 2048;
-  if (gd < 1) gd = 1;
-  int gf = (F.nblk + 255) / 256;
-  hipLaunchKernelGGL(fe_prepare_kernel, dim3(gd), dim3(256), 0, s, F);
-  hipLaunchKernelGGL((fe_stream_kernel<true, true>), dim3(F.nblk), dim3(FE_THREADS), 0, s, F, p->o);
-  hipLaunchKernelGGL((fe_fix_kernel<true, true>), dim3(gf), dim3(256), 0, s, F, p->o);
-  hipLaunchKernelGGL((fe_stream_kernel<false, true>), dim3(F.nblk), dim3(FE_THREADS), 0, s, F, p->o);
-  hipLaunchKernelGGL((fe_fix_kernel<false, true>), dim3(gf), dim3(256), 0, s, F, p->o);
-  hipLaunchKernelGGL(fe_finish_kernel, dim3(gd < FE_FIN_BLOCKS ? FE_FIN_BLOCKS : gd), dim3(FE_THREADS), 0, s, F);
-  hipLaunchKernelGGL(fe_finish2_kernel, dim3(1), dim3(WAVE), 0, s, F);   // fg[D] = sum_i d_i (the intercept's entry), fg[P] unused
-  HIP_TRY(hipGetLastError());
-  return GDMIX_RE_OK;
+  return fe_passes<true>(p, F, static_cast<hipStream_t>(stream), false);
 }
 
 GDMIX_API int gdmix_fe_step(gdmix_fe_problem* p, void* stream, int32_t* status) {
