@@ -13,6 +13,7 @@
 // products into LDS with ds_add_f64. A block with many entries is cut into chunks of equal entry count, one wavefront
 // each, whose partial sums a second small kernel adds in chunk order. One wavefront per accumulator set and in-order
 // LDS atomics: a row's terms are added one by one in column order, a column's in row order, whatever the launch.
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -39,7 +40,6 @@ constexpr int FE_THREADS = 256;
 constexpr int FE_WAVES = FE_THREADS / WAVE;
 constexpr int FE_DOT_BLOCKS = 512;
 constexpr int FE_FIN_BLOCKS = 64;   // workgroups (= lanes of the final wavefront) that add up the per-unit partial sums
-constexpr int FE_FIX_PER_BLOCK = FE_B / FE_THREADS;   // workgroups of fe_rows_fix_kernel per block
 static_assert(FE_B <= 65536 && FE_B % FE_THREADS == 0, "16-bit accumulator index");
 
 // one pass's copy of the non-zeros
@@ -59,7 +59,7 @@ struct FeDev {
   int64_t z, D;
   FeCopy rc, cc;            // row pass, column pass
   const int32_t* multi;     // [nmulti] row blocks cut into several units
-  int nmulti, nred;         // nred = rc.nunit + nmulti * FE_FIX_PER_BLOCK entries of loss_part / rsum_part
+  int nmulti, nred;         // nred = rc.nunit + nmulti * (workgroups of fe_rows_fix_kernel per block) entries of loss_part / rsum_part
   const float *y, *o, *w;   // w may be NULL
   const int64_t* umap;      // [d] local -> global feature id
   double* xl;               // [d] x of the features present in this shard
@@ -181,48 +181,72 @@ __global__ __launch_bounds__(WAVE) void fe_scatter_kernel(FeDev F, SolveParams o
   }
 }
 
-// rows of the blocks that were cut into several units: partial sums in unit order, then as above
+// Partial sums of one output over the units [u0, u1) of its block. A frequent feature's block can have a thousand units: FE_STRANDS
+// threads take every FE_STRANDS-th unit each (several loads in flight), then thread 0 of the output adds the strands in order.
+// Fixed shape; with a single unit the result is that unit's value exactly.
+constexpr int FE_STRANDS = 16;
+constexpr int FE_RED_OUT = FE_THREADS / FE_STRANDS;   // outputs per workgroup; consecutive, so their loads share a line
+static_assert(FE_B % FE_RED_OUT == 0, "a workgroup's outputs lie in one block");
+
+__device__ __forceinline__ double fe_strand_sum(const double* __restrict__ part, int u0, int u1, int i, int strand, double (*lds)[FE_RED_OUT],
+                                                int out) {
+  double t = 0.0;
+  int u = u0 + strand;
+  for (; u + 3 * FE_STRANDS < u1; u += 4 * FE_STRANDS) {
+    const double a0 = part[(size_t)u * FE_B + i], a1 = part[(size_t)(u + FE_STRANDS) * FE_B + i];
+    const double a2 = part[(size_t)(u + 2 * FE_STRANDS) * FE_B + i], a3 = part[(size_t)(u + 3 * FE_STRANDS) * FE_B + i];
+    t += a0; t += a1; t += a2; t += a3;
+  }
+  for (; u < u1; u += FE_STRANDS) t += part[(size_t)u * FE_B + i];
+  lds[strand][out] = t;
+  __syncthreads();
+  double g = 0.0;
+  if (strand == 0) {
+    g = lds[0][out];
+#pragma unroll
+    for (int k = 1; k < FE_STRANDS; ++k) g += lds[k][out];
+  }
+  return g;
+}
+
+// rows of the blocks that were cut into several units
+constexpr int FE_FIX_PER_BLOCK = FE_B / FE_RED_OUT;   // workgroups of fe_rows_fix_kernel per block
 template <bool HESS = false>
 __global__ __launch_bounds__(FE_THREADS) void fe_rows_fix_kernel(FeDev F, SolveParams o) {
-  __shared__ double red[2][FE_WAVES];
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+  __shared__ double lds[FE_STRANDS][FE_RED_OUT];
+  const int tid = threadIdx.x, out = tid % FE_RED_OUT, strand = tid / FE_RED_OUT;
   const int b = F.multi[blockIdx.x / FE_FIX_PER_BLOCK];
-  const int i = (blockIdx.x % FE_FIX_PER_BLOCK) * FE_THREADS + tid;
+  const int i = (blockIdx.x % FE_FIX_PER_BLOCK) * FE_RED_OUT + out;
   const int row = b * FE_B + i;
   const double xb = F.ic ? F.W.x[F.D] : 0.0;
+  const double t = fe_strand_sum(F.rc.part, F.rc.ufirst[b], F.rc.ufirst[b + 1], i, strand, lds, out);
   double loss = 0.0, rsum = 0.0;
-  if (row < F.n) {
-    const int u0 = F.rc.ufirst[b], u1 = F.rc.ufirst[b + 1];
-    double t = F.rc.part[(size_t)u0 * FE_B + i];
-    for (int u = u0 + 1; u < u1; ++u) t += F.rc.part[(size_t)u * FE_B + i];
-    fe_emit_row<HESS>(F, o, row, t, xb, loss, rsum);
-  }
-  loss = wave_sum(loss);
-  rsum = wave_sum(rsum);
-  if (lane == 0) { red[0][wv] = loss; red[1][wv] = rsum; }
-  __syncthreads();
-  if (tid == 0) {
-    double a = red[0][0], r = red[1][0];
-#pragma unroll
-    for (int w = 1; w < FE_WAVES; ++w) { a += red[0][w]; r += red[1][w]; }
-    F.loss_part[F.rc.nunit + blockIdx.x] = a;
-    F.rsum_part[F.rc.nunit + blockIdx.x] = r;
+  if (strand == 0 && row < F.n) fe_emit_row<HESS>(F, o, row, t, xb, loss, rsum);
+  if (tid < WAVE) {   // the outputs' threads are the first FE_RED_OUT lanes of wavefront 0
+    loss = wave_sum(loss);
+    rsum = wave_sum(rsum);
+    if (tid == 0) {
+      F.loss_part[F.rc.nunit + blockIdx.x] = loss;
+      F.rsum_part[F.rc.nunit + blockIdx.x] = rsum;
+    }
   }
 }
 
-// local gradient (the column blocks' partial sums in unit order) into the global coefficient space; the first
-// FE_FIN_BLOCKS workgroups also add up a contiguous range of the per-unit value / residual sums each
+// local gradient (the column blocks' partial sums) into the global coefficient space; the first FE_FIN_BLOCKS workgroups also add
+// up a contiguous range of the per-unit value / residual sums each
 __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
+  __shared__ double lds[FE_STRANDS][FE_RED_OUT];
   __shared__ double red[2][FE_WAVES];
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < F.d; j += gridDim.x * blockDim.x) {
-    const int b = j / FE_B, i = j % FE_B;
-    const int u0 = F.cc.ufirst[b], u1 = F.cc.ufirst[b + 1];
-    double g = F.cc.part[(size_t)u0 * FE_B + i];
-    for (int u = u0 + 1; u < u1; ++u) g += F.cc.part[(size_t)u * FE_B + i];
-    F.fg[F.umap[j]] = g;
+  const int tid = threadIdx.x, out = tid % FE_RED_OUT, strand = tid / FE_RED_OUT;
+  const int j0 = blockIdx.x * FE_RED_OUT;
+  if (j0 < F.d) {   // workgroup-uniform
+    const int jj = j0 + out < F.d ? j0 + out : F.d - 1;
+    const int b = jj / FE_B, i = jj % FE_B;
+    const double g = fe_strand_sum(F.cc.part, F.cc.ufirst[b], F.cc.ufirst[b + 1], i, strand, lds, out);
+    if (strand == 0 && j0 + out < F.d) F.fg[F.umap[jj]] = g;
   }
   if (blockIdx.x >= FE_FIN_BLOCKS) return;
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+  const int lane = tid & (WAVE - 1), wv = tid >> 6;
   const int chunk = (F.nred + FE_FIN_BLOCKS - 1) / FE_FIN_BLOCKS;
   const int b0 = blockIdx.x * chunk;
   const int b1 = (b0 + chunk < F.nred) ? b0 + chunk : F.nred;
@@ -507,6 +531,10 @@ static int fe_chunk_len(int64_t z, int nblock, int num_cus) {
   const int64_t avg = (z + nblock - 1) / nblock;
   int64_t c = (avg <= 2 * target) ? 2 * avg : target;
   if (c < 8192) c = 8192;
+  if (const char* e = getenv("GDMIX_FE_CHUNK")) {   // test hook: small shards through the several-units-per-block code
+    const long v = atol(e);
+    if (v >= 64) c = v;
+  }
   if (c > (1 << 28)) c = 1 << 28;
   return (int)c;
 }
@@ -617,7 +645,8 @@ static int fe_passes(gdmix_fe_problem* p, const FeDev& F, hipStream_t s, bool ti
   if (timed) HIP_TRY(hipEventRecord(p->ev[1], s));
   hipLaunchKernelGGL((fe_scatter_kernel<false, HESS>), dim3(F.cc.nunit), dim3(WAVE), 0, s, F, p->o);
   if (timed) HIP_TRY(hipEventRecord(p->ev[2], s));
-  hipLaunchKernelGGL(fe_finish_kernel, dim3(gd < FE_FIN_BLOCKS ? FE_FIN_BLOCKS : gd), dim3(FE_THREADS), 0, s, F);
+  int gf = (F.d + FE_RED_OUT - 1) / FE_RED_OUT;
+  hipLaunchKernelGGL(fe_finish_kernel, dim3(gf < FE_FIN_BLOCKS ? FE_FIN_BLOCKS : gf), dim3(FE_THREADS), 0, s, F);
   hipLaunchKernelGGL(fe_finish2_kernel, dim3(1), dim3(WAVE), 0, s, F);   // HESS: fg[D] = sum_i d_i (the intercept's entry), fg[P] unused
   HIP_TRY(hipGetLastError());
   return GDMIX_RE_OK;

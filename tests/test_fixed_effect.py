@@ -112,7 +112,7 @@ def test_stepping_kernels_match_reference_ground_truth_and_oracle(device_solver,
 
 @pytest.mark.gpu
 def test_stepping_kernels_on_ragged_rows_long_columns_and_weights(device_solver):
-    """Row lengths from 0 to several blocks of the streaming kernel, a handful of very long columns, empty rows at both
+    """Row lengths from 0 to more than a unit of the passes, a handful of very long columns, empty rows at both
     ends, weights, unregularised intercept: device-wide team kernel, stepping kernels and oracle agree."""
     rng = np.random.default_rng(5)
     n, D = 3000, 700
@@ -142,6 +142,49 @@ def test_stepping_kernels_on_ragged_rows_long_columns_and_weights(device_solver)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [None, "8192", "257"])
+def test_passes_cut_into_units_are_deterministic_and_agree(device_solver, monkeypatch, chunk):
+    """csrc/fe_solve.hip: several row blocks and column blocks, blocks cut into several units (GDMIX_FE_CHUNK forces that on a
+    small shard; 257 is no multiple of anything), a frequent feature, empty rows and features that never occur. Two fits are
+    bitwise equal (one wavefront per accumulator set, in-order LDS adds); every cut agrees with the oracle."""
+    if chunk is None:
+        monkeypatch.delenv("GDMIX_FE_CHUNK", raising=False)
+    else:
+        monkeypatch.setenv("GDMIX_FE_CHUNK", chunk)
+    rng = np.random.default_rng(11)
+    n, D = 9000, 7000
+    k = rng.integers(0, 24, n)
+    k[rng.integers(0, n, 3)] = 3000
+    rp = np.concatenate([[0], np.cumsum(k)]).astype(np.int64)
+    cols = np.minimum((float(D + 1) ** rng.random(rp[-1])).astype(np.int64) - 1, D - 1)     # feature j with probability ~ 1/(j+1)
+    vals = (rng.standard_normal(rp[-1]) * 0.3).astype(np.float32)
+    y = (rng.random(n) < 0.3).astype(np.float32)
+    off = (0.2 * rng.standard_normal(n)).astype(np.float32)
+    wt = (0.5 + rng.random(n)).astype(np.float32)
+    s = fe.FixedEffectDeviceSolver(solver=device_solver)
+    kw = dict(offset=off, weight=wt, l2=1.5, regularize_bias=False, max_iter=40)
+    th1, info1 = s.fit_stepping(rp, cols, vals, y, D, **kw)
+    th2, info2 = s.fit_stepping(rp, cols, vals, y, D, **kw)
+    assert np.array_equal(th1, th2) and info1 == info2
+    batch, dummy = fe.shard_as_batch(rp, cols, vals, y, off, wt, True)
+    pk = oracle.pack(batch.ent_row_ptr, batch.row_nnz_ptr, batch.col_global)
+    o = oracle.make_opts(l2=1.5, regularize_bias=False, has_intercept=True, max_iter=40, threshold=0.0, sum_loss=True)
+    res = oracle.solve(pk, batch.val, batch.y, batch.offset, batch.weight, o)
+    th_o = fe.to_global(res["theta"], pk["unique_global"], D, True, dummy)
+    assert info1["status"] == res["status"][0] and info1["nit"] == res["nit"][0] and info1["nfev"] == res["nfev"][0]
+    assert rel_err(th1, th_o) <= 1e-9, rel_err(th1, th_o)
+    # the Hessian diagonal goes through the same passes
+    th3, info3 = s.fit_stepping(rp, cols, vals, y, D, variance_mode="simple", threshold=0.0, **kw)
+    assert np.array_equal(th3, th1)
+    rows = np.repeat(np.arange(n), k)
+    z = np.bincount(rows, weights=vals.astype(np.float64) * th1[cols], minlength=n) + th1[D] + off
+    rho = 1 / (1 + np.exp(-z))
+    d = rho * (1 - rho) * wt
+    H = np.concatenate([np.bincount(cols, weights=vals.astype(np.float64) ** 2 * d[rows], minlength=D) + 1.5, [d.sum()]])
+    np.testing.assert_allclose(info3["variances"], 1.0 / (H + 1e-12), rtol=1e-10)
+
+
+@pytest.mark.gpu
 def test_two_workers_all_reduce_gradient_and_value(tmp_path):
     """Two processes, each with every other sample as its shard (both on GPU 0, collectives over gloo): the replicated
     L-BFGS step on the all-reduced [gradient, value] gives every worker the coefficients of the whole data set."""
@@ -168,7 +211,7 @@ def test_two_workers_all_reduce_gradient_and_value(tmp_path):
 def test_device_fixed_effect_at_scale_against_oracle(device_solver):
     """600k samples x 8 non-zeros over 5000 features, weights, unregularised intercept, both model types."""
     rng = np.random.default_rng(0)
-    n, k, D = 600_000, 8, 5000   # three row tiles of the column copy
+    n, k, D = 600_000, 8, 5000   # 293 row blocks, 3 column blocks cut into units
     cols = rng.integers(0, D, (n, k))
     vals = rng.standard_normal((n, k)).astype(np.float32)
     w_true = rng.standard_normal(D) * 0.3
@@ -237,7 +280,7 @@ def test_device_scoring_of_a_raw_shard(device_solver, has_intercept):
 @pytest.mark.parametrize("regularize_bias", [False, True])
 def test_device_hessian_diagonal_and_simple_variance(device_solver, regularize_bias):
     """gdmix_fe_hessian_diag: two streaming passes (rows -> w rho (1 - rho), columns -> sum val^2 d) against dense numpy, ragged
-    rows, weights, three row tiles of the column copy; then the SIMPLE variances through fit_stepping."""
+    rows, weights, 293 row blocks; then the SIMPLE variances through fit_stepping."""
     rng = np.random.default_rng(17)
     n, D = 600_000, 700
     k = rng.integers(0, 9, n)

@@ -1,6 +1,8 @@
 """Fixed-effect fit on one MI355X: time per objective evaluation and achieved HBM bandwidth.
 
-    PYTHONPATH=. python tools/fe_bench.py [rows] [nnz_per_row] [features]
+    PYTHONPATH=. python tools/fe_bench.py [rows] [nnz_per_row] [features] [uniform|zipf]
+(zipf: feature j drawn with probability ~ 1/(j+1), the shape of real sparse features: the most frequent one holds 1/ln(features)
+of all entries)
 Algorithmic bytes per evaluation: CSR pass 8 B/nnz (fp32 value + int32 column) + CSC pass 8 B/nnz (value + row) +
 16 B/row (row pointer, y, offset, weight) + 8 B/row residual written and gathered + per coefficient: x read, g written,
 d, r and 2m history vectors read for the fused dot products = (4 + 2m) * 8 B.
@@ -18,8 +20,12 @@ from gdmix_amd.solver import REDeviceSolver, SolverOptions
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 D = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000
+dist = sys.argv[4] if len(sys.argv) > 4 else "uniform"
 rng = np.random.default_rng(0)
-cols = rng.integers(0, D, (n, k), dtype=np.int64)
+if dist == "zipf":
+    cols = np.minimum((float(D + 1) ** rng.random((n, k))).astype(np.int64) - 1, D - 1)
+else:
+    cols = rng.integers(0, D, (n, k), dtype=np.int64)
 vals = rng.standard_normal((n, k)).astype(np.float32)
 w_true = (rng.standard_normal(D) * 0.1)
 z = (vals * w_true[cols]).sum(1)
@@ -68,7 +74,7 @@ for label, (dt, info, extra) in results.items():
     dev_ms = extra.get("device_loop_ms", dt * 1e3)
     ms_eval = dev_ms / nfev
     line = {"path": label, "metric": "fixed-effect L-BFGS evaluations/sec (objective + gradient + step)",
-            "rows": n, "nnz": Z, "features": D, "nit": int(info["nit"]), "nfev": nfev, "status": int(info["status"]),
+            "rows": n, "nnz": Z, "features": D, "columns": dist, "nit": int(info["nit"]), "nfev": nfev, "status": int(info["status"]),
             "fit_wall_ms_incl_upload_pack": dt * 1e3, "ms_per_evaluation": ms_eval, "alg_bytes_per_evaluation": bytes_eval,
             "achieved_GBps": bytes_eval / (ms_eval * 1e-3) / 1e9, "hbm_peak_GBps": 8000.0,
             "frac": bytes_eval / (ms_eval * 1e-3) / 8e12, **extra}
