@@ -7,8 +7,9 @@
 // The two passes (fe_scatter_kernel) are written for HBM: no gather may cost an L2 request per entry, and no sum may
 // depend on the launch. Each pass has its own copy of the non-zeros, grouped by block of FE_B consecutive *outputs* (rows
 // for X theta, columns for X'r) and, inside a block, in the order of the *gathered* vector (columns for X theta, rows for
-// X'r): one wavefront owns a block's FE_B accumulators in LDS, streams the block's entries (index of the gathered
-// element, value, 16-bit accumulator index: 10 B per entry, every byte once), reads the gathered vector almost
+// X'r): one wavefront owns a block's FE_B accumulators in LDS, streams the block's entries (8 B each, every byte once:
+// fp32 value + one word holding the accumulator index and the gathered element's index relative to the unit's first;
+// three arrays and 10 B when a unit spans more than 2^21 gathered elements), reads the gathered vector almost
 // sequentially (a 128-byte line serves all the entries that fall into it, ~20 here, instead of one) and adds the
 // products into LDS with ds_add_f64. A block with many entries is cut into chunks of equal entry count, one wavefront
 // each, whose partial sums a second small kernel adds in chunk order. One wavefront per accumulator set and in-order
@@ -23,6 +24,7 @@
 #include "re_lbfgs_compact.hpp"
 #include "../../include/gdmix_fe.h"
 
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -34,24 +36,33 @@ namespace gdmix {
 #ifndef GDMIX_FE_UNROLL
 #define GDMIX_FE_UNROLL 8
 #endif
+#ifndef GDMIX_FE_PACK
+#define GDMIX_FE_PACK 1      // 0: always the three-array form (tests of that path)
+#endif
 constexpr int FE_B = GDMIX_FE_B;        // accumulators (rows / columns) per block: 16 KiB of LDS per wavefront
 constexpr int FE_U = GDMIX_FE_UNROLL;   // entries per lane in flight
 constexpr int FE_THREADS = 256;
+constexpr int FE_XCDS = 8;           // accelerator dies of an MI355X, each with its own L2; workgroup i runs on die i % 8
 constexpr int FE_WAVES = FE_THREADS / WAVE;
 constexpr int FE_DOT_BLOCKS = 512;
 constexpr int FE_FIN_BLOCKS = 64;   // workgroups (= lanes of the final wavefront) that add up the per-unit partial sums
-static_assert(FE_B <= 65536 && FE_B % FE_THREADS == 0, "16-bit accumulator index");
+static_assert(FE_U % 2 == 0 && FE_B <= 65536 && FE_B % FE_THREADS == 0, "16-bit accumulator index");
 
 // one pass's copy of the non-zeros
+constexpr int FE_LOC_BITS = 11;
+static_assert((1 << FE_LOC_BITS) == GDMIX_FE_B || !GDMIX_FE_PACK, "the packed word holds the accumulator index in its low bits");
 struct FeCopy {
+  const uint2* ent;        // packed [z]: x = (key - kbase[unit]) << FE_LOC_BITS | loc, y = bits of the value; else NULL and:
   const int32_t* key;      // [z] element of the gathered vector: local column (row pass) / row (column pass)
   const float* val;        // [z]
   const uint16_t* loc;     // [z] accumulator within the block
+  const int32_t* kbase;    // [nunit] key of the unit's first entry (the smallest: a unit's keys ascend)
   const int32_t* ustart;   // [nunit+1] unit -> first entry; units tile the copy
   const int32_t* ublock;   // [nunit]
   const int32_t* ufirst;   // [nblock+1] block -> first unit
+  const int32_t* order;    // [nlaunch] workgroup -> unit or -1: units that gather the same stretch of the vector on one XCD (fe_build_copy)
   double* part;            // [nunit][FE_B] partial sums of the blocks that have several units (column pass: of all)
-  int nunit, nblock;
+  int nunit, nblock, nlaunch;
 };
 
 struct FeDev {
@@ -106,18 +117,22 @@ __device__ __forceinline__ void lds_add(double* acc, int loc, double term) {
   __hip_atomic_fetch_add(acc + loc, term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <bool ROWS, bool HESS = false>
+template <bool ROWS, bool HESS, bool PACKED>
 __global__ __launch_bounds__(WAVE) void fe_scatter_kernel(FeDev F, SolveParams o) {
   __shared__ double acc[FE_B + 2];   // + a spare one for the lanes beyond the end of the last trip
-  const int lane = threadIdx.x, u = blockIdx.x;
+  const int lane = threadIdx.x;
   const FeCopy& C = ROWS ? F.rc : F.cc;
+  const int u = C.order[blockIdx.x];
+  if (u < 0) return;
   const int k0 = C.ustart[u], k1 = C.ustart[u + 1], b = C.ublock[u];
+  const int kb = PACKED ? C.kbase[u] : 0;
   const bool whole = ROWS && (C.ufirst[b + 1] - C.ufirst[b] == 1);
   const double xb = (ROWS && F.ic) ? F.W.x[F.D] : 0.0;
+  const uint2* __restrict__ ent = C.ent;
   const int32_t* __restrict__ key = C.key;
   const float* __restrict__ val = C.val;
   const uint16_t* __restrict__ loc = C.loc;
-  const double* __restrict__ vec = ROWS ? F.xl : F.rs;
+  const double* __restrict__ vec = (ROWS ? F.xl : F.rs) + kb;
 #pragma unroll
   for (int i = 0; i < FE_B / WAVE; i += 2) *reinterpret_cast<double2*>(acc + (i * WAVE + 2 * lane)) = make_double2(0.0, 0.0);
   // full trips without a guard in sight (a load under a branch is waited for inside the branch); the last, partial trip
@@ -130,9 +145,19 @@ __global__ __launch_bounds__(WAVE) void fe_scatter_kernel(FeDev F, SolveParams o
 #pragma unroll
     for (int q = 0; q < FE_U; ++q) {
       const int k = base + q * WAVE + lane;
-      kq[q] = key[k];
-      vq[q] = val[k];
-      lq[q] = (int)loc[k];
+      if (PACKED) {
+        // two consecutive entries per lane and 16-byte load; the adds keep entry order within a pair, pairs in lane order
+        if ((q & 1) == 0) {
+          uint4 e2;
+          __builtin_memcpy(&e2, ent + (base + (q >> 1) * 2 * WAVE + 2 * lane), 16);
+          kq[q] = (int)(e2.x >> FE_LOC_BITS); lq[q] = (int)(e2.x & ((1u << FE_LOC_BITS) - 1)); vq[q] = __uint_as_float(e2.y);
+          kq[q + 1] = (int)(e2.z >> FE_LOC_BITS); lq[q + 1] = (int)(e2.z & ((1u << FE_LOC_BITS) - 1)); vq[q + 1] = __uint_as_float(e2.w);
+        }
+      } else {
+        kq[q] = key[k];
+        vq[q] = val[k];
+        lq[q] = (int)loc[k];
+      }
     }
 #pragma unroll
     for (int q = 0; q < FE_U; ++q) xq[q] = vec[kq[q]];
@@ -150,9 +175,18 @@ __global__ __launch_bounds__(WAVE) void fe_scatter_kernel(FeDev F, SolveParams o
     for (int q = 0; q < FE_U; ++q) {
       const int k = base + q * WAVE + lane;
       const int kc = k < k1 ? k : k1 - 1;
-      kq[q] = key[kc];
-      vq[q] = val[kc];
-      lq[q] = k < k1 ? (int)loc[kc] : FE_B;
+      int l;
+      if (PACKED) {
+        const uint2 e = ent[kc];
+        kq[q] = (int)(e.x >> FE_LOC_BITS);
+        l = (int)(e.x & ((1u << FE_LOC_BITS) - 1));
+        vq[q] = __uint_as_float(e.y);
+      } else {
+        kq[q] = key[kc];
+        vq[q] = val[kc];
+        l = (int)loc[kc];
+      }
+      lq[q] = k < k1 ? l : FE_B;
     }
 #pragma unroll
     for (int q = 0; q < FE_U; ++q) xq[q] = vec[kq[q]];
@@ -418,21 +452,45 @@ __global__ void fe_flag_kernel(const int32_t* __restrict__ ptr, int nseg, int64_
   }
 }
 
-__global__ void fe_key_kernel(const int32_t* __restrict__ idx, int64_t z, uint32_t* __restrict__ skey, uint32_t* __restrict__ perm) {
+struct FeEnt { int32_t seg, idx; float val; };   // an entry on its way through the sort
+
+__global__ void fe_ent_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ idx, const float* __restrict__ val, int64_t z,
+                              uint32_t* __restrict__ skey, FeEnt* __restrict__ ent) {
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < z; k += (int64_t)gridDim.x * blockDim.x) {
-    skey[k] = (uint32_t)(idx[k] / FE_B);
-    perm[k] = (uint32_t)k;
+    const int i = idx[k];
+    skey[k] = (uint32_t)(i / FE_B);
+    ent[k] = FeEnt{seg[k], i, val[k]};
   }
 }
 
-__global__ void fe_copy_gather_kernel(const uint32_t* __restrict__ perm, const int32_t* __restrict__ seg, const int32_t* __restrict__ idx,
-                                      const float* __restrict__ val, int64_t z, int32_t* __restrict__ ckey, float* __restrict__ cval,
-                                      uint16_t* __restrict__ cloc) {
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < z; k += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t src = perm[k];
-    ckey[k] = seg[src];
-    cval[k] = val[src];
-    cloc[k] = (uint16_t)(idx[src] % FE_B);
+// widest unit: key of its last entry - key of its first (keys ascend inside a unit)
+__global__ void fe_span_kernel(const FeEnt* __restrict__ ent, const int32_t* __restrict__ ustart, int nunit, int32_t* __restrict__ kbase,
+                               int32_t* __restrict__ max_span) {
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < nunit; u += gridDim.x * blockDim.x) {
+    const int k0 = ustart[u], k1 = ustart[u + 1];
+    const int first = k1 > k0 ? ent[k0].seg : 0;
+    kbase[u] = first;
+    if (k1 > k0) atomicMax(max_span, ent[k1 - 1].seg - first);
+  }
+}
+
+// the copy in the form the pass reads; one workgroup per unit
+template <bool PACKED>
+__global__ __launch_bounds__(256) void fe_pack_kernel(const FeEnt* __restrict__ ent, const int32_t* __restrict__ ustart,
+                                                      const int32_t* __restrict__ kbase, uint2* __restrict__ out, int32_t* __restrict__ ckey,
+                                                      float* __restrict__ cval, uint16_t* __restrict__ cloc) {
+  const int u = blockIdx.x;
+  const int k0 = ustart[u], k1 = ustart[u + 1], kb = kbase[u];
+  for (int k = k0 + threadIdx.x; k < k1; k += 256) {
+    const FeEnt e = ent[k];
+    const int l = e.idx % FE_B;
+    if (PACKED) {
+      out[k] = make_uint2(((uint32_t)(e.seg - kb) << FE_LOC_BITS) | (uint32_t)l, __float_as_uint(e.val));
+    } else {
+      ckey[k] = e.seg;
+      cval[k] = e.val;
+      cloc[k] = (uint16_t)l;
+    }
   }
 }
 
@@ -540,7 +598,7 @@ static int fe_chunk_len(int64_t z, int nblock, int num_cus) {
 }
 
 // Build one pass's copy from segment-major source arrays (ptr [nseg+1], idx / val [z]); `len` = extent of idx (outputs of the
-// pass). Device memory of the result in *owned; the unit table is also returned on the host (ufirst) for the caller.
+// pass). Device memory of the result in *owned; the block -> unit table is also returned on the host (ufirst).
 static int fe_build_copy(hipStream_t s, int num_cus, const int32_t* ptr, int nseg, const int32_t* idx, const float* val, int64_t z,
                          int len, FeCopy* out, void** owned, std::vector<int32_t>* ufirst_host) {
   *owned = nullptr;
@@ -550,17 +608,19 @@ static int fe_build_copy(hipStream_t s, int num_cus, const int32_t* ptr, int nse
   unsigned bits = 1;
   while ((1u << bits) < (unsigned)nblock) ++bits;
   size_t sort_tmp = 0, scan_tmp = 0, scan2_tmp = 0;
-  hipError_t rc = rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                            (uint32_t*)nullptr, zz, 0u, bits, s);
+  hipError_t rc = rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (FeEnt*)nullptr, (FeEnt*)nullptr,
+                                            zz, 0u, bits, s);
   if (rc == hipSuccess) rc = rocprim::inclusive_scan(nullptr, scan_tmp, (int32_t*)nullptr, (int32_t*)nullptr, zz, rocprim::plus<int32_t>(), s);
   if (rc == hipSuccess) rc = rocprim::exclusive_scan(nullptr, scan2_tmp, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)nblock + 1, rocprim::plus<int32_t>(), s);
   if (rc != hipSuccess) { set_error("rocPRIM sizing failed: %s", hipGetErrorString(rc)); return GDMIX_RE_EHIP; }
   size_t lib = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
   if (scan2_tmp > lib) lib = scan2_tmp;
+  // upper bound of the unit count: a block of len entries has at most len / chunk + 1 units
+  const size_t max_units = (size_t)nblock + (size_t)(z / chunk) + 1;
   size_t woff = 0;
   auto wtake = [&](size_t bytes) { size_t r = woff; woff = up256(woff + bytes); return r; };
-  const size_t w_a = wtake(zz * 4), w_seg = wtake(zz * 4), w_key = wtake(zz * 4), w_perm = wtake(zz * 4), w_perm2 = wtake(zz * 4);
-  const size_t w_bp = wtake(((size_t)nblock + 1) * 4), w_nch = wtake(((size_t)nblock + 1) * 4), w_lib = wtake(lib);
+  const size_t w_a = wtake(zz * 4), w_seg = wtake(zz * 4), w_key = wtake(zz * 4), w_ent = wtake(zz * sizeof(FeEnt)), w_ent2 = wtake(zz * sizeof(FeEnt));
+  const size_t w_bp = wtake(((size_t)nblock + 1) * 4), w_nch = wtake(((size_t)nblock + 1) * 4), w_span = wtake(64), w_lib = wtake(lib);
   void* tmp = nullptr;
   rc = hipMalloc(&tmp, woff);
   if (rc != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", woff, hipGetErrorString(rc)); return GDMIX_RE_ENOMEM; }
@@ -568,31 +628,29 @@ static int fe_build_copy(hipStream_t s, int num_cus, const int32_t* ptr, int nse
   int32_t* flag = reinterpret_cast<int32_t*>(wb + w_a);      // later: the sorted block numbers
   int32_t* seg = reinterpret_cast<int32_t*>(wb + w_seg);
   uint32_t* skey = reinterpret_cast<uint32_t*>(wb + w_key);
-  uint32_t* perm = reinterpret_cast<uint32_t*>(wb + w_perm);
   uint32_t* skey2 = reinterpret_cast<uint32_t*>(wb + w_a);
-  uint32_t* perm2 = reinterpret_cast<uint32_t*>(wb + w_perm2);
+  FeEnt* ent = reinterpret_cast<FeEnt*>(wb + w_ent);
+  FeEnt* ent2 = reinterpret_cast<FeEnt*>(wb + w_ent2);
   int32_t* bp = reinterpret_cast<int32_t*>(wb + w_bp);
   int32_t* nch = reinterpret_cast<int32_t*>(wb + w_nch);
-  // the copy itself and the block -> unit table; the unit arrays follow once their number is known
-  size_t coff = 0;
-  auto ctake = [&](size_t bytes) { size_t r = coff; coff = up256(coff + bytes); return r; };
-  const size_t c_key = ctake(zz * 4), c_val = ctake(zz * 4), c_loc = ctake(zz * 2), c_uf = ctake(((size_t)nblock + 1) * 4);
-  // upper bound of the unit count: a block of len entries has at most len / chunk + 1 units
-  const size_t max_units = (size_t)nblock + (size_t)(z / chunk) + 1;
-  const size_t c_us = ctake((max_units + 1) * 4), c_ub = ctake(max_units * 4);
+  int32_t* span = reinterpret_cast<int32_t*>(wb + w_span);
+  // the unit tables; the entries follow once their form is known
+  size_t toff = 0;
+  auto ttake = [&](size_t bytes) { size_t r = toff; toff = up256(toff + bytes); return r; };
+  const size_t c_uf = ttake(((size_t)nblock + 1) * 4), c_us = ttake((max_units + 1) * 4), c_ub = ttake(max_units * 4), c_kb = ttake(max_units * 4), c_ord = ttake((max_units + FE_XCDS) * 4);
+  const size_t c_ent = ttake(zz * 10 + 512);   // 8 B per entry packed, 4 + 4 + 2 otherwise
   void* mem = nullptr;
-  rc = hipMalloc(&mem, coff);
-  if (rc != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", coff, hipGetErrorString(rc)); (void)hipFree(tmp); return GDMIX_RE_ENOMEM; }
+  rc = hipMalloc(&mem, toff);
+  if (rc != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", toff, hipGetErrorString(rc)); (void)hipFree(tmp); return GDMIX_RE_ENOMEM; }
   char* cb = static_cast<char*>(mem);
-  int32_t* ckey = reinterpret_cast<int32_t*>(cb + c_key);
-  float* cval = reinterpret_cast<float*>(cb + c_val);
-  uint16_t* cloc = reinterpret_cast<uint16_t*>(cb + c_loc);
   int32_t* ufirst = reinterpret_cast<int32_t*>(cb + c_uf);
   int32_t* ustart = reinterpret_cast<int32_t*>(cb + c_us);
   int32_t* ublock = reinterpret_cast<int32_t*>(cb + c_ub);
+  int32_t* kbase = reinterpret_cast<int32_t*>(cb + c_kb);
   const int ge = num_cus * 16;
   int gb = (nblock + 1 + 255) / 256;
   if (gb > 4096) gb = 4096;
+  (void)hipMemsetAsync(span, 0, 64, s);
   if (z > 0) {
     (void)hipMemsetAsync(flag, 0, zz * 4, s);
     int gs = (nseg + 255) / 256;
@@ -601,10 +659,9 @@ static int fe_build_copy(hipStream_t s, int num_cus, const int32_t* ptr, int nse
     hipLaunchKernelGGL(fe_flag_kernel, dim3(gs), dim3(256), 0, s, ptr, nseg, z, flag);
     size_t lt = scan_tmp;
     rc = rocprim::inclusive_scan(wb + w_lib, lt, flag, seg, (size_t)z, rocprim::plus<int32_t>(), s);
-    hipLaunchKernelGGL(fe_key_kernel, dim3(ge), dim3(256), 0, s, idx, z, skey, perm);
+    hipLaunchKernelGGL(fe_ent_kernel, dim3(ge), dim3(256), 0, s, seg, idx, val, z, skey, ent);
     lt = sort_tmp;
-    if (rc == hipSuccess) rc = rocprim::radix_sort_pairs(wb + w_lib, lt, skey, skey2, perm, perm2, (size_t)z, 0u, bits, s);
-    hipLaunchKernelGGL(fe_copy_gather_kernel, dim3(ge), dim3(256), 0, s, perm2, seg, idx, val, z, ckey, cval, cloc);
+    if (rc == hipSuccess) rc = rocprim::radix_sort_pairs(wb + w_lib, lt, skey, skey2, ent, ent2, (size_t)z, 0u, bits, s);
   }
   hipLaunchKernelGGL(fe_block_kernel, dim3(gb), dim3(256), 0, s, skey2, z, nblock, bp);
   hipLaunchKernelGGL(fe_chunks_kernel, dim3(gb), dim3(256), 0, s, bp, nblock, chunk, nch);
@@ -614,13 +671,52 @@ static int fe_build_copy(hipStream_t s, int num_cus, const int32_t* ptr, int nse
   ufirst_host->resize((size_t)nblock + 1);
   if (rc == hipSuccess) rc = hipMemcpyAsync(ufirst_host->data(), ufirst, ((size_t)nblock + 1) * 4, hipMemcpyDeviceToHost, s);
   if (rc == hipSuccess) rc = hipStreamSynchronize(s);
+  const int nunit = rc == hipSuccess ? (*ufirst_host)[(size_t)nblock] : 0;
+  int32_t max_span = 0;
+  if (rc == hipSuccess) {
+    int gu = (nunit + 255) / 256;
+    if (gu > 4096) gu = 4096;
+    hipLaunchKernelGGL(fe_span_kernel, dim3(gu), dim3(256), 0, s, ent2, ustart, nunit, kbase, span);
+    rc = hipMemcpyAsync(&max_span, span, 4, hipMemcpyDeviceToHost, s);
+    if (rc == hipSuccess) rc = hipStreamSynchronize(s);
+  }
+  // Launch order. Workgroups go to the XCDs round robin and every XCD has its own L2: units that gather the same stretch of the
+  // vector should meet in one L2 rather than pull it over the fabric eight times (column pass on 4 M samples: 256 MB of
+  // residuals on top of 1 GB of entries). Units sorted by first gathered element, the sorted list cut into one run per XCD,
+  // run x dealt to the workgroups x, x + XCDS, ...
+  std::vector<int32_t> order;
+  if (rc == hipSuccess) {
+    std::vector<int32_t> kb((size_t)nunit), by((size_t)nunit);
+    if (nunit) rc = hipMemcpy(kb.data(), kbase, (size_t)nunit * 4, hipMemcpyDeviceToHost);
+    for (int u = 0; u < nunit; ++u) by[(size_t)u] = u;
+    std::stable_sort(by.begin(), by.end(), [&](int32_t a, int32_t b) { return kb[(size_t)a] < kb[(size_t)b]; });
+    const int per = (nunit + FE_XCDS - 1) / FE_XCDS;
+    order.assign((size_t)per * FE_XCDS, -1);
+    for (int x = 0; x < FE_XCDS; ++x)
+      for (int j = 0; j < per && x * per + j < nunit; ++j) order[(size_t)j * FE_XCDS + x] = by[(size_t)x * per + j];
+    if (rc == hipSuccess && !order.empty()) rc = hipMemcpy(cb + c_ord, order.data(), order.size() * 4, hipMemcpyHostToDevice);
+  }
+  bool packed = GDMIX_FE_PACK && max_span < (1 << (32 - FE_LOC_BITS));
+  if (const char* e = getenv("GDMIX_FE_PACK")) packed = packed && atoi(e) != 0;   // test hook: the three-array form on a small shard
+  uint2* pent = reinterpret_cast<uint2*>(cb + c_ent);
+  int32_t* ckey = reinterpret_cast<int32_t*>(cb + c_ent);
+  float* cval = reinterpret_cast<float*>(cb + c_ent + up256(zz * 4));
+  uint16_t* cloc = reinterpret_cast<uint16_t*>(cb + c_ent + 2 * up256(zz * 4));
+  if (rc == hipSuccess && nunit > 0 && z > 0) {
+    if (packed) hipLaunchKernelGGL((fe_pack_kernel<true>), dim3(nunit), dim3(256), 0, s, ent2, ustart, kbase, pent, ckey, cval, cloc);
+    else hipLaunchKernelGGL((fe_pack_kernel<false>), dim3(nunit), dim3(256), 0, s, ent2, ustart, kbase, pent, ckey, cval, cloc);
+    rc = hipStreamSynchronize(s);
+  }
   if (rc == hipSuccess) rc = hipGetLastError();
   (void)hipFree(tmp);
   if (rc != hipSuccess) { set_error("building a pass's copy failed: %s", hipGetErrorString(rc)); (void)hipFree(mem); return GDMIX_RE_EHIP; }
-  out->key = ckey; out->val = cval; out->loc = cloc; out->ustart = ustart; out->ublock = ublock; out->ufirst = ufirst;
+  out->ent = packed ? pent : nullptr;
+  out->key = ckey; out->val = cval; out->loc = cloc; out->kbase = kbase; out->ustart = ustart; out->ublock = ublock; out->ufirst = ufirst;
   out->part = nullptr;
   out->nblock = nblock;
-  out->nunit = (*ufirst_host)[(size_t)nblock];
+  out->nunit = nunit;
+  out->order = reinterpret_cast<const int32_t*>(cb + c_ord);
+  out->nlaunch = (int)order.size();
   *owned = mem;
   return GDMIX_RE_OK;
 }
@@ -640,10 +736,12 @@ static int fe_passes(gdmix_fe_problem* p, const FeDev& F, hipStream_t s, bool ti
   if (gd < 1) gd = 1;
   hipLaunchKernelGGL(fe_prepare_kernel, dim3(gd), dim3(256), 0, s, F);
   if (timed) HIP_TRY(hipEventRecord(p->ev[0], s));
-  hipLaunchKernelGGL((fe_scatter_kernel<true, HESS>), dim3(F.rc.nunit), dim3(WAVE), 0, s, F, p->o);
+  if (F.rc.ent) hipLaunchKernelGGL((fe_scatter_kernel<true, HESS, true>), dim3(F.rc.nlaunch), dim3(WAVE), 0, s, F, p->o);
+  else hipLaunchKernelGGL((fe_scatter_kernel<true, HESS, false>), dim3(F.rc.nlaunch), dim3(WAVE), 0, s, F, p->o);
   if (F.nmulti) hipLaunchKernelGGL((fe_rows_fix_kernel<HESS>), dim3(F.nmulti * FE_FIX_PER_BLOCK), dim3(FE_THREADS), 0, s, F, p->o);
   if (timed) HIP_TRY(hipEventRecord(p->ev[1], s));
-  hipLaunchKernelGGL((fe_scatter_kernel<false, HESS>), dim3(F.cc.nunit), dim3(WAVE), 0, s, F, p->o);
+  if (F.cc.ent) hipLaunchKernelGGL((fe_scatter_kernel<false, HESS, true>), dim3(F.cc.nlaunch), dim3(WAVE), 0, s, F, p->o);
+  else hipLaunchKernelGGL((fe_scatter_kernel<false, HESS, false>), dim3(F.cc.nlaunch), dim3(WAVE), 0, s, F, p->o);
   if (timed) HIP_TRY(hipEventRecord(p->ev[2], s));
   int gf = (F.d + FE_RED_OUT - 1) / FE_RED_OUT;
   hipLaunchKernelGGL(fe_finish_kernel, dim3(gf < FE_FIN_BLOCKS ? FE_FIN_BLOCKS : gf), dim3(FE_THREADS), 0, s, F);

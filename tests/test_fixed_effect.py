@@ -142,15 +142,17 @@ def test_stepping_kernels_on_ragged_rows_long_columns_and_weights(device_solver)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunk", [None, "8192", "257"])
-def test_passes_cut_into_units_are_deterministic_and_agree(device_solver, monkeypatch, chunk):
+@pytest.mark.parametrize("chunk,pack", [(None, "1"), ("8192", "1"), ("257", "1"), ("257", "0"), (None, "0")])
+def test_passes_cut_into_units_are_deterministic_and_agree(device_solver, monkeypatch, chunk, pack):
     """csrc/fe_solve.hip: several row blocks and column blocks, blocks cut into several units (GDMIX_FE_CHUNK forces that on a
-    small shard; 257 is no multiple of anything), a frequent feature, empty rows and features that never occur. Two fits are
+    small shard; 257 is no multiple of anything), both forms of the entries (GDMIX_FE_PACK=0: the three arrays a unit spanning more
+    than 2^21 gathered elements needs), a frequent feature, empty rows and features that never occur. Two fits are
     bitwise equal (one wavefront per accumulator set, in-order LDS adds); every cut agrees with the oracle."""
     if chunk is None:
         monkeypatch.delenv("GDMIX_FE_CHUNK", raising=False)
     else:
         monkeypatch.setenv("GDMIX_FE_CHUNK", chunk)
+    monkeypatch.setenv("GDMIX_FE_PACK", pack)
     rng = np.random.default_rng(11)
     n, D = 9000, 7000
     k = rng.integers(0, 24, n)
