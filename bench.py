@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="entities per pass of the CPU baseline (0 = 200k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive hand-over measurement")
+    ap.add_argument("--no-fe", action="store_true", help="skip the fixed-effect evaluation leg (detail.fixed_effect_eval)")
+    ap.add_argument("--fe-rows", type=int, default=4_000_000, help="samples of the fixed-effect leg's shard (x 32 non-zeros, 100k features)")
     ap.add_argument("--giant-nnz", type=int, default=-1, help="override the device-wide kernel threshold (exploration)")
     ap.add_argument("--team-nnz", type=int, default=-1, help="override the lowest team-tier threshold (exploration)")
     ap.add_argument("--solve-only", action="store_true", help="time gdmix_re_solve alone (batch packed once)")
@@ -160,6 +162,48 @@ def host_handover(batch, opts, device_index, P, partitions=24, workers=3):
             "serial_one_stream": {"ms": serial * 1e3, "entities_per_s": batch.E / serial},
             "what": "page-locked 32-bit wire batch -> H2D -> gdmix_re_widen -> pack -> solve -> D2H thresholded theta (f64) + status, "
                     f"{workers} streams, partitions round robin; serial_one_stream = the same for one partition without overlap"}
+
+
+def fixed_effect_leg(solver, rows, nnz_per_row=32, features=100_000, iters=20):
+    """SURVEY.md 8(f) N1 next to the headline: one worker's shard (rows x 32 uniform columns of 100k features, logistic, m = 10)
+    resident in HBM, L-BFGS by the stepping kernels of include/gdmix_fe.h; time per evaluation (two passes over the non-zeros
+    + the replicated step) and the algorithmic bytes it moves (tools/fe_bench.py has the same accounting)."""
+    import torch
+    from gdmix_amd import fixed_effect as fe
+    from gdmix_amd.solver import SolverOptions
+    rng = np.random.default_rng(0)
+    n, k, D = rows, nnz_per_row, features
+    cols = rng.integers(0, D, n * k, dtype=np.int64)
+    vals = (rng.random(n * k, dtype=np.float32) - 0.5) * 2.0
+    y = (rng.random(n, dtype=np.float32) < 0.5).astype(np.float32)
+    off = np.zeros(n, np.float32)
+    rp = np.arange(n + 1, dtype=np.int64) * k
+    batch, _ = fe.shard_as_batch(rp, cols, vals, y, off, None, True)
+    packed = solver.pack(batch)
+    opts = SolverOptions(l2=1.0, regularize_bias=True, has_intercept=True, m=10, max_iter=iters, threshold=0.0, sum_loss=True)
+    out = None
+    for _ in range(2):   # the second fit is the measured one
+        prob = fe._SteppingProblem(solver, packed, D, opts, None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fe.run_stepping_loop(prob)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        _, info = prob.result()
+        rows_ms, cols_ms = prob.last_eval_ms()
+        prob.close()
+        nfev = int(info["nfev"])
+        Z, P, m = n * k, D + 1, 10
+        alg = 16.0 * Z + 32.0 * n + (4 + 2 * m) * 8.0 * P
+        ms = dt * 1e3 / nfev
+        out = {"ms_per_evaluation": ms, "rows_pass_ms": rows_ms, "cols_pass_ms": cols_ms, "evaluations": nfev, "alg_bytes_per_evaluation": alg,
+               "GBps": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "shard": f"{n} samples x {k} uniform columns of {D} features, logistic, m=10",
+               "what": "gdmix_fe_eval + gdmix_fe_step per L-BFGS evaluation; bytes = 16 B/nnz (value + index, both passes) + 32 B/sample "
+                       "+ (4 + 2m) x 8 B/coefficient"}
+    del packed
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -337,6 +381,9 @@ def main():
             score = {"ms": sms, "samples_per_s": batch.N / (sms * 1e-3), "alg_bytes": sbytes, "GBps": sbytes / (sms * 1e-3) / 1e9,
                      "frac_of_hbm_peak": sbytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "what": "gdmix_re_score: logits of every sample, 8 B/nnz + 16 B/sample + 8 B/coefficient + pointers"}
+        fe_eval = None
+        if not a.no_fe and world == 1:
+            fe_eval = fixed_effect_leg(solver, a.fe_rows)
         cpu = None
         if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             sample = a.cpu_sample if a.cpu_sample > 0 else min(batch.E, 200_000)
@@ -361,7 +408,7 @@ def main():
                        "classes": classes, "class_ms": [round(float(x) / a.steps, 3) for x in kernel_ms],
                        "mean_nit": nit, "mean_nfev": nfev,
                        "converged_per_step": converged_all, "parity_classes": {"W": well_posed, "D": int(batch.E - well_posed)}, "N": batch.N, "Z": batch.Z, "P": packed.P,
-                       "host_generate_s": t_gen, "host_handover": e2e, "score_pass": score,
+                       "host_generate_s": t_gen, "host_handover": e2e, "score_pass": score, "fixed_effect_eval": fe_eval,
                        "restreamed_bytes_per_step": b_stream,
                        "restreamed_GBps": b_stream / (float(kernel_ms.sum()) / a.steps * 1e-3) / 1e9 if kernel_ms.sum() else None},
         }

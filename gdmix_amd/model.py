@@ -32,6 +32,7 @@ TrainingResult = namedtuple("TrainingResult", ("theta", "variance", "unique_glob
 
 _ROW_BITS = 40
 _ROW_MASK = (1 << _ROW_BITS) - 1
+WRITE_BEHIND_THREADS = int(os.environ.get("GDMIX_WRITE_THREADS", "8"))   # files being written at a time behind the device work
 
 
 class ModelTable:
@@ -253,6 +254,7 @@ class RandomEffectLRLBFGSModel:
         self._solver = None
         self._read_cache = None     # (key, batch) of the partition _train decoded last
         self._io_pool = None        # begin_pipeline(): files are read ahead and written behind the device work
+        self._write_pool = None
         self._prefetched = {}       # read key -> Future[RawBatch]
         self._prefetched_models = {}   # model file -> Future[ModelTable]
         self._pending_writes = []
@@ -339,7 +341,10 @@ class RandomEffectLRLBFGSModel:
         waits for them (and raises what they raised). The native reader / writers release the GIL."""
         if self._io_pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            self._io_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="gdmix-io")
+            # readers and writers apart: a partition's two files take longer to write than the partition takes to solve, and a
+            # read queued behind them would stall the device
+            self._io_pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix="gdmix-read")
+            self._write_pool = ThreadPoolExecutor(max_workers=WRITE_BEHIND_THREADS, thread_name_prefix="gdmix-write")
 
     def _read_key(self, input_path, num_features):
         return (os.path.abspath(input_path), self.model_params.partition_entity, self.feature_bag_name, num_features)
@@ -370,7 +375,7 @@ class RandomEffectLRLBFGSModel:
         self._pending_writes = [(p, f) for p, f in self._pending_writes if not f.done()]
         for _, f in done:
             f.result()
-        self._pending_writes.append((os.path.abspath(path), self._io_pool.submit(fn, *args, **kwargs)))
+        self._pending_writes.append((os.path.abspath(path), self._write_pool.submit(fn, *args, **kwargs)))
 
     def flush(self, path=None):
         """Wait for the files still being written (only `path` if given); the first failure is raised here."""
@@ -389,7 +394,8 @@ class RandomEffectLRLBFGSModel:
             self._prefetched, self._prefetched_models = {}, {}
             if self._io_pool is not None:
                 self._io_pool.shutdown(wait=True)
-                self._io_pool = None
+                self._write_pool.shutdown(wait=True)
+                self._io_pool = self._write_pool = None
 
     def _read(self, input_path, tensor_metadata, schema_params, num_features, need_label):
         assert self.model_params.data_format == constants.TFRECORD
