@@ -194,8 +194,10 @@ static int slots_for(const gdmix_re_packed* b, const gdmix_re_opts* o, size_t* s
   return (int)slots;
 }
 
+static int64_t var_small_p(const gdmix_re_packed* b) { return b->max_p < VAR_FULL_MAX_P ? b->max_p : VAR_FULL_MAX_P; }
+
 static int var_slots_for(const gdmix_re_packed* b) {
-  size_t bytes = var_full_slot_doubles(b->max_p) * 8;
+  size_t bytes = var_full_slot_doubles(var_small_p(b)) * 8;
   size_t slots = ((size_t)2 << 30) / (bytes ? bytes : 1);
   if (slots > 2048) slots = 2048;
   if (slots < 4) slots = 4;
@@ -214,9 +216,13 @@ GDMIX_API size_t gdmix_re_solve_scratch_bytes(const gdmix_re_packed* batch, cons
     const size_t treg = (opts->sum_loss || opts->linear) ? 0 : (size_t)TEAM_MAX_TEAMS * treg_slot_doubles(tp, batch->max_n) * 8;
     if (treg > need) need = treg;
   }
-  if (opts->variance_mode == GDMIX_RE_VAR_FULL && batch->max_p <= VAR_FULL_MAX_P) {
-    size_t v = (size_t)var_slots_for(batch) * var_full_slot_doubles(batch->max_p) * 8;
+  if (opts->variance_mode == GDMIX_RE_VAR_FULL && batch->max_p <= VAR_FULL_BIG_MAX_P) {
+    size_t v = (size_t)var_slots_for(batch) * var_full_slot_doubles(var_small_p(batch)) * 8;
     if (v > need) need = v;
+    if (batch->max_p > VAR_FULL_MAX_P) {
+      v = var_full_big_doubles(batch->max_p, batch->max_n) * 8;
+      if (v > need) need = v;
+    }
   }
   return need;
 }
@@ -285,9 +291,9 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   // random_effect_lr_lbfgs_model.py:48-53): the whole theta is regularised (binary_logistic_regression.py:72-82)
   if (opts->variance_mode == GDMIX_RE_VAR_FULL) {
     if (!out->theta) { set_error("variance_mode FULL needs out->theta"); return GDMIX_RE_EINVAL; }
-    if (b->max_p > VAR_FULL_MAX_P) {
+    if (b->max_p > VAR_FULL_BIG_MAX_P) {
       set_error("variance_mode FULL densifies a p x p Hessian per entity; largest entity has p = %d > %lld", b->max_p,
-                (long long)VAR_FULL_MAX_P);
+                (long long)VAR_FULL_BIG_MAX_P);
       return GDMIX_RE_ERANGE;
     }
   }
@@ -453,7 +459,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     }
   }
   if (opts->variance_mode == GDMIX_RE_VAR_FULL) {
-    const size_t vslot = var_full_slot_doubles(b->max_p);
+    const size_t vslot = var_full_slot_doubles(var_small_p(b));
     int vslots = var_slots_for(b);
     size_t avail = ctx->impl.scratch ? ctx->impl.scratch_bytes : 0;
     void* base = ctx->impl.scratch;
@@ -463,7 +469,15 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
       set_error("variance_mode FULL needs >= %zu bytes of scratch (gdmix_re_set_scratch)", 4 * vslot * 8);
       return GDMIX_RE_ENOMEM;
     }
-    HIP_TRY(launch_variance_full(B, b->E, P, out->theta, out->variance, static_cast<double*>(base), vslot, vslots, b->max_p, s));
+    HIP_TRY(launch_variance_full(B, b->E, P, out->theta, out->variance, static_cast<double*>(base), vslot, vslots, var_small_p(b), s));
+    if (b->max_p > VAR_FULL_MAX_P) {   // the large entities one by one, the whole device on each
+      if (var_full_big_doubles(b->max_p, b->max_n) * 8 > avail) {
+        set_error("variance_mode FULL with p = %d needs >= %zu bytes of scratch (gdmix_re_set_scratch)", b->max_p,
+                  var_full_big_doubles(b->max_p, b->max_n) * 8);
+        return GDMIX_RE_ENOMEM;
+      }
+      HIP_TRY(launch_variance_full_big(&ctx->impl, B, b->E, P, out->theta, out->variance, static_cast<double*>(base), b->max_p, b->max_n, s));
+    }
   }
   return GDMIX_RE_OK;
 }

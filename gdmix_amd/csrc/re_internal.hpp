@@ -152,7 +152,12 @@ hipError_t launch_solve_treg(const BatchDev& B, const OutDev& O, const SolvePara
 inline size_t treg_slot_doubles(int64_t max_p, int64_t max_n) { return (size_t)2 * max_p + (size_t)256 * 64 + (size_t)max_n + 64; }
 hipError_t launch_variance_full(const BatchDev& B, int64_t E, const SolveParams& o, const double* theta, double* variance,
                                 double* scratch, size_t slot_doubles, int slots, int64_t max_p, hipStream_t s);
-constexpr int64_t VAR_FULL_MAX_P = 2048;   // FULL variance densifies p x p (as the reference does)
+constexpr int64_t VAR_FULL_MAX_P = 2048;   // FULL variance densifies p x p (as the reference does): one wavefront per entity up to here,
+constexpr int64_t VAR_FULL_BIG_MAX_P = 16384;   // one entity at a time on the whole device up to here (re_variance_big.hip)
+constexpr int VAR_BIG_BUILD_GROUPS = 128;  // workgroups building the Hessian of a large entity, a sample-length vector each
+size_t var_full_big_doubles(int64_t max_p, int64_t max_n);
+hipError_t launch_variance_full_big(gdmix_ctx_impl* ci, const BatchDev& B, int64_t E, const SolveParams& o, const double* theta,
+                                    double* variance, double* scratch, int64_t max_p, int64_t max_n, hipStream_t s);
 inline size_t var_full_slot_doubles(int64_t max_p) { return (size_t)2 * max_p * max_p + max_p + 8; }
 hipError_t launch_score(const BatchDev& B, int64_t E, int64_t N, int ic, const double* theta, const uint8_t* has_model,
                         float* logit, float* per_coord, hipStream_t s);

@@ -897,6 +897,7 @@ __global__ __launch_bounds__(256) void re_variance_full_kernel(BatchDev B, int64
     const int n = (int)(B.ent_row_ptr[e + 1] - r0);
     const int d = (int)(B.ent_feat_ptr[e + 1] - f0);
     const int p = d + ic;
+    if (p > VAR_FULL_MAX_P) continue;         // wave-uniform: re_variance_big.hip takes these
     const int64_t c0 = f0 + e * ic;
     double* H = slot;                         // p x p, row-major; becomes L (lower)
     double* M = H + (size_t)max_p * max_p;    // p x p, L^-1

@@ -39,7 +39,11 @@ typedef struct gdmix_fe_problem gdmix_fe_problem;
 /* shard: a packed batch with E == 1 (gdmix_re_pack; has_intercept of the pack must equal opts->has_intercept).
  * num_features: size of the global feature space D; coefficients are [D + has_intercept], intercept last.
  * opts: l2, regularize_bias, has_intercept, m (<= 10), max_iter, maxfun, maxls, ftol, pgtol, linear are used.
- * theta0: device pointer [D + has_intercept] or NULL (zeros). */
+ * theta0: device pointer [D + has_intercept] or NULL (zeros).
+ * The problem builds its own two copies of the non-zeros (8 B per non-zero each, 10 B when a unit of a pass spans more than 2^21
+ * elements; temporary: 40 B per non-zero) and keeps reading the shard's y / offset / weight / unique_global, which must outlive it.
+ * Synchronises the stream. Test hooks (environment): GDMIX_FE_CHUNK = entries per unit of a pass, GDMIX_FE_PACK=0 = the
+ * three-array form of the entries. */
 GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* shard, int64_t num_features,
                               const gdmix_re_opts* opts, const double* theta0, gdmix_fe_problem** out, void* stream);
 GDMIX_API void gdmix_fe_destroy(gdmix_fe_problem* p);
@@ -75,7 +79,7 @@ GDMIX_API int gdmix_fe_score(gdmix_re_ctx* ctx, int64_t n, const int64_t* row_nn
                              const float* offset, const double* theta, int64_t num_features, int has_intercept, float* score,
                              float* per_coord, void* stream);
 
-/* Optional timing of the last gdmix_fe_eval (HIP events on the launch stream): ms of the CSR pass, the CSC pass. */
+/* Optional timing of the last gdmix_fe_eval (HIP events on the launch stream): ms of the row pass (X theta), the column pass (X'r). */
 GDMIX_API int gdmix_fe_last_eval_ms(gdmix_fe_problem* p, float* rows_ms, float* cols_ms);
 
 #ifdef __cplusplus

@@ -233,6 +233,48 @@ def test_large_and_giant_entities_pack_and_solve(device_solver):
         assert np.array_equal(res["status"][wp], ref["status"][wp])
 
 
+def test_full_variance_of_entities_beyond_one_wavefront(device_solver):
+    """variance_mode FULL where an entity has more than 2048 coefficients (csrc/re_variance_big.hip: Hessian, tiled Cholesky and
+    inverse on the whole device, one entity at a time) next to small entities (one wavefront each): against the dense statement
+    of binary_logistic_regression.py:181-187 in numpy — toarray() sums repeated columns of a row, inv() of the full Hessian."""
+    from gdmix_amd.batch import concat
+    small = synthetic.make_ragged_batch(40, seed=5, D=300)
+    large = synthetic.make_batch(2, 1500, 8, 2600, seed=31, size_dist="const")
+    tail = synthetic.make_batch(3, 50, 6, 504, seed=32, size_dist="const")
+    b = concat([small, large, tail])
+    for regularize_bias in (False, True):
+        kw = dict(l2=0.7, regularize_bias=regularize_bias, has_intercept=True, m=10, max_iter=25, variance_mode=2)
+        packed = device_solver.pack(b)
+        assert packed.max_p > 2048
+        res = device_solver.solve(packed, SolverOptions(**kw)).to_host()
+        coef_ptr = packed.coef_ptr_host()
+        pk = oracle.pack(b.ent_row_ptr, b.row_nnz_ptr, b.col_global)
+        checked_large = 0
+        for e in range(b.E):
+            r0, r1 = b.ent_row_ptr[e], b.ent_row_ptr[e + 1]
+            f0 = pk["ent_feat_ptr"][e]
+            d = int(pk["ent_feat_ptr"][e + 1] - f0)
+            p = d + 1
+            if p <= 2048 and e % 7:
+                continue
+            uniq = pk["unique_global"][f0:f0 + d]
+            X = np.zeros((r1 - r0, p))
+            X[:, 0] = 1.0
+            for i in range(r0, r1):
+                k0, k1 = b.row_nnz_ptr[i], b.row_nnz_ptr[i + 1]
+                np.add.at(X[i - r0], 1 + np.searchsorted(uniq, b.col_global[k0:k1]), b.val[k0:k1].astype(np.float64))
+            th = res["theta"][coef_ptr[e]:coef_ptr[e + 1]]
+            rho = 1.0 / (1.0 + np.exp(-(X @ th + b.offset[r0:r1])))
+            w = b.weight[r0:r1] if b.weight is not None else 1.0
+            H = (X * (rho * (1 - rho) * w)[:, None]).T @ X + (0.7 + 1e-12) * np.eye(p)
+            if not regularize_bias:
+                H[0, 0] -= 0.7
+            want = np.diag(np.linalg.inv(H))
+            np.testing.assert_allclose(res["variance"][coef_ptr[e]:coef_ptr[e + 1]], want, rtol=1e-8)
+            checked_large += p > 2048
+        assert checked_large == 2
+
+
 def test_score_matches_reference_inference(device_solver):
     import os
     from helpers import GOLDEN
