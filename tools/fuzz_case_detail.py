@@ -34,12 +34,22 @@ kw = dict(l2=float(rng.choice([0.01, 0.1, 1.0, 10.0])), regularize_bias=bool(rng
           m=int(rng.choice([1, 3, 10])), max_iter=int(rng.choice([2, 15, 100])), ftol=float(rng.choice([1e-12, 1e-7])), variance_mode=int(rng.choice([0, 0, 1])))
 solver = REDeviceSolver(0)
 pk = oracle.pack(b.ent_row_ptr, b.row_nnz_ptr, b.col_global)
+if shape in ("c2", "ragged", "ml", "tiny") and np.diff(pk["ent_feat_ptr"]).max() < 300 and rng.random() < 0.3:   # as fuzz_parity.py draws
+    kw["variance_mode"] = 2
 packed = solver.pack(b, has_intercept=has_intercept)
 th0 = 0.1 * rng.standard_normal(int(packed.P)) if rng.random() < 0.3 else None
 print(shape, "E", b.E, kw, "warm", th0 is not None)
 ref = oracle.solve(pk, b.val, b.y, b.offset, b.weight, oracle.make_opts(**kw), theta0=th0)
 cp = packed.coef_ptr_host()
 ents = ents or list(range(min(b.E, 8)))
+# the oracle's own spread: the same solve from starts moved by 1e-15 .. 1e-13 (fuzz_parity.py)
+for j, mag in enumerate((1e-15, 1e-14, 1e-13)):
+    jig = mag * np.random.default_rng(j + 1).standard_normal(int(packed.P))
+    pert = oracle.solve(pk, b.val, b.y, b.offset, b.weight, oracle.make_opts(**kw), theta0=jig if th0 is None else th0 * (1.0 + jig))
+    sj = per_entity_rel_err(pert["theta"], ref["theta"], packed.coef_ptr_host())
+    for e in ents:
+        print(f"oracle start moved by {mag:g}: entity {e}: status {pert['status'][e]} nit {pert['nit'][e]} nfev {pert['nfev'][e]} f {pert['fval'][e]:.15g} "
+              f"|g| {pert['gnorm'][e]:.3e}  theta rel err {sj[e]:.3e}")
 for e in ents:
     print(f"entity {e}: n={b.ent_n()[e]} nnz={b.ent_nnz()[e]} p={cp[e + 1] - cp[e]}   oracle status {ref['status'][e]} nit {ref['nit'][e]} nfev {ref['nfev'][e]} "
           f"f {ref['fval'][e]:.15g} |g| {ref['gnorm'][e]:.3e}")
