@@ -79,6 +79,7 @@ struct FeDev {
   double *loss_part, *rsum_part;   // [nred]
   double* acc_part;         // [FE_DOT_BLOCKS][TEAM_K]
   double* fin_part;         // [FE_FIN_BLOCKS][2]
+  unsigned* fin_count;      // workgroups of fe_finish_kernel that have delivered their range sums
   CompactState* state;
   CompactPlan* plan;
   CompactMats* mats;
@@ -293,23 +294,28 @@ __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
   r = wave_sum(r);
   if (lane == 0) { red[0][wv] = a; red[1][wv] = r; }
   __syncthreads();
+  __shared__ int last;
   if (tid == 0) {
     double sa = red[0][0], sr = red[1][0];
 #pragma unroll
     for (int w = 1; w < FE_WAVES; ++w) { sa += red[0][w]; sr += red[1][w]; }
-    F.fin_part[2 * blockIdx.x] = sa;
-    F.fin_part[2 * blockIdx.x + 1] = sr;
+    st_x<true>(F.fin_part + 2 * blockIdx.x, sa);
+    st_x<true>(F.fin_part + 2 * blockIdx.x + 1, sr);
+    __threadfence();
+    last = atomicAdd(F.fin_count, 1u) == FE_FIN_BLOCKS - 1;
   }
-}
-
-// one wavefront: the FE_FIN_BLOCKS range sums -> data value and intercept gradient
-__global__ __launch_bounds__(WAVE) void fe_finish2_kernel(FeDev F) {
-  const int lane = threadIdx.x;
-  const double a = wave_sum(lane < FE_FIN_BLOCKS ? F.fin_part[2 * lane] : 0.0);
-  const double r = wave_sum(lane < FE_FIN_BLOCKS ? F.fin_part[2 * lane + 1] : 0.0);
-  if (lane == 0) {
-    if (F.ic) F.fg[F.D] = r;
-    F.fg[F.P] = a;
+  __syncthreads();
+  // the workgroup that finishes last adds the FE_FIN_BLOCKS range sums (in lane order, whichever workgroup it is) -> data value and
+  // intercept gradient (HESS: fg[D] = sum_i d_i, the intercept's entry; fg[P] unused)
+  if (last && tid < WAVE) {
+    __threadfence();
+    const double a = wave_sum(tid < FE_FIN_BLOCKS ? ld_x<true>(F.fin_part + 2 * tid) : 0.0);
+    const double r = wave_sum(tid < FE_FIN_BLOCKS ? ld_x<true>(F.fin_part + 2 * tid + 1) : 0.0);
+    if (tid == 0) {
+      if (F.ic) F.fg[F.D] = r;
+      F.fg[F.P] = a;
+      *F.fin_count = 0u;
+    }
   }
 }
 
@@ -325,6 +331,7 @@ __global__ __launch_bounds__(FE_THREADS) void fe_dots_kernel(FeDev F, SolveParam
     const bool reg = (j < F.D) || o.regularize_bias;   // the intercept is coefficient D
     const double xj = F.W.x[j];
     const double gj = F.fg[j] + (reg ? o.l2 * xj : 0.0);
+    F.fg[j] = 0.0;   // consumed: the next evaluation starts from a clear buffer (gdmix_fe_eval)
     F.W.g[j] = gj;
     const double dj = F.W.d[j], rj = F.W.r[j];
     if (reg) acc[0] += xj * xj;
@@ -376,7 +383,15 @@ __global__ __launch_bounds__(FE_THREADS) void fe_step_kernel(FeDev F, SolveParam
     const int v = tid & 31, g = tid >> 5;
     if (v < TEAM_K) {
       double s = 0.0;
-      for (int b = g; b < dot_blocks; b += 8) {
+      int b = g;
+      for (; b + 56 < dot_blocks; b += 64) {   // eight loads in flight
+        double t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = F.acc_part[(size_t)(b + 8 * q) * TEAM_K + v];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s = (v == TEAM_K - 1) ? fmax(s, t[q]) : s + t[q];
+      }
+      for (; b < dot_blocks; b += 8) {
         const double t = F.acc_part[(size_t)b * TEAM_K + v];
         s = (v == TEAM_K - 1) ? fmax(s, t) : s + t;
       }
@@ -569,6 +584,7 @@ struct gdmix_fe_problem {
   int32_t* status_dev;
   hipEvent_t ev[3];
   bool timed;
+  bool dirty;            // the reduce buffer holds a result no step has consumed (and cleared) yet
 };
 
 #define HIP_TRY(expr)                                                                   \
@@ -730,7 +746,9 @@ static void fe_free(gdmix_fe_problem* p) {
 
 template <bool HESS>
 static int fe_passes(gdmix_fe_problem* p, const FeDev& F, hipStream_t s, bool timed) {
-  HIP_TRY(hipMemsetAsync(F.fg, 0, ((size_t)F.P + 1) * 8, s));
+  // features absent from this shard must read 0 in the reduce buffer; fe_dots_kernel leaves it cleared behind a step
+  if (p->dirty) HIP_TRY(hipMemsetAsync(F.fg, 0, ((size_t)F.P + 1) * 8, s));
+  p->dirty = true;
   int gd = (F.d + 255) / 256;
   if (gd > 2048) gd = 2048;
   if (gd < 1) gd = 1;
@@ -745,7 +763,6 @@ static int fe_passes(gdmix_fe_problem* p, const FeDev& F, hipStream_t s, bool ti
   if (timed) HIP_TRY(hipEventRecord(p->ev[2], s));
   int gf = (F.d + FE_RED_OUT - 1) / FE_RED_OUT;
   hipLaunchKernelGGL(fe_finish_kernel, dim3(gf < FE_FIN_BLOCKS ? FE_FIN_BLOCKS : gf), dim3(FE_THREADS), 0, s, F);
-  hipLaunchKernelGGL(fe_finish2_kernel, dim3(1), dim3(WAVE), 0, s, F);   // HESS: fg[D] = sum_i d_i (the intercept's entry), fg[P] unused
   HIP_TRY(hipGetLastError());
   return GDMIX_RE_OK;
 }
@@ -771,6 +788,7 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   p->pool = nullptr;
   p->copies[0] = p->copies[1] = nullptr;
   p->timed = false;
+  p->dirty = false;      // the pool is zeroed at creation
   for (auto& e : p->ev) e = nullptr;
   FeDev& F = p->F;
   const int ic = opts->has_intercept ? 1 : 0;
@@ -795,7 +813,7 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   const size_t o_xl = take((size_t)(F.d + 1) * 8), o_rs = take((size_t)(F.n + 1) * 8), o_fg = take((P + 1) * 8);
   const size_t o_pr = take((size_t)F.rc.nunit * FE_B * 8), o_pc = take((size_t)F.cc.nunit * FE_B * 8);
   const size_t o_multi = take((multi.size() + 1) * 4), o_red = take((size_t)F.nred * 2 * 8 + 16);
-  const size_t o_acc = take((size_t)FE_DOT_BLOCKS * TEAM_K * 8), o_fin = take((size_t)FE_FIN_BLOCKS * 2 * 8);
+  const size_t o_acc = take((size_t)FE_DOT_BLOCKS * TEAM_K * 8), o_fin = take((size_t)FE_FIN_BLOCKS * 2 * 8 + 64);
   const size_t o_state = take(sizeof(CompactState)), o_plan = take(sizeof(CompactPlan)), o_mats = take(sizeof(CompactMats));
   const size_t o_vec = take(((size_t)5 * P + compact_hist_doubles((int64_t)P, opts->m)) * 8 + 16), o_status = take(64);
   hipError_t rc = hipMalloc(&p->pool, off);
@@ -814,6 +832,7 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   F.loss_part = reinterpret_cast<double*>(base + o_red); F.rsum_part = F.loss_part + F.nred;
   F.acc_part = reinterpret_cast<double*>(base + o_acc);
   F.fin_part = reinterpret_cast<double*>(base + o_fin);
+  F.fin_count = reinterpret_cast<unsigned*>(base + o_fin + (size_t)FE_FIN_BLOCKS * 2 * 8);
   F.state = reinterpret_cast<CompactState*>(base + o_state);
   F.plan = reinterpret_cast<CompactPlan*>(base + o_plan);
   F.mats = reinterpret_cast<CompactMats*>(base + o_mats);
@@ -864,6 +883,7 @@ GDMIX_API int gdmix_fe_step(gdmix_fe_problem* p, void* stream, int32_t* status) 
   int gp = (F.P + 255) / 256;
   int dot_blocks = gp < FE_DOT_BLOCKS ? gp : FE_DOT_BLOCKS;
   hipLaunchKernelGGL(fe_dots_kernel, dim3(dot_blocks), dim3(FE_THREADS), 0, s, F, p->o);
+  p->dirty = false;
   hipLaunchKernelGGL(fe_step_kernel, dim3(1), dim3(FE_THREADS), 0, s, F, p->o, dot_blocks, p->status_dev);
   if (gp > 1024) gp = 1024;
   hipLaunchKernelGGL(fe_update_kernel, dim3(gp), dim3(256), 0, s, F, p->o.m);
