@@ -2,6 +2,7 @@
 TFRecord partitions. Same rules and same errors as grouped_reader.read_grouped_partition (which stays as the
 statement of those rules in Python); tests/test_native_io.py compares the two array for array."""
 import ctypes as C
+from collections.abc import Sequence
 import os
 
 import numpy as np
@@ -10,10 +11,10 @@ from ..batch import RawBatch
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "libgdmix_io.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 EXPORTED_SYMBOLS = ("gdmix_io_abi_version", "gdmix_io_last_error", "gdmix_io_read_grouped", "gdmix_io_free",
                     "gdmix_io_crc32c", "gdmix_io_masked_crc32c", "gdmix_io_avro_write_models", "gdmix_io_avro_write_scores",
-                    "gdmix_io_write_grouped", "gdmix_io_read_examples", "gdmix_io_avro_read_models", "gdmix_io_free_models", "gdmix_io_map_coefficients")
+                    "gdmix_io_write_grouped", "gdmix_io_read_examples", "gdmix_io_avro_read_models", "gdmix_io_free_models", "gdmix_io_map_coefficients", "gdmix_io_ids_unique")
 
 
 class GdmixIoError(RuntimeError):
@@ -81,6 +82,7 @@ def load_library():
     lib.gdmix_io_free_models.argtypes = [C.POINTER(_Models)]
     lib.gdmix_io_map_coefficients.argtypes = [C.c_int64] + [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_int32]
     lib.gdmix_io_free_models.restype = None
+    lib.gdmix_io_ids_unique.argtypes = [C.c_char_p, C.c_void_p, C.c_int64]
     lib.gdmix_io_write_grouped.argtypes = [C.c_char_p, C.POINTER(_Batch), C.POINTER(_Schema), C.c_int32]
     lib.gdmix_io_crc32c.argtypes = [C.c_char_p, C.c_size_t]
     lib.gdmix_io_crc32c.restype = C.c_uint32
@@ -134,6 +136,49 @@ def _view(owner, ptr, count, dtype):
     return np.frombuffer(buf, dtype=dtype)
 
 
+class EntityIds(Sequence):
+    """The entity ids of a decoded partition: concatenated UTF-8 bytes + offsets as the native reader returns them. It
+    behaves like the list of str the Python reader returns, but only becomes one when somebody indexes or iterates it:
+    a cold training run hands the bytes straight to the model-file writer and a million ids never become a million
+    Python objects."""
+
+    def __init__(self, raw: bytes, ptr: np.ndarray):
+        self.raw = raw
+        self.ptr = np.ascontiguousarray(ptr, np.int64)
+        self._list = None
+        self._unique = None
+
+    def tolist(self):
+        if self._list is None:
+            self._list = _split_ids(self.raw, self.ptr, len(self))
+        return self._list
+
+    def __len__(self):
+        return int(self.ptr.size) - 1
+
+    def __getitem__(self, i):
+        return self.tolist()[i]
+
+    def __iter__(self):
+        return iter(self.tolist())
+
+    def __eq__(self, other):
+        if isinstance(other, EntityIds):
+            return self.raw == other.raw and np.array_equal(self.ptr, other.ptr)
+        return self.tolist() == (other.tolist() if hasattr(other, "tolist") else list(other))
+
+    def __repr__(self):
+        return f"EntityIds({len(self)} ids)"
+
+    def all_different(self) -> bool:
+        if self._unique is None:
+            rc = load_library().gdmix_io_ids_unique(self.raw, self.ptr.ctypes.data, len(self))
+            if rc < 0:
+                raise GdmixIoError("gdmix_io_ids_unique failed")
+            self._unique = bool(rc)
+        return self._unique
+
+
 def _split_ids(raw, ptr, E):
     """E strings from concatenated UTF-8 bytes + offsets, without a Python-level loop when possible."""
     if E == 0:
@@ -169,7 +214,7 @@ def read_grouped_files(files, entity_name, feature_bag, offset_column_name, uid_
     E, N, Z = int(b.E), int(b.N), int(b.Z)
     idp = _copy(b.ent_id_ptr, E + 1, np.int64)
     raw_ids = C.string_at(b.ent_id_bytes, int(idp[-1])) if E else b""
-    ids = _split_ids(raw_ids, idp, E)
+    ids = EntityIds(raw_ids, idp)
     if stats is not None:
         stats["bytes_read"] = int(b.bytes_read)
     v = lambda ptr, n, dt: _view(owner, ptr, n, dt)
@@ -192,6 +237,8 @@ def _ptr(a):
 def _ids_to_bytes(ids):
     """Concatenated UTF-8 bytes of the ids + [E+1] offsets. Joined, encoded and measured in one piece when no id contains
     the separator (a million Python-level encode calls otherwise)."""
+    if isinstance(ids, EntityIds):
+        return ids.raw, ids.ptr
     E = len(ids)
     ptr = np.zeros(E + 1, np.int64)
     if E == 0:

@@ -37,7 +37,7 @@ extern "C" {
 #define GDMIX_IO_ESCHEMA  (-4)   /* a record does not match the schema (missing column, length mismatch, ...) */
 #define GDMIX_IO_ENOMEM   (-5)
 
-#define GDMIX_IO_ABI_VERSION 3
+#define GDMIX_IO_ABI_VERSION 4
 
 typedef struct gdmix_io_schema {
   const char* entity;        /* context key of the entity id (int64 or bytes scalar)                       */
@@ -182,6 +182,11 @@ GDMIX_IO_API int gdmix_io_map_coefficients(int64_t E, const int64_t* cur_ptr, co
                                            const int64_t* prior_coef_ptr, const int64_t* prior_feat_ptr,
                                            const double* prior_theta, const int64_t* prior_idx, int32_t has_intercept,
                                            double* theta, int32_t threads);
+
+/* 1 when the E byte strings bytes[ptr[e] .. ptr[e+1]) are pairwise different, 0 when two are equal, < 0 on error. The model
+ * dict of random_effect_lr_lbfgs_model.py:155-162 keeps one entry per entity id; a partition whose ids are all different (the
+ * normal case) never has to become that dict on the host. */
+GDMIX_IO_API int gdmix_io_ids_unique(const char* bytes, const int64_t* ptr, int64_t E);
 
 /* CRC-32C (Castagnoli) and TFRecord's masked form ((crc >> 15 | crc << 17) + 0xa282ead8). */
 GDMIX_IO_API uint32_t gdmix_io_crc32c(const void* data, size_t len);
