@@ -15,6 +15,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -77,8 +78,12 @@ struct BufferCache {
 };
 BufferCache g_buffers;
 
-// Encode blocks [0, n_blocks) with `encode(first record, last record, payload)` on `threads` threads, a bounded number of
-// blocks in memory at a time, and append them to the file in order.
+// Encode blocks [0, n_blocks) with `encode(first record, last record, payload)` on `threads` threads and append them to the
+// file in order. The workers take block numbers from a counter and encode into a ring of buffers; the calling thread writes
+// a block as soon as it and all blocks before it are ready, so encoding and the write() of earlier blocks overlap and a
+// bounded number of blocks is in memory. (A first version worked in rounds: start the threads, encode threads x 4 blocks, join,
+// write them, again — a score file of 2 M records is 1 953 small blocks = 15 rounds of thread starts with everybody idle
+// during the writes.)
 template <class Enc>
 int write_blocks(const char* path, const uint8_t* header, int64_t header_len, const uint8_t* sync, int64_t total,
                  int32_t block_records, int32_t deflate_codec, int32_t threads, Enc&& encode) {
@@ -88,47 +93,99 @@ int write_blocks(const char* path, const uint8_t* header, int64_t header_len, co
   bool ok = fwrite(header, 1, (size_t)header_len, f) == (size_t)header_len;
   const int64_t n_blocks = (total + block_records - 1) / block_records;
   if (threads <= 0) threads = gdmix_io_detail::default_threads();
-  const int64_t round = (int64_t)threads * 4;
-  const int64_t in_round = round < n_blocks ? round : n_blocks;
-  std::vector<std::string> out((size_t)(in_round > 0 ? in_round : 0));
-  for (auto& o : out) o = g_buffers.take();
-  std::atomic<int> failed{0};
-  for (int64_t b0 = 0; b0 < n_blocks && ok; b0 += round) {
-    const int64_t nb = (b0 + round < n_blocks) ? round : n_blocks - b0;
-    std::atomic<int64_t> next{0};
-    auto work = [&]() {
-      std::string payload = g_buffers.take(), packed;
-      for (;;) {
-        const int64_t k = next.fetch_add(1);
-        if (k >= nb) break;
-        const int64_t blk = b0 + k;
-        const int64_t r0 = blk * block_records;
-        const int64_t r1 = (r0 + block_records < total) ? r0 + block_records : total;
-        payload.clear();
-        encode(r0, r1, payload);
-        const std::string* body = &payload;
-        if (deflate_codec) {
-          if (!raw_deflate(payload, packed)) { failed.store(1); break; }
-          body = &packed;
-        }
-        std::string& o = out[(size_t)k];
-        o.clear();
-        put_long(o, r1 - r0);
-        put_long(o, (int64_t)body->size());
-        o.append(*body);
-        o.append((const char*)sync, 16);
-      }
-      g_buffers.give(std::move(payload));
-    };
-    const int nt = (int64_t)threads < nb ? threads : (int)nb;
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
-    if (failed.load()) { ok = false; break; }
-    for (int64_t k = 0; k < nb && ok; ++k) ok = fwrite(out[(size_t)k].data(), 1, out[(size_t)k].size(), f) == out[(size_t)k].size();
+  // one block, encoded, framed and appended to `o`
+  auto emit = [&](int64_t blk, std::string& payload, std::string& packed, std::string& o) {
+    const int64_t r0 = blk * block_records;
+    const int64_t r1 = (r0 + block_records < total) ? r0 + block_records : total;
+    payload.clear();
+    encode(r0, r1, payload);
+    const std::string* body = &payload;
+    if (deflate_codec) {
+      if (!raw_deflate(payload, packed)) return false;
+      body = &packed;
+    }
+    put_long(o, r1 - r0);
+    put_long(o, (int64_t)body->size());
+    o.append(*body);
+    o.append((const char*)sync, 16);
+    return true;
+  };
+  // The unit of work and of hand-over is a group of consecutive blocks of about a megabyte (a score block is 20 KB: a lock and
+  // a wake-up per block cost four times what the block takes to encode). The first block is encoded here to learn the size.
+  std::string first = g_buffers.take();
+  {
+    std::string payload = g_buffers.take(), packed;
+    if (n_blocks > 0 && !emit(0, payload, packed, first)) ok = false;
+    g_buffers.give(std::move(payload));
   }
+  if (ok && n_blocks > 0) ok = fwrite(first.data(), 1, first.size(), f) == first.size();
+  int64_t group = first.size() > 0 ? (int64_t)((1 << 20) / first.size()) : 1;
+  if (group < 1) group = 1;
+  if (group > 256) group = 256;
+  g_buffers.give(std::move(first));
+  const int64_t n_groups = n_blocks > 1 ? (n_blocks - 1 + group - 1) / group : 0;   // blocks 1 .. n_blocks-1
+  if ((int64_t)threads > n_groups) threads = (int)n_groups;
+  const int64_t ring = (int64_t)threads * 4 < n_groups ? (int64_t)threads * 4 : (n_groups > 0 ? n_groups : 1);
+  std::vector<std::string> out((size_t)ring);
+  for (auto& o : out) o = g_buffers.take();
+  std::vector<int64_t> ready((size_t)ring, -1);   // group whose bytes the slot holds
+  std::mutex mu;
+  std::condition_variable cv_ready, cv_free;
+  int64_t written = 0;                            // groups [0, written) are in the file: slot g % ring is free for g < written + ring
+  std::atomic<int64_t> next{0};
+  std::atomic<int> failed{0};
+  bool stop = !ok;
+  auto work = [&]() {
+    std::string payload = g_buffers.take(), packed;
+    for (;;) {
+      const int64_t g = next.fetch_add(1);
+      if (g >= n_groups) break;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_free.wait(lk, [&] { return stop || g < written + ring; });
+        if (stop) break;
+      }
+      std::string& o = out[(size_t)(g % ring)];
+      o.clear();
+      const int64_t b0 = 1 + g * group, b1 = (b0 + group < n_blocks) ? b0 + group : n_blocks;
+      for (int64_t blk = b0; blk < b1; ++blk)
+        if (!emit(blk, payload, packed, o)) { failed.store(1); break; }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        ready[(size_t)(g % ring)] = g;
+      }
+      cv_ready.notify_one();
+    }
+    g_buffers.give(std::move(payload));
+  };
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads && ok; ++t) pool.emplace_back(work);
+  for (int64_t g = 0; g < n_groups && ok; ++g) {
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_ready.wait(lk, [&] { return ready[(size_t)(g % ring)] == g; });
+    }
+    const std::string& o = out[(size_t)(g % ring)];
+    if (!failed.load()) ok = fwrite(o.data(), 1, o.size(), f) == o.size();
+    bool wake;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      written = g + 1;
+      if (!ok || failed.load()) stop = true;
+      wake = stop || next.load() >= written + ring - 1;   // somebody may be waiting for this slot
+    }
+    if (wake) cv_free.notify_all();
+    if (!ok || failed.load()) break;
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    stop = stop || !ok || failed.load() != 0;
+    if (stop) written = n_groups;   // nobody waits for a slot any more
+  }
+  cv_free.notify_all();
+  for (auto& th : pool) th.join();
   for (auto& o : out) g_buffers.give(std::move(o));
+  if (failed.load()) ok = false;
   if (fclose(f) != 0) ok = false;
   if (!ok) return set_error(GDMIX_IO_EIO, "%s: write failed", path);
   return GDMIX_IO_OK;
