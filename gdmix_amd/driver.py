@@ -18,6 +18,9 @@ logger = logging.getLogger(__name__)
 logger.setLevel(logging.INFO)
 
 
+PREFETCH_PARTITIONS = 2   # decoded ahead of the one being solved (the reader pool of the model has two workers)
+
+
 def is_empty_directory(input_dir):
     if not os.path.isdir(input_dir):
         raise ValueError(f"Directory expected, but {input_dir} is not a directory")
@@ -119,11 +122,15 @@ class RandomEffectDriver:
                 self.model.idle_round()
                 continue
             partition_index = partition_index_list[k]
-            if pipelined and k + 1 < len(partition_index_list):   # decode the next partition while this one is solved
-                next_dir = self._anchor_directory(self.model.training_data_dir, partition_index_list[k + 1])
-                if not is_empty_directory(next_dir):   # a partition that will be skipped is not decoded (nor kept) at all
-                    self.model.prefetch(next_dir, self.model.metadata_file, schema_params)
-                    self.model.prefetch_prior_model(partition_index_list[k + 1])
+            if pipelined:   # decode the next partitions while this one is solved (prefetch() ignores what is already on its way)
+                for ahead in range(1, PREFETCH_PARTITIONS + 1):
+                    if k + ahead >= len(partition_index_list):
+                        break
+                    next_dir = self._anchor_directory(self.model.training_data_dir, partition_index_list[k + ahead])
+                    if not is_empty_directory(next_dir):   # a partition that will be skipped is not decoded (nor kept) at all
+                        self.model.prefetch(next_dir, self.model.metadata_file, schema_params)
+                        if ahead == 1:
+                            self.model.prefetch_prior_model(partition_index_list[k + 1])
             checkpoint_path = self._anchor_directory(self.model.checkpoint_path, partition_index)
             training_data_dir = self._anchor_directory(self.model.training_data_dir, partition_index)
             validation_data_dir = self._anchor_directory(self.model.validation_data_dir, partition_index) \
