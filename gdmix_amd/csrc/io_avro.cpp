@@ -727,6 +727,58 @@ GDMIX_IO_API int gdmix_io_avro_read_models(const char* path, int64_t data_offset
   return GDMIX_IO_OK;
 }
 
+namespace {
+inline uint64_t id_hash(const char* a, size_t len) {
+  uint64_t h = 1469598103934665603ull;   // 64-bit FNV-1a
+  for (size_t i = 0; i < len; ++i) { h ^= (uint8_t)a[i]; h *= 1099511628211ull; }
+  return h ^ (h >> 29);
+}
+}  // namespace
+
+GDMIX_IO_API int gdmix_io_match_ids(const char* a_bytes, const int64_t* a_ptr, int64_t Ea, const char* b_bytes, const int64_t* b_ptr,
+                                    int64_t Eb, int64_t* row_in_a, int32_t threads) {
+  if (Ea < 0 || Eb < 0 || (Ea > 0 && (!a_bytes || !a_ptr)) || (Eb > 0 && (!b_bytes || !b_ptr || !row_in_a)))
+    return set_error(GDMIX_IO_EINVAL, "bad argument");
+  size_t cap = 16;
+  while (cap < (size_t)Ea * 2) cap <<= 1;
+  std::vector<int64_t> slot(cap, -1);
+  for (int64_t i = 0; i < Ea; ++i) {
+    size_t k = (size_t)id_hash(a_bytes + a_ptr[i], (size_t)(a_ptr[i + 1] - a_ptr[i])) & (cap - 1);
+    while (slot[k] >= 0) k = (k + 1) & (cap - 1);
+    slot[k] = i;
+  }
+  if (threads <= 0) threads = gdmix_io_detail::default_threads();
+  const int64_t piece = 1 << 14;
+  const int64_t n_pieces = (Eb + piece - 1) / piece;
+  if ((int64_t)threads > n_pieces) threads = (int)(n_pieces > 0 ? n_pieces : 1);
+  std::atomic<int64_t> next{0};
+  auto work = [&]() {
+    for (;;) {
+      const int64_t q = next.fetch_add(1);
+      if (q >= n_pieces) return;
+      const int64_t j1 = (q + 1) * piece < Eb ? (q + 1) * piece : Eb;
+      for (int64_t j = q * piece; j < j1; ++j) {
+        const char* b = b_bytes + b_ptr[j];
+        const size_t len = (size_t)(b_ptr[j + 1] - b_ptr[j]);
+        size_t k = (size_t)id_hash(b, len) & (cap - 1);
+        int64_t hit = -1;
+        for (;;) {
+          const int64_t o = slot[k];
+          if (o < 0) break;
+          if ((size_t)(a_ptr[o + 1] - a_ptr[o]) == len && memcmp(a_bytes + a_ptr[o], b, len) == 0) { hit = o; break; }
+          k = (k + 1) & (cap - 1);
+        }
+        row_in_a[j] = hit;
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+  work();
+  for (auto& th : pool) th.join();
+  return GDMIX_IO_OK;
+}
+
 GDMIX_IO_API int gdmix_io_ids_unique(const char* bytes, const int64_t* ptr, int64_t E) {
   if (E < 0 || (E > 0 && (!bytes || !ptr))) return set_error(GDMIX_IO_EINVAL, "bad argument");
   if (E < 2) return 1;

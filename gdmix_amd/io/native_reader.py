@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libgdmix_io.so")
 ABI_VERSION = 4
 EXPORTED_SYMBOLS = ("gdmix_io_abi_version", "gdmix_io_last_error", "gdmix_io_read_grouped", "gdmix_io_free",
                     "gdmix_io_crc32c", "gdmix_io_masked_crc32c", "gdmix_io_avro_write_models", "gdmix_io_avro_write_scores",
-                    "gdmix_io_write_grouped", "gdmix_io_read_examples", "gdmix_io_avro_read_models", "gdmix_io_free_models", "gdmix_io_map_coefficients", "gdmix_io_ids_unique")
+                    "gdmix_io_write_grouped", "gdmix_io_read_examples", "gdmix_io_avro_read_models", "gdmix_io_free_models", "gdmix_io_map_coefficients", "gdmix_io_ids_unique", "gdmix_io_match_ids")
 
 
 class GdmixIoError(RuntimeError):
@@ -83,6 +83,7 @@ def load_library():
     lib.gdmix_io_map_coefficients.argtypes = [C.c_int64] + [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_int32]
     lib.gdmix_io_free_models.restype = None
     lib.gdmix_io_ids_unique.argtypes = [C.c_char_p, C.c_void_p, C.c_int64]
+    lib.gdmix_io_match_ids.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
     lib.gdmix_io_write_grouped.argtypes = [C.c_char_p, C.POINTER(_Batch), C.POINTER(_Schema), C.c_int32]
     lib.gdmix_io_crc32c.argtypes = [C.c_char_p, C.c_size_t]
     lib.gdmix_io_crc32c.restype = C.c_uint32
@@ -169,6 +170,31 @@ class EntityIds(Sequence):
 
     def __repr__(self):
         return f"EntityIds({len(self)} ids)"
+
+    def rows_in(self, table_ids: "EntityIds", threads=0) -> np.ndarray:
+        """For every id of self its position in table_ids (whose ids are all different), or -1."""
+        out = np.empty(len(self), np.int64)
+        rc = load_library().gdmix_io_match_ids(table_ids.raw, table_ids.ptr.ctypes.data, len(table_ids), self.raw, self.ptr.ctypes.data,
+                                               len(self), out.ctypes.data, int(threads))
+        if rc != 0:
+            raise GdmixIoError("gdmix_io_match_ids: " + load_library().gdmix_io_last_error().decode("utf-8", "replace"))
+        return out
+
+    def take(self, rows) -> "EntityIds":
+        """The ids at `rows`, in that order."""
+        from ..batch import _ranges
+        rows = np.asarray(rows, np.int64)
+        lens = self.ptr[rows + 1] - self.ptr[rows]
+        ptr = np.zeros(rows.size + 1, np.int64)
+        np.cumsum(lens, out=ptr[1:])
+        raw = np.frombuffer(self.raw, np.uint8)[_ranges(self.ptr[rows], lens)].tobytes() if rows.size else b""
+        out = EntityIds(raw, ptr)
+        out._unique = True if self._unique else None
+        return out
+
+    def extended(self, other: "EntityIds") -> "EntityIds":
+        """self followed by other."""
+        return EntityIds(self.raw + other.raw, np.concatenate([self.ptr, self.ptr[-1] + other.ptr[1:]]))
 
     def all_different(self) -> bool:
         if self._unique is None:
@@ -377,7 +403,7 @@ def read_models_avro(path, data_offset: int, sync: bytes, deflate: bool, prefix,
     id_ptr = _copy(m.id_ptr, E + 1, np.int64)
     raw = C.string_at(m.id_bytes, int(id_ptr[-1])) if E else b""
     v = lambda ptr, n, dt: _view(owner, ptr, n, dt)
-    return dict(ids=_split_ids(raw, id_ptr, E), coef_ptr=v(m.coef_ptr, E + 1, np.int64), mean=v(m.mean, Cn, np.float64),
+    return dict(ids=EntityIds(raw, id_ptr), coef_ptr=v(m.coef_ptr, E + 1, np.int64), mean=v(m.mean, Cn, np.float64),
                 variance=v(m.variance, Cn, np.float64) if m.any_variance else None,
                 feat_idx=v(m.feat_idx, Fn, np.int64), has_variance=_copy(m.has_variance, E, np.uint8))
 

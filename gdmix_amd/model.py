@@ -47,8 +47,10 @@ class ModelTable:
         # (a warm start, an inference run, a carry-over); a cold training run adds a partition's models and exports them, and its
         # ids — all different, checked natively on the bytes — never become dict entries (10 ms of interpreter time per 125 k).
         self._pending = []
+        self._plan_cache = None
 
     def _index(self):
+        self._plan_cache = None
         for c, ids in self._pending:
             base = c << _ROW_BITS
             if not self._where:
@@ -58,17 +60,49 @@ class ModelTable:
         self._pending = []
         return self._where
 
-    def _single_distinct(self):
-        """The ids of the only chunk when the table is that chunk, unindexed, and its ids are known to be all different."""
-        if len(self._pending) == 1 and not self._where and len(self._chunks) == 1:
-            ids = self._pending[0][1]
-            if hasattr(ids, "all_different") and ids.all_different():
-                return ids
-        return None
+    def _segments(self):
+        """[(chunk, ids)] when the table is still nothing but its chunks in order — not indexed, every chunk's ids native
+        (EntityIds) and all different —, else None. Such a table answers through native joins of the id bytes."""
+        if self._where or not self._pending or len(self._pending) != len(self._chunks):
+            return None
+        for k, (c, ids) in enumerate(self._pending):
+            if c != k or not hasattr(ids, "all_different") or not ids.all_different():
+                return None
+        return self._pending
+
+    def _plan(self):
+        """(ids, chunk-and-row per id) of the table in dict.update order without building the dict: a prior model and the
+        models trained on top of it (existing ids keep their place and take the new model, new ids are appended). One or two
+        chunks; None otherwise."""
+        if self._plan_cache is not None:
+            return self._plan_cache
+        seg = self._segments()
+        if seg is None or len(seg) > 2:
+            return None
+        ids0 = seg[0][1]
+        n0 = len(ids0)
+        cr = np.zeros((n0, 2), np.int64)
+        cr[:, 1] = np.arange(n0)
+        ids = ids0
+        if len(seg) == 2:
+            ids1 = seg[1][1]
+            at = ids1.rows_in(ids0)                  # row of the prior table, or -1
+            hit = np.flatnonzero(at >= 0)
+            cr[at[hit], 0] = 1
+            cr[at[hit], 1] = hit
+            new = np.flatnonzero(at < 0)
+            if new.size:
+                tail = np.ones((new.size, 2), np.int64)
+                tail[:, 1] = new
+                cr = np.concatenate([cr, tail])
+                ids = ids0.extended(ids1.take(new))
+                ids._unique = True
+        self._plan_cache = (ids, cr)
+        return self._plan_cache
 
     def __len__(self):
-        ids = self._single_distinct()
-        return len(ids) if ids is not None else len(self._index())
+        plan = self._plan()
+        return len(plan[0]) if plan is not None else len(self._index())
 
     def __bool__(self):
         return bool(self._where) or any(len(ids) for _, ids in self._pending)
@@ -82,6 +116,7 @@ class ModelTable:
                                  idx=np.asarray(idx, np.int64), coef_ptr=np.asarray(coef_ptr, np.int64),
                                  feat_ptr=np.asarray(feat_ptr, np.int64)))
         self._pending.append((c, ids))
+        self._plan_cache = None
 
     def get(self, k, default=None):
         w = self._index().get(k)
@@ -110,9 +145,10 @@ class ModelTable:
         if isinstance(other, ModelTable):
             base = len(self._chunks)
             self._chunks.extend(other._chunks)
-            if not self._where and not self._pending and not other._where:
-                # nothing to keep the place of: the other table's chunks as they are, still unindexed
-                self._pending = [(base + c, ids) for c, ids in other._pending]
+            self._plan_cache = None
+            if not other._where:
+                # the other table's chunks as they are, still unindexed: _index() / _plan() apply dict.update's rule when asked
+                self._pending += [(base + c, ids) for c, ids in other._pending]
                 return
             shift = base << _ROW_BITS
             self._index().update((k, w + shift) for k, w in other._index().items())
@@ -125,16 +161,20 @@ class ModelTable:
     def flatten(self):
         """Flat arrays over the entities in dict order: (ids, coef_beg, coef_cnt, var_beg, feat_beg, mean, variance,
         feat_idx); var_beg is -1 for an entity whose chunk carries no variance, variance None if no chunk does."""
-        ids = self._single_distinct()
-        if ids is not None:   # the chunk is the table: its arrays as they are
+        plan = self._plan()
+        if plan is not None and len(self._chunks) == 1:   # the chunk is the table: its arrays as they are
+            ids = plan[0]
             ch = self._chunks[0]
             cp, fp = ch["coef_ptr"], ch["feat_ptr"]
             var_beg = cp[:-1].copy() if ch["variance"] is not None else np.full(len(ids), -1, np.int64)
             return ids, cp[:-1].copy(), np.diff(cp), var_beg, fp[:-1].copy(), ch["theta"], ch["variance"], ch["idx"]
-        self._index()
-        ids = list(self._where.keys())
-        w = np.fromiter(self._where.values(), np.int64, count=len(ids))
-        cr = np.stack([w >> _ROW_BITS, w & _ROW_MASK], axis=1) if len(ids) else np.zeros((0, 2), np.int64)
+        if plan is not None:
+            ids, cr = plan
+        else:
+            self._index()
+            ids = list(self._where.keys())
+            w = np.fromiter(self._where.values(), np.int64, count=len(ids))
+            cr = np.stack([w >> _ROW_BITS, w & _ROW_MASK], axis=1) if len(ids) else np.zeros((0, 2), np.int64)
         cbase, fbase, vbase = [], [], []
         co = fo = vo = 0
         any_var = any(ch["variance"] is not None for ch in self._chunks)
@@ -197,6 +237,22 @@ class ModelTable:
 
     def lookup(self, ids):
         """Vectorised: for every id, (found mask, chunk index, row)."""
+        seg = self._segments() if hasattr(ids, "rows_in") else None
+        if seg is not None:   # native joins, the later chunk's model wins
+            row = np.full(len(ids), -1, np.int64)
+            chunk = np.zeros(len(ids), np.int64)
+            for c, seg_ids in reversed(seg):
+                open_ = np.flatnonzero(row < 0) if c != seg[-1][0] else None
+                at = ids.rows_in(seg_ids) if open_ is None else (ids.take(open_).rows_in(seg_ids) if open_.size else np.zeros(0, np.int64))
+                if open_ is None:
+                    row = at
+                    chunk[:] = c
+                else:
+                    got = at >= 0
+                    row[open_[got]] = at[got]
+                    chunk[open_[got]] = c
+            found = row >= 0
+            return found, np.where(found, chunk, 0), np.where(found, row, 0)
         found = np.zeros(len(ids), bool)
         chunk = np.zeros(len(ids), np.int64)
         row = np.zeros(len(ids), np.int64)

@@ -188,6 +188,12 @@ GDMIX_IO_API int gdmix_io_map_coefficients(int64_t E, const int64_t* cur_ptr, co
  * normal case) never has to become that dict on the host. */
 GDMIX_IO_API int gdmix_io_ids_unique(const char* bytes, const int64_t* ptr, int64_t E);
 
+/* row_in_a[j] = the i with a[i] == b[j] (byte strings a_bytes[a_ptr[i] .. a_ptr[i+1]) of a table whose ids are all different),
+ * or -1: the id lookups of a warm start / an inference run / a carry-over (random_effect_lr_lbfgs_model.py:141-162,
+ * job_consumers.py:262-288) for a whole partition at once. */
+GDMIX_IO_API int gdmix_io_match_ids(const char* a_bytes, const int64_t* a_ptr, int64_t Ea, const char* b_bytes, const int64_t* b_ptr,
+                                    int64_t Eb, int64_t* row_in_a, int32_t threads);
+
 /* CRC-32C (Castagnoli) and TFRecord's masked form ((crc >> 15 | crc << 17) + 0xa282ead8). */
 GDMIX_IO_API uint32_t gdmix_io_crc32c(const void* data, size_t len);
 GDMIX_IO_API uint32_t gdmix_io_masked_crc32c(const void* data, size_t len);
