@@ -175,31 +175,48 @@ class ModelTable:
             ids = list(self._where.keys())
             w = np.fromiter(self._where.values(), np.int64, count=len(ids))
             cr = np.stack([w >> _ROW_BITS, w & _ROW_MASK], axis=1) if len(ids) else np.zeros((0, 2), np.int64)
-        cbase, fbase, vbase = [], [], []
-        co = fo = vo = 0
-        any_var = any(ch["variance"] is not None for ch in self._chunks)
-        for ch in self._chunks:
-            cbase.append(co); fbase.append(fo)
-            vbase.append(vo if ch["variance"] is not None else -1)
-            co += len(ch["theta"]); fo += len(ch["idx"])
-            if ch["variance"] is not None:
-                vo += len(ch["variance"])
+        # Only what the table still points at goes into the flat arrays: a chunk none of whose models survived (a prior model
+        # every entity of which was trained again) contributes nothing; a chunk used whole is taken as it is; of a chunk used in
+        # part (the carried-over entities of a prior model) only those models are gathered.
+        from .batch import _ranges
         E = len(ids)
         coef_beg = np.zeros(E, np.int64); coef_cnt = np.zeros(E, np.int64)
         feat_beg = np.zeros(E, np.int64); var_beg = np.full(E, -1, np.int64)
+        means, idxs, variances = [], [], []
+        co = fo = vo = 0
         for c, ch in enumerate(self._chunks):
             sel = np.flatnonzero(cr[:, 0] == c) if E else np.zeros(0, np.int64)
             if sel.size == 0:
                 continue
             rows = cr[sel, 1]
-            coef_beg[sel] = cbase[c] + ch["coef_ptr"][rows]
-            coef_cnt[sel] = ch["coef_ptr"][rows + 1] - ch["coef_ptr"][rows]
-            feat_beg[sel] = fbase[c] + ch["feat_ptr"][rows]
+            cp, fp = ch["coef_ptr"], ch["feat_ptr"]
+            cnt = cp[rows + 1] - cp[rows]
+            fcnt = fp[rows + 1] - fp[rows]
+            whole = 2 * int(cnt.sum()) >= len(ch["theta"])
+            if whole:
+                cstart, fstart = cp[rows], fp[rows]
+                means.append(ch["theta"]); idxs.append(ch["idx"])
+                if ch["variance"] is not None:
+                    variances.append(ch["variance"])
+                n_c, n_f = len(ch["theta"]), len(ch["idx"])
+            else:
+                cstart = np.cumsum(cnt) - cnt
+                fstart = np.cumsum(fcnt) - fcnt
+                take_c = _ranges(cp[rows], cnt)
+                means.append(ch["theta"][take_c]); idxs.append(ch["idx"][_ranges(fp[rows], fcnt)])
+                if ch["variance"] is not None:
+                    variances.append(ch["variance"][take_c])
+                n_c, n_f = int(cnt.sum()), int(fcnt.sum())
+            coef_beg[sel] = co + cstart
+            coef_cnt[sel] = cnt
+            feat_beg[sel] = fo + fstart
             if ch["variance"] is not None:
-                var_beg[sel] = vbase[c] + ch["coef_ptr"][rows]
-        mean = np.concatenate([ch["theta"] for ch in self._chunks]) if self._chunks else np.zeros(0)
-        idx = np.concatenate([ch["idx"] for ch in self._chunks]) if self._chunks else np.zeros(0, np.int64)
-        variance = np.concatenate([ch["variance"] for ch in self._chunks if ch["variance"] is not None]) if any_var else None
+                var_beg[sel] = vo + cstart
+                vo += n_c
+            co += n_c; fo += n_f
+        cat = lambda parts, dt: parts[0] if len(parts) == 1 else (np.concatenate(parts) if parts else np.zeros(0, dt))
+        mean, idx = cat(means, np.float64), cat(idxs, np.int64)
+        variance = cat(variances, np.float64) if variances else None
         return ids, coef_beg, coef_cnt, var_beg, feat_beg, mean, variance, idx
 
     def rows_for(self, ids):
@@ -429,7 +446,7 @@ class RandomEffectLRLBFGSModel:
             from concurrent.futures import ThreadPoolExecutor
             # readers and writers apart: a partition's two files take longer to write than the partition takes to solve, and a
             # read queued behind them would stall the device
-            self._io_pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix="gdmix-read")
+            self._io_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="gdmix-read")   # two partitions ahead + their prior models
             self._write_pool = ThreadPoolExecutor(max_workers=WRITE_BEHIND_THREADS, thread_name_prefix="gdmix-write")
 
     def _read_key(self, input_path, num_features):
