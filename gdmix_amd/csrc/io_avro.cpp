@@ -9,6 +9,10 @@
 // Byte for byte what gdmix_amd/io/avro.py + model.py's Python encoders write (tests/test_native_io.py).
 #include "../../include/gdmix_io.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -22,7 +26,7 @@
 #include <vector>
 
 extern "C" const char* gdmix_io_last_error(void);
-namespace gdmix_io_detail { int set_error(int code, const char* fmt, ...); int default_threads(); }
+namespace gdmix_io_detail { int set_error(int code, const char* fmt, ...); int default_threads(); void* pool_alloc(size_t bytes); void pool_release(void* p); }
 using gdmix_io_detail::set_error;
 
 namespace {
@@ -607,7 +611,9 @@ extern "C" {
 
 GDMIX_IO_API void gdmix_io_free_models(gdmix_io_models* m) {
   if (!m) return;
-  free(m->id_ptr); free(m->id_bytes); free(m->coef_ptr); free(m->mean); free(m->variance); free(m->feat_idx); free(m->has_variance);
+  using gdmix_io_detail::pool_release;
+  pool_release(m->id_ptr); pool_release(m->id_bytes); pool_release(m->coef_ptr); pool_release(m->mean); pool_release(m->variance);
+  pool_release(m->feat_idx); pool_release(m->has_variance);
   free(m);
 }
 
@@ -618,25 +624,32 @@ GDMIX_IO_API int gdmix_io_avro_read_models(const char* path, int64_t data_offset
   if (!path || !sync || !out || data_offset < 0 || n_prefix < 0 || (n_prefix > 0 && (!prefix_ptr || !prefix_bytes)) || !icpt_enc)
     return set_error(GDMIX_IO_EINVAL, "bad argument");
   *out = nullptr;
-  FILE* f = fopen(path, "rb");
-  if (!f) return set_error(GDMIX_IO_EIO, "%s: cannot open", path);
-  std::string file;
+  // the file mapped, pages requested up front (a fresh buffer + fread was 155 MB of first-touch faults and a copy per model file)
+  struct Mapped {
+    const uint8_t* p = nullptr; size_t n = 0;
+    ~Mapped() { if (p && n) munmap((void*)p, n); }
+    const uint8_t* data() const { return p; }
+    size_t size() const { return n; }
+  } file;
   {
-    fseek(f, 0, SEEK_END);
-    const long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    if (sz < 0) { fclose(f); return set_error(GDMIX_IO_EIO, "%s: cannot size", path); }
-    file.resize((size_t)sz);
-    const bool ok = fread(&file[0], 1, (size_t)sz, f) == (size_t)sz;
-    fclose(f);
-    if (!ok) return set_error(GDMIX_IO_EIO, "%s: read failed", path);
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return set_error(GDMIX_IO_EIO, "%s: cannot open", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return set_error(GDMIX_IO_EIO, "%s: cannot size", path); }
+    if (st.st_size > 0) {
+      void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+      if (m == MAP_FAILED) { close(fd); return set_error(GDMIX_IO_EIO, "%s: cannot map", path); }
+      file.p = (const uint8_t*)m;
+      file.n = (size_t)st.st_size;
+    }
+    close(fd);
   }
   if ((size_t)data_offset > file.size()) return set_error(GDMIX_IO_EFORMAT, "%s: header is longer than the file", path);
   // container blocks: count, size, payload, sync
   struct Span { int64_t count; const uint8_t* p; size_t n; };
   std::vector<Span> spans;
   {
-    Cursor c{(const uint8_t*)file.data() + data_offset, (const uint8_t*)file.data() + file.size()};
+    Cursor c{file.data() + data_offset, file.data() + file.size()};
     while (c.p < c.end) {
       const int64_t count = c.get_long();
       const int64_t size = c.get_long();
@@ -688,40 +701,67 @@ GDMIX_IO_API int gdmix_io_avro_read_models(const char* path, int64_t data_offset
   }
   gdmix_io_models* m = (gdmix_io_models*)calloc(1, sizeof(gdmix_io_models));
   if (!m) return set_error(GDMIX_IO_ENOMEM, "out of memory");
+  using gdmix_io_detail::pool_alloc;
   m->E = E;
   m->C = Cn;
-  m->id_ptr = (int64_t*)malloc((size_t)(E + 1) * 8);
-  m->id_bytes = (char*)malloc((size_t)(idb ? idb : 1));
-  m->coef_ptr = (int64_t*)malloc((size_t)(E + 1) * 8);
-  m->mean = (double*)malloc((size_t)(Cn ? Cn : 1) * 8);
-  m->variance = (double*)malloc((size_t)(Cn ? Cn : 1) * 8);
   const int64_t Fn = Cn - (has_intercept ? E : 0);   // every record starts with exactly one intercept
   m->F = Fn;
-  m->feat_idx = (int64_t*)malloc((size_t)(Fn > 0 ? Fn : 1) * 8);
-  m->has_variance = (uint8_t*)malloc((size_t)(E ? E : 1));
+  // arrays from the pool the partition reader uses (pages that have been touched before), filled block by block in parallel
+  m->id_ptr = (int64_t*)pool_alloc((size_t)(E + 1) * 8);
+  m->id_bytes = (char*)pool_alloc((size_t)(idb ? idb : 1));
+  m->coef_ptr = (int64_t*)pool_alloc((size_t)(E + 1) * 8);
+  m->mean = (double*)pool_alloc((size_t)(Cn ? Cn : 1) * 8);
+  m->variance = (double*)pool_alloc((size_t)(Cn ? Cn : 1) * 8);
+  m->feat_idx = (int64_t*)pool_alloc((size_t)(Fn > 0 ? Fn : 1) * 8);
+  m->has_variance = (uint8_t*)pool_alloc((size_t)(E ? E : 1));
   if (!m->id_ptr || !m->id_bytes || !m->coef_ptr || !m->mean || !m->variance || !m->feat_idx || !m->has_variance) {
     gdmix_io_free_models(m);
     return set_error(GDMIX_IO_ENOMEM, "out of memory");
   }
-  int64_t e = 0, cpos = 0, ipos = 0, fpos = 0;
+  const size_t nb = blocks.size();
+  std::vector<int64_t> e0(nb + 1, 0), c0(nb + 1, 0), i0(nb + 1, 0), f0(nb + 1, 0);
+  for (size_t k = 0; k < nb; ++k) {
+    const ModelBlock& B = blocks[k];
+    int64_t feats = 0;
+    for (const int64_t g : B.idx) feats += g >= 0;
+    e0[k + 1] = e0[k] + (int64_t)B.coef_cnt.size();
+    c0[k + 1] = c0[k] + (int64_t)B.mean.size();
+    i0[k + 1] = i0[k] + (int64_t)B.ids.size();
+    f0[k + 1] = f0[k] + feats;
+    for (const uint8_t hv : B.has_var) if (hv) m->any_variance = 1;
+  }
   m->id_ptr[0] = 0;
   m->coef_ptr[0] = 0;
-  for (const ModelBlock& B : blocks) {
-    if (!B.ids.empty()) memcpy(m->id_bytes + ipos, B.ids.data(), B.ids.size());
-    if (!B.mean.empty()) {
-      memcpy(m->mean + cpos, B.mean.data(), B.mean.size() * 8);
-      memcpy(m->variance + cpos, B.var.data(), B.mean.size() * 8);
-      for (const int64_t g : B.idx)
-        if (g >= 0) m->feat_idx[fpos++] = g;
-    }
-    for (size_t r = 0; r < B.coef_cnt.size(); ++r, ++e) {
-      ipos += B.id_len[r];
-      cpos += B.coef_cnt[r];
-      m->id_ptr[e + 1] = ipos;
-      m->coef_ptr[e + 1] = cpos;
-      m->has_variance[e] = B.has_var[r];
-      if (B.has_var[r]) m->any_variance = 1;
-    }
+  {
+    std::atomic<size_t> nxt{0};
+    auto fill = [&]() {
+      for (;;) {
+        const size_t k = nxt.fetch_add(1);
+        if (k >= nb) return;
+        const ModelBlock& B = blocks[k];
+        if (!B.ids.empty()) memcpy(m->id_bytes + i0[k], B.ids.data(), B.ids.size());
+        if (!B.mean.empty()) {
+          memcpy(m->mean + c0[k], B.mean.data(), B.mean.size() * 8);
+          if (m->any_variance) memcpy(m->variance + c0[k], B.var.data(), B.mean.size() * 8);
+          int64_t fpos = f0[k];
+          for (const int64_t g : B.idx)
+            if (g >= 0) m->feat_idx[fpos++] = g;
+        }
+        int64_t e = e0[k], cpos = c0[k], ipos = i0[k];
+        for (size_t r = 0; r < B.coef_cnt.size(); ++r, ++e) {
+          ipos += B.id_len[r];
+          cpos += B.coef_cnt[r];
+          m->id_ptr[e + 1] = ipos;
+          m->coef_ptr[e + 1] = cpos;
+          m->has_variance[e] = B.has_var[r];
+        }
+      }
+    };
+    const int nt = (size_t)threads < nb ? threads : (int)(nb ? nb : 1);
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(fill);
+    fill();
+    for (auto& th : pool) th.join();
   }
   *out = m;
   return GDMIX_IO_OK;

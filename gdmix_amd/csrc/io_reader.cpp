@@ -724,6 +724,14 @@ void pool_free(void* p) {
   free(base);
 }
 
+}  // namespace
+namespace gdmix_io_detail {
+// the array pool for io_avro.cpp (model tables come and go like partitions do)
+void* pool_alloc(size_t bytes) { return pool_malloc(bytes); }
+void pool_release(void* p) { pool_free(p); }
+}  // namespace gdmix_io_detail
+namespace {
+
 template <class T>
 bool alloc(T*& p, int64_t count) {
   p = (T*)pool_malloc((size_t)(count > 0 ? count : 1) * sizeof(T));
