@@ -456,6 +456,8 @@ class REDeviceSolver:
         if theta0 is not None:
             if isinstance(theta0, np.ndarray):
                 theta0 = t.from_numpy(np.ascontiguousarray(theta0, np.float64)).to(self.device)
+            elif not theta0.is_cuda:   # a host tensor, page-locked if the caller wants the copy to be asynchronous
+                theta0 = theta0.to(self.device, non_blocking=theta0.is_pinned())
             if theta0.numel() != packed.P or theta0.dtype != t.float64:
                 raise GdmixReError("theta0 must be float64 with one entry per coefficient")
         tensors = out or self.alloc_result(packed, variance=c_opts.variance_mode != VAR_NONE)
