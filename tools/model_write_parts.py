@@ -39,6 +39,12 @@ with tempfile.TemporaryDirectory() as d:
                                             True, 1e-4, threads=th)
             dt = time.perf_counter() - t
             print(f"write_models_avro threads={th:3d} {1e3 * dt:7.1f} ms  {os.path.getsize(path) / dt / 1e9:5.2f} GB/s ({os.path.getsize(path) / 1e6:.0f} MB)")
+        for k in range(2):
+            t = time.perf_counter()
+            m = native_reader.read_models_avro(path, len(header), sync, False, prefix, icpt, True)
+            dt = time.perf_counter() - t
+            print(f"read_models_avro of that file                    {1e3 * dt:7.1f} ms  {E / dt / 1e6:5.2f} M entities/s")
+            del m
         data = open(path, "rb").read()
         for k in range(2):
             t = time.perf_counter()
