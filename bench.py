@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive hand-over measurement")
     ap.add_argument("--no-fe", action="store_true", help="skip the fixed-effect evaluation leg (detail.fixed_effect_eval)")
+    ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end leg through the CLI (detail.cli_end_to_end)")
+    ap.add_argument("--cli-entities", type=int, default=1_000_000, help="entities of the end-to-end leg (partitions of 125 k)")
     ap.add_argument("--fe-rows", type=int, default=4_000_000, help="samples of the fixed-effect leg's shard (x 32 non-zeros, 100k features)")
     ap.add_argument("--giant-nnz", type=int, default=-1, help="override the device-wide kernel threshold (exploration)")
     ap.add_argument("--team-nnz", type=int, default=-1, help="override the lowest team-tier threshold (exploration)")
@@ -204,6 +206,62 @@ def fixed_effect_leg(solver, rows, nnz_per_row=32, features=100_000, iters=20):
     del packed
     torch.cuda.empty_cache()
     return out
+
+
+def cli_end_to_end_leg(entities):
+    """SURVEY.md 8(f) N3 + rows a9-a11 next to the headline: the drop-in CLI on files. C2-shaped entities written as entity-grouped
+    TFRecord partitions of 125 k (the reference's input format), `gdmix_amd.gdmix --stage=random_effect --action=train` in this
+    process (device context and libraries already up: the steady state of a long job), model + score Avro out; then again as a
+    warm start from the model files just written. tools/e2e_bench.py is the same run with the time of every phase."""
+    import logging
+    import shutil
+    import tempfile
+    from gdmix_amd import gdmix as cli
+    from gdmix_amd import synthetic
+    from gdmix_amd.io.grouped_reader import write_grouped_partition
+    parts = max(1, entities // 125_000)
+    md = {"features": [{"name": "bag", "dtype": "float", "shape": [1024], "isSparse": True},
+                       {"name": "offset", "dtype": "float", "shape": [], "isSparse": False},
+                       {"name": "uid", "dtype": "long", "shape": [], "isSparse": False},
+                       {"name": "ent", "dtype": "string", "shape": [], "isSparse": False}],
+          "labels": [{"name": "response", "dtype": "int", "shape": [], "isSparse": False}]}
+    logging.getLogger("gdmix_amd").setLevel(logging.WARNING)
+    with tempfile.TemporaryDirectory() as d:
+        b = synthetic.make_batch(entities, 16, 4, 1024, seed=1)
+        per = (entities + parts - 1) // parts
+        for k in range(parts):
+            sub = b.select(np.arange(k * per, min(entities, (k + 1) * per)))
+            write_grouped_partition(os.path.join(d, "train", "active", f"partitionId={k}", "part-0.tfrecord"), sub, "ent", "bag",
+                                    weight_column_name=None)
+        with open(os.path.join(d, "meta.json"), "w") as f:
+            json.dump(md, f)
+        with open(os.path.join(d, "features.csv"), "w") as f:
+            f.write("".join(f"f{i},\n" for i in range(1024)))
+        with open(os.path.join(d, "plist.txt"), "w") as f:
+            f.write(",".join(str(k) for k in range(parts)))
+        size_in = sum(os.path.getsize(os.path.join(r, x)) for r, _, fs in os.walk(os.path.join(d, "train")) for x in fs)
+        argv = ["gdmix", "--stage=random_effect", "--model_type=logistic_regression", "--uid_column_name=uid",
+                "--label_column_name=response", "--prediction_score_column_name=predictionScore",
+                f"--partition_list_file={d}/plist.txt", f"--training_data_dir={d}/train", f"--metadata_file={d}/meta.json",
+                f"--output_model_dir={d}/models", "--feature_bag=bag", f"--feature_file={d}/features.csv",
+                "--partition_entity=ent", "--regularize_bias=False", "--l2_reg_weight=1.0", f"--training_score_dir={d}/ts",
+                "--action=train"]
+        os.environ.pop("TF_CONFIG", None)
+        times = []
+        for rep in range(3):   # cold, cold again (the measured one), warm start from the second run's models
+            if rep == 1:
+                shutil.rmtree(os.path.join(d, "models"))
+                shutil.rmtree(os.path.join(d, "ts"), ignore_errors=True)
+            t = time.perf_counter()
+            cli.run(argv)
+            times.append(time.perf_counter() - t)
+        size_out = sum(os.path.getsize(os.path.join(r, x)) for r, _, fs in os.walk(d) for x in fs if x.endswith(".avro"))
+    return {"entities": entities, "partitions": parts, "tfrecord_bytes_in": size_in, "avro_bytes_out": size_out,
+            "cold_s": times[1], "cold_entities_per_s": entities / times[1], "warm_start_s": times[2],
+            "warm_start_entities_per_s": entities / times[2],
+            "what": "python -m gdmix_amd.gdmix --stage=random_effect --action=train on entity-grouped TFRecord partitions: decode, "
+                    "upload, pack, solve, score the training data, model + score Avro files; in-process second run (cold = no prior "
+                    "model), then a warm start from its model files"}
 
 
 def main():
@@ -384,6 +442,9 @@ def main():
         fe_eval = None
         if not a.no_fe and world == 1:
             fe_eval = fixed_effect_leg(solver, a.fe_rows)
+        cli_e2e = None
+        if not a.no_cli and world == 1:
+            cli_e2e = cli_end_to_end_leg(a.cli_entities)
         cpu = None
         if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             sample = a.cpu_sample if a.cpu_sample > 0 else min(batch.E, 200_000)
@@ -408,7 +469,7 @@ def main():
                        "classes": classes, "class_ms": [round(float(x) / a.steps, 3) for x in kernel_ms],
                        "mean_nit": nit, "mean_nfev": nfev,
                        "converged_per_step": converged_all, "parity_classes": {"W": well_posed, "D": int(batch.E - well_posed)}, "N": batch.N, "Z": batch.Z, "P": packed.P,
-                       "host_generate_s": t_gen, "host_handover": e2e, "score_pass": score, "fixed_effect_eval": fe_eval,
+                       "host_generate_s": t_gen, "host_handover": e2e, "score_pass": score, "fixed_effect_eval": fe_eval, "cli_end_to_end": cli_e2e,
                        "restreamed_bytes_per_step": b_stream,
                        "restreamed_GBps": b_stream / (float(kernel_ms.sum()) / a.steps * 1e-3) / 1e9 if kernel_ms.sum() else None},
         }
