@@ -284,6 +284,35 @@ def test_native_score_writer_is_byte_identical(tmp_path, has_label, has_weight):
     assert list(avro.read_file(b)) == []
 
 
+@pytest.mark.parametrize("deflate", [False, True])
+def test_native_block_writer_pipeline_with_many_small_blocks(tmp_path, deflate):
+    """csrc/io_avro.cpp write_blocks: workers encode groups of blocks into a ring, the caller writes them in order. Thousands of
+    3-record blocks on 1, 2 and 7 threads (more groups than ring slots: the ring wraps), both codecs: the same bytes whatever the
+    thread count, and every record back through the generic codec."""
+    from types import SimpleNamespace
+    from gdmix_amd.io import avro
+    sp = SimpleNamespace(uid_column_name="uid", prediction_score_column_name="predictionScore", label_column_name="response",
+                         weight_column_name="weight", prediction_score_per_coordinate_column_name="predictionScorePerCoordinate")
+    schema = avro.inference_output_schema(sp, has_weight=True)
+    rng = np.random.default_rng(8)
+    n = 20_001
+    uid = rng.integers(-2 ** 62, 2 ** 62, n)
+    score, per = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    label, weight = (rng.random(n) < 0.5).astype(np.float32), rng.random(n).astype(np.float32)
+    header, sync = avro.container_header(schema, "deflate" if deflate else "null", bytes(range(16)))
+    files = []
+    for threads in (1, 2, 7):
+        path = str(tmp_path / f"t{threads}.avro")
+        native_reader.write_scores_avro(path, header, sync, uid, score, label, weight, per, block_records=3, deflate=deflate, threads=threads)
+        files.append(open(path, "rb").read())
+    assert files[0] == files[1] == files[2]
+    recs = list(avro.read_file(str(tmp_path / "t7.avro")))
+    assert len(recs) == n
+    assert [r["uid"] for r in recs] == uid.tolist()
+    np.testing.assert_array_equal(np.array([r["predictionScore"] for r in recs], np.float32), score)
+    np.testing.assert_array_equal(np.array([r["weight"] for r in recs], np.float32), weight)
+
+
 @pytest.mark.parametrize("int_ids", [False, True])
 @pytest.mark.parametrize("bag", ["bag", None])
 def test_native_tfrecord_writer_is_byte_identical_and_round_trips(tmp_path, int_ids, bag):
