@@ -11,6 +11,7 @@ read_grouped_partition -> gdmix_re_pack -> gdmix_re_solve / gdmix_re_score (gdmi
 import logging
 import os
 import struct
+import threading
 from collections import namedtuple
 
 import numpy as np
@@ -48,17 +49,21 @@ class ModelTable:
         # ids — all different, checked natively on the bytes — never become dict entries (10 ms of interpreter time per 125 k).
         self._pending = []
         self._plan_cache = None
+        # the table of a partition is exported by a writer thread while the main thread scores with it: the lazy steps below
+        # (building the dict, planning the merged order) happen under a lock whichever thread needs them first
+        self._lock = threading.RLock()
 
     def _index(self):
-        self._plan_cache = None
-        for c, ids in self._pending:
-            base = c << _ROW_BITS
-            if not self._where:
-                self._where = dict(zip(ids, range(base, base + len(ids))))
-            else:
-                self._where.update(zip(ids, range(base, base + len(ids))))   # an existing key keeps its position, only the value changes
-        self._pending = []
-        return self._where
+        with self._lock:
+            self._plan_cache = None
+            pending, self._pending = self._pending, []
+            for c, ids in pending:
+                base = c << _ROW_BITS
+                if not self._where:
+                    self._where = dict(zip(ids, range(base, base + len(ids))))
+                else:
+                    self._where.update(zip(ids, range(base, base + len(ids))))   # an existing key keeps its position, only the value changes
+            return self._where
 
     def _segments(self):
         """[(chunk, ids)] when the table is still nothing but its chunks in order — not indexed, every chunk's ids native
@@ -74,6 +79,10 @@ class ModelTable:
         """(ids, chunk-and-row per id) of the table in dict.update order without building the dict: a prior model and the
         models trained on top of it (existing ids keep their place and take the new model, new ids are appended). One or two
         chunks; None otherwise."""
+        with self._lock:
+            return self._plan_locked()
+
+    def _plan_locked(self):
         if self._plan_cache is not None:
             return self._plan_cache
         seg = self._segments()
@@ -254,8 +263,9 @@ class ModelTable:
 
     def lookup(self, ids):
         """Vectorised: for every id, (found mask, chunk index, row)."""
-        seg = self._segments() if hasattr(ids, "rows_in") else None
-        if seg is not None:   # native joins, the later chunk's model wins
+        with self._lock:
+            seg = list(self._segments() or []) if hasattr(ids, "rows_in") else None
+        if seg:   # native joins, the later chunk's model wins
             row = np.full(len(ids), -1, np.int64)
             chunk = np.zeros(len(ids), np.int64)
             for c, seg_ids in reversed(seg):
