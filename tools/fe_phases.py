@@ -1,5 +1,5 @@
 """Where a fixed-effect fit spends its wall time on the device side: upload, pack (CSR + CSC of one giant entity), gdmix_fe_create
-(row-tiled column copy), the L-BFGS loop.   PYTHONPATH=. python tools/fe_phases.py [rows] [nnz_per_row] [features]"""
+(the two passes' copies of the non-zeros), the L-BFGS loop.   PYTHONPATH=. python tools/fe_phases.py [rows] [nnz_per_row] [features]"""
 import sys
 import time
 
