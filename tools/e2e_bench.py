@@ -50,6 +50,9 @@ timed(M, "_solve_batch", "pack + solve + D2H")
 timed(M, "_save_model", "model Avro")
 timed(M, "_predict", "scoring pass total (read + score + score Avro)")
 timed(model_mod, "_write_scores", "score Avro")
+timed(model_mod, "_model_coefficients_for_batch", "  . prior coefficients into the batch's index space")
+timed(model_mod.ModelTable, "flatten", "  . model table -> flat arrays (in the model Avro time)")
+timed(model_mod.ModelTable, "lookup", "  . id lookups")
 
 from gdmix_amd import solver as solver_mod
 
