@@ -24,6 +24,7 @@ struct PackStats {      // device-side, read back once per pack
   int max_p, max_n, max_nnz, err;
   int n_big, n_mid;       // entities deferred to the device-wide sort / the larger-LDS wavefront pack kernel
   unsigned long long big_nnz;   // non-zeros of the n_big entities
+  int n_mid2, pad;        // entities deferred from the 512-key to the 1024-key kernel
 };
 
 __global__ void pack_entnnz_kernel(const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ row_nnz_ptr,
@@ -327,7 +328,7 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct PackLayout {
   size_t ent_nnz_ptr, ent_feat_ptr, row_ptr, csr_col, col_ptr, csc_row, csc_val, unique_global, order, cls_tmp,
-      d_cnt, class_count, block_sums, stats, sort_key, uniq_sparse, big_list, mid_list, total;
+      d_cnt, class_count, block_sums, stats, sort_key, uniq_sparse, big_list, mid_list, mid2_list, total;
 };
 
 static PackLayout pack_layout(int64_t E, int64_t N, int64_t Z) {
@@ -352,6 +353,7 @@ static PackLayout pack_layout(int64_t E, int64_t N, int64_t Z) {
   L.uniq_sparse = take((size_t)(Z + 1) * 4);
   L.big_list = take((size_t)(E + 1) * 4);
   L.mid_list = take((size_t)(E + 1) * 4);
+  L.mid2_list = take((size_t)(E + 1) * 4);
   L.total = off;
   return L;
 }
@@ -440,8 +442,17 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
                      raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
                      out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
   DBG_STAGE("pack_entity_kernel<256>");
+  // (a C5-shaped entity has 256 +- 50 non-zeros: half of them overflow the first tier; the 512-key tier runs four workgroups of
+  // four wavefronts per CU where the 1024-key one runs four of two, and sorts half as many keys)
+  int32_t* mid2_list = reinterpret_cast<int32_t*>(base + L.mid2_list);
+  hipLaunchKernelGGL((pack_entity_kernel<512, 4>), dim3(ctx->num_cus * 4), dim3(WAVE * 4), 0, s,
+                     (const int32_t*)mid_list, (const int*)&stats->n_mid, mid2_list, &stats->n_mid2, (unsigned long long*)nullptr,
+                     raw->ent_row_ptr,
+                     raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
+                     out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
+  DBG_STAGE("pack_entity_kernel<512>");
   hipLaunchKernelGGL((pack_entity_kernel<1024, 2>), dim3(ctx->num_cus * 4), dim3(WAVE * 2), 0, s,
-                     (const int32_t*)mid_list, (const int*)&stats->n_mid, big_list, &stats->n_big, &stats->big_nnz,
+                     (const int32_t*)mid2_list, (const int*)&stats->n_mid2, big_list, &stats->n_big, &stats->big_nnz,
                      raw->ent_row_ptr,
                      raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
                      out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
