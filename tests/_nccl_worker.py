@@ -1,6 +1,7 @@
 """Worker of the single-rank RCCL test (tests/test_rebalance.py, -m gpu): the RCCL branch of rebalance._Comm on HIP memory —
 all_gather and variable-size all_to_all of every dtype the exchange uses, then a whole Rebalancer.exchange / give_back
-round on the `nccl` backend. One rank: the payloads travel rank 0 -> rank 0 through RCCL on device tensors."""
+round on the `nccl` backend, and the fixed-effect loop with its all-reduce on RCCL. One rank: the payloads travel rank 0 ->
+rank 0 through RCCL on device tensors."""
 import os
 import sys
 
@@ -38,6 +39,26 @@ def main():
     cc, th, va, fc, fi, st = rb.give_back(coef_cnt, theta, None, feat_cnt, feat_idx, {"nit": np.arange(b.E)})
     assert np.array_equal(cc, coef_cnt) and np.array_equal(th, theta) and va is None and np.array_equal(fi, feat_idx)
     assert np.array_equal(st["nit"], np.arange(b.E))
+    # the fixed-effect loop with its all-reduce on RCCL: [gradient, value] summed in place in the problem's device buffer between
+    # gdmix_fe_eval and gdmix_fe_step (one rank: the sum is the identity, the coefficients are those of the plain loop, bitwise)
+    from gdmix_amd import fixed_effect as fe
+    from gdmix_amd.solver import REDeviceSolver, SolverOptions
+    n, k, D = 20_000, 6, 3_000
+    rp = np.arange(n + 1, dtype=np.int64) * k
+    cols = rng.integers(0, D, n * k)
+    vals = rng.standard_normal(n * k).astype(np.float32)
+    y = (rng.random(n) < 0.4).astype(np.float32)
+    solver = REDeviceSolver(0)
+    batch, _ = fe.shard_as_batch(rp, cols, vals, y, None, None, True)
+    opts = SolverOptions(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=25, threshold=0.0, sum_loss=True)
+    thetas = []
+    for reduce in (None, lambda t: dist.all_reduce(t)):
+        prob = fe._SteppingProblem(solver, solver.pack(batch, has_intercept=True), D, opts, None)
+        assert prob.reduce_tensor().is_cuda
+        fe.run_stepping_loop(prob, reduce)
+        thetas.append(prob.result()[0])
+        prob.close()
+    assert np.array_equal(thetas[0], thetas[1]) and np.abs(thetas[0]).max() > 0
     dist.barrier()
     dist.destroy_process_group()
     print("nccl single-rank exchange ok")
