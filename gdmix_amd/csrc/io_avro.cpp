@@ -856,7 +856,7 @@ extern "C" GDMIX_IO_API int gdmix_io_map_coefficients(int64_t E, const int64_t* 
                                                       const int64_t* src_row, const int64_t* prior_coef_ptr,
                                                       const int64_t* prior_feat_ptr, const double* prior_theta,
                                                       const int64_t* prior_idx, int32_t has_intercept, double* theta,
-                                                      int32_t threads) {
+                                                      int32_t zero_first, int32_t threads) {
   if (E < 0 || (E > 0 && (!cur_ptr || !src_row || !prior_coef_ptr || !prior_feat_ptr || !theta)))
     return set_error(GDMIX_IO_EINVAL, "bad argument");
   const int64_t ic = has_intercept ? 1 : 0;
@@ -871,6 +871,11 @@ extern "C" GDMIX_IO_API int gdmix_io_map_coefficients(int64_t E, const int64_t* 
       const int64_t c = next.fetch_add(1);
       if (c >= n_chunks) return;
       const int64_t e1 = std::min(E, (c + 1) * chunk);
+      if (zero_first) {   // this chunk's stretch of theta, by the thread that fills it next
+        double* z0 = theta + cur_ptr[c * chunk] + c * chunk * ic;
+        double* z1 = theta + cur_ptr[e1] + e1 * ic;
+        memset(z0, 0, (size_t)(z1 - z0) * sizeof(double));
+      }
       for (int64_t e = c * chunk; e < e1; ++e) {
         const int64_t r = src_row[e];
         if (r < 0) continue;

@@ -80,7 +80,7 @@ def load_library():
     lib.gdmix_io_avro_read_models.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int32, C.c_void_p, C.c_char_p, C.c_int64,
                                               C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.POINTER(_Models))]
     lib.gdmix_io_free_models.argtypes = [C.POINTER(_Models)]
-    lib.gdmix_io_map_coefficients.argtypes = [C.c_int64] + [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_int32]
+    lib.gdmix_io_map_coefficients.argtypes = [C.c_int64] + [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
     lib.gdmix_io_free_models.restype = None
     lib.gdmix_io_ids_unique.argtypes = [C.c_char_p, C.c_void_p, C.c_int64]
     lib.gdmix_io_match_ids.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
@@ -408,7 +408,8 @@ def read_models_avro(path, data_offset: int, sync: bytes, deflate: bool, prefix,
                 feat_idx=v(m.feat_idx, Fn, np.int64), has_variance=_copy(m.has_variance, E, np.uint8))
 
 
-def map_coefficients(theta, cur_ptr, cur_idx, src_row, prior_coef_ptr, prior_feat_ptr, prior_theta, prior_idx, has_intercept, threads=0):
+def map_coefficients(theta, cur_ptr, cur_idx, src_row, prior_coef_ptr, prior_feat_ptr, prior_theta, prior_idx, has_intercept, threads=0,
+                     zero_first=False):
     """theta (float64, zero where nothing is known, laid out [intercept,] features per entity) gets the coefficients of the
     models in rows src_row (>= 0) of one table chunk; see gdmix_io_map_coefficients."""
     lib = load_library()
@@ -417,6 +418,6 @@ def map_coefficients(theta, cur_ptr, cur_idx, src_row, prior_coef_ptr, prior_fea
     pth = np.ascontiguousarray(prior_theta, np.float64)
     assert theta.dtype == np.float64 and theta.flags.c_contiguous
     rc = lib.gdmix_io_map_coefficients(len(src_row), _ptr(cur_ptr), _ptr(cur_idx), _ptr(src_row), _ptr(pcp), _ptr(pfp), _ptr(pth),
-                                       _ptr(pidx), int(bool(has_intercept)), _ptr(theta), int(threads))
+                                       _ptr(pidx), int(bool(has_intercept)), _ptr(theta), int(bool(zero_first)), int(threads))
     if rc != 0:
         raise GdmixIoError("gdmix_io_map_coefficients: " + lib.gdmix_io_last_error().decode("utf-8", "replace"))

@@ -301,23 +301,28 @@ def _model_coefficients_for_batch(table, entity_ids, unique_global, ent_feat_ptr
     ic = 1 if has_intercept else 0
     d = np.diff(ent_feat_ptr)
     coef_ptr = ent_feat_ptr + np.arange(E + 1, dtype=np.int64) * ic
-    if out is not None:   # a caller-owned (page-locked) block of at least that size: cleared here, filled below
+    if native is None:
+        native = native_reader.available()
+    cleared = True
+    if out is not None:   # a caller-owned (page-locked) block of at least that size: cleared by the native mapping, in parallel
         theta = out[:int(coef_ptr[-1])]
-        theta[:] = 0.0
+        cleared = False
     else:
         theta = np.zeros(int(coef_ptr[-1]), np.float64)
     found, chunk, row = table.lookup(entity_ids)
     has_model = found.astype(np.uint8)
-    if not found.any():
-        return theta, has_model
-    if native is None:
-        native = native_reader.available()
+    if not found.any() or not native:
+        if not cleared:
+            theta[:] = 0.0
+        if not found.any():
+            return theta, has_model
     if native:
         for c in np.unique(chunk[found]):
             ch = table._chunks[int(c)]
             src_row = np.where(found & (chunk == c), row, -1)
             native_reader.map_coefficients(theta, ent_feat_ptr, unique_global, src_row, ch["coef_ptr"], ch["feat_ptr"], ch["theta"],
-                                           ch["idx"], has_intercept)
+                                           ch["idx"], has_intercept, zero_first=not cleared)
+            cleared = True
         return theta, has_model
     F = int(num_features) + 1
     ent_of_feat = np.repeat(np.arange(E, dtype=np.int64), d)

@@ -175,13 +175,14 @@ GDMIX_IO_API void gdmix_io_free_models(gdmix_io_models* models);
  * batch has features cur_idx[cur_ptr[e] .. cur_ptr[e+1]) (global indices) and, when src_row[e] >= 0, a model in row
  * src_row[e] of a table (coefficients prior_theta[prior_coef_ptr[r] ..), intercept first when has_intercept; global
  * feature indices prior_idx[prior_feat_ptr[r] ..)). Writes into theta (laid out [intercept,] features per entity, i.e.
- * entity e starts at cur_ptr[e] + e * has_intercept; the caller zero-fills it): the model's intercept and, for every
+ * entity e starts at cur_ptr[e] + e * has_intercept; zero-filled by the caller, or here when zero_first: in parallel, each
+ * stretch by the thread that writes into it next): the model's intercept and, for every
  * batch feature the model has, its coefficient (of equal indices in a model the first listed). Entities without a model
  * are left untouched. */
 GDMIX_IO_API int gdmix_io_map_coefficients(int64_t E, const int64_t* cur_ptr, const int64_t* cur_idx, const int64_t* src_row,
                                            const int64_t* prior_coef_ptr, const int64_t* prior_feat_ptr,
                                            const double* prior_theta, const int64_t* prior_idx, int32_t has_intercept,
-                                           double* theta, int32_t threads);
+                                           double* theta, int32_t zero_first, int32_t threads);
 
 /* 1 when the E byte strings bytes[ptr[e] .. ptr[e+1]) are pairwise different, 0 when two are equal, < 0 on error. The model
  * dict of random_effect_lr_lbfgs_model.py:155-162 keeps one entry per entity id; a partition whose ids are all different (the
