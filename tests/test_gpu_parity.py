@@ -192,6 +192,58 @@ def test_c2_shape_against_oracle_at_scale(device_solver):
     assert np.isin(res["status"], (0, 1, 2)).all()
 
 
+def test_c2_at_full_size_properties(device_solver):
+    """BASELINE.json's C2 at its full size (1 M entities, 16 M samples, 64 M non-zeros: the bench workload, SURVEY 8(d) generator),
+    where the oracle is too slow to compare everything: properties that do not depend on the size.
+    * every entity ends with one of fmin_l_bfgs_b's own outcomes, the returned gradient norm of a PGTOL stop is below pgtol;
+    * entities are independent: the same entities in another order (other neighbours in a wavefront, other positions in their size
+      class) give bit-identical coefficients, iteration counts and stops;
+    * a solve started from the answer stays there: zero iterations for every entity that had stopped on the gradient test, the
+      coefficients unchanged bit for bit;
+    * a sample of 3 000 entities against the oracle, iteration for iteration."""
+    E = 1_000_000
+    b = synthetic.make_survey_batch(E, 16, 4, 1024, seed=synthetic.C2_SEED)
+    kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
+    o = SolverOptions(**kw)
+    packed = device_solver.pack(b)
+    res = device_solver.solve(packed, o).to_host()
+    coef_ptr = packed.coef_ptr_host()
+    assert np.isin(res["status"], (0, 1, 2)).all() and (res["status"] == 0).mean() > 0.99
+    assert res["gnorm"][res["status"] == 0].max() <= 1e-5
+    assert 8.0 < res["nit"].mean() < 9.0 and 9.0 < res["nfev"].mean() < 10.0        # what SURVEY measured on the reference: 8.4 / 9.4
+    # another order
+    perm = np.random.default_rng(1).permutation(E)
+    bp = b.select(perm)
+    pp = device_solver.pack(bp)
+    rp = device_solver.solve(pp, o).to_host()
+    cp = pp.coef_ptr_host()
+    assert np.array_equal(np.diff(cp), np.diff(coef_ptr)[perm])
+    for k in ("nit", "nfev", "status", "fval"):
+        assert np.array_equal(rp[k], res[k][perm]), k
+    from gdmix_amd.batch import _ranges
+    take = _ranges(coef_ptr[perm], np.diff(coef_ptr)[perm])
+    assert np.array_equal(rp["theta"], res["theta"][take])
+    del pp, rp, bp
+    # started from the answer
+    again = device_solver.solve(packed, o, theta0=res["theta"]).to_host()
+    stopped = res["status"] == 0
+    assert (again["nit"][stopped] == 0).all() and (again["status"][stopped] == 0).all()
+    m = np.zeros(coef_ptr[-1], bool)
+    m[_ranges(coef_ptr[:-1][stopped], np.diff(coef_ptr)[stopped])] = True
+    assert np.array_equal(again["theta"][m], res["theta"][m])
+    # a sample against the oracle
+    sample = np.sort(np.random.default_rng(2).choice(E, 3000, replace=False))
+    sb = b.select(sample)
+    pk = oracle.pack(sb.ent_row_ptr, sb.row_nnz_ptr, sb.col_global)
+    ref = oracle.solve(pk, sb.val, sb.y, sb.offset, None, oracle.make_opts(**kw))
+    wp = well_posed_mask(sb, dict(l2=1.0, regularize_bias=False, has_intercept=True))
+    sub_theta = res["theta"][_ranges(coef_ptr[sample], np.diff(coef_ptr)[sample])]
+    sub_ptr = np.concatenate([[0], np.cumsum(np.diff(coef_ptr)[sample])])
+    err = per_entity_rel_err(sub_theta, ref["theta"], sub_ptr)
+    assert err[wp].max() <= REL_TOL_DEVICE
+    assert np.array_equal(res["nit"][sample][wp], ref["nit"][wp]) and np.array_equal(res["status"][sample][wp], ref["status"][wp])
+
+
 def test_large_and_giant_entities_pack_and_solve(device_solver):
     """Entities beyond the wavefront pack/solve paths: a Zipf tail with one ~50k-nnz entity (workgroup pack
     kernel, workgroup-per-entity solve out of global scratch), pack bit-exact vs the oracle, theta vs oracle."""
