@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from gdmix_amd import fixed_effect as fe
+from gdmix_amd.solver import SolverOptions
 from oracle import oracle
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -184,6 +185,45 @@ def test_passes_cut_into_units_are_deterministic_and_agree(device_solver, monkey
     d = rho * (1 - rho) * wt
     H = np.concatenate([np.bincount(cols, weights=vals.astype(np.float64) ** 2 * d[rows], minlength=D) + 1.5, [d.sum()]])
     np.testing.assert_allclose(info3["variances"], 1.0 / (H + 1e-12), rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_large_shard_properties(device_solver):
+    """2 M samples x 16 Zipf-distributed columns of 200 k features, where the oracle takes too long for a test: properties that
+    hold whatever the size. [gradient, value] of a shard is the sum of those of its two halves (what the all-reduce relies on) and
+    of any other split; evaluating twice gives the same bits; a fit run twice gives the same bits."""
+    rng = np.random.default_rng(21)
+    n, k, D = 2_000_000, 16, 200_000
+    cols = np.minimum((float(D + 1) ** rng.random((n, k))).astype(np.int64) - 1, D - 1).ravel()
+    vals = (rng.standard_normal(n * k) * 0.3).astype(np.float32)
+    y = (rng.random(n) < 0.35).astype(np.float32)
+    off = (0.2 * rng.standard_normal(n)).astype(np.float32)
+    wt = (0.5 + rng.random(n)).astype(np.float32)
+    th0 = 0.05 * rng.standard_normal(D + 1)
+    opts = SolverOptions(l2=2.0, regularize_bias=False, has_intercept=True, m=10, max_iter=8, threshold=0.0, sum_loss=True)
+    t0 = device_solver.torch.from_numpy(th0).to(device_solver.device)
+
+    def local_sums(rows):
+        r0, r1 = rows
+        rp = np.arange(r1 - r0 + 1, dtype=np.int64) * k
+        batch, _ = fe.shard_as_batch(rp, cols[r0 * k:r1 * k], vals[r0 * k:r1 * k], y[r0:r1], off[r0:r1], wt[r0:r1], True, dummy=False)
+        prob = fe._SteppingProblem(device_solver, device_solver.pack(batch, has_intercept=True), D, opts, t0)
+        prob.eval()
+        a = prob.reduce_tensor().cpu().numpy().copy()
+        prob.eval()
+        assert np.array_equal(prob.reduce_tensor().cpu().numpy(), a)
+        prob.close()
+        return a
+
+    whole = local_sums((0, n))
+    assert np.isfinite(whole).all() and np.abs(whole[:D]).max() > 0
+    for cut in (n // 2, 123_457):
+        parts = local_sums((0, cut)) + local_sums((cut, n))
+        np.testing.assert_allclose(parts, whole, rtol=1e-11, atol=1e-9 * np.abs(whole).max())
+    s = fe.FixedEffectDeviceSolver(solver=device_solver)
+    rp = np.arange(n + 1, dtype=np.int64) * k
+    fits = [s.fit_stepping(rp, cols, vals, y, D, offset=off, weight=wt, l2=2.0, regularize_bias=False, max_iter=8, theta0=th0) for _ in range(2)]
+    assert np.array_equal(fits[0][0], fits[1][0]) and fits[0][1] == fits[1][1] and fits[0][1]["nit"] == 8
 
 
 @pytest.mark.gpu
