@@ -53,22 +53,59 @@ def parse():
     ap.add_argument("--solve-only", action="store_true", help="time gdmix_re_solve alone (batch packed once)")
     ap.add_argument("--ranks-share-device", action="store_true",
                     help="test hook for a 1-GPU box: every rank uses cuda:0 and the collectives go over gloo (numbers are meaningless)")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c5mean", "zipf", "ml_user", "ml_movie"],
-                    help="c2 (default, the benchmarked configuration) or an exploration shape")
+    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS),
+                    help="c2 (default, the configuration BASELINE.json's metric is quoted on for one GPU) or another of BASELINE's "
+                         "configurations at its own entity sizes: " + "; ".join(f"{k} = {v}" for k, v in WORKLOADS.items()))
+    ap.add_argument("--c5-entities", type=int, default=4_000_000, help="entities of the c5share workload per GPU (C5's share is 12.5 M)")
     return ap.parse_args()
 
 
-def cpu_baseline(batch, opts_kw, sample, min_seconds=10.0):
-    """Time the fp64 CPU restatement (the oracle, kind 'port') on the first `sample` entities, repeated
-    until at least `min_seconds` of wall time, one oracle call per host core (ctypes releases the GIL)."""
+WORKLOADS = {
+    "c2": "C2, synthetic 1 M entities x avg 64 nnz (SURVEY 8(d) generator)",
+    "c5mean": "C5's mean shape without the tail (32 samples x 8 nnz, D = 65 536), stratified generator",
+    "zipf": "the same with Zipf sizes (round-1/2 exploration shape, tail not capped at 2^20 nnz)",
+    "ml_user": "MovieLens per-user entities at ML-100K sizes (C1 shape)",
+    "ml_movie": "MovieLens per-movie entities at ML-100K sizes (C1 shape)",
+    "ml20m_user": "C3: MovieLens-20M per-user entities (138 493 users, 16 M training rows, n up to 7.4 k, p <= 21)",
+    "ml20m_movie": "C3: MovieLens-20M per-movie entities (26 744 movies, 16 M training rows, head of 54 k samples, p <= 25)",
+    "c5share": "C5's per-GPU share: --c5-entities Zipf-sized entities (P(nnz >= x) ~ x^-1.2 on [8, 2^20], mean 256, D = 65 536), generated in HBM",
+}
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one process
+    per GPU, RCCL) and hand its exit code back. With --ranks-share-device (test hook for a 1-GPU box) the ranks share
+    cuda:0 and talk over gloo."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if not a.ranks_share_device and have < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} HIP device(s) visible (one process per GPU; "
+                         "--ranks-share-device runs the ranks on cuda:0 over gloo as a harness test)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def cpu_baseline(sub, opts_kw, min_seconds=10.0):
+    """Time the fp64 CPU restatement (the oracle, kind 'port') on the entities of `sub`, repeated until at least
+    `min_seconds` of wall time, one oracle call per host core (ctypes releases the GIL), entities dealt to the cores in
+    contiguous runs of about equal non-zero count."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
     cores = os.cpu_count() or 1
-    sub = batch.select(np.arange(min(sample, batch.E)))
     pk = oracle.pack(sub.ent_row_ptr, sub.row_nnz_ptr, sub.col_global)
     o = oracle.make_opts(**opts_kw)
     E = sub.E
-    bounds = np.linspace(0, E, cores + 1).astype(int)
+    work = np.concatenate([[0], np.cumsum(sub.ent_nnz() + 64)])
+    bounds = np.searchsorted(work, np.linspace(0, work[-1], cores + 1)).astype(int)
+    bounds[0], bounds[-1] = 0, E
 
     def run(i):
         r = oracle.solve(pk, sub.val, sub.y, sub.offset, sub.weight, o, e_begin=int(bounds[i]), e_end=int(bounds[i + 1]))
@@ -256,34 +293,110 @@ def cli_end_to_end_leg(entities):
             cli.run(argv)
             times.append(time.perf_counter() - t)
         size_out = sum(os.path.getsize(os.path.join(r, x)) for r, _, fs in os.walk(d) for x in fs if x.endswith(".avro"))
+        # the same run the way gdmix-workflow starts a stage (single_node/local_ops.py:42-54): a fresh `python -m ...` child per
+        # stage — interpreter start, imports, HIP context, library load and the run itself; files are in the page cache
+        import subprocess
+        sub = {}
+        for label, wipe in (("cold", True), ("warm_start", False)):
+            if wipe:
+                shutil.rmtree(os.path.join(d, "models"))
+                shutil.rmtree(os.path.join(d, "ts"), ignore_errors=True)
+            t = time.perf_counter()
+            rc = subprocess.call([sys.executable, "-m", "gdmix_amd.gdmix"] + argv[1:], cwd=ROOT,
+                                 env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")))
+            sub[label + "_s"] = time.perf_counter() - t
+            if rc != 0:
+                raise RuntimeError(f"python -m gdmix_amd.gdmix exited with {rc}")
+            sub[label + "_entities_per_s"] = entities / sub[label + "_s"]
+        t = time.perf_counter()
+        subprocess.check_call([sys.executable, "-c", "import gdmix_amd.gdmix"], cwd=ROOT)
+        sub["import_only_s"] = time.perf_counter() - t
+        sub["what"] = ("wall time of a real child process `python -m gdmix_amd.gdmix --stage=random_effect --action=train ...` on the same "
+                       "files (cold = no prior model; warm_start = from the cold run's model files); import_only_s = a child that only imports the CLI module")
     return {"entities": entities, "partitions": parts, "tfrecord_bytes_in": size_in, "avro_bytes_out": size_out,
             "cold_s": times[1], "cold_entities_per_s": entities / times[1], "warm_start_s": times[2],
             "warm_start_entities_per_s": entities / times[2],
             "what": "python -m gdmix_amd.gdmix --stage=random_effect --action=train on entity-grouped TFRecord partitions: decode, "
                     "upload, pack, solve, score the training data, model + score Avro files; in-process second run (cold = no prior "
-                    "model), then a warm start from its model files"}
+                    "model), then a warm start from its model files"}, sub
+
+
+class Workload:
+    """What a step runs on: a raw batch in HBM (`raw_dev`, the dict REDeviceSolver.pack takes) plus the per-entity host arrays
+    the accounting needs (samples, non-zeros, label sums) and a way to get some entities as a host RawBatch (CPU leg)."""
+
+    def __init__(self, name, raw_dev, n, z, ones, host=None, take=None, what=""):
+        self.name, self.raw_dev, self.n, self.z, self.ones, self.host, self._take, self.what = name, raw_dev, n, z, ones, host, take, what
+        self.E, self.N, self.Z = int(n.size), int(n.sum()), int(z.sum())
+
+    def host_sample(self, count):
+        ents = np.arange(min(int(count), self.E))
+        return self.host.select(ents) if self.host is not None else self._take(ents)
+
+
+def make_workload(a, rank, solver):
+    from gdmix_amd import synthetic
+    w = a.workload
+    if w == "c5share":
+        import torch
+        raw, n = synthetic.make_c5_share_device(solver.device, a.c5_entities, seed=synthetic.C5_SEED + rank)
+        ptr = raw["ent_row_ptr"]
+        cs = torch.cat([torch.zeros(1, dtype=torch.float64, device=ptr.device), torch.cumsum(raw["y"].double(), 0)])
+        ones = (cs[ptr[1:]] - cs[ptr[:-1]]).cpu().numpy()
+        return Workload(w, raw, n, n * (raw["Z"] // raw["N"]), ones, take=lambda ents: synthetic.device_entities_to_host(raw, n, ents),
+                        what=f"C5 per-GPU share: {a.c5_entities} entities/GPU, nnz Zipf-like P(nnz>=x)~x^-1.2 on [8, 2^20] rescaled to mean 256, "
+                             "k=8 distinct uniform columns of D=65536 (SURVEY 8(d) generator, on the device), per-entity L2 LR, L-BFGS m=10")
+    if w == "c2":
+        batch = synthetic.make_survey_batch(a.entities, a.mean_n, a.k, a.dim, seed=synthetic.C2_SEED + rank, entity_id_base=rank * a.entities)
+        what = (f"C2: synthetic {a.entities} entities/GPU x avg {a.mean_n * a.k} nnz (n~max(1,Poisson({a.mean_n})), k={a.k} distinct uniform "
+                f"columns of D={a.dim}, SURVEY 8(d) generator), per-entity L2 LR, L-BFGS m=10")
+    elif w == "c5mean":
+        batch = synthetic.make_batch(a.entities, 32, 8, 65536, seed=synthetic.C5_SEED + rank, with_uid=False)
+        what = f"exploration shape {w}, {a.entities} entities/GPU"
+    elif w == "zipf":
+        batch = synthetic.make_batch(a.entities, 32, 8, 65536, seed=synthetic.C5_SEED + rank, size_dist="zipf", with_uid=False)
+        what = f"exploration shape {w}, {a.entities} entities/GPU"
+    elif w in ("ml_user", "ml_movie"):
+        batch = synthetic.make_movielens_like(a.entities, "per_user" if w == "ml_user" else "per_movie", seed=100 + rank)
+        what = f"exploration shape {w}, {a.entities} entities/GPU"
+    else:
+        kind = "per_user" if w == "ml20m_user" else "per_movie"
+        batch = synthetic.make_movielens_20m(kind, seed=200 + rank)
+        what = (f"C3: MovieLens-20M-sized {kind} random effect, {batch.E} entities/GPU, {batch.N} training rows (count distributions of the public "
+                "dataset card, feature bags of scripts/download_process_movieLens_data.py; synthetic values), per-entity L2 LR, L-BFGS m=10")
+    ones = np.add.reduceat(batch.y.astype(np.float64), batch.ent_row_ptr[:-1]) if batch.N else np.zeros(batch.E)
+    return Workload(w, solver.upload(batch), batch.ent_n(), batch.ent_nnz(), ones, host=batch, what=what)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)      # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} was launched with WORLD_SIZE={world}: start one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...)")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback path)")
     if a.ranks_share_device:
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: HIP device {local_rank} is not visible ({torch.cuda.device_count()} devices)")
     torch.cuda.set_device(local_rank)
-    coll_dev = "cpu" if a.ranks_share_device else "cuda"    # where the two scalars of the collectives live
+    coll_dev = "cpu" if a.ranks_share_device else "cuda"    # where the few scalars of the collectives live
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if a.ranks_share_device else "nccl"
         if a.ranks_share_device:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from gdmix_amd import build, synthetic
+    from gdmix_amd import build
     if rank == 0:
         build.build_library()
     if world > 1:
@@ -292,19 +405,12 @@ def main():
 
     opts_kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
     opts = SolverOptions(**opts_kw)
-    t_gen = time.perf_counter()
-    if a.workload == "c2":
-        batch = synthetic.make_survey_batch(a.entities, a.mean_n, a.k, a.dim, seed=synthetic.C2_SEED + rank,
-                                            entity_id_base=rank * a.entities)
-    elif a.workload == "c5mean":
-        batch = synthetic.make_batch(a.entities, 32, 8, 65536, seed=synthetic.C5_SEED + rank, with_uid=False)
-    elif a.workload == "zipf":
-        batch = synthetic.make_batch(a.entities, 32, 8, 65536, seed=synthetic.C5_SEED + rank, size_dist="zipf", with_uid=False)
-    else:
-        batch = synthetic.make_movielens_like(a.entities, "per_user" if a.workload == "ml_user" else "per_movie", seed=100 + rank)
-    t_gen = time.perf_counter() - t_gen
     solver = REDeviceSolver(local_rank)
-    raw_dev = solver.upload(batch)
+    t_gen = time.perf_counter()
+    wl = make_workload(a, rank, solver)
+    t_gen = time.perf_counter() - t_gen
+    batch = wl.host
+    raw_dev = wl.raw_dev
     packed = solver.pack(raw_dev)
     out = solver.alloc_result(packed)
     solver.set_timing(True)
@@ -339,35 +445,36 @@ def main():
         pack_ms += ev_pack[0].elapsed_time(ev_pack[1])
         solve_ms += ev_pack[1].elapsed_time(ev_pack[2])
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0          # this rank's K steps
     if world > 1:
         dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0              # ... and until the slowest rank is done
+    status = res.status
+    converged = int(((status >= 0) & (status <= 2)).sum().item())
+    per_rank = None
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-
-    status = res.status
-    converged = int(((status >= 0) & (status <= 2)).sum().item())
-    if world > 1:
-        ct = torch.tensor([converged], dtype=torch.int64, device=coll_dev)
-        dist.all_reduce(ct)
-        converged_all = int(ct.item())
+        mine = torch.tensor([rank, local_rank, dt_own / a.steps * 1e3, converged, wl.E], dtype=torch.float64, device=coll_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": int(t[0]), "device": int(t[1]), "ms_per_step": float(t[2]), "converged_per_step": int(t[3]), "entities": int(t[4])}
+                    for t in (x.cpu() for x in allr)]
+        converged_all = sum(r["converged_per_step"] for r in per_rank)
     else:
         converged_all = converged
     value = converged_all * a.steps / dt
 
     if rank == 0:
         # ---- roofline of the dominant kernel = the size-class launch with the largest share of a step ----
-        n = batch.ent_n()
-        z = batch.ent_nnz()
+        n, z = wl.n, wl.z
         p = np.diff(packed.coef_ptr_host())
         b_e = 8.0 * z + 16.0 * n + 8.0 * p + 32.0                    # B(e), SURVEY.md §8(d)
         alg_bytes = float(b_e.sum())
         # parity classes of SURVEY.md §8(d): W = both labels present (a finite optimum exists with the unregularised intercept),
         # D = all labels equal (the solver runs until the gradient test passes; only invariants are comparable)
-        n1 = np.add.reduceat(batch.y.astype(np.float64), batch.ent_row_ptr[:-1]) if batch.N else np.zeros(batch.E)
-        well_posed = int(((n1 > 0) & (n1 < n)).sum())
+        well_posed = int(((wl.ones > 0) & (wl.ones < n)).sum())
         classes = solver.class_counts(packed)
         cls = packed._view(packed.c.cls_tmp, packed.E, torch.int32).cpu().numpy()
         cls_ms = kernel_ms / a.steps
@@ -378,10 +485,23 @@ def main():
         all_ms = float(cls_ms.sum())
         nfev = res.nfev.double().mean().item()
         nit = res.nit.double().mean().item()
+        nfev_e = res.nfev.cpu().numpy().astype(np.float64)
+        # the re-streamed figure of SURVEY.md §8(d), B_stream(e) = nfev (8 nnz + 16 n) + 8 p + 32: what a design that does not keep
+        # the entity resident moves — and for the classes whose entities do not fit on chip (team kernels) the algorithmic figure
+        b_s = nfev_e * (8.0 * z + 16.0 * n) + 8.0 * p + 32.0
+        b_stream = float(b_s.sum())
+        per_class = []
+        for c in np.flatnonzero(cls_ms > 0):
+            sel = cls == c
+            per_class.append({"kernel": classes[c][0], "entities": int(sel.sum()), "ms": round(float(cls_ms[c]), 3),
+                              "alg_GBps": round(float(b_e[sel].sum()) / (cls_ms[c] * 1e-3) / 1e9, 2),
+                              "restreamed_GBps": round(float(b_s[sel].sum()) / (cls_ms[c] * 1e-3) / 1e9, 2),
+                              "mean_n": round(float(n[sel].mean()), 1), "mean_p": round(float(p[sel].mean()), 1),
+                              "max_nnz": int(z[sel].max()), "mean_nfev": round(float(nfev_e[sel].mean()), 2)})
         traffic = traffic_detail = valu = None
         traffic_note = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        workload_id = f"{a.workload} E={a.entities} n~{a.mean_n} k={a.k} D={a.dim} survey-generator"
+        workload_id = f"{a.workload} E={wl.E} n~{a.mean_n} k={a.k} D={a.dim} survey-generator" if a.workload == "c2" else f"{a.workload} E={wl.E}"
         # PMC counters of the same kernel from separate rocprofv3 --pmc runs of this configuration (tools/profile_round.sh);
         # they are per launch of a size class and only valid for the workload they were collected on
         if not os.path.exists(tpath):
@@ -411,16 +531,15 @@ def main():
                     "valu": valu,
                     "kernel": classes[dom][0], "entities_in_launch": int(classes[dom][1]),
                     "avg_launch_ms": dom_ms, "alg_bytes_per_launch": dom_bytes,
-                    "alg_bytes_per_entity": alg_bytes / batch.E,
+                    "alg_bytes_per_entity": alg_bytes / wl.E,
+                    "restreamed_bytes_per_launch": float(b_s[cls == dom].sum()),
                     "all_solve_kernels": {"ms_per_step": all_ms, "alg_GBps": alg_bytes / (all_ms * 1e-3) / 1e9 if all_ms else 0.0},
                     "note": "LDS/register-resident L-BFGS: bound by fp64 VALU issue and latency, not by HBM "
                             "(SURVEY.md §8d honesty note); see DESIGN.md for the VALU-side accounting"}
-        # re-streamed figure (what a design that does not keep the entity resident would move), SURVEY.md §8(d)
-        nfev_e = res.nfev.cpu().numpy().astype(np.float64)
-        b_stream = float((nfev_e * (8.0 * z + 16.0 * n) + 8.0 * p + 32.0).sum())
+        c2_legs = a.workload == "c2" and world == 1
         # host hand-over (SURVEY.md §8(d) metric (ii)): packed host batch -> H2D -> solve -> D2H -> thresholded theta on the host
         e2e = None
-        if world == 1 and not a.no_e2e:
+        if c2_legs and not a.no_e2e:
             e2e = host_handover(batch, opts, local_rank, int(packed.P))
         # the scoring pass over the same resident batch (the path's HBM-bound stream; not part of `value`)
         score = None
@@ -435,41 +554,43 @@ def main():
             ev[1].record()
             torch.cuda.synchronize()
             sms = ev[0].elapsed_time(ev[1]) / 10
-            sbytes = 8.0 * batch.Z + 16.0 * batch.N + 4.0 * (batch.N + batch.E) + 8.0 * float(packed.P) + 24.0 * batch.E
-            score = {"ms": sms, "samples_per_s": batch.N / (sms * 1e-3), "alg_bytes": sbytes, "GBps": sbytes / (sms * 1e-3) / 1e9,
+            sbytes = 8.0 * wl.Z + 16.0 * wl.N + 4.0 * (wl.N + wl.E) + 8.0 * float(packed.P) + 24.0 * wl.E
+            score = {"ms": sms, "samples_per_s": wl.N / (sms * 1e-3), "alg_bytes": sbytes, "GBps": sbytes / (sms * 1e-3) / 1e9,
                      "frac_of_hbm_peak": sbytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "what": "gdmix_re_score: logits of every sample, 8 B/nnz + 16 B/sample + 8 B/coefficient + pointers"}
         fe_eval = None
-        if not a.no_fe and world == 1:
+        if c2_legs and not a.no_fe:
             fe_eval = fixed_effect_leg(solver, a.fe_rows)
-        cli_e2e = None
-        if not a.no_cli and world == 1:
-            cli_e2e = cli_end_to_end_leg(a.cli_entities)
+        cli_e2e = cli_sub = None
+        if c2_legs and not a.no_cli:
+            cli_e2e, cli_sub = cli_end_to_end_leg(a.cli_entities)
         cpu = None
         if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
-            sample = a.cpu_sample if a.cpu_sample > 0 else min(batch.E, 200_000)
-            v, cores, es, d, passes = cpu_baseline(batch, opts_kw, sample)
+            # a bounded sample: about 13 M non-zeros per pass (200 k entities of C2)
+            per_ent = max(1.0, wl.Z / wl.E)
+            sample = a.cpu_sample if a.cpu_sample > 0 else int(min(wl.E, max(64, 12.8e6 / per_ent)))
+            sub = wl.host_sample(sample)
+            v, cores, es, d, passes = cpu_baseline(sub, opts_kw)
             cpu = {"value": round(v, 1), "unit": "entities/s", "cores": cores, "kind": "port",
-                   "sample": f"first {es} entities of the same C2 batch x {passes} passes, oracle/re_oracle.c fp64 "
+                   "sample": f"first {es} entities of the same {a.workload} batch ({sub.Z} non-zeros) x {passes} passes, oracle/re_oracle.c fp64 "
                              f"(restatement pinned to the reference by tests/golden), {cores} threads, {d:.1f} s"}
         line = {
             "metric": "random-effect entities converged/sec", "value": round(value, 1), "unit": "entities/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": (f"C2: synthetic {a.entities} entities/GPU x avg {a.mean_n * a.k} nnz "
-                                    f"(n~max(1,Poisson({a.mean_n})), k={a.k} distinct uniform columns of D={a.dim}, SURVEY 8(d) generator), "
-                                    f"per-entity L2 LR, L-BFGS m=10")
-                       if a.workload == "c2" else f"exploration shape {a.workload}, {a.entities} entities/GPU",
-                       "entities_per_gpu": a.entities, "step": "solve" if a.solve_only else "pack+solve",
-                       "l2": 1.0, "regularize_bias": False, "max_iter": 100, "parallelism": f"entity-shard x{world}"},
+            "config": {"workload": wl.what, "workload_key": a.workload,
+                       "entities_per_gpu": wl.E, "step": "solve" if a.solve_only else "pack+solve",
+                       "l2": 1.0, "regularize_bias": False, "max_iter": 100, "parallelism": f"entity-shard x{world}",
+                       "collective_backend": backend, "ranks": per_rank},
             "roofline": roofline, "cpu_baseline": cpu,
             "detail": {"pack_ms_per_step": pack_ms / a.steps, "solve_ms_per_step": solve_ms / a.steps,
                        "solve_kernel_ms_per_step": float(kernel_ms.sum()) / a.steps,
-                       "classes": classes, "class_ms": [round(float(x) / a.steps, 3) for x in kernel_ms],
+                       "classes": classes, "class_ms": [round(float(x) / a.steps, 3) for x in kernel_ms], "per_class": per_class,
                        "mean_nit": nit, "mean_nfev": nfev,
-                       "converged_per_step": converged_all, "parity_classes": {"W": well_posed, "D": int(batch.E - well_posed)}, "N": batch.N, "Z": batch.Z, "P": packed.P,
+                       "converged_per_step": converged_all, "parity_classes": {"W": well_posed, "D": int(wl.E - well_posed)}, "N": wl.N, "Z": wl.Z, "P": packed.P,
                        "host_generate_s": t_gen, "host_handover": e2e, "score_pass": score, "fixed_effect_eval": fe_eval, "cli_end_to_end": cli_e2e,
+                       "cli_subprocess": cli_sub,
                        "restreamed_bytes_per_step": b_stream,
                        "restreamed_GBps": b_stream / (float(kernel_ms.sum()) / a.steps * 1e-3) / 1e9 if kernel_ms.sum() else None},
         }

@@ -1,15 +1,21 @@
 """Seeded synthetic entity-grouped data of the shapes BASELINE.json / SURVEY.md §8(d) name.
 
-Every entity gets n_e samples; every sample gets k distinct global columns (one per stratum of the
-global feature space, so they are distinct and ascending by construction), fp32 values ~ N(0,1), an
-fp32 offset ~ N(0,1) and a label y ~ Bernoulli(sigmoid(x . w* + b_e + offset)) with a hidden global
-w* ~ 0.5 N(0,1) and a hidden per-entity bias b_e ~ 0.5 N(0,1). Sample weights are 1 unless asked.
+* make_survey_batch — the generator SURVEY.md §8(d) states, to the letter (C2, and the C5 mean shape): k DISTINCT uniform
+  columns per sample in draw order, no hidden per-entity bias. This is what bench.py measures C2 on.
+* make_batch — the stratified generator the committed parity fixtures were produced with (one column per stratum of the
+  global feature space, so distinct and ascending by construction; a hidden per-entity bias b_e ~ 0.5 N(0,1)); also the
+  Zipf-sized exploration shape. Kept as it is so that tests/golden regenerates bit for bit.
+* make_ragged_batch — adversarially ragged entities (empty samples, repeated columns, weights).
+* make_movielens_like / make_movielens_20m — MovieLens-shaped entities at ML-100K and ML-20M entity sizes (C1 / C3).
+  There is no network in the build or GPU containers, so MovieLens itself cannot be downloaded; the feature bags are those
+  of the reference's preprocessing script (scripts/download_process_movieLens_data.py:306-346,384-387): per_user = the
+  rated movie's 1-6 genre flags (value 1.0) out of 19 + release_date/2000 (D = 20); per_movie = the rating user's
+  age/100 + gender one-hot + occupation one-hot (k = 3, D = 24).
+* make_c5_share_device — C5's per-GPU share (millions of Zipf-sized entities, up to 2^20 non-zeros each), generated in HBM
+  by torch's counter-based (Philox) generator because a host generator would take minutes at a billion non-zeros.
 
-There is no network in the build or GPU containers, so MovieLens itself cannot be downloaded; the
-"ml_*" shapes reproduce the per-user / per-movie feature bags of the reference's preprocessing script
-(scripts/download_process_movieLens_data.py:306-346,384-387): per_user = 1-6 genre flags (value 1.0)
-out of 19 + release_date/2000 (D = 20); per_movie = age/100 + gender one-hot + occupation one-hot
-(k = 3, D = 24).
+In all of them: fp32 values, an fp32 offset (the fixed-effect score) and a label y ~ Bernoulli(sigmoid(x . w* [+ b_e] +
+offset)) with a hidden global w*. Sample weights are 1 unless asked.
 """
 import numpy as np
 
@@ -163,6 +169,182 @@ def make_movielens_like(E, kind="per_user", seed=100, mean_n=None):
     return RawBatch(ent_row_ptr=np.concatenate([[0], np.cumsum(n)]), row_nnz_ptr=ptr, col_global=cols,
                     val=vals, y=y, offset=offset, weight=None, uid=np.arange(N, dtype=np.int64),
                     entity_ids=[str(i + 1) for i in range(E)])
+
+
+# MovieLens-20M as the public dataset card states it (BASELINE.json configs[2]): 138 493 users with at least 20 ratings each,
+# 26 744 rated movies, 20 000 263 ratings; the reference keeps a random 80 % of the rows for training
+# (scripts/download_process_movieLens_data.py:154-165,408).
+ML20M_USERS, ML20M_MOVIES, ML20M_RATINGS, ML20M_TRAIN = 138_493, 26_744, 20_000_263, 0.8
+ML20M_MAX_PER_USER, ML20M_MAX_PER_MOVIE = 9_254, 67_310
+
+
+def _ml20m_user_counts(rng, U):
+    """Ratings per user: 20 + a log-normal tail (median 68, mean 144, clipped at the most active user's 9 254)."""
+    extra = np.exp(rng.normal(np.log(48.0), 1.38, size=U))
+    n = np.minimum(20 + np.floor(extra), ML20M_MAX_PER_USER).astype(np.int64)
+    return n
+
+
+def _ml20m_movie_counts(M, total):
+    """Ratings per movie by popularity rank: log-count interpolated through anchor points of the public dataset's long tail
+    (67 k ratings for the most rated title, ~1 000 at rank 3 900, ~100 at rank 8 500, ~10 at rank 15 500, a single rating
+    for the last 4 000 titles), the body then scaled so that the counts add up to `total` rows."""
+    rank = np.array([0, 10, 100, 500, 1000, 3900, 8500, 15500, 19500, 22800, M - 1], np.float64) * (M - 1) / (ML20M_MOVIES - 1)
+    cnt = np.array([ML20M_MAX_PER_MOVIE, 50000, 30000, 12000, 7000, 1000, 100, 10, 3, 1.4, 1.0])
+    n = np.exp(np.interp(np.arange(M, dtype=np.float64), rank, np.log(cnt)))
+    body = np.arange(M) > 0
+    for _ in range(8):   # the head and the floor of one rating stay where they are
+        scaled = np.maximum(1.0, n * np.where(body, (total - n[0]) / n[body].sum(), 1.0))
+        n = np.minimum(scaled, ML20M_MAX_PER_MOVIE)
+    return np.maximum(1, np.round(n)).astype(np.int64)
+
+
+def _ragged_from_padded(table, count, pick):
+    """Rows `pick` of a padded [R, W] table, each cut to count[pick] entries, flattened in row order."""
+    sub = table[pick]
+    keep = np.arange(table.shape[1])[None, :] < count[pick][:, None]
+    return sub[keep]
+
+
+def make_movielens_20m(kind="per_user", seed=200, entities=None, with_uid=False):
+    """MovieLens-20M-sized random-effect entities (BASELINE.json configs[2], C3): the count distributions of the real dataset
+    (see the constants above) with the reference's feature bags. kind = per_user: one entity per user, a sample per rated
+    movie (k = 2..7, D = 20, up to ~7.4 k training rows per user); per_movie: one entity per movie, a sample per rating
+    user (k = 3, D = 24; the most rated title keeps ~54 k training rows, a third of the catalogue one or two): tall and
+    skinny, n >> p. `entities` keeps a random subset of that many entities (tests at reduced size); entity order is random,
+    as a hash partition's is."""
+    rng = np.random.default_rng(seed)
+    U, M = ML20M_USERS, ML20M_MOVIES
+    user_full = _ml20m_user_counts(rng, U)
+    movie_full = _ml20m_movie_counts(M, ML20M_RATINGS)
+    if kind == "per_user":
+        n = np.maximum(1, rng.binomial(user_full, ML20M_TRAIN)).astype(np.int64)
+        n = n[rng.permutation(U)]
+        if entities is not None:
+            n = n[:int(entities)]
+        E, N = n.size, int(n.sum())
+        # the movie catalogue: 1-6 genres (sorted indices 0..18) + release year
+        ng = rng.choice(np.arange(1, 7), size=M, p=[0.36, 0.33, 0.20, 0.08, 0.025, 0.005])
+        genre_pop = np.array([0.2, 3.5, 2.3, 1.0, 1.1, 8.4, 2.9, 2.5, 13.3, 1.4, 0.3, 2.6, 1.0, 1.5, 4.1, 1.7, 4.2, 1.2, 0.7])
+        keys = rng.gumbel(size=(M, 19)) + np.log(genre_pop)[None, :]          # Gumbel top-k = sampling without replacement
+        top = np.argsort(-keys, axis=1)[:, :6]
+        top[np.arange(6)[None, :] >= ng[:, None]] = 99
+        top = np.sort(top, axis=1)                                             # ascending genre index, padding last
+        table = np.full((M, 7), 19, np.int8)
+        table[:, :6] = np.where(top == 99, 19, top)
+        # the release-date column sits right after the movie's genres
+        ctab = np.full((M, 7), 19, np.int8)
+        vtab = np.zeros((M, 7), np.float32)
+        year = (rng.integers(1915, 2016, size=M) / 2000.0).astype(np.float32)
+        for j in range(6):
+            is_genre = j < ng
+            ctab[:, j] = np.where(is_genre, table[:, j], 19)
+            vtab[:, j] = np.where(is_genre, 1.0, year)
+        vtab[:, 6] = year
+        cnt = (ng + 1).astype(np.int64)
+        cdf = np.cumsum(movie_full / movie_full.sum())
+        pick = np.minimum(np.searchsorted(cdf, rng.random(N)), M - 1)          # a popular movie is rated by many users
+        cols = _ragged_from_padded(ctab, cnt, pick).astype(np.int64)
+        vals = _ragged_from_padded(vtab, cnt, pick)
+        k = cnt[pick]
+        D = 20
+    elif kind == "per_movie":
+        n = np.maximum(1, rng.binomial(movie_full, ML20M_TRAIN)).astype(np.int64)
+        n = n[rng.permutation(M)]
+        if entities is not None:
+            n = n[:int(entities)]
+        E, N = n.size, int(n.sum())
+        age = (rng.integers(7, 74, size=U) / 100.0).astype(np.float32)
+        gender = (1 + (rng.random(U) < 0.29)).astype(np.int64)
+        occupation = 3 + rng.integers(0, 21, size=U)
+        cdf = np.cumsum(user_full / user_full.sum())
+        pick = np.minimum(np.searchsorted(cdf, rng.random(N)), U - 1)          # an active user rates many movies
+        cols = np.stack([np.zeros(N, np.int64), gender[pick], occupation[pick]], axis=1).reshape(-1)
+        vals = np.stack([age[pick], np.ones(N, np.float32), np.ones(N, np.float32)], axis=1).reshape(-1)
+        k = np.full(N, 3, np.int64)
+        D = 24
+    else:
+        raise ValueError(kind)
+    ptr = np.concatenate([[0], np.cumsum(k)])
+    offset = (0.8 * rng.standard_normal(N)).astype(np.float32)
+    w_star = 0.6 * rng.standard_normal(D)
+    b_e = 0.7 * rng.standard_normal(E)
+    row_of = np.repeat(np.arange(N), k)
+    logit = np.bincount(row_of, weights=vals.astype(np.float64) * w_star[cols], minlength=N)
+    logit = logit + np.repeat(b_e, n) + offset
+    y = (rng.random(N) < 1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
+    return RawBatch(ent_row_ptr=np.concatenate([[0], np.cumsum(n)]), row_nnz_ptr=ptr, col_global=cols, val=vals, y=y, offset=offset,
+                    weight=None, uid=np.arange(N, dtype=np.int64) if with_uid else None, entity_ids=[str(i + 1) for i in range(E)],
+                    trusted=True)
+
+
+def c5_entity_samples(rng, E, mean_nnz=256, k=8, max_nnz=1 << 20):
+    """Samples per entity of SURVEY.md §8(d)'s C5: nnz_e Zipf-like with P(nnz >= x) ~ x^-1.2, truncated to [k, max_nnz] and
+    rescaled to the requested mean; n_e = nnz_e / k."""
+    raw = (1.0 - rng.random(E)) ** (-1.0 / 1.2)
+    cap, want = max_nnz // k, mean_nnz / k
+    c = want / raw.mean()
+    for _ in range(30):    # the cap removes mass from the tail: solve for the scale that restores the mean
+        n = np.clip(np.floor(raw * c), 1, cap)
+        c *= want / n.mean()
+    return np.clip(np.floor(raw * c), 1, cap).astype(np.int64)
+
+
+def make_c5_share_device(device, E, seed=C5_SEED, mean_nnz=256, k=8, D=65536, max_nnz=1 << 20, chunk_rows=1 << 24):
+    """C5's per-GPU share (BASELINE.json configs[4]) generated in HBM: entity sizes on the host (numpy, seeded),
+    everything per sample on the device with torch's Philox generator — k distinct uniform columns of D per sample, values ~
+    N(0,1) fp32, offset ~ N(0,1) fp32, y ~ Bernoulli(sigmoid(x . w* + offset)), weight 1. Returns (raw, n) with raw the dict
+    of device tensors REDeviceSolver.pack takes and n the host array of samples per entity. Uses torch for plumbing only
+    (random numbers and element-wise arithmetic of the *input*); nothing of the solve."""
+    import torch
+    rng = np.random.default_rng(seed)
+    n = c5_entity_samples(rng, E, mean_nnz, k, max_nnz)
+    N = int(n.sum())
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    w_star = 0.5 * torch.randn(D, generator=g, device=dev, dtype=torch.float64)
+    cols = torch.empty((N, k), dtype=torch.int64, device=dev)
+    vals = torch.empty((N, k), dtype=torch.float32, device=dev)
+    offset = torch.empty(N, dtype=torch.float32, device=dev)
+    y = torch.empty(N, dtype=torch.float32, device=dev)
+    for r0 in range(0, N, chunk_rows):
+        r1 = min(N, r0 + chunk_rows)
+        c = torch.randint(0, D, (r1 - r0, k), generator=g, device=dev, dtype=torch.int64)
+        while True:    # re-draw the samples that drew a column twice
+            s, _ = torch.sort(c, dim=1)
+            bad = torch.nonzero((s[:, 1:] == s[:, :-1]).any(dim=1)).reshape(-1)
+            if bad.numel() == 0:
+                break
+            c[bad] = torch.randint(0, D, (bad.numel(), k), generator=g, device=dev, dtype=torch.int64)
+        v = torch.randn((r1 - r0, k), generator=g, device=dev, dtype=torch.float32)
+        o = torch.randn(r1 - r0, generator=g, device=dev, dtype=torch.float32)
+        logit = (v.double() * w_star[c]).sum(dim=1) + o.double()
+        cols[r0:r1], vals[r0:r1], offset[r0:r1] = c, v, o
+        y[r0:r1] = (torch.rand(r1 - r0, generator=g, device=dev, dtype=torch.float64) < torch.sigmoid(logit)).float()
+        del c, v, o, logit, s, bad
+    ent_row_ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(n)])).to(dev)
+    raw = dict(E=int(E), N=N, Z=N * k, ent_row_ptr=ent_row_ptr, row_nnz_ptr=torch.arange(N + 1, dtype=torch.int64, device=dev) * k,
+               col_global=cols.reshape(-1), val=vals.reshape(-1), y=y, offset=offset, weight=None)
+    return raw, n
+
+
+def device_entities_to_host(raw, n, ents):
+    """The entities `ents` of a device raw batch with a constant number of non-zeros per sample (make_c5_share_device) as a
+    host RawBatch (for comparing a sample with the CPU checker)."""
+    import torch
+    ents = np.asarray(ents, np.int64)
+    ptr = np.concatenate([[0], np.cumsum(n)])
+    k = raw["Z"] // max(1, raw["N"])
+    ne = n[ents]
+    out_start = np.cumsum(ne) - ne
+    rows = torch.from_numpy(np.arange(int(ne.sum()), dtype=np.int64) - np.repeat(out_start, ne) + np.repeat(ptr[ents], ne)).to(raw["y"].device)
+    N = int(ne.sum())
+    g = lambda t: t[rows].cpu().numpy()
+    return RawBatch(ent_row_ptr=np.concatenate([[0], np.cumsum(ne)]), row_nnz_ptr=np.arange(N + 1, dtype=np.int64) * k,
+                    col_global=raw["col_global"].reshape(-1, k)[rows].cpu().numpy().reshape(-1),
+                    val=raw["val"].reshape(-1, k)[rows].cpu().numpy().reshape(-1), y=g(raw["y"]), offset=g(raw["offset"]),
+                    weight=None, entity_ids=[str(int(e)) for e in ents])
 
 
 def algorithmic_bytes(batch_n, batch_nnz, batch_p, warm=False, var=False):

@@ -1,5 +1,7 @@
-"""Worker of the two-process fixed-effect test: each rank holds every other sample of a fixture as its shard on the
-(shared) GPU and runs the product path fit_stepping(); the all-reduce goes through gloo."""
+"""Worker of the two-process fixed-effect test: each rank holds every other sample of a fixture as its shard and runs the
+product path fit_stepping(). On a box with at least two GPUs every rank takes its own device and the all-reduce is RCCL on the
+problem's device buffer (fixed_effect_lr_lbfgs_model.py:384-389 in the reference: two TF collectives); on the 1-GPU box the
+ranks share GPU 0 and the all-reduce goes through gloo."""
 import json
 import os
 import sys
@@ -9,6 +11,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np
+import torch
 import torch.distributed as dist
 
 from gdmix_amd import fixed_effect as fe
@@ -16,10 +19,17 @@ from gdmix_amd import fixed_effect as fe
 
 def main():
     base, names = sys.argv[1], sys.argv[2].split(",")
-    dist.init_process_group("gloo")
+    world = int(os.environ["WORLD_SIZE"])
+    rccl = torch.cuda.device_count() >= world
+    dev = int(os.environ.get("LOCAL_RANK", "0")) if rccl else 0
+    torch.cuda.set_device(dev)
+    if rccl:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    out = {}
-    s = fe.FixedEffectDeviceSolver(0)
+    out = {"_backend": dist.get_backend(), "_device": dev}
+    s = fe.FixedEffectDeviceSolver(dev)
     for name in names:
         z = np.load(os.path.join(ROOT, "tests", "golden", f"fe_{name}.npz"))
         rp, col, val = z["row_nnz_ptr"], z["col_global"], z["val"]

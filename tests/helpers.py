@@ -251,3 +251,54 @@ class OracleFeDouble:
         extra = {} if variances is None else {"variances": variances}
         return theta, dict(**extra, fval=res["fval"][0], gnorm=res["gnorm"][0], nit=int(res["nit"][0]), nfev=int(res["nfev"][0]),
                            status=int(res["status"][0]))
+
+
+# ---- full-size property tests: a class-stratified sample against the oracle ------------------------------
+def oracle_solve_parallel(b, kw, theta0=None):
+    """oracle.pack + oracle.solve of a host RawBatch with the entities dealt to the host cores in contiguous runs of about
+    equal non-zero count (ctypes releases the GIL). Returns (pk, result dict)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    pk = oracle.pack(b.ent_row_ptr, b.row_nnz_ptr, b.col_global)
+    o = oracle.make_opts(**kw)
+    cores = min(os.cpu_count() or 1, max(1, b.E))
+    work = np.concatenate([[0], np.cumsum(b.ent_nnz() + 64)])
+    bounds = np.searchsorted(work, np.linspace(0, work[-1], cores + 1)).astype(int)
+    bounds[0], bounds[-1] = 0, b.E
+    ic = 1 if kw.get("has_intercept", True) else 0
+    cp = pk["ent_feat_ptr"] + np.arange(b.E + 1) * ic
+
+    def run(i):
+        e0, e1 = int(bounds[i]), int(bounds[i + 1])
+        if e0 >= e1:
+            return None
+        r = oracle.solve(pk, b.val, b.y, b.offset, b.weight, o, theta0=theta0, e_begin=e0, e_end=e1)
+        return e0, e1, {k: (v[cp[e0]:cp[e1]].copy() if k in ("theta", "theta_thr", "variance") else v[e0:e1].copy())
+                        for k, v in r.items() if v is not None}
+    with ThreadPoolExecutor(cores) as ex:
+        parts = [p for p in ex.map(run, range(cores)) if p is not None]
+    out = {}
+    for k in parts[0][2]:
+        out[k] = np.concatenate([p[2][k] for p in parts])
+    return pk, out
+
+
+def stratified_sample(cls, nnz, rng, total=2000, nnz_budget_per_class=6_000_000):
+    """Entity indices for an oracle comparison, stratified by kernel class: every class with at least one entity gives
+    min(count, quota) entities drawn at random, stopping early once the class's sample holds `nnz_budget_per_class` non-zeros
+    (the first draw is always taken, so the classes of giant entities are sampled too). Returns (sorted indices, {class: taken})."""
+    present = np.flatnonzero(np.bincount(cls, minlength=1))
+    quota = max(1, total // max(1, present.size))
+    take, taken = [], {}
+    for c in present:
+        members = np.flatnonzero(cls == c)
+        members = members[rng.permutation(members.size)][:quota]
+        csum = np.cumsum(nnz[members])
+        keep = max(1, int(np.searchsorted(csum, nnz_budget_per_class, side="right")))
+        take.append(members[:keep])
+        taken[int(c)] = int(min(keep, members.size))
+    take = np.concatenate(take)
+    if take.size < total:    # fill up from the bulk (entities of ordinary size, any class)
+        rest = np.setdiff1d(np.flatnonzero(nnz <= 20_000), take)
+        take = np.concatenate([take, rest[rng.permutation(rest.size)][:total - take.size]])
+    return np.sort(take), taken

@@ -228,20 +228,25 @@ def test_large_shard_properties(device_solver):
 
 @pytest.mark.gpu
 def test_two_workers_all_reduce_gradient_and_value(tmp_path):
-    """Two processes, each with every other sample as its shard (both on GPU 0, collectives over gloo): the replicated
-    L-BFGS step on the all-reduced [gradient, value] gives every worker the coefficients of the whole data set."""
+    """Two processes, each with every other sample as its shard: the replicated L-BFGS step on the all-reduced [gradient, value]
+    gives every worker the coefficients of the whole data set. With two GPUs visible each rank has its own device and the
+    all-reduce is RCCL in place on the device buffer; on the 1-GPU box both sit on GPU 0 and the collective is gloo."""
     import json
     import subprocess
     import sys
     names = ["logistic_offset", "linear_offset", "logistic_wide", "logistic_no_intercept", "logistic_warm_one_iteration"]
     root = os.path.dirname(HERE)
-    env = dict(os.environ)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("TF_CONFIG", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29617", os.path.join(root, "tests", "_fe_dist_worker.py"), str(tmp_path), ",".join(names)]
     subprocess.run(cmd, check=True, env=env, timeout=600, cwd=root)
     res = json.load(open(tmp_path / "result.json"))
     assert len(res) == 2
+    import torch
+    want = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    assert res[0]["_backend"] == res[1]["_backend"] == want
+    assert (res[0]["_device"], res[1]["_device"]) == ((0, 1) if want == "nccl" else (0, 0))
     for name in names:
         c = load(name)
         a, b = res[0][name], res[1][name]

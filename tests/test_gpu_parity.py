@@ -120,7 +120,7 @@ VARIANT_FIXTURES = ["ref_fixture_l2_0.1", "ref_dataset1", "ref_dataset2", "c2_sh
                     "ragged", "ragged_variance_simple", "ragged_variance_full", "ref_dataset1_variance_full", "ml_per_user", "ml_per_movie", "c5_mean_shape", "zipf_tail",
                     "tiny_entities_regbias", "tiny_entities_shipped_cfg", "warm_stage2",
                     "exit_factr_1e-7", "exit_factr_1e-4_m3_weights", "exit_hard_02", "exit_hard_04", "exit_extreme_00", "exit_extreme_01",
-                    "exit_extreme_02", "exit_extreme_03"]
+                    "exit_extreme_02", "exit_extreme_03", "ml20m_per_movie_tall", "ml20m_per_user_tall"]
 
 
 @pytest.mark.parametrize("name", VARIANT_FIXTURES)
@@ -141,7 +141,7 @@ def test_quad_kernel_matches_reference_fixture(device_solver, name):
 @pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "c2_shipped_cfg", "c2_l2_1e-3", "ragged", "ml_per_user",
                                   "c5_mean_shape", "warm_stage2", "tiny_entities_regbias", "c2_no_intercept",
                                   "ragged_variance_simple", "c2_m3", "exit_factr_1e-4", "exit_hard_02", "exit_hard_03", "exit_extreme_00",
-                                  "exit_extreme_01", "exit_extreme_02", "exit_extreme_03"])
+                                  "exit_extreme_01", "exit_extreme_02", "exit_extreme_03", "ml20m_per_movie_tall", "ml20m_per_user_tall"])
 @pytest.mark.parametrize("in_registers", [True, False])
 def test_block_kernel_matches_reference_fixture(device_solver, name, in_registers):
     # lds limit 0 sends every entity through the team kernels: L-BFGS vectors in HBM, one workgroup per entity (the default), or in
@@ -151,14 +151,15 @@ def test_block_kernel_matches_reference_fixture(device_solver, name, in_register
 
 @pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "ragged", "ml_per_user", "warm_stage2", "tiny_entities_regbias",
                                   "c2_no_intercept", "ragged_variance_simple", "c2_m3", "exit_factr_1e-4_m3_weights", "exit_extreme_00",
-                                  "exit_extreme_02"])
+                                  "exit_extreme_02", "ml20m_per_movie_tall", "ml20m_per_user_tall"])
 def test_device_wide_kernel_matches_reference_fixture(device_solver, name):
     # giant threshold 1 sends every entity, one after another, through the persistent device-wide kernel
     _solve_and_compare(device_solver, name, giant_nnz=1)
 
 
 @pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "ragged", "ml_per_user", "warm_stage2", "c2_no_intercept",
-                                  "ragged_variance_simple", "exit_factr_1e-7", "exit_hard_02", "exit_extreme_01", "exit_extreme_03"])
+                                  "ragged_variance_simple", "exit_factr_1e-7", "exit_hard_02", "exit_extreme_01", "exit_extreme_03",
+                                  "ml20m_per_movie_tall", "ml20m_per_user_tall"])
 @pytest.mark.parametrize("in_registers", [True, False])
 def test_team_tiers_match_reference_fixture(device_solver, name, in_registers):
     # every entity through the persistent kernel split into teams of CUs (2, 8 or 32 CUs by non-zeros)
