@@ -257,8 +257,24 @@ __device__ __forceinline__ void compact_advance(CompactState& S, const double* a
   plan.gamma = 1.0 / theta;
 }
 
+// Dispatch on the number of stored pairs (uniform over the cooperating threads): BODY sees a constexpr int HC = the count.
+// The passes over the history request every pair of a coefficient before the first is used (one memory latency per pass
+// instead of one per pair); with the count a compile-time constant that stays true while only the pairs that exist are
+// requested — the mean history length of a ~10-iteration solve is 4.5 of the 10 slots.
+#define GDMIX_HIST_CASE(N_, BODY_) case N_: { constexpr int HC = N_; BODY_; } break;
+#define GDMIX_HIST_DISPATCH(COUNT_, BODY_)                                                                        \
+  switch (COUNT_) {                                                                                               \
+    GDMIX_HIST_CASE(0, BODY_) GDMIX_HIST_CASE(1, BODY_) GDMIX_HIST_CASE(2, BODY_) GDMIX_HIST_CASE(3, BODY_)       \
+    GDMIX_HIST_CASE(4, BODY_) GDMIX_HIST_CASE(5, BODY_) GDMIX_HIST_CASE(6, BODY_) GDMIX_HIST_CASE(7, BODY_)       \
+    GDMIX_HIST_CASE(8, BODY_) GDMIX_HIST_CASE(9, BODY_)                                                           \
+    default: { constexpr int HC = TEAM_MCAP; BODY_; } break;                                                      \
+  }
+static_assert(TEAM_MCAP == 10, "GDMIX_HIST_DISPATCH lists the counts 0..10");
+
 // The elementwise part of a step for coefficient j (CA_RETRY / CA_DIRECTION). Vectors as in Work; u, q from L.
-__device__ __forceinline__ void compact_update(const CompactPlan& plan, const CompactMats& L, const Work& W, int p, int m, int j) {
+// HC >= plan.col: the number of history slots requested (GDMIX_HIST_DISPATCH(plan.col, ...) makes it equal).
+template <int HC>
+__device__ __forceinline__ void compact_update_n(const CompactPlan& plan, const CompactMats& L, const Work& W, int p, int m, int j) {
   if (plan.action == CA_RETRY) {
     W.x[j] = plan.stp * W.d[j] + W.t[j];
     return;
@@ -272,11 +288,11 @@ __device__ __forceinline__ void compact_update(const CompactPlan& plan, const Co
     compact_hist(W, m, j)[plan.slot * COMPACT_HIST_STRIDE] = make_double2(sn, yn);
   }
   double dj = -gj;
-  if (plan.col > 0) {
-    // every pair is requested before the first is used (see team_eval); slots without a pair are read and discarded
-    double2 h[TEAM_MCAP];
+  if (HC > 0 && plan.col > 0) {
+    // every pair is requested before the first is used (see team_eval)
+    double2 h[HC > 0 ? HC : 1];
 #pragma unroll
-    for (int i = 0; i < TEAM_MCAP; ++i) {
+    for (int i = 0; i < HC; ++i) {
       int sl = plan.head + i;
       if (sl >= m) sl -= m;
       if (i >= m) sl = 0;
@@ -284,7 +300,7 @@ __device__ __forceinline__ void compact_update(const CompactPlan& plan, const Co
     }
     double su = 0.0, yq = 0.0;
 #pragma unroll
-    for (int i = 0; i < TEAM_MCAP; ++i) {
+    for (int i = 0; i < HC; ++i) {
       if (i < plan.col) {
         const bool fresh = plan.store_pair && i == plan.cnew;
         const double si = fresh ? sn : h[i].x;
@@ -301,6 +317,10 @@ __device__ __forceinline__ void compact_update(const CompactPlan& plan, const Co
   W.t[j] = xj;
   W.r[j] = gj;
   W.x[j] = plan.stp * dj + xj;
+}
+
+__device__ __forceinline__ void compact_update(const CompactPlan& plan, const CompactMats& L, const Work& W, int p, int m, int j) {
+  compact_update_n<TEAM_MCAP>(plan, L, W, p, m, j);
 }
 
 }  // namespace gdmix

@@ -384,6 +384,51 @@ __device__ __forceinline__ double team_fg(Team<NW>& tm, const EntityView& P, con
   return loss;
 }
 
+// The products of team_eval over this thread's coefficients, with HC (>= col) history slots requested per coefficient.
+// Two tiles per trip: all 2 x (4 + HC) loads of the trip are in flight before the first product (the passes over the history
+// are bound by how many bytes a CU keeps in flight, not by arithmetic).
+template <int NW, int HC>
+__device__ __forceinline__ void team_products(const Team<NW>& tm, const Work& W, int p, int m, int col, int head, int first_reg,
+                                              double (&acc)[TEAM_K]) {
+  const double* __restrict__ x = W.x;
+  for (int tile = tm.wid; tile * WAVE < p; tile += 2 * tm.nwaves) {
+    const int jv[2] = {tile * WAVE + tm.lane, (tile + tm.nwaves) * WAVE + tm.lane};
+    const bool ok[2] = {jv[0] < p, jv[1] < p};
+    double xj[2], gj[2], dj[2], rj[2];
+    double2 h[2][HC > 0 ? HC : 1];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = ok[u] ? jv[u] : tm.lane;   // tile 0 always exists: a safe address for the lanes past the end
+      xj[u] = x[j]; gj[u] = W.g[j]; dj[u] = W.d[j]; rj[u] = W.r[j];
+#pragma unroll
+      for (int i = 0; i < HC; ++i) {
+        int sl = head + i;
+        if (sl >= m) sl -= m;
+        if (i >= m) sl = 0;
+        h[u][i] = compact_hist(W, m, j)[sl * COMPACT_HIST_STRIDE];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (ok[u]) {
+        if (jv[u] >= first_reg) acc[0] += xj[u] * xj[u];
+        acc[1] += gj[u] * dj[u];
+        acc[2] += gj[u] * gj[u];
+        const double yj = gj[u] - rj[u];
+        acc[3] += yj * yj;
+        acc[4] += yj * gj[u];
+        acc[TEAM_RD] += rj[u] * dj[u];
+        acc[TEAM_K - 1] = fmax(acc[TEAM_K - 1], fabs(gj[u]));
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+          acc[5 + i] += (i < col ? h[u][i].x : 0.0) * yj;
+          acc[5 + TEAM_MCAP + i] += (i < col ? h[u][i].y : 0.0) * yj;
+        }
+      }
+    }
+  }
+}
+
 // f, g and every dot product the driver needs, at W.x, all vectors in HBM. acc[] layout: 0 sum x_j^2 over regularised j,
 // 1 g'd, 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (y = g - r; chronological i < col), K-2 r'd, K-1 max|g_j|.
 template <int NW>
@@ -406,44 +451,7 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
   // back: no synchronisation), so that the accumulators and the tile staging above are not live at the same time.
 #pragma unroll
   for (int k = 0; k < TEAM_K; ++k) acc[k] = 0.0;
-  // two tiles per trip: all 2 x (4 + m) loads of the trip are in flight before the first product (the passes over the history
-  // are bound by how many bytes a CU keeps in flight, not by arithmetic)
-  for (int tile = tm.wid; tile * WAVE < p; tile += 2 * tm.nwaves) {
-    const int jv[2] = {tile * WAVE + tm.lane, (tile + tm.nwaves) * WAVE + tm.lane};
-    const bool ok[2] = {jv[0] < p, jv[1] < p};
-    double xj[2], gj[2], dj[2], rj[2];
-    double2 h[2][TEAM_MCAP];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int j = ok[u] ? jv[u] : tm.lane;   // tile 0 always exists: a safe address for the lanes past the end
-      xj[u] = x[j]; gj[u] = W.g[j]; dj[u] = W.d[j]; rj[u] = W.r[j];
-#pragma unroll
-      for (int i = 0; i < TEAM_MCAP; ++i) {
-        int sl = head + i;
-        if (sl >= m) sl -= m;
-        if (i >= m) sl = 0;
-        h[u][i] = compact_hist(W, m, j)[sl * COMPACT_HIST_STRIDE];   // slots without a pair yet are read and discarded
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (ok[u]) {
-        if (jv[u] >= first_reg) acc[0] += xj[u] * xj[u];
-        acc[1] += gj[u] * dj[u];
-        acc[2] += gj[u] * gj[u];
-        const double yj = gj[u] - rj[u];
-        acc[3] += yj * yj;
-        acc[4] += yj * gj[u];
-        acc[TEAM_RD] += rj[u] * dj[u];
-        acc[TEAM_K - 1] = fmax(acc[TEAM_K - 1], fabs(gj[u]));
-#pragma unroll
-        for (int i = 0; i < TEAM_MCAP; ++i) {
-          acc[5 + i] += (i < col ? h[u][i].x : 0.0) * yj;
-          acc[5 + TEAM_MCAP + i] += (i < col ? h[u][i].y : 0.0) * yj;
-        }
-      }
-    }
-  }
+  GDMIX_HIST_DISPATCH(col, (team_products<NW, HC>(tm, W, p, m, col, head, first_reg, acc)))
   TEAM_PROF(2);
   tm.reduce(acc);
   TEAM_PROF(3);
@@ -506,7 +514,8 @@ __device__ void team_solve(Team<NW>& tm, const EntityView& P, const SolveParams&
       tm.sync();
       break;
     }
-    for (int j = tm.tid; j < p; j += tm.NT) compact_update(plan, L.mats, W, p, m, j);
+    GDMIX_HIST_DISPATCH((plan.action == CA_DIRECTION ? plan.col : 0),
+                        for (int j = tm.tid; j < p; j += tm.NT) compact_update_n<HC>(plan, L.mats, W, p, m, j))
     TEAM_PROF(5);
     tm.sync();
     TEAM_PROF(6);

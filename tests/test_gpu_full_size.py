@@ -57,9 +57,19 @@ def _full_size_properties(device_solver, raw, n, z, ones, take, label, min_pgtol
     rs = device_solver.solve(ps, o).to_host()
     cps = ps.coef_ptr_host()
     assert np.array_equal(np.diff(cps), np.diff(coef_ptr)[ents])
-    for k in ("nit", "nfev", "status", "fval"):
+    for k in ("nit", "nfev", "status"):
         assert np.array_equal(rs[k], res[k][ents]), k
-    assert np.array_equal(rs["theta"], res["theta"][_ranges(coef_ptr[ents], np.diff(coef_ptr)[ents])])
+    # ... bit for bit, except in the tiers where a team of several workgroups works on one entity: the team size of a tier
+    # follows from the tier's whole content (total work / largest entity), and with it the shape of the cross-workgroup sums
+    multi = np.array(["teams" in nm or "device-wide" in nm or "CUs" in nm for nm in names])[cls[ents]]
+    take_theta = res["theta"][_ranges(coef_ptr[ents], np.diff(coef_ptr)[ents])]
+    same_bits = np.repeat(~multi, np.diff(cps))
+    assert np.array_equal(rs["fval"][~multi], res["fval"][ents][~multi])
+    assert np.array_equal(rs["theta"][same_bits], take_theta[same_bits])
+    if multi.any():
+        np.testing.assert_allclose(rs["fval"][multi], res["fval"][ents][multi], rtol=1e-12)
+        err_m = per_entity_rel_err(rs["theta"], take_theta, cps)
+        assert err_m[multi].max() <= 1e-8, err_m[multi].max()     # far inside the 1e-7 bar both hold against the oracle
     del ps, rs
     # (3) started from the answer: zero iterations for every entity that had stopped on the gradient test, coefficients unchanged
     again = device_solver.solve(packed, o, theta0=res_dev.theta).to_host()
@@ -127,5 +137,6 @@ def test_c5_share_properties(device_solver):
     take = lambda ents: synthetic.device_entities_to_host(raw, n, ents)
     res, cls, names = _full_size_properties(device_solver, raw, n, z, ones, take, "C5 share", min_pgtol=0.9)
     present = {names[c] for c in np.unique(cls)}
-    assert any("8 teams" in s or "device-wide" in s for s in present), present     # the giants
-    assert any("128 teams" in s for s in present) and any("workgroup" in s for s in present)
+    # the entities at the 2^20 cap sit in the 32-team tier (the 8-team and device-wide tiers start at 2^21 and 2^24 non-zeros:
+    # tests/test_gpu_parity.py::test_large_and_giant_entities_pack_and_solve drives those)
+    assert any("32 teams" in s for s in present) and any("128 teams" in s for s in present) and any("workgroup" in s for s in present), present
