@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--fe-rows", type=int, default=4_000_000, help="samples of the fixed-effect leg's shard (x 32 non-zeros, 100k features)")
     ap.add_argument("--giant-nnz", type=int, default=-1, help="override the device-wide kernel threshold (exploration)")
     ap.add_argument("--team-nnz", type=int, default=-1, help="override the lowest team-tier threshold (exploration)")
+    ap.add_argument("--tall-min-n", type=int, default=-1, help="override the tall kernel's sample threshold (exploration)")
+    ap.add_argument("--tall-split-n", type=int, default=-1, help="override the tall kernel's one-CU-per-entity threshold (exploration)")
     ap.add_argument("--solve-only", action="store_true", help="time gdmix_re_solve alone (batch packed once)")
     ap.add_argument("--ranks-share-device", action="store_true",
                     help="test hook for a 1-GPU box: every rank uses cuda:0 and the collectives go over gloo (numbers are meaningless)")
@@ -418,6 +420,10 @@ def main():
         solver.set_giant_nnz(a.giant_nnz)
     if a.team_nnz >= 0:
         solver.set_team_nnz(a.team_nnz)
+    if a.tall_min_n >= 0:
+        solver.set_tall_min_n(a.tall_min_n)
+    if a.tall_split_n >= 1:
+        solver.set_tall_split_n(a.tall_split_n)
 
     def step():
         nonlocal packed

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgdmix_re.so")
-SOURCES = ["re_api.hip", "re_solve.hip", "re_pack.hip", "re_pack_big.hip", "re_wire.hip", "re_variance_big.hip", "fe_solve.hip"]
+SOURCES = ["re_api.hip", "re_solve.hip", "re_solve_tall.hip", "re_pack.hip", "re_pack_big.hip", "re_wire.hip", "re_variance_big.hip", "fe_solve.hip"]
 HEADERS = [os.path.basename(h) for h in glob.glob(os.path.join(CSRC, "*.hpp"))] + [os.path.join("..", "..", "include", "gdmix_re.h"), os.path.join("..", "..", "include", "gdmix_fe.h")]
 IO_LIB = os.path.join(HERE, "libgdmix_io.so")
 IO_SOURCES = ["io_reader.cpp", "io_avro.cpp"]

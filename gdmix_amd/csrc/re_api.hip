@@ -58,6 +58,8 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_WREG8, 12288, "re_solve_wreg_kernel<8> lds<=12K"}, {KIND_WREG8, 24576, "re_solve_wreg_kernel<8> lds<=24K"},
     {KIND_WREG8, 65536, "re_solve_wreg_kernel<8> lds<=64K"},
     {KIND_WLDS, 24576, "re_solve_wave_kernel lds<=24K"},     {KIND_WLDS, 65536, "re_solve_wave_kernel lds<=64K"},
+    {KIND_TALL_S, 0, "re_solve_tall_kernel<1> p<=64"},
+    {KIND_TALL, 0, "re_solve_tall_kernel<8> p<=64"},
     {KIND_TREG, 0, "re_solve_treg_kernel 1 CU"},   {KIND_TREG, 0, "re_solve_treg_kernel 2 CUs"},  {KIND_TREG, 0, "re_solve_treg_kernel 3 CUs"},
     {KIND_TREG, 0, "re_solve_treg_kernel 4 CUs"},  {KIND_TREG, 0, "re_solve_treg_kernel 6 CUs"},  {KIND_TREG, 0, "re_solve_treg_kernel 8 CUs"},
     {KIND_TREG, 0, "re_solve_treg_kernel 12 CUs"}, {KIND_TREG, 0, "re_solve_treg_kernel 16 CUs"}, {KIND_TREG, 0, "re_solve_treg_kernel 24 CUs"},
@@ -132,6 +134,8 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   c->impl.timing = 0;
   c->impl.giant_nnz = 16777216;
   c->impl.team_nnz = 16384;
+  c->impl.tall_min_n = GDMIX_RE_TALL_MIN_N_DEFAULT;
+  c->impl.tall_split_n = GDMIX_RE_TALL_SPLIT_N_DEFAULT;
   c->impl.grid_sync = nullptr;
   c->impl.big_tmp = nullptr;
   c->impl.big_tmp_bytes = 0;
@@ -142,7 +146,7 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
     delete c;
     return GDMIX_RE_EHIP;
   }
-  rc = hipMalloc(&c->impl.grid_sync, TEAM_MAX_TEAMS * sizeof(TeamSync));
+  rc = hipMalloc(&c->impl.grid_sync, TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_TAIL_BYTES);
   if (rc != hipSuccess) {
     set_error("hipMalloc failed: %s", hipGetErrorString(rc));
     (void)hipHostFree(c->impl.host_pinned);
@@ -251,6 +255,18 @@ GDMIX_API int gdmix_re_set_team_nnz(gdmix_re_ctx* ctx, int64_t nnz) {
   return GDMIX_RE_OK;
 }
 
+GDMIX_API int gdmix_re_set_tall_min_n(gdmix_re_ctx* ctx, int min_n) {
+  if (!ctx || min_n < 0) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
+  ctx->impl.tall_min_n = min_n;
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_re_set_tall_split_n(gdmix_re_ctx* ctx, int split_n) {
+  if (!ctx || split_n < 1) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
+  ctx->impl.tall_split_n = split_n;
+  return GDMIX_RE_OK;
+}
+
 GDMIX_API int gdmix_re_set_timing(gdmix_re_ctx* ctx, int enabled) {
   if (!ctx) { set_error("ctx is NULL"); return GDMIX_RE_EINVAL; }
   if (enabled && !ctx->impl.ev0[0]) {
@@ -322,6 +338,8 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   tab.giant_nnz = opts->m <= TEAM_MCAP ? ctx->impl.giant_nnz : 0;
   tab.team_nnz = opts->m <= TEAM_MCAP ? ctx->impl.team_nnz : 0;
   tab.treg = (opts->m <= TEAM_MCAP && (ctx->impl.kernel_mask & 8)) ? 1 : 0;
+  tab.tall_min_n = ctx->impl.tall_min_n;
+  tab.tall_split_n = ctx->impl.tall_split_n;
   if (opts->sum_loss || opts->linear) {
     // the fixed-effect objective lives in the team kernels only: every entity goes device-wide, one after another
     if (opts->m > TEAM_MCAP) { set_error("sum_loss / linear need m <= %d", TEAM_MCAP); return GDMIX_RE_EINVAL; }
@@ -349,6 +367,29 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
 
   const bool timing = ctx->impl.timing != 0;
   for (int c = 0; c < GDMIX_RE_NUM_CLASSES; ++c) ctx->impl.ev_used[c] = false;
+  // scratch slots of the workgroup-per-entity and team kernels
+  size_t slot_doubles = 0;
+  int slots = 0;
+  double* slot_scratch = nullptr;
+  const int n_slot_users = hc[BLOCK_CLASS] + hc[TEAM128_CLASS] + hc[TEAM32_CLASS] + hc[TEAM8_CLASS] + hc[GIANT_CLASS];
+  if (n_slot_users > 0) {
+    slots = slots_for(b, opts, &slot_doubles);
+    size_t need = (size_t)slots * slot_doubles * 8;
+    if (ctx->impl.scratch && ctx->impl.scratch_bytes >= need) slot_scratch = static_cast<double*>(ctx->impl.scratch);
+    else if (b->scratch && b->scratch_bytes >= need) slot_scratch = static_cast<double*>(b->scratch);
+    else {
+      // shrink the slot count to what is available rather than failing, but never below one slot
+      size_t avail = ctx->impl.scratch ? ctx->impl.scratch_bytes : 0;
+      void* base = ctx->impl.scratch;
+      if (b->scratch_bytes > avail) { avail = b->scratch_bytes; base = b->scratch; }
+      slots = (int)(avail / (slot_doubles * 8));
+      if (slots < 1) {
+        set_error("%d entities need a scratch slot: provide >= %zu bytes via gdmix_re_set_scratch", n_slot_users, slot_doubles * 8);
+        return GDMIX_RE_ENOMEM;
+      }
+      slot_scratch = static_cast<double*>(base);
+    }
+  }
   int begin = 0;
   for (int c = 0; c < TREG_CLASS0; ++c) {
     if (hc[c] <= 0) continue;
@@ -363,6 +404,8 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
       case KIND_WREG2: HIP_TRY(launch_solve_wreg(2, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
       case KIND_WREG4: HIP_TRY(launch_solve_wreg(4, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
       case KIND_WREG8: HIP_TRY(launch_solve_wreg(8, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
+      case KIND_TALL_S: HIP_TRY(launch_solve_tall(true, B, O, P, theta0, begin, hc[c], ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync), ctx->impl.grid_sync, s)); break;
+      case KIND_TALL: HIP_TRY(launch_solve_tall(false, B, O, P, theta0, begin, hc[c], ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync), ctx->impl.grid_sync, s)); break;
       default: HIP_TRY(launch_solve_wave(B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
     }
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[c], s)); ctx->impl.ev_used[c] = true; }
@@ -392,25 +435,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     }
   }
   if (hc[BLOCK_CLASS] > 0 || hc[TEAM128_CLASS] > 0 || hc[TEAM32_CLASS] > 0 || hc[TEAM8_CLASS] > 0 || hc[GIANT_CLASS] > 0) {
-    size_t slot_doubles;
-    int slots = slots_for(b, opts, &slot_doubles);
-    size_t need = (size_t)slots * slot_doubles * 8;
-    double* scratch = nullptr;
-    if (ctx->impl.scratch && ctx->impl.scratch_bytes >= need) scratch = static_cast<double*>(ctx->impl.scratch);
-    else if (b->scratch && b->scratch_bytes >= need) scratch = static_cast<double*>(b->scratch);
-    else {
-      // shrink the slot count to what is available rather than failing, but never below one slot
-      size_t avail = ctx->impl.scratch ? ctx->impl.scratch_bytes : 0;
-      void* base = ctx->impl.scratch;
-      if (b->scratch_bytes > avail) { avail = b->scratch_bytes; base = b->scratch; }
-      slots = (int)(avail / (slot_doubles * 8));
-      if (slots < 1) {
-        set_error("%d entities need the workgroup kernel: provide >= %zu bytes via gdmix_re_set_scratch", hc[BLOCK_CLASS] + hc[TEAM128_CLASS] + hc[TEAM32_CLASS] + hc[TEAM8_CLASS] + hc[GIANT_CLASS],
-                  slot_doubles * 8);
-        return GDMIX_RE_ENOMEM;
-      }
-      scratch = static_cast<double*>(base);
-    }
+    double* const scratch = slot_scratch;
     if (hc[BLOCK_CLASS] > 0) {
       if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[BLOCK_CLASS], s)); }
       HIP_TRY(launch_solve_block(B, O, P, theta0, begin, hc[BLOCK_CLASS], scratch, slot_doubles, slots, b->max_p, s));

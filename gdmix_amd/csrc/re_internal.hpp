@@ -19,10 +19,12 @@ namespace gdmix {
 //   KIND_WREG1/2/4  register-resident wavefront kernel with 1/2/4 coefficients per lane (p <= 64/128/256)
 //   KIND_WLDS       LDS-resident wavefront kernel (any p whose state fits 64 KiB of LDS, any m)
 //   KIND_BLOCK      workgroup-per-entity kernel working out of a global scratch slot (anything)
+//   KIND_TALL       workgroup-per-entity kernel for tall and skinny entities (p <= 64, n >= tall_min_n): samples over all
+//                   lanes, the L-BFGS driver replicated in every wavefront's registers (re_solve_tall.hip)
 // Each wavefront kind is split into LDS-footprint buckets so that small entities keep high occupancy.
 enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4, KIND_QUAD2 = 5, KIND_QUAD4 = 6, KIND_PAIR4 = 7, KIND_QUAD3 = 8, KIND_PAIR3 = 9, KIND_WREG8 = 10,
        KIND_G64_3 = 11, KIND_G64_4 = 12, KIND_G128_4 = 13, KIND_G256_4 = 14, KIND_G512_4 = 15, KIND_GRID = 16, KIND_G128_3 = 17, KIND_G256_3 = 18,
-       KIND_TREG = 19 };
+       KIND_TREG = 19, KIND_TALL = 20, KIND_TALL_S = 21 };
 
 // group kernels (several entities per wavefront): lanes per entity, coefficient slots per lane; 0 if not a group kind
 __host__ __device__ inline int group_lanes(int kind) {
@@ -41,6 +43,14 @@ constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 5;
 // workgroups (= CUs); a team of s workgroups holds entities of up to s * TREG_COEFS coefficients.
 constexpr int TREG_NUM = 12;
 constexpr int TREG_CLASS0 = BLOCK_CLASS - TREG_NUM;
+constexpr int TALL_CLASS = TREG_CLASS0 - 1;      // tall entities of at least tall_split_n samples: one workgroup of TALL_NW wavefronts per CU
+constexpr int TALL_S_CLASS = TREG_CLASS0 - 2;    // smaller ones: workgroups of TALL_NW_SMALL wavefronts, several per CU
+#ifndef GDMIX_TALL_NW_SMALL
+#define GDMIX_TALL_NW_SMALL 1
+#endif
+constexpr int TALL_NW = 8;
+constexpr int TALL_NW_SMALL = GDMIX_TALL_NW_SMALL;
+constexpr int TALL_MAX_P = 64;      // coefficients (one per lane of the master wavefront)
 constexpr int TREG_NW = 4, TREG_EPL = 4;
 constexpr int TREG_COEFS = TREG_NW * TREG_EPL * 64;   // per workgroup
 __host__ __device__ inline int treg_size(int k) {
@@ -61,6 +71,8 @@ struct ClassTable {
   int64_t giant_nnz;   // 0 = device-wide kernel off
   int64_t team_nnz;    // 0 = team tiers off
   int treg;            // register team kernels on
+  int tall_min_n;      // entities with p <= TALL_MAX_P and at least this many samples use the tall kernel (0 = never)
+  int tall_split_n;    // ... those with at least this many samples one workgroup per CU, the others several
 };
 
 // Device pointers of a packed batch, passed by value to kernels.
@@ -102,7 +114,9 @@ struct gdmix_ctx_impl {
   int timing;             // bracket class launches with events
   int64_t giant_nnz;      // entities with >= this many non-zeros use the device-wide kernel (0 = never)
   int64_t team_nnz;       // lowest tier of the team kernel (0 = never)
-  void* grid_sync;        // device: TeamSync of the team kernels
+  int tall_min_n;         // tall kernel for p <= 64 and n >= this (0 = never)
+  int tall_split_n;       // tall entities with n >= this: one large workgroup per CU
+  void* grid_sync;        // device: TeamSync of the team kernels, followed by TALL_TAIL_BYTES for the tall kernel
   void* big_tmp;          // device: grow-only temporary of the big-entity pack path
   size_t big_tmp_bytes;
   hipEvent_t ev0[GDMIX_RE_NUM_CLASSES], ev1[GDMIX_RE_NUM_CLASSES];
@@ -150,6 +164,10 @@ hipError_t launch_solve_grid(const BatchDev& B, const OutDev& O, const SolvePara
 hipError_t launch_solve_treg(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0, int begin, int count,
                              double* scratch, int64_t max_p, int64_t max_n, void* sync_buf, int blocks, int size, hipStream_t s);
 inline size_t treg_slot_doubles(int64_t max_p, int64_t max_n) { return (size_t)2 * max_p + (size_t)256 * 64 + (size_t)max_n + 64; }
+constexpr int TALL_TAIL_BYTES = 256;   // device buffer of the context: padded copy of the end of the batch's row-major arrays
+hipError_t launch_solve_tall(bool small, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0, int begin, int count,
+                             int num_cus, int64_t Z, void* tail_buf, void* sync_buf, hipStream_t s);
+void launch_sort_class(int32_t* list, int count, const int64_t* ent_nnz_ptr, hipStream_t s);
 hipError_t launch_variance_full(const BatchDev& B, int64_t E, const SolveParams& o, const double* theta, double* variance,
                                 double* scratch, size_t slot_doubles, int slots, int64_t max_p, hipStream_t s);
 constexpr int64_t VAR_FULL_MAX_P = 2048;   // FULL variance densifies p x p (as the reference does): one wavefront per entity up to here,

@@ -45,7 +45,8 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
         if (wlds_bytes <= (size_t)tab.lds_bytes[k]) { c = k; break; }
       }
     }
-    if (tab.giant_nnz > 0 && z >= tab.giant_nnz) c = GIANT_CLASS;
+    if (tab.tall_min_n > 0 && m <= M_REG && p <= TALL_MAX_P && n >= tab.tall_min_n && !(tab.giant_nnz > 0 && z >= tab.giant_nnz)) c = (n >= tab.tall_split_n) ? TALL_CLASS : TALL_S_CLASS;
+    else if (tab.giant_nnz > 0 && z >= tab.giant_nnz) c = GIANT_CLASS;
     else if (c == BLOCK_CLASS || (tab.team_nnz > 0 && z >= tab.team_nnz)) {
       // too large for a wavefront group: a team of CUs. Size by the coefficients (the history has to fit the team's
       // registers) and by the non-zeros (streaming bandwidth), smallest team that has both.
@@ -623,10 +624,11 @@ __global__ __launch_bounds__(WAVE* BLOCK_NW) void re_solve_block_kernel(BatchDev
 // that the long solves start first). One workgroup, bitonic sort in LDS; ties by entity index, so the order
 // and with it the launch are reproducible. Lists longer than SORT_CAP stay in ticket order.
 // ---------------------------------------------------------------------------------------------------
-constexpr int SORT_CAP = 4096;
+constexpr int SORT_CAP = 16384;   // 128 KB of keys in LDS
 __global__ __launch_bounds__(1024) void re_sort_class_kernel(int32_t* __restrict__ list, int count,
                                                              const int64_t* __restrict__ ent_nnz_ptr) {
-  __shared__ unsigned long long key[SORT_CAP];
+  extern __shared__ __align__(16) unsigned char sort_smem[];
+  unsigned long long* const key = reinterpret_cast<unsigned long long*>(sort_smem);
   int np2 = 1;
   while (np2 < count) np2 <<= 1;
   for (int i = threadIdx.x; i < np2; i += blockDim.x) {
@@ -653,6 +655,19 @@ __global__ __launch_bounds__(1024) void re_sort_class_kernel(int32_t* __restrict
     }
   }
   for (int i = threadIdx.x; i < count; i += blockDim.x) list[i] = (int32_t)(uint32_t)key[i];
+}
+
+void launch_sort_class(int32_t* list, int count, const int64_t* ent_nnz_ptr, hipStream_t s) {
+  if (count <= 1 || count > SORT_CAP) return;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(re_sort_class_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return;   // stays in ticket order: slower tail, same results
+    attr_set = true;
+  }
+  int np2 = 1;
+  while (np2 < count) np2 <<= 1;
+  hipLaunchKernelGGL(re_sort_class_kernel, dim3(1), dim3(1024), (size_t)np2 * 8, s, list, count, ent_nnz_ptr);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -817,8 +832,7 @@ hipError_t launch_solve_treg(const BatchDev& B, const OutDev& O, const SolvePara
   if (per_cu < 1) return hipErrorLaunchOutOfResources;
   err = hipMemset2DAsync(sync_buf, sizeof(TeamSync), 0, 64, (size_t)teams, s);
   if (err != hipSuccess) return err;
-  if (count > 1 && count <= SORT_CAP)
-    hipLaunchKernelGGL(re_sort_class_kernel, dim3(1), dim3(1024), 0, s, const_cast<int32_t*>(B.order) + begin, count, B.ent_nnz_ptr);
+  launch_sort_class(const_cast<int32_t*>(B.order) + begin, count, B.ent_nnz_ptr, s);
   hipLaunchKernelGGL((re_solve_treg_kernel<TREG_NW, TREG_EPL>), dim3(teams * size), dim3(WAVE * TREG_NW), 0, s, B, O, o, theta0, begin,
                      count, scratch, treg_slot_doubles(max_p, max_n), max_p, static_cast<TeamSync*>(sync_buf), teams);
   return hipGetLastError();
@@ -831,9 +845,7 @@ static hipError_t launch_team_block(const BatchDev& B, const OutDev& O, const So
   int grid = count < slots ? count : slots;
   // largest first (workgroups start in index order and take the next entity as they finish): a big entity started last
   // would be the tail of the launch
-  if (count > 1 && count <= SORT_CAP)
-    hipLaunchKernelGGL(re_sort_class_kernel, dim3(1), dim3(1024), 0, s, const_cast<int32_t*>(B.order) + begin, count,
-                       B.ent_nnz_ptr);
+  launch_sort_class(const_cast<int32_t*>(B.order) + begin, count, B.ent_nnz_ptr, s);
   hipLaunchKernelGGL((re_solve_team_kernel<NW, false>), dim3(grid), dim3(WAVE * NW), 0, s, B, O, o, theta0, begin,
                      count, scratch, slot_doubles, max_p, static_cast<TeamSync*>(nullptr), 1);
   return hipGetLastError();
@@ -869,9 +881,7 @@ hipError_t launch_solve_grid(const BatchDev& B, const OutDev& O, const SolvePara
   // the counters at the head of every team's TeamSync, in one call (a memset per team was 128 launches per tier)
   err = hipMemset2DAsync(sync_buf, sizeof(TeamSync), 0, 64, (size_t)teams, s);
   if (err != hipSuccess) return err;
-  if (count > 1 && count <= SORT_CAP)
-    hipLaunchKernelGGL(re_sort_class_kernel, dim3(1), dim3(1024), 0, s, const_cast<int32_t*>(B.order) + begin, count,
-                       B.ent_nnz_ptr);
+  launch_sort_class(const_cast<int32_t*>(B.order) + begin, count, B.ent_nnz_ptr, s);
   hipLaunchKernelGGL((re_solve_team_kernel<TEAM_GRID_NW, true>), dim3(blocks), dim3(WAVE * TEAM_GRID_NW), 0, s, B, O, o,
                      theta0, begin, count, scratch, slot_doubles, max_p, static_cast<TeamSync*>(sync_buf), teams);
   return hipGetLastError();

@@ -439,7 +439,6 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
 #endif
                                             ) {
   const int n = P.n, p = P.p, ic = P.ic, m = o.m;
-  const double* __restrict__ x = W.x;
   const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
   const double inv_n = o.sum_loss ? 1.0 : 1.0 / (double)n;
 #ifdef GDMIX_TEAM_PROFILE

@@ -148,18 +148,21 @@ __device__ __forceinline__ double wreg_eval(const WregLds& L, const SolveParams&
 
 // One evaluation site, one line-search site: the solve is written as a loop around "evaluate f, g at the
 // current trial point" so that the (large) inlined eval body and its exp/log temporaries exist once.
-template <int EPL>
-__device__ __forceinline__ void wreg_solve(const WregLds& L, const SolveParams& o, int lane, int n, int p, int ic,
-                                           WregState<EPL>& V, SolveStats& out) {
+// The driver is written against an evaluator `eval(xt, g) -> f` (g <- gradient at the point xt held in registers, coefficient
+// lane + 64 s in slot s; f, and with it every decision below, uniform over the wavefront): wreg_eval below for an entity that
+// lives in one wavefront's LDS, the workgroup-cooperative evaluation of re_solve_tall.hpp for tall entities (every wavefront of
+// the workgroup then runs this driver on identical inputs and so takes identical decisions). rho / alpha / lsp: this
+// wavefront's uniform state in LDS.
+template <int EPL, class Eval>
+__device__ __forceinline__ void wreg_solve_ev(double* const rho, double* const alpha, LineSearch* const lsp, const SolveParams& o,
+                                              WregState<EPL>& V, SolveStats& out, Eval&& eval) {
   double S[M_REG][EPL], Y[M_REG][EPL];
 #pragma unroll
   for (int a = 0; a < M_REG; ++a) {
 #pragma unroll
     for (int s = 0; s < EPL; ++s) { S[a][s] = 0.0; Y[a][s] = 0.0; }
   }
-  double* const rho = L.rho;      // every lane stores the same value: uniform LDS state
-  double* const alpha = L.alpha;
-  const int m = o.m;
+  const int m = o.m;   // rho, alpha: every lane stores the same value (uniform LDS state)
   int cnt = 0;
   double theta = 1.0;
   int nit = 0, nfev = 0, status = -1, ifun = 0;
@@ -168,7 +171,7 @@ __device__ __forceinline__ void wreg_solve(const WregLds& L, const SolveParams& 
   for (;;) {
     // ---- f, g at the trial point; g'd, y'y and max|g| in one reduction pass (the first trial of a
     //      line search is accepted ~95% of the time, so y'y and max|g| are computed speculatively) -------
-    f = uniform_d(wreg_eval<EPL>(L, o, lane, n, p, ic, V.x, V.g));
+    f = uniform_d(eval(V.x, V.g));
     ++nfev;
     {
       double a = 0.0, b = 0.0, c = 0.0;
@@ -187,10 +190,10 @@ __device__ __forceinline__ void wreg_solve(const WregLds& L, const SolveParams& 
       first = false;
       if (sbgnrm <= o.pgtol) { status = 0; break; }
     } else {
-      LineSearch LS = *L.ls;
+      LineSearch LS = *lsp;
       const int task = dcsrch_step(LS, f, gd, stp);
       stp = uniform_d(stp);
-      *L.ls = LS;
+      *lsp = LS;
       if (task == LS_FG) {
         ++ifun;
         if (ifun - 1 < o.maxls) {
@@ -300,7 +303,7 @@ __device__ __forceinline__ void wreg_solve(const WregLds& L, const SolveParams& 
       {
         LineSearch LS;
         dcsrch_start(LS, f, gd, stp);
-        *L.ls = LS;
+        *lsp = LS;
       }
       ifun = 1;
       break;
@@ -325,6 +328,13 @@ __device__ __forceinline__ void wreg_solve(const WregLds& L, const SolveParams& 
   out.nit = nit;
   out.nfev = nfev;
   out.status = status;
+}
+
+template <int EPL>
+__device__ __forceinline__ void wreg_solve(const WregLds& L, const SolveParams& o, int lane, int n, int p, int ic,
+                                           WregState<EPL>& V, SolveStats& out) {
+  wreg_solve_ev<EPL>(L.rho, L.alpha, L.ls, o, V, out,
+                     [&](const double (&xt)[EPL], double (&g)[EPL]) { return wreg_eval<EPL>(L, o, lane, n, p, ic, xt, g); });
 }
 
 }  // namespace gdmix

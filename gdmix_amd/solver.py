@@ -18,7 +18,7 @@ from .batch import RawBatch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgdmix_re.so")
 
-NUM_CLASSES = 60
+NUM_CLASSES = 62
 STATUS_NAMES = ("PGTOL", "FACTR", "MAXITER", "MAXFUN", "ABNORMAL")
 VAR_NONE, VAR_SIMPLE, VAR_FULL = 0, 1, 2
 VARIANCE_MODES = {None: VAR_NONE, "simple": VAR_SIMPLE, "SIMPLE": VAR_SIMPLE, "full": VAR_FULL, "FULL": VAR_FULL,
@@ -70,7 +70,7 @@ EXPORTED_SYMBOLS = (
     "gdmix_re_abi_version", "gdmix_re_last_error", "gdmix_re_default_opts", "gdmix_re_create",
     "gdmix_re_destroy", "gdmix_re_pack_workspace_bytes", "gdmix_re_pack", "gdmix_re_solve",
     "gdmix_re_solve_scratch_bytes", "gdmix_re_set_scratch", "gdmix_re_set_wave_lds_limit", "gdmix_re_score",
-    "gdmix_re_widen_workspace_bytes", "gdmix_re_widen", "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz",
+    "gdmix_re_widen_workspace_bytes", "gdmix_re_widen", "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz", "gdmix_re_set_tall_min_n", "gdmix_re_set_tall_split_n",
     "gdmix_fe_create", "gdmix_fe_destroy", "gdmix_fe_eval", "gdmix_fe_reduce_buffer", "gdmix_fe_step", "gdmix_fe_result",
     "gdmix_fe_last_eval_ms", "gdmix_fe_score", "gdmix_fe_hessian_diag",
     "gdmix_re_class_kernel_name", "gdmix_java_string_hash", "gdmix_java_partition_id",
@@ -130,6 +130,8 @@ def load_library():
                                    C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gdmix_fe_last_eval_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.gdmix_re_set_team_nnz.argtypes = [C.c_void_p, C.c_int64]
+    lib.gdmix_re_set_tall_min_n.argtypes = [C.c_void_p, C.c_int]
+    lib.gdmix_re_set_tall_split_n.argtypes = [C.c_void_p, C.c_int]
     lib.gdmix_re_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.gdmix_re_last_solve_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.gdmix_re_score.argtypes = [C.c_void_p, C.POINTER(_Packed), C.c_int, C.c_void_p, C.c_void_p,
@@ -141,7 +143,7 @@ def load_library():
     lib.gdmix_java_partition_id.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     lib.gdmix_java_partition_id.restype = C.c_int32
     lib.gdmix_java_partition_ids_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
-    if lib.gdmix_re_abi_version() != 4:
+    if lib.gdmix_re_abi_version() != 5:
         raise GdmixReError("libgdmix_re.so ABI version mismatch")
     _lib = lib
     return lib
@@ -345,6 +347,16 @@ class REDeviceSolver:
     def set_team_nnz(self, nnz: int):
         """Entities with >= nnz non-zeros (below the giant threshold) are solved by the team tiers of the persistent kernel (0 = never)."""
         _check(self.lib.gdmix_re_set_team_nnz(self._h, int(nnz)), "set_team_nnz")
+
+    TALL_MIN_N_DEFAULT = 32
+
+    def set_tall_min_n(self, min_n: int):
+        """Entities with at most 64 coefficients and at least min_n samples are solved by the tall kernel (0 = never)."""
+        _check(self.lib.gdmix_re_set_tall_min_n(self._h, int(min_n)), "set_tall_min_n")
+
+    def set_tall_split_n(self, split_n: int):
+        """Tall entities of at least split_n samples get a CU each; smaller ones share a CU (eight single-wavefront workgroups)."""
+        _check(self.lib.gdmix_re_set_tall_split_n(self._h, int(split_n)), "set_tall_split_n")
 
     def set_timing(self, enabled: bool):
         _check(self.lib.gdmix_re_set_timing(self._h, int(bool(enabled))), "set_timing")

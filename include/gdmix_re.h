@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GDMIX_RE_ABI_VERSION 4
+#define GDMIX_RE_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define GDMIX_API __attribute__((visibility("default")))
@@ -140,7 +140,7 @@ typedef struct {
   int32_t        max_p, max_n, max_nnz;  /* per-entity maxima over the batch (host, after pack)     */
 } gdmix_re_packed;
 
-#define GDMIX_RE_NUM_CLASSES 60
+#define GDMIX_RE_NUM_CLASSES 62
 
 /* ---- solver options (defaults = REParams/LRParams defaults + scipy defaults) ----------------------
  * base_lr_params.py:22-27, binary_logistic_regression.py:223-231 (pgtol/maxfun/maxls are scipy's). */
@@ -242,6 +242,18 @@ GDMIX_API int gdmix_re_set_kernel_mask(gdmix_re_ctx* ctx, int mask);
  * the device-wide tier. Results do not depend on the thresholds beyond summation order. */
 GDMIX_API int gdmix_re_set_giant_nnz(gdmix_re_ctx* ctx, int64_t giant_nnz);
 GDMIX_API int gdmix_re_set_team_nnz(gdmix_re_ctx* ctx, int64_t team_nnz);
+
+/* Tall and skinny entities — at most 64 coefficients and at least `min_n` samples (MovieLens per-user / per-movie random
+ * effects: up to ~54 k samples for 25 coefficients) — are solved by one workgroup each, the samples over all its lanes, the
+ * L-BFGS driver replicated in every wavefront's registers (csrc/re_solve_tall.hip). 0 = never. Results do not depend on the
+ * threshold beyond summation order. */
+#define GDMIX_RE_TALL_MIN_N_DEFAULT 32
+GDMIX_API int gdmix_re_set_tall_min_n(gdmix_re_ctx* ctx, int min_n);
+/* Tall entities of at least `split_n` samples get a CU each (a workgroup of eight wavefronts); smaller ones share a CU,
+ * eight single-wavefront workgroups at a time, so that one entity's L-BFGS driver (a latency-bound chain in one
+ * wavefront) runs while the others' passes over their samples do. */
+#define GDMIX_RE_TALL_SPLIT_N_DEFAULT 4096
+GDMIX_API int gdmix_re_set_tall_split_n(gdmix_re_ctx* ctx, int split_n);
 
 /* Optional kernel timing: when enabled, gdmix_re_solve brackets each size class's kernel launch with
  * HIP events on the caller's stream; gdmix_re_last_solve_ms waits for them and returns the elapsed

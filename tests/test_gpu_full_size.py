@@ -90,16 +90,35 @@ def _full_size_properties(device_solver, raw, n, z, ones, take, label, min_pgtol
     sub_ptr = np.concatenate([[0], np.cumsum(np.diff(coef_ptr)[sample])])
     assert np.array_equal(np.diff(sub_ptr), np.diff(pk["ent_feat_ptr"]) + 1)
     err = per_entity_rel_err(sub_theta, ref["theta"], sub_ptr)
-    same = sw & (res["nit"][sample] == ref["nit"]) & (res["status"][sample] == ref["status"])
-    print(f"   oracle sample: {sample.size} entities ({int(sw.sum())} well-posed) over {len(taken)} classes, {int(z[sample].sum())} non-zeros; "
-          f"same nit and stop on {int(same.sum())}; worst theta rel err {err[same].max():.2e}")
+    # Which entities can be compared iteration for iteration is decided the way tests/golden/generate_exit_fixtures.py decides
+    # it for the reference: the checker is run again from a start moved by rounding-sized noise (1e-14); where it does not
+    # reproduce its own answer (long runs on weakly regularised entities: f is divided by n, so a 131 072-sample entity of
+    # 65 537 coefficients has lambda / n = 7.6e-6 and its coefficients are determined by the stop test only to ~1e-4), only
+    # the outcome is comparable: a stop on the gradient test on both sides, the same objective value to 1e-6.
+    noise = 1e-14 * np.random.default_rng(3).standard_normal(int(sub_ptr[-1]))
+    _, ref2 = oracle_solve_parallel(hb, KW, theta0=noise)
+    wobble = per_entity_rel_err(ref2["theta"], ref["theta"], sub_ptr)
+    strict = sw & (wobble <= 1e-9) & (ref2["nit"] == ref["nit"]) & (ref2["status"] == ref["status"])
+    same = strict & (res["nit"][sample] == ref["nit"]) & (res["status"][sample] == ref["status"])
+    print(f"   oracle sample: {sample.size} entities ({int(sw.sum())} well-posed, {int(strict.sum())} of them reproduced by the checker under 1e-14 noise) "
+          f"over {len(taken)} classes, {int(z[sample].sum())} non-zeros; same nit and stop on {int(same.sum())}; worst theta rel err {err[same].max():.2e}")
+    for k in np.argsort(-np.where(sw, err, 0.0))[:4]:
+        e = int(sample[k])
+        print(f"      entity {e}: class {names[cls[e]]}, n={int(n[e])} nnz={int(z[e])} p={int(np.diff(coef_ptr)[e])} nit={int(res['nit'][e])}/{int(ref['nit'][k])} "
+              f"gnorm={res['gnorm'][e]:.2e}/{ref['gnorm'][k]:.2e} f={res['fval'][e]:.15g}/{ref['fval'][k]:.15g} theta rel err {err[k]:.2e} "
+              f"(checker vs itself {wobble[k]:.2e})")
+    assert strict.sum() >= 0.97 * sw.sum()
     assert err[same].max() <= REL_TOL_DEVICE
     # long sums in another order can move a stop test that was decided at rounding level: such entities must be rare and
     # still within the north star's tolerance
-    differ = sw & ~same
+    differ = strict & ~same
     assert differ.sum() <= max(1, sw.sum() // 200), (int(differ.sum()), sample[differ][:10])
     if differ.any():
         assert err[differ].max() <= REL_TOL_NORTH_STAR, err[differ].max()
+    loose = sw & ~strict
+    if loose.any():
+        assert np.isin(res["status"][sample][loose], (0, 1)).all() and (res["gnorm"][sample][loose] <= 1e-5).all()
+        np.testing.assert_allclose(res["fval"][sample][loose], ref["fval"][loose], rtol=1e-6)
     return res, cls, names
 
 

@@ -54,7 +54,8 @@ def _check_pack(packed, pk, val):
     assert np.array_equal(packed.csc_val().cpu().numpy(), csc_val)
 
 
-def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, giant_nnz=16777216, team_nnz=16384):
+def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, giant_nnz=16777216, team_nnz=16384, tall_min_n=0):
+    """tall_min_n: 0 keeps the tall kernel out of the way of the routing under test; None = the library's default."""
     b, opts, exp, _ = load_fixture(name)
     kw = opts_kwargs(opts)
     pk = oracle.pack(b.ent_row_ptr, b.row_nnz_ptr, b.col_global)
@@ -65,6 +66,7 @@ def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, gian
     device_solver.set_kernel_mask(kernel_mask)
     device_solver.set_giant_nnz(giant_nnz)
     device_solver.set_team_nnz(team_nnz)
+    device_solver.set_tall_min_n(device_solver.TALL_MIN_N_DEFAULT if tall_min_n is None else tall_min_n)
     try:
         res = device_solver.solve(packed, SolverOptions(**kw), theta0=th0).to_host()
     finally:
@@ -72,6 +74,7 @@ def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, gian
         device_solver.set_kernel_mask(7)
         device_solver.set_giant_nnz(16777216)
         device_solver.set_team_nnz(16384)
+        device_solver.set_tall_min_n(device_solver.TALL_MIN_N_DEFAULT)
     ref = oracle.solve(pk, b.val, b.y, b.offset, b.weight, oracle.make_opts(**kw), theta0=th0)
     coef_ptr = packed.coef_ptr_host()
     wp = parity_mask(b, opts, exp)
@@ -106,13 +109,23 @@ def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, gian
         conv = dg & (res["status"] == 0)
         assert np.all(res["gnorm"][conv] <= 1e-5)
     check_d_class(b, opts, exp, res, name)
-    return err[wp].max()
+    return dict(device_solver.class_counts(packed)), np.diff(coef_ptr), kw
 
 
 @pytest.mark.parametrize("name", fixture_names())
 def test_default_routing_matches_reference_fixture(device_solver, name):
-    """Default routing: quad kernel (4 entities / wavefront) for p <= 64, register wave kernel above."""
-    _solve_and_compare(device_solver, name)
+    """Default routing: group kernels by size class, the tall kernel for p <= 64 with many samples, team kernels above."""
+    _solve_and_compare(device_solver, name, tall_min_n=None)
+
+
+@pytest.mark.parametrize("name", fixture_names())
+def test_tall_kernel_matches_reference_fixture(device_solver, name):
+    """Every entity with at most 64 coefficients (whatever its sample count: threshold 1) through the tall kernel — one
+    workgroup per entity, the L-BFGS driver replicated in every wavefront; the others keep their default routing."""
+    counts, p, kw = _solve_and_compare(device_solver, name, tall_min_n=1)
+    want = int((p <= 64).sum()) if kw["m"] <= 10 else 0
+    got = counts["re_solve_tall_kernel<8> p<=64"] + counts["re_solve_tall_kernel<1> p<=64"]
+    assert got == want, (got, want)
 
 
 VARIANT_FIXTURES = ["ref_fixture_l2_0.1", "ref_dataset1", "ref_dataset2", "c2_shipped_cfg", "c2_defaults", "c2_l2_1e-3",
