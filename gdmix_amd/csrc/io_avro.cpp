@@ -81,6 +81,21 @@ struct BufferCache {
   }
 };
 BufferCache g_buffers;
+}  // namespace
+namespace gdmix_io_detail {
+size_t buffers_trim() {   // gdmix_io_pool_trim: release the idle byte buffers
+  std::vector<std::string> idle;
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_buffers.mu);
+    idle.swap(g_buffers.free_list);
+    bytes = g_buffers.bytes;
+    g_buffers.bytes = 0;
+  }
+  return bytes;
+}
+}  // namespace gdmix_io_detail
+namespace {
 
 // Encode blocks [0, n_blocks) with `encode(first record, last record, payload)` on `threads` threads and append them to the
 // file in order. The workers take block numbers from a counter and encode into a ring of buffers; the calling thread writes

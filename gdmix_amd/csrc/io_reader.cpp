@@ -673,7 +673,10 @@ int parallel_for(int64_t count, int threads, Fn&& fn, int64_t chunk = 256) {
 // The arrays of a batch are hundreds of MB: a fresh malloc maps them, the decode pass faults every page in and free() unmaps
 // them again — on a 128-thread host that was half the wall time of a read. Blocks of at least POOL_MIN bytes are therefore kept
 // (already faulted in) when a batch is freed and handed out again to the next read of a similar size, up to GDMIX_IO_POOL_MB
-// (default 4096) of idle blocks. A 32-byte header in front of every block holds its capacity.
+// of idle blocks — default 4096 MB divided by the number of worker processes on the node (LOCAL_WORLD_SIZE, as
+// torch.distributed.run exports it), at least 512 MB: eight workers each holding 4 GB of idle pages would pin 32 GB that free()
+// used to return. gdmix_io_pool_trim() releases every idle block (the drivers call it when a stage's partitions are done).
+// A 32-byte header in front of every block holds its capacity.
 constexpr size_t POOL_MIN = (size_t)1 << 20, POOL_HDR = 32;
 struct PoolBlock { void* base; size_t cap; };
 std::mutex g_pool_mu;
@@ -683,7 +686,13 @@ size_t g_pool_bytes = 0;
 size_t pool_limit() {
   static size_t lim = [] {
     const char* e = getenv("GDMIX_IO_POOL_MB");
-    const long long mb = e ? atoll(e) : 4096;
+    long long mb = 4096;
+    if (e) {
+      mb = atoll(e);
+    } else if (const char* l = getenv("LOCAL_WORLD_SIZE")) {
+      const long long workers = atoll(l);
+      if (workers > 1) mb = 4096 / workers < 512 ? 512 : 4096 / workers;
+    }
     return (size_t)(mb < 0 ? 0 : mb) << 20;
   }();
   return lim;
@@ -724,11 +733,25 @@ void pool_free(void* p) {
   free(base);
 }
 
+size_t pool_trim() {
+  std::vector<PoolBlock> idle;
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    idle.swap(g_pool);
+    bytes = g_pool_bytes;
+    g_pool_bytes = 0;
+  }
+  for (auto& b : idle) free(b.base);
+  return bytes;
+}
+
 }  // namespace
 namespace gdmix_io_detail {
 // the array pool for io_avro.cpp (model tables come and go like partitions do)
 void* pool_alloc(size_t bytes) { return pool_malloc(bytes); }
 void pool_release(void* p) { pool_free(p); }
+size_t buffers_trim();   // io_avro.cpp: the writers' byte buffers
 }  // namespace gdmix_io_detail
 namespace {
 
@@ -746,6 +769,8 @@ GDMIX_IO_API int gdmix_io_abi_version(void) { return GDMIX_IO_ABI_VERSION; }
 GDMIX_IO_API const char* gdmix_io_last_error(void) { return g_err; }
 GDMIX_IO_API uint32_t gdmix_io_crc32c(const void* data, size_t len) { return crc32c((const uint8_t*)data, len); }
 GDMIX_IO_API uint32_t gdmix_io_masked_crc32c(const void* data, size_t len) { return masked(crc32c((const uint8_t*)data, len)); }
+
+GDMIX_IO_API size_t gdmix_io_pool_trim(void) { return pool_trim() + gdmix_io_detail::buffers_trim(); }
 
 GDMIX_IO_API void gdmix_io_free(gdmix_io_batch* b) {
   if (!b) return;

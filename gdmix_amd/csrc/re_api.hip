@@ -299,6 +299,32 @@ GDMIX_API int gdmix_re_set_scratch(gdmix_re_ctx* ctx, void* scratch, size_t byte
   return GDMIX_RE_OK;
 }
 
+// diag((X~' D X~ + (l2 + 1e-12) I - l2 e0 e0')^-1) of every entity at `theta` (binary_logistic_regression.py:181-187): one
+// wavefront per entity up to p = 2048, the whole device on one entity at a time above (re_variance_big.hip).
+static int run_variance_full(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const BatchDev& B, const SolveParams& P, const double* theta,
+                             double* variance, hipStream_t s) {
+  const size_t vslot = var_full_slot_doubles(var_small_p(b));
+  int vslots = var_slots_for(b);
+  size_t avail = ctx->impl.scratch ? ctx->impl.scratch_bytes : 0;
+  void* base = ctx->impl.scratch;
+  if (b->scratch_bytes > avail) { avail = b->scratch_bytes; base = b->scratch; }
+  if ((size_t)vslots * vslot * 8 > avail) vslots = (int)(avail / (vslot * 8)) & ~3;
+  if (vslots < 4) {
+    set_error("variance_mode FULL needs >= %zu bytes of scratch (gdmix_re_set_scratch)", 4 * vslot * 8);
+    return GDMIX_RE_ENOMEM;
+  }
+  HIP_TRY(launch_variance_full(B, b->E, P, theta, variance, static_cast<double*>(base), vslot, vslots, var_small_p(b), s));
+  if (b->max_p > VAR_FULL_MAX_P) {   // the large entities one by one, the whole device on each
+    if (var_full_big_doubles(b->max_p, b->max_n) * 8 > avail) {
+      set_error("variance_mode FULL with p = %d needs >= %zu bytes of scratch (gdmix_re_set_scratch)", b->max_p,
+                var_full_big_doubles(b->max_p, b->max_n) * 8);
+      return GDMIX_RE_ENOMEM;
+    }
+    HIP_TRY(launch_variance_full_big(&ctx->impl, B, b->E, P, theta, variance, static_cast<double*>(base), b->max_p, b->max_n, s));
+  }
+  return GDMIX_RE_OK;
+}
+
 GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const gdmix_re_opts* opts, const double* theta0,
                    const gdmix_re_result* out, void* stream) {
   if (!ctx || !b || !opts || !out) { set_error("NULL argument"); return GDMIX_RE_EINVAL; }
@@ -484,27 +510,27 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     }
   }
   if (opts->variance_mode == GDMIX_RE_VAR_FULL) {
-    const size_t vslot = var_full_slot_doubles(var_small_p(b));
-    int vslots = var_slots_for(b);
-    size_t avail = ctx->impl.scratch ? ctx->impl.scratch_bytes : 0;
-    void* base = ctx->impl.scratch;
-    if (b->scratch_bytes > avail) { avail = b->scratch_bytes; base = b->scratch; }
-    if ((size_t)vslots * vslot * 8 > avail) vslots = (int)(avail / (vslot * 8)) & ~3;
-    if (vslots < 4) {
-      set_error("variance_mode FULL needs >= %zu bytes of scratch (gdmix_re_set_scratch)", 4 * vslot * 8);
-      return GDMIX_RE_ENOMEM;
-    }
-    HIP_TRY(launch_variance_full(B, b->E, P, out->theta, out->variance, static_cast<double*>(base), vslot, vslots, var_small_p(b), s));
-    if (b->max_p > VAR_FULL_MAX_P) {   // the large entities one by one, the whole device on each
-      if (var_full_big_doubles(b->max_p, b->max_n) * 8 > avail) {
-        set_error("variance_mode FULL with p = %d needs >= %zu bytes of scratch (gdmix_re_set_scratch)", b->max_p,
-                  var_full_big_doubles(b->max_p, b->max_n) * 8);
-        return GDMIX_RE_ENOMEM;
-      }
-      HIP_TRY(launch_variance_full_big(&ctx->impl, B, b->E, P, out->theta, out->variance, static_cast<double*>(base), b->max_p, b->max_n, s));
-    }
+    const int rc = run_variance_full(ctx, b, B, P, out->theta, out->variance, s);
+    if (rc != GDMIX_RE_OK) return rc;
   }
   return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_re_variance_full(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const gdmix_re_opts* opts, const double* theta,
+                                     double* variance, void* stream) {
+  if (!ctx || !b || !opts || !theta || !variance) { set_error("NULL argument"); return GDMIX_RE_EINVAL; }
+  if (b->max_p > VAR_FULL_BIG_MAX_P) {
+    set_error("variance_mode FULL densifies a p x p Hessian per entity; largest entity has p = %d > %lld", b->max_p, (long long)VAR_FULL_BIG_MAX_P);
+    return GDMIX_RE_ERANGE;
+  }
+  if (b->E == 0) return GDMIX_RE_OK;
+  HIP_TRY(hipSetDevice(ctx->impl.device));
+  SolveParams P;
+  P.l2 = opts->l2; P.ftol = opts->ftol; P.pgtol = opts->pgtol; P.threshold = opts->threshold;
+  P.regularize_bias = opts->regularize_bias; P.has_intercept = opts->has_intercept ? 1 : 0; P.m = opts->m; P.max_iter = opts->max_iter;
+  P.maxfun = opts->maxfun; P.maxls = opts->maxls; P.variance_mode = GDMIX_RE_VAR_FULL;
+  P.sum_loss = 0; P.linear = 0;
+  return run_variance_full(ctx, b, make_batch_dev(b), P, theta, variance, static_cast<hipStream_t>(stream));
 }
 
 GDMIX_API int gdmix_re_score(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int has_intercept, const double* theta,

@@ -268,23 +268,29 @@ size_t var_full_big_doubles(int64_t max_p, int64_t max_n) {
 
 hipError_t launch_variance_full_big(gdmix_ctx_impl* ci, const BatchDev& B, int64_t E, const SolveParams& o, const double* theta,
                                     double* variance, double* scratch, int64_t max_p, int64_t max_n, hipStream_t s) {
-  constexpr int CAP = 256;   // large entities per call of the list kernel
-  VfEntity* list = nullptr;
-  hipError_t rc = hipMalloc(&list, sizeof(VfEntity) * CAP + 64);
-  if (rc != hipSuccess) return rc;
-  int32_t* count = reinterpret_cast<int32_t*>(list + CAP);
-  std::vector<VfEntity> host(CAP);
+  // the large entities: counted first (cap 0: the list kernel only counts), then listed — however many there are
   const int ic = o.has_intercept ? 1 : 0;
-  int32_t n_big = 0;
-  rc = hipMemsetAsync(count, 0, 4, s);
+  int32_t* count = nullptr;
+  hipError_t rc = hipMalloc(&count, 64);
+  if (rc != hipSuccess) return rc;
   int g = (int)((E + 255) / 256);
   if (g > 2048) g = 2048;
-  if (rc == hipSuccess) hipLaunchKernelGGL(vf_list_kernel, dim3(g), dim3(256), 0, s, B, E, ic, (int)VAR_FULL_MAX_P, list, count, CAP);
+  int32_t n_big = 0;
+  rc = hipMemsetAsync(count, 0, 4, s);
+  if (rc == hipSuccess) hipLaunchKernelGGL(vf_list_kernel, dim3(g), dim3(256), 0, s, B, E, ic, (int)VAR_FULL_MAX_P, static_cast<VfEntity*>(nullptr), count, 0);
   if (rc == hipSuccess) rc = hipMemcpyAsync(&n_big, count, 4, hipMemcpyDeviceToHost, s);
   if (rc == hipSuccess) rc = hipStreamSynchronize(s);
-  if (rc == hipSuccess && n_big > CAP) { (void)hipFree(list); return hipErrorInvalidValue; }   // the caller reports the limit
-  if (rc == hipSuccess && n_big) rc = hipMemcpy(host.data(), list, sizeof(VfEntity) * (size_t)n_big, hipMemcpyDeviceToHost);
+  if (rc != hipSuccess || n_big == 0) { (void)hipFree(count); return rc; }
+  VfEntity* list = nullptr;
+  rc = hipMalloc(&list, sizeof(VfEntity) * (size_t)n_big);
+  if (rc != hipSuccess) { (void)hipFree(count); return rc; }
+  std::vector<VfEntity> host((size_t)n_big);
+  rc = hipMemsetAsync(count, 0, 4, s);
+  if (rc == hipSuccess) hipLaunchKernelGGL(vf_list_kernel, dim3(g), dim3(256), 0, s, B, E, ic, (int)VAR_FULL_MAX_P, list, count, n_big);
+  if (rc == hipSuccess) rc = hipMemcpyAsync(host.data(), list, sizeof(VfEntity) * (size_t)n_big, hipMemcpyDeviceToHost, s);
+  if (rc == hipSuccess) rc = hipStreamSynchronize(s);
   (void)hipFree(list);
+  (void)hipFree(count);
   if (rc != hipSuccess) return rc;
   const size_t ldmax = (size_t)(max_p + VF_T - 1) / VF_T * VF_T;
   double* H = scratch;

@@ -57,11 +57,11 @@ class FixedLRParams(LRParams):
 def shard_input_files(input_path, num_shards, shard_index):
     """util/distribution_utils.py:11-47: every entry of the directory (glob '*': whatever its suffix, dot-files
     excluded), sorted, strided over the workers; with fewer files than workers, worker w gets file w (or nothing).
-    Entries that are not record files (Spark's zero-byte `_SUCCESS` marker) take part in the striding exactly as they
-    do upstream and then contribute no records."""
+    Entries that are not record files (Spark's zero-byte `_SUCCESS` marker, sub-directories: upstream's glob returns them too)
+    take part in the striding exactly as they do upstream and then contribute no records (read_per_record_files)."""
     assert 0 <= shard_index < num_shards and num_shards >= 1
     pattern = os.path.join(input_path, "*") if os.path.isdir(input_path) else input_path
-    files = sorted(f for f in glob.glob(pattern) if not os.path.isdir(f))
+    files = sorted(glob.glob(pattern))
     assert len(files) > 0, f"{input_path} is empty"
     if len(files) < num_shards:
         return [files[shard_index]] if shard_index < len(files) else []
@@ -73,7 +73,7 @@ def read_per_record_files(files, metadata: DatasetMetadata, feature_bag, num_fea
     """tf.train.Example records -> flat sample arrays (CSR over samples). Columns that the metadata does not list are
     defaults: offset 0, weight 1, label 0 (fixed_effect_lr_lbfgs_model.py:255-258,345-346). native None: libgdmix_io.so
     when built (same rules; tests/test_fe_model.py compares the two)."""
-    files = [f for f in files if os.path.getsize(f) > 0]   # zero-byte entries (`_SUCCESS`) hold no records
+    files = [f for f in files if os.path.isfile(f) and os.path.getsize(f) > 0]   # zero-byte entries (`_SUCCESS`) and directories hold no records
     names = set(metadata.get_feature_names()) | set(metadata.get_label_names())
     has = lambda n: n is not None and n in names
     has_label, has_offset, has_weight = has(label_name), has(offset_name), has(weight_name)
@@ -247,7 +247,7 @@ class FixedEffectLRModelLBFGS:
                 th = theta if bag else theta[1:]
                 local = to_local(th, uniq, self.num_features if bag else 0, self.has_intercept, dummy)
                 logit, per = fe.solver.score(packed, local)
-                per_coord = per.cpu().numpy()
+                per_coord = per.cpu().numpy()[:n]    # (a shard without any non-zero carries one padding sample of weight 0)
         score = (per_coord.astype(np.float64) + data["offset"].astype(np.float64)).astype(np.float32)
         self._write_inference_result(data["uid"], data["y"] if data["has_label"] else None,
                                      data["weight"] if data["has_weight"] else None, score, per_coord, task_index, schema_params,

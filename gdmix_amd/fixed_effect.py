@@ -261,6 +261,10 @@ def _fit_stepping(self, row_nnz_ptr, col_global, val, y, num_features, offset=No
     D = 1 if dummy else int(num_features)   # the dummy zero feature of an intercept-only model occupies global index 0
     if not dummy and batch.col_global.size and (batch.col_global.min() < 0 or batch.col_global.max() >= D):
         raise ValueError(f"feature index outside [0, {D})")
+    # whether the variances can be computed is decided before any training (a job that trains for its whole budget and
+    # then dies on the variances loses the model)
+    if variance_mode is not None:
+        check_variance_request(str(variance_mode).upper(), D + (1 if has_intercept else 0), _world_size(group))
     s = self.solver
     packed = s.pack(batch, has_intercept=has_intercept)
     opts = SolverOptions(l2=l2, regularize_bias=bool(regularize_bias) and bool(has_intercept), has_intercept=has_intercept, m=m,
@@ -297,7 +301,7 @@ def _fit_stepping(self, row_nnz_ptr, col_global, val, y, num_features, offset=No
         # them (fixed_effect_lr_lbfgs_model.py:648-661, 271-305, 451-463)
         th = np.where(np.abs(theta) <= threshold, 0.0, theta)
         info["variances"] = _variances(s, prob, batch, th, D, has_intercept, float(l2), bool(regularize_bias) and bool(has_intercept),
-                                       str(variance_mode).upper(), all_reduce, group)
+                                       str(variance_mode).upper(), all_reduce, group, packed=packed, dummy=dummy)
         if dummy:
             info["variances"] = info["variances"][D:]
     if dummy:
@@ -308,10 +312,41 @@ def _fit_stepping(self, row_nnz_ptr, col_global, val, y, num_features, offset=No
     return theta, info
 
 
-FULL_VARIANCE_MAX_FEATURES = 4096   # FULL densifies a (D + 1) x (D + 1) Hessian, as the reference does
+# FULL densifies a (D + 1) x (D + 1) Hessian, as the reference does (fixed_effect_lr_lbfgs_model.py:291, 457: no limit there but
+# memory). Up to FULL_VARIANCE_HOST_MAX coefficients the matrix is built and inverted on the host exactly as the reference does
+# (several workers: summed with an all-reduce first); above that and up to FULL_VARIANCE_DEVICE_MAX on the device (tiled Cholesky
+# and inverse over the whole MI355X, csrc/re_variance_big.hip) — one worker only: the matrix is not all-reduced there.
+FULL_VARIANCE_HOST_MAX = 4096
+FULL_VARIANCE_DEVICE_MAX = 16384
+FULL_VARIANCE_MAX_FEATURES = FULL_VARIANCE_HOST_MAX   # (the name round 2 used)
 
 
-def _variances(solver, prob, batch, theta, D, has_intercept, l2, regularize_bias, mode, all_reduce, group):
+def _world_size(group=None):
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(group)
+    except ImportError:
+        pass
+    return 1
+
+
+def check_variance_request(mode, P, num_workers):
+    """Raise before any training if the variances asked for cannot be computed for a model of P coefficients."""
+    if mode == "SIMPLE":
+        return
+    if mode != "FULL":
+        raise ValueError(f"unknown variance mode {mode!r}")
+    if P > FULL_VARIANCE_DEVICE_MAX:
+        raise ValueError(f"fixed_effect_variance_mode FULL inverts a dense {P} x {P} matrix; at most {FULL_VARIANCE_DEVICE_MAX} "
+                         "coefficients (use SIMPLE for larger models)")
+    if P > FULL_VARIANCE_HOST_MAX and num_workers > 1:
+        raise ValueError(f"fixed_effect_variance_mode FULL with {P} coefficients is available on one worker only (above "
+                         f"{FULL_VARIANCE_HOST_MAX} the Hessian is built and inverted on the device, without an all-reduce); "
+                         f"this job has {num_workers} workers — use SIMPLE, or one worker")
+
+
+def _variances(solver, prob, batch, theta, D, has_intercept, l2, regularize_bias, mode, all_reduce, group, packed=None, dummy=False):
     """variance of every coefficient (intercept last). SIMPLE: 1 / (diag(X~' D X~) + l2 [regularised] + 1e-12), the diagonal by two
     more streaming passes on the device and the same all-reduce as an evaluation. FULL: diag((X~' D X~ + (l2 + 1e-12) I - l2
     [intercept unregularised])^-1): the dense matrix is built on the host from the shard (scipy), summed over the workers and
@@ -332,8 +367,20 @@ def _variances(solver, prob, batch, theta, D, has_intercept, l2, regularize_bias
         return 1.0 / (H + eps)
     if mode != "FULL":
         raise ValueError(f"unknown variance mode {mode!r}")
-    if P > FULL_VARIANCE_MAX_FEATURES:
-        raise ValueError(f"fixed_effect_variance_mode FULL inverts a dense {P} x {P} matrix; at most {FULL_VARIANCE_MAX_FEATURES} features")
+    check_variance_request(mode, P, _world_size(group))
+    if P > FULL_VARIANCE_HOST_MAX:
+        # on the device, in the shard's local index space (intercept first): the random-effect FULL variance of a one-entity
+        # batch is this very matrix (binary_logistic_regression.py:181-187 = fixed_effect_lr_lbfgs_model.py:296-305, 457-463).
+        # Features without a non-zero in the shard have a zero row and column in X~' D X~: their variance is 1 / (l2 + 1e-12).
+        uniq = packed.unique_global().cpu().numpy()
+        local = to_local(theta, uniq, D, has_intercept, dummy)
+        o = SolverOptions(l2=l2, regularize_bias=regularize_bias, has_intercept=has_intercept)
+        v_local = solver.variance_full(packed, o, local).cpu().numpy()
+        out = np.full(P, 1.0 / (l2 + eps))
+        out[uniq] = v_local[ic:]
+        if ic:
+            out[D] = v_local[0]
+        return out
     import scipy.sparse as sp
     n = batch.N
     X = sp.csr_matrix((batch.val.astype(np.float64), batch.col_global, batch.row_nnz_ptr), shape=(n, max(D, 1)))[:, :D]

@@ -12,7 +12,7 @@ from ..batch import RawBatch
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "libgdmix_io.so")
 ABI_VERSION = 4
-EXPORTED_SYMBOLS = ("gdmix_io_abi_version", "gdmix_io_last_error", "gdmix_io_read_grouped", "gdmix_io_free",
+EXPORTED_SYMBOLS = ("gdmix_io_abi_version", "gdmix_io_last_error", "gdmix_io_read_grouped", "gdmix_io_free", "gdmix_io_pool_trim",
                     "gdmix_io_crc32c", "gdmix_io_masked_crc32c", "gdmix_io_avro_write_models", "gdmix_io_avro_write_scores",
                     "gdmix_io_write_grouped", "gdmix_io_read_examples", "gdmix_io_avro_read_models", "gdmix_io_free_models", "gdmix_io_map_coefficients", "gdmix_io_ids_unique", "gdmix_io_match_ids")
 
@@ -73,6 +73,8 @@ def load_library():
     lib.gdmix_io_read_examples.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.POINTER(_Schema), C.POINTER(C.POINTER(_Batch))]
     lib.gdmix_io_free.argtypes = [C.POINTER(_Batch)]
     lib.gdmix_io_free.restype = None
+    lib.gdmix_io_pool_trim.argtypes = []
+    lib.gdmix_io_pool_trim.restype = C.c_size_t
     lib.gdmix_io_avro_write_models.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.POINTER(_ModelTable),
                                                C.c_int32, C.c_int32, C.c_int32]
     lib.gdmix_io_avro_write_scores.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p,
@@ -93,6 +95,12 @@ def load_library():
         raise GdmixIoError(f"{LIB_PATH}: ABI version {lib.gdmix_io_abi_version()}, expected {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+def pool_trim() -> int:
+    """Release the idle array blocks and writer buffers the library keeps between partitions (include/gdmix_io.h,
+    gdmix_io_pool_trim). Returns the bytes released; 0 if the library is not loaded."""
+    return int(_lib.gdmix_io_pool_trim()) if _lib is not None else 0
 
 
 def crc32c(data: bytes) -> int:

@@ -518,6 +518,9 @@ class RandomEffectLRLBFGSModel:
                 self._io_pool.shutdown(wait=True)
                 self._write_pool.shutdown(wait=True)
                 self._io_pool = self._write_pool = None
+            self._read_cache = None
+            from .io import native_reader
+            native_reader.pool_trim()    # the pooled host blocks (up to GDMIX_IO_POOL_MB + 1 GB of writer buffers) go back to the allocator
 
     def _read(self, input_path, tensor_metadata, schema_params, num_features, need_label):
         assert self.model_params.data_format == constants.TFRECORD

