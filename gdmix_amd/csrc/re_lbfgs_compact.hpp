@@ -10,10 +10,15 @@
 namespace gdmix {
 
 constexpr int TEAM_MCAP = 10;                 // history pairs the compact path keeps accumulators for
-constexpr int TEAM_K = 2 * TEAM_MCAP + 7;     // fused reduction width: sq, gd, gg, yy, yg, S'y, Y'y, r'd, max|g|
+constexpr int TEAM_K = 2 * TEAM_MCAP + 8;     // fused reduction width: sq, gd, gg, yy, yg, S'y, Y'y, r'd, moved, max|g|
 constexpr int TEAM_RD = 2 * TEAM_MCAP + 5;    // acc index of r'd
+constexpr int TEAM_MV = 2 * TEAM_MCAP + 6;    // acc index of "the point of this evaluation differs from the previous one's"
 // acc[] layout, with y = g - r (r = the gradient at the last accepted iterate): 0 sum x_j^2 over regularised j, 1 g'd,
-// 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (chronological i < col), K-2 r'd, K-1 max|g_j|.
+// 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (chronological i < col), K-3 r'd, K-2 moved, K-1 max|g_j|.
+// moved: how many coefficients of this evaluation's point differ from the previously evaluated point (counted by the thread
+// that formed the trial, compact_update_n below; a sum of small integers: exact in any order). nfev is scipy's funcalls:
+// ScalarFunction serves a point equal to the previous one from its cache without counting it (re_solve_quad.hpp, quad_solve).
+// The fixed-effect stepping kernels do not fill it (memo = false: every evaluation counts).
 // r'd is the slope of the line search at its start, taken from the direction as it is actually used (after mainlb's
 // d = (x + d) - x): the small solve also yields g'd = -g'Hg algebraically, but the two differ once x dwarfs d (badly scaled
 // entities; tests/golden exit_hard_*, exit_extreme_*), and L-BFGS-B's line search runs on the former (lnsrlb: gd = ddot(g, d)).
@@ -51,6 +56,7 @@ struct CompactPlan {    // what the elementwise pass over the p-vectors has to d
   int action;           // CA_STOP: x is the result; CA_STOP_RESTORE: x := t first; CA_RETRY: x := t + stp d;
                         // CA_DIRECTION: store the pair, build d, x := x + stp d
   int store_pair, restore, slot, cnew, col, head, shift;   // shift: the oldest pair was dropped to make room (col == m)
+  int phantom;          // restore after a trial the reference would not have evaluated (g'd >= 0): it is not "the previous evaluation"
   double stp, stp_prev, gamma;
 };
 
@@ -65,14 +71,15 @@ struct CompactMats {    // the m x m part (LDS; every workgroup keeps a replica)
 // Called by every thread of a workgroup with identical arguments. Contains one __syncthreads() on the
 // CA_DIRECTION path.
 __device__ __forceinline__ void compact_advance(CompactState& S, const double* acc /* [TEAM_K], registers or LDS */, double f_new,
-                                                const SolveParams& o, CompactMats& L, CompactPlan& plan) {
+                                                const SolveParams& o, CompactMats& L, CompactPlan& plan, bool memo = false) {
   const int m = o.m;
-  ++S.nfev;
+  const bool counted = !memo || S.first || acc[TEAM_MV] != 0.0;
+  S.nfev += counted ? 1 : 0;
   const double gd = acc[1], gg = acc[2], rr = acc[3], yg = acc[4];
   bool restore = false, store_pair = false, shift = false, descent_lost = false;
   double dr = 0.0;
   const double stp_prev = S.stp;
-  plan.store_pair = 0; plan.restore = 0; plan.slot = 0; plan.cnew = 0; plan.shift = 0; plan.stp_prev = stp_prev;
+  plan.store_pair = 0; plan.restore = 0; plan.slot = 0; plan.cnew = 0; plan.shift = 0; plan.stp_prev = stp_prev; plan.phantom = 0;
   if (S.first) {
     S.first = 0;
     S.f = f_new;
@@ -86,7 +93,7 @@ __device__ __forceinline__ void compact_advance(CompactState& S, const double* a
       S.ls.ginit = g0; S.ls.gtest = LS_FTOL * g0; S.ls.gx = g0; S.ls.gy = g0;
       S.gdold = g0;
       if (g0 >= 0.0) {   // not a descent direction after all (lnsrlb info = -4; it would not have evaluated this trial)
-        --S.nfev;
+        S.nfev -= counted ? 1 : 0;
         descent_lost = true;
       }
     }
@@ -248,6 +255,7 @@ __device__ __forceinline__ void compact_advance(CompactState& S, const double* a
   plan.action = CA_DIRECTION;
   plan.store_pair = store_pair ? 1 : 0;
   plan.restore = restore ? 1 : 0;
+  plan.phantom = descent_lost ? 1 : 0;
   plan.slot = slot;
   plan.cnew = cnew;
   plan.shift = (store_pair && shift) ? 1 : 0;
@@ -273,14 +281,19 @@ static_assert(TEAM_MCAP == 10, "GDMIX_HIST_DISPATCH lists the counts 0..10");
 
 // The elementwise part of a step for coefficient j (CA_RETRY / CA_DIRECTION). Vectors as in Work; u, q from L.
 // HC >= plan.col: the number of history slots requested (GDMIX_HIST_DISPATCH(plan.col, ...) makes it equal).
+// Returns 1.0 if the new trial's coefficient j differs from the previously evaluated point's (after a restore: from the
+// restored iterate's, or if the abandoned search's last trial had moved it), else 0.0.
 template <int HC>
-__device__ __forceinline__ void compact_update_n(const CompactPlan& plan, const CompactMats& L, const Work& W, int p, int m, int j) {
+__device__ __forceinline__ double compact_update_n(const CompactPlan& plan, const CompactMats& L, const Work& W, int p, int m, int j) {
   if (plan.action == CA_RETRY) {
-    W.x[j] = plan.stp * W.d[j] + W.t[j];
-    return;
+    const double xn = plan.stp * W.d[j] + W.t[j];
+    const double moved = (xn != W.x[j]) ? 1.0 : 0.0;
+    W.x[j] = xn;
+    return moved;
   }
   const double gj = plan.restore ? W.r[j] : W.g[j];
   const double xj = plan.restore ? W.t[j] : W.x[j];
+  const bool failed_off = plan.restore && !plan.phantom && W.x[j] != W.t[j];
   double sn = 0.0, yn = 0.0;
   if (plan.store_pair) {
     sn = plan.stp_prev * W.d[j];   // exact for stp == 1
@@ -316,11 +329,13 @@ __device__ __forceinline__ void compact_update_n(const CompactPlan& plan, const 
   W.d[j] = dj;
   W.t[j] = xj;
   W.r[j] = gj;
-  W.x[j] = plan.stp * dj + xj;
+  const double xn = plan.stp * dj + xj;
+  W.x[j] = xn;
+  return (xn != xj || failed_off) ? 1.0 : 0.0;
 }
 
 __device__ __forceinline__ void compact_update(const CompactPlan& plan, const CompactMats& L, const Work& W, int p, int m, int j) {
-  compact_update_n<TEAM_MCAP>(plan, L, W, p, m, j);
+  (void)compact_update_n<TEAM_MCAP>(plan, L, W, p, m, j);
 }
 
 }  // namespace gdmix

@@ -120,11 +120,13 @@ struct LbfgsState {
   LineSearch ls;
   double f, fold, gdold, stp, theta, sbgnrm;
   int col, head, nit, nfev, ifun, status, first, iter0;
+  int counted, failed_at_t;   // nfev is scipy's funcalls (re_solve_quad.hpp, quad_solve): does the next evaluation count?
 };
 
 __device__ __forceinline__ void lbfgs_init(LbfgsState& T) {
   T.f = 0.0; T.fold = 0.0; T.gdold = 0.0; T.stp = 0.0; T.theta = 1.0; T.sbgnrm = 0.0;
   T.col = 0; T.head = 0; T.nit = 0; T.nfev = 0; T.ifun = 0; T.status = -1; T.first = 1; T.iter0 = 1;
+  T.counted = 1; T.failed_at_t = 1;
 }
 
 // One step of the driver: f_new and W.g are the objective and gradient at the trial point W.x. Advances the
@@ -137,7 +139,7 @@ __device__ void lbfgs_advance(G& grp, int p, const SolveParams& o, const Work& W
   const int m = o.m;
   double* alpha = W.alpha;
   double* rho = W.rho;
-  ++T.nfev;
+  T.nfev += T.counted ? 1 : 0;
   bool need_dir = false, restart = false;
   if (T.first) {
     T.first = 0;
@@ -154,7 +156,13 @@ __device__ void lbfgs_advance(G& grp, int p, const SolveParams& o, const Work& W
     if (task == LS_FG) {
       ++T.ifun;
       if (T.ifun - 1 < o.maxls) {
-        for (int j = grp.tid; j < p; j += grp.NT) W.x[j] = stp * W.d[j] + W.t[j];   // stp == 1: exactly t + d
+        double mv = 0.0;
+        for (int j = grp.tid; j < p; j += grp.NT) {
+          const double xn = stp * W.d[j] + W.t[j];   // stp == 1: exactly t + d
+          mv = (xn != W.x[j]) ? 1.0 : mv;
+          W.x[j] = xn;
+        }
+        T.counted = grp.max_nonneg(mv) != 0.0;
         grp.sync();
         return;
       }
@@ -201,7 +209,9 @@ __device__ void lbfgs_advance(G& grp, int p, const SolveParams& o, const Work& W
   }
   while (need_dir) {
     if (restart) {
-      for (int j = grp.tid; j < p; j += grp.NT) { W.x[j] = W.t[j]; W.g[j] = W.r[j]; }
+      double off = 0.0;   // the abandoned search's last trial: had it moved away from the iterate?
+      for (int j = grp.tid; j < p; j += grp.NT) { off = (W.x[j] != W.t[j]) ? 1.0 : off; W.x[j] = W.t[j]; W.g[j] = W.r[j]; }
+      T.failed_at_t = T.failed_at_t && (grp.max_nonneg(off) == 0.0);
       T.f = T.fold;
       restart = false;
       if (T.col == 0) { T.status = 4; grp.sync(); return; }
@@ -251,7 +261,14 @@ __device__ void lbfgs_advance(G& grp, int p, const SolveParams& o, const Work& W
     T.stp = stp;
     dcsrch_start(T.ls, T.f, gd, stp);
     T.ifun = 1;
-    for (int j = grp.tid; j < p; j += grp.NT) W.x[j] = stp * W.d[j] + W.t[j];
+    double mv = 0.0;
+    for (int j = grp.tid; j < p; j += grp.NT) {
+      const double xn = stp * W.d[j] + W.t[j];
+      mv = (xn != W.t[j]) ? 1.0 : mv;
+      W.x[j] = xn;
+    }
+    T.counted = (grp.max_nonneg(mv) != 0.0) || !T.failed_at_t;
+    T.failed_at_t = 1;
     grp.sync();
     need_dir = false;
   }

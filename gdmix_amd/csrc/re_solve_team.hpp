@@ -433,7 +433,7 @@ __device__ __forceinline__ void team_products(const Team<NW>& tm, const Work& W,
 // 1 g'd, 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (y = g - r; chronological i < col), K-2 r'd, K-1 max|g_j|.
 template <int NW>
 __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W,
-                                            int col, int head, double (&acc)[TEAM_K]
+                                            int col, int head, double moved, double (&acc)[TEAM_K]
 #ifdef GDMIX_TEAM_PROFILE
                                             , unsigned long long (&prof_t)[8], unsigned long long& prof_last
 #endif
@@ -450,6 +450,7 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
   // back: no synchronisation), so that the accumulators and the tile staging above are not live at the same time.
 #pragma unroll
   for (int k = 0; k < TEAM_K; ++k) acc[k] = 0.0;
+  acc[TEAM_MV] = moved;   // this thread's coefficients of the trial point that differ from the previously evaluated point
   GDMIX_HIST_DISPATCH(col, (team_products<NW, HC>(tm, W, p, m, col, head, first_reg, acc)))
   TEAM_PROF(2);
   tm.reduce(acc);
@@ -498,14 +499,15 @@ __device__ void team_solve(Team<NW>& tm, const EntityView& P, const SolveParams&
   TEAM_PROF_DECL
   for (int j = tm.tid; j < p; j += tm.NT) { W.d[j] = 0.0; W.r[j] = 0.0; }
   tm.sync();
+  double moved = 0.0;
   for (;;) {
 #ifdef GDMIX_TEAM_PROFILE
-    const double f_new = team_eval(tm, P, o, W, S.col, S.head, acc, prof_t, prof_last);
+    const double f_new = team_eval(tm, P, o, W, S.col, S.head, moved, acc, prof_t, prof_last);
 #else
-    const double f_new = team_eval(tm, P, o, W, S.col, S.head, acc);
+    const double f_new = team_eval(tm, P, o, W, S.col, S.head, moved, acc);
 #endif
     if (tm.aborted()) { ++S.nfev; S.status = GDMIX_RE_ST_ABORTED; break; }
-    compact_advance(S, acc, f_new, o, L.mats, plan);
+    compact_advance(S, acc, f_new, o, L.mats, plan, true);
     TEAM_PROF(4);
     if (plan.action == CA_STOP) break;
     if (plan.action == CA_STOP_RESTORE) {
@@ -513,8 +515,9 @@ __device__ void team_solve(Team<NW>& tm, const EntityView& P, const SolveParams&
       tm.sync();
       break;
     }
+    moved = 0.0;
     GDMIX_HIST_DISPATCH((plan.action == CA_DIRECTION ? plan.col : 0),
-                        for (int j = tm.tid; j < p; j += tm.NT) compact_update_n<HC>(plan, L.mats, W, p, m, j))
+                        for (int j = tm.tid; j < p; j += tm.NT) moved += compact_update_n<HC>(plan, L.mats, W, p, m, j))
     TEAM_PROF(5);
     tm.sync();
     TEAM_PROF(6);
@@ -548,7 +551,7 @@ struct TeamRegs {
 
 template <int NW, int EPL>
 __device__ __forceinline__ double team_eval_reg(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W,
-                                                TeamRegs<EPL>& R, int col, const double*& acc) {
+                                                TeamRegs<EPL>& R, int col, double moved, const double*& acc) {
   const int n = P.n, p = P.p, ic = P.ic;
   const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
   const double inv_n = o.sum_loss ? 1.0 : 1.0 / (double)n;
@@ -594,6 +597,10 @@ __device__ __forceinline__ double team_eval_reg(Team<NW>& tm, const EntityView& 
     }
   }
   GDMIX_TREG_VALUE(TEAM_RD, R.r[i] * R.d[i], false)
+  {
+    const double t_ = wave_sum(moved);
+    if (tm.lane == TEAM_MV) mine = t_;
+  }
   GDMIX_TREG_VALUE(TEAM_K - 1, fabs(R.g[i]), true)
 #undef GDMIX_TREG_VALUE
   acc = tm.template reduce_placed<TEAM_K>(mine);
@@ -603,13 +610,16 @@ __device__ __forceinline__ double team_eval_reg(Team<NW>& tm, const EntityView& 
 // The elementwise part of a step for the coefficient in register slot i (compact_update of re_lbfgs_compact.hpp with the
 // vectors in registers). Returns the new x_j.
 template <int EPL>
-__device__ __forceinline__ double compact_update_reg(const CompactPlan& plan, const CompactMats& L, TeamRegs<EPL>& R, int i, int m) {
+__device__ __forceinline__ double compact_update_reg(const CompactPlan& plan, const CompactMats& L, TeamRegs<EPL>& R, int i, int m, double& moved) {
   if (plan.action == CA_RETRY) {
-    R.x[i] = plan.stp * R.d[i] + R.t[i];
+    const double xn = plan.stp * R.d[i] + R.t[i];
+    moved += (xn != R.x[i]) ? 1.0 : 0.0;
+    R.x[i] = xn;
     return R.x[i];
   }
   const double gj = plan.restore ? R.r[i] : R.g[i];
   const double xj = plan.restore ? R.t[i] : R.x[i];
+  const bool failed_off = plan.restore && !plan.phantom && R.x[i] != R.t[i];
   if (plan.store_pair) {
     const double sn = plan.stp_prev * R.d[i];   // exact for stp == 1
     const double yn = R.g[i] - R.r[i];
@@ -642,6 +652,7 @@ __device__ __forceinline__ double compact_update_reg(const CompactPlan& plan, co
   R.t[i] = xj;
   R.r[i] = gj;
   R.x[i] = plan.stp * dj + xj;
+  moved += (R.x[i] != xj || failed_off) ? 1.0 : 0.0;
   return R.x[i];
 }
 
@@ -669,10 +680,11 @@ __device__ void team_solve_reg(Team<NW>& tm, const EntityView& P, const SolvePar
     if (j < p) st_x<true>(W.x + j, R.x[i]);
   }
   tm.sync();
+  double moved = 0.0;
   for (;;) {
-    const double f_new = team_eval_reg<NW, EPL>(tm, P, o, W, R, S.col, acc);
+    const double f_new = team_eval_reg<NW, EPL>(tm, P, o, W, R, S.col, moved, acc);
     if (tm.aborted()) { ++S.nfev; S.status = GDMIX_RE_ST_ABORTED; break; }
-    compact_advance(S, acc, f_new, o, L.mats, plan);
+    compact_advance(S, acc, f_new, o, L.mats, plan, true);
     if (plan.action == CA_STOP) break;
     if (plan.action == CA_STOP_RESTORE) {
 #pragma unroll
@@ -683,10 +695,11 @@ __device__ void team_solve_reg(Team<NW>& tm, const EntityView& P, const SolvePar
       tm.sync();
       break;
     }
+    moved = 0.0;
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
       const int j = (tm.wid + i * tm.nwaves) * WAVE + tm.lane;
-      if (j < p) st_x<true>(W.x + j, compact_update_reg<EPL>(plan, L.mats, R, i, m));
+      if (j < p) st_x<true>(W.x + j, compact_update_reg<EPL>(plan, L.mats, R, i, m, moved));
     }
     tm.sync();
   }

@@ -167,12 +167,14 @@ __device__ __forceinline__ void wreg_solve_ev(double* const rho, double* const a
   double theta = 1.0;
   int nit = 0, nfev = 0, status = -1, ifun = 0;
   bool iter0 = true, first = true;
+  // nfev is scipy's funcalls (see re_solve_quad.hpp, quad_solve): a trial point equal to the previously evaluated point is not counted
+  bool counted = true, failed_at_t = true;
   double f = 0.0, fold = 0.0, gd = 0.0, gdold = 0.0, rr = 0.0, stp = 0.0, sbgnrm = 0.0;
   for (;;) {
     // ---- f, g at the trial point; g'd, y'y and max|g| in one reduction pass (the first trial of a
     //      line search is accepted ~95% of the time, so y'y and max|g| are computed speculatively) -------
     f = uniform_d(eval(V.x, V.g));
-    ++nfev;
+    nfev += counted ? 1 : 0;
     {
       double a = 0.0, b = 0.0, c = 0.0;
 #pragma unroll
@@ -197,13 +199,14 @@ __device__ __forceinline__ void wreg_solve_ev(double* const rho, double* const a
       if (task == LS_FG) {
         ++ifun;
         if (ifun - 1 < o.maxls) {
-          if (stp == 1.0) {
+          bool mv = false;
 #pragma unroll
-            for (int s = 0; s < EPL; ++s) V.x[s] = V.xo[s] + V.d[s];
-          } else {
-#pragma unroll
-            for (int s = 0; s < EPL; ++s) V.x[s] = stp * V.d[s] + V.xo[s];
+          for (int s = 0; s < EPL; ++s) {
+            const double xn = (stp == 1.0) ? V.xo[s] + V.d[s] : stp * V.d[s] + V.xo[s];
+            mv = mv || (xn != V.x[s]);
+            V.x[s] = xn;
           }
+          counted = __ballot(mv) != 0ull;
           continue;
         }
         restart = true;   // iback >= maxls
@@ -243,8 +246,10 @@ __device__ __forceinline__ void wreg_solve_ev(double* const rho, double* const a
     // ---- new search direction (repeated from steepest descent after a line-search restart) -----------
     for (;;) {
       if (restart) {
+        bool off = false;   // the abandoned search's last trial: had it moved away from the iterate?
 #pragma unroll
-        for (int s = 0; s < EPL; ++s) { V.x[s] = V.xo[s]; V.g[s] = V.go[s]; }
+        for (int s = 0; s < EPL; ++s) { off = off || (V.x[s] != V.xo[s]); V.x[s] = V.xo[s]; V.g[s] = V.go[s]; }
+        failed_at_t = failed_at_t && (__ballot(off) == 0ull);
         f = fold;
         if (cnt == 0) { status = 4; break; }
         cnt = 0; theta = 1.0;
@@ -309,12 +314,16 @@ __device__ __forceinline__ void wreg_solve_ev(double* const rho, double* const a
       break;
     }
     if (status >= 0) break;
-    if (stp == 1.0) {
+    {
+      bool mv = false;
 #pragma unroll
-      for (int s = 0; s < EPL; ++s) V.x[s] = V.xo[s] + V.d[s];
-    } else {
-#pragma unroll
-      for (int s = 0; s < EPL; ++s) V.x[s] = stp * V.d[s] + V.xo[s];
+      for (int s = 0; s < EPL; ++s) {
+        const double xn = (stp == 1.0) ? V.xo[s] + V.d[s] : stp * V.d[s] + V.xo[s];
+        mv = mv || (xn != V.xo[s]);   // V.x == V.xo here (the accepted or restored iterate)
+        V.x[s] = xn;
+      }
+      counted = (__ballot(mv) != 0ull) || !failed_at_t;
+      failed_at_t = true;
     }
   }
   if (status == 4) {   // abnormal stop: report the restored gradient's norm
