@@ -599,55 +599,113 @@ class RandomEffectLRLBFGSModel:
         """-> thresholded coefficients, variances|None, global feature index per coefficient, feat_ptr, solver statistics
         for the entities of `batch`, in its order. With re-balancing part of the work is done on other ranks and
         other ranks' entities here (rebalance.py); the arithmetic per entity is the same either way."""
-        solver = self._get_solver()
-        opts = self._solver_options()
-        rb = None
-        work = batch
-        packed = theta_dev = None
         rebalance, with_prior = self._rebalancing(model_weights)
         if rebalance:
-            from .rebalance import Rebalancer
-            rb = Rebalancer(batch)
-            prior = model_weights.rows_for(batch.entity_ids) if (with_prior and model_weights) else None
-            work = rb.exchange(prior=prior, with_prior=with_prior)
-            if with_prior:   # the models of the entities solved here, wherever they came from
-                model_weights = ModelTable.from_rows(work.entity_ids, rb.work_prior)
-            logger.info(f"re-balancing: loads {rb.loads.tolist()}, sent {[int(x.size) for x in rb.sent]}, "
-                        f"received {rb.recv_counts}, solving {work.E} entities here")
+            return self._solve_batch_rebalanced(batch, model_weights, num_features, with_prior)
+        solver = self._get_solver()
+        opts = self._solver_options()
+        packed = theta_dev = None
         ic = 1 if self.has_intercept else 0
-        if work.E == 0:
+        if batch.E == 0:
             theta_thr, variance, uniq = np.zeros(0), None, np.zeros(0, np.int64)
             feat_ptr = np.zeros(1, np.int64)
             stats = {k: np.zeros(0) for k in self._STAT_KEYS}
         else:
-            packed = solver.pack(work, has_intercept=self.has_intercept)
+            packed = solver.pack(batch, has_intercept=self.has_intercept)
             feat_ptr = host_array(packed.ent_feat_ptr())
             uniq = host_array(packed.unique_global())
-            theta0 = None
-            if model_weights:
-                # the starting point goes up from a page-locked block kept from partition to partition (a fresh 64 MB array per
-                # partition is 16 k page faults and a staged copy: 20 ms per 125 k entities)
-                stage = self._theta0_block(int(feat_ptr[-1]) + work.E * ic)
-                theta0, _ = _model_coefficients_for_batch(model_weights, work.entity_ids, uniq, feat_ptr, self.has_intercept, num_features,
-                                                          out=None if stage is None else stage.numpy())
-                if stage is not None:
-                    theta0 = stage[:int(feat_ptr[-1]) + work.E * ic]
+            theta0 = self._start_point(model_weights, batch.entity_ids, uniq, feat_ptr, batch.E, num_features)
             solved = solver.solve(packed, opts, theta0=theta0)
             res = solved.to_host(("theta_thr", "variance") + self._STAT_KEYS)
             theta_thr, variance = res["theta_thr"], res.get("variance")
-            bad = (res["status"] < 0) | (res["status"] > 4)      # 0..4 are fmin_l_bfgs_b's own outcomes
-            if bad.any():
-                raise RuntimeError(f"{int(bad.sum())} of {work.E} entities were not solved (device status "
-                                   f"{sorted(set(res['status'][bad].tolist()))}: 9 = a team barrier timed out, -1 = never reached)")
+            self._check_statuses(res["status"], batch.E)
             theta_dev = getattr(solved, "theta_thr", None)    # still in HBM: what the scoring pass of this partition reads
             stats = {k: res[k] for k in self._STAT_KEYS}
-        if rb is not None:
-            feat_cnt = np.diff(feat_ptr)
-            coef_cnt, theta_thr, variance, feat_cnt, uniq, st = rb.give_back(feat_cnt + ic, theta_thr, variance, feat_cnt, uniq, stats)
-            feat_ptr = np.concatenate([[0], np.cumsum(feat_cnt)]).astype(np.int64)
-            stats = {k: (st[k].astype(np.int32) if k in ("nit", "nfev", "status") else st[k]) for k in self._STAT_KEYS}
-        resident = None if (rb is not None or packed is None) else (packed, theta_dev if theta_dev is not None else theta_thr)
+        resident = None if packed is None else (packed, theta_dev if theta_dev is not None else theta_thr)
         return theta_thr, variance, uniq, feat_ptr, stats, resident
+
+    def _start_point(self, model_weights, entity_ids, uniq, feat_ptr, E, num_features):
+        """theta0 of a warm start in the packed batch's local order (None without prior models)."""
+        if not model_weights:
+            return None
+        ic = 1 if self.has_intercept else 0
+        # the starting point goes up from a page-locked block kept from partition to partition (a fresh 64 MB array per
+        # partition is 16 k page faults and a staged copy: 20 ms per 125 k entities)
+        stage = self._theta0_block(int(feat_ptr[-1]) + E * ic)
+        theta0, _ = _model_coefficients_for_batch(model_weights, entity_ids, uniq, feat_ptr, self.has_intercept, num_features,
+                                                  out=None if stage is None else stage.numpy())
+        if stage is not None:
+            theta0 = stage[:int(feat_ptr[-1]) + E * ic]
+        return theta0
+
+    @staticmethod
+    def _check_statuses(status, E):
+        bad = (status < 0) | (status > 4)      # 0..4 are fmin_l_bfgs_b's own outcomes
+        if bad.any():
+            raise RuntimeError(f"{int(bad.sum())} of {E} entities were not solved (device status "
+                               f"{sorted(set(np.asarray(status)[bad].tolist()))}: 9 = a team barrier timed out, -1 = never reached)")
+
+    def _solve_batch_rebalanced(self, batch, model_weights, num_features, with_prior):
+        """_solve_batch with entity re-balancing (rebalance.py): the partition's 32-bit wire form goes to the device, the
+        travelling entities are exchanged device to device, kept + received entities are widened, packed and solved in HBM,
+        the results travel back device to device and are read back once, in this partition's entity order. With the CPU
+        stand-in of the host tests the same exchange runs on CPU tensors."""
+        import torch
+        from .rebalance import Rebalancer, wire_tensors, wire_to_raw
+        solver = self._get_solver()
+        opts = self._solver_options()
+        ic = 1 if self.has_intercept else 0
+        on_device = hasattr(solver, "widen")
+        dev = solver.device if on_device else torch.device("cpu")
+        rb = Rebalancer(batch.ent_n(), batch.ent_nnz(), wire_tensors(batch, dev, solver if on_device else None))
+        prior = model_weights.rows_for(batch.entity_ids) if (with_prior and model_weights) else None
+        work = rb.exchange(prior=prior, with_prior=with_prior)
+        E_work = work["E"]
+        logger.info(f"re-balancing: loads {rb.loads.tolist()}, sent {[int(x.size) for x in rb.sent]}, "
+                    f"received {rb.recv_counts}, solving {E_work} entities here")
+        as_t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt)
+        if E_work == 0:
+            cc = torch.zeros(0, dtype=torch.int64, device=dev)
+            th = torch.zeros(0, dtype=torch.float64, device=dev)
+            va = torch.zeros(0, dtype=torch.float64, device=dev) if self.model_params.random_effect_variance_mode is not None else None
+            fi = torch.zeros(0, dtype=torch.int64, device=dev)
+            ints = torch.zeros((0, 3), dtype=torch.int32, device=dev)
+            flts = torch.zeros((0, 2), dtype=torch.float64, device=dev)
+        else:
+            if on_device:
+                packed = solver.pack(solver.widen(work), has_intercept=self.has_intercept)
+                fp_dev, uq_dev = packed.ent_feat_ptr(), packed.unique_global()
+            else:
+                packed = solver.pack(wire_to_raw(work), has_intercept=self.has_intercept)
+                fp_dev, uq_dev = as_t(packed.ent_feat_ptr().cpu().numpy(), torch.int64), as_t(packed.unique_global().cpu().numpy(), torch.int64)
+            theta0 = None
+            if with_prior:   # the models of the entities solved here, wherever they came from, by position
+                ids = [str(i) for i in range(E_work)]
+                theta0 = self._start_point(ModelTable.from_rows(ids, rb.work_prior), ids, host_array(uq_dev), host_array(fp_dev), E_work,
+                                           num_features)
+            solved = solver.solve(packed, opts, theta0=theta0)
+            if on_device:
+                th, va = solved.theta_thr, getattr(solved, "variance", None)
+                ints = torch.stack([solved.nit, solved.nfev, solved.status], dim=1)
+                flts = torch.stack([solved.fval, solved.gnorm], dim=1)
+            else:
+                r = solved.to_host(("theta_thr", "variance") + self._STAT_KEYS)
+                th = as_t(r["theta_thr"], torch.float64)
+                va = None if r.get("variance") is None else as_t(r["variance"], torch.float64)
+                ints = torch.stack([as_t(r[k], torch.int32) for k in ("nit", "nfev", "status")], dim=1)
+                flts = torch.stack([as_t(r[k], torch.float64) for k in ("fval", "gnorm")], dim=1)
+            cc = (fp_dev[1:] - fp_dev[:-1]) + ic
+            fi = uq_dev
+        self.last_exchange_devices = (str(work["val"].device), str(th.device))   # (tests: the payload never left the device)
+        my_cc, theta_thr, variance, uniq, ints, flts = rb.give_back(cc, th, va, fi, ints, flts, has_intercept=self.has_intercept)
+        my_cc, theta_thr, uniq = host_array(my_cc), host_array(theta_thr), host_array(uniq)
+        variance = None if variance is None else host_array(variance)
+        ints, flts = host_array(ints), host_array(flts)
+        self._check_statuses(ints[:, 2], batch.E)
+        feat_ptr = np.concatenate([[0], np.cumsum(my_cc - ic)]).astype(np.int64)
+        stats = dict(nit=ints[:, 0].astype(np.int32), nfev=ints[:, 1].astype(np.int32), status=ints[:, 2].astype(np.int32),
+                     fval=flts[:, 0].copy(), gnorm=flts[:, 1].copy())
+        return theta_thr, variance, uniq.astype(np.int64), feat_ptr, stats, None
 
     def idle_round(self, num_features=1):
         """A rank without a partition in this round still takes part in the re-balancing collectives (and solves what

@@ -9,21 +9,25 @@ partition, which writes the model file. One round per partition step, all ranks 
   2. every rank derives the same transfer matrix from the gathered loads (deterministic greedy: largest surplus
      to largest deficit) and picks which of its own entities travel — smallest first, so the giants, which no
      rank could absorb, stay where they are;
-  3. one all_to_all of the raw ragged arrays of the travelling entities (three flat buffers: int64, float32, id
-     bytes); on the GPU box the tensors live in HBM and the collective is RCCL over xGMI (direct, non-ring
-     all-to-all: 7 links per GPU), in the tests it is gloo on CPU;
-     with a warm start the prior models of the travelling entities go with them (coefficient counts, global
-     feature indices, coefficients: one more int64 and one float64 all_to_all);
-  4. every rank solves its kept + received entities as one batch;
-  5. one all_to_all back: coefficient counts, coefficients, variances, feature indices, solver statistics of the
-     foreign entities; the owner splices them into its results in the original entity order.
+  3. the travelling entities' arrays are gathered ON THE DEVICE out of the partition's 32-bit wire form
+     (gdmix_re_wire_batch: samples per entity, non-zeros per sample, int32 feature ids, values, labels, offsets,
+     weights — what was uploaded for the solve anyway) and exchanged device to device: one all_to_all_single per
+     array over RCCL (xGMI is point to point, 7 links per GPU: a direct all-to-all, not a ring); entity ids and
+     sample ids stay at home — the solving rank does not need them, results come back by position;
+  4. every rank concatenates kept + received wire arrays in HBM, widens and packs them (gdmix_re_widen,
+     gdmix_re_pack) and solves them as one batch;
+  5. one exchange back, device to device: per entity the coefficient count and the solver statistics, per
+     coefficient the value (and variance), per feature its global index; the owner splices them into its
+     partition's entity order with one gather on the device and reads the result back once.
 
-Nothing here touches the arithmetic: results are bit-identical to the unbalanced run (tests/test_distributed.py).
+With a warm start the prior models of the travelling entities go with them (coefficient counts, global feature
+indices, coefficients); they start on the host (the model table) and are mapped to the solve's local order on the
+host of the solving rank, so this small side channel is staged through page-locked memory.
+
+Nothing here touches the arithmetic: results are bit-identical to the unbalanced run (tests/test_rebalance.py).
+In the CPU tests the same code runs on CPU tensors over gloo.
 """
 import numpy as np
-
-from .batch import RawBatch, concat
-from .io.native_reader import _ids_to_bytes, _split_ids   # vectorised id <-> bytes (pure numpy; no library call)
 
 
 # ---- planning (pure numpy, identical on every rank) -----------------------------------------------------------------
@@ -70,46 +74,17 @@ def choose_entities(cost, amounts):
     return out
 
 
-# ---- wire format of a RawBatch slice ----------------------------------------------------------------------------------
-def _pack(b: RawBatch):
-    """RawBatch -> (int64 array, float32 array, uint8 array)."""
-    id_bytes, id_ptr = _ids_to_bytes(b.entity_ids)
-    id_len = np.diff(id_ptr)
-    has_w = b.weight is not None
-    i64 = np.concatenate([np.array([b.E, b.N, b.Z, int(has_w), int(b.has_label)], np.int64), np.diff(b.ent_row_ptr),
-                          np.diff(b.row_nnz_ptr), b.col_global, b.uid if b.uid is not None else np.zeros(b.N, np.int64), id_len])
-    f32 = np.concatenate([b.val, b.y, b.offset] + ([b.weight] if has_w else []))
-    u8 = np.frombuffer(id_bytes, np.uint8)
-    return i64.astype(np.int64), f32.astype(np.float32), u8
-
-
-def _unpack(i64, f32, u8):
-    E, N, Z, has_w, has_label = (int(x) for x in i64[:5])
-    p = 5
-    n = i64[p:p + E]; p += E
-    k = i64[p:p + N]; p += N
-    col = i64[p:p + Z]; p += Z
-    uid = i64[p:p + N]; p += N
-    id_len = i64[p:p + E]; p += E
-    q = 0
-    val = f32[q:q + Z]; q += Z
-    y = f32[q:q + N]; q += N
-    off = f32[q:q + N]; q += N
-    w = f32[q:q + N] if has_w else None
-    idp = np.concatenate([[0], np.cumsum(id_len)]).astype(np.int64)
-    ids = _split_ids(u8.tobytes(), idp, E)
-    return RawBatch(ent_row_ptr=np.concatenate([[0], np.cumsum(n)]).astype(np.int64),
-                    row_nnz_ptr=np.concatenate([[0], np.cumsum(k)]).astype(np.int64), col_global=col.copy(), val=val.copy(),
-                    y=y.copy(), offset=off.copy(), weight=None if w is None else w.copy(), uid=uid.copy(), entity_ids=ids,
-                    has_label=bool(has_label))
-
-
-def _empty_like(b: RawBatch):
-    return b.select(np.zeros(0, np.int64))
+def _segments(t, starts, lens, total):
+    """Indices of the concatenated ranges [starts[k], starts[k] + lens[k]) as an int64 tensor on the tensors' device; `total`
+    = sum(lens), known on the host (no device synchronisation)."""
+    if total == 0:
+        return t.zeros(0, dtype=t.int64, device=starts.device)
+    out_start = t.cumsum(lens, 0) - lens
+    return t.repeat_interleave(starts - out_start, lens, output_size=total) + t.arange(total, dtype=t.int64, device=starts.device)
 
 
 class _Comm:
-    """all_to_all of variable-length numpy arrays over torch.distributed (nccl = RCCL: device tensors; gloo: CPU)."""
+    """Collectives of the exchange over torch.distributed (nccl = RCCL: device tensors; gloo: CPU tensors)."""
 
     def __init__(self, group=None, device=None):
         import torch
@@ -130,32 +105,51 @@ class _Comm:
             self._pinned[(key, tdt)] = buf
         return buf[:count]
 
-    def all_gather_floats(self, x):
+    def all_gather_row(self, values):
+        """values: a few floats of this rank -> [world, len(values)] numpy (small metadata)."""
         t = self.t
-        mine = t.tensor([float(x)], dtype=t.float64, device=self.device)
-        out = [t.zeros(1, dtype=t.float64, device=self.device) for _ in range(self.world)]
+        mine = t.tensor([float(v) for v in values], dtype=t.float64, device=self.device)
+        out = [t.zeros_like(mine) for _ in range(self.world)]
         self.dist.all_gather(out, mine, group=self.group)
-        return np.array([float(o.item()) for o in out])
+        return np.stack([o.cpu().numpy() for o in out])
+
+    def all_gather_floats(self, x):
+        return self.all_gather_row([x])[:, 0]
+
+    def exchange_counts(self, counts):
+        """counts: [world, k] integers this rank sends to every rank -> [world, k] received from every rank."""
+        t = self.t
+        send = t.tensor(np.asarray(counts, np.int64).reshape(self.world, -1), dtype=t.int64, device=self.device)
+        recv = t.zeros_like(send)
+        self.dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
+        return recv.cpu().numpy()
+
+    def all_to_all_t(self, send, send_counts, recv_counts):
+        """send: a tensor on the communicator's device, its rows grouped by destination rank (send_counts rows each; trailing
+        dimensions travel along) -> the rows received, grouped by source rank (recv_counts rows each). Device to device."""
+        t = self.t
+        send = send.contiguous()
+        recv = t.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=self.device)
+        self.dist.all_to_all_single(recv, send, output_split_sizes=[int(c) for c in recv_counts],
+                                    input_split_sizes=[int(c) for c in send_counts], group=self.group)
+        return recv
 
     def all_to_all(self, parts, dtype):
-        """parts[j] = numpy array for rank j -> list of arrays received from every rank."""
+        """parts[j] = numpy array for rank j -> list of numpy arrays received from every rank. Host data (the prior models of a
+        warm start): staged through page-locked memory on the RCCL path."""
         t = self.t
         tdt = {np.int64: t.int64, np.float32: t.float32, np.float64: t.float64, np.uint8: t.uint8, np.int32: t.int32}[dtype]
-        sizes = t.tensor([int(p.size) for p in parts], dtype=t.int64, device=self.device)
-        rsizes = t.zeros(self.world, dtype=t.int64, device=self.device)
-        self.dist.all_to_all_single(rsizes, sizes, group=self.group)
-        rs = [int(x) for x in rsizes.tolist()]
+        counts = [int(p.size) for p in parts]
+        rs = [int(x) for x in self.exchange_counts(np.asarray(counts).reshape(-1, 1))[:, 0]]
         flat = np.concatenate([np.asarray(p, dtype) for p in parts]) if parts else np.zeros(0, dtype)
         on_device = self.device.type != "cpu"
-        if on_device:   # host arrays -> page-locked staging -> HBM; the exchange itself is device to device (RCCL over xGMI)
+        if on_device:
             hs = self._stage("send", flat.size, tdt)
             hs.numpy()[...] = flat
             send = hs.to(self.device, non_blocking=True)
         else:
             send = t.from_numpy(np.ascontiguousarray(flat))
-        recv = t.zeros(sum(rs), dtype=tdt, device=self.device)
-        self.dist.all_to_all_single(recv, send, output_split_sizes=rs, input_split_sizes=[int(p.size) for p in parts],
-                                    group=self.group)
+        recv = self.all_to_all_t(send, counts, rs)
         if on_device:
             hr = self._stage("recv", recv.numel(), tdt)
             hr.copy_(recv, non_blocking=True)
@@ -170,73 +164,130 @@ class _Comm:
         return out
 
 
+WIRE_KEYS = ("ent_n", "row_nnz", "col_global", "val", "y", "offset", "weight")
+
+
+def wire_tensors(batch, device, solver=None):
+    """The partition in the exchange's wire form (gdmix_re_wire_batch with 32-bit counts, int32 feature ids, float labels) as
+    tensors on `device`. With a device solver the arrays go up through its page-locked staging (upload_wire)."""
+    import torch
+    if batch.Z and (batch.col_global.min() < 0 or batch.col_global.max() > 0x7fffffff):
+        raise ValueError("feature index outside [0, 2^31)")
+    w = dict(E=batch.E, N=batch.N, Z=batch.Z, ent_n=np.diff(batch.ent_row_ptr).astype(np.int32), row_nnz=np.diff(batch.row_nnz_ptr).astype(np.int32),
+             row_nnz_width=4, col_global=batch.col_global.astype(np.int32), col_width=4, val=batch.val, y=batch.y, y_width=4,
+             offset=batch.offset, weight=batch.weight)
+    if solver is not None and hasattr(solver, "upload_wire"):
+        return solver.upload_wire(w)
+    d = {k: w[k] for k in ("E", "N", "Z", "row_nnz_width", "y_width", "col_width")}
+    for k in WIRE_KEYS:
+        d[k] = None if w[k] is None else torch.from_numpy(np.ascontiguousarray(w[k])).to(device)
+    return d
+
+
+def wire_to_raw(work):
+    """The wire form exchange() returns (CPU tensors) as a host RawBatch without ids (the CPU tests' solver stand-in takes host
+    batches; the device solver widens the wire form in HBM instead: gdmix_re_widen)."""
+    from .batch import RawBatch
+    g = lambda k: None if work[k] is None else work[k].cpu().numpy()
+    n, k = g("ent_n").astype(np.int64), g("row_nnz").astype(np.int64)
+    return RawBatch(ent_row_ptr=np.concatenate([[0], np.cumsum(n)]), row_nnz_ptr=np.concatenate([[0], np.cumsum(k)]),
+                    col_global=g("col_global").astype(np.int64), val=g("val"), y=g("y"), offset=g("offset"), weight=g("weight"),
+                    uid=None, entity_ids=None, has_label=True, trusted=True)
+
+
 class Rebalancer:
     """One instance per training round. Usage on every rank (collective):
 
-        rb = Rebalancer(batch)                 # batch may be empty (rank without a partition this round)
-        work = rb.exchange()                   # RawBatch to solve here: kept + received entities
-        ... solve `work` -> per-entity results in work's entity order ...
-        mine = rb.give_back(coef_cnt, theta, variance|None, feat_cnt, feat_idx, stats)   # results of MY entities,
-                                                                                        # in batch's entity order
-    """
+        rb = Rebalancer(ent_n, ent_nnz, wire)   # this rank's partition: samples / non-zeros per entity (host), wire form (tensors)
+        work = rb.exchange()                    # wire form of what is solved here: kept + received entities (same device)
+        ... widen, pack, solve `work` -> per-entity results in work's entity order, as tensors on the same device ...
+        mine = rb.give_back(coef_cnt, theta, variance|None, feat_idx, ints, floats)   # results of MY entities, in my entity order
 
-    def __init__(self, batch: RawBatch, group=None, device=None, tolerance=0.05, cost=None):
-        self.batch = batch
-        self.comm = _Comm(group, device)
-        self.cost = np.asarray(batch.ent_nnz() if cost is None else cost, np.float64)
+    A rank without a partition in a round passes empty arrays and still joins the collectives."""
+
+    def __init__(self, ent_n, ent_nnz, wire, group=None, tolerance=0.05, cost=None):
+        self.comm = _Comm(group, wire["val"].device)
+        self.t = self.comm.t
+        self.n = np.asarray(ent_n, np.int64)
+        self.nnz = np.asarray(ent_nnz, np.int64)
+        self.E = int(self.n.size)
+        self.wire = wire
+        self.cost = np.asarray(self.nnz if cost is None else cost, np.float64)
         self.tolerance = tolerance
-        self.sent = None        # per destination: indices into batch
+        self.sent = None        # per destination: entity indices of this rank's partition
         self.kept = None
         self.recv_counts = None
 
-    def exchange(self, prior=None, with_prior=False) -> RawBatch:
-        """with_prior (the same on every rank): prior models travel too. prior = dict(has [E] bool, coef_ptr [E+1],
-        theta, feat_ptr [E+1], idx) for this rank's batch in entity order (None = no entity has one); afterwards
-        self.work_prior is the same structure for the returned batch."""
-        c = self.comm
-        loads = c.all_gather_floats(self.cost.sum())
-        self.loads = loads
-        T = plan_transfers(loads, self.tolerance)
+    # -- helpers ---------------------------------------------------------------------------------------------------
+    def _gather_entities(self, ents):
+        """Wire arrays of the entities `ents` (numpy indices into this rank's partition, any order), gathered on the device."""
+        t, w = self.t, self.wire
+        dev = w["val"].device
+        e = t.from_numpy(np.ascontiguousarray(ents, np.int64)).to(dev)
+        ent_n = w["ent_n"].to(t.int64)
+        if not hasattr(self, "_row_start"):
+            self._row_start = t.cumsum(ent_n, 0) - ent_n
+            rz = w["row_nnz"].to(t.int64)
+            self._nz_start = t.cumsum(rz, 0) - rz
+        n_tot, z_tot = int(self.n[ents].sum()), int(self.nnz[ents].sum())
+        rows = _segments(t, self._row_start[e], ent_n[e], n_tot)
+        rz = w["row_nnz"][rows].to(t.int64)
+        nz = _segments(t, self._nz_start[rows], rz, z_tot)
+        return dict(ent_n=w["ent_n"][e], row_nnz=w["row_nnz"][rows], col_global=w["col_global"][nz], val=w["val"][nz], y=w["y"][rows],
+                    offset=w["offset"][rows], weight=None if w["weight"] is None else w["weight"][rows])
+
+    # -- the exchange ----------------------------------------------------------------------------------------------
+    def exchange(self, prior=None, with_prior=False):
+        """-> the wire form (dict for REDeviceSolver.widen; tensors on the communicator's device) of the entities solved here:
+        this rank's kept entities in their order, then the received ones by origin rank. with_prior (the same on every rank):
+        prior models travel too — prior = dict(has [E] bool, coef_ptr [E+1], theta, feat_ptr [E+1], idx) for this rank's
+        partition in entity order (None = no entity has one); afterwards self.work_prior is the same structure for the
+        returned batch."""
+        c, t = self.comm, self.t
+        has_w = self.wire["weight"] is not None
+        meta = c.all_gather_row([self.cost.sum(), 1.0 if has_w else 0.0])
+        self.loads = meta[:, 0]
+        any_w = bool(meta[:, 1].any())
+        if any_w and not has_w:     # a rank without weights may receive weighted entities (and vice versa): make the pieces uniform
+            self.wire = dict(self.wire, weight=t.ones(self.wire["y"].numel(), dtype=t.float32, device=self.wire["val"].device))
+        T = plan_transfers(self.loads, self.tolerance)
         self.sent = choose_entities(self.cost, T[c.rank])
         self.sent[c.rank] = np.zeros(0, np.int64)
         moving = np.concatenate(self.sent) if self.sent else np.zeros(0, np.int64)
-        mask = np.ones(self.batch.E, bool)
+        mask = np.ones(self.E, bool)
         mask[moving] = False
         self.kept = np.flatnonzero(mask)
-        packs = [_pack(self.batch.select(ix)) if ix.size else (np.zeros(0, np.int64), np.zeros(0, np.float32), np.zeros(0, np.uint8))
-                 for ix in self.sent]
-        ri = c.all_to_all([p[0] for p in packs], np.int64)
-        rf = c.all_to_all([p[1] for p in packs], np.float32)
-        ru = c.all_to_all([p[2] for p in packs], np.uint8)
-        parts = [self.batch.select(self.kept)]
-        self.recv_counts = []
-        for j in range(c.world):
-            if ri[j].size:
-                b = _unpack(ri[j], rf[j], ru[j])
-                # a rank without weights may receive weighted entities (and vice versa): make the pieces uniform
-                parts.append(b)
-                self.recv_counts.append(b.E)
-            else:
-                self.recv_counts.append(0)
-        has_w = any(p.weight is not None and p.E for p in parts)
-        if has_w:
-            for p in parts:
-                if p.weight is None:
-                    p.weight = np.ones(p.N, np.float32)
-        self.work_prior = None
-        if with_prior:
-            self.work_prior = self._exchange_prior(prior)
-        parts = [p for p in parts if p.E] or [parts[0]]
-        self.work = concat(parts) if len(parts) > 1 else parts[0]
-        self.work_has_label = all(p.has_label for p in parts)
-        return self.work
+        # rows of every array that go to each destination: entities, samples, non-zeros
+        send_enz = np.array([[ix.size, int(self.n[ix].sum()), int(self.nnz[ix].sum())] for ix in self.sent], np.int64)
+        recv_enz = c.exchange_counts(send_enz)
+        self.recv_counts = [int(x) for x in recv_enz[:, 0]]
+        out_part = self._gather_entities(moving) if moving.size else None
+        kept_part = self.wire if moving.size == 0 else self._gather_entities(self.kept)
+        level = {"ent_n": 0, "row_nnz": 1, "col_global": 2, "val": 2, "y": 1, "offset": 1, "weight": 1}
+        work = {}
+        for k in WIRE_KEYS:
+            if k == "weight" and not any_w:
+                work[k] = None
+                continue
+            lv = level[k]
+            like = kept_part[k]
+            send = out_part[k] if out_part is not None else like[:0]
+            recv = c.all_to_all_t(send, send_enz[:, lv], recv_enz[:, lv])
+            work[k] = t.cat([like, recv]) if recv.numel() else like
+        work["E"] = int(self.kept.size + recv_enz[:, 0].sum())
+        work["N"] = int(self.n[self.kept].sum() + recv_enz[:, 1].sum())
+        work["Z"] = int(self.nnz[self.kept].sum() + recv_enz[:, 2].sum())
+        work.update(row_nnz_width=4, y_width=4, col_width=4)
+        self.work_E = work["E"]
+        self.work_prior = self._exchange_prior(prior) if with_prior else None
+        return work
 
     def _exchange_prior(self, prior):
         """Prior models of the kept entities followed by those received, origin ranks in rank order (= the entity order
         of the batch exchange() returns)."""
         from .batch import _ranges
         c = self.comm
-        E = self.batch.E
+        E = self.E
         if prior is None:
             prior = dict(has=np.zeros(E, bool), coef_ptr=np.zeros(E + 1, np.int64), theta=np.zeros(0), feat_ptr=np.zeros(E + 1, np.int64),
                          idx=np.zeros(0, np.int64))
@@ -249,9 +300,9 @@ class Rebalancer:
             return has[sel].astype(np.int64), cc, fc, th[_ranges(cp[sel], cc)], ix[_ranges(fp[sel], fc)]
         i_parts, f_parts = [], []
         for sel in self.sent:
-            h, cc, fc, t, i = rows(sel)
+            h, cc, fc, tt, i = rows(sel)
             i_parts.append(np.concatenate([h, cc, fc, i]) if sel.size else np.zeros(0, np.int64))
-            f_parts.append(t if sel.size else np.zeros(0, np.float64))
+            f_parts.append(tt if sel.size else np.zeros(0, np.float64))
         ri = c.all_to_all(i_parts, np.int64)
         rf = c.all_to_all(f_parts, np.float64)
         hs, ccs, fcs, ths, ixs = [[x] for x in rows(self.kept)]
@@ -266,92 +317,55 @@ class Rebalancer:
                     theta=np.concatenate(ths).astype(np.float64), feat_ptr=np.concatenate([[0], np.cumsum(fc)]).astype(np.int64),
                     idx=np.concatenate(ixs).astype(np.int64))
 
-    def give_back(self, coef_cnt, theta, variance, feat_cnt, feat_idx, stats=None):
-        """Per-entity results of the batch returned by exchange(), in its entity order:
-        coef_cnt[E'], theta[sum coef_cnt] (float64), variance or None, feat_cnt[E'], feat_idx[sum feat_cnt] (int64),
-        stats: dict of per-entity int32/float64 arrays (nit, nfev, status, fval, gnorm) or None.
-        Returns the same tuple for THIS rank's original batch, in its original entity order."""
-        c = self.comm
-        coef_cnt = np.asarray(coef_cnt, np.int64)
-        feat_cnt = np.asarray(feat_cnt, np.int64)
-        cptr = np.concatenate([[0], np.cumsum(coef_cnt)])
-        fptr = np.concatenate([[0], np.cumsum(feat_cnt)])
-        nk = self.kept.size
-        stats = stats or {}
-        skeys = sorted(stats)
+    def give_back(self, coef_cnt, theta, variance, feat_idx, ints, floats, has_intercept=True):
+        """Per-entity results of the batch exchange() returned, in its entity order, as tensors on the communicator's device:
+        coef_cnt [E'] (integers), theta [sum coef_cnt] float64, variance (same shape) or None, feat_idx [sum (coef_cnt - ic)]
+        (integers: global feature index per non-intercept coefficient), ints [E', a] / floats [E', b]: per-entity solver
+        statistics. Returns (coef_cnt, theta, variance, feat_idx, ints, floats) for THIS rank's partition in its entity
+        order, on the same device. Device to device; the only host traffic is 2 x world counts."""
+        c, t = self.comm, self.t
+        dev = theta.device
+        ic = 1 if has_intercept else 0
+        cc = coef_cnt.to(t.int64)
+        fc = cc - ic
+        nk = int(self.kept.size)
         # foreign entities sit after the kept ones, grouped by origin rank in rank order
-        seg = [nk]
-        for j in range(c.world):
-            seg.append(seg[-1] + self.recv_counts[j])
-
-        def slices(j):
-            a, b = seg[j], seg[j + 1]
-            return a, b, cptr[a], cptr[b], fptr[a], fptr[b]
-        i64_parts, f64_parts = [], []
-        for j in range(c.world):
-            a, b, c0, c1, f0, f1 = slices(j)
-            if b == a:
-                i64_parts.append(np.zeros(0, np.int64))
-                f64_parts.append(np.zeros(0, np.float64))
-                continue
-            ints = [np.array([b - a, int(variance is not None)], np.int64), coef_cnt[a:b], feat_cnt[a:b], np.asarray(feat_idx, np.int64)[f0:f1]]
-            flts = [np.asarray(theta, np.float64)[c0:c1]]
-            if variance is not None:
-                flts.append(np.asarray(variance, np.float64)[c0:c1])
-            for k in skeys:
-                flts.append(np.asarray(stats[k], np.float64)[a:b])
-            i64_parts.append(np.concatenate(ints))
-            f64_parts.append(np.concatenate(flts))
-        ri = c.all_to_all(i64_parts, np.int64)
-        rf = c.all_to_all(f64_parts, np.float64)
-        # assemble my batch's results in original entity order: every source (kept here, returned by rank j) is appended
-        # to a pool, every entity remembers where its slice of the pool starts
-        from .batch import _ranges
-        E = self.batch.E
-        theta = np.asarray(theta, np.float64)
-        feat_idx = np.asarray(feat_idx, np.int64)
-        my_coef = np.zeros(E, np.int64)
-        my_feat = np.zeros(E, np.int64)
-        c_start = np.zeros(E, np.int64)
-        f_start = np.zeros(E, np.int64)
-        any_var = variance is not None
-        th_pool, fi_pool, va_pool = [theta[:cptr[nk]]], [feat_idx[:fptr[nk]]], [None if variance is None else np.asarray(variance, np.float64)[:cptr[nk]]]
-        st_out = {k: np.zeros(E, np.float64) for k in skeys}
-        my_coef[self.kept] = coef_cnt[:nk]
-        my_feat[self.kept] = feat_cnt[:nk]
-        c_start[self.kept] = cptr[:nk]
-        f_start[self.kept] = fptr[:nk]
-        for k in skeys:
-            st_out[k][self.kept] = np.asarray(stats[k], np.float64)[:nk]
-        c_base, f_base = int(cptr[nk]), int(fptr[nk])
-        for j in range(c.world):
-            ix = self.sent[j]
-            if ix.size == 0:
-                continue
-            ii, ff = ri[j], rf[j]
-            n, hv = int(ii[0]), int(ii[1])
-            assert n == ix.size, "result count differs from the entities sent"
-            cc = ii[2:2 + n]; fc = ii[2 + n:2 + 2 * n]; fi = ii[2 + 2 * n:]
-            tot = int(cc.sum())
-            q = tot
-            va = None
-            if hv:
-                va = ff[q:q + tot]; q += tot
-                any_var = True
-            for k in skeys:
-                st_out[k][ix] = ff[q:q + n]; q += n
-            my_coef[ix] = cc
-            my_feat[ix] = fc
-            c_start[ix] = c_base + np.cumsum(cc) - cc
-            f_start[ix] = f_base + np.cumsum(fc) - fc
-            th_pool.append(ff[:tot]); fi_pool.append(fi); va_pool.append(va)
-            c_base += tot
-            f_base += int(fc.sum())
-        cg = _ranges(c_start, my_coef)
-        th_all = np.concatenate(th_pool).astype(np.float64)
-        fi_all = np.concatenate(fi_pool).astype(np.int64)
-        va_out = None
-        if any_var:
-            va_all = np.concatenate([v if v is not None else np.zeros(t.size) for v, t in zip(va_pool, th_pool)]).astype(np.float64)
-            va_out = va_all[cg]
-        return my_coef, th_all[cg], va_out, my_feat, fi_all[_ranges(f_start, my_feat)], st_out
+        seg = np.concatenate([[nk], nk + np.cumsum(self.recv_counts)]).astype(np.int64)
+        cptr = t.cat([t.zeros(1, dtype=t.int64, device=dev), t.cumsum(cc, 0)])
+        fptr = t.cat([t.zeros(1, dtype=t.int64, device=dev), t.cumsum(fc, 0)])
+        at = t.from_numpy(seg).to(dev)
+        cb, fb = cptr[at].cpu().numpy(), fptr[at].cpu().numpy()       # coefficient / feature offsets of the segment boundaries
+        send_e = np.diff(seg)
+        send_c, send_f = np.diff(cb), np.diff(fb)
+        recv = c.exchange_counts(np.stack([send_e, send_c, send_f], axis=1))
+        sent_e = np.array([ix.size for ix in self.sent], np.int64)
+        if not np.array_equal(recv[:, 0], sent_e):
+            raise RuntimeError("re-balancing: result counts differ from the entities sent")
+        r_cc = c.all_to_all_t(cc[nk:], send_e, recv[:, 0])
+        r_int = c.all_to_all_t(ints[nk:], send_e, recv[:, 0])
+        r_flt = c.all_to_all_t(floats[nk:], send_e, recv[:, 0])
+        r_th = c.all_to_all_t(theta[int(cb[0]):], send_c, recv[:, 1])
+        r_va = c.all_to_all_t(variance[int(cb[0]):], send_c, recv[:, 1]) if variance is not None else None
+        r_fi = c.all_to_all_t(feat_idx[int(fb[0]):], send_f, recv[:, 2])
+        # the pool: kept entities, then what every rank returned (in the order the entities were sent); an entity of the
+        # partition finds its pool position through `where`
+        where = np.empty(self.E, np.int64)
+        where[self.kept] = np.arange(nk)
+        pos = nk
+        for ix in self.sent:
+            where[ix] = pos + np.arange(ix.size)
+            pos += ix.size
+        w_t = t.from_numpy(where).to(dev)
+        p_cc = t.cat([cc[:nk], r_cc])
+        p_cstart = t.cumsum(p_cc, 0) - p_cc
+        p_fc = p_cc - ic
+        p_fstart = t.cumsum(p_fc, 0) - p_fc
+        my_cc = p_cc[w_t]
+        total_c = int(cb[0]) + int(recv[:, 1].sum())
+        total_f = int(fb[0]) + int(recv[:, 2].sum())
+        cg = _segments(t, p_cstart[w_t], my_cc, total_c)
+        fg = _segments(t, p_fstart[w_t], p_fc[w_t], total_f)
+        th_all = t.cat([theta[:int(cb[0])], r_th])
+        va_out = t.cat([variance[:int(cb[0])], r_va])[cg] if variance is not None else None
+        fi_all = t.cat([feat_idx[:int(fb[0])], r_fi])
+        return (my_cc, th_all[cg], va_out, fi_all[fg], t.cat([ints[:nk], r_int])[w_t], t.cat([floats[:nk], r_flt])[w_t])

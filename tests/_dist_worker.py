@@ -22,7 +22,11 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])   # the driver opens the process group when it needs one
     argv = json.load(open(os.path.join(base, "argv.json")))
     model = RandomEffectLRLBFGSModel(argv)
-    model._solver = OracleSolverDouble()
+    real = os.environ.get("GDMIX_TEST_DEVICE_SOLVER") == "1"   # -m gpu on a box with a GPU per rank: the product path, RCCL
+    if real:
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+    else:
+        model._solver = OracleSolverDouble()
     # record what every re-balancing round did on this rank
     rounds = []
     from gdmix_amd import rebalance as rbm
@@ -30,9 +34,10 @@ def main():
 
     def exchange(self, *a, **k):
         work = orig_exchange(self, *a, **k)
-        rounds.append({"entities": int(self.batch.E), "sent": [int(x.size) for x in self.sent], "received": list(self.recv_counts),
-                       "solved": int(work.E), "with_prior": bool(k.get("with_prior", False)),
-                       "prior_models": int(self.work_prior["has"].sum()) if self.work_prior is not None else 0})
+        rounds.append({"entities": int(self.E), "sent": [int(x.size) for x in self.sent], "received": list(self.recv_counts),
+                       "solved": int(work["E"]), "with_prior": bool(k.get("with_prior", False)),
+                       "prior_models": int(self.work_prior["has"].sum()) if self.work_prior is not None else 0,
+                       "device": str(work["val"].device)})
         return work
     rbm.Rebalancer.exchange = exchange
     driver = RandomEffectDriver(Params.__from_argv__(argv), model)
@@ -44,12 +49,12 @@ def main():
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
     # load totals: the only collective the RE path needs is this kind of tiny metadata exchange
-    t = torch.tensor([len(mine)], dtype=torch.int64)
+    t = torch.tensor([len(mine)], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t)
     all_rounds = [None] * world
     dist.all_gather_object(all_rounds, rounds)
     if rank == 0:
-        json.dump({"per_rank": gathered, "total": int(t.item()), "rebalance": all_rounds},
+        json.dump({"per_rank": gathered, "total": int(t.item()), "rebalance": all_rounds, "backend": dist.get_backend()},
                   open(os.path.join(base, "result.json"), "w"))
     dist.barrier()
     dist.destroy_process_group()

@@ -11,7 +11,7 @@ import pytest
 from gdmix_amd import synthetic
 from gdmix_amd.io import avro
 from gdmix_amd.io.grouped_reader import write_grouped_partition
-from gdmix_amd.rebalance import choose_entities, plan_transfers, _pack, _unpack
+from gdmix_amd.rebalance import choose_entities, plan_transfers, wire_tensors, wire_to_raw
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -38,30 +38,36 @@ def test_choose_entities_deals_out_the_small_ones_and_keeps_the_giants():
     assert sorted(cost[to[2]].tolist()) == [5]                  # continues where the previous destination stopped
 
 
-def test_wire_format_round_trip():
+def test_wire_form_round_trip():
+    """What travels: the 32-bit wire form of a partition (no ids, no sample ids); back to a host batch it is the same numbers."""
+    import torch
     b = synthetic.make_ragged_batch(40, seed=2)
-    r = _unpack(*_pack(b))
-    for k in ("ent_row_ptr", "row_nnz_ptr", "col_global", "val", "y", "offset", "weight", "uid"):
+    w = wire_tensors(b, torch.device("cpu"))
+    assert w["E"] == b.E and w["row_nnz"].dtype == torch.int32 and w["col_global"].dtype == torch.int32 and w["y"].dtype == torch.float32
+    r = wire_to_raw(w)
+    for k in ("ent_row_ptr", "row_nnz_ptr", "col_global", "val", "y", "offset", "weight"):
         np.testing.assert_array_equal(getattr(r, k), getattr(b, k))
-    assert r.entity_ids == b.entity_ids and r.has_label == b.has_label
+    assert r.uid is None and r.entity_ids is None
 
 
-def _run(tmp_path, tag, rebalance, extra=()):
+def _run(tmp_path, tag, rebalance, extra=(), device_solver=False):
     out = tmp_path / tag
     argv = json.load(open(tmp_path / "argv.json"))
     argv = [a for a in argv if not a.startswith("--output_model_dir")] + [f"--output_model_dir={out / 'models'}",
                                                                          f"--rebalance_entities={rebalance}"] + list(extra)
     os.makedirs(out, exist_ok=True)
     json.dump(argv, open(out / "argv.json", "w"))
-    env = dict(os.environ)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("TF_CONFIG", None)
+    if device_solver:
+        env["GDMIX_TEST_DEVICE_SOLVER"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29613", os.path.join(ROOT, "tests", "_dist_worker.py"), str(out)]
     subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
     return out
 
 
-def test_two_ranks_rebalance_skewed_partitions_and_write_the_same_models(tmp_path):
+def _skewed_partitions(tmp_path):
     # partition 0 (rank 0) is ~10x heavier than partition 1 (rank 1); partition 2 exists only for rank 0, so rank 1
     # idles through the second round and still receives work
     heavy = synthetic.make_batch(300, 24, 4, 256, seed=1)
@@ -85,6 +91,11 @@ def test_two_ranks_rebalance_skewed_partitions_and_write_the_same_models(tmp_pat
             "--partition_entity=ent", "--regularize_bias=False", "--disable_random_effect_scoring_after_training=True",
             f"--training_score_dir={tmp_path / 'ts'}", "--prediction_score_column_name=predictionScore", "--output_model_dir=x"]
     json.dump(argv, open(tmp_path / "argv.json", "w"))
+    return heavy, light, third
+
+
+def test_two_ranks_rebalance_skewed_partitions_and_write_the_same_models(tmp_path):
+    heavy, light, third = _skewed_partitions(tmp_path)
     plain = _run(tmp_path, "plain", False)
     moved = _run(tmp_path, "rebalanced", True)
     for k, b in enumerate((heavy, light, third)):
@@ -115,9 +126,10 @@ def test_two_ranks_rebalance_skewed_partitions_and_write_the_same_models(tmp_pat
 
 @pytest.mark.gpu
 def test_rccl_branch_of_the_exchange_runs_on_device_memory():
-    """The `nccl` (= RCCL) branch of rebalance._Comm has only one GPU to run on here: a single-rank process group, device
-    tensors, payloads of every dtype the exchange uses travelling rank 0 -> rank 0 through RCCL, page-locked staging on
-    both sides, and a whole exchange / give_back round (tests/_nccl_worker.py)."""
+    """The `nccl` (= RCCL) branch of the exchange has only one GPU to run on here: a single-rank process group, the wire form of a
+    partition in HBM, every array travelling rank 0 -> rank 0 through RCCL's all_to_all_single on device tensors, widen + pack +
+    solve of what came back, give_back on device tensors — no device-to-host copy of entity payload in between
+    (tests/_nccl_worker.py)."""
     env = dict(os.environ)
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("TF_CONFIG", None)
@@ -125,3 +137,23 @@ def test_rccl_branch_of_the_exchange_runs_on_device_memory():
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "nccl single-rank exchange ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_two_ranks_rebalance_over_rccl_when_the_box_has_two_gpus(tmp_path):
+    """The same two-rank run on the product path: one process per GPU, the device solver, the exchange over RCCL on device tensors.
+    Needs two devices (the driver's 8-GPU box); on the 1-GPU box the single-rank RCCL test above is what can run."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: one process per GPU")
+    heavy, light, third = _skewed_partitions(tmp_path)
+    plain = _run(tmp_path, "plain", False, device_solver=True)
+    moved = _run(tmp_path, "rebalanced", True, device_solver=True)
+    for k, b in enumerate((heavy, light, third)):
+        a = list(avro.read_file(str(plain / "models" / f"part-{k:05d}.avro")))
+        r = list(avro.read_file(str(moved / "models" / f"part-{k:05d}.avro")))
+        assert len(a) == b.E and a == r
+    res = json.load(open(moved / "result.json"))
+    assert res["backend"] == "nccl"
+    rounds = res["rebalance"]
+    assert rounds[0][0]["sent"][1] > 0 and rounds[0][0]["device"].startswith("cuda") and rounds[1][1]["device"].startswith("cuda")
