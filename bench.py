@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS),
                     help="c2 (default, the configuration BASELINE.json's metric is quoted on for one GPU) or another of BASELINE's "
                          "configurations at its own entity sizes: " + "; ".join(f"{k} = {v}" for k, v in WORKLOADS.items()))
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip detail.workloads: C3 (MovieLens-20M per-user / per-movie) and C5's per-GPU share, two steps each, next to the C2 headline")
     ap.add_argument("--c5-entities", type=int, default=4_000_000, help="entities of the c5share workload per GPU (C5's share is 12.5 M)")
     return ap.parse_args()
 
@@ -370,6 +372,59 @@ def make_workload(a, rank, solver):
     return Workload(w, solver.upload(batch), batch.ent_n(), batch.ent_nnz(), ones, host=batch, what=what)
 
 
+def other_workloads_leg(a, rank, world, solver, opts, coll_dev):
+    """BASELINE.json's other random-effect configurations at their own entity sizes, next to the C2 headline: C3 = MovieLens-20M
+    per-user and per-movie (north_star: "entities-converged/sec on synthetic MovieLens-shaped data"), C5 = one GPU's share of the
+    Zipf-sized job. One warm-up and two timed steps (pack + solve) each, every rank on its own data (weak scaling), max over
+    ranks; the same code path as `--workload X`, which also prints the roofline of X's dominant kernel."""
+    import copy
+    import torch
+    import torch.distributed as dist
+    out = {}
+    for w in ("ml20m_user", "ml20m_movie", "c5share"):
+        b = copy.copy(a)
+        b.workload = w
+        t_gen = time.perf_counter()
+        wl = make_workload(b, rank, solver)
+        t_gen = time.perf_counter() - t_gen
+        for _ in range(2):   # warm-up: kernels, and the allocator's two alternating pack workspaces
+            packed = solver.pack(wl.raw_dev)
+            res = solver.solve(packed, opts)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        steps = 2
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            packed = solver.pack(wl.raw_dev)
+            res = solver.solve(packed, opts)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        kernel_ms = np.array(solver.last_solve_ms())
+        st = res.status
+        conv = int(((st >= 0) & (st <= 2)).sum().item())
+        if world > 1:
+            tt = torch.tensor([dt, float(conv)], dtype=torch.float64, device=coll_dev)
+            mx = tt.clone()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tt)
+            dt, conv = float(mx[0].item()), int(tt[1].item())
+        if rank == 0:
+            classes = solver.class_counts(packed)
+            top = sorted(((float(kernel_ms[c]), classes[c][0], int(classes[c][1])) for c in range(len(classes)) if kernel_ms[c] > 0), reverse=True)[:4]
+            n = wl.n
+            out[w] = {"what": wl.what, "entities_per_gpu": wl.E, "N": wl.N, "Z": wl.Z, "entities_per_s": conv * steps / dt,
+                      "ms_per_step": dt / steps * 1e3, "converged_per_step": conv, "host_generate_s": t_gen,
+                      "parity_classes": {"W": int(((wl.ones > 0) & (wl.ones < n)).sum()), "D": int(wl.E - ((wl.ones > 0) & (wl.ones < n)).sum())},
+                      "mean_nit": res.nit.double().mean().item(), "mean_nfev": res.nfev.double().mean().item(),
+                      "largest_launches": [{"kernel": k, "entities": e, "ms": round(ms, 3)} for ms, k, e in top]}
+        del wl, packed, res
+        torch.cuda.empty_cache()
+    return out if rank == 0 else None
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -471,6 +526,12 @@ def main():
     else:
         converged_all = converged
     value = converged_all * a.steps / dt
+    others = None
+    if a.workload == "c2" and not a.no_other_workloads:
+        del res
+        res = None
+        others = other_workloads_leg(a, rank, world, solver, opts, coll_dev)
+        res = solver.solve(packed, opts, out=out)    # (the statistics of the C2 batch again, for the lines below)
 
     if rank == 0:
         # ---- roofline of the dominant kernel = the size-class launch with the largest share of a step ----
@@ -596,7 +657,7 @@ def main():
                        "mean_nit": nit, "mean_nfev": nfev,
                        "converged_per_step": converged_all, "parity_classes": {"W": well_posed, "D": int(wl.E - well_posed)}, "N": wl.N, "Z": wl.Z, "P": packed.P,
                        "host_generate_s": t_gen, "host_handover": e2e, "score_pass": score, "fixed_effect_eval": fe_eval, "cli_end_to_end": cli_e2e,
-                       "cli_subprocess": cli_sub,
+                       "cli_subprocess": cli_sub, "workloads": others,
                        "restreamed_bytes_per_step": b_stream,
                        "restreamed_GBps": b_stream / (float(kernel_ms.sum()) / a.steps * 1e-3) / 1e9 if kernel_ms.sum() else None},
         }

@@ -10,15 +10,14 @@
 namespace gdmix {
 
 constexpr int TEAM_MCAP = 10;                 // history pairs the compact path keeps accumulators for
-constexpr int TEAM_K = 2 * TEAM_MCAP + 8;     // fused reduction width: sq, gd, gg, yy, yg, S'y, Y'y, r'd, moved, max|g|
+constexpr int TEAM_K = 2 * TEAM_MCAP + 7;     // fused reduction width: sq, gd, gg, yy, yg, S'y, Y'y, r'd, max|g|
 constexpr int TEAM_RD = 2 * TEAM_MCAP + 5;    // acc index of r'd
-constexpr int TEAM_MV = 2 * TEAM_MCAP + 6;    // acc index of "the point of this evaluation differs from the previous one's"
 // acc[] layout, with y = g - r (r = the gradient at the last accepted iterate): 0 sum x_j^2 over regularised j, 1 g'd,
-// 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (chronological i < col), K-3 r'd, K-2 moved, K-1 max|g_j|.
-// moved: how many coefficients of this evaluation's point differ from the previously evaluated point (counted by the thread
-// that formed the trial, compact_update_n below; a sum of small integers: exact in any order). nfev is scipy's funcalls:
-// ScalarFunction serves a point equal to the previous one from its cache without counting it (re_solve_quad.hpp, quad_solve).
-// The fixed-effect stepping kernels do not fill it (memo = false: every evaluation counts).
+// 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (chronological i < col), K-2 r'd, K-1 max|g_j|.
+// nfev is scipy's funcalls: ScalarFunction serves a point equal to the previously evaluated one from its cache without counting
+// it (re_solve_quad.hpp, quad_solve). Whether the trial moved is known to the threads that formed it (compact_update_n returns
+// it per coefficient); the team kernels pass it on as a flag next to their barrier (Team::moved_*), compact_advance takes it as
+// `counted`. The fixed-effect stepping kernels count every evaluation.
 // r'd is the slope of the line search at its start, taken from the direction as it is actually used (after mainlb's
 // d = (x + d) - x): the small solve also yields g'd = -g'Hg algebraically, but the two differ once x dwarfs d (badly scaled
 // entities; tests/golden exit_hard_*, exit_extreme_*), and L-BFGS-B's line search runs on the former (lnsrlb: gd = ddot(g, d)).
@@ -71,9 +70,9 @@ struct CompactMats {    // the m x m part (LDS; every workgroup keeps a replica)
 // Called by every thread of a workgroup with identical arguments. Contains one __syncthreads() on the
 // CA_DIRECTION path.
 __device__ __forceinline__ void compact_advance(CompactState& S, const double* acc /* [TEAM_K], registers or LDS */, double f_new,
-                                                const SolveParams& o, CompactMats& L, CompactPlan& plan, bool memo = false) {
+                                                const SolveParams& o, CompactMats& L, CompactPlan& plan, bool counted = true) {
   const int m = o.m;
-  const bool counted = !memo || S.first || acc[TEAM_MV] != 0.0;
+  counted = counted || S.first;
   S.nfev += counted ? 1 : 0;
   const double gd = acc[1], gg = acc[2], rr = acc[3], yg = acc[4];
   bool restore = false, store_pair = false, shift = false, descent_lost = false;
@@ -281,15 +280,17 @@ static_assert(TEAM_MCAP == 10, "GDMIX_HIST_DISPATCH lists the counts 0..10");
 
 // The elementwise part of a step for coefficient j (CA_RETRY / CA_DIRECTION). Vectors as in Work; u, q from L.
 // HC >= plan.col: the number of history slots requested (GDMIX_HIST_DISPATCH(plan.col, ...) makes it equal).
-// Returns 1.0 if the new trial's coefficient j differs from the previously evaluated point's (after a restore: from the
-// restored iterate's, or if the abandoned search's last trial had moved it), else 0.0.
+// moved (may be NULL): set to 1 if the new trial's coefficient j differs from the previously evaluated point's (after a
+// restore: from the restored iterate's, or if the abandoned search's last trial had moved it). A store, not a return value:
+// carrying the flag out of the count-dispatched loops in a register made the team kernel spill 36 VGPRs.
 template <int HC>
-__device__ __forceinline__ double compact_update_n(const CompactPlan& plan, const CompactMats& L, const Work& W, int p, int m, int j) {
+__device__ __forceinline__ void compact_update_n(const CompactPlan& plan, const CompactMats& L, const Work& W, int p, int m, int j,
+                                                 unsigned* moved = nullptr) {
   if (plan.action == CA_RETRY) {
     const double xn = plan.stp * W.d[j] + W.t[j];
-    const double moved = (xn != W.x[j]) ? 1.0 : 0.0;
+    if (moved && xn != W.x[j]) *moved = 1u;
     W.x[j] = xn;
-    return moved;
+    return;
   }
   const double gj = plan.restore ? W.r[j] : W.g[j];
   const double xj = plan.restore ? W.t[j] : W.x[j];
@@ -331,11 +332,11 @@ __device__ __forceinline__ double compact_update_n(const CompactPlan& plan, cons
   W.r[j] = gj;
   const double xn = plan.stp * dj + xj;
   W.x[j] = xn;
-  return (xn != xj || failed_off) ? 1.0 : 0.0;
+  if (moved && (xn != xj || failed_off)) *moved = 1u;
 }
 
 __device__ __forceinline__ void compact_update(const CompactPlan& plan, const CompactMats& L, const Work& W, int p, int m, int j) {
-  (void)compact_update_n<TEAM_MCAP>(plan, L, W, p, m, j);
+  compact_update_n<TEAM_MCAP>(plan, L, W, p, m, j);
 }
 
 }  // namespace gdmix

@@ -304,8 +304,7 @@ static_assert(sizeof(LineSearch) <= 128, "LineSearch must fit its LDS slot");
 enum { SC_FOLD = 0, SC_GDOLD = 1, SC_THETA = 2, SC_MOVED = 3 };
 
 // Is `v` true in any lane of the entity's group? G <= 64: from the wavefront's ballot (all lanes of a group are active
-// together). Wider groups: every wavefront leaves its own answer in its header; quad_solve collects them behind the next
-// evaluation's barriers (grp_any_collect).
+// together). Wider groups: this wavefront's part only (quad_eval collects the wavefronts' parts behind its first fence).
 template <int G>
 __device__ __forceinline__ bool grp_any(bool v) {
   const unsigned long long m = __ballot(v);
@@ -351,15 +350,30 @@ __device__ __forceinline__ double gather_dot2(const int2* pairs, int len, const 
 template <int G, int EPL>
 __device__ __forceinline__ double quad_eval(const QuadLds& L, const SolveParams& o, int gl, int n, int p, int ic,
                                             unsigned rowc, const unsigned (&colc)[EPL], const double (&xt)[EPL],
-                                            double (&g)[EPL], XWave& X) {
+                                            double (&g)[EPL], XWave& X, bool first, bool& counted) {
   double* const xs = L.xs();
   double* const rs = L.rs();
+  // xs still holds the point of the previous evaluation: scipy's ScalarFunction serves an equal point from its cache without
+  // counting it (nfev is its funcalls; a step too small to move x, _differentiable_functions.py)
+  bool mv = first;
 #pragma unroll
   for (int s = 0; s < EPL; ++s) {
     const int j = gl + G * s;
-    if (j < p) xs[j] = xt[s];
+    if (j < p) {
+      mv = mv || (xs[j] != xt[s]);
+      xs[j] = xt[s];
+    }
   }
+  counted = grp_any<G>(mv);
+  if (G > WAVE) L.scal()[SC_MOVED] = counted ? 1.0 : 0.0;   // this wavefront's part; the others' behind the fence
   grp_fence<G>();
+  if (G > WAVE) {
+    constexpr int NWG = G / WAVE;
+    bool any = false;
+#pragma unroll
+    for (int w = 0; w < NWG; ++w) any = any || reinterpret_cast<const double*>(L.base + w * QUAD_HDR_BYTES + 16 * M_REG + 128)[SC_MOVED] != 0.0;
+    counted = any;
+  }
   double part = 0.0, rpart = 0.0;
   const double x0 = ic ? xs[0] : 0.0;
   if (gl < n) {
@@ -434,16 +448,10 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
   int nit = 0, nfev = 0, ifun = 0;
   int status = valid ? -1 : 0;
   bool iter0 = true, first = true;
-  // nfev is scipy's funcalls: ScalarFunction serves a trial point equal to the previously evaluated one from its cache and
-  // does not count it (a step too small to move x; _differentiable_functions.py). `counted`: the trial point that is
-  // evaluated next differs from the point of the previous evaluation. After a line search that was abandoned (restart) the
-  // previous evaluation was the last failed trial: the new trial is compared with the restored iterate, and counts anyway
-  // unless that failed trial had not moved either.
-  bool counted = true, failed_at_t = true;
-  constexpr int NWG = G > WAVE ? G / WAVE : 1;
+  // nfev is scipy's funcalls: an evaluation at the point of the previous evaluation is not counted (quad_eval)
   double f = 0.0, gd = 0.0, rr = 0.0, stp = 0.0, sbgnrm = 0.0;
   if (valid) {
-    scal[SC_FOLD] = 0.0; scal[SC_GDOLD] = 0.0; scal[SC_THETA] = 1.0; scal[SC_MOVED] = 1.0;
+    scal[SC_FOLD] = 0.0; scal[SC_GDOLD] = 0.0; scal[SC_THETA] = 1.0;
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
       const int j = gl + G * s;
@@ -454,13 +462,8 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
     bool need_dir = false, restart = false;
     if (status < 0) {
       // ---- f, g at the trial point; g'd, y'y and max|g| in one reduction pass ------------------------
-      f = quad_eval<G, EPL>(L, o, gl, n, p, ic, rowc, colc, V.x, V.g, X);
-      if (G > WAVE) {   // the wavefronts' answers (left in their headers when the trial was formed), behind quad_eval's barriers
-        bool any = false;
-#pragma unroll
-        for (int w = 0; w < NWG; ++w) any = any || reinterpret_cast<const double*>(L.base + w * QUAD_HDR_BYTES + 16 * M_REG + 128)[SC_MOVED] != 0.0;
-        counted = any;
-      }
+      bool counted;
+      f = quad_eval<G, EPL>(L, o, gl, n, p, ic, rowc, colc, V.x, V.g, X, first, counted);
       nfev += counted ? 1 : 0;
       {
         double a = 0.0, b = 0.0, c = 0.0;
@@ -487,18 +490,11 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
         if (task == LS_FG) {
           ++ifun;
           if (ifun - 1 < o.maxls) {
-            bool mv = false;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
               const int j = gl + G * s;
-              if (j < p) {
-                const double xn = stp * V.d[s] + xo[j];   // stp == 1: exactly xo + d
-                mv = mv || (xn != V.x[s]);
-                V.x[s] = xn;
-              }
+              if (j < p) V.x[s] = stp * V.d[s] + xo[j];   // stp == 1: exactly xo + d
             }
-            counted = grp_any<G>(mv);
-            if (G > WAVE) scal[SC_MOVED] = counted ? 1.0 : 0.0;
           } else {
             restart = true;   // iback >= maxls
             need_dir = true;
@@ -544,13 +540,11 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
     // ---- new search direction for the rows that need one (again after a line-search restart) ---------
     while (__any(need_dir)) {
       if (need_dir && restart) {
-        bool off = false;   // the abandoned search's last trial: had it moved away from the iterate?
 #pragma unroll
         for (int s = 0; s < EPL; ++s) {
           const int j = gl + G * s;
-          if (j < p) { off = off || (V.x[s] != xo[j]); V.x[s] = xo[j]; V.g[s] = go[j]; }
+          if (j < p) { V.x[s] = xo[j]; V.g[s] = go[j]; }
         }
-        failed_at_t = failed_at_t && !grp_any<G>(off);
         f = scal[SC_FOLD];
         restart = false;
         if (cnt == 0) { status = 4; need_dir = false; }
@@ -621,16 +615,8 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
           dcsrch_start(LS, f, gd, stp);
           *L.ls() = LS;
           ifun = 1;
-          bool mv = false;
 #pragma unroll
-          for (int s = 0; s < EPL; ++s) {
-            const double xn = stp * V.d[s] + V.x[s];   // V.x still holds x_old here
-            mv = mv || (xn != V.x[s]);
-            V.x[s] = xn;
-          }
-          counted = grp_any<G>(mv) || !failed_at_t;
-          if (G > WAVE) scal[SC_MOVED] = counted ? 1.0 : 0.0;
-          failed_at_t = true;
+          for (int s = 0; s < EPL; ++s) V.x[s] = stp * V.d[s] + V.x[s];   // V.x still holds x_old here
           need_dir = false;
         }
       }

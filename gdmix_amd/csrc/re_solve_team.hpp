@@ -46,7 +46,8 @@ struct TeamSync {
   unsigned abort;    // a workgroup gave up waiting (never expected; keeps a lost workgroup from hanging the GPU)
   unsigned next;     // team 0's copy: next entity of the class to hand out
   int cur;           // entity this team is working on
-  unsigned pad[12];
+  unsigned moved[2]; // by parity of the update: some coefficient of the trial differs from the previously evaluated point
+  unsigned pad[10];
   double vec[2][TEAM_VEC][TEAM_MAX_BLOCKS];   // [phase][value][workgroup]
 };
 
@@ -60,6 +61,7 @@ struct TeamLds {
   int llist[TEAM_LONG_CAP];       // long columns of the entity, ascending
   int lraw[TEAM_LONG_CAP];
   int n_long, n_long_raw;
+  unsigned moved[2];              // one-workgroup teams: the flag of TeamSync::moved
 };
 
 template <int NW>
@@ -111,6 +113,25 @@ struct Team {
   __device__ __forceinline__ void sync() {
     if (nblocks > 1) device_barrier();
     else __syncthreads();
+  }
+  // "The trial point just formed differs from the previously evaluated point": set by any wavefront that moved a coefficient
+  // during update number u (slot u & 1), read by everybody after the evaluation of that trial, cleared for its next use at the
+  // start of that evaluation (behind the barrier that follows the update; the slot's previous value was read an evaluation ago).
+  __device__ __forceinline__ unsigned* moved_slot(unsigned u) const { return nblocks > 1 ? &gs->moved[u & 1u] : &L->moved[u & 1u]; }
+  __device__ __forceinline__ void moved_set(unsigned u, bool mine) {
+    if (__ballot(mine) != 0ull && lane == 0) {
+      if (nblocks > 1) __hip_atomic_store(&gs->moved[u & 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else L->moved[u & 1u] = 1u;
+    }
+  }
+  __device__ __forceinline__ bool moved_get(unsigned u) const {
+    return (nblocks > 1 ? __hip_atomic_load(&gs->moved[u & 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : L->moved[u & 1u]) != 0u;
+  }
+  __device__ __forceinline__ void moved_clear(unsigned u) {
+    if (threadIdx.x == 0) {
+      if (nblocks > 1) { if (bid == 0) __hip_atomic_store(&gs->moved[u & 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      else L->moved[u & 1u] = 0u;
+    }
   }
   __device__ __forceinline__ bool aborted() const {
     return nblocks > 1 && __hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
@@ -433,7 +454,7 @@ __device__ __forceinline__ void team_products(const Team<NW>& tm, const Work& W,
 // 1 g'd, 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (y = g - r; chronological i < col), K-2 r'd, K-1 max|g_j|.
 template <int NW>
 __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W,
-                                            int col, int head, double moved, double (&acc)[TEAM_K]
+                                            int col, int head, double (&acc)[TEAM_K]
 #ifdef GDMIX_TEAM_PROFILE
                                             , unsigned long long (&prof_t)[8], unsigned long long& prof_last
 #endif
@@ -450,7 +471,6 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
   // back: no synchronisation), so that the accumulators and the tile staging above are not live at the same time.
 #pragma unroll
   for (int k = 0; k < TEAM_K; ++k) acc[k] = 0.0;
-  acc[TEAM_MV] = moved;   // this thread's coefficients of the trial point that differ from the previously evaluated point
   GDMIX_HIST_DISPATCH(col, (team_products<NW, HC>(tm, W, p, m, col, head, first_reg, acc)))
   TEAM_PROF(2);
   tm.reduce(acc);
@@ -488,7 +508,7 @@ __device__ __forceinline__ void team_long_setup(Team<NW>& tm, const EntityView& 
 }
 
 template <int NW>
-__device__ void team_solve(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W, SolveStats& out) {
+__device__ __forceinline__ void team_solve(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W, SolveStats& out) {
   const int p = P.p, m = o.m;
   TeamLds<NW>& L = *tm.L;
   team_long_setup(tm, P);
@@ -499,15 +519,18 @@ __device__ void team_solve(Team<NW>& tm, const EntityView& P, const SolveParams&
   TEAM_PROF_DECL
   for (int j = tm.tid; j < p; j += tm.NT) { W.d[j] = 0.0; W.r[j] = 0.0; }
   tm.sync();
-  double moved = 0.0;
+  unsigned upd = 0;   // updates so far = trials formed
+  tm.moved_clear(0u); tm.moved_clear(1u);
+  tm.sync();
   for (;;) {
+    tm.moved_clear(upd + 1u);   // the slot the next update uses
 #ifdef GDMIX_TEAM_PROFILE
-    const double f_new = team_eval(tm, P, o, W, S.col, S.head, moved, acc, prof_t, prof_last);
+    const double f_new = team_eval(tm, P, o, W, S.col, S.head, acc, prof_t, prof_last);
 #else
-    const double f_new = team_eval(tm, P, o, W, S.col, S.head, moved, acc);
+    const double f_new = team_eval(tm, P, o, W, S.col, S.head, acc);
 #endif
     if (tm.aborted()) { ++S.nfev; S.status = GDMIX_RE_ST_ABORTED; break; }
-    compact_advance(S, acc, f_new, o, L.mats, plan, true);
+    compact_advance(S, acc, f_new, o, L.mats, plan, tm.moved_get(upd));
     TEAM_PROF(4);
     if (plan.action == CA_STOP) break;
     if (plan.action == CA_STOP_RESTORE) {
@@ -515,9 +538,12 @@ __device__ void team_solve(Team<NW>& tm, const EntityView& P, const SolveParams&
       tm.sync();
       break;
     }
-    moved = 0.0;
-    GDMIX_HIST_DISPATCH((plan.action == CA_DIRECTION ? plan.col : 0),
-                        for (int j = tm.tid; j < p; j += tm.NT) moved += compact_update_n<HC>(plan, L.mats, W, p, m, j))
+    ++upd;
+    {
+      unsigned* const mv = tm.moved_slot(upd);   // plain stores of 1 (a team's workgroups: made visible by the barrier's release)
+      GDMIX_HIST_DISPATCH((plan.action == CA_DIRECTION ? plan.col : 0),
+                          for (int j = tm.tid; j < p; j += tm.NT) compact_update_n<HC>(plan, L.mats, W, p, m, j, mv))
+    }
     TEAM_PROF(5);
     tm.sync();
     TEAM_PROF(6);
@@ -551,7 +577,7 @@ struct TeamRegs {
 
 template <int NW, int EPL>
 __device__ __forceinline__ double team_eval_reg(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W,
-                                                TeamRegs<EPL>& R, int col, double moved, const double*& acc) {
+                                                TeamRegs<EPL>& R, int col, const double*& acc) {
   const int n = P.n, p = P.p, ic = P.ic;
   const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
   const double inv_n = o.sum_loss ? 1.0 : 1.0 / (double)n;
@@ -597,10 +623,6 @@ __device__ __forceinline__ double team_eval_reg(Team<NW>& tm, const EntityView& 
     }
   }
   GDMIX_TREG_VALUE(TEAM_RD, R.r[i] * R.d[i], false)
-  {
-    const double t_ = wave_sum(moved);
-    if (tm.lane == TEAM_MV) mine = t_;
-  }
   GDMIX_TREG_VALUE(TEAM_K - 1, fabs(R.g[i]), true)
 #undef GDMIX_TREG_VALUE
   acc = tm.template reduce_placed<TEAM_K>(mine);
@@ -660,7 +682,7 @@ __device__ __forceinline__ double compact_update_reg(const CompactPlan& plan, co
 // are written straight from the owners' registers (theta_out / thr_out: the entity's slices, either may be NULL); W.x holds
 // theta on exit for sc1 readers (variance_simple<true>).
 template <int NW, int EPL>
-__device__ void team_solve_reg(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W, const double* theta0,
+__device__ __forceinline__ void team_solve_reg(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W, const double* theta0,
                                double* theta_out, double* thr_out, SolveStats& out) {
   const int p = P.p, m = o.m;
   TeamLds<NW>& L = *tm.L;
@@ -680,11 +702,14 @@ __device__ void team_solve_reg(Team<NW>& tm, const EntityView& P, const SolvePar
     if (j < p) st_x<true>(W.x + j, R.x[i]);
   }
   tm.sync();
-  double moved = 0.0;
+  unsigned upd = 0;
+  tm.moved_clear(0u); tm.moved_clear(1u);
+  tm.sync();
   for (;;) {
-    const double f_new = team_eval_reg<NW, EPL>(tm, P, o, W, R, S.col, moved, acc);
+    tm.moved_clear(upd + 1u);
+    const double f_new = team_eval_reg<NW, EPL>(tm, P, o, W, R, S.col, acc);
     if (tm.aborted()) { ++S.nfev; S.status = GDMIX_RE_ST_ABORTED; break; }
-    compact_advance(S, acc, f_new, o, L.mats, plan, true);
+    compact_advance(S, acc, f_new, o, L.mats, plan, tm.moved_get(upd));
     if (plan.action == CA_STOP) break;
     if (plan.action == CA_STOP_RESTORE) {
 #pragma unroll
@@ -695,11 +720,15 @@ __device__ void team_solve_reg(Team<NW>& tm, const EntityView& P, const SolvePar
       tm.sync();
       break;
     }
-    moved = 0.0;
+    ++upd;
+    {
+      double moved = 0.0;
 #pragma unroll
-    for (int i = 0; i < EPL; ++i) {
-      const int j = (tm.wid + i * tm.nwaves) * WAVE + tm.lane;
-      if (j < p) st_x<true>(W.x + j, compact_update_reg<EPL>(plan, L.mats, R, i, m, moved));
+      for (int i = 0; i < EPL; ++i) {
+        const int j = (tm.wid + i * tm.nwaves) * WAVE + tm.lane;
+        if (j < p) st_x<true>(W.x + j, compact_update_reg<EPL>(plan, L.mats, R, i, m, moved));
+      }
+      tm.moved_set(upd, moved != 0.0);
     }
     tm.sync();
   }

@@ -86,12 +86,18 @@ struct WregState {
 // f and g at the point held in `xt` (registers). g <- gradient, returns f. rsum_out: sum of residuals.
 template <int EPL>
 __device__ __forceinline__ double wreg_eval(const WregLds& L, const SolveParams& o, int lane, int n, int p, int ic,
-                                            const double (&xt)[EPL], double (&g)[EPL]) {
+                                            const double (&xt)[EPL], double (&g)[EPL], bool first, bool& counted) {
+  // xs still holds the point of the previous evaluation: an evaluation at the same point is not counted (nfev is scipy's funcalls)
+  bool mv = first;
 #pragma unroll
   for (int s = 0; s < EPL; ++s) {
     const int j = lane + WAVE * s;
-    if (j < p) L.xs[j] = xt[s];
+    if (j < p) {
+      mv = mv || (L.xs[j] != xt[s]);
+      L.xs[j] = xt[s];
+    }
   }
+  counted = __ballot(mv) != 0ull;
   wave_lds_fence();
   double part = 0.0, rpart = 0.0;
   const double x0 = ic ? L.xs[0] : 0.0;
@@ -148,8 +154,9 @@ __device__ __forceinline__ double wreg_eval(const WregLds& L, const SolveParams&
 
 // One evaluation site, one line-search site: the solve is written as a loop around "evaluate f, g at the
 // current trial point" so that the (large) inlined eval body and its exp/log temporaries exist once.
-// The driver is written against an evaluator `eval(xt, g) -> f` (g <- gradient at the point xt held in registers, coefficient
-// lane + 64 s in slot s; f, and with it every decision below, uniform over the wavefront): wreg_eval below for an entity that
+// The driver is written against an evaluator `eval(xt, g, first, counted) -> f` (g <- gradient at the point xt held in registers,
+// coefficient lane + 64 s in slot s; f, and with it every decision below, uniform over the wavefront; counted <- xt differs from
+// the point of the previous evaluation — nfev is scipy's funcalls, which leaves out a repeated point — or first): wreg_eval below for an entity that
 // lives in one wavefront's LDS, the workgroup-cooperative evaluation of re_solve_tall.hpp for tall entities (every wavefront of
 // the workgroup then runs this driver on identical inputs and so takes identical decisions). rho / alpha / lsp: this
 // wavefront's uniform state in LDS.
@@ -167,13 +174,12 @@ __device__ __forceinline__ void wreg_solve_ev(double* const rho, double* const a
   double theta = 1.0;
   int nit = 0, nfev = 0, status = -1, ifun = 0;
   bool iter0 = true, first = true;
-  // nfev is scipy's funcalls (see re_solve_quad.hpp, quad_solve): a trial point equal to the previously evaluated point is not counted
-  bool counted = true, failed_at_t = true;
   double f = 0.0, fold = 0.0, gd = 0.0, gdold = 0.0, rr = 0.0, stp = 0.0, sbgnrm = 0.0;
   for (;;) {
     // ---- f, g at the trial point; g'd, y'y and max|g| in one reduction pass (the first trial of a
     //      line search is accepted ~95% of the time, so y'y and max|g| are computed speculatively) -------
-    f = uniform_d(eval(V.x, V.g));
+    bool counted;
+    f = uniform_d(eval(V.x, V.g, first, counted));
     nfev += counted ? 1 : 0;
     {
       double a = 0.0, b = 0.0, c = 0.0;
@@ -199,14 +205,13 @@ __device__ __forceinline__ void wreg_solve_ev(double* const rho, double* const a
       if (task == LS_FG) {
         ++ifun;
         if (ifun - 1 < o.maxls) {
-          bool mv = false;
+          if (stp == 1.0) {
 #pragma unroll
-          for (int s = 0; s < EPL; ++s) {
-            const double xn = (stp == 1.0) ? V.xo[s] + V.d[s] : stp * V.d[s] + V.xo[s];
-            mv = mv || (xn != V.x[s]);
-            V.x[s] = xn;
+            for (int s = 0; s < EPL; ++s) V.x[s] = V.xo[s] + V.d[s];
+          } else {
+#pragma unroll
+            for (int s = 0; s < EPL; ++s) V.x[s] = stp * V.d[s] + V.xo[s];
           }
-          counted = __ballot(mv) != 0ull;
           continue;
         }
         restart = true;   // iback >= maxls
@@ -246,10 +251,8 @@ __device__ __forceinline__ void wreg_solve_ev(double* const rho, double* const a
     // ---- new search direction (repeated from steepest descent after a line-search restart) -----------
     for (;;) {
       if (restart) {
-        bool off = false;   // the abandoned search's last trial: had it moved away from the iterate?
 #pragma unroll
-        for (int s = 0; s < EPL; ++s) { off = off || (V.x[s] != V.xo[s]); V.x[s] = V.xo[s]; V.g[s] = V.go[s]; }
-        failed_at_t = failed_at_t && (__ballot(off) == 0ull);
+        for (int s = 0; s < EPL; ++s) { V.x[s] = V.xo[s]; V.g[s] = V.go[s]; }
         f = fold;
         if (cnt == 0) { status = 4; break; }
         cnt = 0; theta = 1.0;
@@ -314,16 +317,12 @@ __device__ __forceinline__ void wreg_solve_ev(double* const rho, double* const a
       break;
     }
     if (status >= 0) break;
-    {
-      bool mv = false;
+    if (stp == 1.0) {
 #pragma unroll
-      for (int s = 0; s < EPL; ++s) {
-        const double xn = (stp == 1.0) ? V.xo[s] + V.d[s] : stp * V.d[s] + V.xo[s];
-        mv = mv || (xn != V.xo[s]);   // V.x == V.xo here (the accepted or restored iterate)
-        V.x[s] = xn;
-      }
-      counted = (__ballot(mv) != 0ull) || !failed_at_t;
-      failed_at_t = true;
+      for (int s = 0; s < EPL; ++s) V.x[s] = V.xo[s] + V.d[s];
+    } else {
+#pragma unroll
+      for (int s = 0; s < EPL; ++s) V.x[s] = stp * V.d[s] + V.xo[s];
     }
   }
   if (status == 4) {   // abnormal stop: report the restored gradient's norm
@@ -343,7 +342,9 @@ template <int EPL>
 __device__ __forceinline__ void wreg_solve(const WregLds& L, const SolveParams& o, int lane, int n, int p, int ic,
                                            WregState<EPL>& V, SolveStats& out) {
   wreg_solve_ev<EPL>(L.rho, L.alpha, L.ls, o, V, out,
-                     [&](const double (&xt)[EPL], double (&g)[EPL]) { return wreg_eval<EPL>(L, o, lane, n, p, ic, xt, g); });
+                     [&](const double (&xt)[EPL], double (&g)[EPL], bool first, bool& counted) {
+                       return wreg_eval<EPL>(L, o, lane, n, p, ic, xt, g, first, counted);
+                     });
 }
 
 }  // namespace gdmix
