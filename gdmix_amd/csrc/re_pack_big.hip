@@ -4,8 +4,9 @@
 // copy with every column's entries in row-major order (the order scipy's COO mat-vec accumulates them
 // in; job_consumers.py:209-258 slices, binary_logistic_regression.py:84-131 multiplies).
 //
-// All such entities are sorted together, device-wide: key = (rank in the big list << 32) | global column,
-// value = position inside the entity. The input is in position order and the radix sort is stable, so
+// All such entities are sorted together, device-wide: key = (rank in the big list << cbits) | global column with cbits = the
+// bits of the largest column index among them (a radix pass per 8 key bits: MovieLens bags need 3 passes instead of the 6 of
+// a 32-bit column field, a 65 536-feature space 4), value = position inside the entity. The input is in position order and the radix sort is stable, so
 // equal columns stay in row-major order without the position being part of the key. The sort itself is the
 // library's (rocPRIM radix_sort_pairs); everything around it is here.
 #include <cstring>
@@ -44,22 +45,39 @@ __device__ __forceinline__ int big_find(const int64_t* __restrict__ offs, int n_
   return lo;
 }
 
+// largest global column index among the big entities (and the range check of all of them)
+__global__ __launch_bounds__(256) void big_maxcol_kernel(const int64_t* __restrict__ ent_nnz_ptr, const int64_t* __restrict__ col_global,
+                                                         const int32_t* __restrict__ big_list, const int64_t* __restrict__ offs, int n_big,
+                                                         int64_t total, unsigned* __restrict__ max_col, int* __restrict__ err) {
+  bool bad = false;
+  unsigned mx = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = big_find(offs, n_big, i);
+    const int64_t c = col_global[ent_nnz_ptr[big_list[b]] + (i - offs[b])];
+    bad |= (c < 0 || c > 0x7fffffffll);
+    mx = (!bad && (unsigned)c > mx) ? (unsigned)c : mx;
+  }
+  __shared__ unsigned smx;
+  if (threadIdx.x == 0) smx = 0;
+  __syncthreads();
+  atomicMax(&smx, mx);
+  __syncthreads();
+  if (threadIdx.x == 0 && smx) atomicMax(max_col, smx);
+  if (bad) atomicExch(err, GDMIX_RE_ERANGE);
+}
+
 __global__ __launch_bounds__(256) void big_fill_kernel(const int64_t* __restrict__ ent_nnz_ptr,
                                                        const int64_t* __restrict__ col_global,
                                                        const int32_t* __restrict__ big_list,
-                                                       const int64_t* __restrict__ offs, int n_big, int64_t total,
-                                                       unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                       int* __restrict__ err) {
-  bool bad = false;
+                                                       const int64_t* __restrict__ offs, int n_big, int64_t total, unsigned cbits,
+                                                       unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int b = big_find(offs, n_big, i);
     const int64_t pos = i - offs[b];
     const int64_t c = col_global[ent_nnz_ptr[big_list[b]] + pos];
-    bad |= (c < 0 || c > 0x7fffffffll);
-    keys[i] = ((unsigned long long)(uint32_t)b << 32) | (uint32_t)c;
+    keys[i] = ((unsigned long long)(uint32_t)b << cbits) | ((unsigned long long)c & ((1ull << cbits) - 1ull));
     vals[i] = (uint32_t)pos;
   }
-  if (bad) atomicExch(err, GDMIX_RE_ERANGE);
 }
 
 // rows[b] = samples of big entity b + 1 (its row-pointer entries)
@@ -101,13 +119,13 @@ __global__ __launch_bounds__(256) void big_heads_kernel(const unsigned long long
     head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void big_emit_kernel(BigPackArgs a, const int64_t* __restrict__ offs, int64_t total,
+__global__ __launch_bounds__(256) void big_emit_kernel(BigPackArgs a, const int64_t* __restrict__ offs, int64_t total, unsigned cbits,
                                                        const unsigned long long* __restrict__ keys,
                                                        const uint32_t* __restrict__ vals, const int32_t* __restrict__ head,
                                                        const int64_t* __restrict__ scan, const uint32_t* __restrict__ row_of) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const unsigned long long key = keys[i];
-    const int b = (int)(key >> 32);
+    const int b = (int)(key >> cbits);
     const int64_t e = a.big_list[b];
     const int64_t z0 = a.ent_nnz_ptr[e];
     const int nnz = (int)(a.ent_nnz_ptr[e + 1] - z0);
@@ -117,7 +135,7 @@ __global__ __launch_bounds__(256) void big_emit_kernel(BigPackArgs a, const int6
     const int h = head[i];
     const int lid = (int)(scan[i] + h - 1 - scan[o]);   // runs started before or at i, minus one; the entity's first run is 0
     int32_t* const cp = a.col_ptr + z0 + e;
-    if (h) { a.uniq_sparse[z0 + lid] = (int32_t)(uint32_t)key; cp[lid] = k; }
+    if (h) { a.uniq_sparse[z0 + lid] = (int32_t)(key & ((1ull << cbits) - 1ull)); cp[lid] = k; }
     a.csr_col[z0 + pos] = lid;
     a.csc_val[z0 + k] = a.val[z0 + pos];
     a.csc_row[z0 + k] = (int32_t)row_of[o + pos];   // filled by big_rows_kernel (a bisection of the row pointers per entry before)
@@ -138,11 +156,10 @@ int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s) 
   if (nb <= 0 || T <= 0) return GDMIX_RE_OK;
   unsigned ebits = 1;
   while ((1ll << ebits) < nb) ++ebits;
-  const unsigned end_bit = 32 + ebits;
 
   size_t sort_tmp = 0, scan_tmp = 0, scan2_tmp = 0;
   HIP_TRY((rocprim::radix_sort_pairs(nullptr, sort_tmp, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                     (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)T, 0u, end_bit, s)));
+                                     (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)T, 0u, 32 + ebits, s)));
   HIP_TRY((rocprim::exclusive_scan(nullptr, scan_tmp, (int32_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)T,
                                    rocprim::plus<int64_t>(), s)));
   HIP_TRY((rocprim::exclusive_scan(nullptr, scan2_tmp, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)nb,
@@ -189,8 +206,18 @@ int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s) 
   HIP_TRY((rocprim::exclusive_scan(lib, tmp, sizes, offs, (int64_t)0, (size_t)nb, rocprim::plus<int64_t>(), s)));
   int64_t g64 = (T + 255) / 256;
   grid = (int)(g64 > ctx->num_cus * 32 ? ctx->num_cus * 32 : g64);
-  hipLaunchKernelGGL(big_fill_kernel, dim3(grid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, offs, nb, T,
-                     keys_a, vals_a, a.err);
+  // the bits of the column field: of the largest column index among these entities (one small read-back)
+  unsigned* max_col_dev = reinterpret_cast<unsigned*>(sizes + nb);   // the spare entry of `sizes`
+  HIP_TRY(hipMemsetAsync(max_col_dev, 0, 4, s));
+  hipLaunchKernelGGL(big_maxcol_kernel, dim3(grid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, offs, nb, T, max_col_dev, a.err);
+  unsigned max_col = 0;
+  HIP_TRY(hipMemcpyAsync(&max_col, max_col_dev, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  unsigned cbits = 1;
+  while (cbits < 32 && (max_col >> cbits) != 0u) ++cbits;
+  const unsigned end_bit = cbits + ebits;
+  hipLaunchKernelGGL(big_fill_kernel, dim3(grid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, offs, nb, T, cbits,
+                     keys_a, vals_a);
   tmp = lib_tmp;
   HIP_TRY((rocprim::radix_sort_pairs(lib, tmp, keys_a, keys_b, vals_a, vals_b, (size_t)T, 0u, end_bit, s)));
   hipLaunchKernelGGL(big_heads_kernel, dim3(grid), dim3(256), 0, s, keys_b, T, head);
@@ -202,7 +229,7 @@ int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s) 
   tmp = lib_tmp;
   HIP_TRY((rocprim::exclusive_scan(lib, tmp, rows, row_offs, (int64_t)0, (size_t)nb, rocprim::plus<int64_t>(), s)));
   hipLaunchKernelGGL(big_rows_kernel, dim3(ctx->num_cus * 32), dim3(256), 0, s, a, offs, row_offs, rows, row_of);
-  hipLaunchKernelGGL(big_emit_kernel, dim3(grid), dim3(256), 0, s, a, offs, T, keys_b, vals_b, head, scan, row_of);
+  hipLaunchKernelGGL(big_emit_kernel, dim3(grid), dim3(256), 0, s, a, offs, T, cbits, keys_b, vals_b, head, scan, row_of);
   HIP_TRY(hipGetLastError());
   return GDMIX_RE_OK;
 }
