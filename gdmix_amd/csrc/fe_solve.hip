@@ -65,10 +65,28 @@ struct FeCopy {
   int nunit, nblock, nlaunch;
 };
 
+// Frequent features (real feature frequencies are Zipf-like: one feature can hold a tenth of the non-zeros): in the column pass
+// their adds pile up on one LDS address (of the 64 lanes of an instruction, those that hold an entry of the same column
+// serialise), 0.34 ms instead of 0.25 on the Zipf shard of tools/fe_bench.py. A dense pass per frequent column straight off the
+// column-major arrays was tried and lost (0.52 ms): every such column then gathers the residuals on its own, 64 columns =
+// 64 sweeps over them instead of one. So the scatter form stays and the frequent columns (at least FE_HOT_MIN entries, the
+// FE_HOT_MAX most frequent of them) get FE_HOT_REP accumulators each: in the column pass's copy an entry of frequent column h in
+// row r goes to the virtual column vbase + h * FE_HOT_REP + r % FE_HOT_REP. The virtual columns form one more block at the end
+// (entries by ascending row like every block: one sweep over the residuals for all of them), neighbouring rows land on different
+// accumulators, and fe_hot_finish_kernel adds a column's FE_HOT_REP sums in replica order. No atomics across workgroups, fixed shape.
+constexpr int FE_HOT_MAX = 64;
+constexpr int FE_HOT_REP = 32;
+static_assert(FE_HOT_MAX * FE_HOT_REP <= FE_B && FE_B % FE_HOT_REP == 0, "the virtual columns are one block");
+struct FeHot {
+  int n, vbase;              // vbase: first virtual column (a multiple of FE_B, >= d)
+  const int32_t* col;        // [n] local column of frequent column h
+};
+
 struct FeDev {
   int n, d, ic, P, m;
   int64_t z, D;
   FeCopy rc, cc;            // row pass, column pass
+  FeHot hot;                // frequent columns: left out of cc
   const int32_t* multi;     // [nmulti] row blocks cut into several units
   int nmulti, nred;         // nred = rc.nunit + nmulti * (workgroups of fe_rows_fix_kernel per block) entries of loss_part / rsum_part
   const float *y, *o, *w;   // w may be NULL
@@ -319,6 +337,56 @@ __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
   }
 }
 
+// ---- frequent columns: FE_HOT_REP accumulators each (FeHot above) -------------------------------------------------------------
+// after fe_finish_kernel (which left 0 for a frequent column: the copy holds no entry under its own number). One workgroup per
+// frequent column: replica r's sum over the virtual block's units by 8 strands, strands in order, then the replicas in order.
+__global__ __launch_bounds__(FE_THREADS) void fe_hot_finish_kernel(FeDev F) {
+  constexpr int STR = FE_THREADS / FE_HOT_REP;
+  __shared__ double lds[STR][FE_HOT_REP];
+  __shared__ double rep[FE_HOT_REP];
+  const FeHot& H = F.hot;
+  const int h = blockIdx.x, tid = threadIdx.x, r = tid % FE_HOT_REP, strand = tid / FE_HOT_REP;
+  const int b = H.vbase / FE_B, i = h * FE_HOT_REP + r;
+  const int u0 = F.cc.ufirst[b], u1 = F.cc.ufirst[b + 1];
+  const double* __restrict__ part = F.cc.part;
+  double t = 0.0;
+  int u = u0 + strand;
+  for (; u + 3 * STR < u1; u += 4 * STR) {
+    const double a0 = part[(size_t)u * FE_B + i], a1 = part[(size_t)(u + STR) * FE_B + i];
+    const double a2 = part[(size_t)(u + 2 * STR) * FE_B + i], a3 = part[(size_t)(u + 3 * STR) * FE_B + i];
+    t += a0; t += a1; t += a2; t += a3;
+  }
+  for (; u < u1; u += STR) t += part[(size_t)u * FE_B + i];
+  lds[strand][r] = t;
+  __syncthreads();
+  if (strand == 0) {
+    double g = lds[0][r];
+#pragma unroll
+    for (int k = 1; k < STR; ++k) g += lds[k][r];
+    rep[r] = g;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double g = rep[0];
+#pragma unroll
+    for (int k = 1; k < FE_HOT_REP; ++k) g += rep[k];
+    F.fg[F.umap[H.col[h]]] = g;
+  }
+}
+
+// the column pass's source columns with the frequent ones replaced by their virtual columns; one thread per row
+__global__ void fe_hot_remap_kernel(const int32_t* __restrict__ ptr, int n, const int32_t* __restrict__ col, const int32_t* __restrict__ hotmap,
+                                    int vbase, int32_t* __restrict__ col2) {
+  for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x) {
+    const int k1 = ptr[row + 1];
+    for (int k = ptr[row]; k < k1; ++k) {
+      const int c = col[k];
+      const int h = hotmap[c];
+      col2[k] = h >= 0 ? vbase + h * FE_HOT_REP + (row % FE_HOT_REP) : c;
+    }
+  }
+}
+
 // g = reduced data gradient + regulariser, and every product the driver needs (re_lbfgs_compact.hpp acc[] layout)
 __global__ __launch_bounds__(FE_THREADS) void fe_dots_kernel(FeDev F, SolveParams o) {
   __shared__ double red[FE_WAVES][TEAM_K];
@@ -469,12 +537,17 @@ __global__ void fe_flag_kernel(const int32_t* __restrict__ ptr, int nseg, int64_
 
 struct FeEnt { int32_t seg, idx; float val; };   // an entry on its way through the sort
 
+// Sort key: the block, refined by the window of 2^FE_SPAN_BITS gathered elements the entry's key lies in. The entries of a block
+// already come by ascending key, so the windows do not change the sorted order; they only add cut points, so that no unit's keys
+// span more than the packed word can hold (a block with few entries is one unit over the whole vector otherwise, and one such
+// unit would send the whole copy to the three-array form: the Zipf shard of tools/fe_bench.py, 0.34 ms instead of 0.26).
+constexpr int FE_SPAN_BITS = 32 - FE_LOC_BITS;
 __global__ void fe_ent_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ idx, const float* __restrict__ val, int64_t z,
-                              uint32_t* __restrict__ skey, FeEnt* __restrict__ ent) {
+                              int nwin, int wbits, uint32_t* __restrict__ skey, FeEnt* __restrict__ ent) {
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < z; k += (int64_t)gridDim.x * blockDim.x) {
-    const int i = idx[k];
-    skey[k] = (uint32_t)(i / FE_B);
-    ent[k] = FeEnt{seg[k], i, val[k]};
+    const int i = idx[k], sg = seg[k];
+    skey[k] = (uint32_t)(i / FE_B) * (uint32_t)nwin + (uint32_t)(sg >> wbits);
+    ent[k] = FeEnt{sg, i, val[k]};
   }
 }
 
@@ -521,23 +594,37 @@ __global__ void fe_block_kernel(const uint32_t* __restrict__ sorted, int64_t z, 
   }
 }
 
-// units of block b (an empty block keeps one: its outputs are still due)
-__global__ void fe_chunks_kernel(const int32_t* __restrict__ bp, int nblock, int chunk, int32_t* __restrict__ nch) {
+// Entries per unit of a (block, window) with len entries. A unit is one wavefront; where a block has fewer than four entries
+// per 128-byte line of the gathered vector, nearly every gather is a line of its own out of the far cache and the unit crawls
+// at a few microseconds per trip of 512 entries: 62 500 entries = 0.3 ms, the length of the whole pass (the rare features' blocks
+// of a Zipf shard). Such blocks get units an eighth as long (sparse_chunk; 0 = never).
+__device__ __forceinline__ int fe_block_chunk(int len, int chunk, int sparse_chunk, int extent) {
+  return (sparse_chunk > 0 && (int64_t)len * 4 < (int64_t)extent) ? sparse_chunk : chunk;
+}
+
+// units of (block, window) b; the first window of a block keeps one even when empty: the block's outputs are still due
+__global__ void fe_chunks_kernel(const int32_t* __restrict__ bp, int nblock, int nwin, int chunk, int sparse_chunk, int extent,
+                                 int32_t* __restrict__ nch) {
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b <= nblock; b += gridDim.x * blockDim.x) {
     const int len = b < nblock ? bp[b + 1] - bp[b] : 0;
-    nch[b] = b < nblock ? (len <= chunk ? 1 : (len + chunk - 1) / chunk) : 0;
+    const int c = fe_block_chunk(len, chunk, sparse_chunk, extent);
+    nch[b] = b < nblock ? (len == 0 ? (b % nwin == 0 ? 1 : 0) : (len + c - 1) / c) : 0;
   }
 }
 
-__global__ void fe_units_kernel(const int32_t* __restrict__ bp, const int32_t* __restrict__ ufirst, int nblock, int chunk, int64_t z,
-                                int32_t* __restrict__ ustart, int32_t* __restrict__ ublock) {
+// ufirst: first unit per (block, window); out: the units' first entries and blocks, and first unit per block
+__global__ void fe_units_kernel(const int32_t* __restrict__ bp, const int32_t* __restrict__ ufirst, int nblock, int nwin, int chunk,
+                                int sparse_chunk, int extent, int64_t z, int32_t* __restrict__ ustart, int32_t* __restrict__ ublock,
+                                int32_t* __restrict__ block_first) {
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblock; b += gridDim.x * blockDim.x) {
     const int u0 = ufirst[b], u1 = ufirst[b + 1];
+    const int c = fe_block_chunk(bp[b + 1] - bp[b], chunk, sparse_chunk, extent);
     for (int u = u0; u < u1; ++u) {
-      ustart[u] = bp[b] + (u - u0) * chunk;
-      ublock[u] = b;
+      ustart[u] = bp[b] + (u - u0) * c;
+      ublock[u] = b / nwin;
     }
-    if (b == nblock - 1) ustart[u1] = (int32_t)z;
+    if (b % nwin == 0) block_first[b / nwin] = u0;
+    if (b == nblock - 1) { ustart[u1] = (int32_t)z; block_first[nblock / nwin] = u1; }
   }
 }
 
@@ -581,10 +668,12 @@ struct gdmix_fe_problem {
   SolveParams o;
   void* pool;            // one device allocation carved into the vectors and partial sums
   void* copies[2];       // the row pass's and the column pass's copy of the non-zeros, with their unit tables
+  void* hot_mem;         // the frequent columns' tables
   int32_t* status_dev;
   hipEvent_t ev[3];
   bool timed;
   bool dirty;            // the reduce buffer holds a result no step has consumed (and cleared) yet
+  std::vector<int32_t> uf_c;
 };
 
 #define HIP_TRY(expr)                                                                   \
@@ -616,27 +705,38 @@ static int fe_chunk_len(int64_t z, int nblock, int num_cus) {
 // Build one pass's copy from segment-major source arrays (ptr [nseg+1], idx / val [z]); `len` = extent of idx (outputs of the
 // pass). Device memory of the result in *owned; the block -> unit table is also returned on the host (ufirst).
 static int fe_build_copy(hipStream_t s, int num_cus, const int32_t* ptr, int nseg, const int32_t* idx, const float* val, int64_t z,
-                         int len, FeCopy* out, void** owned, std::vector<int32_t>* ufirst_host) {
+                         int len, bool cut_sparse, FeCopy* out, void** owned, std::vector<int32_t>* ufirst_host) {
   *owned = nullptr;
   const int nblock = len > 0 ? (len + FE_B - 1) / FE_B : 1;
   const int chunk = fe_chunk_len(z, nblock, num_cus);
   const size_t zz = (size_t)(z > 0 ? z : 1);
+  int wbits = FE_SPAN_BITS;
+  if (const char* e = getenv("GDMIX_FE_WINDOW_BITS")) {   // test hook: several windows on a small shard (narrower is always valid)
+    const int v = atoi(e);
+    if (v >= 1 && v < FE_SPAN_BITS) wbits = v;
+  }
+  const int nwin = ((nseg > 0 ? nseg - 1 : 0) >> wbits) + 1;   // windows of the gathered vector (fe_ent_kernel)
+  if ((int64_t)nblock * nwin > 0x7fffff00ll) { set_error("shard too large for the pass tables"); return GDMIX_RE_ERANGE; }
+  const int nbw = nblock * nwin;
+  const int extent = nseg < (1 << wbits) ? (nseg > 0 ? nseg : 1) : (1 << wbits);   // gathered elements per window
+  const int sparse_chunk = cut_sparse ? (chunk / 8 > 4096 ? chunk / 8 : (chunk < 4096 ? chunk : 4096)) : 0;
   unsigned bits = 1;
-  while ((1u << bits) < (unsigned)nblock) ++bits;
+  while (bits < 32 && (1u << bits) < (unsigned)nbw) ++bits;
   size_t sort_tmp = 0, scan_tmp = 0, scan2_tmp = 0;
   hipError_t rc = rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (FeEnt*)nullptr, (FeEnt*)nullptr,
                                             zz, 0u, bits, s);
   if (rc == hipSuccess) rc = rocprim::inclusive_scan(nullptr, scan_tmp, (int32_t*)nullptr, (int32_t*)nullptr, zz, rocprim::plus<int32_t>(), s);
-  if (rc == hipSuccess) rc = rocprim::exclusive_scan(nullptr, scan2_tmp, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)nblock + 1, rocprim::plus<int32_t>(), s);
+  if (rc == hipSuccess) rc = rocprim::exclusive_scan(nullptr, scan2_tmp, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)nbw + 1, rocprim::plus<int32_t>(), s);
   if (rc != hipSuccess) { set_error("rocPRIM sizing failed: %s", hipGetErrorString(rc)); return GDMIX_RE_EHIP; }
   size_t lib = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
   if (scan2_tmp > lib) lib = scan2_tmp;
   // upper bound of the unit count: a block of len entries has at most len / chunk + 1 units
-  const size_t max_units = (size_t)nblock + (size_t)(z / chunk) + 1;
+  const size_t max_units = (size_t)nbw + (size_t)(z / (sparse_chunk > 0 ? sparse_chunk : chunk)) + 1;
   size_t woff = 0;
   auto wtake = [&](size_t bytes) { size_t r = woff; woff = up256(woff + bytes); return r; };
   const size_t w_a = wtake(zz * 4), w_seg = wtake(zz * 4), w_key = wtake(zz * 4), w_ent = wtake(zz * sizeof(FeEnt)), w_ent2 = wtake(zz * sizeof(FeEnt));
-  const size_t w_bp = wtake(((size_t)nblock + 1) * 4), w_nch = wtake(((size_t)nblock + 1) * 4), w_span = wtake(64), w_lib = wtake(lib);
+  const size_t w_bp = wtake(((size_t)nbw + 1) * 4), w_nch = wtake(((size_t)nbw + 1) * 4), w_uf = wtake(((size_t)nbw + 1) * 4);
+  const size_t w_span = wtake(64), w_lib = wtake(lib);
   void* tmp = nullptr;
   rc = hipMalloc(&tmp, woff);
   if (rc != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", woff, hipGetErrorString(rc)); return GDMIX_RE_ENOMEM; }
@@ -649,6 +749,7 @@ static int fe_build_copy(hipStream_t s, int num_cus, const int32_t* ptr, int nse
   FeEnt* ent2 = reinterpret_cast<FeEnt*>(wb + w_ent2);
   int32_t* bp = reinterpret_cast<int32_t*>(wb + w_bp);
   int32_t* nch = reinterpret_cast<int32_t*>(wb + w_nch);
+  int32_t* ufw = reinterpret_cast<int32_t*>(wb + w_uf);     // first unit per (block, window)
   int32_t* span = reinterpret_cast<int32_t*>(wb + w_span);
   // the unit tables; the entries follow once their form is known
   size_t toff = 0;
@@ -664,7 +765,7 @@ static int fe_build_copy(hipStream_t s, int num_cus, const int32_t* ptr, int nse
   int32_t* ublock = reinterpret_cast<int32_t*>(cb + c_ub);
   int32_t* kbase = reinterpret_cast<int32_t*>(cb + c_kb);
   const int ge = num_cus * 16;
-  int gb = (nblock + 1 + 255) / 256;
+  int gb = (nbw + 1 + 255) / 256;
   if (gb > 4096) gb = 4096;
   (void)hipMemsetAsync(span, 0, 64, s);
   if (z > 0) {
@@ -675,15 +776,15 @@ static int fe_build_copy(hipStream_t s, int num_cus, const int32_t* ptr, int nse
     hipLaunchKernelGGL(fe_flag_kernel, dim3(gs), dim3(256), 0, s, ptr, nseg, z, flag);
     size_t lt = scan_tmp;
     rc = rocprim::inclusive_scan(wb + w_lib, lt, flag, seg, (size_t)z, rocprim::plus<int32_t>(), s);
-    hipLaunchKernelGGL(fe_ent_kernel, dim3(ge), dim3(256), 0, s, seg, idx, val, z, skey, ent);
+    hipLaunchKernelGGL(fe_ent_kernel, dim3(ge), dim3(256), 0, s, seg, idx, val, z, nwin, wbits, skey, ent);
     lt = sort_tmp;
     if (rc == hipSuccess) rc = rocprim::radix_sort_pairs(wb + w_lib, lt, skey, skey2, ent, ent2, (size_t)z, 0u, bits, s);
   }
-  hipLaunchKernelGGL(fe_block_kernel, dim3(gb), dim3(256), 0, s, skey2, z, nblock, bp);
-  hipLaunchKernelGGL(fe_chunks_kernel, dim3(gb), dim3(256), 0, s, bp, nblock, chunk, nch);
+  hipLaunchKernelGGL(fe_block_kernel, dim3(gb), dim3(256), 0, s, skey2, z, nbw, bp);
+  hipLaunchKernelGGL(fe_chunks_kernel, dim3(gb), dim3(256), 0, s, bp, nbw, nwin, chunk, sparse_chunk, extent, nch);
   size_t lt = scan2_tmp;
-  if (rc == hipSuccess) rc = rocprim::exclusive_scan(wb + w_lib, lt, nch, ufirst, 0, (size_t)nblock + 1, rocprim::plus<int32_t>(), s);
-  hipLaunchKernelGGL(fe_units_kernel, dim3(gb), dim3(256), 0, s, bp, ufirst, nblock, chunk, z, ustart, ublock);
+  if (rc == hipSuccess) rc = rocprim::exclusive_scan(wb + w_lib, lt, nch, ufw, 0, (size_t)nbw + 1, rocprim::plus<int32_t>(), s);
+  hipLaunchKernelGGL(fe_units_kernel, dim3(gb), dim3(256), 0, s, bp, ufw, nbw, nwin, chunk, sparse_chunk, extent, z, ustart, ublock, ufirst);
   ufirst_host->resize((size_t)nblock + 1);
   if (rc == hipSuccess) rc = hipMemcpyAsync(ufirst_host->data(), ufirst, ((size_t)nblock + 1) * 4, hipMemcpyDeviceToHost, s);
   if (rc == hipSuccess) rc = hipStreamSynchronize(s);
@@ -741,7 +842,65 @@ static void fe_free(gdmix_fe_problem* p) {
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
   if (p->pool) (void)hipFree(p->pool);
   for (auto& c : p->copies) if (c) (void)hipFree(c);
+  if (p->hot_mem) (void)hipFree(p->hot_mem);
   delete p;
+}
+
+// The column pass's copy, frequent columns under their virtual numbers (FeHot above). Entry counts per column come from the
+// packed shard's column pointers (one read-back at creation).
+static int fe_split_hot(gdmix_fe_problem* p, const gdmix_re_packed* b, hipStream_t s) {
+  FeDev& F = p->F;
+  gdmix_ctx_impl* ci = &p->ctx->impl;
+  F.hot = FeHot{0, 0, nullptr};
+  long hot_min = 1 << 16;
+  if (const char* e = getenv("GDMIX_FE_HOT_MIN")) hot_min = atol(e);   // test hook (0 = no frequent columns)
+  std::vector<int32_t> cp((size_t)F.d + 1), hot_cols;
+  if (hot_min > 0 && F.d > 0 && F.z > 0) {
+    HIP_TRY(hipMemcpyAsync(cp.data(), b->col_ptr, ((size_t)F.d + 1) * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<std::pair<int32_t, int32_t>> cand;   // (-count, column): most frequent first, ties by column
+    for (int c = 0; c < F.d; ++c)
+      if (cp[(size_t)c + 1] - cp[(size_t)c] >= hot_min) cand.emplace_back(-(cp[(size_t)c + 1] - cp[(size_t)c]), c);
+    std::sort(cand.begin(), cand.end());
+    if (cand.size() > (size_t)FE_HOT_MAX) cand.resize(FE_HOT_MAX);
+    for (auto& q : cand) hot_cols.push_back(q.second);
+    std::sort(hot_cols.begin(), hot_cols.end());
+  }
+  if (hot_cols.empty())
+    return fe_build_copy(s, ci->num_cus, b->row_ptr, F.n, b->csr_col, b->csr_val, F.z, F.d, true, &F.cc, &p->copies[1], &p->uf_c);
+  const int nh = (int)hot_cols.size();
+  const int vbase = (F.d + FE_B - 1) / FE_B * FE_B;
+  std::vector<int32_t> hotmap((size_t)F.d, -1);
+  for (int h = 0; h < nh; ++h) hotmap[(size_t)hot_cols[(size_t)h]] = h;
+  const size_t zz = (size_t)F.z;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t r = off; off = up256(off + bytes); return r; };
+  const size_t o_map = take((size_t)F.d * 4), o_col2 = take(zz * 4);
+  void* mem = nullptr;
+  hipError_t rc = hipMalloc(&mem, off);
+  if (rc != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(rc)); return GDMIX_RE_ENOMEM; }
+  void* small = nullptr;
+  rc = hipMalloc(&small, (size_t)nh * 4);
+  if (rc != hipSuccess) { (void)hipFree(mem); set_error("hipMalloc failed: %s", hipGetErrorString(rc)); return GDMIX_RE_ENOMEM; }
+  p->hot_mem = small;                                  // freed with the problem
+  char* m = static_cast<char*>(mem);
+  int32_t* col2 = reinterpret_cast<int32_t*>(m + o_col2);
+  rc = hipMemcpyAsync(m + o_map, hotmap.data(), (size_t)F.d * 4, hipMemcpyHostToDevice, s);
+  if (rc == hipSuccess) rc = hipMemcpyAsync(small, hot_cols.data(), (size_t)nh * 4, hipMemcpyHostToDevice, s);
+  if (rc == hipSuccess) {
+    int g = (F.n + 255) / 256;
+    if (g > ci->num_cus * 32) g = ci->num_cus * 32;
+    hipLaunchKernelGGL(fe_hot_remap_kernel, dim3(g), dim3(256), 0, s, b->row_ptr, F.n, b->csr_col, reinterpret_cast<const int32_t*>(m + o_map), vbase, col2);
+    rc = hipStreamSynchronize(s);                      // (also: the host vectors above are done with)
+  }
+  if (rc != hipSuccess) { (void)hipFree(mem); set_error("frequent-column tables: %s", hipGetErrorString(rc)); return GDMIX_RE_EHIP; }
+  const int rc2 = fe_build_copy(s, ci->num_cus, b->row_ptr, F.n, col2, b->csr_val, F.z, vbase + nh * FE_HOT_REP, true, &F.cc, &p->copies[1], &p->uf_c);
+  (void)hipFree(mem);
+  if (rc2 != GDMIX_RE_OK) return rc2;
+  F.hot.n = nh;
+  F.hot.vbase = vbase;
+  F.hot.col = static_cast<const int32_t*>(small);
+  return GDMIX_RE_OK;
 }
 
 template <bool HESS>
@@ -763,6 +922,7 @@ static int fe_passes(gdmix_fe_problem* p, const FeDev& F, hipStream_t s, bool ti
   if (timed) HIP_TRY(hipEventRecord(p->ev[2], s));
   int gf = (F.d + FE_RED_OUT - 1) / FE_RED_OUT;
   hipLaunchKernelGGL(fe_finish_kernel, dim3(gf < FE_FIN_BLOCKS ? FE_FIN_BLOCKS : gf), dim3(FE_THREADS), 0, s, F);
+  if (F.hot.n > 0) hipLaunchKernelGGL(fe_hot_finish_kernel, dim3(F.hot.n), dim3(FE_THREADS), 0, s, F);
   HIP_TRY(hipGetLastError());
   return GDMIX_RE_OK;
 }
@@ -787,6 +947,7 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   p->ctx = ctx;
   p->pool = nullptr;
   p->copies[0] = p->copies[1] = nullptr;
+  p->hot_mem = nullptr;
   p->timed = false;
   p->dirty = false;      // the pool is zeroed at creation
   for (auto& e : p->ev) e = nullptr;
@@ -800,9 +961,10 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   o.variance_mode = 0; o.sum_loss = 1; o.linear = opts->linear ? 1 : 0;
   // row pass: outputs = rows, gathered = x by local column: from the column-major arrays. Column pass: the other way round.
   std::vector<int32_t> uf_r, uf_c;
-  int rc2 = fe_build_copy(s, ci->num_cus, b->col_ptr, F.d, b->csc_row, b->csc_val, F.z, F.n, &F.rc, &p->copies[0], &uf_r);
-  if (rc2 == GDMIX_RE_OK) rc2 = fe_build_copy(s, ci->num_cus, b->row_ptr, F.n, b->csr_col, b->csr_val, F.z, F.d, &F.cc, &p->copies[1], &uf_c);
+  int rc2 = fe_build_copy(s, ci->num_cus, b->col_ptr, F.d, b->csc_row, b->csc_val, F.z, F.n, false, &F.rc, &p->copies[0], &uf_r);
+  if (rc2 == GDMIX_RE_OK) rc2 = fe_split_hot(p, b, s);    // the frequent columns, and the column pass's copy of the others
   if (rc2 != GDMIX_RE_OK) { fe_free(p); return rc2; }
+  uf_c = p->uf_c;
   std::vector<int32_t> multi;
   for (int rb = 0; rb < F.rc.nblock; ++rb) if (uf_r[(size_t)rb + 1] - uf_r[(size_t)rb] > 1) multi.push_back(rb);
   F.nmulti = (int)multi.size();

@@ -143,12 +143,27 @@ def test_stepping_kernels_on_ragged_rows_long_columns_and_weights(device_solver)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunk,pack", [(None, "1"), ("8192", "1"), ("257", "1"), ("257", "0"), (None, "0")])
-def test_passes_cut_into_units_are_deterministic_and_agree(device_solver, monkeypatch, chunk, pack):
+@pytest.mark.parametrize("chunk,pack,hot,window", [(None, "1", None, None), ("8192", "1", None, None), ("257", "1", None, None),
+                                                   ("257", "0", None, None), (None, "0", None, None), (None, "1", "300", None),
+                                                   ("257", "1", "2000", None), ("257", "0", "40", None), (None, "1", None, "10"),
+                                                   ("257", "1", "300", "11"), ("8192", "0", None, "12")])
+def test_passes_cut_into_units_are_deterministic_and_agree(device_solver, monkeypatch, chunk, pack, hot, window):
     """csrc/fe_solve.hip: several row blocks and column blocks, blocks cut into several units (GDMIX_FE_CHUNK forces that on a
     small shard; 257 is no multiple of anything), both forms of the entries (GDMIX_FE_PACK=0: the three arrays a unit spanning more
     than 2^21 gathered elements needs), a frequent feature, empty rows and features that never occur. Two fits are
-    bitwise equal (one wavefront per accumulator set, in-order LDS adds); every cut agrees with the oracle."""
+    bitwise equal (one wavefront per accumulator set, in-order LDS adds); every cut agrees with the oracle. hot: GDMIX_FE_HOT_MIN
+    lowers the entry count from which a column gets 32 accumulators of its own in the column pass (65 536 in production): a
+    handful of columns, or the 64 most frequent of hundreds, go through that here. window: GDMIX_FE_WINDOW_BITS narrows the
+    windows of gathered elements a unit may span (2^21 in production, so that the packed word always holds the key): blocks
+    of this shard are cut at every 1024 / 2048 / 4096 samples or features as well."""
+    if window is None:
+        monkeypatch.delenv("GDMIX_FE_WINDOW_BITS", raising=False)
+    else:
+        monkeypatch.setenv("GDMIX_FE_WINDOW_BITS", window)
+    if hot is None:
+        monkeypatch.delenv("GDMIX_FE_HOT_MIN", raising=False)
+    else:
+        monkeypatch.setenv("GDMIX_FE_HOT_MIN", hot)
     if chunk is None:
         monkeypatch.delenv("GDMIX_FE_CHUNK", raising=False)
     else:
