@@ -353,7 +353,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     int lds = kClasses[c].lds;
     const int gl = group_lanes(kClasses[c].kind);
     if (lds > 0 && gl > 0)
-      lds = (gl >= WAVE ? 1 : WAVE / gl) * quad_layout(gl * group_epl(kClasses[c].kind), kClasses[c].ncap, kClasses[c].zcap, gl > WAVE ? gl / WAVE : 1).bytes;
+      lds = (gl >= WAVE ? 1 : WAVE / gl) * quad_layout(gl * group_epl(kClasses[c].kind), kClasses[c].ncap, kClasses[c].zcap, gl > WAVE ? gl / WAVE : 1, quad_nold(gl, group_epl(kClasses[c].kind))).bytes;
     bool on = lds > 0 && (lds <= ctx->impl.wave_lds_limit || (gl > WAVE && ctx->impl.wave_lds_limit >= 65536 && lds <= 160 * 1024));
     if ((kClasses[c].kind <= KIND_WREG4 || kClasses[c].kind == KIND_WREG8) && !(ctx->impl.kernel_mask & 1)) on = false;
     if (gl > 0 && !(ctx->impl.kernel_mask & 4)) on = false;
