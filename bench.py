@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--giant-nnz", type=int, default=-1, help="override the device-wide kernel threshold (exploration)")
     ap.add_argument("--team-nnz", type=int, default=-1, help="override the lowest team-tier threshold (exploration)")
     ap.add_argument("--tall-min-n", type=int, default=-1, help="override the tall kernel's sample threshold (exploration)")
+    ap.add_argument("--kernel-mask", type=int, default=-1, help="gdmix_re_set_kernel_mask (exploration)")
     ap.add_argument("--tall-split-n", type=int, default=-1, help="override the tall kernel's one-CU-per-entity threshold (exploration)")
     ap.add_argument("--solve-only", action="store_true", help="time gdmix_re_solve alone (batch packed once)")
     ap.add_argument("--ranks-share-device", action="store_true",
@@ -477,6 +478,8 @@ def main():
         solver.set_team_nnz(a.team_nnz)
     if a.tall_min_n >= 0:
         solver.set_tall_min_n(a.tall_min_n)
+    if a.kernel_mask >= 0:
+        solver.set_kernel_mask(a.kernel_mask)
     if a.tall_split_n >= 1:
         solver.set_tall_split_n(a.tall_split_n)
 

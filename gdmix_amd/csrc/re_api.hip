@@ -60,10 +60,6 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_WLDS, 24576, "re_solve_wave_kernel lds<=24K"},     {KIND_WLDS, 65536, "re_solve_wave_kernel lds<=64K"},
     {KIND_TALL_S, 0, "re_solve_tall_kernel<1> p<=64"},
     {KIND_TALL, 0, "re_solve_tall_kernel<8> p<=64"},
-    {KIND_TREG, 0, "re_solve_treg_kernel 1 CU"},   {KIND_TREG, 0, "re_solve_treg_kernel 2 CUs"},  {KIND_TREG, 0, "re_solve_treg_kernel 3 CUs"},
-    {KIND_TREG, 0, "re_solve_treg_kernel 4 CUs"},  {KIND_TREG, 0, "re_solve_treg_kernel 6 CUs"},  {KIND_TREG, 0, "re_solve_treg_kernel 8 CUs"},
-    {KIND_TREG, 0, "re_solve_treg_kernel 12 CUs"}, {KIND_TREG, 0, "re_solve_treg_kernel 16 CUs"}, {KIND_TREG, 0, "re_solve_treg_kernel 24 CUs"},
-    {KIND_TREG, 0, "re_solve_treg_kernel 32 CUs"}, {KIND_TREG, 0, "re_solve_treg_kernel 48 CUs"}, {KIND_TREG, 0, "re_solve_treg_kernel 64 CUs"},
     {KIND_BLOCK, 0, "re_solve_team_kernel workgroup"},
     {KIND_GRID, 0, "re_solve_team_kernel 128 teams"},
     {KIND_GRID, 0, "re_solve_team_kernel 32 teams"},
@@ -130,7 +126,7 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   c->impl.scratch_bytes = 0;
   c->impl.host_pinned = nullptr;
   c->impl.wave_lds_limit = 65536;
-  c->impl.kernel_mask = 7;   // bit 3 (history-in-registers team kernels) is opt-in: measured slower than streaming the history, DESIGN.md section 4
+  c->impl.kernel_mask = 7;
   c->impl.timing = 0;
   c->impl.giant_nnz = 16777216;
   c->impl.team_nnz = 16384;
@@ -214,12 +210,6 @@ GDMIX_API size_t gdmix_re_solve_scratch_bytes(const gdmix_re_packed* batch, cons
   size_t slot_doubles;
   int slots = slots_for(batch, opts, &slot_doubles);
   size_t need = (size_t)slots * slot_doubles * 8;
-  {
-    // register team kernels: a slot per team, at most one team per CU; no entity above 64 * TREG_COEFS coefficients goes there
-    const int64_t tp = batch->max_p < 64 * TREG_COEFS ? batch->max_p : 64 * TREG_COEFS;
-    const size_t treg = (opts->sum_loss || opts->linear) ? 0 : (size_t)TEAM_MAX_TEAMS * treg_slot_doubles(tp, batch->max_n) * 8;
-    if (treg > need) need = treg;
-  }
   if (opts->variance_mode == GDMIX_RE_VAR_FULL && batch->max_p <= VAR_FULL_BIG_MAX_P) {
     size_t v = (size_t)var_slots_for(batch) * var_full_slot_doubles(var_small_p(batch)) * 8;
     if (v > need) need = v;
@@ -239,7 +229,7 @@ GDMIX_API int gdmix_re_set_wave_lds_limit(gdmix_re_ctx* ctx, int bytes) {
 
 GDMIX_API int gdmix_re_set_kernel_mask(gdmix_re_ctx* ctx, int mask) {
   if (!ctx) { set_error("ctx is NULL"); return GDMIX_RE_EINVAL; }
-  ctx->impl.kernel_mask = mask & 15;
+  ctx->impl.kernel_mask = mask & 7;
   return GDMIX_RE_OK;
 }
 
@@ -363,7 +353,6 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   // the compact-form team kernels keep TEAM_MCAP history pairs
   tab.giant_nnz = opts->m <= TEAM_MCAP ? ctx->impl.giant_nnz : 0;
   tab.team_nnz = opts->m <= TEAM_MCAP ? ctx->impl.team_nnz : 0;
-  tab.treg = (opts->m <= TEAM_MCAP && (ctx->impl.kernel_mask & 8)) ? 1 : 0;
   tab.tall_min_n = ctx->impl.tall_min_n;
   tab.tall_split_n = ctx->impl.tall_split_n;
   if (opts->sum_loss || opts->linear) {
@@ -417,7 +406,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     }
   }
   int begin = 0;
-  for (int c = 0; c < TREG_CLASS0; ++c) {
+  for (int c = 0; c < BLOCK_CLASS; ++c) {
     if (hc[c] <= 0) continue;
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[c], s)); }
     switch (kClasses[c].kind) {
@@ -436,29 +425,6 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     }
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[c], s)); ctx->impl.ev_used[c] = true; }
     begin += hc[c];
-  }
-  int n_treg = 0;
-  for (int k = 0; k < TREG_NUM; ++k) n_treg += hc[TREG_CLASS0 + k];
-  if (n_treg > 0) {
-    // one scratch slot per team: x, g, split-column partials, residuals
-    const int64_t tp = b->max_p < 64 * TREG_COEFS ? b->max_p : 64 * TREG_COEFS;
-    const size_t need = (size_t)ctx->impl.num_cus * treg_slot_doubles(tp, b->max_n) * 8;
-    double* scratch = nullptr;
-    if (ctx->impl.scratch && ctx->impl.scratch_bytes >= need) scratch = static_cast<double*>(ctx->impl.scratch);
-    else if (b->scratch && b->scratch_bytes >= need) scratch = static_cast<double*>(b->scratch);
-    if (!scratch) {
-      set_error("%d entities need the team kernels: provide >= %zu bytes via gdmix_re_set_scratch", n_treg, need);
-      return GDMIX_RE_ENOMEM;
-    }
-    for (int k = 0; k < TREG_NUM; ++k) {
-      const int cls = TREG_CLASS0 + k;
-      if (hc[cls] <= 0) continue;
-      if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[cls], s)); }
-      HIP_TRY(launch_solve_treg(B, O, P, theta0, begin, hc[cls], scratch, tp, b->max_n, ctx->impl.grid_sync, ctx->impl.num_cus,
-                                treg_size(k), s));
-      if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[cls], s)); ctx->impl.ev_used[cls] = true; }
-      begin += hc[cls];
-    }
   }
   if (hc[BLOCK_CLASS] > 0 || hc[TEAM128_CLASS] > 0 || hc[TEAM32_CLASS] > 0 || hc[TEAM8_CLASS] > 0 || hc[GIANT_CLASS] > 0) {
     double* const scratch = slot_scratch;

@@ -24,7 +24,7 @@ namespace gdmix {
 // Each wavefront kind is split into LDS-footprint buckets so that small entities keep high occupancy.
 enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4, KIND_QUAD2 = 5, KIND_QUAD4 = 6, KIND_PAIR4 = 7, KIND_QUAD3 = 8, KIND_PAIR3 = 9, KIND_WREG8 = 10,
        KIND_G64_3 = 11, KIND_G64_4 = 12, KIND_G128_4 = 13, KIND_G256_4 = 14, KIND_G512_4 = 15, KIND_GRID = 16, KIND_G128_3 = 17, KIND_G256_3 = 18,
-       KIND_TREG = 19, KIND_TALL = 20, KIND_TALL_S = 21 };
+       KIND_TALL = 20, KIND_TALL_S = 21 };   // (19: the register team kernels of round 2, removed in round 3)
 
 // group kernels (several entities per wavefront): lanes per entity, coefficient slots per lane; 0 if not a group kind
 __host__ __device__ inline int group_lanes(int kind) {
@@ -39,23 +39,14 @@ constexpr int TEAM8_CLASS = GDMIX_RE_NUM_CLASSES - 2;    // 8 teams of 32 CUs
 constexpr int TEAM32_CLASS = GDMIX_RE_NUM_CLASSES - 3;   // 32 teams of 8 CUs
 constexpr int TEAM128_CLASS = GDMIX_RE_NUM_CLASSES - 4;  // 128 teams of 2 CUs
 constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 5;
-// Team kernels with the L-BFGS vectors in registers (re_solve_team.hpp, team_solve_reg): one class per team size, in
-// workgroups (= CUs); a team of s workgroups holds entities of up to s * TREG_COEFS coefficients.
-constexpr int TREG_NUM = 12;
-constexpr int TREG_CLASS0 = BLOCK_CLASS - TREG_NUM;
-constexpr int TALL_CLASS = TREG_CLASS0 - 1;      // tall entities of at least tall_split_n samples: one workgroup of TALL_NW wavefronts per CU
-constexpr int TALL_S_CLASS = TREG_CLASS0 - 2;    // smaller ones: workgroups of TALL_NW_SMALL wavefronts, several per CU
+constexpr int TALL_CLASS = BLOCK_CLASS - 1;      // tall entities of at least tall_split_n samples: one workgroup of TALL_NW wavefronts per CU
+constexpr int TALL_S_CLASS = BLOCK_CLASS - 2;    // smaller ones: workgroups of TALL_NW_SMALL wavefronts, several per CU
 #ifndef GDMIX_TALL_NW_SMALL
 #define GDMIX_TALL_NW_SMALL 1
 #endif
 constexpr int TALL_NW = 8;
 constexpr int TALL_NW_SMALL = GDMIX_TALL_NW_SMALL;
 constexpr int TALL_MAX_P = 64;      // coefficients (one per lane of the master wavefront)
-constexpr int TREG_NW = 4, TREG_EPL = 4;
-constexpr int TREG_COEFS = TREG_NW * TREG_EPL * 64;   // per workgroup
-__host__ __device__ inline int treg_size(int k) {
-  return k == 0 ? 1 : (k == 1 ? 2 : (k == 2 ? 3 : (k == 3 ? 4 : (k == 4 ? 6 : (k == 5 ? 8 : (k == 6 ? 12 : (k == 7 ? 16 : (k == 8 ? 24 : (k == 9 ? 32 : (k == 10 ? 48 : 64))))))))));
-}
 constexpr int BLOCK_NW = 4;   // wavefronts per workgroup of the block kernel
 #ifndef GDMIX_TEAM_BLOCK_NW
 #define GDMIX_TEAM_BLOCK_NW 8
@@ -70,7 +61,6 @@ struct ClassTable {
   int zcap[GDMIX_RE_NUM_CLASSES];
   int64_t giant_nnz;   // 0 = device-wide kernel off
   int64_t team_nnz;    // 0 = team tiers off
-  int treg;            // register team kernels on
   int tall_min_n;      // entities with p <= TALL_MAX_P and at least this many samples use the tall kernel (0 = never)
   int tall_split_n;    // ... those with at least this many samples one workgroup per CU, the others several
 };
@@ -161,9 +151,6 @@ hipError_t launch_solve_block(const BatchDev& B, const OutDev& O, const SolvePar
 hipError_t launch_solve_grid(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
                              int begin, int count, double* scratch, size_t slot_doubles, int64_t max_p,
                              void* sync_buf, int blocks, int teams, hipStream_t s);
-hipError_t launch_solve_treg(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0, int begin, int count,
-                             double* scratch, int64_t max_p, int64_t max_n, void* sync_buf, int blocks, int size, hipStream_t s);
-inline size_t treg_slot_doubles(int64_t max_p, int64_t max_n) { return (size_t)2 * max_p + (size_t)256 * 64 + (size_t)max_n + 64; }
 constexpr int TALL_TAIL_BYTES = 256;   // device buffer of the context: padded copy of the end of the batch's row-major arrays
 hipError_t launch_solve_tall(bool small, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0, int begin, int count,
                              int num_cus, int64_t Z, void* tail_buf, void* sync_buf, hipStream_t s);

@@ -48,18 +48,8 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
     if (tab.tall_min_n > 0 && m <= M_REG && p <= TALL_MAX_P && n >= tab.tall_min_n && !(tab.giant_nnz > 0 && z >= tab.giant_nnz)) c = (n >= tab.tall_split_n) ? TALL_CLASS : TALL_S_CLASS;
     else if (tab.giant_nnz > 0 && z >= tab.giant_nnz) c = GIANT_CLASS;
     else if (c == BLOCK_CLASS || (tab.team_nnz > 0 && z >= tab.team_nnz)) {
-      // too large for a wavefront group: a team of CUs. Size by the coefficients (the history has to fit the team's
-      // registers) and by the non-zeros (streaming bandwidth), smallest team that has both.
-      const int need_z = (tab.team_nnz > 0 && z >= tab.team_nnz) ? ((z >= 128 * tab.team_nnz) ? 32 : ((z >= 8 * tab.team_nnz) ? 8 : 2)) : 1;
-      const int need_p = (p + TREG_COEFS - 1) / TREG_COEFS;
-      const int need = need_p > need_z ? need_p : need_z;
-      int k = -1;
-      if (tab.treg) {
-        for (int q = 0; q < TREG_NUM; ++q)
-          if (treg_size(q) >= need) { k = q; break; }
-      }
-      if (k >= 0) c = TREG_CLASS0 + k;
-      else if (tab.team_nnz > 0 && z >= tab.team_nnz)
+      // too large for a wavefront group: a team of CUs, sized by the non-zeros (streaming bandwidth)
+      if (tab.team_nnz > 0 && z >= tab.team_nnz)
         c = (z >= 128 * tab.team_nnz) ? TEAM8_CLASS : ((z >= 8 * tab.team_nnz) ? TEAM32_CLASS : TEAM128_CLASS);
     }
     cls_out[e] = c;
@@ -710,7 +700,6 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(GDMIX_
   tm.L = &lds;
   tm.epoch = 0;
   tm.phase = 0;
-  tm.cheap = false;
   double* slot = scratch + (size_t)(GRID ? team : (int)blockIdx.x) * slot_doubles;
   for (int idx = (int)blockIdx.x;; idx += (int)gridDim.x) {
     if (GRID) {
@@ -751,91 +740,6 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(GDMIX_
     if (o.variance_mode == GDMIX_RE_VAR_SIMPLE && O.variance) variance_simple(grp, P, o, W, O.variance + c0);
     tm.sync();   // the slot is reused by the next entity
   }
-}
-
-// The same persistent grid with the L-BFGS vectors of every coefficient in the registers of the thread that owns it
-// (re_solve_team.hpp, team_solve_reg): a team is `size` workgroups and holds entities of up to size * NW * EPL * 64
-// coefficients. Scratch slot of a team: x [max_p], g [max_p], split-column partials, residuals [max_n].
-template <int NW, int EPL>
-__global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1, 1))) void re_solve_treg_kernel(BatchDev B, OutDev O, SolveParams o, const double* __restrict__ theta0,
-                                                                 int begin, int count, double* scratch, size_t slot_doubles,
-                                                                 int64_t max_p, TeamSync* gs, int teams) {
-  __shared__ TeamLds<NW> lds;
-  const int ic = o.has_intercept ? 1 : 0;
-  Team<NW> tm;
-  const int team = (int)blockIdx.x % teams;
-  tm.bid = blockIdx.x / teams;
-  tm.nblocks = gridDim.x / teams;
-  tm.tid = (int)(tm.bid * blockDim.x + threadIdx.x);
-  tm.NT = (int)(tm.nblocks * blockDim.x);
-  gs += team;
-  tm.wid = tm.tid >> 6;
-  tm.nwaves = tm.NT >> 6;
-  tm.lane = (int)threadIdx.x & (WAVE - 1);
-  tm.gs = gs;
-  tm.L = &lds;
-  tm.epoch = 0;
-  tm.phase = 0;
-  tm.cheap = false;
-  double* slot = scratch + (size_t)team * slot_doubles;
-  for (;;) {
-    // teams take the next entity of the class (largest first, re_sort_class_kernel) as they become free
-    if (tm.bid == 0 && threadIdx.x == 0)
-      gs->cur = (int)__hip_atomic_fetch_add(&(gs - team)->next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tm.sync();   // fenced: also the previous entity's results and slot are done with
-    const int idx = gs->cur;
-    if (idx >= count) break;
-    const int64_t e = B.order[begin + idx];
-    const int64_t r0 = B.ent_row_ptr[e], z0 = B.ent_nnz_ptr[e], f0 = B.ent_feat_ptr[e];
-    const int n = (int)(B.ent_row_ptr[e + 1] - r0);
-    const int d = (int)(B.ent_feat_ptr[e + 1] - f0);
-    const int p = d + ic;
-    const int64_t c0 = f0 + e * ic;
-    double* dp = slot;
-    Work W;
-    W.x = dp; dp += max_p;
-    W.g = dp; dp += max_p;
-    W.d = nullptr; W.t = nullptr; W.r = nullptr; W.ws = nullptr; W.wy = nullptr; W.alpha = nullptr; W.rho = nullptr;
-    W.part = dp; dp += TEAM_LONG_CAP * WAVE;
-    W.rs = dp;
-    EntityView P{n, d, p, ic, B.row_ptr + r0 + e, B.csr_col + z0, B.csr_val + z0, B.col_ptr + z0 + e,
-                 B.csc_row + z0, B.csc_val + z0, B.y + r0, B.offset + r0, B.weight ? B.weight + r0 : nullptr};
-    SolveStats st;
-    tm.cheap = tm.nblocks > 1;
-    team_solve_reg<NW, EPL>(tm, P, o, W, theta0 ? theta0 + c0 : nullptr, O.theta ? O.theta + c0 : nullptr,
-                            O.theta_thr ? O.theta_thr + c0 : nullptr, st);
-    if (tm.tid == 0) {
-      if (O.fval) O.fval[e] = st.f;
-      if (O.gnorm) O.gnorm[e] = st.gnorm;
-      if (O.nit) O.nit[e] = st.nit;
-      if (O.nfev) O.nfev[e] = st.nfev;
-      if (O.status) O.status[e] = st.status;
-    }
-    if (o.variance_mode == GDMIX_RE_VAR_SIMPLE && O.variance) {   // W.x, W.rs stay sc1-only: no cache maintenance needed
-      TeamAsGroup<NW> grp{tm, tm.tid, tm.NT};
-      variance_simple<true>(grp, P, o, W, O.variance + c0);
-    }
-    tm.cheap = false;
-  }
-}
-
-static_assert(TEAM_LONG_CAP * WAVE == 256 * 64, "treg_slot_doubles assumes TEAM_LONG_CAP * 64 partials");
-
-hipError_t launch_solve_treg(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0, int begin, int count,
-                             double* scratch, int64_t max_p, int64_t max_n, void* sync_buf, int blocks, int size, hipStream_t s) {
-  if (count <= 0) return hipSuccess;
-  const int teams = blocks / size;
-  if (size < 1 || teams < 1 || teams > TEAM_MAX_TEAMS || size > TEAM_MAX_BLOCKS) return hipErrorInvalidValue;
-  int per_cu = 0;
-  hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, re_solve_treg_kernel<TREG_NW, TREG_EPL>, WAVE * TREG_NW, 0);
-  if (err != hipSuccess) return err;
-  if (per_cu < 1) return hipErrorLaunchOutOfResources;
-  err = hipMemset2DAsync(sync_buf, sizeof(TeamSync), 0, 64, (size_t)teams, s);
-  if (err != hipSuccess) return err;
-  launch_sort_class(const_cast<int32_t*>(B.order) + begin, count, B.ent_nnz_ptr, s);
-  hipLaunchKernelGGL((re_solve_treg_kernel<TREG_NW, TREG_EPL>), dim3(teams * size), dim3(WAVE * TREG_NW), 0, s, B, O, o, theta0, begin,
-                     count, scratch, treg_slot_doubles(max_p, max_n), max_p, static_cast<TeamSync*>(sync_buf), teams);
-  return hipGetLastError();
 }
 
 template <int NW>

@@ -73,8 +73,6 @@ struct Team {
   TeamLds<NW>* L;
   unsigned epoch;
   int phase;
-  bool cheap;             // every vector the workgroups exchange goes through sc1 accesses (ld_x / st_x below): the barrier
-                          // needs no L2 write-back and no L1 invalidate, only drained stores
 
   __device__ __forceinline__ void block_sync() const { __syncthreads(); }
 
@@ -86,10 +84,8 @@ struct Team {
     __syncthreads();
     ++epoch;
     if (threadIdx.x == 0) {
-      if (!cheap) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_fetch_add(&gs->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned target = epoch * nblocks;
       unsigned spins = 0;
@@ -106,7 +102,7 @@ struct Team {
           }
         }
       }
-      if (!cheap) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
   }
@@ -172,8 +168,7 @@ struct Team {
         s = (threadIdx.x == K - 1) ? fmax(s, t) : s + t;
       }
       if (nblocks > 1) {
-        if (cheap) st_x<true>(&gs->vec[ph][threadIdx.x][bid], s);
-        else gs->vec[ph][threadIdx.x][bid] = s;
+        gs->vec[ph][threadIdx.x][bid] = s;
       } else {
         L->out[ph][threadIdx.x] = s;
       }
@@ -190,7 +185,7 @@ struct Team {
 #pragma unroll
         for (int j = 0; j < BPL; ++j) {
           const unsigned b = lane + j * WAVE;
-          t[i][j] = (k < K && b < nblocks) ? (cheap ? ld_x<true>(&gs->vec[ph][k][b]) : gs->vec[ph][k][b]) : 0.0;
+          t[i][j] = (k < K && b < nblocks) ? gs->vec[ph][k][b] : 0.0;
         }
       }
 #pragma unroll
@@ -554,194 +549,6 @@ __device__ __forceinline__ void team_solve(Team<NW>& tm, const EntityView& P, co
            prof_t[0] * 0.01 / S.nfev, prof_t[1] * 0.01 / S.nfev, prof_t[2] * 0.01 / S.nfev, prof_t[3] * 0.01 / S.nfev,
            prof_t[4] * 0.01 / S.nfev, prof_t[5] * 0.01 / S.nfev, prof_t[6] * 0.01 / S.nfev);
 #endif
-  out.f = S.f;
-  out.gnorm = S.sbgnrm;
-  out.nit = S.nit;
-  out.nfev = S.nfev;
-  out.status = S.status;
-}
-
-// ---- the same solve with the L-BFGS vectors on chip ------------------------------------------------------------------
-// What an evaluation of a large entity moves is not its matrix but the L-BFGS history: 2 m p doubles read by the pass that
-// forms the products and again by the pass that forms the direction (p = 4.4 k: 1.4 MB against 88 KB of matrix). Every
-// coefficient already belongs to one thread for the whole solve (tile = wavefront + k * wavefronts of the team), so with a
-// team sized by p — at most EPL tiles per wavefront — that thread keeps its coefficients' x, g, d, x_old, g_old and all 2 m
-// history entries in registers (25 EPL doubles), the history as a shift register in chronological order (static indices).
-// Only x (for the row gathers) and the residuals (for the column gathers) still go through memory, as sc1 accesses, and the
-// barriers of an evaluation carry no cache maintenance (Team::cheap).
-template <int EPL>
-struct TeamRegs {
-  double x[EPL], g[EPL], d[EPL], t[EPL], r[EPL];
-  double S[TEAM_MCAP][EPL], Y[TEAM_MCAP][EPL];
-};
-
-template <int NW, int EPL>
-__device__ __forceinline__ double team_eval_reg(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W,
-                                                TeamRegs<EPL>& R, int col, const double*& acc) {
-  const int n = P.n, p = P.p, ic = P.ic;
-  const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
-  const double inv_n = o.sum_loss ? 1.0 : 1.0 / (double)n;
-#ifdef GDMIX_TEAM_PROFILE
-  unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = wall_clock64();
-  const double loss = team_fg<NW, true>(tm, P, o, W, prof_t, prof_last);
-#else
-  const double loss = team_fg<NW, true>(tm, P, o, W);
-#endif
-  // the products, one value at a time: its sum over this thread's coefficients, then over the wavefront, kept by lane k
-  // (an accumulator per value, as the HBM form has them, would be 54 more live registers next to the history)
-  double yv[EPL];
-  bool ok[EPL];
-#pragma unroll
-  for (int i = 0; i < EPL; ++i) {
-    const int j = (tm.wid + i * tm.nwaves) * WAVE + tm.lane;
-    ok[i] = j < p;
-    R.g[i] = ok[i] ? W.g[j] : 0.0;   // this thread's own store of team_fg
-    yv[i] = R.g[i] - R.r[i];
-  }
-  double mine = 0.0;
-#define GDMIX_TREG_VALUE(K_, EXPR_, MAX_)                                   \
-  {                                                                         \
-    double t_ = 0.0;                                                        \
-    _Pragma("unroll") for (int i = 0; i < EPL; ++i) {                       \
-      const int j = (tm.wid + i * tm.nwaves) * WAVE + tm.lane;              \
-      (void)j;                                                              \
-      if (ok[i]) t_ = (MAX_) ? fmax(t_, (EXPR_)) : t_ + (EXPR_);            \
-    }                                                                       \
-    t_ = (MAX_) ? wave_max_nonneg(t_) : wave_sum(t_);                       \
-    if (tm.lane == (K_)) mine = t_;                                         \
-  }
-  GDMIX_TREG_VALUE(0, (j >= first_reg ? R.x[i] * R.x[i] : 0.0), false)
-  GDMIX_TREG_VALUE(1, R.g[i] * R.d[i], false)
-  GDMIX_TREG_VALUE(2, R.g[i] * R.g[i], false)
-  GDMIX_TREG_VALUE(3, yv[i] * yv[i], false)
-  GDMIX_TREG_VALUE(4, yv[i] * R.g[i], false)
-#pragma unroll
-  for (int a = 0; a < TEAM_MCAP; ++a) {
-    if (a < col) {   // uniform
-      GDMIX_TREG_VALUE(5 + a, R.S[a][i] * yv[i], false)
-      GDMIX_TREG_VALUE(5 + TEAM_MCAP + a, R.Y[a][i] * yv[i], false)
-    }
-  }
-  GDMIX_TREG_VALUE(TEAM_RD, R.r[i] * R.d[i], false)
-  GDMIX_TREG_VALUE(TEAM_K - 1, fabs(R.g[i]), true)
-#undef GDMIX_TREG_VALUE
-  acc = tm.template reduce_placed<TEAM_K>(mine);
-  return inv_n * (loss + 0.5 * o.l2 * acc[0]);
-}
-
-// The elementwise part of a step for the coefficient in register slot i (compact_update of re_lbfgs_compact.hpp with the
-// vectors in registers). Returns the new x_j.
-template <int EPL>
-__device__ __forceinline__ double compact_update_reg(const CompactPlan& plan, const CompactMats& L, TeamRegs<EPL>& R, int i, int m, double& moved) {
-  if (plan.action == CA_RETRY) {
-    const double xn = plan.stp * R.d[i] + R.t[i];
-    moved += (xn != R.x[i]) ? 1.0 : 0.0;
-    R.x[i] = xn;
-    return R.x[i];
-  }
-  const double gj = plan.restore ? R.r[i] : R.g[i];
-  const double xj = plan.restore ? R.t[i] : R.x[i];
-  const bool failed_off = plan.restore && !plan.phantom && R.x[i] != R.t[i];
-  if (plan.store_pair) {
-    const double sn = plan.stp_prev * R.d[i];   // exact for stp == 1
-    const double yn = R.g[i] - R.r[i];
-    if (plan.shift) {
-#pragma unroll
-      for (int a = 0; a + 1 < TEAM_MCAP; ++a) {
-        if (a + 1 < m) { R.S[a][i] = R.S[a + 1][i]; R.Y[a][i] = R.Y[a + 1][i]; }
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < TEAM_MCAP; ++a) {
-      if (a == plan.cnew) { R.S[a][i] = sn; R.Y[a][i] = yn; }
-    }
-  }
-  double dj = -gj;
-  if (plan.col > 0) {
-    double su = 0.0, yq = 0.0;
-#pragma unroll
-    for (int a = 0; a < TEAM_MCAP; ++a) {
-      if (a < plan.col) {
-        su += L.u[a] * R.S[a][i];
-        yq += L.q[a] * R.Y[a][i];
-      }
-    }
-    dj = plan.gamma * (yq - gj) - su;
-  }
-  const double z = xj + dj;   // mainlb re-derives d from the subspace point
-  dj = z - xj;
-  R.d[i] = dj;
-  R.t[i] = xj;
-  R.r[i] = gj;
-  R.x[i] = plan.stp * dj + xj;
-  moved += (R.x[i] != xj || failed_off) ? 1.0 : 0.0;
-  return R.x[i];
-}
-
-// Requires 1 <= o.m <= TEAM_MCAP and p <= EPL * 64 * wavefronts of the team. theta0 may be NULL (zeros). The coefficients
-// are written straight from the owners' registers (theta_out / thr_out: the entity's slices, either may be NULL); W.x holds
-// theta on exit for sc1 readers (variance_simple<true>).
-template <int NW, int EPL>
-__device__ __forceinline__ void team_solve_reg(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W, const double* theta0,
-                               double* theta_out, double* thr_out, SolveStats& out) {
-  const int p = P.p, m = o.m;
-  TeamLds<NW>& L = *tm.L;
-  team_long_setup(tm, P);
-  CompactState S;
-  compact_init(S);
-  CompactPlan plan;
-  const double* acc = nullptr;
-  TeamRegs<EPL> R;
-#pragma unroll
-  for (int i = 0; i < EPL; ++i) {
-    const int j = (tm.wid + i * tm.nwaves) * WAVE + tm.lane;
-    R.x[i] = (theta0 && j < p) ? theta0[j] : 0.0;
-    R.g[i] = 0.0; R.d[i] = 0.0; R.t[i] = 0.0; R.r[i] = 0.0;
-#pragma unroll
-    for (int a = 0; a < TEAM_MCAP; ++a) { R.S[a][i] = 0.0; R.Y[a][i] = 0.0; }
-    if (j < p) st_x<true>(W.x + j, R.x[i]);
-  }
-  tm.sync();
-  unsigned upd = 0;
-  tm.moved_clear(0u); tm.moved_clear(1u);
-  tm.sync();
-  for (;;) {
-    tm.moved_clear(upd + 1u);
-    const double f_new = team_eval_reg<NW, EPL>(tm, P, o, W, R, S.col, acc);
-    if (tm.aborted()) { ++S.nfev; S.status = GDMIX_RE_ST_ABORTED; break; }
-    compact_advance(S, acc, f_new, o, L.mats, plan, tm.moved_get(upd));
-    if (plan.action == CA_STOP) break;
-    if (plan.action == CA_STOP_RESTORE) {
-#pragma unroll
-      for (int i = 0; i < EPL; ++i) {
-        const int j = (tm.wid + i * tm.nwaves) * WAVE + tm.lane;
-        if (j < p) st_x<true>(W.x + j, R.t[i]);
-      }
-      tm.sync();
-      break;
-    }
-    ++upd;
-    {
-      double moved = 0.0;
-#pragma unroll
-      for (int i = 0; i < EPL; ++i) {
-        const int j = (tm.wid + i * tm.nwaves) * WAVE + tm.lane;
-        if (j < p) st_x<true>(W.x + j, compact_update_reg<EPL>(plan, L.mats, R, i, m, moved));
-      }
-      tm.moved_set(upd, moved != 0.0);
-    }
-    tm.sync();
-  }
-#pragma unroll
-  for (int i = 0; i < EPL; ++i) {
-    const int j = (tm.wid + i * tm.nwaves) * WAVE + tm.lane;
-    if (j < p) {
-      const double v = (plan.action == CA_STOP_RESTORE) ? R.t[i] : R.x[i];
-      if (theta_out) theta_out[j] = v;
-      // threshold_coefficients: |x| <= threshold -> 0.0, intercept included (util/model_utils.py:4-12)
-      if (thr_out) thr_out[j] = (fabs(v) <= o.threshold) ? 0.0 : v;
-    }
-  }
   out.f = S.f;
   out.gnorm = S.sbgnrm;
   out.nit = S.nit;

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GDMIX_RE_ABI_VERSION 5
+#define GDMIX_RE_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define GDMIX_API __attribute__((visibility("default")))
@@ -140,7 +140,7 @@ typedef struct {
   int32_t        max_p, max_n, max_nnz;  /* per-entity maxima over the batch (host, after pack)     */
 } gdmix_re_packed;
 
-#define GDMIX_RE_NUM_CLASSES 62
+#define GDMIX_RE_NUM_CLASSES 50
 
 /* ---- solver options (defaults = REParams/LRParams defaults + scipy defaults) ----------------------
  * base_lr_params.py:22-27, binary_logistic_regression.py:223-231 (pgtol/maxfun/maxls are scipy's). */
@@ -233,10 +233,9 @@ GDMIX_API int gdmix_re_score(gdmix_re_ctx* ctx, const gdmix_re_packed* batch, in
 GDMIX_API int gdmix_re_set_wave_lds_limit(gdmix_re_ctx* ctx, int bytes);
 
 /* Tuning/testing knob: which per-entity kernels the solver may use. bit 0 = register-resident wavefront
- * kernel, bit 1 = LDS-resident wavefront kernel, bit 2 = four-entities-per-wavefront kernel, bit 3 = the team kernels
- * that keep the L-BFGS history in registers (teams of 1 .. 64 CUs sized by the entity's coefficient count); the team
- * kernels with their vectors in HBM are always available. Default 7: bit 3 is opt-in (an evaluation is bound by latency and
- * synchronisation, so spreading an entity over the CUs its history needs costs more CU-time than streaming it: DESIGN.md). */
+ * kernel, bit 1 = LDS-resident wavefront kernel, bit 2 = the group kernels (several entities per wavefront); the tall kernel
+ * and the team kernels are always available. Default 7. (Round 2 had a bit 3: team kernels with the L-BFGS history in
+ * registers; slower than streaming the history at every team size, removed in round 3 - profiles/r03_zipf_register_team_kernels.txt.) */
 GDMIX_API int gdmix_re_set_kernel_mask(gdmix_re_ctx* ctx, int mask);
 
 /* The head of a Zipf-distributed partition is solved by a persistent kernel (one workgroup per CU) split into teams

@@ -153,11 +153,9 @@ def test_quad_kernel_matches_reference_fixture(device_solver, name):
                                   "c5_mean_shape", "warm_stage2", "tiny_entities_regbias", "c2_no_intercept",
                                   "ragged_variance_simple", "c2_m3", "exit_factr_1e-4", "exit_hard_02", "exit_hard_03", "exit_extreme_00",
                                   "exit_extreme_01", "exit_extreme_02", "exit_extreme_03", "ml20m_per_movie_tall", "ml20m_per_user_tall"])
-@pytest.mark.parametrize("in_registers", [True, False])
-def test_block_kernel_matches_reference_fixture(device_solver, name, in_registers):
-    # lds limit 0 sends every entity through the team kernels: L-BFGS vectors in HBM, one workgroup per entity (the default), or in
-    # the registers of a team of CUs sized by the coefficient count (opt-in, kernel mask bit 3)
-    _solve_and_compare(device_solver, name, lds_limit=0, kernel_mask=15 if in_registers else 7)
+def test_block_kernel_matches_reference_fixture(device_solver, name):
+    # lds limit 0 sends every entity through the team kernel, one workgroup per entity, L-BFGS vectors in HBM
+    _solve_and_compare(device_solver, name, lds_limit=0)
 
 
 @pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "ragged", "ml_per_user", "warm_stage2", "tiny_entities_regbias",
@@ -171,10 +169,9 @@ def test_device_wide_kernel_matches_reference_fixture(device_solver, name):
 @pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "ragged", "ml_per_user", "warm_stage2", "c2_no_intercept",
                                   "ragged_variance_simple", "exit_factr_1e-7", "exit_hard_02", "exit_extreme_01", "exit_extreme_03",
                                   "ml20m_per_movie_tall", "ml20m_per_user_tall"])
-@pytest.mark.parametrize("in_registers", [True, False])
-def test_team_tiers_match_reference_fixture(device_solver, name, in_registers):
+def test_team_tiers_match_reference_fixture(device_solver, name):
     # every entity through the persistent kernel split into teams of CUs (2, 8 or 32 CUs by non-zeros)
-    _solve_and_compare(device_solver, name, giant_nnz=0, team_nnz=1, kernel_mask=15 if in_registers else 7)
+    _solve_and_compare(device_solver, name, giant_nnz=0, team_nnz=1)
 
 
 def test_results_are_bitwise_reproducible(device_solver):
@@ -274,12 +271,9 @@ def test_large_and_giant_entities_pack_and_solve(device_solver):
     coef_ptr = packed.coef_ptr_host()
     wp = well_posed_mask(b, dict(l2=1.0, regularize_bias=False, has_intercept=True))
     # the two 48k-nnz entities through each tier: workgroup kernel, 128 / 32 / 8 teams, device-wide kernel
-    # ... and through the teams that keep the L-BFGS vectors in registers: sized by coefficients (p = 4097: 5 -> 6 CUs) or by
-    # non-zeros (2, 8, 32 CUs)
     for giant_nnz, team_nnz, mask, cls in ((0, 0, 7, "re_solve_team_kernel workgroup"), (16777216, 16384, 7, "re_solve_team_kernel 128 teams"),
                                            (16777216, 4096, 7, "re_solve_team_kernel 32 teams"), (16777216, 256, 7, "re_solve_team_kernel 8 teams"),
-                                           (40000, 0, 7, "re_solve_team_kernel device-wide"), (0, 0, 15, "re_solve_treg_kernel 6 CUs"),
-                                           (16777216, 4096, 15, "re_solve_treg_kernel 8 CUs"), (16777216, 256, 15, "re_solve_treg_kernel 32 CUs")):
+                                           (40000, 0, 7, "re_solve_team_kernel device-wide")):
         device_solver.set_giant_nnz(giant_nnz)
         device_solver.set_team_nnz(team_nnz)
         device_solver.set_kernel_mask(mask)

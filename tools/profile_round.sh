@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for the bench command (run on the GPU box): kernel-trace stats, then PMC passes on their own
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-fe --no-cli"
+CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-fe --no-cli --no-other-workloads"
 O=gpurun_out/prof_final
 rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- $CMD > $O/stats.log 2>&1

@@ -3,7 +3,7 @@
 # kernel-trace stats always; with "pmc" also the FETCH_SIZE / WRITE_SIZE / SQ passes, each in its own run.
 W=${1:-c2}; NAME=${2:-$W}; PMC=$3
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-CMD="python bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-fe --no-cli"
+CMD="python bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-fe --no-cli --no-other-workloads"
 O=gpurun_out/prof_$NAME
 rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- $CMD > $O/stats.log 2>&1

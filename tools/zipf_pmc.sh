@@ -2,7 +2,7 @@
 # HBM traffic of the tail (team) kernels on the Zipf workload: FETCH_SIZE / WRITE_SIZE per dispatch, separate passes
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 E=${1:-1000000}
-CMD="python bench.py --workload zipf --entities $E --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-fe --no-cli"
+CMD="python bench.py --workload zipf --entities $E --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-fe --no-cli --no-other-workloads"
 O=gpurun_out/zipf_pmc
 rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- $CMD > $O/stats.log 2>&1
