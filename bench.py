@@ -12,7 +12,14 @@ entities x avg 64 nnz (n ~ max(1, Poisson(16)), k = 4 distinct uniform columns o
 SURVEY.md §8(d), gdmix_amd.synthetic.make_survey_batch), solver options of the
 shipped MovieLens config (l2 = 1, regularize_bias = false, m = 10, max_iter = 100, tol = 1e-12).
 Inputs are resident in HBM before the timed region; outputs stay in HBM. With N > 1 every rank owns
-its own shard of 1M entities (weak scaling; entities are independent, no data-path collective).
+its own shard of 1M entities (weak scaling; entities are independent, no data-path collective); started
+without WORLD_SIZE in the environment, `--gpus N` re-executes the script under torch.distributed.run with N
+ranks, one device each (spawn_ranks), and a WORLD_SIZE that differs from --gpus is an error.
+
+`--workload` picks another BASELINE configuration for the step: ml20m_user / ml20m_movie (C3: MovieLens-20M
+entity sizes), c5share (C5: one GPU's share, 4M Zipf entities generated on the device), zipf, ...; the
+default C2 run also measures ml20m_user, ml20m_movie and c5share briefly and reports them under
+detail.workloads (--no-other-workloads skips that; it is never part of `value`).
 
 One JSON line is printed by rank 0. `roofline` is the HBM roofline of the dominant kernel
 (the size-class launch that takes the largest share of a step) by the algorithmic-bytes formula of SURVEY.md §8(d); `cpu_baseline` times the

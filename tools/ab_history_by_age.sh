@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of the group kernels' history split (GDMIX_QUAD_NOLD = pairs kept in LDS) on the C2 bench
+# A/B of the group kernels' history split (GDMIX_QUAD_NOLD = pairs kept in LDS) on the C2 bench. Build the variants first (CPU box):
+#   for n in 0 2 3 4; do GDMIX_EXTRA_FLAGS="-DGDMIX_QUAD_NOLD=$n" python -m gdmix_amd.build --force; cp gdmix_amd/libgdmix_re.so gdmix_amd/lib_nold$n.so; done
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r03i
 cp gdmix_amd/libgdmix_re.so /tmp/keep.so

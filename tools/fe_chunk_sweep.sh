@@ -1,4 +1,5 @@
 #!/bin/bash
+# fixed effect: column / row pass time against the unit length (GDMIX_FE_CHUNK), uniform and Zipf columns
 mkdir -p gpurun_out/r03h
 cd /root/repo
 : > gpurun_out/r03h/fe_sweep.txt
