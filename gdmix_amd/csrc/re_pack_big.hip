@@ -9,6 +9,12 @@
 // a 32-bit column field, a 65 536-feature space 4), value = position inside the entity. The input is in position order and the radix sort is stable, so
 // equal columns stay in row-major order without the position being part of the key. The sort itself is the
 // library's (rocPRIM radix_sort_pairs); everything around it is here.
+//
+// When the largest column index among them is below 2^BIG_COUNT_CBITS (MovieLens bags: 20 and 24 features; C3's per-movie entities
+// are 48 M non-zeros of such columns) no sort is needed at all: a stable counting sort per entity over chunks of BIG_CH entries —
+// histogram per chunk (big_hist_kernel), per entity the columns present, their local ids and every (column, chunk) bucket's first
+// CSC position (big_cols_kernel), then one wavefront per chunk places its entries in position order (big_scatter_kernel). Same
+// bytes out as the sort path (tests/test_gpu_parity.py::_check_pack on every fixture, both paths forced).
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -27,11 +33,19 @@ namespace gdmix {
     }                                                                                   \
   } while (0)
 
+constexpr int BIG_CH = 4096;               // entries per chunk: the unit of work of every per-entry pass here
+constexpr unsigned BIG_COUNT_CBITS = 11;   // counting path for column indices below 2^11 (its tables are C counters per chunk)
+
+// sizes[b] = non-zeros of big entity b, nch[b] = its chunks (at least one, so that an entity without non-zeros still gets its
+// pointers written); nch[n_big] = 0 closes the scan
 __global__ void big_sizes_kernel(const int64_t* __restrict__ ent_nnz_ptr, const int32_t* __restrict__ big_list, int n_big,
-                                 int64_t* __restrict__ sizes) {
-  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < n_big; b += gridDim.x * blockDim.x) {
+                                 int64_t* __restrict__ sizes, int64_t* __restrict__ nch) {
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b <= n_big; b += gridDim.x * blockDim.x) {
+    if (b == n_big) { nch[b] = 0; continue; }
     const int64_t e = big_list[b];
-    sizes[b] = ent_nnz_ptr[e + 1] - ent_nnz_ptr[e];
+    const int64_t z = ent_nnz_ptr[e + 1] - ent_nnz_ptr[e];
+    sizes[b] = z;
+    nch[b] = z > 0 ? (z + BIG_CH - 1) / BIG_CH : 1;
   }
 }
 
@@ -45,17 +59,37 @@ __device__ __forceinline__ int big_find(const int64_t* __restrict__ offs, int n_
   return lo;
 }
 
+// Chunk q of the big entities' non-zeros: entity b (one bisection per workgroup instead of one per entry, which is what the
+// per-entry passes used to spend their time on), first position inside the entity, length. chunk0 [n_big + 1] = exclusive scan of nch.
+struct BigChunk { int b; int64_t e, z0, start; int len; };
+__device__ __forceinline__ BigChunk big_chunk(const int64_t* __restrict__ chunk0, const int64_t* __restrict__ ent_nnz_ptr,
+                                              const int32_t* __restrict__ big_list, int n_big, int64_t q) {
+  BigChunk c;
+  c.b = big_find(chunk0, n_big, q);
+  c.e = big_list[c.b];
+  c.z0 = ent_nnz_ptr[c.e];
+  const int64_t z = ent_nnz_ptr[c.e + 1] - c.z0;
+  c.start = (q - chunk0[c.b]) * BIG_CH;
+  const int64_t left = z - c.start;
+  c.len = (int)(left < BIG_CH ? (left > 0 ? left : 0) : BIG_CH);
+  return c;
+}
+
 // largest global column index among the big entities (and the range check of all of them)
 __global__ __launch_bounds__(256) void big_maxcol_kernel(const int64_t* __restrict__ ent_nnz_ptr, const int64_t* __restrict__ col_global,
-                                                         const int32_t* __restrict__ big_list, const int64_t* __restrict__ offs, int n_big,
-                                                         int64_t total, unsigned* __restrict__ max_col, int* __restrict__ err) {
+                                                         const int32_t* __restrict__ big_list, const int64_t* __restrict__ chunk0, int n_big,
+                                                         unsigned* __restrict__ max_col, int* __restrict__ err) {
   bool bad = false;
   unsigned mx = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int b = big_find(offs, n_big, i);
-    const int64_t c = col_global[ent_nnz_ptr[big_list[b]] + (i - offs[b])];
-    bad |= (c < 0 || c > 0x7fffffffll);
-    mx = (!bad && (unsigned)c > mx) ? (unsigned)c : mx;
+  const int64_t nq = chunk0[n_big];
+  for (int64_t q = blockIdx.x; q < nq; q += gridDim.x) {
+    const BigChunk k = big_chunk(chunk0, ent_nnz_ptr, big_list, n_big, q);
+    const int64_t* __restrict__ col = col_global + k.z0 + k.start;
+    for (int i = threadIdx.x; i < k.len; i += 256) {
+      const int64_t c = col[i];
+      bad |= (c < 0 || c > 0x7fffffffll);
+      mx = (!bad && (unsigned)c > mx) ? (unsigned)c : mx;
+    }
   }
   __shared__ unsigned smx;
   if (threadIdx.x == 0) smx = 0;
@@ -68,15 +102,163 @@ __global__ __launch_bounds__(256) void big_maxcol_kernel(const int64_t* __restri
 
 __global__ __launch_bounds__(256) void big_fill_kernel(const int64_t* __restrict__ ent_nnz_ptr,
                                                        const int64_t* __restrict__ col_global,
-                                                       const int32_t* __restrict__ big_list,
-                                                       const int64_t* __restrict__ offs, int n_big, int64_t total, unsigned cbits,
+                                                       const int32_t* __restrict__ big_list, const int64_t* __restrict__ chunk0,
+                                                       const int64_t* __restrict__ offs, int n_big, unsigned cbits,
                                                        unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int b = big_find(offs, n_big, i);
-    const int64_t pos = i - offs[b];
-    const int64_t c = col_global[ent_nnz_ptr[big_list[b]] + pos];
-    keys[i] = ((unsigned long long)(uint32_t)b << cbits) | ((unsigned long long)c & ((1ull << cbits) - 1ull));
-    vals[i] = (uint32_t)pos;
+  const int64_t nq = chunk0[n_big];
+  for (int64_t q = blockIdx.x; q < nq; q += gridDim.x) {
+    const BigChunk k = big_chunk(chunk0, ent_nnz_ptr, big_list, n_big, q);
+    const int64_t* __restrict__ col = col_global + k.z0 + k.start;
+    const int64_t o = offs[k.b] + k.start;
+    for (int i = threadIdx.x; i < k.len; i += 256) {
+      keys[o + i] = ((unsigned long long)(uint32_t)k.b << cbits) | ((unsigned long long)col[i] & ((1ull << cbits) - 1ull));
+      vals[o + i] = (uint32_t)(k.start + i);
+    }
+  }
+}
+
+// ---- counting path ------------------------------------------------------------------------------------------------------
+// hist[q][c] = entries of column c in chunk q (C = 2^cbits counters per chunk)
+__global__ __launch_bounds__(256) void big_hist_kernel(const int64_t* __restrict__ ent_nnz_ptr, const int64_t* __restrict__ col_global,
+                                                       const int32_t* __restrict__ big_list, const int64_t* __restrict__ chunk0, int n_big,
+                                                       int C, uint32_t* __restrict__ hist) {
+  __shared__ unsigned h[1 << BIG_COUNT_CBITS];
+  const int64_t nq = chunk0[n_big];
+  for (int64_t q = blockIdx.x; q < nq; q += gridDim.x) {
+    const BigChunk k = big_chunk(chunk0, ent_nnz_ptr, big_list, n_big, q);
+    for (int c = threadIdx.x; c < C; c += 256) h[c] = 0u;
+    __syncthreads();
+    const int64_t* __restrict__ col = col_global + k.z0 + k.start;
+    for (int i = threadIdx.x; i < k.len; i += 256) atomicAdd(&h[(unsigned)col[i] & (unsigned)(C - 1)], 1u);
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) hist[q * C + c] = h[c];
+    __syncthreads();
+  }
+}
+
+// One workgroup per big entity: column totals over its chunks -> which columns are present, their local ids (rank among the
+// present ones: the order of the global index), the column pointers, and in place of every chunk's count the CSC position of
+// the chunk's first entry of that column. bits / lidbase [n_big][W], W = max(C / 32, 1): presence bitmap and the local id of a
+// word's first column, from which the scatter pass derives the local id of any column.
+__global__ __launch_bounds__(256) void big_cols_kernel(BigPackArgs a, const int64_t* __restrict__ chunk0, int C, uint32_t* __restrict__ hist,
+                                                       uint32_t* __restrict__ bits, uint32_t* __restrict__ lidbase) {
+  constexpr int CMAX = 1 << BIG_COUNT_CBITS, PER = CMAX / 256;
+  __shared__ unsigned tot[CMAX], lid[CMAX], start[CMAX];
+  __shared__ unsigned part_n[256], part_p[256];
+  const int tid = threadIdx.x;
+  for (int b = blockIdx.x; b < a.n_big; b += gridDim.x) {
+    const int64_t e = a.big_list[b], z0 = a.ent_nnz_ptr[e];
+    const int nnz = (int)(a.ent_nnz_ptr[e + 1] - z0);
+    const int64_t q0 = chunk0[b], q1 = chunk0[b + 1];
+    for (int c = tid; c < CMAX; c += 256) {
+      unsigned t = 0;
+      if (c < C)
+        for (int64_t q = q0; q < q1; ++q) t += hist[q * C + c];
+      tot[c] = t;
+    }
+    __syncthreads();
+    // exclusive scans over the columns of the totals (-> first CSC position) and of the presence flags (-> local id): PER
+    // consecutive columns per thread, the 256 thread sums by thread 0 .. 255 in order
+    unsigned sn = 0, sp = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const unsigned t = tot[tid * PER + i]; sn += t; sp += t ? 1u : 0u; }
+    part_n[tid] = sn; part_p[tid] = sp;
+    __syncthreads();
+    if (tid < WAVE) {   // 256 partial sums: four per lane, then a wavefront scan
+      unsigned n4[4], p4[4], rn = 0, rp = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { n4[i] = rn; p4[i] = rp; rn += part_n[tid * 4 + i]; rp += part_p[tid * 4 + i]; }
+      unsigned xn = rn, xp = rp;
+#pragma unroll
+      for (int d = 1; d < WAVE; d <<= 1) {
+        const unsigned yn = __shfl_up(xn, d), yp = __shfl_up(xp, d);
+        if (tid >= d) { xn += yn; xp += yp; }
+      }
+      xn -= rn; xp -= rp;   // exclusive
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { part_n[tid * 4 + i] = xn + n4[i]; part_p[tid * 4 + i] = xp + p4[i]; }
+    }
+    __syncthreads();
+    unsigned rn = part_n[tid], rp = part_p[tid];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid * PER + i;
+      const unsigned t = tot[c];
+      start[c] = rn; lid[c] = rp;
+      rn += t; rp += t ? 1u : 0u;
+    }
+    __syncthreads();
+    const int d = (int)(lid[CMAX - 1] + (tot[CMAX - 1] ? 1u : 0u));
+    int32_t* const cp = a.col_ptr + z0 + e;
+    for (int c = tid; c < C; c += 256) {
+      if (tot[c]) { a.uniq_sparse[z0 + lid[c]] = c; cp[lid[c]] = (int32_t)start[c]; }
+      unsigned run = start[c];
+      for (int64_t q = q0; q < q1; ++q) { const unsigned t = hist[q * C + c]; hist[q * C + c] = run; run += t; }
+    }
+    const int W = C >= 32 ? C / 32 : 1;
+    for (int w = tid; w < W; w += 256) {
+      unsigned m = 0;
+      for (int i = 0; i < 32 && w * 32 + i < C; ++i) m |= (tot[w * 32 + i] ? 1u : 0u) << i;
+      bits[(size_t)b * W + w] = m;
+      lidbase[(size_t)b * W + w] = lid[w * 32];
+    }
+    if (tid == 0) {
+      cp[d] = nnz;
+      a.d_cnt[e] = d;
+      atomicMax(a.max_p, d + a.ic);
+    }
+    __syncthreads();
+  }
+}
+
+// One wavefront per chunk: its entries, 64 at a time in position order, go to the CSC position base[column] + (entries of the
+// same column before it in the tile); the first lane of every column of a tile then advances the base. In-order LDS, one
+// wavefront: no atomics, and the CSC copy is in row-major order within a column, as the stable sort leaves it.
+__global__ __launch_bounds__(WAVE) void big_scatter_kernel(BigPackArgs a, const int64_t* __restrict__ chunk0, const int64_t* __restrict__ offs,
+                                                           int C, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ bits,
+                                                           const uint32_t* __restrict__ lidbase, const uint32_t* __restrict__ row_of) {
+  constexpr int CMAX = 1 << BIG_COUNT_CBITS;
+  __shared__ unsigned base[CMAX], bm[CMAX / 32], lb[CMAX / 32];
+  const int lane = threadIdx.x;
+  const int W = C >= 32 ? C / 32 : 1;
+  const int64_t nq = chunk0[a.n_big];
+  for (int64_t q = blockIdx.x; q < nq; q += gridDim.x) {
+    const BigChunk k = big_chunk(chunk0, a.ent_nnz_ptr, a.big_list, a.n_big, q);
+    for (int c = lane; c < C; c += WAVE) base[c] = hist[q * C + c];
+    for (int w = lane; w < W; w += WAVE) { bm[w] = bits[(size_t)k.b * W + w]; lb[w] = lidbase[(size_t)k.b * W + w]; }
+    wave_lds_fence();
+    const int64_t* __restrict__ col = a.col_global + k.z0 + k.start;
+    const float* __restrict__ val = a.val + k.z0 + k.start;
+    const uint32_t* __restrict__ rof = row_of + offs[k.b] + k.start;
+    for (int t = 0; t < k.len; t += WAVE) {
+      const int i = t + lane;
+      const bool valid = i < k.len;
+      const unsigned c = valid ? ((unsigned)col[i] & (unsigned)(C - 1)) : 0u;
+      const float v = valid ? val[i] : 0.0f;
+      const uint32_t r = valid ? rof[i] : 0u;
+      unsigned rank = 0, cnt = 0;
+      unsigned long long todo = __ballot(valid);
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned cl = (unsigned)__shfl((int)c, leader);
+        const unsigned long long m = __ballot(valid && c == cl);
+        if (valid && c == cl) {
+          rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+          cnt = (unsigned)__popcll(m);
+        }
+        todo &= ~m;
+      }
+      if (valid) {
+        const unsigned kpos = base[c] + rank;
+        const unsigned lid = lb[c >> 5] + (unsigned)__popc(bm[c >> 5] & ((1u << (c & 31u)) - 1u));
+        a.csr_col[k.z0 + k.start + i] = (int32_t)lid;
+        a.csc_val[k.z0 + kpos] = v;
+        a.csc_row[k.z0 + kpos] = (int32_t)r;
+      }
+      wave_lds_fence();
+      if (valid && rank == 0) base[c] += cnt;
+      wave_lds_fence();
+    }
   }
 }
 
@@ -104,6 +286,11 @@ __global__ __launch_bounds__(256) void big_rows_kernel(BigPackArgs a, const int6
     const int64_t n = a.ent_row_ptr[e + 1] - r0;
     const int64_t k0 = a.row_nnz_ptr[r0 + i] - z0;
     a.row_ptr[r0 + e + i] = (int32_t)k0;
+    if (i == 0 && a.ent_nnz_ptr[e + 1] == z0) {   // samples but not a single non-zero: no entry reaches the passes that write these
+      a.col_ptr[z0 + e] = 0;
+      a.d_cnt[e] = 0;
+      atomicMax(a.max_p, a.ic);
+    }
     if (i < n) {
       const int64_t k1 = a.row_nnz_ptr[r0 + i + 1] - z0;
       uint32_t* const dst = row_of + offs[b];
@@ -153,27 +340,33 @@ static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s) {
   const int64_t T = a.big_nnz;
   const int nb = a.n_big;
-  if (nb <= 0 || T <= 0) return GDMIX_RE_OK;
+  if (nb <= 0) return GDMIX_RE_OK;
   unsigned ebits = 1;
   while ((1ll << ebits) < nb) ++ebits;
+  const size_t TT = (size_t)(T > 0 ? T : 1);
+  const int64_t max_chunks = T / BIG_CH + nb;          // every entity: floor(z / CH) + 1 chunks at most
 
   size_t sort_tmp = 0, scan_tmp = 0, scan2_tmp = 0;
   HIP_TRY((rocprim::radix_sort_pairs(nullptr, sort_tmp, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                     (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)T, 0u, 32 + ebits, s)));
-  HIP_TRY((rocprim::exclusive_scan(nullptr, scan_tmp, (int32_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)T,
+                                     (uint32_t*)nullptr, (uint32_t*)nullptr, TT, 0u, 32 + ebits, s)));
+  HIP_TRY((rocprim::exclusive_scan(nullptr, scan_tmp, (int32_t*)nullptr, (int64_t*)nullptr, (int64_t)0, TT,
                                    rocprim::plus<int64_t>(), s)));
-  HIP_TRY((rocprim::exclusive_scan(nullptr, scan2_tmp, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)nb,
+  HIP_TRY((rocprim::exclusive_scan(nullptr, scan2_tmp, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)nb + 1,
                                    rocprim::plus<int64_t>(), s)));
   size_t lib_tmp = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
   if (scan2_tmp > lib_tmp) lib_tmp = scan2_tmp;
 
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = up256(off + bytes); return o; };
-  const size_t o_keys_a = take((size_t)T * 8), o_keys_b = take((size_t)T * 8);
-  const size_t o_vals_a = take((size_t)T * 4), o_vals_b = take((size_t)T * 4);
-  const size_t o_head = take((size_t)T * 4), o_scan = take((size_t)T * 8);
-  const size_t o_sizes = take((size_t)(nb + 1) * 8), o_offs = take((size_t)(nb + 1) * 8);
-  const size_t o_rows = take((size_t)(nb + 1) * 8), o_row_offs = take((size_t)(nb + 1) * 8);
+  // sort path: keys / values in and out, run heads and their scan. The counting path's tables (chunk histograms of at most
+  // 2^BIG_COUNT_CBITS counters, presence bitmaps) live in the same stretch; it is sized for the larger of the two.
+  const size_t sort_bytes = up256(TT * 8) * 2 + up256(TT * 4) * 3 + up256(TT * 8);
+  const size_t W_MAX = (size_t)1 << (BIG_COUNT_CBITS - 5);
+  const size_t count_bytes = up256((size_t)max_chunks * ((size_t)4 << BIG_COUNT_CBITS)) + 2 * up256((size_t)nb * W_MAX * 4) + up256(TT * 4);
+  const size_t o_work = take(sort_bytes > count_bytes ? sort_bytes : count_bytes);
+  const size_t o_sizes = take((size_t)(nb + 2) * 8), o_offs = take((size_t)(nb + 2) * 8);
+  const size_t o_rows = take((size_t)(nb + 2) * 8), o_row_offs = take((size_t)(nb + 2) * 8);
+  const size_t o_nch = take((size_t)(nb + 2) * 8), o_chunk0 = take((size_t)(nb + 2) * 8);
   const size_t o_lib = take(lib_tmp);
   if (ctx->big_tmp_bytes < off) {
     HIP_TRY(hipStreamSynchronize(s));
@@ -188,46 +381,73 @@ int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s) 
     ctx->big_tmp_bytes = want;
   }
   char* base = static_cast<char*>(ctx->big_tmp);
-  unsigned long long* keys_a = reinterpret_cast<unsigned long long*>(base + o_keys_a);
-  unsigned long long* keys_b = reinterpret_cast<unsigned long long*>(base + o_keys_b);
-  uint32_t* vals_a = reinterpret_cast<uint32_t*>(base + o_vals_a);
-  uint32_t* vals_b = reinterpret_cast<uint32_t*>(base + o_vals_b);
-  int32_t* head = reinterpret_cast<int32_t*>(base + o_head);
-  int64_t* scan = reinterpret_cast<int64_t*>(base + o_scan);
   int64_t* sizes = reinterpret_cast<int64_t*>(base + o_sizes);
   int64_t* offs = reinterpret_cast<int64_t*>(base + o_offs);
   int64_t* rows = reinterpret_cast<int64_t*>(base + o_rows);
   int64_t* row_offs = reinterpret_cast<int64_t*>(base + o_row_offs);
+  int64_t* nch = reinterpret_cast<int64_t*>(base + o_nch);
+  int64_t* chunk0 = reinterpret_cast<int64_t*>(base + o_chunk0);
   void* lib = base + o_lib;
 
-  int grid = (nb + 255) / 256;
-  hipLaunchKernelGGL(big_sizes_kernel, dim3(grid), dim3(256), 0, s, a.ent_nnz_ptr, a.big_list, nb, sizes);
+  int grid = (nb + 1 + 255) / 256;
+  hipLaunchKernelGGL(big_sizes_kernel, dim3(grid), dim3(256), 0, s, a.ent_nnz_ptr, a.big_list, nb, sizes, nch);
   size_t tmp = lib_tmp;
   HIP_TRY((rocprim::exclusive_scan(lib, tmp, sizes, offs, (int64_t)0, (size_t)nb, rocprim::plus<int64_t>(), s)));
-  int64_t g64 = (T + 255) / 256;
-  grid = (int)(g64 > ctx->num_cus * 32 ? ctx->num_cus * 32 : g64);
+  tmp = lib_tmp;
+  HIP_TRY((rocprim::exclusive_scan(lib, tmp, nch, chunk0, (int64_t)0, (size_t)nb + 1, rocprim::plus<int64_t>(), s)));
+  // workgroups of the per-entry passes: one per chunk up to a few per CU's worth, strided beyond
+  const int cgrid = (int)(max_chunks > (int64_t)ctx->num_cus * 64 ? (int64_t)ctx->num_cus * 64 : (max_chunks > 0 ? max_chunks : 1));
   // the bits of the column field: of the largest column index among these entities (one small read-back)
-  unsigned* max_col_dev = reinterpret_cast<unsigned*>(sizes + nb);   // the spare entry of `sizes`
+  unsigned* max_col_dev = reinterpret_cast<unsigned*>(sizes + nb + 1);   // the spare entry of `sizes`
   HIP_TRY(hipMemsetAsync(max_col_dev, 0, 4, s));
-  hipLaunchKernelGGL(big_maxcol_kernel, dim3(grid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, offs, nb, T, max_col_dev, a.err);
+  hipLaunchKernelGGL(big_maxcol_kernel, dim3(cgrid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, chunk0, nb, max_col_dev, a.err);
   unsigned max_col = 0;
   HIP_TRY(hipMemcpyAsync(&max_col, max_col_dev, 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   unsigned cbits = 1;
   while (cbits < 32 && (max_col >> cbits) != 0u) ++cbits;
+  // row pointers of these entities and the row of every raw position (both paths)
+  hipLaunchKernelGGL(big_rowcount_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, a.ent_row_ptr, a.big_list, nb, rows);
+  tmp = lib_tmp;
+  HIP_TRY((rocprim::exclusive_scan(lib, tmp, rows, row_offs, (int64_t)0, (size_t)nb, rocprim::plus<int64_t>(), s)));
+  bool counting = cbits <= BIG_COUNT_CBITS;
+  if (const char* e = getenv("GDMIX_PACK_BIG_COUNT")) counting = counting && atoi(e) != 0;   // test hook: 0 = always the sort path
+  if (counting) {
+    const int C = 1 << cbits;
+    const size_t W = C >= 32 ? (size_t)C / 32 : 1;
+    size_t o = o_work;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(base + o); o += up256((size_t)max_chunks * (size_t)C * 4);
+    uint32_t* bits = reinterpret_cast<uint32_t*>(base + o); o += up256((size_t)nb * W * 4);
+    uint32_t* lidbase = reinterpret_cast<uint32_t*>(base + o); o += up256((size_t)nb * W * 4);
+    uint32_t* row_of = reinterpret_cast<uint32_t*>(base + o);
+    hipLaunchKernelGGL(big_rows_kernel, dim3(ctx->num_cus * 32), dim3(256), 0, s, a, offs, row_offs, rows, row_of);
+    hipLaunchKernelGGL(big_hist_kernel, dim3(cgrid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, chunk0, nb, C, hist);
+    hipLaunchKernelGGL(big_cols_kernel, dim3(nb < ctx->num_cus * 16 ? nb : ctx->num_cus * 16), dim3(256), 0, s, a, chunk0, C, hist, bits, lidbase);
+    const int sgrid = (int)(max_chunks > (int64_t)ctx->num_cus * 256 ? (int64_t)ctx->num_cus * 256 : (max_chunks > 0 ? max_chunks : 1));
+    hipLaunchKernelGGL(big_scatter_kernel, dim3(sgrid), dim3(WAVE), 0, s, a, chunk0, offs, C, hist, bits, lidbase, row_of);
+    HIP_TRY(hipGetLastError());
+    return GDMIX_RE_OK;
+  }
+  if (T <= 0) return GDMIX_RE_OK;
+  size_t o = o_work;
+  unsigned long long* keys_a = reinterpret_cast<unsigned long long*>(base + o); o += up256(TT * 8);
+  unsigned long long* keys_b = reinterpret_cast<unsigned long long*>(base + o); o += up256(TT * 8);
+  uint32_t* vals_a = reinterpret_cast<uint32_t*>(base + o); o += up256(TT * 4);
+  uint32_t* vals_b = reinterpret_cast<uint32_t*>(base + o); o += up256(TT * 4);
+  int32_t* head = reinterpret_cast<int32_t*>(base + o); o += up256(TT * 4);
+  int64_t* scan = reinterpret_cast<int64_t*>(base + o);
+  int64_t g64 = (T + 255) / 256;
+  grid = (int)(g64 > ctx->num_cus * 32 ? ctx->num_cus * 32 : g64);
   const unsigned end_bit = cbits + ebits;
-  hipLaunchKernelGGL(big_fill_kernel, dim3(grid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, offs, nb, T, cbits,
+  hipLaunchKernelGGL(big_fill_kernel, dim3(cgrid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, chunk0, offs, nb, cbits,
                      keys_a, vals_a);
   tmp = lib_tmp;
   HIP_TRY((rocprim::radix_sort_pairs(lib, tmp, keys_a, keys_b, vals_a, vals_b, (size_t)T, 0u, end_bit, s)));
   hipLaunchKernelGGL(big_heads_kernel, dim3(grid), dim3(256), 0, s, keys_b, T, head);
   tmp = lib_tmp;
   HIP_TRY((rocprim::exclusive_scan(lib, tmp, head, scan, (int64_t)0, (size_t)T, rocprim::plus<int64_t>(), s)));
-  // row pointers of these entities and the row of every raw position; the sort's input values are free again
+  // the row of every raw position; the sort's input values are free again
   uint32_t* row_of = vals_a;
-  hipLaunchKernelGGL(big_rowcount_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, a.ent_row_ptr, a.big_list, nb, rows);
-  tmp = lib_tmp;
-  HIP_TRY((rocprim::exclusive_scan(lib, tmp, rows, row_offs, (int64_t)0, (size_t)nb, rocprim::plus<int64_t>(), s)));
   hipLaunchKernelGGL(big_rows_kernel, dim3(ctx->num_cus * 32), dim3(256), 0, s, a, offs, row_offs, rows, row_of);
   hipLaunchKernelGGL(big_emit_kernel, dim3(grid), dim3(256), 0, s, a, offs, T, cbits, keys_b, vals_b, head, scan, row_of);
   HIP_TRY(hipGetLastError());

@@ -174,6 +174,37 @@ def test_team_tiers_match_reference_fixture(device_solver, name):
     _solve_and_compare(device_solver, name, giant_nnz=0, team_nnz=1)
 
 
+@pytest.mark.parametrize("dim,count_path", [(20, True), (24, False), (1000, True), (2048, True), (2049, True), (70000, True)])
+def test_pack_of_large_entities_counting_and_sort_paths(device_solver, monkeypatch, dim, count_path):
+    """csrc/re_pack_big.hip: entities above 1 024 non-zeros. Column indices below 2^11 take the counting path (chunk histograms, no
+    sort), larger feature spaces the device-wide radix sort; GDMIX_PACK_BIG_COUNT=0 forces the sort path on a small feature space.
+    Every array of the packed batch equals the oracle's, whichever path ran: entities of one chunk and of many (chunks of 4 096
+    entries), a column that occurs once, empty samples, an entity with samples and no non-zero at all, small entities in between."""
+    if count_path:
+        monkeypatch.delenv("GDMIX_PACK_BIG_COUNT", raising=False)
+    else:
+        monkeypatch.setenv("GDMIX_PACK_BIG_COUNT", "0")
+    from gdmix_amd.batch import RawBatch
+    rng = np.random.default_rng(dim)
+    ent_n = np.array([1500, 3, 9000, 40, 1100, 30000, 2, 1300, 5000], np.int64)      # 1 100 samples of no entry: large by its samples
+    ent_k = [(1, 5), (1, 4), (2, 4), (0, 9), (0, 1), (1, 3), (5, 6), (0, 3), (3, 4)]   # non-zeros per sample, [lo, hi)
+    ent_k[4] = (0, 1)
+    row_nnz = np.concatenate([rng.integers(lo, hi, n) for n, (lo, hi) in zip(ent_n, ent_k)])
+    rp = np.concatenate([[0], np.cumsum(row_nnz)]).astype(np.int64)
+    Z = int(rp[-1])
+    # Zipf-like columns, plus the largest index exactly once (it sets the width of the column field)
+    cols = np.minimum((float(dim) ** rng.random(Z)).astype(np.int64) - 1, dim - 1)
+    cols[rng.integers(0, Z)] = dim - 1
+    N = int(ent_n.sum())
+    b = RawBatch(ent_row_ptr=np.concatenate([[0], np.cumsum(ent_n)]), row_nnz_ptr=rp, col_global=cols,
+                 val=rng.standard_normal(Z).astype(np.float32), y=(rng.random(N) < 0.5).astype(np.float32),
+                 offset=np.zeros(N, np.float32))
+    pk = oracle.pack(b.ent_row_ptr, b.row_nnz_ptr, b.col_global)
+    packed = device_solver.pack(b)
+    _check_pack(packed, pk, b.val)
+    assert packed.max_p == int(np.diff(pk["ent_feat_ptr"]).max()) + 1
+
+
 def test_results_are_bitwise_reproducible(device_solver):
     b = synthetic.make_batch(2000, 16, 4, 1024, seed=5)
     packed = device_solver.pack(b)
