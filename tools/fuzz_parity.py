@@ -24,7 +24,7 @@ t0 = time.time()
 worst = 0.0
 for case in range(cases):
     rng = np.random.default_rng(seed0 + case)
-    shape = rng.choice(["c2", "ragged", "zipf", "ml", "wide", "tall", "tiny"])
+    shape = rng.choice(["c2", "ragged", "zipf", "ml", "ml20m", "wide", "tall", "tiny"])
     if shape == "c2":
         b = synthetic.make_batch(int(rng.integers(50, 3000)), int(rng.integers(2, 40)), int(rng.choice([1, 2, 4, 8])), int(rng.choice([64, 1024, 65536])),
                                  seed=seed0 + case, with_uid=False)
@@ -36,6 +36,8 @@ for case in range(cases):
                                  with_uid=False)
     elif shape == "ml":
         b = synthetic.make_movielens_like(int(rng.integers(50, 1500)), str(rng.choice(["per_user", "per_movie"])), seed=seed0 + case)
+    elif shape == "ml20m":   # MovieLens-20M entity sizes (tall and skinny: the tall kernel, the counting pack path)
+        b = synthetic.make_movielens_20m(str(rng.choice(["per_user", "per_movie"])), seed=seed0 + case, entities=int(rng.integers(20, 400)))
     elif shape == "wide":    # few samples, many features
         b = synthetic.make_batch(int(rng.integers(3, 40)), int(rng.integers(2, 30)), int(rng.choice([64, 128, 256])), 65536, seed=seed0 + case,
                                  size_dist="const", with_uid=False)
@@ -57,12 +59,13 @@ for case in range(cases):
     if rng.random() < 0.3:
         th0 = 0.1 * rng.standard_normal(int(packed.P))
     routing = dict(giant=int(rng.choice([16777216, 16777216, 200000, 1])), team=int(rng.choice([16384, 16384, 2048, 256])),
-                   mask=int(rng.choice([7, 7, 1])))
+                   mask=int(rng.choice([7, 7, 1])), tall=int(rng.choice([32, 32, 1, 0])))
     solver.set_giant_nnz(routing["giant"]); solver.set_team_nnz(routing["team"]); solver.set_kernel_mask(routing["mask"])
+    solver.set_tall_min_n(routing["tall"])
     try:
         res = solver.solve(packed, SolverOptions(**kw), theta0=th0).to_host()
     finally:
-        solver.set_giant_nnz(16777216); solver.set_team_nnz(16384); solver.set_kernel_mask(7)
+        solver.set_giant_nnz(16777216); solver.set_team_nnz(16384); solver.set_kernel_mask(7); solver.set_tall_min_n(solver.TALL_MIN_N_DEFAULT)
     ref = oracle.solve(pk, b.val, b.y, b.offset, b.weight, oracle.make_opts(**kw), theta0=th0)
     coef_ptr = packed.coef_ptr_host()
     wp = well_posed_mask(b, opts_j)
@@ -94,6 +97,9 @@ for case in range(cases):
         k = np.flatnonzero(strict & ~same)
         problems.append(f"{k.size} entities differ in status/nit, e.g. {k[:3]}: dev {res['status'][k[:3]]}/{res['nit'][k[:3]]} "
                         f"ref {ref['status'][k[:3]]}/{ref['nit'][k[:3]]}")
+    if strict.any() and not np.array_equal(res["nfev"][strict & same], ref["nfev"][strict & same]):   # scipy's funcalls, counted on the device
+        k = np.flatnonzero(strict & same & (res["nfev"] != ref["nfev"]))
+        problems.append(f"{k.size} entities differ in nfev, e.g. {k[:3]}: dev {res['nfev'][k[:3]]} ref {ref['nfev'][k[:3]]}")
     # a FACTR stop with a loose ftol leaves the coefficients determined to about sqrt(ftol) only
     tol = np.where((res["status"] == 1) | (ref["status"] == 1), 1e-6 if kw["ftol"] <= 1e-12 else 1e-3, 1e-6)
     if wp.any() and np.any(err[wp] > tol[wp]):
