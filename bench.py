@@ -392,6 +392,21 @@ def other_workloads_leg(a, rank, world, solver, opts, coll_dev):
     for w in ("ml20m_user", "ml20m_movie", "c5share"):
         b = copy.copy(a)
         b.workload = w
+        if w == "c5share":
+            # 4 M Zipf entities take ~110 GB of a device (raw arrays, two alternating pack workspaces, results): skipped — by all
+            # ranks together — when a rank does not have that much free, e.g. ranks sharing one device in the harness test
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            free = torch.cuda.mem_get_info()[0]
+            ok = 1 if free >= int(130e9 * b.c5_entities / 4_000_000) else 0
+            if world > 1:
+                tt = torch.tensor([ok], dtype=torch.int64, device=coll_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+                ok = int(tt.item())
+            if not ok:
+                if rank == 0:
+                    out[w] = {"skipped": "not enough free device memory on some rank (%.0f GB free on rank 0)" % (free / 1e9)}
+                continue
         t_gen = time.perf_counter()
         wl = make_workload(b, rank, solver)
         t_gen = time.perf_counter() - t_gen

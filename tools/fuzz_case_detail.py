@@ -14,7 +14,7 @@ from helpers import per_entity_rel_err  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 rng = np.random.default_rng(seed)
-shape = rng.choice(["c2", "ragged", "zipf", "ml", "wide", "tall", "tiny"])
+shape = rng.choice(["c2", "ragged", "zipf", "ml", "ml20m", "wide", "tall", "tiny"])   # as fuzz_parity.py draws (round 3 list)
 if shape == "c2":
     b = synthetic.make_batch(int(rng.integers(50, 3000)), int(rng.integers(2, 40)), int(rng.choice([1, 2, 4, 8])), int(rng.choice([64, 1024, 65536])), seed=seed, with_uid=False)
 elif shape == "ragged":
@@ -23,6 +23,8 @@ elif shape == "zipf":
     b = synthetic.make_batch(int(rng.integers(200, 4000)), 32, 8, int(rng.choice([4096, 65536])), seed=seed, size_dist="zipf", with_uid=False)
 elif shape == "ml":
     b = synthetic.make_movielens_like(int(rng.integers(50, 1500)), str(rng.choice(["per_user", "per_movie"])), seed=seed)
+elif shape == "ml20m":
+    b = synthetic.make_movielens_20m(str(rng.choice(["per_user", "per_movie"])), seed=seed, entities=int(rng.integers(20, 400)))
 elif shape == "wide":
     b = synthetic.make_batch(int(rng.integers(3, 40)), int(rng.integers(2, 30)), int(rng.choice([64, 128, 256])), 65536, seed=seed, size_dist="const", with_uid=False)
 elif shape == "tall":
@@ -53,8 +55,10 @@ for j, mag in enumerate((1e-15, 1e-14, 1e-13)):
 for e in ents:
     print(f"entity {e}: n={b.ent_n()[e]} nnz={b.ent_nnz()[e]} p={cp[e + 1] - cp[e]}   oracle status {ref['status'][e]} nit {ref['nit'][e]} nfev {ref['nfev'][e]} "
           f"f {ref['fval'][e]:.15g} |g| {ref['gnorm'][e]:.3e}")
-for label, giant, team, mask in (("default", 16777216, 16384, 7), ("device-wide", 1, 16384, 7), ("teams from 256", 16777216, 256, 7), ("register wave only", 16777216, 16384, 1)):
-    solver.set_giant_nnz(giant); solver.set_team_nnz(team); solver.set_kernel_mask(mask)
+for label, giant, team, mask, tall in (("default", 16777216, 16384, 7, 32), ("no tall kernel", 16777216, 16384, 7, 0), ("device-wide", 1, 16384, 7, 0),
+                                      ("teams from 256", 16777216, 256, 7, 0), ("teams from 256, wave kernels, tall", 16777216, 256, 1, 32),
+                                      ("register wave only", 16777216, 16384, 1, 0)):
+    solver.set_giant_nnz(giant); solver.set_team_nnz(team); solver.set_kernel_mask(mask); solver.set_tall_min_n(tall)
     res = solver.solve(packed, SolverOptions(**kw), theta0=th0).to_host()
     err = per_entity_rel_err(res["theta"], ref["theta"], cp)
     classes = {n: c for n, c in solver.class_counts(packed) if c}
