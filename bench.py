@@ -393,19 +393,20 @@ def other_workloads_leg(a, rank, world, solver, opts, coll_dev):
         b = copy.copy(a)
         b.workload = w
         if w == "c5share":
-            # 4 M Zipf entities take ~110 GB of a device (raw arrays, two alternating pack workspaces, results): skipped — by all
+            # 4 M Zipf entities take ~125 GB of a device (raw arrays, two alternating pack workspaces, results): skipped — by all
             # ranks together — when a rank does not have that much free, e.g. ranks sharing one device in the harness test
             torch.cuda.synchronize()
             torch.cuda.empty_cache()
             free = torch.cuda.mem_get_info()[0]
-            ok = 1 if free >= int(130e9 * b.c5_entities / 4_000_000) else 0
+            sharing = world if getattr(a, "ranks_share_device", False) else 1   # ranks that will ask the same device for it
+            ok = 1 if free >= int(150e9 * b.c5_entities / 4_000_000) * sharing else 0
             if world > 1:
                 tt = torch.tensor([ok], dtype=torch.int64, device=coll_dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MIN)
                 ok = int(tt.item())
             if not ok:
                 if rank == 0:
-                    out[w] = {"skipped": "not enough free device memory on some rank (%.0f GB free on rank 0)" % (free / 1e9)}
+                    out[w] = {"skipped": "not enough free device memory on some rank (%.0f GB free on rank 0, %d rank(s) per device)" % (free / 1e9, sharing)}
                 continue
         t_gen = time.perf_counter()
         wl = make_workload(b, rank, solver)
@@ -528,6 +529,7 @@ def main():
         res = solver.solve(packed, opts, out=out)
         ev_pack[2].record()
         kernel_ms += np.array(solver.last_solve_ms())      # waits for this step's solve kernels
+        ev_pack[2].synchronize()                            # (recorded right behind them; not necessarily complete yet)
         pack_ms += ev_pack[0].elapsed_time(ev_pack[1])
         solve_ms += ev_pack[1].elapsed_time(ev_pack[2])
     torch.cuda.synchronize()
