@@ -70,3 +70,21 @@ def test_other_workloads_produce_a_line(workload):
     assert line["detail"]["converged_per_step"] == line["config"]["entities_per_gpu"] == 26744
     pc = line["detail"]["per_class"]
     assert sum(c["entities"] for c in pc) == 26744 and len(pc) >= 4
+
+
+@pytest.mark.gpu
+def test_default_legs_of_a_two_rank_run():
+    """The driver's scaling run is the default command with --gpus N: every rank also measures the MovieLens-20M workloads and
+    C5's per-GPU share after C2 (detail.workloads, collectives inside). Two ranks here; on the 1-GPU box they share the device and
+    the C5 leg must be skipped by both ranks together (a rank that ran out of memory alone would leave the other in a barrier)."""
+    import torch
+    share = [] if torch.cuda.device_count() >= 2 else ["--ranks-share-device"]
+    line = _line(_run(["--gpus", "2"] + share + ["--entities", "20000", "--steps", "2", "--warmup", "1"], timeout=1500))
+    assert line["n_gpus"] == 2 and line["detail"]["converged_per_step"] == 40000
+    w = line["detail"]["workloads"]
+    assert set(w) == {"ml20m_user", "ml20m_movie", "c5share"}
+    assert w["ml20m_user"]["entities_per_gpu"] == 138493 and w["ml20m_user"]["converged_per_step"] == 2 * 138493
+    assert w["ml20m_movie"]["entities_per_gpu"] == 26744 and w["ml20m_movie"]["entities_per_s"] > 0
+    assert ("skipped" in w["c5share"]) == bool(share)
+    if not share:
+        assert w["c5share"]["converged_per_step"] == 2 * w["c5share"]["entities_per_gpu"]
