@@ -211,6 +211,49 @@ __global__ __launch_bounds__(256) void big_cols_kernel(BigPackArgs a, const int6
   }
 }
 
+// The same for C <= 64 columns (MovieLens bags: 32): one wavefront per entity, lane = column, four entities per workgroup — with
+// tens of thousands of entities of a few chunks each a whole workgroup per entity is mostly launch and barriers.
+__global__ __launch_bounds__(256) void big_cols_small_kernel(BigPackArgs a, const int64_t* __restrict__ chunk0, int C, uint32_t* __restrict__ hist,
+                                                             uint32_t* __restrict__ bits, uint32_t* __restrict__ lidbase) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int nw = (int)(gridDim.x * (blockDim.x >> 6));
+  for (int b = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); b < a.n_big; b += nw) {
+    const int64_t e = a.big_list[b], z0 = a.ent_nnz_ptr[e];
+    const int nnz = (int)(a.ent_nnz_ptr[e + 1] - z0);
+    const int64_t q0 = chunk0[b], q1 = chunk0[b + 1];
+    const bool col = lane < C;
+    unsigned tot = 0;
+    if (col)
+      for (int64_t q = q0; q < q1; ++q) tot += hist[q * C + lane];
+    // exclusive scans over the lanes: first CSC position and local id of the lane's column
+    unsigned xn = tot, xp = tot ? 1u : 0u;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const unsigned yn = __shfl_up(xn, d), yp = __shfl_up(xp, d);
+      if (lane >= d) { xn += yn; xp += yp; }
+    }
+    const unsigned start = xn - tot, lid = xp - (tot ? 1u : 0u);
+    const int d = (int)__shfl((int)xp, WAVE - 1);
+    int32_t* const cp = a.col_ptr + z0 + e;
+    if (tot) { a.uniq_sparse[z0 + lid] = lane; cp[lid] = (int32_t)start; }
+    if (col) {
+      unsigned run = start;
+      for (int64_t q = q0; q < q1; ++q) { const unsigned t = hist[q * C + lane]; hist[q * C + lane] = run; run += t; }
+    }
+    const unsigned long long present = __ballot(tot != 0u);
+    const int W = C >= 32 ? C / 32 : 1;
+    if (lane < W) {
+      bits[(size_t)b * W + lane] = (unsigned)(present >> (32 * lane));
+      lidbase[(size_t)b * W + lane] = (unsigned)__popcll(present & ((1ull << (32 * lane)) - 1ull));
+    }
+    if (lane == 0) {
+      cp[d] = nnz;
+      a.d_cnt[e] = d;
+      atomicMax(a.max_p, d + a.ic);
+    }
+  }
+}
+
 // One wavefront per chunk: its entries, 64 at a time in position order, go to the CSC position base[column] + (entries of the
 // same column before it in the tile); the first lane of every column of a tile then advances the base. In-order LDS, one
 // wavefront: no atomics, and the CSC copy is in row-major order within a column, as the stable sort leaves it.
@@ -422,7 +465,8 @@ int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s) 
     uint32_t* row_of = reinterpret_cast<uint32_t*>(base + o);
     hipLaunchKernelGGL(big_rows_kernel, dim3(ctx->num_cus * 32), dim3(256), 0, s, a, offs, row_offs, rows, row_of);
     hipLaunchKernelGGL(big_hist_kernel, dim3(cgrid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, chunk0, nb, C, hist);
-    hipLaunchKernelGGL(big_cols_kernel, dim3(nb < ctx->num_cus * 16 ? nb : ctx->num_cus * 16), dim3(256), 0, s, a, chunk0, C, hist, bits, lidbase);
+    if (C <= WAVE) hipLaunchKernelGGL(big_cols_small_kernel, dim3((nb + 3) / 4 < ctx->num_cus * 32 ? (nb + 3) / 4 : ctx->num_cus * 32), dim3(256), 0, s, a, chunk0, C, hist, bits, lidbase);
+    else hipLaunchKernelGGL(big_cols_kernel, dim3(nb < ctx->num_cus * 16 ? nb : ctx->num_cus * 16), dim3(256), 0, s, a, chunk0, C, hist, bits, lidbase);
     const int sgrid = (int)(max_chunks > (int64_t)ctx->num_cus * 256 ? (int64_t)ctx->num_cus * 256 : (max_chunks > 0 ? max_chunks : 1));
     hipLaunchKernelGGL(big_scatter_kernel, dim3(sgrid), dim3(WAVE), 0, s, a, chunk0, offs, C, hist, bits, lidbase, row_of);
     HIP_TRY(hipGetLastError());
