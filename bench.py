@@ -411,7 +411,9 @@ def other_workloads_leg(a, rank, world, solver, opts, coll_dev):
         t_gen = time.perf_counter()
         wl = make_workload(b, rank, solver)
         t_gen = time.perf_counter() - t_gen
-        for _ in range(2):   # warm-up: kernels, and the allocator's two alternating pack workspaces
+        packed = res = None
+        for _ in range(2):   # warm-up: kernels, and the allocator's cached blocks
+            packed = res = None      # the previous step's workspace (35 GB for C5) goes back to the allocator before the next is asked for
             packed = solver.pack(wl.raw_dev)
             res = solver.solve(packed, opts)
         torch.cuda.synchronize()
@@ -420,6 +422,7 @@ def other_workloads_leg(a, rank, world, solver, opts, coll_dev):
         steps = 2
         t0 = time.perf_counter()
         for _ in range(steps):
+            packed = res = None
             packed = solver.pack(wl.raw_dev)
             res = solver.solve(packed, opts)
         torch.cuda.synchronize()
