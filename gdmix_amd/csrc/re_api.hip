@@ -58,6 +58,7 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_WREG8, 12288, "re_solve_wreg_kernel<8> lds<=12K"}, {KIND_WREG8, 24576, "re_solve_wreg_kernel<8> lds<=24K"},
     {KIND_WREG8, 65536, "re_solve_wreg_kernel<8> lds<=64K"},
     {KIND_WLDS, 24576, "re_solve_wave_kernel lds<=24K"},     {KIND_WLDS, 65536, "re_solve_wave_kernel lds<=64K"},
+    {KIND_TALL_L, 0, "re_solve_tall_kernel<1> lean p<=64"},
     {KIND_TALL_S, 0, "re_solve_tall_kernel<1> p<=64"},
     {KIND_TALL, 0, "re_solve_tall_kernel<8> p<=64"},
     {KIND_BLOCK, 0, "re_solve_team_kernel workgroup"},
@@ -405,26 +406,35 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
       slot_scratch = static_cast<double*>(base);
     }
   }
+  // A lean tall class of a few thousand entities is not worth a launch of its own (a launch lasts at least one entity's solve and
+  // ends in a thin tail): it then runs with the class behind it — its entities sit right in front of that class's in `order`, and
+  // the general one-wavefront kernel takes any of them. An entity's result does not depend on which of the two ran it: same
+  // accumulator sets, same order of the adds (the variants differ in where loads are issued and in occupancy only).
+  const int lean_merged = (hc[TALL_L_CLASS] > 0 && hc[TALL_L_CLASS] < 4 * ctx->impl.num_cus * TALL_LEAN_WGS) ? hc[TALL_L_CLASS] : 0;
   int begin = 0;
   for (int c = 0; c < BLOCK_CLASS; ++c) {
-    if (hc[c] <= 0) continue;
+    int cnt = hc[c], b0 = begin;
+    begin += hc[c];
+    if (c == TALL_L_CLASS && lean_merged) continue;
+    if (c == TALL_S_CLASS && lean_merged) { b0 -= lean_merged; cnt += lean_merged; }
+    if (cnt <= 0) continue;
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[c], s)); }
     switch (kClasses[c].kind) {
       case KIND_QUAD2: case KIND_QUAD3: case KIND_QUAD4: case KIND_PAIR3: case KIND_PAIR4:
       case KIND_G64_3: case KIND_G64_4: case KIND_G128_3: case KIND_G128_4: case KIND_G256_3: case KIND_G256_4: case KIND_G512_4:
-        HIP_TRY(launch_solve_quad(group_lanes(kClasses[c].kind), group_epl(kClasses[c].kind), B, O, P, theta0, begin, hc[c],
+        HIP_TRY(launch_solve_quad(group_lanes(kClasses[c].kind), group_epl(kClasses[c].kind), B, O, P, theta0, b0, cnt,
                                   kClasses[c].ncap, kClasses[c].zcap, s));
         break;
-      case KIND_WREG1: HIP_TRY(launch_solve_wreg(1, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
-      case KIND_WREG2: HIP_TRY(launch_solve_wreg(2, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
-      case KIND_WREG4: HIP_TRY(launch_solve_wreg(4, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
-      case KIND_WREG8: HIP_TRY(launch_solve_wreg(8, B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
-      case KIND_TALL_S: HIP_TRY(launch_solve_tall(true, B, O, P, theta0, begin, hc[c], ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync), ctx->impl.grid_sync, s)); break;
-      case KIND_TALL: HIP_TRY(launch_solve_tall(false, B, O, P, theta0, begin, hc[c], ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync), ctx->impl.grid_sync, s)); break;
-      default: HIP_TRY(launch_solve_wave(B, O, P, theta0, begin, hc[c], kClasses[c].lds, s)); break;
+      case KIND_WREG1: HIP_TRY(launch_solve_wreg(1, B, O, P, theta0, b0, cnt, kClasses[c].lds, s)); break;
+      case KIND_WREG2: HIP_TRY(launch_solve_wreg(2, B, O, P, theta0, b0, cnt, kClasses[c].lds, s)); break;
+      case KIND_WREG4: HIP_TRY(launch_solve_wreg(4, B, O, P, theta0, b0, cnt, kClasses[c].lds, s)); break;
+      case KIND_WREG8: HIP_TRY(launch_solve_wreg(8, B, O, P, theta0, b0, cnt, kClasses[c].lds, s)); break;
+      case KIND_TALL_L: HIP_TRY(launch_solve_tall(TALL_VARIANT_LEAN, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync), ctx->impl.grid_sync, s)); break;
+      case KIND_TALL_S: HIP_TRY(launch_solve_tall(TALL_VARIANT_SMALL, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync), ctx->impl.grid_sync, s)); break;
+      case KIND_TALL: HIP_TRY(launch_solve_tall(TALL_VARIANT_LARGE, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync), ctx->impl.grid_sync, s)); break;
+      default: HIP_TRY(launch_solve_wave(B, O, P, theta0, b0, cnt, kClasses[c].lds, s)); break;
     }
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[c], s)); ctx->impl.ev_used[c] = true; }
-    begin += hc[c];
   }
   if (hc[BLOCK_CLASS] > 0 || hc[TEAM128_CLASS] > 0 || hc[TEAM32_CLASS] > 0 || hc[TEAM8_CLASS] > 0 || hc[GIANT_CLASS] > 0) {
     double* const scratch = slot_scratch;

@@ -24,7 +24,7 @@ namespace gdmix {
 // Each wavefront kind is split into LDS-footprint buckets so that small entities keep high occupancy.
 enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4, KIND_QUAD2 = 5, KIND_QUAD4 = 6, KIND_PAIR4 = 7, KIND_QUAD3 = 8, KIND_PAIR3 = 9, KIND_WREG8 = 10,
        KIND_G64_3 = 11, KIND_G64_4 = 12, KIND_G128_4 = 13, KIND_G256_4 = 14, KIND_G512_4 = 15, KIND_GRID = 16, KIND_G128_3 = 17, KIND_G256_3 = 18,
-       KIND_TALL = 20, KIND_TALL_S = 21 };   // (19: the register team kernels of round 2, removed in round 3)
+       KIND_TALL = 20, KIND_TALL_S = 21, KIND_TALL_L = 22 };   // (19: the register team kernels of round 2, removed in round 3)
 
 // group kernels (several entities per wavefront): lanes per entity, coefficient slots per lane; 0 if not a group kind
 __host__ __device__ inline int group_lanes(int kind) {
@@ -41,12 +41,26 @@ constexpr int TEAM128_CLASS = GDMIX_RE_NUM_CLASSES - 4;  // 128 teams of 2 CUs
 constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 5;
 constexpr int TALL_CLASS = BLOCK_CLASS - 1;      // tall entities of at least tall_split_n samples: one workgroup of TALL_NW wavefronts per CU
 constexpr int TALL_S_CLASS = BLOCK_CLASS - 2;    // smaller ones: workgroups of TALL_NW_SMALL wavefronts, several per CU
+constexpr int TALL_L_CLASS = BLOCK_CLASS - 3;    // ... and those that fit a twelfth of a CU's LDS: the lean variant, three wavefronts per SIMD
 #ifndef GDMIX_TALL_NW_SMALL
 #define GDMIX_TALL_NW_SMALL 1
 #endif
 constexpr int TALL_NW = 8;
 constexpr int TALL_NW_SMALL = GDMIX_TALL_NW_SMALL;
 constexpr int TALL_MAX_P = 64;      // coefficients (one per lane of the master wavefront)
+constexpr int TALL_LEAN_WAVES = 3;                    // lean variant: wavefronts per SIMD,
+constexpr int TALL_LEAN_WGS = 4 * TALL_LEAN_WAVES;    // one-wavefront workgroups per CU,
+// accumulator sets per column and wavefront of the tall kernels: 16 in the one-wavefront workgroups (both variants the same: an
+// entity's sums do not depend on which of them ran it), 32 for up to 32 coefficients in the eight-wavefront ones
+__host__ __device__ constexpr int tall_sets(int nw, int p) { return (nw > 1 && p <= 32) ? 32 : 16; }
+__host__ __device__ constexpr int tall_lds_bytes(int wg_per_cu) { return 160 * 1024 / wg_per_cu - 512; }
+constexpr int TALL_LEAN_ARENA = (tall_lds_bytes(TALL_LEAN_WGS) - 1408) & ~15;   // what its workgroup can stage (re_solve_tall.hip asserts it)
+// LDS bytes of an entity that stays resident in a tall workgroup: accumulators [nw][d + 1][S + 1], entries, row pointers, labels,
+// offsets, weights (the carve-up of re_solve_tall_kernel)
+__host__ __device__ inline size_t tall_resident_bytes(int nw, int S, int d, int n, int nnz, bool has_w) {
+  return (size_t)nw * (d + 1) * (S + 1) * 8 + (size_t)8 * (nnz + 8) + (size_t)4 * (n + 2) + (size_t)(has_w ? 12 : 8) * n + 16;
+}
+enum { TALL_VARIANT_LARGE = 0, TALL_VARIANT_SMALL = 1, TALL_VARIANT_LEAN = 2 };
 constexpr int BLOCK_NW = 4;   // wavefronts per workgroup of the block kernel
 #ifndef GDMIX_TEAM_BLOCK_NW
 #define GDMIX_TEAM_BLOCK_NW 8
@@ -152,7 +166,7 @@ hipError_t launch_solve_grid(const BatchDev& B, const OutDev& O, const SolvePara
                              int begin, int count, double* scratch, size_t slot_doubles, int64_t max_p,
                              void* sync_buf, int blocks, int teams, hipStream_t s);
 constexpr int TALL_TAIL_BYTES = 256;   // device buffer of the context: padded copy of the end of the batch's row-major arrays
-hipError_t launch_solve_tall(bool small, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0, int begin, int count,
+hipError_t launch_solve_tall(int variant, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0, int begin, int count,
                              int num_cus, int64_t Z, void* tail_buf, void* sync_buf, hipStream_t s);
 void launch_sort_class(int32_t* list, int count, const int64_t* ent_nnz_ptr, hipStream_t s);
 hipError_t launch_variance_full(const BatchDev& B, int64_t E, const SolveParams& o, const double* theta, double* variance,

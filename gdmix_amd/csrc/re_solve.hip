@@ -45,7 +45,8 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
         if (wlds_bytes <= (size_t)tab.lds_bytes[k]) { c = k; break; }
       }
     }
-    if (tab.tall_min_n > 0 && m <= M_REG && p <= TALL_MAX_P && n >= tab.tall_min_n && !(tab.giant_nnz > 0 && z >= tab.giant_nnz)) c = (n >= tab.tall_split_n) ? TALL_CLASS : TALL_S_CLASS;
+    if (tab.tall_min_n > 0 && m <= M_REG && p <= TALL_MAX_P && n >= tab.tall_min_n && !(tab.giant_nnz > 0 && z >= tab.giant_nnz)) c = (n >= tab.tall_split_n) ? TALL_CLASS
+        : (tall_resident_bytes(1, tall_sets(1, p), d, n, z, has_w) <= (size_t)TALL_LEAN_ARENA ? TALL_L_CLASS : TALL_S_CLASS);
     else if (tab.giant_nnz > 0 && z >= tab.giant_nnz) c = GIANT_CLASS;
     else if (c == BLOCK_CLASS || (tab.team_nnz > 0 && z >= tab.team_nnz)) {
       // too large for a wavefront group: a team of CUs, sized by the non-zeros (streaming bandwidth)

@@ -18,7 +18,7 @@ from .batch import RawBatch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgdmix_re.so")
 
-NUM_CLASSES = 50
+NUM_CLASSES = 51
 STATUS_NAMES = ("PGTOL", "FACTR", "MAXITER", "MAXFUN", "ABNORMAL")
 VAR_NONE, VAR_SIMPLE, VAR_FULL = 0, 1, 2
 VARIANCE_MODES = {None: VAR_NONE, "simple": VAR_SIMPLE, "SIMPLE": VAR_SIMPLE, "full": VAR_FULL, "FULL": VAR_FULL,
@@ -144,7 +144,7 @@ def load_library():
     lib.gdmix_java_partition_id.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     lib.gdmix_java_partition_id.restype = C.c_int32
     lib.gdmix_java_partition_ids_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
-    if lib.gdmix_re_abi_version() != 6:
+    if lib.gdmix_re_abi_version() != 7:
         raise GdmixReError("libgdmix_re.so ABI version mismatch")
     _lib = lib
     return lib

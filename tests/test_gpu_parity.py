@@ -118,11 +118,12 @@ def test_default_routing_matches_reference_fixture(device_solver, name):
 
 @pytest.mark.parametrize("name", fixture_names())
 def test_tall_kernel_matches_reference_fixture(device_solver, name):
-    """Every entity with at most 64 coefficients (whatever its sample count: threshold 1) through the tall kernel — one
-    workgroup per entity, the L-BFGS driver replicated in every wavefront; the others keep their default routing."""
+    """Every entity with at most 64 coefficients (whatever its sample count: threshold 1) through the tall kernels — one
+    workgroup per entity: the lean variant for those that fit a twelfth of a CU's LDS, one-wavefront workgroups for the others
+    below 4 096 samples, eight wavefronts above; entities of more coefficients keep their default routing."""
     counts, p, kw = _solve_and_compare(device_solver, name, tall_min_n=1)
     want = int((p <= 64).sum()) if kw["m"] <= 10 else 0
-    got = counts["re_solve_tall_kernel<8> p<=64"] + counts["re_solve_tall_kernel<1> p<=64"]
+    got = counts["re_solve_tall_kernel<8> p<=64"] + counts["re_solve_tall_kernel<1> p<=64"] + counts["re_solve_tall_kernel<1> lean p<=64"]
     assert got == want, (got, want)
 
 
