@@ -91,6 +91,16 @@ using namespace gdmix;
 
 extern "C" {
 
+// A class whose launch cannot fill the device: fewer wavefronts than half of what the CUs hold at two per SIMD (the eight-wavefront
+// tall workgroups: fewer entities than CUs). Such a class runs on the context's side stream next to the large ones.
+static bool class_is_small(int kind, int count, int num_cus) {
+  const int gl = group_lanes(kind);
+  long waves = count;                                   // wavefront kernels, one-wavefront tall variants
+  if (kind == KIND_TALL) waves = (long)count * 4 * TALL_NW / 8;   // one workgroup per CU: count < num_cus
+  else if (gl > 0) waves = gl >= WAVE ? (long)count * (gl / WAVE) : ((long)count * gl + WAVE - 1) / WAVE;
+  return waves < (long)num_cus * 4;
+}
+
 GDMIX_API int gdmix_re_abi_version(void) { return GDMIX_RE_ABI_VERSION; }
 
 GDMIX_API const char* gdmix_re_last_error(void) { return g_err; }
@@ -136,6 +146,7 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   c->impl.grid_sync = nullptr;
   c->impl.big_tmp = nullptr;
   c->impl.big_tmp_bytes = 0;
+  c->impl.side = nullptr; c->impl.side_fork = nullptr; c->impl.side_join = nullptr;
   for (int k = 0; k < GDMIX_RE_NUM_CLASSES; ++k) { c->impl.ev0[k] = nullptr; c->impl.ev1[k] = nullptr; c->impl.ev_used[k] = false; }
   hipError_t rc = hipHostMalloc(reinterpret_cast<void**>(&c->impl.host_pinned), 4096, hipHostMallocDefault);
   if (rc != hipSuccess) {
@@ -143,7 +154,21 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
     delete c;
     return GDMIX_RE_EHIP;
   }
-  rc = hipMalloc(&c->impl.grid_sync, TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_TAIL_BYTES);
+  {
+    const char* e = getenv("GDMIX_RE_SIDE_STREAM");   // test hook: 0 = every class on the caller's stream
+    if (!e || atoi(e) != 0) {
+      rc = hipStreamCreateWithFlags(&c->impl.side, hipStreamNonBlocking);
+      if (rc == hipSuccess) rc = hipEventCreateWithFlags(&c->impl.side_fork, hipEventDisableTiming);
+      if (rc == hipSuccess) rc = hipEventCreateWithFlags(&c->impl.side_join, hipEventDisableTiming);
+      if (rc != hipSuccess) {
+        set_error("creating the side stream failed: %s", hipGetErrorString(rc));
+        (void)hipHostFree(c->impl.host_pinned);
+        delete c;
+        return GDMIX_RE_EHIP;
+      }
+    }
+  }
+  rc = hipMalloc(&c->impl.grid_sync, TEAM_MAX_TEAMS * sizeof(TeamSync) + 3 * TALL_TAIL_BYTES);
   if (rc != hipSuccess) {
     set_error("hipMalloc failed: %s", hipGetErrorString(rc));
     (void)hipHostFree(c->impl.host_pinned);
@@ -159,6 +184,9 @@ GDMIX_API void gdmix_re_destroy(gdmix_re_ctx* ctx) {
   if (ctx->impl.grid_sync) (void)hipFree(ctx->impl.grid_sync);
   if (ctx->impl.big_tmp) (void)hipFree(ctx->impl.big_tmp);
   if (ctx->impl.host_pinned) (void)hipHostFree(ctx->impl.host_pinned);
+  if (ctx->impl.side_fork) (void)hipEventDestroy(ctx->impl.side_fork);
+  if (ctx->impl.side_join) (void)hipEventDestroy(ctx->impl.side_join);
+  if (ctx->impl.side) (void)hipStreamDestroy(ctx->impl.side);
   for (int k = 0; k < GDMIX_RE_NUM_CLASSES; ++k) {
     if (ctx->impl.ev0[k]) (void)hipEventDestroy(ctx->impl.ev0[k]);
     if (ctx->impl.ev1[k]) (void)hipEventDestroy(ctx->impl.ev1[k]);
@@ -411,6 +439,24 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   // the general one-wavefront kernel takes any of them. An entity's result does not depend on which of the two ran it: same
   // accumulator sets, same order of the adds (the variants differ in where loads are issued and in occupancy only).
   const int lean_merged = (hc[TALL_L_CLASS] > 0 && hc[TALL_L_CLASS] < 4 * ctx->impl.num_cus * TALL_LEAN_WGS) ? hc[TALL_L_CLASS] : 0;
+  int n_launch_classes = 0;
+  for (int c = 0; c < GDMIX_RE_NUM_CLASSES; ++c) n_launch_classes += (hc[c] > 0 && !(c == TALL_L_CLASS && lean_merged)) ? 1 : 0;
+  hipStream_t const s_main = s;
+  // the side stream starts where the caller's stream stands now (the class lists are ready), not where it stands when the first
+  // small class comes up in the loop: that one may be the last
+  bool forked = false;
+  if (ctx->impl.side && n_launch_classes > 1) {
+    for (int c = 0; c < BLOCK_CLASS && !forked; ++c) {
+      int cnt = hc[c];
+      if (c == TALL_L_CLASS && lean_merged) continue;
+      if (c == TALL_S_CLASS) cnt += lean_merged;
+      forked = cnt > 0 && class_is_small(kClasses[c].kind, cnt, ctx->impl.num_cus);
+    }
+    if (forked) {
+      HIP_TRY(hipEventRecord(ctx->impl.side_fork, s_main));
+      HIP_TRY(hipStreamWaitEvent(ctx->impl.side, ctx->impl.side_fork, 0));
+    }
+  }
   int begin = 0;
   for (int c = 0; c < BLOCK_CLASS; ++c) {
     int cnt = hc[c], b0 = begin;
@@ -418,6 +464,10 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     if (c == TALL_L_CLASS && lean_merged) continue;
     if (c == TALL_S_CLASS && lean_merged) { b0 -= lean_merged; cnt += lean_merged; }
     if (cnt <= 0) continue;
+    // A class that cannot fill the device (class_is_small: 60 eight-wavefront tall entities take a millisecond on 60 CUs) runs
+    // on the side stream, next to the large classes; joined below, before the team kernels. Disjoint entities and outputs.
+    hipStream_t s = s_main;
+    if (forked && class_is_small(kClasses[c].kind, cnt, ctx->impl.num_cus)) s = ctx->impl.side;
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[c], s)); }
     switch (kClasses[c].kind) {
       case KIND_QUAD2: case KIND_QUAD3: case KIND_QUAD4: case KIND_PAIR3: case KIND_PAIR4:
@@ -429,12 +479,16 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
       case KIND_WREG2: HIP_TRY(launch_solve_wreg(2, B, O, P, theta0, b0, cnt, kClasses[c].lds, s)); break;
       case KIND_WREG4: HIP_TRY(launch_solve_wreg(4, B, O, P, theta0, b0, cnt, kClasses[c].lds, s)); break;
       case KIND_WREG8: HIP_TRY(launch_solve_wreg(8, B, O, P, theta0, b0, cnt, kClasses[c].lds, s)); break;
-      case KIND_TALL_L: HIP_TRY(launch_solve_tall(TALL_VARIANT_LEAN, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync), ctx->impl.grid_sync, s)); break;
-      case KIND_TALL_S: HIP_TRY(launch_solve_tall(TALL_VARIANT_SMALL, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync), ctx->impl.grid_sync, s)); break;
-      case KIND_TALL: HIP_TRY(launch_solve_tall(TALL_VARIANT_LARGE, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync), ctx->impl.grid_sync, s)); break;
+      case KIND_TALL_L: HIP_TRY(launch_solve_tall(TALL_VARIANT_LEAN, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_LEAN * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_LEAN, s)); break;
+      case KIND_TALL_S: HIP_TRY(launch_solve_tall(TALL_VARIANT_SMALL, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_SMALL * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_SMALL, s)); break;
+      case KIND_TALL: HIP_TRY(launch_solve_tall(TALL_VARIANT_LARGE, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_LARGE * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_LARGE, s)); break;
       default: HIP_TRY(launch_solve_wave(B, O, P, theta0, b0, cnt, kClasses[c].lds, s)); break;
     }
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[c], s)); ctx->impl.ev_used[c] = true; }
+  }
+  if (forked) {
+    HIP_TRY(hipEventRecord(ctx->impl.side_join, ctx->impl.side));
+    HIP_TRY(hipStreamWaitEvent(s_main, ctx->impl.side_join, 0));
   }
   if (hc[BLOCK_CLASS] > 0 || hc[TEAM128_CLASS] > 0 || hc[TEAM32_CLASS] > 0 || hc[TEAM8_CLASS] > 0 || hc[GIANT_CLASS] > 0) {
     double* const scratch = slot_scratch;

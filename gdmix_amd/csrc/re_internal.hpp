@@ -120,9 +120,12 @@ struct gdmix_ctx_impl {
   int64_t team_nnz;       // lowest tier of the team kernel (0 = never)
   int tall_min_n;         // tall kernel for p <= 64 and n >= this (0 = never)
   int tall_split_n;       // tall entities with n >= this: one large workgroup per CU
-  void* grid_sync;        // device: TeamSync of the team kernels, followed by TALL_TAIL_BYTES for the tall kernel
+  void* grid_sync;        // device: TeamSync of the team kernels (the first three also: ticket counters of the tall variants), followed
+                          // by TALL_TAIL_BYTES for each tall variant
   void* big_tmp;          // device: grow-only temporary of the big-entity pack path
   size_t big_tmp_bytes;
+  hipStream_t side;       // classes too small to fill the device run here, next to the large ones on the caller's stream (nullptr: off)
+  hipEvent_t side_fork, side_join;
   hipEvent_t ev0[GDMIX_RE_NUM_CLASSES], ev1[GDMIX_RE_NUM_CLASSES];
   bool ev_used[GDMIX_RE_NUM_CLASSES];
 };
