@@ -133,6 +133,74 @@ __device__ __forceinline__ int emit_entity(KeyPtr sk, ValPtr vals, const int32_t
   return carry;
 }
 
+// An entity of more than PACK_RANK_MAX non-zeros all of whose columns are below 64 (MovieLens bags: 20 and 24 features) needs no
+// sort: lane c counts column c, a scan over the lanes gives every column's first CSC position and local id, and the entries are
+// placed 64 at a time in position order (lanes of equal column rank themselves with a ballot per distinct column of the tile;
+// in-order LDS, one wavefront, no atomics in the placement). keys: the staged (column << 32 | position) keys, unsorted; base: 64
+// words of LDS. Same outputs as the sort + emit_entity, without the 55 passes of the bitonic network over 1 024 keys.
+constexpr int PACK_COUNT_COLS = 64;
+template <class ValPtr>
+__device__ __forceinline__ int count_entity(const unsigned long long* keys, unsigned* base, ValPtr vals, const int32_t* __restrict__ rp, int n,
+                                            int nnz, int lane, int32_t* __restrict__ csr_col, int32_t* __restrict__ col_ptr,
+                                            int32_t* __restrict__ csc_row, float* __restrict__ csc_val,
+                                            int32_t* __restrict__ uniq_sparse) {
+  base[lane] = 0u;
+  wave_lds_fence();
+  for (int k = lane; k < nnz; k += WAVE) atomicAdd(&base[(unsigned)(keys[k] >> 32)], 1u);   // integer counts: any order
+  wave_lds_fence();
+  const unsigned tot = base[lane];
+  unsigned xn = tot;
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const unsigned yn = __shfl_up(xn, d);
+    if (lane >= d) xn += yn;
+  }
+  const unsigned start = xn - tot;
+  const unsigned long long present = __ballot(tot != 0u);
+  const int d = __popcll(present);
+  if (tot) {
+    const int lid = __popcll(present & ((1ull << lane) - 1ull));
+    uniq_sparse[lid] = lane;
+    col_ptr[lid] = (int32_t)start;
+  }
+  if (lane == 0) col_ptr[d] = nnz;
+  wave_lds_fence();
+  base[lane] = start;
+  wave_lds_fence();
+  for (int t = 0; t < nnz; t += WAVE) {
+    const int k = t + lane;
+    const bool valid = k < nnz;
+    const unsigned c = valid ? (unsigned)(keys[k] >> 32) : 0u;
+    unsigned rank = 0, cnt = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const unsigned cl = (unsigned)__shfl((int)c, leader);
+      const unsigned long long m = __ballot(valid && c == cl);
+      if (valid && c == cl) {
+        rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        cnt = (unsigned)__popcll(m);
+      }
+      todo &= ~m;
+    }
+    if (valid) {
+      const unsigned kpos = base[c] + rank;
+      csr_col[k] = __popcll(present & ((1ull << c) - 1ull));
+      csc_val[kpos] = vals[k];
+      int lo = 0, hi = n - 1;   // sample of non-zero k: last i with rp[i] <= k
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rp[mid] <= k) lo = mid; else hi = mid - 1;
+      }
+      csc_row[kpos] = lo;
+    }
+    wave_lds_fence();
+    if (valid && rank == 0) base[c] += cnt;
+    wave_lds_fence();
+  }
+  return d;
+}
+
 // CAP = LDS staging capacity (non-zeros and samples) of a wavefront, NWAVES = wavefronts per workgroup.
 // in_list == nullptr: all E entities; otherwise the *in_count entities of in_list. Entities above CAP are
 // appended to out_list (counter *out_count).
@@ -191,9 +259,11 @@ __global__ __launch_bounds__(WAVE* NWAVES) void pack_entity_kernel(
     {
       // explicit LDS instantiation (ds_* accesses; a generic pointer selecting between LDS and HBM compiles
       // to flat_* accesses whose base+offset folding faults at the LDS aperture edge)
+      bool wide = false;   // a column of PACK_COUNT_COLS or above (or out of range)
       for (int k = lane; k < nnz; k += WAVE) {
         const int64_t c = col_global[z0 + k];
         bad |= (c < 0 || c > 0x7fffffffll);
+        wide |= (uint64_t)c >= (uint64_t)PACK_COUNT_COLS;
         lds_keys[wv][k] = ((unsigned long long)(uint32_t)c << 32) | (unsigned)k;
         lds_val[wv][k] = val[z0 + k];
       }
@@ -202,6 +272,9 @@ __global__ __launch_bounds__(WAVE* NWAVES) void pack_entity_kernel(
         wave_rank_sort(lds_keys[wv], lds_sorted[wv], nnz, lane);
         d = emit_entity(lds_sorted[wv], lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0, col_ptr + z0 + e,
                         csc_row + z0, csc_val + z0, uniq_sparse + z0);
+      } else if (__ballot(wide) == 0ull) {
+        d = count_entity(lds_keys[wv], reinterpret_cast<unsigned*>(lds_sorted[wv]), lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0,
+                         col_ptr + z0 + e, csc_row + z0, csc_val + z0, uniq_sparse + z0);
       } else {
         wave_bitonic_sort(lds_keys[wv], nnz, lane);
         d = emit_entity(lds_keys[wv], lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0, col_ptr + z0 + e,
