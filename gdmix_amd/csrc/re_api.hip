@@ -91,14 +91,14 @@ using namespace gdmix;
 
 extern "C" {
 
-// A class whose launch cannot fill the device: fewer wavefronts than half of what the CUs hold at two per SIMD (the eight-wavefront
+// A class whose launch cannot fill the device: fewer wavefronts than three quarters of what the CUs hold at two per SIMD (the eight-wavefront
 // tall workgroups: fewer entities than CUs). Such a class runs on the context's side stream next to the large ones.
 static bool class_is_small(int kind, int count, int num_cus) {
   const int gl = group_lanes(kind);
   long waves = count;                                   // wavefront kernels, one-wavefront tall variants
   if (kind == KIND_TALL) waves = (long)count * 4 * TALL_NW / 8;   // one workgroup per CU: count < num_cus
   else if (gl > 0) waves = gl >= WAVE ? (long)count * (gl / WAVE) : ((long)count * gl + WAVE - 1) / WAVE;
-  return waves < (long)num_cus * 4;
+  return waves < (long)num_cus * 6;
 }
 
 GDMIX_API int gdmix_re_abi_version(void) { return GDMIX_RE_ABI_VERSION; }
