@@ -207,6 +207,28 @@ def test_pack_of_large_entities_counting_and_sort_paths(device_solver, monkeypat
         assert packed.max_n == int(ent_n.max()) and packed.max_nnz == int(np.diff(rp[np.concatenate([[0], np.cumsum(ent_n)])]).max())
 
 
+def test_side_stream_does_not_change_results(device_solver, monkeypatch):
+    """gdmix_re_solve launches the classes that cannot fill the device on a second stream of the context, beside the large ones
+    (csrc/re_api.hip: class_is_small). A batch with a dozen classes, most of them small: a context without the side stream
+    (GDMIX_RE_SIDE_STREAM=0 at creation) gives the same bits, SIMPLE variances included."""
+    from gdmix_amd.batch import concat
+    from gdmix_amd.solver import REDeviceSolver
+    b = concat([synthetic.make_batch(3000, 16, 4, 1024, seed=61), synthetic.make_batch(200, 24, 8, 4096, seed=62, size_dist="zipf"),
+                synthetic.make_movielens_20m("per_user", seed=63, entities=400), synthetic.make_batch(3, 900, 8, 4096, seed=64, size_dist="const")])
+    kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12, variance_mode=1)
+    packed = device_solver.pack(b)
+    a = device_solver.solve(packed, SolverOptions(**kw)).to_host()
+    assert sum(1 for _, c in device_solver.class_counts(packed) if c > 0) >= 8
+    monkeypatch.setenv("GDMIX_RE_SIDE_STREAM", "0")
+    plain = REDeviceSolver(0)
+    try:
+        r = plain.solve(plain.pack(b), SolverOptions(**kw)).to_host()
+    finally:
+        plain.close()
+    for k in ("theta", "variance", "fval", "gnorm", "nit", "nfev", "status"):
+        assert np.array_equal(a[k], r[k]), k
+
+
 def test_results_are_bitwise_reproducible(device_solver):
     b = synthetic.make_batch(2000, 16, 4, 1024, seed=5)
     packed = device_solver.pack(b)
