@@ -69,10 +69,25 @@ def parse():
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip detail.workloads: C3 (MovieLens-20M per-user / per-movie) and C5's per-GPU share, two steps each, next to the C2 headline")
     ap.add_argument("--c5-entities", type=int, default=4_000_000, help="entities of the c5share workload per GPU (C5's share is 12.5 M)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank owns its own batch, the headline of the bench contract. strong: ONE population split over "
+                         "the ranks by the reference's partition hash and partitions[rank::ranks] (bench_strong.py); --workload picks "
+                         "ml20m_user / ml20m_movie / c5 (default c5), `value` is that job's entities/s")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="with --gpus N > 1 the default run also measures the three strong-scaling populations (top-level `strong_scaling`); skip that")
+    ap.add_argument("--no-rebalance", action="store_true", help="strong-scaling legs: skip the run through the re-balancer")
+    ap.add_argument("--rebalance-tolerance", type=float, default=0.02,
+                    help="strong-scaling legs: ranks within (1 + tolerance) x the mean cost neither send nor receive (the product's default is 0.05)")
+    ap.add_argument("--strong-steps", type=int, default=2, help="timed steps of each strong-scaling / projection leg")
+    ap.add_argument("--project-ranks", type=int, default=8,
+                    help="--gpus 1, default workload: also solve the shares of an N-rank job one after another on this GPU "
+                         "(detail.strong_projection; 0 = skip)")
+    ap.add_argument("--ml-entities", type=int, default=0, help="strong legs: keep this many MovieLens entities (tests at reduced size; 0 = all)")
     return ap.parse_args()
 
 
 WORKLOADS = {
+    "c5": "strong scaling only: ONE Zipf population of --c5-entities x ranks entities hashed into 1 024 partitions (bench_strong.py)",
     "c2": "C2, synthetic 1 M entities x avg 64 nnz (SURVEY 8(d) generator)",
     "c5mean": "C5's mean shape without the tail (32 samples x 8 nnz, D = 65 536), stratified generator",
     "zipf": "the same with Zipf sizes (round-1/2 exploration shape, tail not capped at 2^20 nnz)",
@@ -373,7 +388,11 @@ def make_workload(a, rank, solver):
         what = f"exploration shape {w}, {a.entities} entities/GPU"
     else:
         kind = "per_user" if w == "ml20m_user" else "per_movie"
-        batch = synthetic.make_movielens_20m(kind, seed=200 + rank)
+        if rank == 0:     # the same population the strong-scaling / projection legs split (generated once per process)
+            import bench_strong
+            batch = bench_strong.ml20m_population(kind, None)
+        else:
+            batch = synthetic.make_movielens_20m(kind, seed=200 + rank)
         what = (f"C3: MovieLens-20M-sized {kind} random effect, {batch.E} entities/GPU, {batch.N} training rows (count distributions of the public "
                 "dataset card, feature bags of scripts/download_process_movieLens_data.py; synthetic values), per-entity L2 LR, L-BFGS m=10")
     ones = np.add.reduceat(batch.y.astype(np.float64), batch.ent_row_ptr[:-1]) if batch.N else np.zeros(batch.E)
@@ -452,6 +471,45 @@ def other_workloads_leg(a, rank, world, solver, opts, coll_dev):
     return out if rank == 0 else None
 
 
+def _fits(w, a, world, coll_dev):
+    """The c5 population needs ~150 GB per 4 M entities of a rank's share (raw arrays, pack workspace, results, and for the re-balanced
+    run the wire form): skipped — by all ranks together — when a rank does not have that, e.g. ranks sharing one device in the tests."""
+    if w != "c5":
+        return True
+    import torch
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free = torch.cuda.mem_get_info()[0]
+    sharing = world if getattr(a, "ranks_share_device", False) else 1
+    per_rank = 150e9 if (world == 1 or a.no_rebalance) else 200e9    # the give-back of a re-balanced run assembles the results once more
+    ok = 1 if free >= int(per_rank * a.c5_entities / 4_000_000) * sharing else 0
+    if world > 1:
+        tt = torch.tensor([ok], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        ok = int(tt.item())
+    return bool(ok)
+
+
+def strong_main(a, rank, world, solver, opts, coll_dev, backend):
+    """--scaling strong: the headline is ONE population split over the ranks (bench_strong.py)."""
+    import bench_strong
+    name = a.workload if a.workload in bench_strong.STRONG_WORKLOADS else "c5"
+    r = bench_strong.strong_leg(name, rank, world, solver, opts, coll_dev, a.c5_entities, steps=a.steps, warmup=a.warmup,
+                                rebalance=not a.no_rebalance, ml_entities=a.ml_entities or None, tolerance=a.rebalance_tolerance)
+    if rank == 0:
+        line = {"metric": "random-effect entities converged/sec", "value": round(r["entities_per_s"], 1), "unit": "entities/s",
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": r["ms"], "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": r["what"], "workload_key": name, "total_entities": r["total_entities"], "step": "pack+solve",
+                           "l2": 1.0, "regularize_bias": False, "max_iter": 100, "parallelism": f"partitions[rank::{world}]",
+                           "collective_backend": backend},
+                "roofline": None, "cpu_baseline": None,
+                "note": "strong-scaling mode: roofline and cpu_baseline belong to the default (weak, C2) line",
+                "strong_scaling": [r]}
+        print(json.dumps(line))
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -490,6 +548,14 @@ def main():
     opts_kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
     opts = SolverOptions(**opts_kw)
     solver = REDeviceSolver(local_rank)
+    if a.scaling == "strong":
+        strong_main(a, rank, world, solver, opts, coll_dev, backend)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if a.workload == "c5":
+        raise SystemExit("--workload c5 is a strong-scaling population: use --scaling strong (c5share is its weak-scaling counterpart)")
     t_gen = time.perf_counter()
     wl = make_workload(a, rank, solver)
     t_gen = time.perf_counter() - t_gen
@@ -562,6 +628,23 @@ def main():
         res = None
         others = other_workloads_leg(a, rank, world, solver, opts, coll_dev)
         res = solver.solve(packed, opts, out=out)    # (the statistics of the C2 batch again, for the lines below)
+
+    # ---- ONE population split over the ranks (BASELINE configs[2] and [4]): measured with ranks, projected on one GPU ----
+    strong = projection = None
+    if a.workload == "c2" and not a.no_other_workloads:
+        import bench_strong
+        res = None
+        torch.cuda.empty_cache()
+        if world > 1 and not a.no_strong:
+            strong = [bench_strong.strong_leg(w, rank, world, solver, opts, coll_dev, a.c5_entities, steps=a.strong_steps, warmup=1,
+                                              rebalance=not a.no_rebalance, ml_entities=a.ml_entities or None, tolerance=a.rebalance_tolerance)
+                      for w in bench_strong.STRONG_WORKLOADS if _fits(w, a, world, coll_dev)]
+        elif world == 1 and a.project_ranks > 1:
+            projection = [bench_strong.projection_leg(w, a.project_ranks, solver, opts, a.c5_entities, steps=a.strong_steps, warmup=1,
+                                                      ml_entities=a.ml_entities or None, tolerance=a.rebalance_tolerance)
+                          for w in bench_strong.STRONG_WORKLOADS if _fits(w, a, world, coll_dev)]
+        solver.set_timing(True)
+        res = solver.solve(packed, opts, out=out)
 
     if rank == 0:
         # ---- roofline of the dominant kernel = the size-class launch with the largest share of a step ----
@@ -689,8 +772,8 @@ def main():
                        "entities_per_gpu": wl.E, "step": "solve" if a.solve_only else "pack+solve",
                        "l2": 1.0, "regularize_bias": False, "max_iter": 100, "parallelism": f"entity-shard x{world}",
                        "collective_backend": backend, "ranks": per_rank},
-            "roofline": roofline, "cpu_baseline": cpu,
-            "detail": {"pack_ms_per_step": pack_ms / a.steps, "solve_ms_per_step": solve_ms / a.steps,
+            "roofline": roofline, "cpu_baseline": cpu, "strong_scaling": strong,
+            "detail": {"strong_projection": projection,"pack_ms_per_step": pack_ms / a.steps, "solve_ms_per_step": solve_ms / a.steps,
                        "solve_kernel_ms_per_step": float(kernel_ms.sum()) / a.steps,
                        "classes": classes, "class_ms": [round(float(x) / a.steps, 3) for x in kernel_ms], "per_class": per_class,
                        "mean_nit": nit, "mean_nfev": nfev,

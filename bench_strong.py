@@ -1,0 +1,273 @@
+"""Strong-scaling legs of bench.py: ONE population split over the ranks the reference's way, and the re-balancer timed.
+
+BASELINE.json configs[2] is one MovieLens-20M split over 8 GPUs and configs[4] one 100 M-entity Zipf population "with dynamic entity
+rebalancing" — not eight copies. The split is the reference's: entity -> partition by the Java hash of its decimal id
+(gdmix-data/.../PartitionUtils.scala:31-37, contract B4: gdmix_java_partition_ids_i64 on the device), partition -> worker by
+partitions[rank::world] (gdmix-trainer/src/gdmix/drivers/random_effect_driver.py:60-68). A rank's share is its partitions
+concatenated in partition order; a step is pack + solve of the share, resident in HBM, exactly as in the weak-scaling headline.
+
+  strong_leg        N ranks (torch.distributed): every rank generates its share of the population, K timed steps between barriers,
+                    job time = the slowest rank. With `rebalance` the share then goes through gdmix_amd.rebalance: cost model from
+                    the plain run's per-class kernel times (CostModel), exchange -> widen -> pack -> solve -> give_back, every phase
+                    timed, bytes sent / received counted, and the coefficients that come back compared with the plain run's.
+  projection_leg    one process, one GPU: the R shares solved one after another on the same device. Entities are independent and
+                    the data path has no collective, so max over shares is what an R-GPU job would take apart from its barriers;
+                    this is how a 1-GPU box can say something about ML-20M over 8 GPUs (17 k users per GPU: a latency-bound regime).
+                    Labelled as a projection wherever it is reported; it also reports the re-balancing *plan* (predicted loads
+                    before / after, bytes that would move) without executing it.
+"""
+import time
+
+import numpy as np
+
+STRONG_WORKLOADS = {
+    "ml20m_user": ("C3: ONE MovieLens-20M per-user population (138 493 users, 16 M training rows) hashed into 64 partitions", 64),
+    "ml20m_movie": ("C3: ONE MovieLens-20M per-movie population (26 744 movies, 16 M training rows) hashed into 64 partitions", 64),
+    "c5": ("C5: ONE Zipf population of --c5-entities x ranks entities (P(nnz >= x) ~ x^-1.2 on [8, 2^20], mean 256, D = 65 536) "
+           "hashed into 1 024 partitions (SURVEY 8(d))", 1024),
+}
+
+
+class Share:
+    """A rank's share of a population, raw form resident in HBM."""
+
+    def __init__(self, name, raw_dev, n, z, ids, pid, total_entities, partitions, gen_s):
+        self.name, self.raw_dev, self.n, self.z, self.ids, self.pid = name, raw_dev, n, z, ids, pid
+        self.E, self.N, self.Z = int(n.size), int(n.sum()), int(z.sum())
+        self.total_entities, self.partitions, self.gen_s = int(total_entities), int(partitions), gen_s
+
+
+_ML_CACHE = {}
+
+
+def ml20m_population(kind, ml_entities=None):
+    """The MovieLens-20M-sized population (seed 200), generated once per process: the projection asks for every share of it."""
+    from gdmix_amd import synthetic
+    key = (kind, ml_entities or None)
+    if key not in _ML_CACHE:
+        _ML_CACHE[key] = synthetic.make_movielens_20m(kind, seed=200, entities=ml_entities or None)
+    return _ML_CACHE[key]
+
+
+def make_share(name, world, rank, solver, c5_entities, ml_entities=None):
+    """Rank `rank`'s share of population `name` for a job of `world` workers."""
+    from gdmix_amd import synthetic
+    t0 = time.perf_counter()
+    P = STRONG_WORKLOADS[name][1]
+    dev_pids = lambda ids, parts: solver.partition_ids(np.ascontiguousarray(ids, np.int64), parts).cpu().numpy()
+    if name == "c5":
+        total = int(c5_entities) * world
+        raw, n, ids, pid = synthetic.make_c5_population_share(solver.device, total, world, rank, P, partition_ids_fn=dev_pids)
+        z = n * (raw["Z"] // max(1, raw["N"]))
+        return Share(name, raw, n, z, ids, pid, total, P, time.perf_counter() - t0)
+    full = ml20m_population("per_user" if name == "ml20m_user" else "per_movie", ml_entities)
+    ids_all = np.arange(1, full.E + 1, dtype=np.int64)          # MovieLens ids are 1-based decimals
+    own, pid = synthetic.population_share(ids_all, P, world, rank, dev_pids(ids_all, P))
+    sub = full.select(own)
+    return Share(name, solver.upload(sub), sub.ent_n(), sub.ent_nnz(), ids_all[own], pid, full.E, P, time.perf_counter() - t0)
+
+
+def _wire_from_raw(raw):
+    """The 32-bit wire form (what the re-balancer exchanges) of a raw batch in HBM."""
+    import torch
+    d = dict(E=raw["E"], N=raw["N"], Z=raw["Z"], row_nnz_width=4, y_width=4, col_width=4)
+    d["ent_n"] = (raw["ent_row_ptr"][1:] - raw["ent_row_ptr"][:-1]).to(torch.int32)
+    d["row_nnz"] = (raw["row_nnz_ptr"][1:] - raw["row_nnz_ptr"][:-1]).to(torch.int32)
+    d["col_global"] = raw["col_global"].to(torch.int32)
+    d["val"], d["y"], d["offset"], d["weight"] = raw["val"], raw["y"], raw["offset"], raw["weight"]
+    return d
+
+
+def _timed_steps(solver, share, opts, steps, warmup, sync, barrier):
+    """-> (packed, res, seconds of this rank's `steps` steps, seconds until every rank is done, class ms of the last step)."""
+    packed = res = None
+    for _ in range(max(1, warmup)):
+        packed = res = None
+        packed = solver.pack(share.raw_dev)
+        res = solver.solve(packed, opts)
+    sync()
+    barrier()
+    import torch
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    pack_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        packed = res = None
+        ev[0].record()
+        packed = solver.pack(share.raw_dev)
+        ev[1].record()
+        res = solver.solve(packed, opts)
+        ev[2].record()
+        ev[2].synchronize()
+        pack_ms += ev[0].elapsed_time(ev[1])
+    sync()
+    own = time.perf_counter() - t0
+    barrier()
+    share.pack_ms = pack_ms / steps
+    return packed, res, own, time.perf_counter() - t0, np.array(solver.last_solve_ms())
+
+
+def _converged(res):
+    st = res.status
+    return int(((st >= 0) & (st <= 2)).sum().item())
+
+
+def _entity_classes(packed, torch):
+    return packed._view(packed.c.cls_tmp, packed.E, torch.int32).cpu().numpy()
+
+
+def strong_leg(name, rank, world, solver, opts, coll_dev, c5_entities, steps=2, warmup=1, rebalance=True, ml_entities=None, tolerance=0.05):
+    """Every rank: its share of population `name`, `steps` timed steps. -> dict on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    from gdmix_amd.rebalance import CostModel, Rebalancer, _Comm
+    from gdmix_amd.solver import NUM_CLASSES
+    sync = torch.cuda.synchronize
+    barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
+
+    def gather_rows(row):
+        mine = torch.tensor([float(v) for v in row], dtype=torch.float64, device=coll_dev)
+        if world == 1:
+            return mine.cpu().numpy()[None, :]
+        out = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(out, mine)
+        return np.stack([o.cpu().numpy() for o in out])
+
+    share = make_share(name, world, rank, solver, c5_entities, ml_entities)
+    solver.set_timing(True)
+    packed, res, own_s, job_s, class_ms = _timed_steps(solver, share, opts, steps, warmup, sync, barrier)
+    conv = _converged(res)
+    rows = gather_rows([rank, share.E, share.N, share.Z, own_s / steps * 1e3, conv, job_s, float(class_ms.sum()), share.gen_s,
+                        len(set(share.pid.tolist())), share.pack_ms])
+    job_ms = float(rows[:, 6].max()) / steps * 1e3
+    ms = rows[:, 4]
+    out = {"workload": name, "what": STRONG_WORKLOADS[name][0], "partitions": share.partitions, "ranks": world,
+           "split": "entity -> partition: Java hash of the decimal id (PartitionUtils.scala:31-37); partition -> rank: partitions[rank::ranks] "
+                    "(random_effect_driver.py:60-68)",
+           "total_entities": int(rows[:, 1].sum()), "total_nnz": int(rows[:, 3].sum()), "steps": steps,
+           "ms": job_ms, "entities_per_s": float(rows[:, 5].sum()) / (job_ms * 1e-3), "converged_per_step": int(rows[:, 5].sum()),
+           "imbalance": float(ms.max() / ms.mean()),
+           "per_rank": [{"rank": int(r[0]), "entities": int(r[1]), "samples": int(r[2]), "nnz": int(r[3]), "ms_per_step": float(r[4]),
+                         "pack_ms": float(r[10]), "solve_kernel_ms": float(r[7]), "partitions": int(r[9]), "generate_s": round(float(r[8]), 2)}
+                        for r in rows]}
+    assert out["total_entities"] == share.total_entities, (out["total_entities"], share.total_entities)
+    if rebalance and world > 1:
+        # ---- the same share through the re-balancer ----
+        cls = _entity_classes(packed, torch)
+        additive = np.arange(NUM_CLASSES) <= NUM_CLASSES - 5          # everything but the multi-workgroup team tiers
+        tot = torch.from_numpy(CostModel.totals(cls, share.z, class_ms, NUM_CLASSES)).to(coll_dev)
+        dist.all_reduce(tot)
+        model = CostModel.from_totals(tot.cpu().numpy(), additive)
+        cost, order = model.cost(cls, share.z), model.order(cls, share.z)
+        theta_plain, status_plain = res.theta_thr.clone(), res.status.clone()
+        cp_plain = torch.from_numpy(packed.coef_ptr_host()).to(solver.device)
+        packed = res = None
+        torch.cuda.empty_cache()
+        wire = _wire_from_raw(share.raw_dev)
+        comm = _Comm(None, solver.device)
+        phases = np.zeros(5)
+        moved = None
+        diff = 0.0
+        status_equal = 0
+        for it in range(warmup + steps):
+            if it == warmup:
+                phases[:] = 0
+                comm.bytes_sent = comm.bytes_received = 0
+                sync(); barrier()
+                t_job = time.perf_counter()
+            t = [time.perf_counter()]
+            rb = Rebalancer(share.n, share.z, dict(wire), cost=cost, order=order, comm=comm, tolerance=tolerance)
+            work = rb.exchange()
+            sync(); t.append(time.perf_counter())
+            pk = solver.pack(solver.widen(work))
+            sync(); t.append(time.perf_counter())
+            rs = solver.solve(pk, opts)
+            sync(); t.append(time.perf_counter())
+            fp = pk.ent_feat_ptr()
+            cc = (fp[1:] - fp[:-1]) + 1
+            ints = torch.stack([rs.nit, rs.nfev, rs.status], dim=1)
+            flts = torch.stack([rs.fval, rs.gnorm], dim=1)
+            my_cc, th, _, _, my_ints, _ = rb.give_back(cc, rs.theta_thr, None, pk.unique_global(), ints, flts)
+            sync(); t.append(time.perf_counter())
+            barrier(); t.append(time.perf_counter())
+            phases += np.diff(t)
+            moved = [int(ix.size) for ix in rb.sent]
+            if it == warmup + steps - 1:
+                # what came back, against the plain run of the same entities (the multi-workgroup team tiers reproduce to ~1e-8:
+                # a tier's team size depends on what else is in it; everything else is bit for bit)
+                assert th.numel() == theta_plain.numel() and bool((my_cc.cumsum(0) == cp_plain[1:]).all())
+                scale = torch.clamp(theta_plain.abs(), min=1e-3)
+                diff = float(((th - theta_plain).abs() / scale).max().item()) if th.numel() else 0.0
+                status_equal = int((my_ints[:, 2] == status_plain).sum().item())
+            del rb, work, pk, rs, th
+        job2 = time.perf_counter() - t_job
+        rrows = gather_rows([rank, *(phases / steps * 1e3), comm.bytes_sent / steps, comm.bytes_received / steps, sum(moved), diff, status_equal,
+                             float(cost.sum()), job2])
+        job2_ms = float(rrows[:, 12].max()) / steps * 1e3
+        work_ms = rrows[:, 2] + rrows[:, 3]        # pack + solve where the entities ended up
+        out["rebalanced"] = {
+            "ms": job2_ms, "entities_per_s": out["converged_per_step"] / (job2_ms * 1e-3),
+            "imbalance_of_pack_plus_solve": float(work_ms.max() / work_ms.mean()), "tolerance": tolerance,
+            "cost_model": "milliseconds: per-class kernel time / non-zeros of the plain run, summed over ranks (rebalance.CostModel); entities of the "
+                          "multi-workgroup team tiers stay; the costliest per byte travel first",
+            "max_rel_diff_vs_plain": float(rrows[:, 9].max()), "status_equal": int(rrows[:, 10].sum()),
+            "per_rank": [{"rank": int(r[0]), "exchange_ms": float(r[1]), "widen_pack_ms": float(r[2]), "solve_ms": float(r[3]), "give_back_ms": float(r[4]),
+                          "wait_ms": float(r[5]), "bytes_sent": int(r[6]), "bytes_received": int(r[7]), "entities_sent": int(r[8]),
+                          "predicted_cost_ms": float(r[11])} for r in rrows]}
+    return out if rank == 0 else None
+
+
+def projection_leg(name, ranks, solver, opts, c5_entities, steps=2, warmup=1, ml_entities=None, tolerance=0.05):
+    """One GPU: the `ranks` shares of population `name` one after another (see the module docstring)."""
+    import torch
+    from gdmix_amd.rebalance import CostModel, choose_entities, plan_transfers
+    from gdmix_amd.solver import NUM_CLASSES
+    solver.set_timing(True)
+    per, totals, kept = [], np.zeros((2, NUM_CLASSES)), []
+    for r in range(ranks):
+        share = make_share(name, ranks, r, solver, c5_entities, ml_entities)
+        packed, res, own_s, _, class_ms = _timed_steps(solver, share, opts, steps, warmup, torch.cuda.synchronize, lambda: None)
+        cls = _entity_classes(packed, torch)
+        totals += CostModel.totals(cls, share.z, class_ms, NUM_CLASSES)
+        kept.append((cls, share.z, share.n))
+        per.append({"rank": r, "entities": share.E, "samples": share.N, "nnz": share.Z, "ms_per_step": own_s / steps * 1e3,
+                    "pack_ms": share.pack_ms, "solve_kernel_ms": float(class_ms.sum()), "converged": _converged(res),
+                    "largest_nnz": int(share.z.max()) if share.E else 0,
+                    "generate_s": round(share.gen_s, 2)})
+        total_entities, partitions = share.total_entities, share.partitions
+        del share, packed, res
+        torch.cuda.empty_cache()
+    ms = np.array([p["ms_per_step"] for p in per])
+    conv = sum(p["converged"] for p in per)
+    out = {"workload": name, "what": STRONG_WORKLOADS[name][0], "ranks": ranks, "partitions": partitions,
+           "projection": f"the {ranks} shares were solved one after another on ONE MI355X (no collective on the data path): ms = the slowest share",
+           "total_entities": sum(p["entities"] for p in per), "total_nnz": sum(p["nnz"] for p in per),
+           "ms": float(ms.max()), "entities_per_s": conv / (float(ms.max()) * 1e-3), "imbalance": float(ms.max() / ms.mean()),
+           "sum_of_shares_ms": float(ms.sum()), "per_rank": per}
+    assert out["total_entities"] == total_entities
+    # the re-balancing plan on measured costs (not executed here: the exchange needs the other ranks)
+    additive = np.arange(NUM_CLASSES) <= NUM_CLASSES - 5
+    model = CostModel.from_totals(totals, additive)
+    costs = [model.cost(c, z) for c, z, _ in kept]
+    loads = np.array([c.sum() for c in costs])
+    T = plan_transfers(loads, tolerance)
+    after = loads.copy()
+    bytes_moved = 0.0
+    ents_moved = 0
+    for i in range(ranks):
+        if T[i].sum() <= 0:
+            continue
+        cls, z, n = kept[i]
+        sent = choose_entities(costs[i], T[i], model.order(cls, z))
+        for j, ix in enumerate(sent):
+            after[i] -= costs[i][ix].sum()
+            after[j] += costs[i][ix].sum()
+            # wire form: int32 feature id + fp32 value per non-zero; count, label, offset per sample; a count per entity
+            bytes_moved += float(z[ix].sum()) * 8.0 + float(n[ix].sum()) * 12.0 + float(ix.size) * 4.0
+            ents_moved += int(ix.size)
+    out["rebalance_plan"] = {"predicted_load_ms": [round(float(x), 3) for x in loads], "after_ms": [round(float(x), 3) for x in after],
+                             "predicted_imbalance": float(loads.max() / loads.mean()), "after_imbalance": float(after.max() / after.mean()),
+                             "entities_to_move": ents_moved, "wire_bytes_to_move": bytes_moved, "tolerance": tolerance,
+                             "note": "plan only (rebalance.plan_transfers / choose_entities on rebalance.CostModel costs measured here); executed by "
+                                     "strong_leg when the job has ranks"}
+    return out

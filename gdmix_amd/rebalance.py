@@ -54,12 +54,13 @@ def plan_transfers(loads, tolerance=0.05):
     return T
 
 
-def choose_entities(cost, amounts):
-    """Which local entities go to each destination: entities in ascending cost order (ties by index) are dealt out
-    until each destination's amount is reached. Returns a list of index arrays, one per destination (possibly
-    empty); every entity appears at most once; the rest stays."""
+def choose_entities(cost, amounts, order=None):
+    """Which local entities go to each destination: entities in ascending cost order (ties by index) — or in the order
+    `order` lists them, which may leave entities out: those never travel — are dealt out until each destination's amount
+    is reached. Returns a list of index arrays, one per destination (possibly empty); every entity appears at most once;
+    the rest stays."""
     cost = np.asarray(cost, np.float64)
-    order = np.argsort(cost, kind="stable")
+    order = np.argsort(cost, kind="stable") if order is None else np.asarray(order, np.int64)
     csum = np.concatenate([[0.0], np.cumsum(cost[order])])   # costs are non-zero counts: the sums are exact
     out = []
     pos = 0
@@ -72,6 +73,50 @@ def choose_entities(cost, amounts):
         out.append(np.sort(order[pos:end].astype(np.int64)))
         pos = end
     return out
+
+
+class CostModel:
+    """Measured cost of an entity, in milliseconds of solve-kernel time: what the re-balancer equalises when the plain
+    non-zero count is a poor proxy (a Zipf partition: the 1 % of entities that run on the team kernels cost several times
+    more per non-zero than the small ones). Built from a solve that was timed per size class (gdmix_re_set_timing /
+    gdmix_re_last_solve_ms): a class launch of `ms` milliseconds over entities holding `nnz` non-zeros prices a non-zero of
+    that class at ms / nnz; rates are summed over ranks (`totals` -> all-reduce -> `from_totals`) so that every rank prices
+    an entity the same. `additive` classes are those whose launch time is about the sum of its entities' work (one entity
+    per wavefront group / workgroup); in the multi-workgroup team tiers the longest entity is the critical path, so moving
+    their entities is not priced — they stay (`movable`)."""
+
+    def __init__(self, rate, additive):
+        self.rate = np.asarray(rate, np.float64)          # [classes] ms per non-zero (0 = class not seen)
+        self.additive = np.asarray(additive, bool)
+
+    @staticmethod
+    def totals(cls, nnz, class_ms, num_classes):
+        """This rank's [2, classes] sums: milliseconds and non-zeros per class (to be added up over ranks)."""
+        cls = np.asarray(cls, np.int64)
+        z = np.bincount(cls, weights=np.asarray(nnz, np.float64) + 64.0, minlength=num_classes)[:num_classes]
+        return np.stack([np.asarray(class_ms, np.float64)[:num_classes], z])
+
+    @classmethod
+    def from_totals(cls, totals, additive):
+        ms, z = np.asarray(totals, np.float64)
+        # a class that ran inside another class's launch has entities and no time of its own: priced like its neighbour
+        rate = np.where((z > 0) & (ms > 0), ms / np.maximum(z, 1.0), 0.0)
+        seen = np.flatnonzero(rate > 0)
+        if seen.size:
+            for c in np.flatnonzero((z > 0) & (rate == 0)):
+                rate[c] = rate[seen[np.argmin(np.abs(seen - c))]]
+        return cls(rate, additive)
+
+    def cost(self, cls, nnz):
+        return self.rate[np.asarray(cls, np.int64)] * (np.asarray(nnz, np.float64) + 64.0)
+
+    def order(self, cls, nnz):
+        """The order in which entities are offered for travel: only entities of additive classes; the ones that cost most per
+        byte moved first (the fewest bytes for the milliseconds shed), ties by size then index."""
+        cls = np.asarray(cls, np.int64)
+        ok = np.flatnonzero(self.additive[cls])
+        key = np.lexsort((ok, np.asarray(nnz)[ok], -self.rate[cls[ok]]))
+        return ok[key]
 
 
 def _segments(t, starts, lens, total):
@@ -91,10 +136,16 @@ class _Comm:
         import torch.distributed as dist
         self.t, self.dist, self.group = torch, dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        nccl = dist.get_backend(group) == "nccl"
         if device is None:
-            device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            device = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
         self.device = device
+        # device tensors over gloo (ranks sharing one GPU in the harness tests — RCCL refuses two ranks on one device): the
+        # collectives run on host copies. Never the case in a real job (nccl).
+        self.staged = (not nccl) and device.type != "cpu"
+        self.coll_device = torch.device("cpu") if self.staged else device
         self._pinned = {}     # (direction, dtype) -> page-locked staging tensor, grown as needed and reused from round to round
+        self.bytes_sent = self.bytes_received = 0      # payload of all_to_all_t since construction (diagnostics)
 
     def _stage(self, key, count, tdt):
         """A page-locked host tensor of at least `count` elements (RCCL path: the device copies run at PCIe rate and without a
@@ -108,7 +159,7 @@ class _Comm:
     def all_gather_row(self, values):
         """values: a few floats of this rank -> [world, len(values)] numpy (small metadata)."""
         t = self.t
-        mine = t.tensor([float(v) for v in values], dtype=t.float64, device=self.device)
+        mine = t.tensor([float(v) for v in values], dtype=t.float64, device=self.coll_device)
         out = [t.zeros_like(mine) for _ in range(self.world)]
         self.dist.all_gather(out, mine, group=self.group)
         return np.stack([o.cpu().numpy() for o in out])
@@ -119,7 +170,7 @@ class _Comm:
     def exchange_counts(self, counts):
         """counts: [world, k] integers this rank sends to every rank -> [world, k] received from every rank."""
         t = self.t
-        send = t.tensor(np.asarray(counts, np.int64).reshape(self.world, -1), dtype=t.int64, device=self.device)
+        send = t.tensor(np.asarray(counts, np.int64).reshape(self.world, -1), dtype=t.int64, device=self.coll_device)
         recv = t.zeros_like(send)
         self.dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
         return recv.cpu().numpy()
@@ -129,10 +180,16 @@ class _Comm:
         dimensions travel along) -> the rows received, grouped by source rank (recv_counts rows each). Device to device."""
         t = self.t
         send = send.contiguous()
-        recv = t.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=self.device)
+        if self.staged:
+            send = send.cpu()
+        recv = t.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=self.coll_device)
         self.dist.all_to_all_single(recv, send, output_split_sizes=[int(c) for c in recv_counts],
                                     input_split_sizes=[int(c) for c in send_counts], group=self.group)
-        return recv
+        row = send.element_size() * int(np.prod(send.shape[1:], dtype=np.int64))
+        mine = self.rank
+        self.bytes_sent += row * (int(sum(send_counts)) - int(send_counts[mine]))
+        self.bytes_received += row * (int(sum(recv_counts)) - int(recv_counts[mine]))
+        return recv.to(self.device) if self.staged else recv
 
     def all_to_all(self, parts, dtype):
         """parts[j] = numpy array for rank j -> list of numpy arrays received from every rank. Host data (the prior models of a
@@ -177,7 +234,7 @@ def wire_tensors(batch, device, solver=None):
              row_nnz_width=4, col_global=batch.col_global.astype(np.int32), col_width=4, val=batch.val, y=batch.y, y_width=4,
              offset=batch.offset, weight=batch.weight)
     if solver is not None and hasattr(solver, "upload_wire"):
-        return solver.upload_wire(w)
+        return solver.upload_wire(w, pinned=solver.wire_stage(w) if hasattr(solver, "wire_stage") else None)
     d = {k: w[k] for k in ("E", "N", "Z", "row_nnz_width", "y_width", "col_width")}
     for k in WIRE_KEYS:
         d[k] = None if w[k] is None else torch.from_numpy(np.ascontiguousarray(w[k])).to(device)
@@ -205,14 +262,18 @@ class Rebalancer:
 
     A rank without a partition in a round passes empty arrays and still joins the collectives."""
 
-    def __init__(self, ent_n, ent_nnz, wire, group=None, tolerance=0.05, cost=None):
-        self.comm = _Comm(group, wire["val"].device)
+    def __init__(self, ent_n, ent_nnz, wire, group=None, tolerance=0.05, cost=None, order=None, comm=None):
+        """cost: per-entity cost the ranks equalise (default: non-zeros; CostModel.cost for measured milliseconds); order: the
+        order in which this rank's entities are offered for travel (default: ascending cost; entities left out never travel;
+        CostModel.order); comm: a _Comm kept from round to round (its page-locked staging blocks are reused)."""
+        self.comm = comm if comm is not None else _Comm(group, wire["val"].device)
         self.t = self.comm.t
         self.n = np.asarray(ent_n, np.int64)
         self.nnz = np.asarray(ent_nnz, np.int64)
         self.E = int(self.n.size)
         self.wire = wire
         self.cost = np.asarray(self.nnz if cost is None else cost, np.float64)
+        self.order = None if order is None else np.asarray(order, np.int64)
         self.tolerance = tolerance
         self.sent = None        # per destination: entity indices of this rank's partition
         self.kept = None
@@ -251,7 +312,7 @@ class Rebalancer:
         if any_w and not has_w:     # a rank without weights may receive weighted entities (and vice versa): make the pieces uniform
             self.wire = dict(self.wire, weight=t.ones(self.wire["y"].numel(), dtype=t.float32, device=self.wire["val"].device))
         T = plan_transfers(self.loads, self.tolerance)
-        self.sent = choose_entities(self.cost, T[c.rank])
+        self.sent = choose_entities(self.cost, T[c.rank], self.order)
         self.sent[c.rank] = np.zeros(0, np.int64)
         moving = np.concatenate(self.sent) if self.sent else np.zeros(0, np.int64)
         mask = np.ones(self.E, bool)
@@ -279,6 +340,12 @@ class Rebalancer:
         work["Z"] = int(self.nnz[self.kept].sum() + recv_enz[:, 2].sum())
         work.update(row_nnz_width=4, y_width=4, col_width=4)
         self.work_E = work["E"]
+        # the partition's own wire arrays and the prefix sums of the gathers are not needed again: when entities moved, `work`
+        # holds copies of what stayed (the re-balanced path kept the partition in HBM several times over)
+        self.wire = None
+        for k in ("_row_start", "_nz_start"):
+            if hasattr(self, k):
+                delattr(self, k)
         self.work_prior = self._exchange_prior(prior) if with_prior else None
         return work
 
@@ -347,6 +414,10 @@ class Rebalancer:
         r_th = c.all_to_all_t(theta[int(cb[0]):], send_c, recv[:, 1])
         r_va = c.all_to_all_t(variance[int(cb[0]):], send_c, recv[:, 1]) if variance is not None else None
         r_fi = c.all_to_all_t(feat_idx[int(fb[0]):], send_f, recv[:, 2])
+        if nk == self.E and int(recv[:, 0].sum()) == 0 and int(send_e.sum()) == 0:
+            # nothing left this rank and nothing came: its results already are in its partition's order (no copies: a rank
+            # that stays out of a round pays nothing for it but the count exchanges)
+            return cc, theta, variance, feat_idx, ints, floats
         # the pool: kept entities, then what every rank returned (in the order the entities were sent); an entity of the
         # partition finds its pool position through `where`
         where = np.empty(self.E, np.int64)

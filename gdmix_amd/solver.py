@@ -407,6 +407,22 @@ class REDeviceSolver:
                 d[k] = t.from_numpy(a).to(self.device)
         return d
 
+    def wire_stage(self, wire):
+        """Page-locked host tensors for upload_wire(wire, pinned=...), one per wire array, kept by the solver and grown when a
+        partition needs more: the copies of the next partition reuse them (the previous upload must have completed: callers
+        synchronise the stream once per partition anyway, when they read the results back)."""
+        t = self.torch
+        st = self.__dict__.setdefault("_wire_stage", {})
+        for k in self.WIRE_ARRAYS:
+            a = wire[k]
+            if a is None or isinstance(a, t.Tensor):
+                continue
+            tdt = t.from_numpy(a[:0]).dtype
+            cur = st.get(k)
+            if cur is None or cur.dtype != tdt or cur.numel() < a.size:
+                st[k] = t.empty(int(a.size * 1.25) + 1024, dtype=tdt, pin_memory=True)
+        return st
+
     def widen(self, wd):
         """gdmix_re_widen: wire form (device tensors from upload_wire) -> the raw form gdmix_re_pack takes, on the device."""
         t = self.torch

@@ -286,8 +286,31 @@ def c5_entity_samples(rng, E, mean_nnz=256, k=8, max_nnz=1 << 20):
     c = want / raw.mean()
     for _ in range(30):    # the cap removes mass from the tail: solve for the scale that restores the mean
         n = np.clip(np.floor(raw * c), 1, cap)
-        c *= want / n.mean()
+        c_next = c * (want / n.mean())
+        if c_next == c:    # a fixed point (reached after a handful of rounds): the remaining rounds would not change anything
+            break
+        c = c_next
     return np.clip(np.floor(raw * c), 1, cap).astype(np.int64)
+
+
+def _c5_rows(g, dev, rows, k, D, w_star, cols, vals, offset, y, at, chunk_rows=1 << 24):
+    """`rows` samples of SURVEY.md §8(d)'s C5 written at [at, at + rows) of the output arrays, drawn from generator g."""
+    import torch
+    for r0 in range(0, rows, chunk_rows):
+        r1 = min(rows, r0 + chunk_rows)
+        c = torch.randint(0, D, (r1 - r0, k), generator=g, device=dev, dtype=torch.int64)
+        while True:    # re-draw the samples that drew a column twice
+            s, _ = torch.sort(c, dim=1)
+            bad = torch.nonzero((s[:, 1:] == s[:, :-1]).any(dim=1)).reshape(-1)
+            if bad.numel() == 0:
+                break
+            c[bad] = torch.randint(0, D, (bad.numel(), k), generator=g, device=dev, dtype=torch.int64)
+        v = torch.randn((r1 - r0, k), generator=g, device=dev, dtype=torch.float32)
+        o = torch.randn(r1 - r0, generator=g, device=dev, dtype=torch.float32)
+        logit = (v.double() * w_star[c]).sum(dim=1) + o.double()
+        cols[at + r0:at + r1], vals[at + r0:at + r1], offset[at + r0:at + r1] = c, v, o
+        y[at + r0:at + r1] = (torch.rand(r1 - r0, generator=g, device=dev, dtype=torch.float64) < torch.sigmoid(logit)).float()
+        del c, v, o, logit, s, bad
 
 
 def make_c5_share_device(device, E, seed=C5_SEED, mean_nnz=256, k=8, D=65536, max_nnz=1 << 20, chunk_rows=1 << 24):
@@ -308,25 +331,72 @@ def make_c5_share_device(device, E, seed=C5_SEED, mean_nnz=256, k=8, D=65536, ma
     vals = torch.empty((N, k), dtype=torch.float32, device=dev)
     offset = torch.empty(N, dtype=torch.float32, device=dev)
     y = torch.empty(N, dtype=torch.float32, device=dev)
-    for r0 in range(0, N, chunk_rows):
-        r1 = min(N, r0 + chunk_rows)
-        c = torch.randint(0, D, (r1 - r0, k), generator=g, device=dev, dtype=torch.int64)
-        while True:    # re-draw the samples that drew a column twice
-            s, _ = torch.sort(c, dim=1)
-            bad = torch.nonzero((s[:, 1:] == s[:, :-1]).any(dim=1)).reshape(-1)
-            if bad.numel() == 0:
-                break
-            c[bad] = torch.randint(0, D, (bad.numel(), k), generator=g, device=dev, dtype=torch.int64)
-        v = torch.randn((r1 - r0, k), generator=g, device=dev, dtype=torch.float32)
-        o = torch.randn(r1 - r0, generator=g, device=dev, dtype=torch.float32)
-        logit = (v.double() * w_star[c]).sum(dim=1) + o.double()
-        cols[r0:r1], vals[r0:r1], offset[r0:r1] = c, v, o
-        y[r0:r1] = (torch.rand(r1 - r0, generator=g, device=dev, dtype=torch.float64) < torch.sigmoid(logit)).float()
-        del c, v, o, logit, s, bad
+    _c5_rows(g, dev, N, k, D, w_star, cols, vals, offset, y, 0, chunk_rows)
     ent_row_ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(n)])).to(dev)
     raw = dict(E=int(E), N=N, Z=N * k, ent_row_ptr=ent_row_ptr, row_nnz_ptr=torch.arange(N + 1, dtype=torch.int64, device=dev) * k,
                col_global=cols.reshape(-1), val=vals.reshape(-1), y=y, offset=offset, weight=None)
     return raw, n
+
+
+def rank_partitions(num_partitions, world, rank):
+    """The partitions worker `rank` of `world` trains: partitions[rank::world] of the partition list 0..P-1
+    (drivers/random_effect_driver.py:60-68)."""
+    return list(range(int(num_partitions)))[int(rank)::int(world)]
+
+
+def population_share(entity_ids, num_partitions, world, rank, partition_ids=None):
+    """One population split the reference's way: entity -> partition by the Java hash of its decimal id (PartitionUtils.scala:31-37,
+    contract B4), partition -> worker by partitions[rank::world]. -> (indices of this rank's entities, ordered by partition and,
+    inside a partition, by their order in `entity_ids`; their partition ids). `partition_ids` (from the device routine
+    gdmix_java_partition_ids_i64) may be handed in; the host routine of partitioner.py is the default."""
+    ids = np.asarray(entity_ids, np.int64)
+    if partition_ids is None:
+        from .partitioner import java_partition_ids_int64
+        partition_ids = java_partition_ids_int64(ids, num_partitions)
+    pid = np.asarray(partition_ids, np.int64)
+    mine = np.zeros(int(num_partitions), bool)
+    mine[rank_partitions(num_partitions, world, rank)] = True
+    own = np.flatnonzero(mine[pid])
+    own = own[np.argsort(pid[own], kind="stable")]
+    return own, pid[own]
+
+
+def make_c5_population_share(device, E_total, world, rank, num_partitions=1024, seed=C5_SEED, mean_nnz=256, k=8, D=65536,
+                             max_nnz=1 << 20, partition_ids_fn=None):
+    """Rank `rank`'s share of ONE C5 population of E_total entities (BASELINE.json configs[4]; SURVEY.md §8(d): "partition = Java
+    hash (B4) of the decimal entity id into 1 024 partitions"), generated in HBM. The population does not depend on the number
+    of workers: entity e has id e and n_e samples from one seeded host draw over all E_total entities; its partition is the
+    Java hash of str(e); the samples of partition K come from a Philox stream seeded by (seed, K), entities of K in id order.
+    Worker r holds partitions[r::world], concatenated in partition order. -> (raw, n, ids, pid): the dict of device tensors
+    REDeviceSolver.pack takes, and per entity of the share (host arrays) its samples, global id and partition."""
+    import torch
+    rng = np.random.default_rng(seed)
+    n_all = c5_entity_samples(rng, int(E_total), mean_nnz, k, max_nnz)
+    ids_all = np.arange(int(E_total), dtype=np.int64)
+    pid_all = None if partition_ids_fn is None else np.asarray(partition_ids_fn(ids_all, num_partitions))
+    own, pid = population_share(ids_all, num_partitions, world, rank, pid_all)
+    n = n_all[own]
+    N = int(n.sum())
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    w_star = 0.5 * torch.randn(D, generator=g, device=dev, dtype=torch.float64)
+    cols = torch.empty((N, k), dtype=torch.int64, device=dev)
+    vals = torch.empty((N, k), dtype=torch.float32, device=dev)
+    offset = torch.empty(N, dtype=torch.float32, device=dev)
+    y = torch.empty(N, dtype=torch.float32, device=dev)
+    at = 0
+    rows_of = np.bincount(pid, weights=n, minlength=int(num_partitions)).astype(np.int64)
+    for K in rank_partitions(num_partitions, world, rank):
+        rows = int(rows_of[K])
+        if rows:
+            g.manual_seed(int(seed) * 1_000_003 + 1 + K)
+            _c5_rows(g, dev, rows, k, D, w_star, cols, vals, offset, y, at)
+            at += rows
+    ent_row_ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(n)])).to(dev)
+    raw = dict(E=int(own.size), N=N, Z=N * k, ent_row_ptr=ent_row_ptr, row_nnz_ptr=torch.arange(N + 1, dtype=torch.int64, device=dev) * k,
+               col_global=cols.reshape(-1), val=vals.reshape(-1), y=y, offset=offset, weight=None)
+    return raw, n, own, pid
 
 
 def device_entities_to_host(raw, n, ents):

@@ -88,3 +88,48 @@ def test_default_legs_of_a_two_rank_run():
     assert ("skipped" in w["c5share"]) == bool(share)
     if not share:
         assert w["c5share"]["converged_per_step"] == 2 * w["c5share"]["entities_per_gpu"]
+    # ... and ONE population of each kind split over the two ranks (top-level strong_scaling; the C5 population is skipped together
+    # with c5share when the ranks share a device)
+    st = {s["workload"]: s for s in line["strong_scaling"]}
+    assert set(st) == ({"ml20m_user", "ml20m_movie"} if share else {"ml20m_user", "ml20m_movie", "c5"})
+    assert st["ml20m_user"]["total_entities"] == 138493 == sum(r["entities"] for r in st["ml20m_user"]["per_rank"])
+    assert st["ml20m_movie"]["total_entities"] == 26744 and st["ml20m_movie"]["rebalanced"]["status_equal"] == 26744
+    assert st["ml20m_user"]["rebalanced"]["max_rel_diff_vs_plain"] <= 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,extra,total", [("ml20m_user", ["--ml-entities", "6000"], 6000), ("ml20m_movie", ["--ml-entities", "3000"], 3000),
+                                                  ("c5", ["--c5-entities", "30000"], 60000)])
+def test_strong_scaling_splits_one_population_and_rebalancing_returns_the_same_models(workload, extra, total):
+    """--scaling strong: ONE population, entity -> partition by the Java hash, partition -> rank by partitions[rank::2]; the same
+    share then through the re-balancer (exchange -> widen -> pack -> solve -> give back), whose coefficients must be the plain
+    run's. Two ranks: on the 1-GPU box they share cuda:0 and the collectives are staged over gloo; with two devices it is RCCL."""
+    import torch
+    share = [] if torch.cuda.device_count() >= 2 else ["--ranks-share-device"]
+    line = _line(_run(["--gpus", "2"] + share + ["--scaling", "strong", "--workload", workload, "--steps", "2", "--warmup", "1"] + extra))
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2 and line["config"]["workload_key"] == workload
+    s = line["strong_scaling"][0]
+    assert s["total_entities"] == total == sum(r["entities"] for r in s["per_rank"]) == s["converged_per_step"]
+    assert all(r["entities"] > 0 and r["ms_per_step"] > 0 for r in s["per_rank"]) and s["imbalance"] >= 1.0
+    assert sum(r["partitions"] for r in s["per_rank"]) <= s["partitions"]
+    assert abs(line["value"] - total / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    rb = s["rebalanced"]
+    assert rb["status_equal"] == total and rb["max_rel_diff_vs_plain"] <= 1e-7
+    assert sum(r["bytes_sent"] for r in rb["per_rank"]) == sum(r["bytes_received"] for r in rb["per_rank"])
+    assert all(r["solve_ms"] > 0 for r in rb["per_rank"])
+
+
+@pytest.mark.gpu
+def test_projection_of_an_eight_rank_job_on_one_device():
+    """--gpus 1: the shares of an 8-rank job solved one after another (detail.strong_projection), with the re-balancing plan."""
+    line = _line(_run(["--entities", "20000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-fe", "--no-cli",
+                       "--ml-entities", "8000", "--c5-entities", "20000", "--project-ranks", "8"], timeout=1500))
+    proj = {p["workload"]: p for p in line["detail"]["strong_projection"]}
+    assert set(proj) == {"ml20m_user", "ml20m_movie", "c5"} and line["strong_scaling"] is None
+    assert proj["ml20m_user"]["total_entities"] == 8000 and proj["c5"]["total_entities"] == 160000
+    for p in proj.values():
+        assert p["ranks"] == 8 and len(p["per_rank"]) == 8 and p["imbalance"] >= 1.0
+        assert sum(r["converged"] for r in p["per_rank"]) == p["total_entities"]
+        assert abs(p["ms"] - max(r["ms_per_step"] for r in p["per_rank"])) < 1e-9
+        plan = p["rebalance_plan"]
+        assert plan["after_imbalance"] <= plan["predicted_imbalance"] + 1e-9
