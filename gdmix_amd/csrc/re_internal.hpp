@@ -216,4 +216,19 @@ hipError_t launch_partition_ids(const int64_t* ids, int64_t count, int32_t num_p
 
 void set_error(const char* fmt, ...);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: one flag per call site would leave the
+// second device of a process at the 64 KB default. One of these per call site (static), a bit per device.
+struct DynLdsOnce {
+  unsigned long long done = 0;   // (set twice by racing threads at worst: the call is idempotent)
+  hipError_t set(const void* fn, int bytes = 160 * 1024) {
+    int dev = 0;
+    hipError_t rc = hipGetDevice(&dev);
+    if (rc != hipSuccess) return rc;
+    if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return hipSuccess;
+    rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (rc == hipSuccess && dev >= 0 && dev < 64) done |= 1ull << dev;
+    return rc;
+  }
+};
+
 }  // namespace gdmix

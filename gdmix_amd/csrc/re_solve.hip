@@ -279,13 +279,8 @@ __attribute__((amdgpu_waves_per_eu(EPL == 1 ? GDMIX_WREG_WAVES_EPL1 : (EPL == 2 
 template <int EPL>
 static hipError_t launch_wreg_t(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
                                 int begin, int count, int lds_bytes, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(re_solve_wreg_kernel<EPL>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (rc != hipSuccess) return rc;
-    attr_set = true;
-  }
+  static DynLdsOnce lds_attr;
+  if (hipError_t rc = lds_attr.set(reinterpret_cast<const void*>(re_solve_wreg_kernel<EPL>)); rc != hipSuccess) return rc;
   hipLaunchKernelGGL(re_solve_wreg_kernel<EPL>, dim3(count), dim3(WAVE), (size_t)lds_bytes, s, B, O, o, theta0, begin);
   return hipGetLastError();
 }
@@ -455,13 +450,8 @@ static hipError_t launch_quad_t(const BatchDev& B, const OutDev& O, const SolveP
   constexpr int NG = G >= WAVE ? 1 : WAVE / G;
   constexpr int NWG = G > WAVE ? G / WAVE : 1;
   const int row_lds_bytes = quad_layout(G * EPL, NCAP, ZCAP, NWG, quad_nold(G, EPL)).bytes;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(re_solve_grp_kernel<G, EPL, NCAP, ZCAP>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (rc != hipSuccess) return rc;
-    attr_set = true;
-  }
+  static DynLdsOnce lds_attr;
+  if (hipError_t rc = lds_attr.set(reinterpret_cast<const void*>(re_solve_grp_kernel<G, EPL, NCAP, ZCAP>)); rc != hipSuccess) return rc;
   hipLaunchKernelGGL((re_solve_grp_kernel<G, EPL, NCAP, ZCAP>), dim3((count + NG - 1) / NG), dim3(G > WAVE ? G : WAVE),
                      (size_t)row_lds_bytes * NG, s, B, O, o, theta0, begin, count);
   return hipGetLastError();
@@ -556,13 +546,8 @@ __global__ __launch_bounds__(WAVE) void re_solve_wave_kernel(BatchDev B, OutDev 
 hipError_t launch_solve_wave(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
                              int begin, int count, int lds_bytes, hipStream_t s) {
   if (count <= 0) return hipSuccess;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(re_solve_wave_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (rc != hipSuccess) return rc;
-    attr_set = true;
-  }
+  static DynLdsOnce lds_attr;
+  if (hipError_t rc = lds_attr.set(reinterpret_cast<const void*>(re_solve_wave_kernel)); rc != hipSuccess) return rc;
   hipLaunchKernelGGL(re_solve_wave_kernel, dim3(count), dim3(WAVE), (size_t)lds_bytes, s, B, O, o, theta0, begin);
   return hipGetLastError();
 }
@@ -650,12 +635,8 @@ __global__ __launch_bounds__(1024) void re_sort_class_kernel(int32_t* __restrict
 
 void launch_sort_class(int32_t* list, int count, const int64_t* ent_nnz_ptr, hipStream_t s) {
   if (count <= 1 || count > SORT_CAP) return;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(re_sort_class_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return;   // stays in ticket order: slower tail, same results
-    attr_set = true;
-  }
+  static DynLdsOnce lds_attr;
+  if (lds_attr.set(reinterpret_cast<const void*>(re_sort_class_kernel)) != hipSuccess) return;   // stays in ticket order: slower tail, same results
   int np2 = 1;
   while (np2 < count) np2 <<= 1;
   hipLaunchKernelGGL(re_sort_class_kernel, dim3(1), dim3(1024), (size_t)np2 * 8, s, list, count, ent_nnz_ptr);
@@ -671,12 +652,50 @@ void launch_sort_class(int32_t* list, int count, const int64_t* ent_nnz_ptr, hip
 #ifndef GDMIX_TEAM_WAVES_PER_EU
 #define GDMIX_TEAM_WAVES_PER_EU 2
 #endif
+// Where the five p-vectors and the residuals of a one-workgroup entity live (round 4). The workgroup kernel holds one entity per CU
+// (eight wavefronts of up to 256 VGPRs) and its static LDS is 41 KB, so ~119 KB of the CU's LDS are free: x, g, d (and x_old,
+// g_old where they fit) and the per-sample residuals go there instead of the global scratch slot — a quarter of the reads and
+// three quarters of the writes of the class, and the two gather passes (x by the rows, the residuals by
+// the columns) become LDS gathers. The history stays in HBM. VEC = 0: everything in the slot (entities too large, and every
+// multi-workgroup team: x and the residuals are read by all workgroups); 3: x, g, d + residuals; 5: + x_old, g_old.
+// Same arithmetic in the same order: results do not depend on the placement (test_block_kernel_*, test_team_lds_vectors_*).
+extern __shared__ __attribute__((aligned(16))) double team_arena[];
+__host__ __device__ inline int team_vec_level(int p, int n, int arena_doubles) {
+  const long pp = (p + 1) & ~1, nn = (n + 1) & ~1;
+  if (5 * pp + nn <= arena_doubles) return 5;
+  if (3 * pp + nn <= arena_doubles) return 3;
+  return 0;
+}
+
+template <int NW, int VEC>
+__device__ __forceinline__ void team_entity(Team<NW>& tm, const EntityView& P, const SolveParams& o, Work W, const OutDev& O,
+                                            const double* __restrict__ theta0, int64_t e, int64_t c0) {
+  const int p = P.p;
+  if (VEC >= 3) {
+    const int pp = (p + 1) & ~1;
+    double* a = team_arena;
+    W.x = a; a += pp;
+    W.g = a; a += pp;
+    W.d = a; a += pp;
+    if (VEC >= 5) { W.t = a; a += pp; W.r = a; a += pp; }
+    W.rs = a;
+  }
+  for (int j = tm.tid; j < p; j += tm.NT) W.x[j] = theta0 ? theta0[c0 + j] : 0.0;
+  SolveStats st;
+  team_solve(tm, P, o, W, st);
+  TeamAsGroup<NW> grp{tm, tm.tid, tm.NT};
+  write_results(grp, O, o, e, c0, p, W.x, st);
+  if (o.variance_mode == GDMIX_RE_VAR_SIMPLE && O.variance) variance_simple(grp, P, o, W, O.variance + c0);
+  tm.sync();   // the slot (and the arena) is reused by the next entity
+}
+
 template <int NW, bool GRID>
 __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(GDMIX_TEAM_WAVES_PER_EU))) void re_solve_team_kernel(BatchDev B, OutDev O, SolveParams o,
                                                                  const double* __restrict__ theta0, int begin, int count,
                                                                  double* scratch, size_t slot_doubles, int64_t max_p,
-                                                                 TeamSync* gs, int teams) {
+                                                                 TeamSync* gs, int teams, int arena_doubles, int xcd_barrier) {
   __shared__ TeamLds<NW> lds;
+  static_assert(sizeof(TeamLds<NW>) % 16 == 0, "the dynamic arena behind the static LDS must stay 16-byte aligned");
   const int ic = o.has_intercept ? 1 : 0;
   const int m = o.m;
   Team<NW> tm;
@@ -701,6 +720,8 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(GDMIX_
   tm.L = &lds;
   tm.epoch = 0;
   tm.phase = 0;
+  tm.one_xcd = false;
+  if (GRID && xcd_barrier) tm.team_placement();
   double* slot = scratch + (size_t)(GRID ? team : (int)blockIdx.x) * slot_doubles;
   for (int idx = (int)blockIdx.x;; idx += (int)gridDim.x) {
     if (GRID) {
@@ -731,15 +752,12 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(GDMIX_
     W.rho = dp; dp += m;
     W.part = dp; dp += TEAM_LONG_CAP * WAVE;
     W.rs = dp;
-    for (int j = tm.tid; j < p; j += tm.NT) W.x[j] = theta0 ? theta0[c0 + j] : 0.0;
     EntityView P{n, d, p, ic, B.row_ptr + r0 + e, B.csr_col + z0, B.csr_val + z0, B.col_ptr + z0 + e,
                  B.csc_row + z0, B.csc_val + z0, B.y + r0, B.offset + r0, B.weight ? B.weight + r0 : nullptr};
-    SolveStats st;
-    team_solve(tm, P, o, W, st);
-    TeamAsGroup<NW> grp{tm, tm.tid, tm.NT};
-    write_results(grp, O, o, e, c0, p, W.x, st);
-    if (o.variance_mode == GDMIX_RE_VAR_SIMPLE && O.variance) variance_simple(grp, P, o, W, O.variance + c0);
-    tm.sync();   // the slot is reused by the next entity
+    const int vec = GRID ? 0 : team_vec_level(p, n, arena_doubles);   // uniform over the workgroup
+    if (!GRID && vec == 5) team_entity<NW, 5>(tm, P, o, W, O, theta0, e, c0);
+    else if (!GRID && vec == 3) team_entity<NW, 3>(tm, P, o, W, O, theta0, e, c0);
+    else team_entity<NW, 0>(tm, P, o, W, O, theta0, e, c0);
   }
 }
 
@@ -751,8 +769,18 @@ static hipError_t launch_team_block(const BatchDev& B, const OutDev& O, const So
   // largest first (workgroups start in index order and take the next entity as they finish): a big entity started last
   // would be the tail of the launch
   launch_sort_class(const_cast<int32_t*>(B.order) + begin, count, B.ent_nnz_ptr, s);
-  hipLaunchKernelGGL((re_solve_team_kernel<NW, false>), dim3(grid), dim3(WAVE * NW), 0, s, B, O, o, theta0, begin,
-                     count, scratch, slot_doubles, max_p, static_cast<TeamSync*>(nullptr), 1);
+  // the LDS the workgroup leaves free (one workgroup per CU: eight wavefronts at two per SIMD) holds the p-vectors of an
+  // entity that fits (team_vec_level); GDMIX_TEAM_ARENA_KB=0 keeps everything in the scratch slot (A/B and tests)
+  constexpr int kArenaMax = (160 * 1024 - (int)sizeof(TeamLds<NW>) - 64) & ~15;
+  int arena_bytes = kArenaMax;
+  if (const char* ev = getenv("GDMIX_TEAM_ARENA_KB")) {
+    const int kb = atoi(ev);
+    if (kb >= 0 && kb * 1024 < arena_bytes) arena_bytes = kb * 1024;
+  }
+  static DynLdsOnce lds_attr;   // (the limit counts the dynamic part only: static + dynamic must stay within the CU's 160 KB)
+  if (hipError_t err = lds_attr.set(reinterpret_cast<const void*>(&re_solve_team_kernel<NW, false>), kArenaMax); err != hipSuccess) return err;
+  hipLaunchKernelGGL((re_solve_team_kernel<NW, false>), dim3(grid), dim3(WAVE * NW), (size_t)arena_bytes, s, B, O, o, theta0, begin,
+                     count, scratch, slot_doubles, max_p, static_cast<TeamSync*>(nullptr), 1, arena_bytes / 8, 0);
   return hipGetLastError();
 }
 
@@ -787,8 +815,11 @@ hipError_t launch_solve_grid(const BatchDev& B, const OutDev& O, const SolvePara
   err = hipMemset2DAsync(sync_buf, sizeof(TeamSync), 0, 64, (size_t)teams, s);
   if (err != hipSuccess) return err;
   launch_sort_class(const_cast<int32_t*>(B.order) + begin, count, B.ent_nnz_ptr, s);
+  // GDMIX_RE_XCD_BARRIER=0: every barrier with the full release (A/B and tests); default: measured per team (Team::team_placement)
+  const char* xe = getenv("GDMIX_RE_XCD_BARRIER");
+  const int xcd_barrier = (xe && atoi(xe) == 0) ? 0 : 1;
   hipLaunchKernelGGL((re_solve_team_kernel<TEAM_GRID_NW, true>), dim3(blocks), dim3(WAVE * TEAM_GRID_NW), 0, s, B, O, o,
-                     theta0, begin, count, scratch, slot_doubles, max_p, static_cast<TeamSync*>(sync_buf), teams);
+                     theta0, begin, count, scratch, slot_doubles, max_p, static_cast<TeamSync*>(sync_buf), teams, 0, xcd_barrier);
   return hipGetLastError();
 }
 

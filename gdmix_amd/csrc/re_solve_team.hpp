@@ -49,6 +49,7 @@ struct TeamSync {
   unsigned moved[2]; // by parity of the update: some coefficient of the trial differs from the previously evaluated point
   unsigned pad[10];
   double vec[2][TEAM_VEC][TEAM_MAX_BLOCKS];   // [phase][value][workgroup]
+  unsigned xcc[TEAM_MAX_BLOCKS];              // HW_REG_XCC_ID of every workgroup of the team, published once per launch (1 + id)
 };
 
 // LDS of one workgroup of a team.
@@ -73,6 +74,7 @@ struct Team {
   TeamLds<NW>* L;
   unsigned epoch;
   int phase;
+  bool one_xcd;           // every workgroup of the team reported the same XCD (measured at the start of the launch, team_placement)
 
   __device__ __forceinline__ void block_sync() const { __syncthreads(); }
 
@@ -84,8 +86,14 @@ struct Team {
     __syncthreads();
     ++epoch;
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // The release writes the XCD's dirty L2 lines back so that another XCD can see them (1.7 - 6.5 us, MI355X_MICROARCH.md).
+      // A team whose workgroups all sit on ONE XCD shares one L2: its stores are there once acknowledged (the vmcnt(0) above;
+      // the vector L1 writes through), and the acquire below drops this CU's stale L1 lines — no write-back needed. Which case
+      // applies is measured, not assumed (team_placement): a different placement changes the speed, never the result.
+      if (!one_xcd) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __hip_atomic_fetch_add(&gs->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned target = epoch * nblocks;
       unsigned spins = 0;
@@ -109,6 +117,20 @@ struct Team {
   __device__ __forceinline__ void sync() {
     if (nblocks > 1) device_barrier();
     else __syncthreads();
+  }
+  // Once per launch (teams are fixed for the launch): every workgroup publishes the XCD it runs on, one full barrier, then
+  // everybody reads the team's list. HIP promises nothing about placement (block b is observed on XCD b % 8, so teams of a
+  // launch with a multiple of 8 teams sit on one XCD each): the fast barrier is used only where the measurement says so.
+  __device__ __forceinline__ void team_placement() {
+    one_xcd = false;
+    if (nblocks <= 1) return;
+    const unsigned mine = 1u + ((unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u);   // HW_REG_XCC_ID, bits [3:0]
+    if (threadIdx.x == 0) __hip_atomic_store(&gs->xcc[bid], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    device_barrier();
+    bool same = true;
+    for (unsigned b = threadIdx.x; b < nblocks; b += blockDim.x)
+      same = same && __hip_atomic_load(&gs->xcc[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine;
+    one_xcd = __syncthreads_and(same ? 1 : 0) != 0;
   }
   // "The trial point just formed differs from the previously evaluated point": set by any wavefront that moved a coefficient
   // during update number u (slot u & 1), read by everybody after the evaluation of that trial, cleared for its next use at the

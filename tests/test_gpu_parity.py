@@ -229,6 +229,37 @@ def test_side_stream_does_not_change_results(device_solver, monkeypatch):
         assert np.array_equal(a[k], r[k]), k
 
 
+def test_team_lds_vectors_do_not_change_results(device_solver, monkeypatch):
+    """The one-workgroup team kernel keeps x, g, d (and x_old, g_old where they fit) and the residuals of an entity in the LDS
+    its workgroup leaves free (csrc/re_solve.hip: team_vec_level) instead of the global scratch slot. Same arithmetic in the
+    same order: with the arena cut to 0 KB (everything in the slot), to 24 KB (x, g, d of the small ones only) and at its full
+    size the bits are the same — entities of p from a few dozen to ~9 000, SIMPLE variances, a warm start."""
+    from gdmix_amd.batch import concat
+    b = concat([synthetic.make_batch(60, 40, 8, 65536, seed=71, size_dist="zipf"), synthetic.make_batch(6, 600, 8, 65536, seed=72, size_dist="const"),
+                synthetic.make_batch(3, 1200, 8, 65536, seed=73, size_dist="const"), synthetic.make_batch(40, 12, 4, 256, seed=74)])
+    kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12, variance_mode=1)
+    device_solver.set_wave_lds_limit(0)       # every entity through the one-workgroup team kernel
+    try:
+        packed = device_solver.pack(b)
+        p = np.diff(packed.coef_ptr_host())
+        assert p.min() < 200 and 3200 < np.sort(p)[-9] < 5200 and p.max() > 8000      # all three placements occur at the full arena
+        theta0 = np.random.default_rng(5).normal(0, 0.05, packed.P)
+        runs = {}
+        for kb in ("full", "24", "0"):
+            if kb == "full":
+                monkeypatch.delenv("GDMIX_TEAM_ARENA_KB", raising=False)
+            else:
+                monkeypatch.setenv("GDMIX_TEAM_ARENA_KB", kb)
+            runs[kb] = (device_solver.solve(packed, SolverOptions(**kw)).to_host(), device_solver.solve(packed, SolverOptions(**kw), theta0=theta0).to_host())
+    finally:
+        device_solver.set_wave_lds_limit(65536)
+    for kb in ("24", "0"):
+        for cold_warm in (0, 1):
+            for k in ("theta", "theta_thr", "variance", "fval", "gnorm", "nit", "nfev", "status"):
+                assert np.array_equal(runs["full"][cold_warm][k], runs[kb][cold_warm][k]), (kb, cold_warm, k)
+    assert runs["full"][0]["nit"].max() > 5 and np.all(runs["full"][0]["status"] <= 2)
+
+
 def test_results_are_bitwise_reproducible(device_solver):
     b = synthetic.make_batch(2000, 16, 4, 1024, seed=5)
     packed = device_solver.pack(b)
