@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--tall-min-n", type=int, default=-1, help="override the tall kernel's sample threshold (exploration)")
     ap.add_argument("--kernel-mask", type=int, default=-1, help="gdmix_re_set_kernel_mask (exploration)")
     ap.add_argument("--tall-split-n", type=int, default=-1, help="override the tall kernel's one-CU-per-entity threshold (exploration)")
+    ap.add_argument("--lbfgs-m", type=int, default=10, help="history pairs (exploration: what the direction step costs; the shipped config has 10)")
     ap.add_argument("--solve-only", action="store_true", help="time gdmix_re_solve alone (batch packed once)")
     ap.add_argument("--ranks-share-device", action="store_true",
                     help="test hook for a 1-GPU box: every rank uses cuda:0 and the collectives go over gloo (numbers are meaningless)")
@@ -545,7 +546,7 @@ def main():
         dist.barrier()
     from gdmix_amd.solver import NUM_CLASSES, REDeviceSolver, SolverOptions
 
-    opts_kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
+    opts_kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=a.lbfgs_m, max_iter=100, ftol=1e-12)
     opts = SolverOptions(**opts_kw)
     solver = REDeviceSolver(local_rank)
     if a.scaling == "strong":
