@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-fe", action="store_true", help="skip the fixed-effect evaluation leg (detail.fixed_effect_eval)")
     ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end leg through the CLI (detail.cli_end_to_end)")
     ap.add_argument("--cli-entities", type=int, default=1_000_000, help="entities of the end-to-end leg (partitions of 125 k)")
+    ap.add_argument("--cli-c5-entities", type=int, default=200_000, help="entities of the C5-shaped end-to-end leg (detail.cli_end_to_end_c5)")
     ap.add_argument("--fe-rows", type=int, default=4_000_000, help="samples of the fixed-effect leg's shard (x 32 non-zeros, 100k features)")
     ap.add_argument("--giant-nnz", type=int, default=-1, help="override the device-wide kernel threshold (exploration)")
     ap.add_argument("--team-nnz", type=int, default=-1, help="override the lowest team-tier threshold (exploration)")
@@ -349,6 +350,79 @@ def cli_end_to_end_leg(entities):
                     "model), then a warm start from its model files"}, sub
 
 
+def cli_shape_leg(kind, entities):
+    """The drop-in CLI on partition directories of BASELINE's other shapes: kind = "c5" — Zipf-sized entities
+    (SURVEY 8(d) sizes, up to 2^20 non-zeros, D = 65 536) — or "ml20m_movie" — the MovieLens-20M per-movie population (head of
+    54 k samples). Entities are hashed into 8 partitions (Java hash, as DataPartitioner does), written as entity-grouped TFRecords,
+    trained in this process (second pass timed: context and libraries up), model + score Avro out, phases timed by wrapping the
+    model's own methods (summed thread time of each: reads ahead and writes behind overlap the device work)."""
+    import logging
+    import shutil
+    import tempfile
+    from gdmix_amd import gdmix as cli
+    from gdmix_amd import model as model_mod
+    from gdmix_amd import synthetic
+    from gdmix_amd.partition_dirs import write_partition_dir
+    logging.getLogger("gdmix_amd").setLevel(logging.WARNING)
+    t0 = time.perf_counter()
+    if kind == "c5":
+        b = synthetic.make_survey_batch(entities, 32, 8, 65536, seed=synthetic.C5_SEED, size_dist="c5zipf", with_uid=True)
+        dim = 65536
+    else:
+        import bench_strong
+        b = bench_strong.ml20m_population("per_movie", None)
+        if b.uid is None:
+            b.uid = np.arange(b.N, dtype=np.int64)
+        dim = 24
+    t_gen = time.perf_counter() - t0
+    phases = {}
+    M = model_mod.RandomEffectLRLBFGSModel
+    saved = []
+
+    def timed(owner, name, label):
+        fn = getattr(owner, name)
+        saved.append((owner, name, fn))
+
+        def wrapper(*a, **k):
+            t = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                phases[label] = phases.get(label, 0.0) + time.perf_counter() - t
+        setattr(owner, name, wrapper)
+    with tempfile.TemporaryDirectory() as d:
+        t = time.perf_counter()
+        argv, members, size_in = write_partition_dir(d, b, 8, dim)
+        t_write = time.perf_counter() - t
+        os.environ.pop("TF_CONFIG", None)
+        try:
+            timed(M, "_read", "read_tfrecord_s")
+            timed(M, "_solve_batch", "upload_pack_solve_readback_s")
+            timed(M, "_save_model", "model_avro_s")
+            timed(model_mod, "_write_scores", "score_avro_s")
+            times = []
+            for rep in range(2):
+                phases.clear()
+                if rep:
+                    shutil.rmtree(os.path.join(d, "models"))
+                    shutil.rmtree(os.path.join(d, "ts"), ignore_errors=True)
+                t = time.perf_counter()
+                cli.run(argv)
+                times.append(time.perf_counter() - t)
+        finally:
+            for owner, name, fn in saved:
+                setattr(owner, name, fn)
+        size_out = sum(os.path.getsize(os.path.join(r, x)) for r, _, fs in os.walk(d) for x in fs if x.endswith(".avro"))
+    z = b.ent_nnz()
+    dom = max(phases, key=phases.get) if phases else None
+    return {"shape": kind, "entities": int(b.E), "samples": int(b.N), "nnz": int(b.Z), "largest_entity_nnz": int(z.max()), "partitions": len(members),
+            "tfrecord_bytes_in": size_in, "avro_bytes_out": size_out, "cold_s": times[1], "entities_per_s": b.E / times[1],
+            "first_run_s": times[0], "phases_thread_s": {k: round(v, 4) for k, v in phases.items()}, "dominant_phase": dom,
+            "generate_s": round(t_gen, 2), "write_tfrecord_s": round(t_write, 2),
+            "what": "python -m gdmix_amd.gdmix --stage=random_effect --action=train (in process, second run) on 8 Java-hashed partitions of this "
+                    "shape: TFRecord decode, upload, pack, solve, scoring of the training data, model + score Avro"}
+
+
 class Workload:
     """What a step runs on: a raw batch in HBM (`raw_dev`, the dict REDeviceSolver.pack takes) plus the per-entity host arrays
     the accounting needs (samples, non-zeros, label sums) and a way to get some entities as a host RawBatch (CPU leg)."""
@@ -623,6 +697,42 @@ def main():
     else:
         converged_all = converged
     value = converged_all * a.steps / dt
+    # ---- the single-GPU legs next to the headline, BEFORE the large workloads: measured after them (BENCH_r03) the hand-over ran at
+    # 58 M entities/s instead of 77 M — the 125 GB of the C5 share churn the allocator's blocks and the page-locked staging
+    # (profiles/r04_host_path.txt: the same leg alone, with and without round 3's side stream)
+    p_host = int(packed.P)
+    th_host = out["theta_thr"]
+    c2_legs = a.workload == "c2" and world == 1
+    # host hand-over (SURVEY.md §8(d) metric (ii)): packed host batch -> H2D -> solve -> D2H -> thresholded theta on the host
+    e2e = None
+    if c2_legs and not a.no_e2e:
+        e2e = host_handover(batch, opts, local_rank, p_host)
+    # the scoring pass over the same resident batch (the path's HBM-bound stream; not part of `value`)
+    score = None
+    if not a.no_e2e and world == 1:
+        th = th_host
+        for _ in range(2):
+            solver.score(packed, th)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(10):
+            solver.score(packed, th)
+        ev[1].record()
+        torch.cuda.synchronize()
+        sms = ev[0].elapsed_time(ev[1]) / 10
+        sbytes = 8.0 * wl.Z + 16.0 * wl.N + 4.0 * (wl.N + wl.E) + 8.0 * float(packed.P) + 24.0 * wl.E
+        score = {"ms": sms, "samples_per_s": wl.N / (sms * 1e-3), "alg_bytes": sbytes, "GBps": sbytes / (sms * 1e-3) / 1e9,
+                 "frac_of_hbm_peak": sbytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "what": "gdmix_re_score: logits of every sample, 8 B/nnz + 16 B/sample + 8 B/coefficient + pointers"}
+    fe_eval = None
+    if c2_legs and not a.no_fe:
+        fe_eval = fixed_effect_leg(solver, a.fe_rows)
+    cli_e2e = cli_sub = cli_c5 = cli_movie = None
+    if c2_legs and not a.no_cli:
+        cli_e2e, cli_sub = cli_end_to_end_leg(a.cli_entities)
+        if not a.no_other_workloads:
+            cli_c5 = cli_shape_leg("c5", a.cli_c5_entities)
+            cli_movie = cli_shape_leg("ml20m_movie", None)
     others = None
     if a.workload == "c2" and not a.no_other_workloads:
         del res
@@ -726,34 +836,6 @@ def main():
                     "all_solve_kernels": {"ms_per_step": all_ms, "alg_GBps": alg_bytes / (all_ms * 1e-3) / 1e9 if all_ms else 0.0},
                     "note": "LDS/register-resident L-BFGS: bound by fp64 VALU issue and latency, not by HBM "
                             "(SURVEY.md §8d honesty note); see DESIGN.md for the VALU-side accounting"}
-        c2_legs = a.workload == "c2" and world == 1
-        # host hand-over (SURVEY.md §8(d) metric (ii)): packed host batch -> H2D -> solve -> D2H -> thresholded theta on the host
-        e2e = None
-        if c2_legs and not a.no_e2e:
-            e2e = host_handover(batch, opts, local_rank, int(packed.P))
-        # the scoring pass over the same resident batch (the path's HBM-bound stream; not part of `value`)
-        score = None
-        if not a.no_e2e and world == 1:
-            th = out["theta_thr"]
-            for _ in range(2):
-                solver.score(packed, th)
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            ev[0].record()
-            for _ in range(10):
-                solver.score(packed, th)
-            ev[1].record()
-            torch.cuda.synchronize()
-            sms = ev[0].elapsed_time(ev[1]) / 10
-            sbytes = 8.0 * wl.Z + 16.0 * wl.N + 4.0 * (wl.N + wl.E) + 8.0 * float(packed.P) + 24.0 * wl.E
-            score = {"ms": sms, "samples_per_s": wl.N / (sms * 1e-3), "alg_bytes": sbytes, "GBps": sbytes / (sms * 1e-3) / 1e9,
-                     "frac_of_hbm_peak": sbytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "what": "gdmix_re_score: logits of every sample, 8 B/nnz + 16 B/sample + 8 B/coefficient + pointers"}
-        fe_eval = None
-        if c2_legs and not a.no_fe:
-            fe_eval = fixed_effect_leg(solver, a.fe_rows)
-        cli_e2e = cli_sub = None
-        if c2_legs and not a.no_cli:
-            cli_e2e, cli_sub = cli_end_to_end_leg(a.cli_entities)
         cpu = None
         if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             # a bounded sample: about 13 M non-zeros per pass (200 k entities of C2)
@@ -780,7 +862,7 @@ def main():
                        "mean_nit": nit, "mean_nfev": nfev,
                        "converged_per_step": converged_all, "parity_classes": {"W": well_posed, "D": int(wl.E - well_posed)}, "N": wl.N, "Z": wl.Z, "P": packed.P,
                        "host_generate_s": t_gen, "host_handover": e2e, "score_pass": score, "fixed_effect_eval": fe_eval, "cli_end_to_end": cli_e2e,
-                       "cli_subprocess": cli_sub, "workloads": others,
+                       "cli_subprocess": cli_sub, "cli_end_to_end_c5": cli_c5, "cli_end_to_end_ml20m_movie": cli_movie, "workloads": others,
                        "restreamed_bytes_per_step": b_stream,
                        "restreamed_GBps": b_stream / (float(kernel_ms.sum()) / a.steps * 1e-3) / 1e9 if kernel_ms.sum() else None},
         }

@@ -230,7 +230,10 @@ def projection_leg(name, ranks, solver, opts, c5_entities, steps=2, warmup=1, ml
         cls = _entity_classes(packed, torch)
         totals += CostModel.totals(cls, share.z, class_ms, NUM_CLASSES)
         kept.append((cls, share.z, share.n))
-        per.append({"rank": r, "entities": share.E, "samples": share.N, "nnz": share.Z, "ms_per_step": own_s / steps * 1e3,
+        names = [n for n, _ in solver.class_counts(packed)]
+        cnts = np.bincount(cls, minlength=NUM_CLASSES)
+        top = sorted(((float(class_ms[c]), names[c], int(cnts[c])) for c in range(NUM_CLASSES) if class_ms[c] > 0), reverse=True)[:5]
+        per.append({"rank": r, "largest_launches": [{"kernel": k, "entities": e, "ms": round(ms, 3)} for ms, k, e in top], "entities": share.E, "samples": share.N, "nnz": share.Z, "ms_per_step": own_s / steps * 1e3,
                     "pack_ms": share.pack_ms, "solve_kernel_ms": float(class_ms.sum()), "converged": _converged(res),
                     "largest_nnz": int(share.z.max()) if share.E else 0,
                     "generate_s": round(share.gen_s, 2)})

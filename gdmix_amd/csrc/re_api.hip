@@ -444,6 +444,18 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   hipStream_t const s_main = s;
   // the side stream starts where the caller's stream stands now (the class lists are ready), not where it stands when the first
   // small class comes up in the loop: that one may be the last
+  // Once the side stream has forked, EVERY way out of this function joins it back into the caller's stream (an error
+  // between fork and join used to return with side-stream kernels still running on buffers the caller may then free or reuse).
+  struct SideJoin {
+    gdmix_ctx_impl* ci; hipStream_t main; bool active = false;
+    void join() {
+      if (!active) return;
+      active = false;
+      if (hipEventRecord(ci->side_join, ci->side) != hipSuccess || hipStreamWaitEvent(main, ci->side_join, 0) != hipSuccess)
+        (void)hipStreamSynchronize(ci->side);   // last resort: the caller's stream must not run ahead of the side stream
+    }
+    ~SideJoin() { join(); }
+  } side_join{&ctx->impl, s_main};
   bool forked = false;
   if (ctx->impl.side && n_launch_classes > 1) {
     for (int c = 0; c < BLOCK_CLASS && !forked; ++c) {
@@ -455,6 +467,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     if (forked) {
       HIP_TRY(hipEventRecord(ctx->impl.side_fork, s_main));
       HIP_TRY(hipStreamWaitEvent(ctx->impl.side, ctx->impl.side_fork, 0));
+      side_join.active = true;
     }
   }
   int begin = 0;
@@ -486,10 +499,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     }
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[c], s)); ctx->impl.ev_used[c] = true; }
   }
-  if (forked) {
-    HIP_TRY(hipEventRecord(ctx->impl.side_join, ctx->impl.side));
-    HIP_TRY(hipStreamWaitEvent(s_main, ctx->impl.side_join, 0));
-  }
+  side_join.join();   // before the team kernels (they use the whole device and the scratch slots)
   if (hc[BLOCK_CLASS] > 0 || hc[TEAM128_CLASS] > 0 || hc[TEAM32_CLASS] > 0 || hc[TEAM8_CLASS] > 0 || hc[GIANT_CLASS] > 0) {
     double* const scratch = slot_scratch;
     if (hc[BLOCK_CLASS] > 0) {

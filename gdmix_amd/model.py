@@ -749,8 +749,17 @@ class RandomEffectLRLBFGSModel:
                            weights if has_weight else None, per_coord)
         logger.info(f"Inference complete: {input_path}.")
 
+    def _encoded_features(self, feature_file):
+        """(feature list, its Avro-encoded form) of a feature file, read and encoded once per model object."""
+        cache = self.__dict__.setdefault("_feature_cache", {})
+        if feature_file not in cache:
+            fl = read_feature_list(feature_file)
+            enc = [avro.enc_string(n) + avro.enc_string(t) for (n, t) in fl]
+            cache[feature_file] = (fl, native_reader.EncodedFeatures(enc) if native_reader.available() else enc)
+        return cache[feature_file]
+
     def _save_model(self, output_file, model_coefficients, num_features, feature_file):
-        feature_list = read_feature_list(feature_file) if feature_file else None
+        feature_list = self._encoded_features(feature_file) if feature_file else None
         if feature_file is None:
             assert num_features == 1   # intercept only model
         with_variance = self.model_params.random_effect_variance_mode is not None
@@ -803,7 +812,7 @@ class RandomEffectLRLBFGSModel:
         schema, codec, sync, data_offset = avro.read_header(model_file)
         if codec not in ("null", "deflate") or not avro.is_model_schema(schema):
             return False
-        prefix = [avro.enc_string(n) + avro.enc_string(t) for (n, t) in read_feature_list(self.feature_file)]
+        prefix = self._encoded_features(self.feature_file)[1]
         icpt = avro.enc_string(constants.INTERCEPT) + avro.enc_string("")
         m = native_reader.read_models_avro(model_file, data_offset, sync, codec == "deflate", prefix, icpt, self.has_intercept)
         if m["ids"]:
@@ -853,7 +862,9 @@ def _export_models_to_avro(output_file, table, feature_list, has_intercept, with
     loss = avro.enc_long(1) + avro.enc_string("")                      # lossFunction = "" (not null)
     icpt = avro.enc_string(constants.INTERCEPT) + avro.enc_string("")
     prefix = None
-    if feature_list is not None:
+    if isinstance(feature_list, tuple) and len(feature_list) == 2 and not isinstance(feature_list[0], tuple):
+        feature_list, prefix = feature_list        # (list, encoded form) from RandomEffectLRLBFGSModel._encoded_features
+    elif feature_list is not None:
         prefix = [avro.enc_string(n) + avro.enc_string(t) for (n, t) in feature_list]
     if native is None:
         native = native_reader.available() and isinstance(table, ModelTable)

@@ -32,6 +32,10 @@ def _entity_sizes(rng, E, shape, mean_n):
         return np.full(E, int(mean_n), np.int64)
     if shape == "geometric":
         return rng.geometric(1.0 / mean_n, size=E).astype(np.int64)
+    if shape == "c5zipf":
+        # SURVEY.md §8(d)'s C5 sizes to the letter (c5_entity_samples below): P(nnz >= x) ~ x^-1.2 on [k, 2^20], mean rescaled; the
+        # caller's mean_n is the mean number of samples (mean nnz / k with k = 8)
+        return c5_entity_samples(rng, E, mean_nnz=8 * mean_n, k=8)
     if shape == "zipf":
         # P(n >= x) ~ x^-1.2 truncated, rescaled to the requested mean
         u = rng.random(E)

@@ -94,3 +94,81 @@ def test_cli_train_then_inference_on_partitioned_c2_data(tmp_path):
     for k in parts:
         again = list(avro.read_file(str(tmp_path / "vs2" / f"partitionId={k}" / f"part-{k:05d}.avro")))
         assert again == valid_scores[k]
+
+
+def _means_by_feature(rec):
+    """modelId, {global feature index: value} (intercept under -1) of one BayesianLinearModelAvro record."""
+    out = {}
+    for c in rec["means"]:
+        out[-1 if c["name"] == "(INTERCEPT)" else int(c["name"][1:])] = c["value"]
+    return out
+
+
+@pytest.mark.parametrize("shape", ["c5", "ml20m_movie"])
+def test_cli_process_on_zipf_and_movielens_shaped_partition_directories(tmp_path, shape):
+    """The real pipeline of BASELINE configs[2] and [4] at reduced size: a partition directory whose entities were hashed into
+    partitions the reference's way (io/input_data_pipeline.py:223-332 reads it, util/io_utils.py:163-212 is the model file) —
+    C5: Zipf sizes of SURVEY 8(d) plus one entity above 2^17 non-zeros (team tiers); MovieLens-20M per-movie: tall and skinny,
+    a third of the entities with one rating — trained by a real `python -m gdmix_amd.gdmix` child process. A sample stratified by
+    entity size is compared with the oracle: every model present once, thresholded zero pattern and coefficients."""
+    import subprocess
+    import sys
+    from gdmix_amd import synthetic
+    from gdmix_amd.batch import concat
+    from gdmix_amd.partition_dirs import write_partition_dir
+    from helpers import oracle_solve_parallel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shape == "c5":
+        b = concat([synthetic.make_survey_batch(6000, 32, 8, 65536, seed=41, size_dist="c5zipf", with_uid=True),
+                    synthetic.make_survey_batch(1, 17000, 8, 65536, seed=42, size_dist="const", entity_id_base=900_000, with_uid=True)])
+        b.uid = np.arange(b.N, dtype=np.int64)
+        dim = 65536
+        assert b.ent_nnz().max() >= (1 << 17)
+    else:
+        b = synthetic.make_movielens_20m("per_movie", seed=43, entities=2500, with_uid=True)
+        dim = 24
+        assert b.ent_n().max() > 4096 and (b.ent_n() == 1).sum() > 100
+    argv, members, _ = write_partition_dir(str(tmp_path), b, 4, dim)
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("TF_CONFIG", None)
+    r = subprocess.run([sys.executable, "-m", "gdmix_amd.gdmix"] + argv[1:], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    models = {}
+    for k, own in members.items():
+        recs = list(avro.read_file(str(tmp_path / "models" / f"part-{k:05d}.avro")))
+        assert [rec["modelId"] for rec in recs] == [b.entity_ids[e] for e in own]       # file order = partition order, every entity once
+        for e, rec in zip(own, recs):
+            models[int(e)] = rec
+    assert len(models) == b.E
+    scores = sum(len(list(avro.read_file(str(tmp_path / "ts" / f"partitionId={k}" / "part-00000-active.avro")))) for k in members)
+    assert scores == b.N
+    # the sample: the largest entities, the smallest, and a random draw of the rest
+    nnz = b.ent_nnz()
+    order = np.argsort(-nnz, kind="stable")
+    rng = np.random.default_rng(7)
+    sample = np.unique(np.concatenate([order[:6], order[-20:], rng.choice(b.E, 150, replace=False)]))
+    sub = b.select(sample)
+    kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
+    pk, ref = oracle_solve_parallel(sub, kw)
+    y1 = np.add.reduceat(sub.y.astype(np.float64), sub.ent_row_ptr[:-1])
+    wp = (y1 > 0) & (y1 < sub.ent_n())
+    cp = pk["ent_feat_ptr"] + np.arange(sub.E + 1)
+    worst, compared = 0.0, 0
+    for i, e in enumerate(sample):
+        got = _means_by_feature(models[int(e)])
+        want = ref["theta_thr"][cp[i]:cp[i + 1]]
+        feats = pk["unique_global"][pk["ent_feat_ptr"][i]:pk["ent_feat_ptr"][i + 1]]
+        assert -1 in got                                                                   # the intercept is always written (io_utils.py:118)
+        if not wp[i]:
+            # class D (all labels equal, unregularised intercept): no finite optimum; every other coefficient is thresholded away
+            assert set(got) == {-1} and np.sign(got[-1]) == (1.0 if y1[i] > 0 else -1.0)
+            continue
+        live = {int(f): v for f, v in zip(feats, want[1:]) if abs(v) > 1e-4}
+        # a coefficient within rounding of the threshold may fall on either side
+        edge = {int(f) for f, v in zip(feats, want[1:]) if abs(abs(v) - 1e-4) < 1e-9}
+        assert (set(got) - {-1}) ^ set(live) <= edge, (int(e), sorted((set(got) - {-1}) ^ set(live))[:5])
+        scale = max(np.max(np.abs(want)), 1e-300)
+        err = max([abs(got[-1] - want[0])] + [abs(got[f] - v) for f, v in live.items() if f in got]) / scale
+        worst = max(worst, err)
+        compared += 1
+    assert compared >= 100 and worst <= 1e-5, (compared, worst)      # north_star: coefficients within 1e-5 rel-err of the reference L-BFGS
