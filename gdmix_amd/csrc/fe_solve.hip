@@ -1038,6 +1038,36 @@ GDMIX_API int gdmix_fe_hessian_diag(gdmix_fe_problem* p, const double* theta, vo
   return fe_passes<true>(p, F, static_cast<hipStream_t>(stream), false);
 }
 
+GDMIX_API size_t gdmix_fe_hessian_dense_scratch_bytes(const gdmix_re_packed* shard) {
+  return shard ? hessian_dense_scratch_doubles(shard->N) * 8 : 0;
+}
+
+GDMIX_API int gdmix_fe_hessian_dense(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int has_intercept, const double* theta_local, double* H,
+                                     int64_t ld, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!ctx || !b || !theta_local || !H || !scratch) { set_error("NULL argument"); return GDMIX_RE_EINVAL; }
+  if (b->E != 1) { set_error("gdmix_fe_hessian_dense takes a one-entity batch (a worker's shard)"); return GDMIX_RE_EINVAL; }
+  const int ic = has_intercept ? 1 : 0;
+  if (b->D + ic > VAR_FULL_BIG_MAX_P) { set_error("dense Hessian of %lld coefficients: at most %lld", (long long)(b->D + ic), (long long)VAR_FULL_BIG_MAX_P); return GDMIX_RE_ERANGE; }
+  if (ld < b->D + ic || ld % 64) { set_error("ld must be d + has_intercept rounded up to a multiple of 64"); return GDMIX_RE_EINVAL; }
+  if (scratch_bytes < hessian_dense_scratch_doubles(b->N) * 8) { set_error("scratch too small"); return GDMIX_RE_ENOMEM; }
+  HIP_TRY(hipSetDevice(ctx->impl.device));
+  BatchDev B;
+  B.ent_row_ptr = b->ent_row_ptr; B.ent_nnz_ptr = b->ent_nnz_ptr; B.ent_feat_ptr = b->ent_feat_ptr; B.row_ptr = b->row_ptr; B.csr_col = b->csr_col;
+  B.csr_val = b->csr_val; B.col_ptr = b->col_ptr; B.csc_row = b->csc_row; B.csc_val = b->csc_val; B.y = b->y; B.offset = b->offset; B.weight = b->weight;
+  B.order = b->order;
+  HIP_TRY(launch_hessian_dense(&ctx->impl, B, b->N, b->D, ic, theta_local, H, ld, static_cast<double*>(scratch), static_cast<hipStream_t>(stream)));
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_fe_variance_of_hessian(gdmix_re_ctx* ctx, double* H, int64_t p, int64_t ld, double l2, int64_t unregularised_index,
+                                           double* work, double* variance, void* stream) {
+  if (!ctx || !H || !work || !variance) { set_error("NULL argument"); return GDMIX_RE_EINVAL; }
+  if (p < 1 || p > VAR_FULL_BIG_MAX_P || ld < p || ld % 64) { set_error("bad matrix dimensions (p = %lld, ld = %lld)", (long long)p, (long long)ld); return GDMIX_RE_EINVAL; }
+  HIP_TRY(hipSetDevice(ctx->impl.device));
+  HIP_TRY(launch_variance_of_hessian(&ctx->impl, H, work, p, ld, l2, unregularised_index, variance, static_cast<hipStream_t>(stream)));
+  return GDMIX_RE_OK;
+}
+
 GDMIX_API int gdmix_fe_step(gdmix_fe_problem* p, void* stream, int32_t* status) {
   if (!p || !status) { set_error("NULL argument"); return GDMIX_RE_EINVAL; }
   hipStream_t s = static_cast<hipStream_t>(stream);

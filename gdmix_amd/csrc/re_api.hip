@@ -50,13 +50,6 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_G256_3, 1, "re_solve_grp_kernel<256,3> n<=256 nnz<=2048", 256, 2048}, {KIND_G256_3, 1, "re_solve_grp_kernel<256,3> n<=2048 nnz<=4096", 2048, 4096},
     {KIND_G256_4, 1, "re_solve_grp_kernel<256,4> n<=256 nnz<=2048", 256, 2048}, {KIND_G256_4, 1, "re_solve_grp_kernel<256,4> n<=2048 nnz<=4096", 2048, 4096},
     {KIND_G512_4, 1, "re_solve_grp_kernel<512,4> n<=512 nnz<=4096", 512, 4096},
-    {KIND_WREG1, 3072, "re_solve_wreg_kernel<1> lds<=3K"},   {KIND_WREG1, 65536, "re_solve_wreg_kernel<1> lds<=64K"},
-    {KIND_WREG2, 3072, "re_solve_wreg_kernel<2> lds<=3K"},   {KIND_WREG2, 6144, "re_solve_wreg_kernel<2> lds<=6K"},
-    {KIND_WREG2, 16384, "re_solve_wreg_kernel<2> lds<=16K"}, {KIND_WREG2, 65536, "re_solve_wreg_kernel<2> lds<=64K"},
-    {KIND_WREG4, 6144, "re_solve_wreg_kernel<4> lds<=6K"},   {KIND_WREG4, 12288, "re_solve_wreg_kernel<4> lds<=12K"},
-    {KIND_WREG4, 24576, "re_solve_wreg_kernel<4> lds<=24K"}, {KIND_WREG4, 65536, "re_solve_wreg_kernel<4> lds<=64K"},
-    {KIND_WREG8, 12288, "re_solve_wreg_kernel<8> lds<=12K"}, {KIND_WREG8, 24576, "re_solve_wreg_kernel<8> lds<=24K"},
-    {KIND_WREG8, 65536, "re_solve_wreg_kernel<8> lds<=64K"},
     {KIND_WLDS, 24576, "re_solve_wave_kernel lds<=24K"},     {KIND_WLDS, 65536, "re_solve_wave_kernel lds<=64K"},
     {KIND_TALL_L, 0, "re_solve_tall_kernel<1> lean p<=64"},
     {KIND_TALL_S, 0, "re_solve_tall_kernel<1> p<=64"},
@@ -372,9 +365,8 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     int lds = kClasses[c].lds;
     const int gl = group_lanes(kClasses[c].kind);
     if (lds > 0 && gl > 0)
-      lds = (gl >= WAVE ? 1 : WAVE / gl) * quad_layout(gl * group_epl(kClasses[c].kind), kClasses[c].ncap, kClasses[c].zcap, gl > WAVE ? gl / WAVE : 1, quad_nold(gl, group_epl(kClasses[c].kind))).bytes;
+      lds = (gl >= WAVE ? 1 : WAVE / gl) * quad_layout(gl * group_epl(kClasses[c].kind), kClasses[c].ncap, kClasses[c].zcap, gl > WAVE ? gl / WAVE : 1).bytes;
     bool on = lds > 0 && (lds <= ctx->impl.wave_lds_limit || (gl > WAVE && ctx->impl.wave_lds_limit >= 65536 && lds <= 160 * 1024));
-    if ((kClasses[c].kind <= KIND_WREG4 || kClasses[c].kind == KIND_WREG8) && !(ctx->impl.kernel_mask & 1)) on = false;
     if (gl > 0 && !(ctx->impl.kernel_mask & 4)) on = false;
     if (kClasses[c].kind == KIND_WLDS && !(ctx->impl.kernel_mask & 2)) on = false;
     tab.lds_bytes[c] = on ? lds : 0;
@@ -488,10 +480,6 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
         HIP_TRY(launch_solve_quad(group_lanes(kClasses[c].kind), group_epl(kClasses[c].kind), B, O, P, theta0, b0, cnt,
                                   kClasses[c].ncap, kClasses[c].zcap, s));
         break;
-      case KIND_WREG1: HIP_TRY(launch_solve_wreg(1, B, O, P, theta0, b0, cnt, kClasses[c].lds, s)); break;
-      case KIND_WREG2: HIP_TRY(launch_solve_wreg(2, B, O, P, theta0, b0, cnt, kClasses[c].lds, s)); break;
-      case KIND_WREG4: HIP_TRY(launch_solve_wreg(4, B, O, P, theta0, b0, cnt, kClasses[c].lds, s)); break;
-      case KIND_WREG8: HIP_TRY(launch_solve_wreg(8, B, O, P, theta0, b0, cnt, kClasses[c].lds, s)); break;
       case KIND_TALL_L: HIP_TRY(launch_solve_tall(TALL_VARIANT_LEAN, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_LEAN * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_LEAN, s)); break;
       case KIND_TALL_S: HIP_TRY(launch_solve_tall(TALL_VARIANT_SMALL, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_SMALL * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_SMALL, s)); break;
       case KIND_TALL: HIP_TRY(launch_solve_tall(TALL_VARIANT_LARGE, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_LARGE * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_LARGE, s)); break;

@@ -16,7 +16,8 @@ namespace gdmix {
 //   KIND_PAIR3/4    two entities per wavefront (one per pair of DPP rows), p <= 96/128
 //   KIND_G64_3/4    one entity per wavefront, same register/LDS design, p <= 192/256
 //   KIND_G128..512  one entity per workgroup of 2/4/8 wavefronts (cross-wave reduction stage), p <= 512/1024/2048
-//   KIND_WREG1/2/4  register-resident wavefront kernel with 1/2/4 coefficients per lane (p <= 64/128/256)
+//   (KIND_WREG1/2/4/8: the register-resident one-entity-per-wavefront kernels of round 1; superseded by the group kernels, unreachable
+//    under default routing since round 2 and removed in round 4 — the ids stay reserved)
 //   KIND_WLDS       LDS-resident wavefront kernel (any p whose state fits 64 KiB of LDS, any m)
 //   KIND_BLOCK      workgroup-per-entity kernel working out of a global scratch slot (anything)
 //   KIND_TALL       workgroup-per-entity kernel for tall and skinny entities (p <= 64, n >= tall_min_n): samples over all
@@ -114,7 +115,7 @@ struct gdmix_ctx_impl {
   size_t scratch_bytes;
   int32_t* host_pinned;   // small pinned buffer for count read-backs
   int wave_lds_limit;     // entities above this LDS footprint use the block kernel
-  int kernel_mask;        // bit0 register wave kernel, bit1 LDS wave kernel, bit2 quad kernel
+  int kernel_mask;        // bit1 LDS wave kernel, bit2 group kernels (bit0: the removed register wave kernel, ignored)
   int timing;             // bracket class launches with events
   int64_t giant_nnz;      // entities with >= this many non-zeros use the device-wide kernel (0 = never)
   int64_t team_nnz;       // lowest tier of the team kernel (0 = never)
@@ -156,8 +157,6 @@ hipError_t launch_classify(const gdmix_re_packed* b, int ic, int m, const ClassT
                            int32_t* counts_dev, hipStream_t s);
 hipError_t launch_order(const gdmix_re_packed* b, const int32_t* cls_tmp, const int32_t* class_base_dev,
                         int32_t* cursor_dev, hipStream_t s);
-hipError_t launch_solve_wreg(int epl, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
-                             int begin, int count, int lds_bytes, hipStream_t s);
 hipError_t launch_solve_quad(int g, int epl, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
                              int begin, int count, int ncap, int zcap, hipStream_t s);
 hipError_t launch_solve_wave(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
@@ -180,6 +179,11 @@ constexpr int VAR_BIG_BUILD_GROUPS = 128;  // workgroups building the Hessian of
 size_t var_full_big_doubles(int64_t max_p, int64_t max_n);
 hipError_t launch_variance_full_big(gdmix_ctx_impl* ci, const BatchDev& B, int64_t E, const SolveParams& o, const double* theta,
                                     double* variance, double* scratch, int64_t max_p, int64_t max_n, hipStream_t s);
+size_t hessian_dense_scratch_doubles(int64_t n);
+hipError_t launch_hessian_dense(gdmix_ctx_impl* ci, const BatchDev& B, int64_t n, int64_t d, int ic, const double* theta, double* H, int64_t ld,
+                                double* scratch, hipStream_t s);
+hipError_t launch_variance_of_hessian(gdmix_ctx_impl* ci, double* H, double* M, int64_t p, int64_t ld, double l2, int64_t unreg, double* variance,
+                                      hipStream_t s);
 inline size_t var_full_slot_doubles(int64_t max_p) { return (size_t)2 * max_p * max_p + max_p + 8; }
 hipError_t launch_score(const BatchDev& B, int64_t E, int64_t N, int ic, const double* theta, const uint8_t* has_model,
                         float* logit, float* per_coord, hipStream_t s);

@@ -27,10 +27,8 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
     const int d = (int)(ent_feat_ptr[e + 1] - ent_feat_ptr[e]);
     const int p = d + ic;
     int c = BLOCK_CLASS;
-    // cheapest first: register kernel with the fewest coefficient slots that hold p, smallest LDS bucket
-    // register wave kernels: fewest coefficient slots per lane that hold p (1, 2, 4 or 8)
-    const int want_epl = (m <= M_REG) ? (p <= WAVE ? 1 : (p <= 2 * WAVE ? 2 : (p <= 4 * WAVE ? 4 : (p <= 8 * WAVE ? 8 : 0)))) : 0;
-    const size_t wreg_bytes = wreg_lds_bytes(p, n, z, d, has_w);
+    // cheapest first: the group kernel with the fewest lanes and coefficient slots that holds the entity, smallest LDS bucket;
+    // then the LDS-resident wavefront kernel (any m); the one-workgroup team kernel takes what is left
     const size_t wlds_bytes = wave_lds_bytes(p, n, z, d, m, has_w);
     for (int k = 0; k < BLOCK_CLASS; ++k) {
       if (tab.lds_bytes[k] <= 0) continue;
@@ -38,9 +36,6 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
       if (group_lanes(kind) > 0) {
         const int cap = group_lanes(kind) * group_epl(kind);
         if (m <= M_REG && p <= cap && n <= tab.ncap[k] && z <= tab.zcap[k]) { c = k; break; }
-      } else if (kind <= KIND_WREG4 || kind == KIND_WREG8) {
-        const int epl = (kind == KIND_WREG1) ? 1 : (kind == KIND_WREG2 ? 2 : (kind == KIND_WREG4 ? 4 : 8));
-        if (want_epl > 0 && epl >= want_epl && wreg_bytes <= (size_t)tab.lds_bytes[k]) { c = k; break; }
       } else if (kind == KIND_WLDS) {
         if (wlds_bytes <= (size_t)tab.lds_bytes[k]) { c = k; break; }
       }
@@ -139,165 +134,6 @@ __device__ __forceinline__ void write_results(G& grp, const OutDev& O, const Sol
 }
 
 // ---------------------------------------------------------------------------------------------------
-// one wavefront per entity, L-BFGS state in registers (re_solve_wreg.hpp) — the hot kernel
-// ---------------------------------------------------------------------------------------------------
-// Occupancy targets (waves per SIMD) the register allocator must meet: EPL = 1 -> 3 (<= 168 VGPRs),
-// EPL = 2 -> 2 (<= 256), EPL = 4 -> 1.
-#ifndef GDMIX_WREG_WAVES_EPL1
-#define GDMIX_WREG_WAVES_EPL1 4
-#endif
-#ifndef GDMIX_WREG_WAVES_EPL2
-#define GDMIX_WREG_WAVES_EPL2 2
-#endif
-template <int EPL>
-__global__ __launch_bounds__(WAVE)
-__attribute__((amdgpu_waves_per_eu(EPL == 1 ? GDMIX_WREG_WAVES_EPL1 : (EPL == 2 ? GDMIX_WREG_WAVES_EPL2 : 1)))) void re_solve_wreg_kernel(BatchDev B, OutDev O, SolveParams o,
-                                                             const double* __restrict__ theta0, int begin) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = threadIdx.x;
-  const int64_t e = B.order[begin + blockIdx.x];
-  const int ic = o.has_intercept ? 1 : 0;
-  const int64_t r0 = B.ent_row_ptr[e], z0 = B.ent_nnz_ptr[e], f0 = B.ent_feat_ptr[e];
-  const int n = (int)(B.ent_row_ptr[e + 1] - r0);
-  const int nnz = (int)(B.ent_nnz_ptr[e + 1] - z0);
-  const int d = (int)(B.ent_feat_ptr[e + 1] - f0);
-  const int p = d + ic;
-  const int64_t c0 = f0 + e * ic;
-
-  WregLds L;
-  double* dp = reinterpret_cast<double*>(smem);
-  L.rho = dp; dp += M_REG;
-  L.alpha = dp; dp += M_REG;
-  L.ls = reinterpret_cast<LineSearch*>(dp); dp += 16;
-  static_assert(sizeof(LineSearch) <= 16 * sizeof(double), "LineSearch must fit its LDS slot");
-  L.xs = dp; dp += p;
-  L.rs = dp; dp += n;
-  int2* pp = reinterpret_cast<int2*>(dp);
-  L.csr = pp; pp += nnz;
-  L.csc = pp; pp += nnz;
-  int32_t* ip = reinterpret_cast<int32_t*>(pp);
-  L.row_ptr = ip; ip += n + 1;
-  L.col_ptr = ip; ip += d + 1;
-  float* fp = reinterpret_cast<float*>(ip);
-  L.y = fp; fp += n;
-  L.o = fp; fp += n;
-  L.w = nullptr;
-  if (B.weight) { L.w = fp; fp += n; }
-
-  for (int k = lane; k < nnz; k += WAVE) {
-    L.csr[k] = make_int2(B.csr_col[z0 + k], __float_as_int(B.csr_val[z0 + k]));
-    L.csc[k] = make_int2(B.csc_row[z0 + k], __float_as_int(B.csc_val[z0 + k]));
-  }
-  for (int i = lane; i < n; i += WAVE) {
-    L.y[i] = B.y[r0 + i];
-    L.o[i] = B.offset[r0 + i];
-    if (L.w) L.w[i] = B.weight[r0 + i];
-  }
-  for (int i = lane; i <= n; i += WAVE) L.row_ptr[i] = B.row_ptr[r0 + e + i];
-  for (int i = lane; i <= d; i += WAVE) L.col_ptr[i] = B.col_ptr[z0 + e + i];
-
-  WregState<EPL> V;
-#pragma unroll
-  for (int s = 0; s < EPL; ++s) {
-    const int j = lane + WAVE * s;
-    V.x[s] = (theta0 && j < p) ? theta0[c0 + j] : 0.0;
-    V.g[s] = 0.0; V.d[s] = 0.0; V.xo[s] = 0.0; V.go[s] = 0.0;
-  }
-  wave_lds_fence();
-  SolveStats st;
-  wreg_solve<EPL>(L, o, lane, n, p, ic, V, st);
-
-#pragma unroll
-  for (int s = 0; s < EPL; ++s) {
-    const int j = lane + WAVE * s;
-    if (j < p) {
-      const double v = V.x[s];
-      if (O.theta) O.theta[c0 + j] = v;
-      if (O.theta_thr) O.theta_thr[c0 + j] = (fabs(v) <= o.threshold) ? 0.0 : v;
-    }
-  }
-  if (lane == 0) {
-    if (O.fval) O.fval[e] = st.f;
-    if (O.gnorm) O.gnorm[e] = st.gnorm;
-    if (O.nit) O.nit[e] = st.nit;
-    if (O.nfev) O.nfev[e] = st.nfev;
-    if (O.status) O.status[e] = st.status;
-  }
-  if (o.variance_mode == GDMIX_RE_VAR_SIMPLE && O.variance) {
-    // _compute_variance SIMPLE (binary_logistic_regression.py:175-180) with the final theta
-#pragma unroll
-    for (int s = 0; s < EPL; ++s) {
-      const int j = lane + WAVE * s;
-      if (j < p) L.xs[j] = V.x[s];
-    }
-    wave_lds_fence();
-    const double x0 = ic ? L.xs[0] : 0.0;
-    double dpart = 0.0;
-    for (int i = lane; i < n; i += WAVE) {
-      double acc = x0;
-      const int k1 = L.row_ptr[i + 1];
-      for (int k = L.row_ptr[i]; k < k1; ++k) {
-        const int2 cv = L.csr[k];
-        acc += (double)__int_as_float(cv.y) * L.xs[ic + cv.x];
-      }
-      const double z = acc + (double)L.o[i];
-      const double rho = 1.0 / (1.0 + exp(-z));
-      const double di = rho * (1.0 - rho) * (L.w ? (double)L.w[i] : 1.0);
-      L.rs[i] = di;
-      dpart += di;
-    }
-    const double dsum = wave_sum(dpart);
-    wave_lds_fence();
-    const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
-#pragma unroll
-    for (int s = 0; s < EPL; ++s) {
-      const int j = lane + WAVE * s;
-      if (j < p) {
-        double h;
-        if (ic && j == 0) {
-          h = dsum;
-        } else {
-          h = 0.0;
-          const int c = j - ic;
-          const int k1 = L.col_ptr[c + 1];
-          int k = L.col_ptr[c];
-          while (k < k1) {
-            const int row = L.csc[k].x;
-            double v = (double)__int_as_float(L.csc[k].y);
-            ++k;
-            while (k < k1 && L.csc[k].x == row) { v += (double)__int_as_float(L.csc[k].y); ++k; }
-            h += v * v * L.rs[row];
-          }
-        }
-        h += (j < first_reg) ? 0.0 : o.l2;
-        O.variance[c0 + j] = 1.0 / (h + 1.0e-12);
-      }
-    }
-  }
-}
-
-template <int EPL>
-static hipError_t launch_wreg_t(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
-                                int begin, int count, int lds_bytes, hipStream_t s) {
-  static DynLdsOnce lds_attr;
-  if (hipError_t rc = lds_attr.set(reinterpret_cast<const void*>(re_solve_wreg_kernel<EPL>)); rc != hipSuccess) return rc;
-  hipLaunchKernelGGL(re_solve_wreg_kernel<EPL>, dim3(count), dim3(WAVE), (size_t)lds_bytes, s, B, O, o, theta0, begin);
-  return hipGetLastError();
-}
-
-hipError_t launch_solve_wreg(int epl, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
-                             int begin, int count, int lds_bytes, hipStream_t s) {
-  if (count <= 0) return hipSuccess;
-  switch (epl) {
-    case 1: return launch_wreg_t<1>(B, O, o, theta0, begin, count, lds_bytes, s);
-    case 2: return launch_wreg_t<2>(B, O, o, theta0, begin, count, lds_bytes, s);
-    case 4: return launch_wreg_t<4>(B, O, o, theta0, begin, count, lds_bytes, s);
-    case 8: return launch_wreg_t<8>(B, O, o, theta0, begin, count, lds_bytes, s);
-    default: return hipErrorInvalidValue;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // four entities per wavefront, one per 16-lane DPP row (re_solve_quad.hpp)
 // ---------------------------------------------------------------------------------------------------
 // G lanes per entity: G = 16 -> four entities per wavefront ("quad"), G = 32 -> two ("pair").
@@ -333,7 +169,7 @@ __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL >= 3 
   const int64_t c0 = f0 + e * ic;
 
   QuadLds L;
-  L.q = quad_layout(G * EPL, NCAP, ZCAP, NWG, quad_nold(G, EPL));
+  L.q = quad_layout(G * EPL, NCAP, ZCAP, NWG);
   L.base = smem + (size_t)row * L.q.bytes;
   L.hdr = L.base + (NWG > 1 ? (tid >> 6) * QUAD_HDR_BYTES : 0);
   L.has_w = B.weight != nullptr;
@@ -449,7 +285,7 @@ static hipError_t launch_quad_t(const BatchDev& B, const OutDev& O, const SolveP
                                 int begin, int count, hipStream_t s) {
   constexpr int NG = G >= WAVE ? 1 : WAVE / G;
   constexpr int NWG = G > WAVE ? G / WAVE : 1;
-  const int row_lds_bytes = quad_layout(G * EPL, NCAP, ZCAP, NWG, quad_nold(G, EPL)).bytes;
+  const int row_lds_bytes = quad_layout(G * EPL, NCAP, ZCAP, NWG).bytes;
   static DynLdsOnce lds_attr;
   if (hipError_t rc = lds_attr.set(reinterpret_cast<const void*>(re_solve_grp_kernel<G, EPL, NCAP, ZCAP>)); rc != hipSuccess) return rc;
   hipLaunchKernelGGL((re_solve_grp_kernel<G, EPL, NCAP, ZCAP>), dim3((count + NG - 1) / NG), dim3(G > WAVE ? G : WAVE),
@@ -657,13 +493,15 @@ void launch_sort_class(int32_t* list, int count, const int64_t* ent_nnz_ptr, hip
 // g_old where they fit) and the per-sample residuals go there instead of the global scratch slot — a quarter of the reads and
 // three quarters of the writes of the class, and the two gather passes (x by the rows, the residuals by
 // the columns) become LDS gathers. The history stays in HBM. VEC = 0: everything in the slot (entities too large, and every
-// multi-workgroup team: x and the residuals are read by all workgroups); 3: x, g, d + residuals; 5: + x_old, g_old.
+// multi-workgroup team: x and the residuals are read by all workgroups); 1: x + residuals (the two gather targets; p up to
+// ~15 k); 3: x, g, d + residuals (p up to ~4.9 k); 5: + x_old, g_old (p up to ~3 k).
 // Same arithmetic in the same order: results do not depend on the placement (test_block_kernel_*, test_team_lds_vectors_*).
 extern __shared__ __attribute__((aligned(16))) double team_arena[];
 __host__ __device__ inline int team_vec_level(int p, int n, int arena_doubles) {
   const long pp = (p + 1) & ~1, nn = (n + 1) & ~1;
   if (5 * pp + nn <= arena_doubles) return 5;
   if (3 * pp + nn <= arena_doubles) return 3;
+  if (pp + nn <= arena_doubles) return 1;
   return 0;
 }
 
@@ -671,12 +509,11 @@ template <int NW, int VEC>
 __device__ __forceinline__ void team_entity(Team<NW>& tm, const EntityView& P, const SolveParams& o, Work W, const OutDev& O,
                                             const double* __restrict__ theta0, int64_t e, int64_t c0) {
   const int p = P.p;
-  if (VEC >= 3) {
+  if (VEC >= 1) {
     const int pp = (p + 1) & ~1;
     double* a = team_arena;
     W.x = a; a += pp;
-    W.g = a; a += pp;
-    W.d = a; a += pp;
+    if (VEC >= 3) { W.g = a; a += pp; W.d = a; a += pp; }
     if (VEC >= 5) { W.t = a; a += pp; W.r = a; a += pp; }
     W.rs = a;
   }
@@ -757,6 +594,7 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(GDMIX_
     const int vec = GRID ? 0 : team_vec_level(p, n, arena_doubles);   // uniform over the workgroup
     if (!GRID && vec == 5) team_entity<NW, 5>(tm, P, o, W, O, theta0, e, c0);
     else if (!GRID && vec == 3) team_entity<NW, 3>(tm, P, o, W, O, theta0, e, c0);
+    else if (!GRID && vec == 1) team_entity<NW, 1>(tm, P, o, W, O, theta0, e, c0);
     else team_entity<NW, 0>(tm, P, o, W, O, theta0, e, c0);
   }
 }

@@ -251,24 +251,14 @@ __device__ __forceinline__ void grp_fence() {
 // ---- capacity-based LDS layout of one row (entity) ---------------------------------------------------
 // Offsets depend only on (PCAP = 16*EPL, NCAP, ZCAP), i.e. they are wave-uniform.
 struct QuadLayout {
-  int xs, xo, go, rs, csr, csc, row_ptr, col_ptr, y, o, w, hist, bytes;
+  int xs, xo, go, rs, csr, csc, row_ptr, col_ptr, y, o, w, bytes;
 };
 
-// History split by age, an experiment that lost and is compiled out (GDMIX_QUAD_NOLD = 0). The (s, y)
-// pairs of an EPL = 4 kernel alone are 160 VGPRs and the kernel spills 34 at the 256 it may use (two wavefronts per SIMD). With
-// the QUAD_NOLD oldest pairs in the entity's LDS block (every lane keeping its own coefficients there; the newest
-// M_REG - QUAD_NOLD in VGPRs) the spills go (247 VGPRs, no scratch at QUAD_NOLD = 3) and the fixtures stay bit for bit, but
-// <16,4> runs 2.75 -> 2.85 / 3.19 / 3.80 ms on C2 for QUAD_NOLD = 2 / 3 / 4 (profiles/r03_c2_history_by_age.txt): the 8 - 16 KB
-// of LDS per wavefront cost a workgroup or two of the eight a CU holds, and from iteration M_REG - QUAD_NOLD + 1 on the LDS
-// round trips sit in the dependent chain of the two-loop recursion; the spilled registers were cold ones.
-#ifndef GDMIX_QUAD_NOLD
-#define GDMIX_QUAD_NOLD 0
-#endif
-__host__ __device__ constexpr int quad_nold(int g, int epl) { return (epl == 4 && g <= 64) ? GDMIX_QUAD_NOLD : 0; }
-
+// (The history split by age of round 3 — the oldest pairs of an EPL = 4 kernel in LDS instead of spilled VGPRs — lost 4 - 38 % on
+// <16,4> and was deleted in round 4: profiles/r03_c2_history_by_age.txt.)
 constexpr int QUAD_HDR_BYTES = 8 * (2 * M_REG + 16 + 8);   // rho, alpha, LineSearch slot, 8 scalars (one per wavefront of the group)
 
-__host__ __device__ inline QuadLayout quad_layout(int pcap, int ncap, int zcap, int waves = 1, int nold = 0) {
+__host__ __device__ inline QuadLayout quad_layout(int pcap, int ncap, int zcap, int waves = 1) {
   QuadLayout q;
   // groups wider than a wavefront keep one private copy of the uniform solver state per wavefront (all
   // copies hold the same values; sharing one would race between a fast wave's write and a slow wave's read)
@@ -285,8 +275,6 @@ __host__ __device__ inline QuadLayout quad_layout(int pcap, int ncap, int zcap, 
   q.y = off; off += 4 * ncap;
   q.o = off; off += 4 * ncap;
   q.w = off; off += 4 * ncap;
-  off = (off + 7) & ~7;
-  q.hist = off; off += 16 * pcap * nold;   // [nold][s, y][pcap]
   q.bytes = (off + 15) & ~15;
   return q;
 }
@@ -312,7 +300,6 @@ struct QuadLds {
   __device__ __forceinline__ float* y() const { return reinterpret_cast<float*>(base + q.y); }
   __device__ __forceinline__ float* o() const { return reinterpret_cast<float*>(base + q.o); }
   __device__ __forceinline__ float* w() const { return reinterpret_cast<float*>(base + q.w); }
-  __device__ __forceinline__ double* hist() const { return reinterpret_cast<double*>(base + q.hist); }
 };
 static_assert(sizeof(LineSearch) <= 128, "LineSearch must fit its LDS slot");
 
@@ -447,16 +434,14 @@ template <int G, int EPL>
 __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& o, int gl, int n, int p, int ic,
                                            bool valid, unsigned rowc, const unsigned (&colc)[EPL], QuadState<EPL>& V,
                                            XWave& X, SolveStats& out) {
-  // pair a of M_REG (newest last): a >= NOLD in registers S[a - NOLD], a < NOLD in LDS slot (a + head) mod NOLD
-  constexpr int NOLD = quad_nold(G, EPL), KR = M_REG - NOLD, PCAP = G * EPL;
+  // pair a of M_REG, newest last: a register shift register (every index a compile-time constant)
+  constexpr int KR = M_REG;
   double S[KR][EPL], Y[KR][EPL];
 #pragma unroll
   for (int a = 0; a < KR; ++a) {
 #pragma unroll
     for (int s = 0; s < EPL; ++s) { S[a][s] = 0.0; Y[a][s] = 0.0; }
   }
-  double* const hist = L.hist();
-  int head = 0;
   double* const rho = L.rho();      // per-entity uniform state: every lane of the row stores the same value
   double* const alpha = L.alpha();
   double* const scal = L.scal();
@@ -535,17 +520,7 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
             if (stp == 1.0) { dr = gd - gdold; ddum = -gdold; }
             else { dr = (gd - gdold) * stp; ddum = -gdold * stp; }
             if (dr > EPSMCH * ddum) {
-              // push (s, y): the oldest register pair takes the place of the oldest LDS pair (which drops out), the register
-              // history shifts down by one, newest at KR-1
-              if (NOLD > 0) {
-                double* const hs = hist + head * 2 * PCAP;
-#pragma unroll
-                for (int s = 0; s < EPL; ++s) {
-                  const int j = gl + G * s;
-                  if (j < p) { hs[j] = S[0][s]; hs[PCAP + j] = Y[0][s]; }
-                }
-                head = (head + 1 == NOLD) ? 0 : head + 1;
-              }
+              // push (s, y): the history shifts down by one, newest at KR-1
 #pragma unroll
               for (int a = 0; a < M_REG - 1; ++a) rho[a] = rho[a + 1];
 #pragma unroll
@@ -591,19 +566,8 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
         if (__any(use)) {
           if (use) {
             double sa[EPL], ya[EPL];
-            if (a >= NOLD) {
 #pragma unroll
-              for (int s = 0; s < EPL; ++s) { sa[s] = S[a >= NOLD ? a - NOLD : 0][s]; ya[s] = Y[a >= NOLD ? a - NOLD : 0][s]; }
-            } else {
-              const int ph = (a + head >= NOLD) ? a + head - NOLD : a + head;
-              const double* const hs = hist + ph * 2 * PCAP;
-#pragma unroll
-              for (int s = 0; s < EPL; ++s) {
-                const int j = gl + G * s;
-                sa[s] = (j < p) ? hs[j] : 0.0;
-                ya[s] = (j < p) ? hs[PCAP + j] : 0.0;
-              }
-            }
+            for (int s = 0; s < EPL; ++s) { sa[s] = S[a][s]; ya[s] = Y[a][s]; }
             double t = 0.0;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) t += sa[s] * V.d[s];
@@ -625,19 +589,8 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
         if (__any(use)) {
           if (use) {
             double sa[EPL], ya[EPL];
-            if (a >= NOLD) {
 #pragma unroll
-              for (int s = 0; s < EPL; ++s) { sa[s] = S[a >= NOLD ? a - NOLD : 0][s]; ya[s] = Y[a >= NOLD ? a - NOLD : 0][s]; }
-            } else {
-              const int ph = (a + head >= NOLD) ? a + head - NOLD : a + head;
-              const double* const hs = hist + ph * 2 * PCAP;
-#pragma unroll
-              for (int s = 0; s < EPL; ++s) {
-                const int j = gl + G * s;
-                sa[s] = (j < p) ? hs[j] : 0.0;
-                ya[s] = (j < p) ? hs[PCAP + j] : 0.0;
-              }
-            }
+            for (int s = 0; s < EPL; ++s) { sa[s] = S[a][s]; ya[s] = Y[a][s]; }
             double t = 0.0;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) t += ya[s] * V.d[s];

@@ -1,4 +1,6 @@
-// re_solve_wreg.hpp — register-resident one-wavefront-per-entity L-BFGS (the hot kernel).
+// re_solve_wreg.hpp — the L-BFGS driver with one coefficient set per lane in registers (wreg_solve_ev), as the master wavefront
+// of the tall kernel runs it (re_solve_tall.hip). Round 1's kernel around it — one wavefront per entity, X block in LDS — was
+// superseded by the group kernels (re_solve_quad.hpp) and removed in round 4 with its thirteen size classes.
 //
 // Coefficient j of the entity lives in lane (j mod 64), slot (j div 64): x, g, d, x_old, g_old and
 // the whole (s, y) history (M_REG = 10 pairs) are VGPRs. LDS holds only what lanes gather from each
@@ -55,111 +57,12 @@ __device__ __forceinline__ void wave_sum2_max(double& a, double& b, double& c) {
   c = readlane63(c);
 }
 
-// LDS bytes of one entity in the register kernel (must match the carve-up below)
-__host__ __device__ inline size_t wreg_lds_bytes(int p, int n, int nnz, int d, bool has_w) {
-  size_t b = (size_t)8 * (p + 2 * M_REG + 16) + (size_t)8 * n + (size_t)16 * nnz + (size_t)4 * (n + 1) +
-             (size_t)4 * (d + 1) + (size_t)(has_w ? 12 : 8) * n;
-  return (b + 15 + 16) & ~(size_t)15;   // + slack for the 8-byte alignment of the pair arrays
-}
-
-struct WregLds {
-  // wave-uniform solver state parked in LDS so that it does not occupy VGPRs across the evaluation
-  double* rho;       // [M_REG] 1/(s'y) per history slot
-  double* alpha;     // [M_REG] two-loop coefficients
-  LineSearch* ls;    // More'-Thuente state (16 doubles reserved)
-  double* xs;        // [p]   trial point
-  double* rs;        // [n]   residuals
-  int2* csr;         // [nnz] {local col, float bits}
-  int2* csc;         // [nnz] {sample,    float bits}
-  int32_t* row_ptr;  // [n+1]
-  int32_t* col_ptr;  // [d+1]
-  float* y;          // [n]
-  float* o;          // [n]
-  float* w;          // [n] or nullptr
-};
-
 template <int EPL>
 struct WregState {
   double x[EPL], g[EPL], d[EPL], xo[EPL], go[EPL];
 };
 
 // f and g at the point held in `xt` (registers). g <- gradient, returns f. rsum_out: sum of residuals.
-template <int EPL>
-__device__ __forceinline__ double wreg_eval(const WregLds& L, const SolveParams& o, int lane, int n, int p, int ic,
-                                            const double (&xt)[EPL], double (&g)[EPL], bool first, bool& counted) {
-  // xs still holds the point of the previous evaluation: an evaluation at the same point is not counted (nfev is scipy's funcalls)
-  bool mv = first;
-#pragma unroll
-  for (int s = 0; s < EPL; ++s) {
-    const int j = lane + WAVE * s;
-    if (j < p) {
-      mv = mv || (L.xs[j] != xt[s]);
-      L.xs[j] = xt[s];
-    }
-  }
-  counted = __ballot(mv) != 0ull;
-  wave_lds_fence();
-  double part = 0.0, rpart = 0.0;
-  const double x0 = ic ? L.xs[0] : 0.0;
-  for (int i = lane; i < n; i += WAVE) {
-    double acc = x0;
-    const int k1 = L.row_ptr[i + 1];
-    for (int k = L.row_ptr[i]; k < k1; ++k) {
-      const int2 cv = L.csr[k];
-      acc += (double)__int_as_float(cv.y) * L.xs[ic + cv.x];
-    }
-    const double z = acc + (double)L.o[i];
-    const double yi = (double)L.y[i];
-    const double wi = L.w ? (double)L.w[i] : 1.0;
-    double ri;
-    part += logistic_terms(z, yi, wi, ri);
-    L.rs[i] = ri;
-    rpart += ri;
-  }
-  const int first_reg = (ic && !o.regularize_bias) ? 1 : 0;
-  double sq = 0.0;
-#pragma unroll
-  for (int s = 0; s < EPL; ++s) {
-    const int j = lane + WAVE * s;
-    if (j >= first_reg && j < p) sq += xt[s] * xt[s];
-  }
-  wave_sum2(part, rpart);
-  part += 0.5 * o.l2 * wave_sum(sq);   // cost.sum() + regulariser, added once (binary_logistic_regression.py:105-108)
-  wave_lds_fence();
-  const double inv_n = 1.0 / (double)n;
-#pragma unroll
-  for (int s = 0; s < EPL; ++s) {
-    const int j = lane + WAVE * s;
-    double gj = 0.0;
-    if (j < p) {
-      double acc;
-      if (ic && j == 0) {
-        acc = rpart;
-      } else {
-        acc = 0.0;
-        const int c = j - ic;
-        const int k1 = L.col_ptr[c + 1];
-        for (int k = L.col_ptr[c]; k < k1; ++k) {
-          const int2 rv = L.csc[k];
-          acc += (double)__int_as_float(rv.y) * L.rs[rv.x];
-        }
-      }
-      const double reg = (j < first_reg) ? 0.0 : o.l2 * xt[s];
-      gj = inv_n * (acc + reg);
-    }
-    g[s] = gj;
-  }
-  return inv_n * part;
-}
-
-// One evaluation site, one line-search site: the solve is written as a loop around "evaluate f, g at the
-// current trial point" so that the (large) inlined eval body and its exp/log temporaries exist once.
-// The driver is written against an evaluator `eval(xt, g, first, counted) -> f` (g <- gradient at the point xt held in registers,
-// coefficient lane + 64 s in slot s; f, and with it every decision below, uniform over the wavefront; counted <- xt differs from
-// the point of the previous evaluation — nfev is scipy's funcalls, which leaves out a repeated point — or first): wreg_eval below for an entity that
-// lives in one wavefront's LDS, the workgroup-cooperative evaluation of re_solve_tall.hpp for tall entities (every wavefront of
-// the workgroup then runs this driver on identical inputs and so takes identical decisions). rho / alpha / lsp: this
-// wavefront's uniform state in LDS.
 template <int EPL, class Eval>
 __device__ __forceinline__ void wreg_solve_ev(double* const rho, double* const alpha, LineSearch* const lsp, const SolveParams& o,
                                               WregState<EPL>& V, SolveStats& out, Eval&& eval) {
@@ -336,15 +239,6 @@ __device__ __forceinline__ void wreg_solve_ev(double* const rho, double* const a
   out.nit = nit;
   out.nfev = nfev;
   out.status = status;
-}
-
-template <int EPL>
-__device__ __forceinline__ void wreg_solve(const WregLds& L, const SolveParams& o, int lane, int n, int p, int ic,
-                                           WregState<EPL>& V, SolveStats& out) {
-  wreg_solve_ev<EPL>(L.rho, L.alpha, L.ls, o, V, out,
-                     [&](const double (&xt)[EPL], double (&g)[EPL], bool first, bool& counted) {
-                       return wreg_eval<EPL>(L, o, lane, n, p, ic, xt, g, first, counted);
-                     });
 }
 
 }  // namespace gdmix

@@ -61,7 +61,7 @@ __global__ void vf_clear_kernel(double* __restrict__ H, int p, int ld) {
 // Column a of X~ times d, spread over the samples (w, all zero on entry and on exit), then its products with the columns b >= a.
 // Repeated (row, column) pairs are summed first, as toarray() does.
 __global__ __launch_bounds__(VF_THREADS) void vf_build_kernel(BatchDev B, VfEntity V, SolveParams o, const double* __restrict__ dvec,
-                                                              double* __restrict__ wslots, double* __restrict__ H) {
+                                                              double* __restrict__ wslots, double* __restrict__ H, int add_diag) {
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
   const int ic = o.has_intercept ? 1 : 0;
   double* w = wslots + (size_t)blockIdx.x * V.n;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(VF_THREADS) void vf_build_kernel(BatchDev B, VfEnti
         if (b == a) {
           double add = o.l2 + 1.0e-12;
           if (a_icpt && !o.regularize_bias) add -= o.l2;
-          H[(size_t)a * V.ld + a] = s + add;
+          H[(size_t)a * V.ld + a] = add_diag ? s + add : s;   // (the curvature part alone: gdmix_fe_hessian_dense)
         } else {
           H[(size_t)a * V.ld + b] = s;
           H[(size_t)b * V.ld + a] = s;
@@ -266,6 +266,20 @@ size_t var_full_big_doubles(int64_t max_p, int64_t max_n) {
   return 2 * ld * ld + (size_t)max_n * (1 + VAR_BIG_BUILD_GROUPS) + 64;
 }
 
+// H (ld x ld, SPD, identity on the padding) -> diag(H^-1)[0, p) into `out`; H is overwritten by its Cholesky factor, M is ld x ld scratch
+static hipError_t vf_factor_and_invert(double* H, double* M, int ld, int p, double* out, hipStream_t s) {
+  const int T = ld / VF_T;
+  for (int k = 0; k < T; ++k) {
+    hipLaunchKernelGGL(vf_potrf_kernel, dim3(1), dim3(VF_THREADS), 0, s, H, ld, k);
+    if (k + 1 < T) {
+      hipLaunchKernelGGL(vf_trsm_kernel, dim3(T - k - 1), dim3(VF_T), 0, s, H, ld, k);
+      hipLaunchKernelGGL(vf_syrk_kernel, dim3(T - k - 1, T - k - 1), dim3(VF_THREADS), 0, s, H, ld, k);
+    }
+  }
+  hipLaunchKernelGGL(vf_inverse_kernel, dim3(T), dim3(VF_THREADS), 0, s, H, M, ld, p, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_variance_full_big(gdmix_ctx_impl* ci, const BatchDev& B, int64_t E, const SolveParams& o, const double* theta,
                                     double* variance, double* scratch, int64_t max_p, int64_t max_n, hipStream_t s) {
   // the large entities: counted first (cap 0: the list kernel only counts), then listed — however many there are
@@ -299,24 +313,56 @@ hipError_t launch_variance_full_big(gdmix_ctx_impl* ci, const BatchDev& B, int64
   double* wslots = dvec + max_n;
   for (int q = 0; q < n_big; ++q) {
     const VfEntity& V = host[(size_t)q];
-    const int T = V.ld / VF_T;
     hipLaunchKernelGGL(vf_rows_kernel, dim3((V.n + 255) / 256), dim3(256), 0, s, B, V, ic, theta, dvec);
     hipLaunchKernelGGL(vf_clear_kernel, dim3(ci->num_cus * 8), dim3(256), 0, s, H, V.p, V.ld);
     rc = hipMemsetAsync(wslots, 0, (size_t)V.n * VAR_BIG_BUILD_GROUPS * 8, s);
     if (rc != hipSuccess) return rc;
-    hipLaunchKernelGGL(vf_build_kernel, dim3(VAR_BIG_BUILD_GROUPS), dim3(VF_THREADS), 0, s, B, V, o, dvec, wslots, H);
-    for (int k = 0; k < T; ++k) {
-      hipLaunchKernelGGL(vf_potrf_kernel, dim3(1), dim3(VF_THREADS), 0, s, H, V.ld, k);
-      if (k + 1 < T) {
-        hipLaunchKernelGGL(vf_trsm_kernel, dim3(T - k - 1), dim3(VF_T), 0, s, H, V.ld, k);
-        hipLaunchKernelGGL(vf_syrk_kernel, dim3(T - k - 1, T - k - 1), dim3(VF_THREADS), 0, s, H, V.ld, k);
-      }
-    }
-    hipLaunchKernelGGL(vf_inverse_kernel, dim3(T), dim3(VF_THREADS), 0, s, H, M, V.ld, V.p, variance + V.c0);
-    rc = hipGetLastError();
+    hipLaunchKernelGGL(vf_build_kernel, dim3(VAR_BIG_BUILD_GROUPS), dim3(VF_THREADS), 0, s, B, V, o, dvec, wslots, H, 1);
+    rc = vf_factor_and_invert(H, M, V.ld, V.p, variance + V.c0, s);
     if (rc != hipSuccess) return rc;
   }
   return hipSuccess;
+}
+
+// ---- two-stage form for several fixed-effect workers (include/gdmix_fe.h: gdmix_fe_hessian_dense / gdmix_fe_variance_of_hessian) ----
+// Stage 1, per worker: the curvature part X~' D X~ of its shard (entity 0 of a one-entity packed batch) as a dense matrix in the
+// shard's local index space, no regulariser. Stage 2, after the caller has scattered the matrices into the common index space and
+// all-reduced them: regulariser on the diagonal, tiled Cholesky, diag of the inverse (fixed_effect_lr_lbfgs_model.py:296-305, 457-463).
+size_t hessian_dense_scratch_doubles(int64_t n) { return (size_t)n * (1 + VAR_BIG_BUILD_GROUPS) + 64; }
+
+hipError_t launch_hessian_dense(gdmix_ctx_impl* ci, const BatchDev& B, int64_t n, int64_t d, int ic, const double* theta, double* H, int64_t ld,
+                                double* scratch, hipStream_t s) {
+  VfEntity V;
+  V.e = 0; V.r0 = 0; V.z0 = 0; V.c0 = 0;
+  V.n = (int)n; V.d = (int)d; V.p = (int)d + ic; V.ld = (int)ld;
+  if (V.ld < V.p || V.ld % VF_T) return hipErrorInvalidValue;
+  SolveParams o{};
+  o.has_intercept = ic;
+  double* dvec = scratch;
+  double* wslots = dvec + n;
+  hipLaunchKernelGGL(vf_rows_kernel, dim3((V.n + 255) / 256), dim3(256), 0, s, B, V, ic, theta, dvec);
+  hipLaunchKernelGGL(vf_clear_kernel, dim3(ci->num_cus * 8), dim3(256), 0, s, H, V.ld, V.ld);   // (p = ld: all zero, no identity on the padding)
+  hipError_t rc = hipMemsetAsync(wslots, 0, (size_t)V.n * VAR_BIG_BUILD_GROUPS * 8, s);
+  if (rc != hipSuccess) return rc;
+  hipLaunchKernelGGL(vf_build_kernel, dim3(VAR_BIG_BUILD_GROUPS), dim3(VF_THREADS), 0, s, B, V, o, dvec, wslots, H, 0);
+  return hipGetLastError();
+}
+
+// diagonal of a summed curvature matrix: + l2 + 1e-12 (without l2 at `unreg`), identity on the padding rows / columns
+__global__ void vf_regularise_kernel(double* __restrict__ H, int p, int ld, double l2, int unreg) {
+  const size_t total = (size_t)ld * ld;
+  for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < total; a += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(a / ld), c = (int)(a % ld);
+    if (r >= p || c >= p) H[a] = (r == c) ? 1.0 : 0.0;
+    else if (r == c) H[a] += (r == unreg ? 0.0 : l2) + 1.0e-12;
+  }
+}
+
+hipError_t launch_variance_of_hessian(gdmix_ctx_impl* ci, double* H, double* M, int64_t p, int64_t ld, double l2, int64_t unreg, double* variance,
+                                      hipStream_t s) {
+  if (ld < p || ld % VF_T || p < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(vf_regularise_kernel, dim3(ci->num_cus * 8), dim3(256), 0, s, H, (int)p, (int)ld, l2, (int)unreg);
+  return vf_factor_and_invert(H, M, (int)ld, (int)p, variance, s);
 }
 
 }  // namespace gdmix

@@ -315,7 +315,9 @@ def _fit_stepping(self, row_nnz_ptr, col_global, val, y, num_features, offset=No
 # FULL densifies a (D + 1) x (D + 1) Hessian, as the reference does (fixed_effect_lr_lbfgs_model.py:291, 457: no limit there but
 # memory). Up to FULL_VARIANCE_HOST_MAX coefficients the matrix is built and inverted on the host exactly as the reference does
 # (several workers: summed with an all-reduce first); above that and up to FULL_VARIANCE_DEVICE_MAX on the device (tiled Cholesky
-# and inverse over the whole MI355X, csrc/re_variance_big.hip) — one worker only: the matrix is not all-reduced there.
+# and inverse over the whole MI355X, csrc/re_variance_big.hip). Several workers (round 4): every worker builds the dense curvature
+# matrix of its shard on its device (gdmix_fe_hessian_dense), scatters it into the common index space, one all-reduce of the
+# P x P matrix (RCCL), and every worker factors the sum (gdmix_fe_variance_of_hessian) — replicated, as scipy is in the reference.
 FULL_VARIANCE_HOST_MAX = 4096
 FULL_VARIANCE_DEVICE_MAX = 16384
 FULL_VARIANCE_MAX_FEATURES = FULL_VARIANCE_HOST_MAX   # (the name round 2 used)
@@ -340,10 +342,6 @@ def check_variance_request(mode, P, num_workers):
     if P > FULL_VARIANCE_DEVICE_MAX:
         raise ValueError(f"fixed_effect_variance_mode FULL inverts a dense {P} x {P} matrix; at most {FULL_VARIANCE_DEVICE_MAX} "
                          "coefficients (use SIMPLE for larger models)")
-    if P > FULL_VARIANCE_HOST_MAX and num_workers > 1:
-        raise ValueError(f"fixed_effect_variance_mode FULL with {P} coefficients is available on one worker only (above "
-                         f"{FULL_VARIANCE_HOST_MAX} the Hessian is built and inverted on the device, without an all-reduce); "
-                         f"this job has {num_workers} workers — use SIMPLE, or one worker")
 
 
 def _variances(solver, prob, batch, theta, D, has_intercept, l2, regularize_bias, mode, all_reduce, group, packed=None, dummy=False):
@@ -368,6 +366,8 @@ def _variances(solver, prob, batch, theta, D, has_intercept, l2, regularize_bias
     if mode != "FULL":
         raise ValueError(f"unknown variance mode {mode!r}")
     check_variance_request(mode, P, _world_size(group))
+    if P > FULL_VARIANCE_HOST_MAX and _world_size(group) > 1:
+        return _full_variances_several_workers(solver, packed, theta, D, has_intercept, l2, regularize_bias, group, dummy)
     if P > FULL_VARIANCE_HOST_MAX:
         # on the device, in the shard's local index space (intercept first): the random-effect FULL variance of a one-entity
         # batch is this very matrix (binary_logistic_regression.py:181-187 = fixed_effect_lr_lbfgs_model.py:296-305, 457-463).
@@ -408,6 +408,37 @@ def _variances(solver, prob, batch, theta, D, has_intercept, l2, regularize_bias
     if ic and not regularize_bias:
         H[-1, -1] -= l2
     return np.diagonal(np.linalg.inv(H)).copy()
+
+
+def _full_variances_several_workers(solver, packed, theta, D, has_intercept, l2, regularize_bias, group, dummy=False):
+    """FULL variances on the device with the Hessian summed over the workers (fixed_effect_lr_lbfgs_model.py:291-305, 384-389,
+    457-463). Coefficient order: features 0 .. D-1, intercept last."""
+    import torch
+    import torch.distributed as dist
+    ic = 1 if has_intercept else 0
+    P = D + ic
+    uniq_dev = packed.unique_global()
+    uniq = uniq_dev.cpu().numpy()
+    local = to_local(theta, uniq, D, has_intercept, dummy)
+    Hl = solver.hessian_dense(packed, local, has_intercept)            # [ld_l, ld_l], local order: intercept first
+    p_l = uniq.size + ic
+    ld = (P + 63) // 64 * 64
+    idx = torch.cat([torch.full((ic,), D, dtype=torch.int64, device=solver.device), uniq_dev.to(torch.int64)])   # local -> global coefficient
+    if dummy:     # a worker without data trains on one weight-0 sample: its curvature is exactly zero
+        Hl = torch.zeros_like(Hl)
+    rows = torch.zeros((ld, p_l), dtype=torch.float64, device=solver.device)
+    rows.index_copy_(0, idx, Hl[:p_l, :p_l].contiguous())
+    Hg = torch.zeros((ld, ld), dtype=torch.float64, device=solver.device)
+    Hg.index_copy_(1, idx, rows)
+    del rows, Hl
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(Hg, group=group)
+    else:      # (gloo: the two-worker tests on one device)
+        h = Hg.cpu()
+        dist.all_reduce(h, group=group)
+        Hg = h.to(solver.device)
+    unreg = D if (ic and not regularize_bias) else -1
+    return solver.variance_of_hessian(Hg, P, l2, unreg).cpu().numpy()
 
 
 FixedEffectDeviceSolver.fit_stepping = _fit_stepping

@@ -18,7 +18,7 @@ from .batch import RawBatch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgdmix_re.so")
 
-NUM_CLASSES = 51
+NUM_CLASSES = 38
 STATUS_NAMES = ("PGTOL", "FACTR", "MAXITER", "MAXFUN", "ABNORMAL")
 VAR_NONE, VAR_SIMPLE, VAR_FULL = 0, 1, 2
 VARIANCE_MODES = {None: VAR_NONE, "simple": VAR_SIMPLE, "SIMPLE": VAR_SIMPLE, "full": VAR_FULL, "FULL": VAR_FULL,
@@ -72,7 +72,8 @@ EXPORTED_SYMBOLS = (
     "gdmix_re_solve_scratch_bytes", "gdmix_re_set_scratch", "gdmix_re_variance_full", "gdmix_re_set_wave_lds_limit", "gdmix_re_score",
     "gdmix_re_widen_workspace_bytes", "gdmix_re_widen", "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz", "gdmix_re_set_tall_min_n", "gdmix_re_set_tall_split_n",
     "gdmix_fe_create", "gdmix_fe_destroy", "gdmix_fe_eval", "gdmix_fe_reduce_buffer", "gdmix_fe_step", "gdmix_fe_result",
-    "gdmix_fe_last_eval_ms", "gdmix_fe_score", "gdmix_fe_hessian_diag",
+    "gdmix_fe_last_eval_ms", "gdmix_fe_score", "gdmix_fe_hessian_diag", "gdmix_fe_hessian_dense_scratch_bytes", "gdmix_fe_hessian_dense",
+    "gdmix_fe_variance_of_hessian",
     "gdmix_re_class_kernel_name", "gdmix_java_string_hash", "gdmix_java_partition_id",
     "gdmix_java_partition_ids_i64")
 
@@ -129,6 +130,10 @@ def load_library():
                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]
     lib.gdmix_fe_score.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gdmix_fe_hessian_dense_scratch_bytes.argtypes = [C.POINTER(_Packed)]
+    lib.gdmix_fe_hessian_dense_scratch_bytes.restype = C.c_size_t
+    lib.gdmix_fe_hessian_dense.argtypes = [C.c_void_p, C.POINTER(_Packed), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.gdmix_fe_variance_of_hessian.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gdmix_fe_last_eval_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.gdmix_re_set_team_nnz.argtypes = [C.c_void_p, C.c_int64]
     lib.gdmix_re_set_tall_min_n.argtypes = [C.c_void_p, C.c_int]
@@ -144,7 +149,7 @@ def load_library():
     lib.gdmix_java_partition_id.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     lib.gdmix_java_partition_id.restype = C.c_int32
     lib.gdmix_java_partition_ids_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
-    if lib.gdmix_re_abi_version() != 7:
+    if lib.gdmix_re_abi_version() != 8:
         raise GdmixReError("libgdmix_re.so ABI version mismatch")
     _lib = lib
     return lib
@@ -337,8 +342,8 @@ class REDeviceSolver:
         _check(self.lib.gdmix_re_set_wave_lds_limit(self._h, int(nbytes)), "set_wave_lds_limit")
 
     def set_kernel_mask(self, mask: int):
-        """bit0: register-resident wave kernel, bit1: LDS-resident wave kernel, bit2: group kernels (the tall kernel and the
-        team kernels are always on). Default 7."""
+        """bit1: LDS-resident wave kernel, bit2: group kernels (the tall kernel and the team kernels are always on; bit0, the
+        register wave kernel removed in round 4, is ignored). Default 7."""
         _check(self.lib.gdmix_re_set_kernel_mask(self._h, int(mask)), "set_kernel_mask")
 
     def set_giant_nnz(self, nnz: int):
@@ -514,6 +519,32 @@ class REDeviceSolver:
         out = t.empty(packed.P, dtype=t.float64, device=self.device)
         _check(self.lib.gdmix_re_variance_full(self._h, C.byref(packed.c), C.byref(c_opts), theta.data_ptr(), out.data_ptr(), self._stream()),
                "gdmix_re_variance_full")
+        return out
+
+    # ---- fixed effect, FULL variances with several workers (include/gdmix_fe.h) -----------------------
+    def hessian_dense(self, packed: PackedBatch, theta_local, has_intercept=True):
+        """X~' D X~ of a one-entity batch (a worker's shard) at theta_local (the shard's local order, intercept first) as a dense
+        [ld, ld] device tensor, ld = p rounded up to 64; no regulariser."""
+        t = self.torch
+        if isinstance(theta_local, np.ndarray):
+            theta_local = t.from_numpy(np.ascontiguousarray(theta_local, np.float64)).to(self.device)
+        p = packed.D + (1 if has_intercept else 0)
+        ld = (p + 63) // 64 * 64
+        H = t.empty((ld, ld), dtype=t.float64, device=self.device)
+        nbytes = self.lib.gdmix_fe_hessian_dense_scratch_bytes(C.byref(packed.c))
+        scratch = t.empty(nbytes, dtype=t.uint8, device=self.device)
+        _check(self.lib.gdmix_fe_hessian_dense(self._h, C.byref(packed.c), int(bool(has_intercept)), theta_local.data_ptr(), H.data_ptr(), ld,
+                                               scratch.data_ptr(), nbytes, self._stream()), "gdmix_fe_hessian_dense")
+        return H
+
+    def variance_of_hessian(self, H, p, l2, unregularised_index=-1):
+        """diag((H + (l2 + 1e-12) I - l2 e_u e_u')^-1)[0, p) of a summed curvature matrix H ([ld, ld] device tensor, overwritten)."""
+        t = self.torch
+        ld = int(H.shape[0])
+        work = t.empty_like(H)
+        out = t.empty(int(p), dtype=t.float64, device=self.device)
+        _check(self.lib.gdmix_fe_variance_of_hessian(self._h, H.data_ptr(), int(p), ld, float(l2), int(unregularised_index), work.data_ptr(),
+                                                     out.data_ptr(), self._stream()), "gdmix_fe_variance_of_hessian")
         return out
 
     def class_counts(self, packed: PackedBatch):

@@ -62,6 +62,20 @@ GDMIX_API double* gdmix_fe_reduce_buffer(gdmix_fe_problem* p, int64_t* count);
  * reference does this arithmetic in float32, this library in float64. Two more streaming passes over the shard. */
 GDMIX_API int gdmix_fe_hessian_diag(gdmix_fe_problem* p, const double* theta, void* stream);
 
+/* fixed_effect_variance_mode = FULL with several workers, on the device (round 4). The reference sums the workers' dense Hessians
+ * and inverts the sum (fixed_effect_lr_lbfgs_model.py:291-305, 384-389, 457-463). Stage 1, per worker: the curvature part X~' D X~ of
+ * the shard — `shard` is the one-entity packed batch gdmix_fe_create took — at theta_local ([d + has_intercept], the shard's LOCAL
+ * order: intercept first, then its features in ascending global index, packed->unique_global) as a dense symmetric matrix H
+ * [ld x ld] row-major, ld = d + has_intercept rounded up to a multiple of 64, no regulariser, zero on the padding. The caller
+ * scatters H into the common (global) index space and all-reduces it (RCCL through torch.distributed). Stage 2: variance [p] =
+ * diag((H + (l2 + 1e-12) I - l2 e_u e_u' [u = unregularised_index, -1: none])^-1) of the summed matrix H [ld x ld] (overwritten),
+ * work = another ld x ld doubles. Tiled Cholesky + inverse on the whole device (csrc/re_variance_big.hip), p <= 16 384. */
+GDMIX_API size_t gdmix_fe_hessian_dense_scratch_bytes(const gdmix_re_packed* shard);
+GDMIX_API int gdmix_fe_hessian_dense(gdmix_re_ctx* ctx, const gdmix_re_packed* shard, int has_intercept, const double* theta_local,
+                                     double* H, int64_t ld, void* scratch, size_t scratch_bytes, void* stream);
+GDMIX_API int gdmix_fe_variance_of_hessian(gdmix_re_ctx* ctx, double* H, int64_t p, int64_t ld, double l2, int64_t unregularised_index,
+                                           double* work, double* variance, void* stream);
+
 /* Consumes the (all-reduced) buffer. *status: -1 = evaluate again, else GDMIX_RE_ST_*. Synchronises the stream. */
 GDMIX_API int gdmix_fe_step(gdmix_fe_problem* p, void* stream, int32_t* status);
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GDMIX_RE_ABI_VERSION 7
+#define GDMIX_RE_ABI_VERSION 8
 
 #if defined(__GNUC__)
 #define GDMIX_API __attribute__((visibility("default")))
@@ -140,7 +140,7 @@ typedef struct {
   int32_t        max_p, max_n, max_nnz;  /* per-entity maxima over the batch (host, after pack)     */
 } gdmix_re_packed;
 
-#define GDMIX_RE_NUM_CLASSES 51
+#define GDMIX_RE_NUM_CLASSES 38
 
 /* ---- solver options (defaults = REParams/LRParams defaults + scipy defaults) ----------------------
  * base_lr_params.py:22-27, binary_logistic_regression.py:223-231 (pgtol/maxfun/maxls are scipy's). */
@@ -232,10 +232,12 @@ GDMIX_API int gdmix_re_score(gdmix_re_ctx* ctx, const gdmix_re_packed* batch, in
  * workgroup-per-entity kernel (0 => every entity). Default and maximum 65536. */
 GDMIX_API int gdmix_re_set_wave_lds_limit(gdmix_re_ctx* ctx, int bytes);
 
-/* Tuning/testing knob: which per-entity kernels the solver may use. bit 0 = register-resident wavefront
- * kernel, bit 1 = LDS-resident wavefront kernel, bit 2 = the group kernels (several entities per wavefront); the tall kernel
- * and the team kernels are always available. Default 7. (Round 2 had a bit 3: team kernels with the L-BFGS history in
- * registers; slower than streaming the history at every team size, removed in round 3 - profiles/r03_zipf_register_team_kernels.txt.) */
+/* Tuning/testing knob: which per-entity kernels the solver may use. bit 1 = LDS-resident wavefront kernel (any m), bit 2 = the
+ * group kernels (several entities per wavefront); the tall kernel and the team kernels are always available. Default 7. Bit 0 was
+ * round 1's register-resident one-entity-per-wavefront kernel: unreachable under default routing once the group kernels covered
+ * p <= 2048 (tests/test_gpu_parity.py::test_default_routing_reaches_only_these_classes), removed in round 4 with its thirteen size
+ * classes (ABI 8, GDMIX_RE_NUM_CLASSES 38); the bit is accepted and ignored. (Round 2's bit 3, team kernels with the history in
+ * registers, went in round 3 - profiles/r03_zipf_register_team_kernels.txt.) */
 GDMIX_API int gdmix_re_set_kernel_mask(gdmix_re_ctx* ctx, int mask);
 
 /* The head of a Zipf-distributed partition is solved by a persistent kernel (one workgroup per CU) split into teams

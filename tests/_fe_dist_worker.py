@@ -17,6 +17,18 @@ import torch.distributed as dist
 from gdmix_amd import fixed_effect as fe
 
 
+def wide_case():
+    """3 000 samples x 6 non-zeros over 4 500 features (a few of them in no sample at all), weights, offsets."""
+    rng = np.random.default_rng(12)
+    n, k, D = 3000, 6, 4500
+    col = rng.integers(0, D - 40, (n, k)).astype(np.int64).ravel()      # the last 40 features never occur
+    val = rng.standard_normal(n * k).astype(np.float32)
+    y = (rng.random(n) < 0.5).astype(np.float32)
+    off = (0.2 * rng.standard_normal(n)).astype(np.float32)
+    wt = (0.5 + rng.random(n)).astype(np.float32)
+    return np.arange(n + 1, dtype=np.int64) * k, col, val, y, off, wt, D
+
+
 def main():
     base, names = sys.argv[1], sys.argv[2].split(",")
     world = int(os.environ["WORLD_SIZE"])
@@ -42,6 +54,16 @@ def main():
                                      model_type=fe.LINEAR_REGRESSION if z["linear"] else fe.LOGISTIC_REGRESSION,
                                      theta0=z["theta0"] if z["theta0"].size else None, max_iter=int(z["max_iter"]))
         out[name] = {"theta": theta.tolist(), "status": int(info["status"]), "nit": int(info["nit"]), "nfev": int(info["nfev"])}
+    if len(sys.argv) > 3 and sys.argv[3] == "full_variance":
+        # FULL variances of a model too wide for the host path (P = 4 501 > 4 096): dense curvature matrix per worker on its device,
+        # one all-reduce of the P x P matrix, replicated factorisation (fixed_effect._full_variances_several_workers)
+        rp, col, val, y, off, wt, D = wide_case()
+        rows = np.arange(rank, rp.size - 1, world)
+        k = np.diff(rp)[rows]
+        nz = np.concatenate([np.arange(rp[i], rp[i + 1]) for i in rows])
+        theta, info = s.fit_stepping(np.concatenate([[0], np.cumsum(k)]), col[nz], val[nz], y[rows], D, offset=off[rows], weight=wt[rows],
+                                     has_intercept=True, l2=0.7, regularize_bias=False, max_iter=4, variance_mode="FULL")
+        out["full_variance"] = {"theta": theta.tolist(), "variances": np.asarray(info["variances"]).tolist()}
     gathered = [None] * world
     dist.all_gather_object(gathered, out)
     if rank == 0:

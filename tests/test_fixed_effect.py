@@ -270,6 +270,41 @@ def test_two_workers_all_reduce_gradient_and_value(tmp_path):
 
 
 @pytest.mark.gpu
+def test_two_workers_full_variances_on_the_device(tmp_path):
+    """fixed_effect_variance_mode FULL with two workers and a model wider than the host path takes (4 501 coefficients): each
+    worker's dense curvature matrix on its device, one all-reduce, the factorisation replicated — against numpy's inverse of the
+    whole data set's Hessian at the returned coefficients (fixed_effect_lr_lbfgs_model.py:291-305, 384-389, 457-463)."""
+    import json
+    import subprocess
+    import sys
+    import scipy.sparse as sp
+    root = os.path.dirname(HERE)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    from _fe_dist_worker import wide_case
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TF_CONFIG", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29619", os.path.join(root, "tests", "_fe_dist_worker.py"), str(tmp_path), "logistic_offset", "full_variance"]
+    subprocess.run(cmd, check=True, env=env, timeout=900, cwd=root)
+    res = json.load(open(tmp_path / "result.json"))
+    a, b = res[0]["full_variance"], res[1]["full_variance"]
+    assert a["theta"] == b["theta"] and a["variances"] == b["variances"]             # replicated: bitwise equal on both workers
+    rp, col, val, y, off, wt, D = wide_case()
+    theta = np.array(a["theta"])
+    X = sp.csr_matrix((val.astype(np.float64), col, rp), shape=(rp.size - 1, D))
+    X = sp.hstack([X, sp.csr_matrix(np.ones((rp.size - 1, 1)))], format="csr")
+    rho = 1.0 / (1.0 + np.exp(-(X @ theta + off)))
+    H = np.asarray((X.T @ X.multiply((rho * (1 - rho) * wt)[:, None])).todense())
+    H += np.diag([0.7 + 1e-12] * (D + 1))
+    H[-1, -1] -= 0.7                                                                   # the intercept is not regularised
+    want = np.diagonal(np.linalg.inv(H))
+    got = np.array(a["variances"])
+    assert got.shape == (D + 1,)
+    np.testing.assert_allclose(got, want, rtol=1e-8)
+    np.testing.assert_allclose(got[D - 40:D], 1.0 / (0.7 + 1e-12), rtol=1e-12)       # features no worker has seen
+
+
+@pytest.mark.gpu
 def test_device_fixed_effect_at_scale_against_oracle(device_solver):
     """600k samples x 8 non-zeros over 5000 features, weights, unregularised intercept, both model types."""
     rng = np.random.default_rng(0)
@@ -371,13 +406,12 @@ def test_device_hessian_diagonal_and_simple_variance(device_solver, regularize_b
 
 def test_variance_request_is_checked_before_training():
     """fixed_effect_variance_mode FULL beyond what can be inverted fails before any device work, not after the L-BFGS loop
-    (fixed_effect_lr_lbfgs_model.py:291,457 has no limit but memory; here: 4 096 coefficients on the host with any number of
-    workers, 16 384 on the device with one)."""
+    (fixed_effect_lr_lbfgs_model.py:291,457 has no limit but memory; here: 16 384 coefficients, on the device above 4 096,
+    with any number of workers)."""
     fe.check_variance_request("SIMPLE", 10 ** 7, 8)
     fe.check_variance_request("FULL", fe.FULL_VARIANCE_HOST_MAX, 8)
     fe.check_variance_request("FULL", fe.FULL_VARIANCE_DEVICE_MAX, 1)
-    with pytest.raises(ValueError, match="one worker only"):
-        fe.check_variance_request("FULL", fe.FULL_VARIANCE_HOST_MAX + 1, 2)
+    fe.check_variance_request("FULL", fe.FULL_VARIANCE_DEVICE_MAX, 8)     # several workers: the P x P matrix is all-reduced (round 4)
     with pytest.raises(ValueError, match="at most"):
         fe.check_variance_request("FULL", fe.FULL_VARIANCE_DEVICE_MAX + 1, 1)
     with pytest.raises(ValueError, match="unknown variance mode"):

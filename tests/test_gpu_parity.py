@@ -135,9 +135,29 @@ VARIANT_FIXTURES = ["ref_fixture_l2_0.1", "ref_dataset1", "ref_dataset2", "c2_sh
                     "exit_extreme_02", "exit_extreme_03", "ml20m_per_movie_tall", "ml20m_per_user_tall"]
 
 
-@pytest.mark.parametrize("name", VARIANT_FIXTURES)
-def test_register_wave_kernel_matches_reference_fixture(device_solver, name):
-    _solve_and_compare(device_solver, name, kernel_mask=1)
+def test_default_routing_reaches_only_these_classes(device_solver):
+    """Which size classes does the default routing use? BASELINE-shaped batches (C2, C5 / Zipf, MovieLens per-user and per-movie at
+    ML-100K and ML-20M sizes), ragged and tiny ones, wide and tall ones, at m = 10 and (the LDS-resident wavefront kernel's reason
+    to exist) at m = 12: group kernels, the tall kernels, the team kernels — and the wavefront kernel for m > 10 only. Round 1's
+    register wavefront kernel had thirteen classes that none of this reached; they were removed in round 4."""
+    from gdmix_amd.batch import concat
+    from gdmix_amd.solver import NUM_CLASSES
+    shapes = [synthetic.make_survey_batch(4000, 16, 4, 1024, seed=1), synthetic.make_batch(3000, 32, 8, 65536, seed=2, size_dist="zipf"),
+              synthetic.make_movielens_like(600, "per_user", seed=3), synthetic.make_movielens_like(600, "per_movie", seed=4),
+              synthetic.make_movielens_20m("per_user", seed=5, entities=500), synthetic.make_movielens_20m("per_movie", seed=6, entities=900),
+              synthetic.make_ragged_batch(800, seed=7), synthetic.make_batch(300, 1, 2, 16, seed=8, size_dist="const"),
+              synthetic.make_batch(30, 20, 128, 65536, seed=9, size_dist="const"), synthetic.make_batch(3, 9000, 2, 512, seed=10, size_dist="const"),
+              synthetic.make_batch(4, 3000, 1, 400, seed=11, size_dist="const")]      # (n > every group kernel's sample cap, 64 < p <= 512)
+    used = {10: set(), 12: set()}
+    for m in (10, 12):
+        for b in shapes:
+            packed = device_solver.pack(b)
+            res = device_solver.solve(packed, SolverOptions(l2=1.0, regularize_bias=False, m=m, max_iter=5))
+            assert int((res.status < 0).sum().item()) == 0
+            used[m] |= {name.split("<")[0].split(" ")[0] for name, c in device_solver.class_counts(packed) if c > 0}
+    assert len(device_solver.class_counts(packed)) == NUM_CLASSES == 38
+    assert used[10] == {"re_solve_grp_kernel", "re_solve_tall_kernel", "re_solve_team_kernel"}, used[10]
+    assert used[12] == {"re_solve_wave_kernel", "re_solve_team_kernel"}, used[12]      # m > 10: the LDS wavefront kernel and the two-loop block kernel
 
 
 @pytest.mark.parametrize("name", VARIANT_FIXTURES)
@@ -242,7 +262,7 @@ def test_team_lds_vectors_do_not_change_results(device_solver, monkeypatch):
     try:
         packed = device_solver.pack(b)
         p = np.diff(packed.coef_ptr_host())
-        assert p.min() < 200 and 3200 < np.sort(p)[-9] < 5200 and p.max() > 8000      # all three placements occur at the full arena
+        assert p.min() < 200 and 3200 < np.sort(p)[-9] < 5200 and p.max() > 8000      # placements 5, 3 and 1 occur at the full arena (0: arena cut)
         theta0 = np.random.default_rng(5).normal(0, 0.05, packed.P)
         runs = {}
         for kb in ("full", "24", "0"):
