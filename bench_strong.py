@@ -217,7 +217,40 @@ def strong_leg(name, rank, world, solver, opts, coll_dev, c5_entities, steps=2, 
     return out if rank == 0 else None
 
 
-def projection_leg(name, ranks, solver, opts, c5_entities, steps=2, warmup=1, ml_entities=None, tolerance=0.05):
+def _slice_entities(raw, e0, e1):
+    """Entities [e0, e1) of a raw batch in HBM as a raw batch of their own (views; the pointers rebased)."""
+    erp = raw["ent_row_ptr"]
+    r0, r1 = int(erp[e0].item()), int(erp[e1].item())
+    rnp = raw["row_nnz_ptr"]
+    z0, z1 = int(rnp[r0].item()), int(rnp[r1].item())
+    return dict(E=e1 - e0, N=r1 - r0, Z=z1 - z0, ent_row_ptr=erp[e0:e1 + 1] - r0, row_nnz_ptr=rnp[r0:r1 + 1] - z0,
+                col_global=raw["col_global"][z0:z1], val=raw["val"][z0:z1], y=raw["y"][r0:r1], offset=raw["offset"][r0:r1],
+                weight=None if raw["weight"] is None else raw["weight"][r0:r1])
+
+
+def partition_rounds(share, solver, opts, rounds):
+    """The product path's granularity: worker r trains ONE partition per round (drivers/random_effect_driver.py:65-68 walks
+    partitions[r::R]). -> per round the milliseconds (pack + solve, best of two) and non-zeros of this share's partition of that round."""
+    import torch
+    parts = np.unique(share.pid)[:rounds]
+    out = []
+    for K in parts:
+        idx = np.flatnonzero(share.pid == K)
+        raw = _slice_entities(share.raw_dev, int(idx[0]), int(idx[-1]) + 1)
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pk = solver.pack(raw)
+            solver.solve(pk, opts)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) * 1e3
+            best = dt if best is None else min(best, dt)
+        out.append({"partition": int(K), "entities": int(idx.size), "nnz": int(share.z[idx].sum()), "largest_nnz": int(share.z[idx].max()), "ms": best})
+    return out
+
+
+def projection_leg(name, ranks, solver, opts, c5_entities, steps=2, warmup=1, ml_entities=None, tolerance=0.05, rounds=4):
     """One GPU: the `ranks` shares of population `name` one after another (see the module docstring)."""
     import torch
     from gdmix_amd.rebalance import CostModel, choose_entities, plan_transfers
@@ -238,6 +271,8 @@ def projection_leg(name, ranks, solver, opts, c5_entities, steps=2, warmup=1, ml
                     "largest_nnz": int(share.z.max()) if share.E else 0,
                     "generate_s": round(share.gen_s, 2)})
         total_entities, partitions = share.total_entities, share.partitions
+        if name == "c5" and rounds > 0:
+            per[-1]["rounds"] = partition_rounds(share, solver, opts, rounds)
         del share, packed, res
         torch.cuda.empty_cache()
     ms = np.array([p["ms_per_step"] for p in per])
@@ -248,6 +283,19 @@ def projection_leg(name, ranks, solver, opts, c5_entities, steps=2, warmup=1, ml
            "ms": float(ms.max()), "entities_per_s": conv / (float(ms.max()) * 1e-3), "imbalance": float(ms.max() / ms.mean()),
            "sum_of_shares_ms": float(ms.sum()), "per_rank": per}
     assert out["total_entities"] == total_entities
+    if all("rounds" in p for p in per):
+        # one partition per worker and round, all workers in lockstep (what --rebalance_entities balances): a round lasts as long as its
+        # slowest partition
+        rr = []
+        for k in range(min(len(p["rounds"]) for p in per)):
+            ms_k = np.array([p["rounds"][k]["ms"] for p in per])
+            big = max(p["rounds"][k]["largest_nnz"] for p in per)
+            rr.append({"round": k, "ms": [round(float(x), 2) for x in ms_k], "imbalance": float(ms_k.max() / ms_k.mean()), "largest_entity_nnz": int(big)})
+        out["partition_rounds"] = {"what": "the product path's granularity: one partition per worker and round, workers in lockstep; ms = pack + solve of "
+                                           "that partition alone on this device (best of three)", "rounds": rr,
+                                   "mean_imbalance": float(np.mean([r["imbalance"] for r in rr])), "worst_imbalance": float(max(r["imbalance"] for r in rr))}
+        for p in per:
+            del p["rounds"]
     # the re-balancing plan on measured costs (not executed here: the exchange needs the other ranks)
     additive = np.arange(NUM_CLASSES) <= NUM_CLASSES - 5
     model = CostModel.from_totals(totals, additive)

@@ -11,7 +11,7 @@ from ..batch import RawBatch
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "libgdmix_io.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 EXPORTED_SYMBOLS = ("gdmix_io_abi_version", "gdmix_io_last_error", "gdmix_io_read_grouped", "gdmix_io_free", "gdmix_io_pool_trim",
                     "gdmix_io_crc32c", "gdmix_io_masked_crc32c", "gdmix_io_avro_write_models", "gdmix_io_avro_write_scores",
                     "gdmix_io_write_grouped", "gdmix_io_read_examples", "gdmix_io_avro_read_models", "gdmix_io_free_models", "gdmix_io_map_coefficients", "gdmix_io_ids_unique", "gdmix_io_match_ids")

@@ -479,7 +479,7 @@ class RandomEffectLRLBFGSModel:
         num_features = 1 if self.feature_bag_name is None else tensor_metadata.get_feature_shape(self.feature_bag_name)[0]
         key = self._read_key(input_path, num_features)
         if key not in self._prefetched:
-            self._prefetched[key] = self._io_pool.submit(self._read_files, input_path, tensor_metadata, schema_params, num_features)
+            self._prefetched[key] = self._io_pool.submit(self._read_ahead, input_path, tensor_metadata, schema_params, num_features)
 
     def prefetch_prior_model(self, partition_index):
         """Start loading the model file train() will warm-start partition `partition_index` from, if there is one."""
@@ -519,8 +519,11 @@ class RandomEffectLRLBFGSModel:
                 self._write_pool.shutdown(wait=True)
                 self._io_pool = self._write_pool = None
             self._read_cache = None
-            from .io import native_reader
-            native_reader.pool_trim()    # the pooled host blocks (up to GDMIX_IO_POOL_MB + 1 GB of writer buffers) go back to the allocator
+            # the pooled host blocks (up to GDMIX_IO_POOL_MB + 1 GB of writer buffers) go back to the allocator — behind the caller's
+            # back: unmapping 5 GB of touched pages takes 36 - 105 ms (profiles/r04_host_path.txt), a fifth of a warm-started
+            # million-entity run when it was done here in line
+            import threading
+            threading.Thread(target=native_reader.pool_trim, name="gdmix-pool-trim", daemon=True).start()
 
     def _read(self, input_path, tensor_metadata, schema_params, num_features, need_label):
         assert self.model_params.data_format == constants.TFRECORD
@@ -544,6 +547,42 @@ class RandomEffectLRLBFGSModel:
             label_column_name=schema_params.label_column_name, weight_column_name=schema_params.weight_column_name,
             num_features=num_features)
 
+    def _read_ahead(self, input_path, tensor_metadata, schema_params, num_features):
+        """prefetch(): decode the partition and — once the device solver exists — copy its arrays to HBM on a stream of this
+        thread's own, so that the main thread finds the partition resident (the copy of a 125 k-entity C2 partition from
+        pageable memory is 6 of the ~22 ms the main thread spends per partition: profiles/r04_host_path.txt). The first
+        partitions of a run, decoded before the solver exists, are uploaded by the main thread as before."""
+        batch = self._read_files(input_path, tensor_metadata, schema_params, num_features)
+        s = self._solver
+        if isinstance(s, REDeviceSolver) and batch.E > 0 and not self.model_params.rebalance_entities:
+            try:
+                import torch
+                st = self.__dict__.get("_upload_stream")
+                if st is None:
+                    st = self.__dict__.setdefault("_upload_stream", torch.cuda.Stream(device=s.device))
+                with torch.cuda.stream(st):
+                    raw = s.upload(batch)
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                batch._device = (raw, ev)
+            except Exception as e:    # the main thread uploads it then; a real device problem shows up there
+                logger.debug(f"upload ahead of {input_path} failed: {e}")
+        return batch
+
+    def _pack(self, solver, batch):
+        """gdmix_re_pack of a partition; of its copy in HBM when _read_ahead made one."""
+        ahead = batch.__dict__.pop("_device", None) if isinstance(solver, REDeviceSolver) else None
+        if ahead is None:
+            return solver.pack(batch, has_intercept=self.has_intercept)
+        import torch
+        raw, ev = ahead
+        cur = torch.cuda.current_stream(solver.device)
+        cur.wait_event(ev)
+        for v in raw.values():       # allocated on the upload stream, used (and later freed) on this one
+            if isinstance(v, torch.Tensor):
+                v.record_stream(cur)
+        return solver.pack(raw, has_intercept=self.has_intercept)
+
     def _train(self, input_path, tensor_metadata, model_weights, num_features, schema_params, output_model_file):
         logger.info(f"Start training with {f'loaded {len(model_weights)} previous models' if model_weights else 'zeros'} "
                     f"as the model initial value.")
@@ -561,9 +600,10 @@ class RandomEffectLRLBFGSModel:
         # The trained model is updated over the prior model: prior entities that are not in the current data
         # are carried over (random_effect_lr_lbfgs_model.py:155-162).
         model_weights.update(results)
-        logger.info(f"{len(model_weights)} models in total after training/refreshing.")
+        # (the count of the merged table is a hash join of prior and trained ids — 6 ms per 125 k entities: logged by the thread that
+        # writes the file, which needs the join anyway, not by this one)
         self._write_behind(output_model_file, self._save_model, output_model_file, model_coefficients=model_weights, num_features=num_features,
-                           feature_file=self.feature_file)
+                           feature_file=self.feature_file, log_total=True)
         return model_weights
 
     _STAT_KEYS = ("nit", "nfev", "status", "fval", "gnorm")
@@ -611,7 +651,7 @@ class RandomEffectLRLBFGSModel:
             feat_ptr = np.zeros(1, np.int64)
             stats = {k: np.zeros(0) for k in self._STAT_KEYS}
         else:
-            packed = solver.pack(batch, has_intercept=self.has_intercept)
+            packed = self._pack(solver, batch)
             feat_ptr = host_array(packed.ent_feat_ptr())
             uniq = host_array(packed.unique_global())
             theta0 = self._start_point(model_weights, batch.entity_ids, uniq, feat_ptr, batch.E, num_features)
@@ -737,7 +777,7 @@ class RandomEffectLRLBFGSModel:
             return
         solver = self._get_solver()
         if packed is None:
-            packed = solver.pack(batch, has_intercept=self.has_intercept)
+            packed = self._pack(solver, batch)
             feat_ptr = host_array(packed.ent_feat_ptr())
             uniq = host_array(packed.unique_global())
             theta, has_model = _model_coefficients_for_batch(model_weights, batch.entity_ids, uniq, feat_ptr,
@@ -758,7 +798,9 @@ class RandomEffectLRLBFGSModel:
             cache[feature_file] = (fl, native_reader.EncodedFeatures(enc) if native_reader.available() else enc)
         return cache[feature_file]
 
-    def _save_model(self, output_file, model_coefficients, num_features, feature_file):
+    def _save_model(self, output_file, model_coefficients, num_features, feature_file, log_total=False):
+        if log_total:
+            logger.info(f"{len(model_coefficients)} models in total after training/refreshing.")
         feature_list = self._encoded_features(feature_file) if feature_file else None
         if feature_file is None:
             assert num_features == 1   # intercept only model

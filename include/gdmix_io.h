@@ -37,7 +37,7 @@ extern "C" {
 #define GDMIX_IO_ESCHEMA  (-4)   /* a record does not match the schema (missing column, length mismatch, ...) */
 #define GDMIX_IO_ENOMEM   (-5)
 
-#define GDMIX_IO_ABI_VERSION 4
+#define GDMIX_IO_ABI_VERSION 5
 
 typedef struct gdmix_io_schema {
   const char* entity;        /* context key of the entity id (int64 or bytes scalar)                       */

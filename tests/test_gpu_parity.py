@@ -280,6 +280,53 @@ def test_team_lds_vectors_do_not_change_results(device_solver, monkeypatch):
     assert runs["full"][0]["nit"].max() > 5 and np.all(runs["full"][0]["status"] <= 2)
 
 
+def test_tall_kernels_give_the_same_bits_under_concurrent_load(device_solver):
+    """The tall kernels add a sample's products into per-wavefront column accumulators with ds_add_f64, sixteen (or 32) sets per
+    column indexed by lane, so lanes l, l + 16, l + 32, l + 48 of one instruction add to the same address: their bit reproducibility
+    rests on the LDS applying the lanes of an instruction in lane order and a wavefront's instructions in issue order — observed
+    on gfx950, not an architectural promise (csrc/re_solve_tall.hip documents the assumption). This test is the tripwire:
+    MovieLens-20M-shaped entities (all three tall variants) solved twelve times, alone and while two other contexts on their own
+    streams keep the device busy with C2-shaped solves — every run must give the same bits."""
+    import threading
+    from gdmix_amd.solver import REDeviceSolver
+    import torch
+    b = concat_ml = None
+    from gdmix_amd.batch import concat
+    b = concat([synthetic.make_movielens_20m("per_user", seed=81, entities=900), synthetic.make_movielens_20m("per_movie", seed=82, entities=2500)])
+    kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
+    packed = device_solver.pack(b)
+    first = device_solver.solve(packed, SolverOptions(**kw)).to_host()
+    counts = dict(device_solver.class_counts(packed))
+    assert all(counts[k] > 0 for k in ("re_solve_tall_kernel<8> p<=64", "re_solve_tall_kernel<1> p<=64", "re_solve_tall_kernel<1> lean p<=64"))
+    stop = threading.Event()
+
+    def load(seed):
+        s2 = REDeviceSolver(0)
+        st = torch.cuda.Stream()
+        noise = synthetic.make_batch(60_000, 16, 4, 1024, seed=seed)
+        with torch.cuda.stream(st):
+            pk = s2.pack(noise)
+            while not stop.is_set():
+                s2.solve(pk, SolverOptions(**kw))
+                st.synchronize()
+        s2.close()
+    runs = []
+    for phase in ("alone", "loaded"):
+        threads = [threading.Thread(target=load, args=(90 + i,)) for i in range(2)] if phase == "loaded" else []
+        for t in threads:
+            t.start()
+        try:
+            for _ in range(6):
+                runs.append(device_solver.solve(packed, SolverOptions(**kw)).to_host())
+        finally:
+            stop.set()
+            for t in threads:
+                t.join()
+    for r in runs:
+        for k in ("theta", "fval", "gnorm", "nit", "nfev", "status"):
+            assert np.array_equal(first[k], r[k]), k
+
+
 def test_results_are_bitwise_reproducible(device_solver):
     b = synthetic.make_batch(2000, 16, 4, 1024, seed=5)
     packed = device_solver.pack(b)

@@ -106,9 +106,21 @@ with tempfile.TemporaryDirectory() as d:
         if rep == 1:
             shutil.rmtree(os.path.join(d, "models"))
         phases.clear()
+        prof = None
+        if os.environ.get("E2E_PROFILE") and rep >= 1:    # cProfile of the main thread (the pipeline's other threads are not seen)
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         t = time.perf_counter()
         cli.run(argv)
         dt = time.perf_counter() - t
+        if prof is not None:
+            import io
+            import pstats
+            prof.disable()
+            buf = io.StringIO()
+            pstats.Stats(prof, stream=buf).sort_stats("cumulative").print_stats(int(os.environ["E2E_PROFILE"]))
+            print("\n".join(l[:160] for l in buf.getvalue().splitlines() if l.strip()))
         out = sum(os.path.getsize(os.path.join(r, x)) for r, _, fs in os.walk(d) for x in fs if x.endswith(".avro"))
         print(f"{label}: {dt:.2f} s  {E / dt:,.0f} entities/s end to end ({out / 1e6:.0f} MB of Avro written)")
         for k, v in phases.items():
