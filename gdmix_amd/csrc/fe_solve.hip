@@ -382,7 +382,12 @@ __global__ void fe_hot_remap_kernel(const int32_t* __restrict__ ptr, int n, cons
     for (int k = ptr[row]; k < k1; ++k) {
       const int c = col[k];
       const int h = hotmap[c];
-      col2[k] = h >= 0 ? vbase + h * FE_HOT_REP + (row % FE_HOT_REP) : c;
+      // the replica by the entry's POSITION, not by its row (round 4): a wavefront's 128 entries in flight are consecutive in row
+      // order and span only ~4 rows of a 32-non-zero shard, so row % 32 sent all entries of all frequent columns of an instruction to
+      // four replica slots = four LDS bank pairs (replicas of different columns 256 B apart share banks): SQ_LDS_BANK_CONFLICT + 62 %
+      // against a uniform shard (profiles/r04_fe_counters.txt). The position spreads them over all 32; still a fixed assignment, so a
+      // replica's terms are added in row order and two fits give the same bits.
+      col2[k] = h >= 0 ? vbase + h * FE_HOT_REP + (k % FE_HOT_REP) : c;
     }
   }
 }
