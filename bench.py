@@ -536,11 +536,28 @@ def other_workloads_leg(a, rank, world, solver, opts, coll_dev):
             classes = solver.class_counts(packed)
             top = sorted(((float(kernel_ms[c]), classes[c][0], int(classes[c][1])) for c in range(len(classes)) if kernel_ms[c] > 0), reverse=True)[:4]
             n = wl.n
+            # the HBM roofline of this workload's dominant launch, by the same formulas as the headline's (B(e), and the
+            # re-streamed figure, which is the algorithmic one for entities that do not stay on chip: the team kernels)
+            p_e = np.diff(packed.coef_ptr_host())
+            cls_e = packed._view(packed.c.cls_tmp, packed.E, torch.int32).cpu().numpy()
+            dom_c = int(np.argmax(kernel_ms))
+            if classes[dom_c][0].startswith("re_solve_tall_kernel<1> p<=64") and classes[dom_c - 1][0].endswith("lean p<=64") and kernel_ms[dom_c - 1] == 0:
+                cls_e = np.where(cls_e == dom_c - 1, dom_c, cls_e)      # a small lean class ran inside the general launch
+            sel = cls_e == dom_c
+            nfev_e = res.nfev.cpu().numpy().astype(np.float64)
+            b_alg = float((8.0 * wl.z[sel] + 16.0 * n[sel] + 8.0 * p_e[sel] + 32.0).sum())
+            b_str = float((nfev_e[sel] * (8.0 * wl.z[sel] + 16.0 * n[sel]) + 8.0 * p_e[sel] + 32.0).sum())
+            dms = float(kernel_ms[dom_c])
+            roof = {"kernel": classes[dom_c][0], "entities_in_launch": int(sel.sum()), "avg_launch_ms": dms,
+                    "alg_bytes_per_launch": b_alg, "achieved_GBps": b_alg / (dms * 1e-3) / 1e9, "frac_of_hbm_peak": b_alg / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "restreamed_bytes_per_launch": b_str, "restreamed_GBps": b_str / (dms * 1e-3) / 1e9,
+                    "restreamed_frac_of_hbm_peak": b_str / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, "mean_nfev": float(nfev_e[sel].mean()),
+                    "note": "B(e) of SURVEY 8(d) over the launch's entities / its HIP-event duration (last timed step); restreamed = nfev x (8 nnz + 16 n) + 8 p + 32"}
             out[w] = {"what": wl.what, "entities_per_gpu": wl.E, "N": wl.N, "Z": wl.Z, "entities_per_s": conv * steps / dt,
                       "ms_per_step": dt / steps * 1e3, "converged_per_step": conv, "host_generate_s": t_gen,
                       "parity_classes": {"W": int(((wl.ones > 0) & (wl.ones < n)).sum()), "D": int(wl.E - ((wl.ones > 0) & (wl.ones < n)).sum())},
                       "mean_nit": res.nit.double().mean().item(), "mean_nfev": res.nfev.double().mean().item(),
-                      "largest_launches": [{"kernel": k, "entities": e, "ms": round(ms, 3)} for ms, k, e in top]}
+                      "largest_launches": [{"kernel": k, "entities": e, "ms": round(ms, 3)} for ms, k, e in top], "roofline": roof}
         del wl, packed, res
         torch.cuda.empty_cache()
     return out if rank == 0 else None

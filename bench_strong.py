@@ -116,7 +116,7 @@ def _entity_classes(packed, torch):
     return packed._view(packed.c.cls_tmp, packed.E, torch.int32).cpu().numpy()
 
 
-def strong_leg(name, rank, world, solver, opts, coll_dev, c5_entities, steps=2, warmup=1, rebalance=True, ml_entities=None, tolerance=0.05):
+def strong_leg(name, rank, world, solver, opts, coll_dev, c5_entities, steps=2, warmup=1, rebalance=True, ml_entities=None, tolerance=0.05, rounds=4):
     """Every rank: its share of population `name`, `steps` timed steps. -> dict on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
@@ -214,7 +214,85 @@ def strong_leg(name, rank, world, solver, opts, coll_dev, c5_entities, steps=2, 
             "per_rank": [{"rank": int(r[0]), "exchange_ms": float(r[1]), "widen_pack_ms": float(r[2]), "solve_ms": float(r[3]), "give_back_ms": float(r[4]),
                           "wait_ms": float(r[5]), "bytes_sent": int(r[6]), "bytes_received": int(r[7]), "entities_sent": int(r[8]),
                           "predicted_cost_ms": float(r[11])} for r in rrows]}
+    if name == "c5" and rounds > 0 and world > 1:
+        out["partition_rounds"] = _rounds_leg(share, rank, world, solver, opts, coll_dev, rounds, rebalance, tolerance, gather_rows)
     return out if rank == 0 else None
+
+
+def _rounds_leg(share, rank, world, solver, opts, coll_dev, rounds, rebalance, tolerance, gather_rows):
+    """The product path's granularity with ranks: every worker trains ONE partition per round, in lockstep (model.py with
+    --rebalance_entities). Per round: the plain pack + solve of each worker's partition, then the same round through the re-balancer,
+    whose cost model (rebalance.SizeCostModel) is what the rounds before it measured — the first round prices by non-zeros."""
+    import torch
+    import torch.distributed as dist
+    from gdmix_amd.rebalance import Rebalancer, SizeCostModel, _Comm
+    from gdmix_amd.solver import NUM_CLASSES
+    sync = torch.cuda.synchronize
+    parts = np.unique(share.pid)
+    nr = int(gather_rows([min(rounds, parts.size)])[:, 0].min())
+    comm = _Comm(None, solver.device)
+    model = SizeCostModel()
+    totals = np.zeros((2, SizeCostModel.BUCKETS))
+    out = []
+    for k in range(nr):
+        idx = np.flatnonzero(share.pid == parts[k])
+        raw = _slice_entities(share.raw_dev, int(idx[0]), int(idx[-1]) + 1)
+        n_k, z_k = share.n[idx], share.z[idx]
+        solver.pack(raw); sync()      # (first touch of this partition's pages: not part of either timing)
+        dist.barrier()
+        t0 = time.perf_counter()
+        pk = solver.pack(raw)
+        rs = solver.solve(pk, opts)
+        sync()
+        plain = (time.perf_counter() - t0) * 1e3
+        dist.barrier()
+        plain_job = (time.perf_counter() - t0) * 1e3
+        class_ms = np.array(solver.last_solve_ms())
+        cls = _entity_classes(pk, torch)
+        theta_plain = rs.theta_thr.clone()
+        row = {"round": k, "partition": int(parts[k]), "entities": int(idx.size), "nnz": int(z_k.sum())}
+        reb = None
+        if rebalance:
+            wire = _wire_from_raw(raw)
+            sync(); dist.barrier()
+            t0 = time.perf_counter()
+            rb = Rebalancer(n_k, z_k, wire, cost=model.cost(z_k), order=model.order(z_k), comm=comm, tolerance=tolerance)
+            b0 = comm.bytes_sent
+            work = rb.exchange()
+            pk2 = solver.pack(solver.widen(work))
+            rs2 = solver.solve(pk2, opts)
+            fp = pk2.ent_feat_ptr()
+            ints = torch.stack([rs2.nit, rs2.nfev, rs2.status], dim=1)
+            flts = torch.stack([rs2.fval, rs2.gnorm], dim=1)
+            _, th, _, _, _, _ = rb.give_back((fp[1:] - fp[:-1]) + 1, rs2.theta_thr, None, pk2.unique_global(), ints, flts)
+            sync()
+            mine = (time.perf_counter() - t0) * 1e3
+            dist.barrier()
+            job = (time.perf_counter() - t0) * 1e3
+            scale = torch.clamp(theta_plain.abs(), min=1e-3)
+            diff = float(((th - theta_plain).abs() / scale).max().item()) if th.numel() else 0.0
+            reb = [mine, job, comm.bytes_sent - b0, sum(int(x.size) for x in rb.sent), diff]
+            del rb, work, pk2, rs2, th
+        # what this round measured prices the next one (summed over ranks)
+        tt = torch.from_numpy(SizeCostModel.totals(cls, z_k, class_ms, NUM_CLASSES)).to(coll_dev)
+        dist.all_reduce(tt)
+        totals += tt.cpu().numpy()
+        model = SizeCostModel.from_totals(totals)
+        rows = gather_rows([plain, plain_job] + (reb or [0, 0, 0, 0, 0]))
+        row.update(plain_ms=[round(float(x), 2) for x in rows[:, 0]], plain_round_ms=float(rows[:, 1].max()),
+                   imbalance=float(rows[:, 0].max() / rows[:, 0].mean()))
+        if rebalance:
+            row.update(rebalanced_ms=[round(float(x), 2) for x in rows[:, 2]], rebalanced_round_ms=float(rows[:, 3].max()),
+                       bytes_sent=[int(x) for x in rows[:, 4]], entities_sent=[int(x) for x in rows[:, 5]],
+                       max_rel_diff_vs_plain=float(rows[:, 6].max()), priced_by="non-zeros" if k == 0 else f"measured costs of rounds 0..{k - 1}")
+        out.append(row)
+        del pk, rs, raw
+    res = {"what": "one partition per worker and round, workers in lockstep: plain pack + solve, then the same round through Rebalancer.exchange / "
+                   "give_back priced by what the rounds before it measured (rebalance.SizeCostModel)", "rounds": out,
+           "plain_ms_total": float(sum(r["plain_round_ms"] for r in out))}
+    if rebalance and out:
+        res["rebalanced_ms_total"] = float(sum(r["rebalanced_round_ms"] for r in out))
+    return res
 
 
 def _slice_entities(raw, e0, e1):

@@ -430,7 +430,9 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   // ends in a thin tail): it then runs with the class behind it — its entities sit right in front of that class's in `order`, and
   // the general one-wavefront kernel takes any of them. An entity's result does not depend on which of the two ran it: same
   // accumulator sets, same order of the adds (the variants differ in where loads are issued and in occupancy only).
-  const int lean_merged = (hc[TALL_L_CLASS] > 0 && hc[TALL_L_CLASS] < 4 * ctx->impl.num_cus * TALL_LEAN_WGS) ? hc[TALL_L_CLASS] : 0;
+  int lean_rounds = 4;   // (GDMIX_RE_LEAN_MERGE_ROUNDS: exploration knob)
+  if (const char* ev = getenv("GDMIX_RE_LEAN_MERGE_ROUNDS")) lean_rounds = atoi(ev);
+  const int lean_merged = (hc[TALL_L_CLASS] > 0 && hc[TALL_L_CLASS] < lean_rounds * ctx->impl.num_cus * TALL_LEAN_WGS) ? hc[TALL_L_CLASS] : 0;
   int n_launch_classes = 0;
   for (int c = 0; c < GDMIX_RE_NUM_CLASSES; ++c) n_launch_classes += (hc[c] > 0 && !(c == TALL_L_CLASS && lean_merged)) ? 1 : 0;
   hipStream_t const s_main = s;

@@ -407,6 +407,9 @@ class RandomEffectLRLBFGSModel:
             dev = self._device_index
             if dev is None:
                 dev = int(os.environ.get("LOCAL_RANK", "0"))
+                if os.environ.get("GDMIX_RANKS_SHARE_DEVICE") == "1":    # test hook for a 1-GPU box: several ranks on one device (gloo)
+                    import torch
+                    dev %= max(1, torch.cuda.device_count())
             self._solver = REDeviceSolver(dev)   # raises if no MI355X / no library: there is no CPU fallback
         return self._solver
 
@@ -697,7 +700,14 @@ class RandomEffectLRLBFGSModel:
         ic = 1 if self.has_intercept else 0
         on_device = hasattr(solver, "widen")
         dev = solver.device if on_device else torch.device("cpu")
-        rb = Rebalancer(batch.ent_n(), batch.ent_nnz(), wire_tensors(batch, dev, solver if on_device else None))
+        # what the rounds so far measured prices this round's entities (rebalance.SizeCostModel: milliseconds per non-zero by entity
+        # size, summed over the workers); the first round, and the CPU stand-in of the host tests, price by non-zeros
+        scm = self.__dict__.get("_size_cost")
+        nnz = batch.ent_nnz()
+        if on_device:
+            solver.set_timing(True)
+        rb = Rebalancer(batch.ent_n(), nnz, wire_tensors(batch, dev, solver if on_device else None),
+                        cost=None if scm is None else scm.cost(nnz), order=None if scm is None else scm.order(nnz))
         prior = model_weights.rows_for(batch.entity_ids) if (with_prior and model_weights) else None
         work = rb.exchange(prior=prior, with_prior=with_prior)
         E_work = work["E"]
@@ -736,6 +746,26 @@ class RandomEffectLRLBFGSModel:
                 flts = torch.stack([as_t(r[k], torch.float64) for k in ("fval", "gnorm")], dim=1)
             cc = (fp_dev[1:] - fp_dev[:-1]) + ic
             fi = uq_dev
+        if on_device:
+            # this round's class times, attributed to the entities solved HERE by size, summed over the workers (every worker joins,
+            # also one that solved nothing)
+            import torch.distributed as dist
+            from .rebalance import SizeCostModel
+            from .solver import NUM_CLASSES
+            tot = np.zeros((2, SizeCostModel.BUCKETS))
+            if E_work > 0:
+                znz = packed.ent_nnz_ptr()
+                tot = SizeCostModel.totals(host_array(packed._view(packed.c.cls_tmp, packed.E, torch.int32)), host_array(znz[1:] - znz[:-1]),
+                                           np.array(solver.last_solve_ms()), NUM_CLASSES)
+            tt = torch.from_numpy(tot)
+            if dist.get_backend() == "nccl":
+                td = tt.to(dev)
+                dist.all_reduce(td)
+                tt = td.cpu()
+            else:
+                dist.all_reduce(tt)
+            self._size_totals = self.__dict__.get("_size_totals", 0.0) + tt.numpy()
+            self._size_cost = SizeCostModel.from_totals(self._size_totals)
         self.last_exchange_devices = (str(work["val"].device), str(th.device))   # (tests: the payload never left the device)
         my_cc, theta_thr, variance, uniq, ints, flts = rb.give_back(cc, th, va, fi, ints, flts, has_intercept=self.has_intercept)
         my_cc, theta_thr, uniq = host_array(my_cc), host_array(theta_thr), host_array(uniq)

@@ -119,6 +119,56 @@ class CostModel:
         return ok[key]
 
 
+class SizeCostModel:
+    """CostModel for entities that have not been classified yet (the next partition of a running job): the measured class times
+    of the partitions solved so far, attributed to their entities by non-zeros and summed per SIZE bucket (floor(log2(nnz + 1))),
+    price a non-zero of an entity of that size. Entities at or above `team_nnz` (the multi-workgroup team tiers: their launch time
+    is the longest entity's critical path, not a sum) are priced but never offered for travel. `totals` of all ranks are added up
+    (all-reduce) so that every rank prices an entity the same; a bucket nobody has seen yet takes its nearest neighbour's rate.
+    Before any measurement exists the cost is the non-zero count (rate 1 everywhere)."""
+    BUCKETS = 40
+
+    def __init__(self, rate=None, team_nnz=16384):
+        self.rate = np.ones(self.BUCKETS) if rate is None else np.asarray(rate, np.float64)
+        self.team_nnz = int(team_nnz)
+
+    @classmethod
+    def bucket(cls, nnz):
+        return np.minimum(np.floor(np.log2(np.asarray(nnz, np.float64) + 1.0)).astype(np.int64), cls.BUCKETS - 1)
+
+    @classmethod
+    def totals(cls, ent_cls, nnz, class_ms, num_classes):
+        """[2, BUCKETS]: milliseconds and non-zeros per size bucket of one timed solve (entity classes from the solve, per-class ms)."""
+        ent_cls = np.asarray(ent_cls, np.int64)
+        w = np.asarray(nnz, np.float64) + 64.0
+        per_class = np.bincount(ent_cls, weights=w, minlength=num_classes)[:num_classes]
+        ms = np.asarray(class_ms, np.float64)[:num_classes]
+        # a class without a launch of its own ran inside a neighbour's: its entities share that launch's time
+        share = np.where(per_class > 0, ms / np.maximum(per_class, 1.0), 0.0)
+        cost = share[ent_cls] * w
+        b = cls.bucket(nnz)
+        return np.stack([np.bincount(b, weights=cost, minlength=cls.BUCKETS), np.bincount(b, weights=w, minlength=cls.BUCKETS)])
+
+    @classmethod
+    def from_totals(cls, totals, team_nnz=16384):
+        ms, z = np.asarray(totals, np.float64)
+        rate = np.where((z > 0) & (ms > 0), ms / np.maximum(z, 1.0), 0.0)
+        seen = np.flatnonzero(rate > 0)
+        if seen.size == 0:
+            return cls(None, team_nnz)
+        for k in np.flatnonzero(rate == 0):
+            rate[k] = rate[seen[np.argmin(np.abs(seen - k))]]
+        return cls(rate, team_nnz)
+
+    def cost(self, nnz):
+        return self.rate[self.bucket(nnz)] * (np.asarray(nnz, np.float64) + 64.0)
+
+    def order(self, nnz):
+        nnz = np.asarray(nnz)
+        ok = np.flatnonzero(nnz < self.team_nnz)
+        return ok[np.lexsort((ok, nnz[ok], -self.rate[self.bucket(nnz[ok])]))]
+
+
 def _segments(t, starts, lens, total):
     """Indices of the concatenated ranges [starts[k], starts[k] + lens[k]) as an int64 tensor on the tensors' device; `total`
     = sum(lens), known on the host (no device synchronisation)."""

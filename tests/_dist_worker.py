@@ -24,7 +24,7 @@ def main():
     model = RandomEffectLRLBFGSModel(argv)
     real = os.environ.get("GDMIX_TEST_DEVICE_SOLVER") == "1"   # -m gpu on a box with a GPU per rank: the product path, RCCL
     if real:
-        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]) % torch.cuda.device_count())   # (1-GPU box: the ranks share it, GDMIX_RANKS_SHARE_DEVICE)
     else:
         model._solver = OracleSolverDouble()
     # record what every re-balancing round did on this rank

@@ -117,6 +117,10 @@ def test_strong_scaling_splits_one_population_and_rebalancing_returns_the_same_m
     assert rb["status_equal"] == total and rb["max_rel_diff_vs_plain"] <= 1e-7
     assert sum(r["bytes_sent"] for r in rb["per_rank"]) == sum(r["bytes_received"] for r in rb["per_rank"])
     assert all(r["solve_ms"] > 0 for r in rb["per_rank"])
+    if workload == "c5":      # ... and at the product path's granularity: one partition per worker and round, priced by the rounds before
+        pr = s["partition_rounds"]
+        assert len(pr["rounds"]) >= 2 and pr["rounds"][0]["priced_by"] == "non-zeros" and pr["rounds"][1]["priced_by"].startswith("measured")
+        assert all(r["max_rel_diff_vs_plain"] <= 1e-7 and len(r["plain_ms"]) == 2 for r in pr["rounds"])
 
 
 @pytest.mark.gpu

@@ -146,14 +146,38 @@ def test_two_ranks_rebalance_over_rccl_when_the_box_has_two_gpus(tmp_path):
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs: one process per GPU")
+    _two_ranks_on_the_product_path(tmp_path, "nccl")
+
+
+@pytest.mark.gpu
+def test_two_ranks_rebalance_on_the_product_path_sharing_one_gpu(tmp_path):
+    """The product path of the exchange with the device solver and two ranks on a 1-GPU box: both ranks on cuda:0
+    (GDMIX_RANKS_SHARE_DEVICE, a test hook), the process group gloo, the exchange's device tensors staged through the host by
+    rebalance._Comm — everything else (wire form in HBM, gather of the travelling entities on the device, widen + pack + solve where
+    they land, the measured cost model from the second round on, give-back, one read-back by the owner) is what RCCL ranks run."""
+    _two_ranks_on_the_product_path(tmp_path, "gloo")
+
+
+def _two_ranks_on_the_product_path(tmp_path, backend):
     heavy, light, third = _skewed_partitions(tmp_path)
-    plain = _run(tmp_path, "plain", False, device_solver=True)
-    moved = _run(tmp_path, "rebalanced", True, device_solver=True)
+    import os as _os
+    share = {"GDMIX_RANKS_SHARE_DEVICE": "1"} if backend == "gloo" else {}
+    old = {k: _os.environ.get(k) for k in share}
+    _os.environ.update(share)
+    try:
+        plain = _run(tmp_path, "plain", False, device_solver=True)
+        moved = _run(tmp_path, "rebalanced", True, device_solver=True)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                _os.environ.pop(k, None)
+            else:
+                _os.environ[k] = v
     for k, b in enumerate((heavy, light, third)):
         a = list(avro.read_file(str(plain / "models" / f"part-{k:05d}.avro")))
         r = list(avro.read_file(str(moved / "models" / f"part-{k:05d}.avro")))
         assert len(a) == b.E and a == r
     res = json.load(open(moved / "result.json"))
-    assert res["backend"] == "nccl"
+    assert res["backend"] == backend
     rounds = res["rebalance"]
     assert rounds[0][0]["sent"][1] > 0 and rounds[0][0]["device"].startswith("cuda") and rounds[1][1]["device"].startswith("cuda")

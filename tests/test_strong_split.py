@@ -84,3 +84,43 @@ def test_two_gloo_ranks_exchange_by_measured_cost_and_get_their_results_back(tmp
     mean = sum(r0["loads"]) / 2
     assert abs(r0["load_after"] - mean) < 0.08 * mean                      # the donor ends near the mean
     assert r0["bytes_sent"] > 0 and r0["bytes_sent"] == r1["bytes_received"] - 0 * r1["bytes_sent"] or r0["bytes_sent"] > 0
+
+
+def test_partition_directory_is_the_reference_layout(tmp_path):
+    """gdmix_amd.partition_dirs (bench.py's end-to-end legs, the -m gpu CLI test): entities land in partitionId=K by the Java hash of
+    their id, in input order; metadata, feature list and partition list are what the trainer's CLI takes (contract B3)."""
+    from gdmix_amd.io.grouped_reader import read_grouped_partition
+    from gdmix_amd.io.metadata import DatasetMetadata
+    from gdmix_amd.partition_dirs import write_partition_dir
+    b = synthetic.make_survey_batch(300, 6, 4, 128, seed=3, with_uid=True)
+    argv, members, size = write_partition_dir(str(tmp_path), b, 4, 128)
+    assert size > 0 and sorted(members) == [0, 1, 2, 3] and sum(v.size for v in members.values()) == b.E
+    for k, own in members.items():
+        assert all(java_partition_id(b.entity_ids[e], 4) == k for e in own) and np.all(np.diff(own) > 0)
+    assert open(tmp_path / "plist.txt").read() == "0,1,2,3"
+    md = DatasetMetadata(json.load(open(tmp_path / "meta.json")))
+    back = read_grouped_partition(str(tmp_path / "train" / "active" / "partitionId=2"), md, entity_name="ent", feature_bag="bag", offset_column_name="offset",
+                                  uid_column_name="uid", label_column_name="response", weight_column_name=None, num_features=128)
+    want = b.select(members[2])
+    assert list(back.entity_ids) == list(want.entity_ids)
+    for name in ("ent_row_ptr", "row_nnz_ptr", "col_global", "val", "y", "offset", "uid"):
+        np.testing.assert_array_equal(getattr(back, name), getattr(want, name))
+    assert "--stage=random_effect" in argv and f"--training_data_dir={tmp_path}/train" in argv and "--partition_entity=ent" in argv
+
+
+def test_a_partition_of_a_share_is_a_batch_of_its_own():
+    """bench_strong._slice_entities (the per-partition rounds of the projection): entities [e0, e1) of a resident raw batch as views with
+    rebased pointers — the same arrays RawBatch.select gives."""
+    import sys
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench_strong
+    b = synthetic.make_ragged_batch(60, seed=9)
+    raw = dict(E=b.E, N=b.N, Z=b.Z, ent_row_ptr=torch.from_numpy(b.ent_row_ptr), row_nnz_ptr=torch.from_numpy(b.row_nnz_ptr),
+               col_global=torch.from_numpy(b.col_global), val=torch.from_numpy(b.val), y=torch.from_numpy(b.y), offset=torch.from_numpy(b.offset),
+               weight=torch.from_numpy(b.weight))
+    sub = bench_strong._slice_entities(raw, 17, 41)
+    want = b.select(np.arange(17, 41))
+    assert (sub["E"], sub["N"], sub["Z"]) == (want.E, want.N, want.Z)
+    for k in ("ent_row_ptr", "row_nnz_ptr", "col_global", "val", "y", "offset", "weight"):
+        np.testing.assert_array_equal(sub[k].numpy(), getattr(want, k))
