@@ -124,3 +124,29 @@ def test_a_partition_of_a_share_is_a_batch_of_its_own():
     assert (sub["E"], sub["N"], sub["Z"]) == (want.E, want.N, want.Z)
     for k in ("ent_row_ptr", "row_nnz_ptr", "col_global", "val", "y", "offset", "weight"):
         np.testing.assert_array_equal(sub[k].numpy(), getattr(want, k))
+
+
+def test_size_cost_model_prices_unclassified_entities_by_what_was_measured():
+    """rebalance.SizeCostModel: the next partition's entities have no size class yet; the class times of the solves so far,
+    attributed by non-zeros and summed per size bucket, price them. Before any measurement: the non-zero count."""
+    from gdmix_amd.rebalance import SizeCostModel
+    fresh = SizeCostModel()
+    nnz = np.array([10, 20, 100, 5000, 20000, 300, 40, 8000])
+    assert np.allclose(fresh.cost(nnz), nnz + 64.0) and 4 not in fresh.order(nnz)           # 20 000 >= 16 384: a team-tier entity never travels
+    cls = np.array([0, 0, 1, 2, 3, 1, 0, 2])
+    ms = np.array([0.1, 0.4, 3.0, 9.0])
+    tot = SizeCostModel.totals(cls, nnz, ms, 4)
+    assert tot.shape == (2, SizeCostModel.BUCKETS) and np.isclose(tot[0].sum(), ms.sum())   # every launch's time is handed out once
+    m = SizeCostModel.from_totals(tot + tot)                                                # two ranks with the same measurement: same rates
+    cost = m.cost(nnz)
+    assert np.isclose(cost.sum(), ms.sum(), rtol=1e-12)                                     # (same entities: the costs add up to the launches)
+    assert cost[4] > cost[3] > cost[2] > cost[0]
+    order = m.order(nnz)
+    assert 4 not in order and set(order) == {0, 1, 2, 3, 5, 6, 7}
+    rate = m.rate[SizeCostModel.bucket(nnz[order])]
+    assert np.all(np.diff(rate) <= 1e-18)                                                   # costliest per non-zero first
+    unseen = SizeCostModel.bucket(np.array([3_000_000]))[0]
+    assert m.rate[unseen] == m.rate[SizeCostModel.bucket(np.array([20000]))[0]]             # an unseen size takes its nearest neighbour's rate
+    # a class with entities and no launch of its own (ran inside a neighbour's) does not create cost out of nothing
+    tot2 = SizeCostModel.totals(cls, nnz, np.array([0.1, 0.0, 3.0, 9.0]), 4)
+    assert np.isclose(tot2[0].sum(), 12.1)
