@@ -104,32 +104,45 @@ static void logits_(const problem* P, const double* th, double* z) {
  * tools/fuzz_fe.py case 5). So the sums over samples and over coefficients of the sum_loss objective are accumulated
  * in long double here: 11 more mantissa bits stand in for the blocked reductions. The random-effect objective
  * (n ~ 10^1 .. 10^3, pinned bit-tight against the reference's fixtures) keeps its plain fp64 sums. */
+/* ORACLE_FE_NARROW=1 (tools/fuzz_fe.py, detail mode): every wide accumulator is rounded to double after each addition, i.e. the
+ * sums become plain fp64 running sums in sample order — another legitimate fp64 evaluation of the same objective. Used to measure how
+ * far a fit moves under EVALUATION-level rounding (a start perturbation is damped by the first iterations; rounding in every
+ * evaluation is not), which is the perturbation a device kernel with another summation order applies. */
+static int fe_narrow_(void) {
+  const char* e = getenv("ORACLE_FE_NARROW");   /* read at every evaluation: the tool switches it between two solves of one process */
+  return (e && e[0] == '1') ? 1 : 0;
+}
+#define WIDE_ROUND(x) do { if (narrow) (x) = (long double)(double)(x); } while (0)
 static double fg_wide_(const problem* P, const double* th, double* g) {
   const int n = P->n, p = P->p, ic = P->ic;
+  const int narrow = fe_narrow_();
   logits_(P, th, P->z);
   long double cost = 0.0L, rsum = 0.0L;
   for (int i = 0; i < n; ++i) {
     double zi = P->z[i], yi = (double)P->y[i], wi = P->w ? (double)P->w[i] : 1.0;
     if (P->linear) {
       cost += (long double)(wi * (yi - zi) * (yi - zi));
+      WIDE_ROUND(cost);
       P->r[i] = 2.0 * wi * (zi - yi);
     } else {
       double ce = fmax(zi, 0.0) - zi * yi + log(1.0 + exp(-fabs(zi)));
       cost += (long double)(wi * ce);
+      WIDE_ROUND(cost);
       P->r[i] = wi * (expit_(zi) - yi);
     }
     rsum += (long double)P->r[i];
+    WIDE_ROUND(rsum);
   }
   int first_reg = (ic && !P->reg_bias) ? 1 : 0;
   long double sq = 0.0L;
-  for (int j = first_reg; j < p; ++j) sq += (long double)(th[j] * th[j]);
+  for (int j = first_reg; j < p; ++j) { sq += (long double)(th[j] * th[j]); WIDE_ROUND(sq); }
   double f = (double)(cost + (long double)(P->l2 / 2.0) * sq);
   long double* gw = (long double*)malloc((size_t)(p > 0 ? p : 1) * sizeof(long double));
   for (int j = 0; j < p; ++j) gw[j] = 0.0L;
   if (ic) gw[0] = rsum;
   for (int i = 0; i < n; ++i)
     for (int k = P->row_ptr[i]; k < P->row_ptr[i + 1]; ++k)
-      gw[ic + P->col[k]] += (long double)((double)P->val[k] * P->r[i]);
+    { gw[ic + P->col[k]] += (long double)((double)P->val[k] * P->r[i]); WIDE_ROUND(gw[ic + P->col[k]]); }
   for (int j = 0; j < p; ++j) {
     double reg = P->l2 * th[j];
     if (j < first_reg) reg = 0.0;
@@ -360,7 +373,7 @@ void oracle_branch_counts(long long* out, int reset) {
 
 static __thread int g_wide_dots = 0;   /* set per solve: the fixed-effect coefficient space has 10^4 .. 10^6 dimensions (see fg_wide_) */
 static double dot_(const double* a, const double* b, int n) {
-  if (g_wide_dots) {
+  if (g_wide_dots && !fe_narrow_()) {
     long double s = 0.0L;
     for (int i = 0; i < n; ++i) s += (long double)(a[i] * b[i]);
     return (double)s;

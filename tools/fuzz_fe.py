@@ -3,6 +3,7 @@ kernel against the CPU oracle on seeded random shards. A tool for the GPU box, n
 
     PYTHONPATH=.:tests python tools/fuzz_fe.py [cases] [first_seed]
 """
+import os
 import sys
 import time
 
@@ -82,7 +83,59 @@ for case in range(cases):
         pert = oracle.solve(pk, batch.val, batch.y, batch.offset, batch.weight, o, theta0=jig if t0l is None else t0l * (1.0 + jig))
         sens = max(sens, rel_err(pert["theta"], res["theta"]))
         stable = stable and int(pert["nit"][0]) == int(res["nit"][0]) and int(pert["status"][0]) == int(res["status"][0])
+    # ... and from the same start with rounding in EVERY evaluation: the oracle with plain fp64 running sums instead of its long-double
+    # accumulators (ORACLE_FE_NARROW) — what a kernel with another summation order applies; a start perturbation is damped by the
+    # first iterations, this one is not (profiles/r04_fuzz.txt, cases 1100036 and 1100226)
+    os.environ["ORACLE_FE_NARROW"] = "1"
+    try:
+        pert = oracle.solve(pk, batch.val, batch.y, batch.offset, batch.weight, o, theta0=t0l)
+    finally:
+        os.environ.pop("ORACLE_FE_NARROW", None)
+    sens = max(sens, rel_err(pert["theta"], res["theta"]))
+    stable = stable and int(pert["nit"][0]) == int(res["nit"][0]) and int(pert["status"][0]) == int(res["status"][0])
     stable = stable and sens < 1e-9
+    if os.environ.get("FUZZ_FE_DETAIL"):
+        # one case in detail (FUZZ_FE_DETAIL=1 python tools/fuzz_fe.py 1 <seed>): objective values, counts, and the oracle under a wider
+        # set of start perturbations — is the disagreement larger than what the reference's own arithmetic does to itself?
+        print(f"oracle           status {int(res['status'][0])} nit {int(res['nit'][0])} nfev {int(res['nfev'][0])} f {res['fval'][0]:.12g} |g| {res['gnorm'][0]:.3e}")
+        for name, th, info in (("stepping", th_step, info_step), ("team", th_team, info_team)):
+            if th is not None:
+                print(f"device {name:9s} status {int(info['status'])} nit {int(info['nit'])} nfev {int(info['nfev'])} f {float(info['fval']):.12g} |g| {float(info['gnorm']):.3e} "
+                      f"theta rel err vs oracle {rel_err(th, th_o):.2e}")
+        for j, mag in enumerate((1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10, 1e-13, 1e-12, 1e-11, 1e-10)):
+            jig = mag * np.random.default_rng(100 + j).standard_normal(P_loc)
+            pert = oracle.solve(pk, batch.val, batch.y, batch.offset, batch.weight, o, theta0=jig if t0l is None else t0l * (1.0 + jig))
+            print(f"oracle, start noise {mag:.0e}: status {int(pert['status'][0])} nit {int(pert['nit'][0])} nfev {int(pert['nfev'][0])} f {pert['fval'][0]:.12g} "
+                  f"theta rel err vs oracle {rel_err(pert['theta'], res['theta']):.2e}")
+    if os.environ.get("FUZZ_FE_DETAIL"):
+        # ... and the oracle with plain fp64 running sums instead of its long-double accumulators (ORACLE_FE_NARROW): rounding in EVERY
+        # evaluation, which is what a kernel with another summation order applies — a start perturbation is damped by the first iterations
+        os.environ["ORACLE_FE_NARROW"] = "1"
+        try:
+            nar = oracle.solve(pk, batch.val, batch.y, batch.offset, batch.weight, o, theta0=t0l)
+        finally:
+            os.environ.pop("ORACLE_FE_NARROW", None)
+        print(f"oracle, fp64 running sums: status {int(nar['status'][0])} nit {int(nar['nit'][0])} nfev {int(nar['nfev'][0])} f {nar['fval'][0]:.12g} "
+              f"theta rel err vs oracle {rel_err(nar['theta'], res['theta']):.2e}")
+    if os.environ.get("FUZZ_FE_ITERS"):
+        # iteration by iteration: the same fit cut off after k iterations, device (stepping kernels) against the oracle — do the two
+        # trajectories part gradually (rounding amplified by the problem) or at once (a defect)?
+        for kk in [int(x) for x in os.environ["FUZZ_FE_ITERS"].split(",")]:
+            kw_k = dict(kw, max_iter=kk)
+            th_k, info_k = s.fit_stepping(rp, cols, vals, y, D, **kw_k)
+            o_k = oracle.make_opts(l2=l2, regularize_bias=regb and ic, has_intercept=ic, m=m, max_iter=kk, threshold=0.0, sum_loss=True, linear=linear)
+            r_k = oracle.solve(pk, batch.val, batch.y, batch.offset, batch.weight, o_k, theta0=t0l)
+            jig = 1e-13 * np.random.default_rng(7).standard_normal(P_loc)
+            r_j = oracle.solve(pk, batch.val, batch.y, batch.offset, batch.weight, o_k, theta0=jig if t0l is None else t0l * (1.0 + jig))
+            os.environ["ORACLE_FE_NARROW"] = "1"
+            try:
+                r_n = oracle.solve(pk, batch.val, batch.y, batch.offset, batch.weight, o_k, theta0=t0l)
+            finally:
+                os.environ.pop("ORACLE_FE_NARROW", None)
+            tho_k = fe.to_global(r_k["theta"], pk["unique_global"], Dg, ic, False)
+            print(f"max_iter {kk:3d}: oracle nit {int(r_k['nit'][0])} nfev {int(r_k['nfev'][0])} f {r_k['fval'][0]:.12g} | device nit {int(info_k['nit'])} nfev {int(info_k['nfev'])} "
+                  f"f {float(info_k['fval']):.12g} theta rel err {rel_err(th_k, tho_k):.2e} | oracle + 1e-13 start noise: {rel_err(r_j['theta'], r_k['theta']):.2e} | "
+                  f"oracle with fp64 running sums: nfev {int(r_n['nfev'][0])} f {r_n['fval'][0]:.12g} theta rel err {rel_err(r_n['theta'], r_k['theta']):.2e}")
     problems = []
     for name, th, info in (("stepping", th_step, info_step), ("team", th_team, info_team)):
         if th is None:
