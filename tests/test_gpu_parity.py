@@ -5,6 +5,8 @@ Bars (BASELINE.json north_star): coefficients within 1e-5 relative error of the 
 result on well-posed entities — asserted here two orders tighter (1e-7) — and bit-exact integer work
 (np.unique / local indices / CSC order / partition ids).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -322,6 +324,60 @@ def test_tall_kernels_give_the_same_bits_under_concurrent_load(device_solver):
             stop.set()
             for t in threads:
                 t.join()
+    for r in runs:
+        for k in ("theta", "fval", "gnorm", "nit", "nfev", "status"):
+            assert np.array_equal(first[k], r[k]), k
+
+
+def test_team_tiers_give_the_same_bits_run_after_run_under_load(device_solver):
+    """The multi-workgroup team kernels hand x, the residuals and the partial sums from workgroup to workgroup through HBM/L2 at
+    every barrier; since round 4 a team whose workgroups all sit on one XCD skips the L2 write-back of the release (measured
+    placement, csrc/re_solve_team.hpp: team_placement). A stale read would not crash, it would change a sum: the tripwire is that a
+    batch solved twenty times — alone, and while two other contexts keep the device busy (uneven load, warm L1s) — gives the same
+    bits every time, with the fast barrier and with the full one (GDMIX_RE_XCD_BARRIER=0) agreeing bit for bit as well."""
+    import threading
+    import torch
+    from gdmix_amd.solver import REDeviceSolver
+    b = synthetic.make_batch(1500, 32, 8, 65536, seed=91, size_dist="zipf")
+    kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
+    device_solver.set_team_nnz(64)           # [64, 512) -> up to 128 teams, [512, 8192) -> 32 teams, above -> 8 teams
+    stop = threading.Event()
+
+    def load(seed):
+        s2 = REDeviceSolver(0)
+        st = torch.cuda.Stream()
+        noise = synthetic.make_batch(40_000, 16, 4, 1024, seed=seed)
+        with torch.cuda.stream(st):
+            pk = s2.pack(noise)
+            while not stop.is_set():
+                s2.solve(pk, SolverOptions(**kw))
+                st.synchronize()
+        s2.close()
+    try:
+        packed = device_solver.pack(b)
+        first = device_solver.solve(packed, SolverOptions(**kw)).to_host()
+        counts = dict(device_solver.class_counts(packed))
+        assert counts["re_solve_team_kernel 128 teams"] > 50 and counts["re_solve_team_kernel 32 teams"] > 5, counts
+        assert np.all(first["status"] <= 2)
+        runs = []
+        for phase in ("alone", "loaded"):
+            threads = [threading.Thread(target=load, args=(95 + i,)) for i in range(2)] if phase == "loaded" else []
+            for t in threads:
+                t.start()
+            try:
+                for _ in range(10):
+                    runs.append(device_solver.solve(packed, SolverOptions(**kw)).to_host())
+            finally:
+                stop.set()
+                for t in threads:
+                    t.join()
+        os.environ["GDMIX_RE_XCD_BARRIER"] = "0"
+        try:
+            runs.append(device_solver.solve(packed, SolverOptions(**kw)).to_host())
+        finally:
+            os.environ.pop("GDMIX_RE_XCD_BARRIER", None)
+    finally:
+        device_solver.set_team_nnz(16384)
     for r in runs:
         for k in ("theta", "fval", "gnorm", "nit", "nfev", "status"):
             assert np.array_equal(first[k], r[k]), k
