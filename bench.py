@@ -21,6 +21,13 @@ entity sizes), c5share (C5: one GPU's share, 4M Zipf entities generated on the d
 default C2 run also measures ml20m_user, ml20m_movie and c5share briefly and reports them under
 detail.workloads (--no-other-workloads skips that; it is never part of `value`).
 
+ONE population over the ranks (BASELINE configs[2] and [4]; bench_strong.py): with --gpus N > 1 the default run also measures three
+populations split the reference's way — entity -> partition by the Java hash of its decimal id, partition -> rank by partitions[rank::N] —
+plain and through the re-balancer (top-level `strong_scaling`; `--scaling strong --workload c5|ml20m_user|ml20m_movie` makes one of them
+the headline); with --gpus 1 it solves the shares of an 8-rank job one after another on this device (detail.strong_projection: the data
+path has no collective, so max over shares is the job time apart from barriers — labelled a projection), including the first
+per-partition rounds of the C5 job, the granularity at which the product path re-balances.
+
 One JSON line is printed by rank 0. `roofline` is the HBM roofline of the dominant kernel
 (the size-class launch that takes the largest share of a step) by the algorithmic-bytes formula of SURVEY.md §8(d); `cpu_baseline` times the
 CPU oracle (oracle/re_oracle.c, a port) on a bounded sample on this box's host cores.
