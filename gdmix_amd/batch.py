@@ -118,6 +118,50 @@ class RawBatch:
             has_label=self.has_label)
 
 
+class WireRawBatch(RawBatch):
+    """A partition as libgdmix_io's gdmix_io_narrow leaves it: the 32-bit hand-over form (per-sample counts, uint16 / int32 feature
+    indices, byte labels) next to the arrays both forms share (ent_row_ptr, val, y, offset, weight, uid, ids). to_wire() hands the
+    library's arrays over as they are — no pass over the partition on this side; the two large 64-bit arrays of RawBatch (row_nnz_ptr,
+    col_global) exist only if somebody asks for them (host-side consumers: select(), the CPU stand-ins of the tests), rebuilt then by a
+    cumsum and a widening copy."""
+
+    def __init__(self, ent_row_ptr, ent_n, row_nnz, col, val, y, y8, offset, weight=None, uid=None, entity_ids=None, has_label=True):
+        d = self.__dict__
+        d.update(ent_row_ptr=ent_row_ptr, val=val, y=y, offset=offset, weight=weight, uid=uid, entity_ids=entity_ids, has_label=has_label,
+                 binary_labels=True, trusted=True, _ent_n=ent_n, _row_nnz=row_nnz, _col=col, _y8=y8, _row_nnz_ptr=None, _col_global=None)
+
+    @property
+    def row_nnz_ptr(self):
+        if self._row_nnz_ptr is None:
+            p = np.zeros(self._row_nnz.size + 1, np.int64)
+            np.cumsum(self._row_nnz, dtype=np.int64, out=p[1:])
+            self.__dict__["_row_nnz_ptr"] = p
+        return self._row_nnz_ptr
+
+    @property
+    def col_global(self):
+        if self._col_global is None:
+            self.__dict__["_col_global"] = self._col.astype(np.int64)
+        return self._col_global
+
+    @property
+    def N(self):
+        return self._row_nnz.size
+
+    @property
+    def Z(self):
+        return self._col.size
+
+    def ent_n(self):
+        return self._ent_n.astype(np.int64)
+
+    def to_wire(self):
+        binary = self._y8 is not None
+        return dict(E=self.E, N=self.N, Z=self.Z, ent_n=self._ent_n, row_nnz=self._row_nnz, row_nnz_width=self._row_nnz.dtype.itemsize,
+                    col_global=self._col, col_width=self._col.dtype.itemsize, val=self.val, y=self._y8 if binary else self.y,
+                    y_width=1 if binary else 4, offset=self.offset, weight=self.weight)
+
+
 def _ranges(starts, lens):
     """Concatenate arange(s, s+l) for every (s, l) without a Python loop."""
     lens = np.asarray(lens, np.int64)

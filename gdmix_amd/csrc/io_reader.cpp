@@ -776,7 +776,69 @@ GDMIX_IO_API void gdmix_io_free(gdmix_io_batch* b) {
   if (!b) return;
   pool_free(b->ent_row_ptr); pool_free(b->row_nnz_ptr); pool_free(b->col_global); pool_free(b->val); pool_free(b->y);
   pool_free(b->offset); pool_free(b->weight); pool_free(b->uid); pool_free(b->ent_id_ptr); pool_free(b->ent_id_bytes);
+  pool_free(b->ent_n); pool_free(b->row_nnz); pool_free(b->col); pool_free(b->y8);
   free(b);
+}
+
+GDMIX_IO_API int gdmix_io_narrow(gdmix_io_batch* b, int32_t threads) {
+  if (!b) return fail(GDMIX_IO_EINVAL, "batch is NULL");
+  if (b->ent_n) return GDMIX_IO_OK;                       // already narrow
+  if (!b->ent_row_ptr || !b->row_nnz_ptr || (b->Z > 0 && !b->col_global)) return fail(GDMIX_IO_EINVAL, "batch has no 64-bit arrays to narrow");
+  if (threads <= 0) threads = gdmix_io_detail::default_threads();
+  const int64_t E = b->E, N = b->N, Z = b->Z;
+  // widths: one pass over the per-sample counts and the indices (maxima per chunk, then over the chunks)
+  const int64_t CH = 1 << 16;
+  const int64_t nch_n = (N + CH - 1) / CH, nch_z = (Z + CH - 1) / CH;
+  std::vector<int64_t> kmax((size_t)(nch_n > 0 ? nch_n : 1), 0), cmax((size_t)(nch_z > 0 ? nch_z : 1), 0), cmin((size_t)(nch_z > 0 ? nch_z : 1), 0);
+  int rc = parallel_for(nch_n, threads, [&](int64_t c) {
+    int64_t m = 0;
+    const int64_t e = (c + 1) * CH < N ? (c + 1) * CH : N;
+    for (int64_t i = c * CH; i < e; ++i) { const int64_t k = b->row_nnz_ptr[i + 1] - b->row_nnz_ptr[i]; if (k > m) m = k; }
+    kmax[(size_t)c] = m;
+    return GDMIX_IO_OK;
+  }, 1);
+  if (rc != GDMIX_IO_OK) return rc;
+  rc = parallel_for(nch_z, threads, [&](int64_t c) {
+    int64_t m = 0, lo = 0;
+    const int64_t e = (c + 1) * CH < Z ? (c + 1) * CH : Z;
+    for (int64_t i = c * CH; i < e; ++i) { const int64_t v = b->col_global[i]; if (v > m) m = v; if (v < lo) lo = v; }
+    cmax[(size_t)c] = m; cmin[(size_t)c] = lo;
+    return GDMIX_IO_OK;
+  }, 1);
+  if (rc != GDMIX_IO_OK) return rc;
+  int64_t km = 0, cm = 0, cl = 0;
+  for (int64_t v : kmax) if (v > km) km = v;
+  for (int64_t v : cmax) if (v > cm) cm = v;
+  for (int64_t v : cmin) if (v < cl) cl = v;
+  if (cl < 0 || cm > 0x7fffffffll) return fail(GDMIX_IO_ERANGE, "feature index outside [0, 2^31)");
+  for (int64_t e = 0; e < E; ++e)
+    if (b->ent_row_ptr[e + 1] - b->ent_row_ptr[e] > 0x7fffffffll) return fail(GDMIX_IO_ERANGE, "an entity has more than 2^31 samples");
+  const int kw = km <= 0xff ? 1 : (km <= 0xffff ? 2 : 4);
+  const int cw = cm <= 0xffff ? 2 : 4;
+  const bool bytes_y = b->has_label && b->labels_binary;
+  int32_t* ent_n = nullptr; uint8_t* row_nnz = nullptr; uint8_t* col = nullptr; uint8_t* y8 = nullptr;
+  bool ok = alloc(ent_n, E) && alloc(row_nnz, N * kw) && alloc(col, Z * cw) && (!bytes_y || alloc(y8, N));
+  if (!ok) { pool_free(ent_n); pool_free(row_nnz); pool_free(col); pool_free(y8); return fail(GDMIX_IO_ENOMEM, "out of memory"); }
+  for (int64_t e = 0; e < E; ++e) ent_n[e] = (int32_t)(b->ent_row_ptr[e + 1] - b->ent_row_ptr[e]);
+  parallel_for(nch_n, threads, [&](int64_t c) {
+    const int64_t e = (c + 1) * CH < N ? (c + 1) * CH : N;
+    for (int64_t i = c * CH; i < e; ++i) {
+      const int64_t k = b->row_nnz_ptr[i + 1] - b->row_nnz_ptr[i];
+      if (kw == 1) row_nnz[i] = (uint8_t)k; else if (kw == 2) ((uint16_t*)row_nnz)[i] = (uint16_t)k; else ((uint32_t*)row_nnz)[i] = (uint32_t)k;
+      if (bytes_y) y8[i] = b->y[i] != 0.0f ? 1 : 0;
+    }
+    return GDMIX_IO_OK;
+  }, 1);
+  parallel_for(nch_z, threads, [&](int64_t c) {
+    const int64_t e = (c + 1) * CH < Z ? (c + 1) * CH : Z;
+    if (cw == 2) for (int64_t i = c * CH; i < e; ++i) ((uint16_t*)col)[i] = (uint16_t)b->col_global[i];
+    else for (int64_t i = c * CH; i < e; ++i) ((int32_t*)col)[i] = (int32_t)b->col_global[i];
+    return GDMIX_IO_OK;
+  }, 1);
+  pool_free(b->row_nnz_ptr); b->row_nnz_ptr = nullptr;
+  pool_free(b->col_global); b->col_global = nullptr;
+  b->ent_n = ent_n; b->row_nnz = row_nnz; b->col = col; b->y8 = y8; b->row_nnz_width = kw; b->col_width = cw;
+  return GDMIX_IO_OK;
 }
 
 GDMIX_IO_API int gdmix_io_read_grouped(const char* const* files, int32_t n_files, const gdmix_io_schema* sc,

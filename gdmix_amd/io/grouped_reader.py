@@ -46,13 +46,14 @@ def _column(ctx, name, kinds, entity_label):
 
 def read_grouped_partition(input_path, metadata, entity_name, feature_bag, offset_column_name,
                            uid_column_name, label_column_name=None, weight_column_name=None,
-                           num_features=None, check_crc=False, native=None, threads=0):
+                           num_features=None, check_crc=False, native=None, threads=0, wire=False):
     """Read every record under input_path into one RawBatch (entity order = file order, then record order).
 
     feature_bag None => intercept-only model: one dummy zero feature per sample (job_consumers.py:213-218).
     label_column_name None (or absent from the records) => batch.has_label False (inference data).
     native: True = libgdmix_io.so (multi-threaded C++), False = the Python decoder below, None = native when the
     library has been built. Both follow the same rules (tests/test_native_io.py).
+    wire: with the native reader, hand the partition over in the 32-bit form (batch.WireRawBatch); ignored by the Python decoder.
     """
     md = metadata if isinstance(metadata, DatasetMetadata) else DatasetMetadata(metadata)
     if entity_name not in md.get_feature_names():
@@ -65,7 +66,7 @@ def read_grouped_partition(input_path, metadata, entity_name, feature_bag, offse
     if native:
         return native_reader.read_grouped_files(files, entity_name, feature_bag, offset_column_name, uid_column_name,
                                                 label_column_name, weight_column_name if has_weight_col else None,
-                                                num_features, check_crc, threads)
+                                                num_features, check_crc, threads, wire=wire)
     ent_n, row_k = [], []
     cols, vals, ys, offs, ws, uids, ids = [], [], [], [], [], [], []
     has_label = label_column_name is not None

@@ -7,12 +7,12 @@ import os
 
 import numpy as np
 
-from ..batch import RawBatch
+from ..batch import RawBatch, WireRawBatch
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "libgdmix_io.so")
-ABI_VERSION = 5
-EXPORTED_SYMBOLS = ("gdmix_io_abi_version", "gdmix_io_last_error", "gdmix_io_read_grouped", "gdmix_io_free", "gdmix_io_pool_trim",
+ABI_VERSION = 6
+EXPORTED_SYMBOLS = ("gdmix_io_abi_version", "gdmix_io_last_error", "gdmix_io_read_grouped", "gdmix_io_free", "gdmix_io_narrow", "gdmix_io_pool_trim",
                     "gdmix_io_crc32c", "gdmix_io_masked_crc32c", "gdmix_io_avro_write_models", "gdmix_io_avro_write_scores",
                     "gdmix_io_write_grouped", "gdmix_io_read_examples", "gdmix_io_avro_read_models", "gdmix_io_free_models", "gdmix_io_map_coefficients", "gdmix_io_ids_unique", "gdmix_io_match_ids")
 
@@ -32,7 +32,9 @@ class _Batch(C.Structure):
                 ("row_nnz_ptr", C.POINTER(C.c_int64)), ("col_global", C.POINTER(C.c_int64)), ("val", C.POINTER(C.c_float)),
                 ("y", C.POINTER(C.c_float)), ("offset", C.POINTER(C.c_float)), ("weight", C.POINTER(C.c_float)),
                 ("uid", C.POINTER(C.c_int64)), ("ent_id_ptr", C.POINTER(C.c_int64)), ("ent_id_bytes", C.POINTER(C.c_char)),
-                ("has_label", C.c_int32), ("bytes_read", C.c_int64), ("labels_binary", C.c_int32)]
+                ("has_label", C.c_int32), ("bytes_read", C.c_int64), ("labels_binary", C.c_int32),
+                ("ent_n", C.POINTER(C.c_int32)), ("row_nnz", C.c_void_p), ("col", C.c_void_p), ("y8", C.POINTER(C.c_uint8)),
+                ("row_nnz_width", C.c_int32), ("col_width", C.c_int32)]
 
 
 class _ModelTable(C.Structure):
@@ -73,6 +75,7 @@ def load_library():
     lib.gdmix_io_read_examples.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.POINTER(_Schema), C.POINTER(C.POINTER(_Batch))]
     lib.gdmix_io_free.argtypes = [C.POINTER(_Batch)]
     lib.gdmix_io_free.restype = None
+    lib.gdmix_io_narrow.argtypes = [C.POINTER(_Batch), C.c_int32]
     lib.gdmix_io_pool_trim.argtypes = []
     lib.gdmix_io_pool_trim.restype = C.c_size_t
     lib.gdmix_io_avro_write_models.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.POINTER(_ModelTable),
@@ -133,14 +136,15 @@ class _BatchOwner:
             self._handle = None
 
 
-_CTYPE = {np.dtype(np.int64): C.c_int64, np.dtype(np.float32): C.c_float, np.dtype(np.float64): C.c_double}
+_CTYPE = {np.dtype(np.int64): C.c_int64, np.dtype(np.float32): C.c_float, np.dtype(np.float64): C.c_double, np.dtype(np.int32): C.c_int32,
+          np.dtype(np.uint8): C.c_uint8, np.dtype(np.uint16): C.c_uint16, np.dtype(np.uint32): C.c_uint32}
 
 
 def _view(owner, ptr, count, dtype):
     """The library's array as a numpy array without a copy (hundreds of MB per partition); the array holds the owner."""
     if count == 0:
         return np.zeros(0, dtype)
-    buf = (_CTYPE[np.dtype(dtype)] * count).from_address(C.addressof(ptr.contents))
+    buf = (_CTYPE[np.dtype(dtype)] * count).from_address(ptr if isinstance(ptr, int) else C.addressof(ptr.contents))
     buf._owner = owner
     return np.frombuffer(buf, dtype=dtype)
 
@@ -229,9 +233,10 @@ def _split_ids(raw, ptr, E):
 
 
 def read_grouped_files(files, entity_name, feature_bag, offset_column_name, uid_column_name, label_column_name=None,
-                       weight_column_name=None, num_features=None, check_crc=False, threads=0, stats=None) -> RawBatch:
+                       weight_column_name=None, num_features=None, check_crc=False, threads=0, stats=None, wire=False) -> RawBatch:
     """files -> RawBatch; same arguments as grouped_reader.read_grouped_partition after file resolution and the
-    metadata checks. weight_column_name None => no weight array."""
+    metadata checks. weight_column_name None => no weight array. wire=True: the library narrows the partition to the 32-bit hand-over
+    form (gdmix_io_narrow) and the result is a batch.WireRawBatch around its arrays — what a device solver uploads as it is."""
     lib = load_library()
     sc = _Schema(_enc(entity_name), _enc(feature_bag), _enc(offset_column_name), _enc(uid_column_name),
                  _enc(label_column_name), _enc(weight_column_name),
@@ -254,6 +259,17 @@ def read_grouped_files(files, entity_name, feature_bag, offset_column_name, uid_
     v = lambda ptr, n, dt: _view(owner, ptr, n, dt)
     if bool(b.has_label) and not int(b.labels_binary):
         raise AssertionError("labels must be 0 or 1")   # fit() asserts it (binary_logistic_regression.py:208)
+    if wire:
+        rc = lib.gdmix_io_narrow(out, int(threads))
+        if rc != 0:
+            raise (ValueError if rc == -6 else GdmixIoError)(f"gdmix_io_narrow: {lib.gdmix_io_last_error().decode('utf-8', 'replace')}")
+        kdt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[int(b.row_nnz_width)]
+        cdt = {2: np.uint16, 4: np.int32}[int(b.col_width)]
+        return WireRawBatch(ent_row_ptr=v(b.ent_row_ptr, E + 1, np.int64), ent_n=v(b.ent_n, E, np.int32),
+                            row_nnz=v(b.row_nnz or 0, N, kdt), col=v(b.col or 0, Z, cdt), val=v(b.val, Z, np.float32),
+                            y=v(b.y, N, np.float32), y8=v(b.y8, N, np.uint8) if b.y8 else None, offset=v(b.offset, N, np.float32),
+                            weight=v(b.weight, N, np.float32) if weight_column_name is not None else None,
+                            uid=v(b.uid, N, np.int64), entity_ids=ids, has_label=bool(b.has_label))
     # the library built these arrays itself (monotone pointers, matching lengths, labels checked while decoding): the
     # passes RawBatch.validate would make over them are skipped
     return RawBatch(ent_row_ptr=v(b.ent_row_ptr, E + 1, np.int64), row_nnz_ptr=v(b.row_nnz_ptr, N + 1, np.int64),

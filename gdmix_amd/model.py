@@ -22,6 +22,7 @@ from .io.features import get_feature_map, read_feature_list
 from .io.grouped_reader import read_grouped_partition
 from .io.metadata import DatasetMetadata, read_json_file
 from .params import REParams
+from .batch import WireRawBatch
 from .solver import REDeviceSolver, SolverOptions, VARIANCE_MODES, host_array
 
 logger = logging.getLogger(__name__)
@@ -548,7 +549,16 @@ class RandomEffectLRLBFGSModel:
             feature_bag=self.feature_bag_name, offset_column_name=self.model_params.offset_column_name,
             uid_column_name=schema_params.uid_column_name,
             label_column_name=schema_params.label_column_name, weight_column_name=schema_params.weight_column_name,
-            num_features=num_features)
+            num_features=num_features, wire=self._wants_wire())
+
+    def _wants_wire(self):
+        """The reader narrows the partition to the 32-bit hand-over form when a device solver will take it (it uploads that form as it
+        is: 0.47 of the bytes of a C2 partition, and no 64-bit arrays for the main thread to pass over); the CPU stand-in of the host
+        tests keeps the 64-bit arrays it works on."""
+        if os.environ.get("GDMIX_IO_WIRE", "1") == "0":     # A/B switch (tools/r04_wire.sh)
+            return False
+        s = self._solver      # None: not created yet — it will be the device solver (there is no other in the product path)
+        return s is None or isinstance(s, REDeviceSolver)
 
     def _read_ahead(self, input_path, tensor_metadata, schema_params, num_features):
         """prefetch(): decode the partition and — once the device solver exists — copy its arrays to HBM on a stream of this
@@ -564,7 +574,7 @@ class RandomEffectLRLBFGSModel:
                 if st is None:
                     st = self.__dict__.setdefault("_upload_stream", torch.cuda.Stream(device=s.device))
                 with torch.cuda.stream(st):
-                    raw = s.upload(batch)
+                    raw = s.upload_wire(batch.to_wire()) if isinstance(batch, WireRawBatch) else s.upload(batch)
                     ev = torch.cuda.Event()
                     ev.record(st)
                 batch._device = (raw, ev)
@@ -584,7 +594,7 @@ class RandomEffectLRLBFGSModel:
         for v in raw.values():       # allocated on the upload stream, used (and later freed) on this one
             if isinstance(v, torch.Tensor):
                 v.record_stream(cur)
-        return solver.pack(raw, has_intercept=self.has_intercept)
+        return solver.pack(solver.widen(raw) if "ent_n" in raw else raw, has_intercept=self.has_intercept)
 
     def _train(self, input_path, tensor_metadata, model_weights, num_features, schema_params, output_model_file):
         logger.info(f"Start training with {f'loaded {len(model_weights)} previous models' if model_weights else 'zeros'} "

@@ -278,11 +278,17 @@ def wire_tensors(batch, device, solver=None):
     """The partition in the exchange's wire form (gdmix_re_wire_batch with 32-bit counts, int32 feature ids, float labels) as
     tensors on `device`. With a device solver the arrays go up through its page-locked staging (upload_wire)."""
     import torch
-    if batch.Z and (batch.col_global.min() < 0 or batch.col_global.max() > 0x7fffffff):
-        raise ValueError("feature index outside [0, 2^31)")
-    w = dict(E=batch.E, N=batch.N, Z=batch.Z, ent_n=np.diff(batch.ent_row_ptr).astype(np.int32), row_nnz=np.diff(batch.row_nnz_ptr).astype(np.int32),
-             row_nnz_width=4, col_global=batch.col_global.astype(np.int32), col_width=4, val=batch.val, y=batch.y, y_width=4,
-             offset=batch.offset, weight=batch.weight)
+    from .batch import WireRawBatch
+    if isinstance(batch, WireRawBatch):      # narrowed (and range-checked) by the reader: only the widths are made uniform over the ranks
+        n = batch.to_wire()
+        w = dict(n, row_nnz=n["row_nnz"].astype(np.int32), row_nnz_width=4, col_global=n["col_global"].astype(np.int32), col_width=4,
+                 y=batch.y, y_width=4)
+    else:
+        if batch.Z and (batch.col_global.min() < 0 or batch.col_global.max() > 0x7fffffff):
+            raise ValueError("feature index outside [0, 2^31)")
+        w = dict(E=batch.E, N=batch.N, Z=batch.Z, ent_n=np.diff(batch.ent_row_ptr).astype(np.int32), row_nnz=np.diff(batch.row_nnz_ptr).astype(np.int32),
+                 row_nnz_width=4, col_global=batch.col_global.astype(np.int32), col_width=4, val=batch.val, y=batch.y, y_width=4,
+                 offset=batch.offset, weight=batch.weight)
     if solver is not None and hasattr(solver, "upload_wire"):
         return solver.upload_wire(w, pinned=solver.wire_stage(w) if hasattr(solver, "wire_stage") else None)
     d = {k: w[k] for k in ("E", "N", "Z", "row_nnz_width", "y_width", "col_width")}

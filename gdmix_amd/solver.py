@@ -13,7 +13,7 @@ from typing import Optional
 
 import numpy as np
 
-from .batch import RawBatch
+from .batch import RawBatch, WireRawBatch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgdmix_re.so")
@@ -452,9 +452,13 @@ class REDeviceSolver:
         return rd
 
     def pack(self, raw, has_intercept=True) -> PackedBatch:
-        """raw: RawBatch (host) or the dict returned by upload() (device)."""
+        """raw: RawBatch (host) or the dict returned by upload() / widen() (device). A batch the reader narrowed (WireRawBatch) is uploaded
+        in that form and widened on the device."""
         t = self.torch
-        rd = self.upload(raw) if isinstance(raw, RawBatch) else raw
+        if isinstance(raw, WireRawBatch):
+            rd = self.widen(self.upload_wire(raw.to_wire()))
+        else:
+            rd = self.upload(raw) if isinstance(raw, RawBatch) else raw
         E, N, Z = rd["E"], rd["N"], rd["Z"]
         ptr = lambda x: None if x is None or x.numel() == 0 else x.data_ptr()
         c_raw = _RawBatch(E, N, Z, rd["ent_row_ptr"].data_ptr(), rd["row_nnz_ptr"].data_ptr(), ptr(rd["col_global"]),

@@ -36,8 +36,9 @@ extern "C" {
 #define GDMIX_IO_EFORMAT  (-3)   /* framing, CRC or protobuf wire error */
 #define GDMIX_IO_ESCHEMA  (-4)   /* a record does not match the schema (missing column, length mismatch, ...) */
 #define GDMIX_IO_ENOMEM   (-5)
+#define GDMIX_IO_ERANGE   (-6)   /* a value does not fit the 32-bit hand-over form (gdmix_io_narrow) */
 
-#define GDMIX_IO_ABI_VERSION 5
+#define GDMIX_IO_ABI_VERSION 6
 
 typedef struct gdmix_io_schema {
   const char* entity;        /* context key of the entity id (int64 or bytes scalar)                       */
@@ -72,6 +73,12 @@ typedef struct gdmix_io_batch {
   int64_t  bytes_read;    /* decompressed bytes of TFRecord framing parsed         */
   int32_t  labels_binary; /* every label read is exactly 0 or 1 (what fit() asserts, binary_logistic_regression.py:208);
                            * checked while decoding, so that the caller need not pass over y again */
+  /* the 32-bit hand-over form (include/gdmix_re.h: gdmix_re_wire_batch), filled by gdmix_io_narrow; NULL / 0 before */
+  int32_t* ent_n;         /* [E] samples per entity                                                          */
+  void*    row_nnz;       /* [N] non-zeros per sample, row_nnz_width bytes each (1, 2 or 4: the narrowest that fits) */
+  void*    col;           /* [Z] global feature index, col_width bytes each (2 when every index is below 65 536, else 4) */
+  uint8_t* y8;            /* [N] labels as bytes when has_label and labels_binary, else NULL                     */
+  int32_t  row_nnz_width, col_width;
 } gdmix_io_batch;
 
 GDMIX_IO_API int gdmix_io_abi_version(void);
@@ -82,6 +89,12 @@ GDMIX_IO_API const char* gdmix_io_last_error(void);
 GDMIX_IO_API int gdmix_io_read_grouped(const char* const* files, int32_t n_files, const gdmix_io_schema* schema,
                                        gdmix_io_batch** out);
 GDMIX_IO_API void gdmix_io_free(gdmix_io_batch* batch);
+
+/* Round 4: turn a decoded batch into the 32-bit form a partition crosses PCIe in — counts instead of 64-bit
+ * pointers, int32 / uint16 feature indices, byte labels: 0.47 of the bytes for a C2 partition — in pooled blocks, and give the two large
+ * 64-bit arrays (row_nnz_ptr, col_global) back to the pool: they become NULL; ent_row_ptr, val, y, offset, weight, uid and the ids stay.
+ * One parallel pass over the arrays. Fails (GDMIX_IO_ERANGE) if a feature index is outside [0, 2^31) or an entity has 2^31 samples. */
+GDMIX_IO_API int gdmix_io_narrow(gdmix_io_batch* batch, int32_t threads);
 
 /* The library keeps freed arrays (and the Avro writers' byte buffers) for the next partition instead of returning them to the
  * allocator: up to GDMIX_IO_POOL_MB megabytes of idle blocks (environment; default 4096 / LOCAL_WORLD_SIZE, at least 512) plus up

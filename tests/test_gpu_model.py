@@ -172,3 +172,35 @@ def test_cli_process_on_zipf_and_movielens_shaped_partition_directories(tmp_path
         worst = max(worst, err)
         compared += 1
     assert compared >= 100 and worst <= 1e-5, (compared, worst)      # north_star: coefficients within 1e-5 rel-err of the reference L-BFGS
+
+
+@pytest.mark.parametrize("dim,k", [(1024, 16), (1 << 17, 512)])
+def test_a_partition_the_reader_narrowed_packs_to_the_same_arrays(tmp_path, dim, k):
+    """native reader with wire=True (gdmix_io_narrow) -> upload of the 32-bit form -> gdmix_re_widen -> pack: the packed batch and the
+    solve are bit for bit those of the 64-bit hand-over, for both widths of the counts and the indices."""
+    from gdmix_amd import synthetic
+    from gdmix_amd.batch import WireRawBatch
+    from gdmix_amd.io.grouped_reader import read_grouped_partition
+    from gdmix_amd.solver import REDeviceSolver, SolverOptions
+    b = synthetic.make_batch(300, 12, k, dim, seed=5)
+    md = {"features": [{"name": "bag", "dtype": "float", "shape": [dim], "isSparse": True},
+                       {"name": "offset", "dtype": "float", "shape": [], "isSparse": False},
+                       {"name": "uid", "dtype": "long", "shape": [], "isSparse": False},
+                       {"name": "ent", "dtype": "string", "shape": [], "isSparse": False}],
+          "labels": [{"name": "response", "dtype": "int", "shape": [], "isSparse": False}]}
+    write_grouped_partition(str(tmp_path / "part-0.tfrecord"), b, "ent", "bag", "offset", "uid", "response", None)
+    args = (str(tmp_path), md, "ent", "bag", "offset", "uid", "response", None)
+    wide = read_grouped_partition(*args, num_features=dim, native=True)
+    narrow = read_grouped_partition(*args, num_features=dim, native=True, wire=True)
+    assert isinstance(narrow, WireRawBatch) and not isinstance(wide, WireRawBatch)
+    assert narrow.to_wire()["col_width"] == (2 if dim <= 65536 else 4) and narrow.to_wire()["row_nnz_width"] == (1 if k <= 255 else 2)
+    s = REDeviceSolver(0)
+    pa, pb = s.pack(wide), s.pack(narrow)
+    assert narrow._row_nnz_ptr is None and narrow._col_global is None       # the 64-bit arrays were never rebuilt on the host
+    for name in ("ent_feat_ptr", "unique_global", "ent_nnz_ptr"):
+        assert np.array_equal(getattr(pa, name)().cpu().numpy(), getattr(pb, name)().cpu().numpy()), name
+    o = SolverOptions(l2=1.0, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
+    ra, rb = s.solve(pa, o).to_host(), s.solve(pb, o).to_host()
+    for key in ("theta", "nit", "nfev", "status", "fval"):
+        assert np.array_equal(ra[key], rb[key]), key
+    s.close()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from gdmix_amd import synthetic
-from gdmix_amd.batch import RawBatch
+from gdmix_amd.batch import RawBatch, WireRawBatch
 from gdmix_amd.io import native_reader, tfrecord
 from gdmix_amd.io.grouped_reader import read_grouped_partition, write_grouped_partition
 from helpers import load_fixture
@@ -41,7 +41,28 @@ def both(path, *args, **kw):
     for threads in (1, 4):
         nat = read_grouped_partition(path, *args, native=True, threads=threads, **kw)
         same(py, nat)
+        same_wire(py, read_grouped_partition(path, *args, native=True, threads=threads, wire=True, **kw))
     return py
+
+
+def same_wire(py: RawBatch, w):
+    """The batch the library narrowed (gdmix_io_narrow): its hand-over arrays are the ones RawBatch.to_wire() derives from the 64-bit
+    arrays, element for element and width for width; the 64-bit arrays it rebuilds on demand are the originals."""
+    assert isinstance(w, WireRawBatch) and (w.E, w.N, w.Z) == (py.E, py.N, py.Z)
+    assert w._row_nnz_ptr is None and w._col_global is None       # nothing 64-bit until somebody asks
+    a, b = py.to_wire(), w.to_wire()
+    assert a.keys() == b.keys()
+    for k, x in a.items():
+        if isinstance(x, np.ndarray):
+            assert b[k].dtype == x.dtype and b[k].flags.c_contiguous, k
+            np.testing.assert_array_equal(b[k], x, err_msg=k)
+        else:
+            assert b[k] == x or (x is None and b[k] is None), k
+    np.testing.assert_array_equal(w.ent_n(), py.ent_n())
+    np.testing.assert_array_equal(w.ent_nnz(), py.ent_nnz())
+    same(py, w)
+    if py.E > 1:
+        same(py.select([py.E - 1, 0]), w.select([py.E - 1, 0]))
 
 
 def test_library_exports_every_symbol_the_header_declares():
@@ -483,3 +504,28 @@ def test_pool_trim_releases_idle_blocks(tmp_path):
     freed = native_reader.pool_trim()
     assert freed >= b.Z * 8                             # at least the feature index array (int64) was idle in the pool
     assert native_reader.pool_trim() == 0
+
+
+def test_narrowing_picks_the_widths_and_refuses_what_does_not_fit(tmp_path):
+    """gdmix_io_narrow: one byte per count while every sample has at most 255 non-zeros, two bytes per feature index while every index is
+    below 65 536; a wide sample or a high index switches that one array over; an index of 2^31 is an error, as in RawBatch.to_wire()."""
+    def read(cols_of_sample, dim):
+        md = dict(MD, features=[dict(MD["features"][0], shape=[dim])] + MD["features"][1:])
+        k = [len(c) for c in cols_of_sample]
+        b = RawBatch(ent_row_ptr=[0, len(k)], row_nnz_ptr=np.concatenate([[0], np.cumsum(k)]), col_global=np.concatenate(cols_of_sample),
+                     val=np.ones(sum(k), np.float32), y=np.arange(len(k)) % 2, offset=np.zeros(len(k), np.float32),
+                     uid=np.arange(len(k)), entity_ids=["e"])
+        d = tmp_path / f"d{dim}_{max(k)}"
+        write_grouped_partition(str(d / "part-0.tfrecord"), b, "ent", "bag", "offset", "uid", "response", None)
+        return b, read_grouped_partition(str(d), md, "ent", "bag", "offset", "uid", "response", None, num_features=dim, native=True, wire=True)
+    b, w = read([np.arange(255), np.array([65535])], 65536)
+    assert (w.to_wire()["row_nnz_width"], w.to_wire()["col_width"], w.to_wire()["y_width"]) == (1, 2, 1)
+    same_wire(b, w)
+    b, w = read([np.arange(256), np.array([65536])], 1 << 20)
+    assert (w.to_wire()["row_nnz_width"], w.to_wire()["col_width"]) == (2, 4)
+    same_wire(b, w)
+    b, w = read([np.arange(65536), np.array([0x7fffffff])], 1 << 31)
+    assert (w.to_wire()["row_nnz_width"], w.to_wire()["col_width"]) == (4, 4)
+    same_wire(b, w)
+    with pytest.raises(ValueError, match=r"2\^31"):
+        read([np.array([1 << 31])], 1 << 32)
