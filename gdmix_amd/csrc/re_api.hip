@@ -60,9 +60,25 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_GRID, 0, "re_solve_team_kernel 8 teams"},
     {KIND_GRID, 0, "re_solve_team_kernel device-wide"}};
 
-__global__ void class_base_kernel(int32_t* cc) {
+__global__ void class_base_kernel(int32_t* cc, int tall_adapt_limit) {
   // cc[0..NC) counts -> cc[NC..2NC) exclusive bases, cc[2NC..3NC) cursors = 0
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    // The split between the one-wavefront and the eight-wavefront tall kernels (4 096 samples by default: right for a batch with
+    // thousands of tall entities, where a CU is better spent on eight entities than on one) is lowered for a batch whose
+    // eight-wavefront class stays small anyway — a share of a strongly scaled job: 17 k users, 5 - 11 of them above 4 096 samples, and
+    // the step lasts as long as ONE wavefront needs for a 4 000-sample entity (tools/share_timeline.py). The lowest of 512 / 1 024 /
+    // 2 048 that keeps the class within `tall_adapt_limit` workgroups (one per CU) wins; re_order_kernel moves the entities.
+    int32_t* const ge = cc + 3 * GDMIX_RE_NUM_CLASSES;
+    int split = 0;
+    if (tall_adapt_limit > 0) {
+      for (int k = 0; k < TALL_ADAPT_STEPS && split == 0; ++k)
+        if (ge[k] > 0 && cc[TALL_CLASS] + ge[k] <= tall_adapt_limit) {
+          split = tall_adapt_n(k);
+          cc[TALL_CLASS] += ge[k];
+          cc[TALL_S_CLASS] -= ge[k];
+        }
+    }
+    ge[TALL_ADAPT_SLOT] = split;
     int run = 0;
     for (int c = 0; c < GDMIX_RE_NUM_CLASSES; ++c) { cc[GDMIX_RE_NUM_CLASSES + c] = run; run += cc[c]; cc[2 * GDMIX_RE_NUM_CLASSES + c] = 0; }
   }
@@ -85,7 +101,8 @@ using namespace gdmix;
 extern "C" {
 
 // A class whose launch cannot fill the device: fewer wavefronts than three quarters of what the CUs hold at two per SIMD (the eight-wavefront
-// tall workgroups: fewer entities than CUs). Such a class runs on the context's side stream next to the large ones.
+// tall workgroups: fewer entities than CUs). Such a class runs on one of the context's side streams, next to the large ones and to
+// the other small ones.
 static bool class_is_small(int kind, int count, int num_cus) {
   const int gl = group_lanes(kind);
   long waves = count;                                   // wavefront kernels, one-wavefront tall variants
@@ -126,6 +143,9 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   if (!c) { set_error("out of host memory"); return GDMIX_RE_ENOMEM; }
   c->impl.device = hip_device;
   c->impl.num_cus = prop.multiProcessorCount;
+  c->impl.tall_adapt_limit = c->impl.num_cus * 3 / 4;   // (tools/r04_adapt.sh: 64 / 128 / 192 / 256 / 384 / 512 / 1024 workgroups on a 17 k-user share:
+                                                        // 2.51 / 2.39 / 2.22 / 2.51* / 2.24 / 2.43 / 2.83 ms; * one share of eight, the others 2.2)
+  if (const char* e = getenv("GDMIX_RE_TALL_ADAPT")) c->impl.tall_adapt_limit = atoi(e) > 0 ? atoi(e) : 0;
   c->impl.scratch = nullptr;
   c->impl.scratch_bytes = 0;
   c->impl.host_pinned = nullptr;
@@ -139,7 +159,8 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   c->impl.grid_sync = nullptr;
   c->impl.big_tmp = nullptr;
   c->impl.big_tmp_bytes = 0;
-  c->impl.side = nullptr; c->impl.side_fork = nullptr; c->impl.side_join = nullptr;
+  c->impl.n_side = 0; c->impl.side_fork = nullptr;
+  for (int k = 0; k < gdmix_ctx_impl::MAX_SIDE; ++k) { c->impl.side[k] = nullptr; c->impl.side_join[k] = nullptr; }
   for (int k = 0; k < GDMIX_RE_NUM_CLASSES; ++k) { c->impl.ev0[k] = nullptr; c->impl.ev1[k] = nullptr; c->impl.ev_used[k] = false; }
   hipError_t rc = hipHostMalloc(reinterpret_cast<void**>(&c->impl.host_pinned), 4096, hipHostMallocDefault);
   if (rc != hipSuccess) {
@@ -148,15 +169,19 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
     return GDMIX_RE_EHIP;
   }
   {
-    const char* e = getenv("GDMIX_RE_SIDE_STREAM");   // test hook: 0 = every class on the caller's stream
-    if (!e || atoi(e) != 0) {
-      rc = hipStreamCreateWithFlags(&c->impl.side, hipStreamNonBlocking);
-      if (rc == hipSuccess) rc = hipEventCreateWithFlags(&c->impl.side_fork, hipEventDisableTiming);
-      if (rc == hipSuccess) rc = hipEventCreateWithFlags(&c->impl.side_join, hipEventDisableTiming);
+    const char* e = getenv("GDMIX_RE_SIDE_STREAM");   // test hook: 0 = every class on the caller's stream; N = that many side streams
+    int want = e ? atoi(e) : 3;   // with the caller's stream: the four hardware queues a process gets by default
+    if (want > gdmix_ctx_impl::MAX_SIDE) want = gdmix_ctx_impl::MAX_SIDE;
+    if (want > 0) {
+      rc = hipEventCreateWithFlags(&c->impl.side_fork, hipEventDisableTiming);
+      for (int k = 0; k < want && rc == hipSuccess; ++k) {
+        rc = hipStreamCreateWithFlags(&c->impl.side[k], hipStreamNonBlocking);
+        if (rc == hipSuccess) rc = hipEventCreateWithFlags(&c->impl.side_join[k], hipEventDisableTiming);
+        if (rc == hipSuccess) c->impl.n_side = k + 1;
+      }
       if (rc != hipSuccess) {
-        set_error("creating the side stream failed: %s", hipGetErrorString(rc));
-        (void)hipHostFree(c->impl.host_pinned);
-        delete c;
+        set_error("creating the side streams failed: %s", hipGetErrorString(rc));
+        gdmix_re_destroy(c);
         return GDMIX_RE_EHIP;
       }
     }
@@ -178,8 +203,10 @@ GDMIX_API void gdmix_re_destroy(gdmix_re_ctx* ctx) {
   if (ctx->impl.big_tmp) (void)hipFree(ctx->impl.big_tmp);
   if (ctx->impl.host_pinned) (void)hipHostFree(ctx->impl.host_pinned);
   if (ctx->impl.side_fork) (void)hipEventDestroy(ctx->impl.side_fork);
-  if (ctx->impl.side_join) (void)hipEventDestroy(ctx->impl.side_join);
-  if (ctx->impl.side) (void)hipStreamDestroy(ctx->impl.side);
+  for (int k = 0; k < gdmix_ctx_impl::MAX_SIDE; ++k) {
+    if (ctx->impl.side_join[k]) (void)hipEventDestroy(ctx->impl.side_join[k]);
+    if (ctx->impl.side[k]) (void)hipStreamDestroy(ctx->impl.side[k]);
+  }
   for (int k = 0; k < GDMIX_RE_NUM_CLASSES; ++k) {
     if (ctx->impl.ev0[k]) (void)hipEventDestroy(ctx->impl.ev0[k]);
     if (ctx->impl.ev1[k]) (void)hipEventDestroy(ctx->impl.ev1[k]);
@@ -376,6 +403,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   tab.team_nnz = opts->m <= TEAM_MCAP ? ctx->impl.team_nnz : 0;
   tab.tall_min_n = ctx->impl.tall_min_n;
   tab.tall_split_n = ctx->impl.tall_split_n;
+  tab.tall_adapt_limit = (ctx->impl.tall_split_n == GDMIX_RE_TALL_SPLIT_N_DEFAULT) ? ctx->impl.tall_adapt_limit : 0;   // an explicit split is kept
   if (opts->sum_loss || opts->linear) {
     // the fixed-effect objective lives in the team kernels only: every entity goes device-wide, one after another
     if (opts->m > TEAM_MCAP) { set_error("sum_loss / linear need m <= %d", TEAM_MCAP); return GDMIX_RE_EINVAL; }
@@ -386,7 +414,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   int32_t* cc = b->class_count;
   HIP_TRY(hipMemsetAsync(cc, 0, 6 * GDMIX_RE_NUM_CLASSES * sizeof(int32_t), s));
   HIP_TRY(launch_classify(b, ic, opts->m, tab, b->cls_tmp, cc, s));
-  hipLaunchKernelGGL(class_base_kernel, dim3(1), dim3(1), 0, s, cc);
+  hipLaunchKernelGGL(class_base_kernel, dim3(1), dim3(1), 0, s, cc, tab.tall_adapt_limit);
   HIP_TRY(hipGetLastError());
   HIP_TRY(launch_order(b, b->cls_tmp, cc + GDMIX_RE_NUM_CLASSES, cc + 2 * GDMIX_RE_NUM_CLASSES, s));
   int32_t* hc = ctx->impl.host_pinned + 256;
@@ -440,18 +468,9 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   // small class comes up in the loop: that one may be the last
   // Once the side stream has forked, EVERY way out of this function joins it back into the caller's stream (an error
   // between fork and join used to return with side-stream kernels still running on buffers the caller may then free or reuse).
-  struct SideJoin {
-    gdmix_ctx_impl* ci; hipStream_t main; bool active = false;
-    void join() {
-      if (!active) return;
-      active = false;
-      if (hipEventRecord(ci->side_join, ci->side) != hipSuccess || hipStreamWaitEvent(main, ci->side_join, 0) != hipSuccess)
-        (void)hipStreamSynchronize(ci->side);   // last resort: the caller's stream must not run ahead of the side stream
-    }
-    ~SideJoin() { join(); }
-  } side_join{&ctx->impl, s_main};
+  SideJoin side_join{&ctx->impl, s_main};
   bool forked = false;
-  if (ctx->impl.side && n_launch_classes > 1) {
+  if (ctx->impl.n_side > 0 && n_launch_classes > 1) {
     for (int c = 0; c < BLOCK_CLASS && !forked; ++c) {
       int cnt = hc[c];
       if (c == TALL_L_CLASS && lean_merged) continue;
@@ -460,21 +479,55 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     }
     if (forked) {
       HIP_TRY(hipEventRecord(ctx->impl.side_fork, s_main));
-      HIP_TRY(hipStreamWaitEvent(ctx->impl.side, ctx->impl.side_fork, 0));
+      for (int k = 0; k < ctx->impl.n_side; ++k) HIP_TRY(hipStreamWaitEvent(ctx->impl.side[k], ctx->impl.side_fork, 0));
       side_join.active = true;
     }
   }
+  // Launch plan. The tall classes go first: their kernels are the longest chains of a small batch (one workgroup, or one wavefront,
+  // per entity, for as long as that entity's solve lasts) and each is preceded by three small launches (fill, sort, tail) that must
+  // not queue behind the group kernels' workgroups. Stream of a class:
+  //   large class                      -> the caller's stream, in launch order;
+  //   small tall class (<8>, <1>, lean) -> a side stream of its own (side 0, 1, 2: the device has four hardware queues by default,
+  //                                        a fourth side stream would share one — measured: both tall classes of a MovieLens share on
+  //                                        one queue, 1.1 + 2.1 ms one after the other);
+  //   other small classes              -> the caller's stream when no large class uses it, else the last side stream (behind the
+  //                                        lean tall class, the shortest of the three).
+  // Disjoint entities and outputs; the tall variants have a tail slot each: a schedule changes the time, never a bit of the result.
+  struct Launch { int c, b0, cnt; bool small; };
+  Launch plan[GDMIX_RE_NUM_CLASSES];
+  int n_plan = 0;
+  bool any_large = false;
+  {
+    int begin = 0;
+    int b0s[GDMIX_RE_NUM_CLASSES], cnts[GDMIX_RE_NUM_CLASSES];
+    for (int c = 0; c < BLOCK_CLASS; ++c) {
+      b0s[c] = begin; cnts[c] = hc[c];
+      begin += hc[c];
+      if (c == TALL_L_CLASS && lean_merged) cnts[c] = 0;
+      if (c == TALL_S_CLASS && lean_merged) { b0s[c] -= lean_merged; cnts[c] += lean_merged; }
+    }
+    const int first[3] = {TALL_CLASS, TALL_S_CLASS, TALL_L_CLASS};
+    for (int k = 0; k < 3 + BLOCK_CLASS; ++k) {
+      const int c = k < 3 ? first[k] : k - 3;
+      if (k >= 3 && (c == TALL_CLASS || c == TALL_S_CLASS || c == TALL_L_CLASS)) continue;
+      if (cnts[c] <= 0) continue;
+      const bool small = forked && class_is_small(kClasses[c].kind, cnts[c], ctx->impl.num_cus);
+      any_large = any_large || !small;
+      plan[n_plan++] = Launch{c, b0s[c], cnts[c], small};
+    }
+  }
   int begin = 0;
-  for (int c = 0; c < BLOCK_CLASS; ++c) {
-    int cnt = hc[c], b0 = begin;
-    begin += hc[c];
-    if (c == TALL_L_CLASS && lean_merged) continue;
-    if (c == TALL_S_CLASS && lean_merged) { b0 -= lean_merged; cnt += lean_merged; }
-    if (cnt <= 0) continue;
-    // A class that cannot fill the device (class_is_small: 60 eight-wavefront tall entities take a millisecond on 60 CUs) runs
-    // on the side stream, next to the large classes; joined below, before the team kernels. Disjoint entities and outputs.
+  for (int c = 0; c < BLOCK_CLASS; ++c) begin += hc[c];
+  for (int k = 0; k < n_plan; ++k) {
+    const int c = plan[k].c, b0 = plan[k].b0, cnt = plan[k].cnt;
     hipStream_t s = s_main;
-    if (forked && class_is_small(kClasses[c].kind, cnt, ctx->impl.num_cus)) s = ctx->impl.side;
+    if (plan[k].small) {
+      const int ns = ctx->impl.n_side;
+      if (c == TALL_CLASS) s = ctx->impl.side[0];
+      else if (c == TALL_S_CLASS) s = ctx->impl.side[1 % ns];
+      else if (c == TALL_L_CLASS) s = ctx->impl.side[2 % ns];
+      else s = any_large ? ctx->impl.side[ns - 1] : s_main;
+    }
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[c], s)); }
     switch (kClasses[c].kind) {
       case KIND_QUAD2: case KIND_QUAD3: case KIND_QUAD4: case KIND_PAIR3: case KIND_PAIR4:
@@ -482,9 +535,9 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
         HIP_TRY(launch_solve_quad(group_lanes(kClasses[c].kind), group_epl(kClasses[c].kind), B, O, P, theta0, b0, cnt,
                                   kClasses[c].ncap, kClasses[c].zcap, s));
         break;
-      case KIND_TALL_L: HIP_TRY(launch_solve_tall(TALL_VARIANT_LEAN, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_LEAN * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_LEAN, s)); break;
-      case KIND_TALL_S: HIP_TRY(launch_solve_tall(TALL_VARIANT_SMALL, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_SMALL * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_SMALL, s)); break;
-      case KIND_TALL: HIP_TRY(launch_solve_tall(TALL_VARIANT_LARGE, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_LARGE * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_LARGE, s)); break;
+      case KIND_TALL_L: HIP_TRY(launch_solve_tall(TALL_VARIANT_LEAN, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_LEAN * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_LEAN, 0, s)); break;
+      case KIND_TALL_S: HIP_TRY(launch_solve_tall(TALL_VARIANT_SMALL, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_SMALL * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_SMALL, lean_merged, s)); break;
+      case KIND_TALL: HIP_TRY(launch_solve_tall(TALL_VARIANT_LARGE, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_LARGE * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_LARGE, 0, s)); break;
       default: HIP_TRY(launch_solve_wave(B, O, P, theta0, b0, cnt, kClasses[c].lds, s)); break;
     }
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev1[c], s)); ctx->impl.ev_used[c] = true; }

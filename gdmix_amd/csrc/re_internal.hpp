@@ -78,7 +78,14 @@ struct ClassTable {
   int64_t team_nnz;    // 0 = team tiers off
   int tall_min_n;      // entities with p <= TALL_MAX_P and at least this many samples use the tall kernel (0 = never)
   int tall_split_n;    // ... those with at least this many samples one workgroup per CU, the others several
+  int tall_adapt_limit;   // > 0: a batch whose eight-wavefront tall class would stay this small with a lower split (2 048, 1 024 or 512 samples)
+                          // gets that split (class_base_kernel decides on the device, re_order_kernel moves the entities); 0 = the split is fixed
 };
+// counts[3 * NUM_CLASSES + k], k = 0..2: one-wavefront tall entities (TALL_S_CLASS) with at least TALL_ADAPT_N[k] samples;
+// counts[3 * NUM_CLASSES + TALL_ADAPT_SLOT]: the split class_base_kernel chose (0: none). (The row's team-tier columns hold the tiers' largest entity.)
+constexpr int TALL_ADAPT_STEPS = 3;
+__host__ __device__ constexpr int tall_adapt_n(int k) { return k == 0 ? 512 : (k == 1 ? 1024 : 2048); }
+constexpr int TALL_ADAPT_SLOT = 3;
 
 // Device pointers of a packed batch, passed by value to kernels.
 struct BatchDev {
@@ -121,12 +128,17 @@ struct gdmix_ctx_impl {
   int64_t team_nnz;       // lowest tier of the team kernel (0 = never)
   int tall_min_n;         // tall kernel for p <= 64 and n >= this (0 = never)
   int tall_split_n;       // tall entities with n >= this: one large workgroup per CU
+  int tall_adapt_limit;   // ClassTable::tall_adapt_limit of this device (half its CUs; GDMIX_RE_TALL_ADAPT overrides, 0 = off)
   void* grid_sync;        // device: TeamSync of the team kernels (the first three also: ticket counters of the tall variants), followed
                           // by TALL_TAIL_BYTES for each tall variant
   void* big_tmp;          // device: grow-only temporary of the big-entity pack path
   size_t big_tmp_bytes;
-  hipStream_t side;       // classes too small to fill the device run here, next to the large ones on the caller's stream (nullptr: off)
-  hipEvent_t side_fork, side_join;
+  // classes too small to fill the device run on side streams, next to the large ones on the caller's stream and next to each other
+  // (round-robin; n_side == 0: off). A share of a strongly scaled job is ALL small classes: on one side stream they ran one after another.
+  static constexpr int MAX_SIDE = 4;
+  hipStream_t side[MAX_SIDE];
+  int n_side;
+  hipEvent_t side_fork, side_join[MAX_SIDE];
   hipEvent_t ev0[GDMIX_RE_NUM_CLASSES], ev1[GDMIX_RE_NUM_CLASSES];
   bool ev_used[GDMIX_RE_NUM_CLASSES];
 };
@@ -153,9 +165,23 @@ inline size_t block_slot_doubles(int64_t max_p, int64_t max_n, int m) {
   return (size_t)5 * max_p + (size_t)2 * m * ((max_p + 63) & ~(int64_t)63) + max_n + 2 * m + 8 + 256 * 64;
 }
 
+// Once side streams have forked from the caller's stream, EVERY way out of the function joins them back (an error between
+// fork and join used to return with side-stream kernels still running on buffers the caller may then free or reuse).
+struct SideJoin {
+  gdmix_ctx_impl* ci; hipStream_t main; bool active = false;
+  void join() {
+    if (!active) return;
+    active = false;
+    for (int k = 0; k < ci->n_side; ++k)
+      if (hipEventRecord(ci->side_join[k], ci->side[k]) != hipSuccess || hipStreamWaitEvent(main, ci->side_join[k], 0) != hipSuccess)
+        (void)hipStreamSynchronize(ci->side[k]);   // last resort: the caller's stream must not run ahead of a side stream
+  }
+  ~SideJoin() { join(); }
+};
+
 hipError_t launch_classify(const gdmix_re_packed* b, int ic, int m, const ClassTable& tab, int32_t* cls_tmp,
                            int32_t* counts_dev, hipStream_t s);
-hipError_t launch_order(const gdmix_re_packed* b, const int32_t* cls_tmp, const int32_t* class_base_dev,
+hipError_t launch_order(const gdmix_re_packed* b, int32_t* cls_tmp, const int32_t* class_base_dev,
                         int32_t* cursor_dev, hipStream_t s);
 hipError_t launch_solve_quad(int g, int epl, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0,
                              int begin, int count, int ncap, int zcap, hipStream_t s);
@@ -169,7 +195,7 @@ hipError_t launch_solve_grid(const BatchDev& B, const OutDev& O, const SolvePara
                              void* sync_buf, int blocks, int teams, hipStream_t s);
 constexpr int TALL_TAIL_BYTES = 256;   // device buffer of the context: padded copy of the end of the batch's row-major arrays
 hipError_t launch_solve_tall(int variant, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0, int begin, int count,
-                             int num_cus, int64_t Z, void* tail_buf, void* sync_buf, hipStream_t s);
+                             int num_cus, int64_t Z, void* tail_buf, void* sync_buf, int front_small, hipStream_t s);
 void launch_sort_class(int32_t* list, int count, const int64_t* ent_nnz_ptr, hipStream_t s);
 hipError_t launch_variance_full(const BatchDev& B, int64_t E, const SolveParams& o, const double* theta, double* variance,
                                 double* scratch, size_t slot_doubles, int slots, int64_t max_p, hipStream_t s);

@@ -27,10 +27,66 @@ struct PackStats {      // device-side, read back once per pack
   int n_mid2, pad;        // entities deferred from the 512-key to the 1024-key kernel
 };
 
-__global__ void pack_entnnz_kernel(const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ row_nnz_ptr,
-                                   int64_t E, int64_t* __restrict__ ent_nnz_ptr) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e <= E; e += (int64_t)gridDim.x * blockDim.x)
-    ent_nnz_ptr[e] = row_nnz_ptr[ent_row_ptr[e]];
+// ent_nnz_ptr, and the route of every entity through the pack: by max(samples, non-zeros) the 256-key wavefront tier (nothing to
+// do here: that tier walks all entities and skips the others), the 512-key list, the 1 024-key list, or the list of the device-wide
+// sort. The lists are complete when this kernel ends, so the tiers and the device-wide path run next to each other (round 4; before,
+// each tier appended what it could not hold to the next one's list: three launches and a read-back in a row, ~0.45 ms of a 17 k-entity
+// MovieLens share's 0.83 ms pack). One atomic per wavefront and list (ballot + count); the order inside a list is arbitrary, as before,
+// and matters to nothing: every entity's output lies at offsets of its own.
+constexpr int PACK_CAP1 = PACK_LDS_KEYS, PACK_CAP2 = 512, PACK_CAP3 = 1024;   // the tiers' capacities (pack_entity_kernel<CAP, ...>)
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o); v = w > v ? w : v; }
+  return v;
+}
+__global__ __launch_bounds__(256) void pack_entnnz_kernel(const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ row_nnz_ptr,
+                                                          int64_t E, int64_t* __restrict__ ent_nnz_ptr, int32_t* __restrict__ mid_list,
+                                                          int32_t* __restrict__ mid2_list, int32_t* __restrict__ big_list,
+                                                          PackStats* __restrict__ stats) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t rounds = (E + 1 + stride - 1) / stride;     // every lane of a wavefront makes the same number of trips (ballots below)
+  for (int64_t r = 0; r < rounds; ++r) {
+    const int64_t e = r * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int tier = 0;
+    int n = 0, z = 0;
+    if (e <= E) {
+      const int64_t r0 = ent_row_ptr[e];
+      const int64_t z0 = row_nnz_ptr[r0];
+      ent_nnz_ptr[e] = z0;
+      if (e < E) {
+        const int64_t r1 = ent_row_ptr[e + 1];
+        const int64_t n64 = r1 - r0, z64 = row_nnz_ptr[r1] - z0;
+        if (n64 <= 0x7ffffff0ll && z64 <= 0x7ffffff0ll) {   // (beyond: the first tier reports the entity, GDMIX_RE_ERANGE)
+          n = (int)n64; z = (int)z64;
+          const int mx = n > z ? n : z;
+          tier = mx <= PACK_CAP1 ? 0 : (mx <= PACK_CAP2 ? 1 : (mx <= PACK_CAP3 ? 2 : 3));
+        }
+      }
+    }
+    if (__ballot(tier != 0) == 0ull) continue;
+#pragma unroll
+    for (int t = 1; t <= 3; ++t) {
+      const unsigned long long mask = __ballot(tier == t);
+      if (mask == 0ull) continue;
+      int32_t* const list = t == 1 ? mid_list : (t == 2 ? mid2_list : big_list);
+      int* const counter = t == 1 ? &stats->n_mid : (t == 2 ? &stats->n_mid2 : &stats->n_big);
+      int base = 0;
+      if (lane == 0) base = atomicAdd(counter, __popcll(mask));
+      base = __shfl(base, 0);
+      if (tier == t) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)e;
+    }
+    if (__ballot(tier == 3) != 0ull) {   // the device-wide sort's entities: their total, and their part of the batch's maxima
+      const unsigned long long zz = (unsigned long long)wave_sum_u64(tier == 3 ? (unsigned long long)z : 0ull);
+      const int mn = wave_max_i32(tier == 3 ? n : 0), mz = wave_max_i32(tier == 3 ? z : 0);
+      if (lane == 0) { atomicAdd(&stats->big_nnz, zz); atomicMax(&stats->max_n, mn); atomicMax(&stats->max_nnz, mz); }
+    }
+  }
 }
 
 // ---- per-entity pack -----------------------------------------------------------------------------------------
@@ -202,12 +258,11 @@ __device__ __forceinline__ int count_entity(const unsigned long long* keys, unsi
 }
 
 // CAP = LDS staging capacity (non-zeros and samples) of a wavefront, NWAVES = wavefronts per workgroup.
-// in_list == nullptr: all E entities; otherwise the *in_count entities of in_list. Entities above CAP are
-// appended to out_list (counter *out_count).
+// in_list == nullptr: all E entities, those above CAP skipped (pack_entnnz_kernel put them on a later stage's list);
+// otherwise the *in_count entities of in_list, which fit by construction.
 template <int CAP, int NWAVES>
 __global__ __launch_bounds__(WAVE* NWAVES) void pack_entity_kernel(
-    const int32_t* __restrict__ in_list, const int* __restrict__ in_count, int32_t* __restrict__ out_list,
-    int* __restrict__ out_count, unsigned long long* __restrict__ out_nnz,
+    const int32_t* __restrict__ in_list, const int* __restrict__ in_count,
     const int64_t* __restrict__ ent_row_ptr, const int64_t* __restrict__ row_nnz_ptr,
     const int64_t* __restrict__ ent_nnz_ptr, const int64_t* __restrict__ col_global, const float* __restrict__ val,
     int64_t E, int ic, int32_t* __restrict__ row_ptr, unsigned long long* __restrict__ sort_key,
@@ -238,16 +293,8 @@ __global__ __launch_bounds__(WAVE* NWAVES) void pack_entity_kernel(
     }
     const int n = (int)n64, nnz = (int)nnz64;
     const bool small = nnz <= CAP && n <= CAP;
-    if (!small) {
-      // too large for this kernel's LDS staging: deferred to the next pack stage, which also writes its row pointers (one
-      // wavefront walking the rows of a 4 M-sample entity here cost 27 ms; the last stage does it one thread per row)
-      if (lane == 0) {
-        out_list[atomicAdd(out_count, 1)] = (int32_t)e;
-        if (out_nnz) atomicAdd(out_nnz, (unsigned long long)nnz);
-      }
-      mx_n = max(mx_n, n); mx_z = max(mx_z, nnz);
-      continue;
-    }
+    if (!small) continue;   // a later stage's (which also writes its row pointers: one wavefront walking the rows of a 4 M-sample
+                            // entity here cost 27 ms; the last stage does it one thread per row)
     int32_t* const rp_out = row_ptr + r0 + e;
     for (int i = lane; i <= n; i += WAVE) {
       const int32_t v = (int32_t)(row_nnz_ptr[r0 + i] - z0);
@@ -494,56 +541,64 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
   unsigned long long* sort_key = reinterpret_cast<unsigned long long*>(base + L.sort_key);
 
   HIP_TRY(hipMemsetAsync(stats, 0, sizeof(PackStats), s));
+  int32_t* uniq_sparse = reinterpret_cast<int32_t*>(base + L.uniq_sparse);
+  int32_t* big_list = reinterpret_cast<int32_t*>(base + L.big_list);
+  int32_t* mid_list = reinterpret_cast<int32_t*>(base + L.mid_list);
+  int32_t* mid2_list = reinterpret_cast<int32_t*>(base + L.mid2_list);
   {
     int grid = (int)((E + 1 + 255) / 256);
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(pack_entnnz_kernel, dim3(grid), dim3(256), 0, s, raw->ent_row_ptr, raw->row_nnz_ptr, E,
-                       out->ent_nnz_ptr);
+                       out->ent_nnz_ptr, mid_list, mid2_list, big_list, stats);
   }
   DBG_STAGE("pack_entnnz_kernel");
+  // Four stages by entity size — wavefront + 256-key LDS staging (rank sort), + 512 keys, + 1 024 keys, and the device-wide sort
+  // for what is larger — on four streams: their entity lists are complete (pack_entnnz_kernel), their outputs disjoint. The later
+  // stages read their counts from device counters (usually zero: the fixed grids exit at once). With fewer than three side
+  // streams (GDMIX_RE_SIDE_STREAM) the stages run one after another on the caller's stream.
+  const bool fan = ctx->n_side >= 3;
+  SideJoin side_join{ctx, s};
+  hipStream_t s2 = s, s3 = s, sb = s;
+  if (fan) {
+    HIP_TRY(hipEventRecord(ctx->side_fork, s));
+    for (int k = 0; k < 3; ++k) HIP_TRY(hipStreamWaitEvent(ctx->side[k], ctx->side_fork, 0));
+    side_join.active = true;
+    sb = ctx->side[0]; s2 = ctx->side[1]; s3 = ctx->side[2];
+  }
+  // the device-wide sort's entities (usually none): their number and size are only known on the device, hence the read-back — on
+  // its own stream, while the wavefront stages below run
+  PackStats* hs = reinterpret_cast<PackStats*>(ctx->host_pinned);
+  HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(PackStats), hipMemcpyDeviceToHost, sb));
   int eblocks = (int)((E + PACK_WAVES - 1) / PACK_WAVES);
   if (eblocks > ctx->num_cus * 16) eblocks = ctx->num_cus * 16;
-  int32_t* uniq_sparse = reinterpret_cast<int32_t*>(base + L.uniq_sparse);
-  int32_t* big_list = reinterpret_cast<int32_t*>(base + L.big_list);
-  int32_t* mid_list = reinterpret_cast<int32_t*>(base + L.mid_list);
-  // three tiers by entity size: wavefront + 256-key LDS staging (rank sort), wavefront + 1024-key staging,
-  // workgroup + in-place sort in HBM scratch. The later tiers read their entity lists from device counters
-  // (usually empty: the fixed grids exit at once).
   hipLaunchKernelGGL((pack_entity_kernel<PACK_LDS_KEYS, PACK_WAVES>), dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s,
-                     (const int32_t*)nullptr, (const int*)nullptr, mid_list, &stats->n_mid, (unsigned long long*)nullptr,
-                     raw->ent_row_ptr,
+                     (const int32_t*)nullptr, (const int*)nullptr, raw->ent_row_ptr,
                      raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
                      out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
   DBG_STAGE("pack_entity_kernel<256>");
   // (a C5-shaped entity has 256 +- 50 non-zeros: half of them overflow the first tier; the 512-key tier runs four workgroups of
   // four wavefronts per CU where the 1024-key one runs four of two, and sorts half as many keys)
-  int32_t* mid2_list = reinterpret_cast<int32_t*>(base + L.mid2_list);
-  hipLaunchKernelGGL((pack_entity_kernel<512, 4>), dim3(ctx->num_cus * 4), dim3(WAVE * 4), 0, s,
-                     (const int32_t*)mid_list, (const int*)&stats->n_mid, mid2_list, &stats->n_mid2, (unsigned long long*)nullptr,
-                     raw->ent_row_ptr,
+  hipLaunchKernelGGL((pack_entity_kernel<PACK_CAP2, 4>), dim3(ctx->num_cus * 4), dim3(WAVE * 4), 0, s2,
+                     (const int32_t*)mid_list, (const int*)&stats->n_mid, raw->ent_row_ptr,
                      raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
                      out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
   DBG_STAGE("pack_entity_kernel<512>");
-  hipLaunchKernelGGL((pack_entity_kernel<1024, 2>), dim3(ctx->num_cus * 4), dim3(WAVE * 2), 0, s,
-                     (const int32_t*)mid2_list, (const int*)&stats->n_mid2, big_list, &stats->n_big, &stats->big_nnz,
-                     raw->ent_row_ptr,
+  hipLaunchKernelGGL((pack_entity_kernel<PACK_CAP3, 2>), dim3(ctx->num_cus * 4), dim3(WAVE * 2), 0, s3,
+                     (const int32_t*)mid2_list, (const int*)&stats->n_mid2, raw->ent_row_ptr,
                      raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
                      out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
   DBG_STAGE("pack_entity_kernel<1024>");
-  // entities too large for the wavefront kernels (usually none): one device-wide sort over all of them. Their
-  // number and size are only known on the device, hence the read-back in the middle of the pack.
   {
-    PackStats* hs = reinterpret_cast<PackStats*>(ctx->host_pinned);
-    HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(PackStats), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipStreamSynchronize(sb));
     if (hs->n_big > 0) {
       BigPackArgs A{raw->ent_row_ptr, out->ent_nnz_ptr, raw->row_nnz_ptr, raw->col_global, raw->val, ic, out->row_ptr, out->csr_col,
                     out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, big_list, hs->n_big,
                     (int64_t)hs->big_nnz, &stats->max_p, &stats->err};
-      const int rc = pack_big_entities(ctx, A, s);
+      const int rc = pack_big_entities(ctx, A, sb);
       if (rc != GDMIX_RE_OK) return rc;
     }
   }
+  side_join.join();
   DBG_STAGE("pack_big_entities");
   const int nb = (int)((E + SCAN_CHUNK - 1) / SCAN_CHUNK);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, s, d_cnt, E, block_sums);
@@ -558,7 +613,6 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
   }
   DBG_STAGE("pack_compact_unique_kernel");
   HIP_TRY(hipGetLastError());
-  PackStats* hs = reinterpret_cast<PackStats*>(ctx->host_pinned);
   HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(PackStats), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (hs->err) {

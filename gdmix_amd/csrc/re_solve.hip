@@ -19,7 +19,9 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
                                    const int64_t* __restrict__ ent_feat_ptr, int64_t E, int ic, int m, bool has_w,
                                    ClassTable tab, int32_t* __restrict__ cls_out, int32_t* __restrict__ counts) {
   __shared__ int32_t local[GDMIX_RE_NUM_CLASSES];
+  __shared__ int32_t tall_ge[TALL_ADAPT_STEPS];
   if (threadIdx.x < GDMIX_RE_NUM_CLASSES) local[threadIdx.x] = 0;
+  if (threadIdx.x < TALL_ADAPT_STEPS) tall_ge[threadIdx.x] = 0;
   __syncthreads();
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(ent_row_ptr[e + 1] - ent_row_ptr[e]);
@@ -50,6 +52,11 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
     }
     cls_out[e] = c;
     atomicAdd(&local[c], 1);
+    if (c == TALL_S_CLASS && tab.tall_adapt_limit > 0 && n >= tall_adapt_n(0)) {
+#pragma unroll
+      for (int k = 0; k < TALL_ADAPT_STEPS; ++k)
+        if (n >= tall_adapt_n(k)) atomicAdd(&tall_ge[k], 1);
+    }
     if (c >= TEAM128_CLASS && c <= TEAM8_CLASS) {
       // work of the team tiers (non-zeros: total and largest entity), for the choice of the team size; rare entities
       atomicAdd(reinterpret_cast<unsigned long long*>(counts + 4 * GDMIX_RE_NUM_CLASSES) + c, (unsigned long long)z);
@@ -58,16 +65,21 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
   }
   __syncthreads();
   if (threadIdx.x < GDMIX_RE_NUM_CLASSES && local[threadIdx.x]) atomicAdd(&counts[threadIdx.x], local[threadIdx.x]);
+  if (threadIdx.x < TALL_ADAPT_STEPS && tall_ge[threadIdx.x]) atomicAdd(&counts[3 * GDMIX_RE_NUM_CLASSES + threadIdx.x], tall_ge[threadIdx.x]);
 }
 
 // order[class_base[c] + k] = e. Position inside a class is by ticket: the launch order inside a class
 // does not influence any entity's result (every entity is solved independently and deterministically),
 // only which workgroup picks it up. Tickets are taken per workgroup (LDS histogram, then one global
 // atomic per class per workgroup): per-entity global atomics on 8 addresses serialise in L2.
-__global__ __launch_bounds__(256) void re_order_kernel(const int32_t* __restrict__ cls, int64_t E,
+// split > 0 (class_base_kernel lowered the split of the tall classes for this batch): one-wavefront tall entities of at least
+// `split` samples move to the eight-wavefront class here, in cls as well (the per-class times are attributed through it).
+__global__ __launch_bounds__(256) void re_order_kernel(int32_t* __restrict__ cls, int64_t E,
                                                        const int32_t* __restrict__ class_base,
-                                                       int32_t* __restrict__ cursor, int32_t* __restrict__ order) {
+                                                       int32_t* __restrict__ cursor, int32_t* __restrict__ order,
+                                                       const int64_t* __restrict__ ent_row_ptr, const int32_t* __restrict__ split_dev) {
   __shared__ int32_t cnt[GDMIX_RE_NUM_CLASSES], base[GDMIX_RE_NUM_CLASSES];
+  const int split = *split_dev;
   const int64_t chunk = (int64_t)blockDim.x * 8;
   for (int64_t start = (int64_t)blockIdx.x * chunk; start < E; start += (int64_t)gridDim.x * chunk) {
     if (threadIdx.x < GDMIX_RE_NUM_CLASSES) cnt[threadIdx.x] = 0;
@@ -77,6 +89,7 @@ __global__ __launch_bounds__(256) void re_order_kernel(const int32_t* __restrict
     for (int k = 0; k < 8; ++k) {
       const int64_t e = start + (int64_t)k * blockDim.x + threadIdx.x;
       c[k] = (e < E) ? cls[e] : -1;
+      if (split > 0 && c[k] == TALL_S_CLASS && ent_row_ptr[e + 1] - ent_row_ptr[e] >= split) { c[k] = TALL_CLASS; cls[e] = TALL_CLASS; }
       pos[k] = (c[k] >= 0) ? atomicAdd(&cnt[c[k]], 1) : 0;
     }
     __syncthreads();
@@ -102,13 +115,14 @@ hipError_t launch_classify(const gdmix_re_packed* b, int ic, int m, const ClassT
   return hipGetLastError();
 }
 
-hipError_t launch_order(const gdmix_re_packed* b, const int32_t* cls_tmp, const int32_t* class_base_dev,
+hipError_t launch_order(const gdmix_re_packed* b, int32_t* cls_tmp, const int32_t* class_base_dev,
                         int32_t* cursor_dev, hipStream_t s) {
   if (b->E == 0) return hipSuccess;
   int grid = (int)((b->E + 2047) / 2048);
   if (grid > 2048) grid = 2048;
+  // (class_base_dev = counts + NUM_CLASSES: the chosen split sits two rows further)
   hipLaunchKernelGGL(re_order_kernel, dim3(grid), dim3(256), 0, s, cls_tmp, b->E, class_base_dev, cursor_dev,
-                     b->order);
+                     b->order, b->ent_row_ptr, class_base_dev + 2 * GDMIX_RE_NUM_CLASSES + TALL_ADAPT_SLOT);
   return hipGetLastError();
 }
 
@@ -437,6 +451,7 @@ __global__ __launch_bounds__(WAVE* BLOCK_NW) void re_solve_block_kernel(BatchDev
 // and with it the launch are reproducible. Lists longer than SORT_CAP stay in ticket order.
 // ---------------------------------------------------------------------------------------------------
 constexpr int SORT_CAP = 16384;   // 128 KB of keys in LDS
+constexpr int SORT_RANK_CAP = 4096;
 __global__ __launch_bounds__(1024) void re_sort_class_kernel(int32_t* __restrict__ list, int count,
                                                              const int64_t* __restrict__ ent_nnz_ptr) {
   extern __shared__ __align__(16) unsigned char sort_smem[];
@@ -453,6 +468,30 @@ __global__ __launch_bounds__(1024) void re_sort_class_kernel(int32_t* __restrict
     key[i] = k;
   }
   __syncthreads();
+  if (count <= SORT_RANK_CAP) {
+    // short lists: the rank of a key is the number of smaller keys (keys are distinct: the entity index is part of them) — one
+    // barrier instead of the ~60 of the bitonic network, whose stages each wait for the slowest wavefront of a CU the group kernels
+    // of the same solve are using (1 746 entities of a MovieLens share: 325 us on the critical path of a 3 ms step).
+    unsigned long long mine[SORT_RANK_CAP / 1024];
+    int rank[SORT_RANK_CAP / 1024];
+#pragma unroll
+    for (int q = 0; q < SORT_RANK_CAP / 1024; ++q) {
+      const int i = threadIdx.x + q * 1024;
+      mine[q] = i < count ? key[i] : ~0ull;
+      rank[q] = 0;
+    }
+    const int nq = (count + 1023) / 1024;      // rows of keys in use (uniform)
+    for (int t = 0; t < count; ++t) {
+      const unsigned long long other = key[t];   // the same address for every lane: one broadcast read
+#pragma unroll
+      for (int q = 0; q < SORT_RANK_CAP / 1024; ++q)
+        if (q < nq) rank[q] += other < mine[q] ? 1 : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < SORT_RANK_CAP / 1024; ++q)
+      if (threadIdx.x + q * 1024 < count) list[rank[q]] = (int32_t)(uint32_t)mine[q];
+    return;
+  }
   for (int k = 2; k <= np2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int t = threadIdx.x; t < np2; t += blockDim.x) {

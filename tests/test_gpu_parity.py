@@ -651,3 +651,47 @@ def test_wire_form_widens_to_the_raw_batch(device_solver, shape):
     torch.cuda.synchronize()
     for k in ("ent_row_ptr", "row_nnz_ptr", "col_global", "y"):
         assert np.array_equal(rd2[k].cpu().numpy(), getattr(b, k)), k
+
+
+def test_a_small_batch_lowers_the_tall_split_and_only_the_rounding_changes(device_solver):
+    """Round 4: a batch whose eight-wavefront tall class stays small anyway (a share of a strongly scaled MovieLens job) gets a lower
+    split between the one-wavefront and the eight-wavefront tall kernels — chosen on the device (class_base_kernel), the entities moved
+    by re_order_kernel. 1 500 MovieLens-20M users: with the split fixed (an explicit gdmix_re_set_tall_split_n keeps it) only the few
+    users above 4 096 samples take the eight-wavefront kernel; by default every user of at least the chosen split does, the counts add
+    up, nobody is lost, and the two solutions agree to rounding (different summation order; same iteration counts but for the
+    entities whose trajectory is rounding-sensitive) — both against the oracle's tolerance of the fixtures."""
+    b = synthetic.make_movielens_20m("per_user", seed=83, entities=1500)
+    n = b.ent_n()
+    kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
+    names = ("re_solve_tall_kernel<8> p<=64", "re_solve_tall_kernel<1> p<=64", "re_solve_tall_kernel<1> lean p<=64")
+    packed = device_solver.pack(b)
+    adaptive = device_solver.solve(packed, SolverOptions(**kw)).to_host()
+    ca = dict(device_solver.class_counts(packed))
+    cls_a = packed._view(packed.c.cls_tmp, packed.E, device_solver.torch.int32).cpu().numpy().copy()
+    try:
+        device_solver.set_tall_split_n(4097)      # any explicit value switches the per-batch choice off
+        fixed = device_solver.solve(packed, SolverOptions(**kw)).to_host()
+        cf = dict(device_solver.class_counts(packed))
+        cls_f = packed._view(packed.c.cls_tmp, packed.E, device_solver.torch.int32).cpu().numpy().copy()
+    finally:
+        device_solver.set_tall_split_n(4096)
+    assert cf[names[0]] == int((n >= 4097).sum()) and cf[names[0]] < 20
+    moved = ca[names[0]] - cf[names[0]]
+    assert moved > 20 and ca[names[0]] <= 192, (ca[names[0]], cf[names[0]])
+    assert ca[names[1]] == cf[names[1]] - moved and ca[names[2]] == cf[names[2]]
+    assert sum(ca.values()) == sum(cf.values()) == b.E
+    # exactly the one-wavefront entities of at least the chosen split moved, and the split is one of the three candidates
+    idx = {name: i for i, (name, _) in enumerate(device_solver.class_counts(packed))}
+    went = (cls_a == idx[names[0]]) & (cls_f != idx[names[0]])
+    assert int(went.sum()) == moved
+    assert [s for s in (512, 1024, 2048) if np.array_equal(went, (cls_f == idx[names[1]]) & (n >= s))], int(n[went].min())
+    assert np.array_equal(adaptive["status"], fixed["status"])
+    same_nit = adaptive["nit"] == fixed["nit"]
+    assert same_nit.mean() > 0.97
+    cp = packed.coef_ptr_host()
+    worst = 0.0
+    for e in np.flatnonzero(same_nit):
+        a, f = adaptive["theta"][cp[e]:cp[e + 1]], fixed["theta"][cp[e]:cp[e + 1]]
+        worst = max(worst, float(np.max(np.abs(a - f)) / max(np.max(np.abs(f)), 1e-300)))
+    assert worst <= 1e-7, worst
+    np.testing.assert_allclose(adaptive["fval"], fixed["fval"], rtol=1e-9, atol=1e-12)
