@@ -477,21 +477,18 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
       if (c == TALL_S_CLASS) cnt += lean_merged;
       forked = cnt > 0 && class_is_small(kClasses[c].kind, cnt, ctx->impl.num_cus);
     }
-    if (forked) {
-      HIP_TRY(hipEventRecord(ctx->impl.side_fork, s_main));
-      for (int k = 0; k < ctx->impl.n_side; ++k) HIP_TRY(hipStreamWaitEvent(ctx->impl.side[k], ctx->impl.side_fork, 0));
-      side_join.active = true;
-    }
+    if (forked) HIP_TRY(hipEventRecord(ctx->impl.side_fork, s_main));
   }
   // Launch plan. The tall classes go first: their kernels are the longest chains of a small batch (one workgroup, or one wavefront,
   // per entity, for as long as that entity's solve lasts) and each is preceded by three small launches (fill, sort, tail) that must
   // not queue behind the group kernels' workgroups. Stream of a class:
   //   large class                      -> the caller's stream, in launch order;
-  //   small tall class (<8>, <1>, lean) -> a side stream of its own (side 0, 1, 2: the device has four hardware queues by default,
+  //   small tall class (<8>, <1>, lean) -> a side stream of its own (side 1, 2, 0: the device has four hardware queues by default,
   //                                        a fourth side stream would share one — measured: both tall classes of a MovieLens share on
   //                                        one queue, 1.1 + 2.1 ms one after the other);
-  //   other small classes              -> the caller's stream when no large class uses it, else the last side stream (behind the
-  //                                        lean tall class, the shortest of the three).
+  //   other small classes              -> the caller's stream when no large class uses it, else side 0 (behind the lean tall class,
+  //                                        the shortest of the three).
+  // Only the streams that get work are woken (SideJoin::use): a C2 partition touches the caller's stream and side 0.
   // Disjoint entities and outputs; the tall variants have a tail slot each: a schedule changes the time, never a bit of the result.
   struct Launch { int c, b0, cnt; bool small; };
   Launch plan[GDMIX_RE_NUM_CLASSES];
@@ -523,10 +520,11 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     hipStream_t s = s_main;
     if (plan[k].small) {
       const int ns = ctx->impl.n_side;
-      if (c == TALL_CLASS) s = ctx->impl.side[0];
-      else if (c == TALL_S_CLASS) s = ctx->impl.side[1 % ns];
-      else if (c == TALL_L_CLASS) s = ctx->impl.side[2 % ns];
-      else s = any_large ? ctx->impl.side[ns - 1] : s_main;
+      int k_side = -1;
+      if (c == TALL_CLASS) k_side = 1 % ns;
+      else if (c == TALL_S_CLASS) k_side = 2 % ns;
+      else if (c == TALL_L_CLASS || any_large) k_side = 0;
+      if (k_side >= 0) { HIP_TRY(side_join.use(k_side)); s = ctx->impl.side[k_side]; }
     }
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[c], s)); }
     switch (kClasses[c].kind) {

@@ -168,13 +168,21 @@ inline size_t block_slot_doubles(int64_t max_p, int64_t max_n, int m) {
 // Once side streams have forked from the caller's stream, EVERY way out of the function joins them back (an error between
 // fork and join used to return with side-stream kernels still running on buffers the caller may then free or reuse).
 struct SideJoin {
-  gdmix_ctx_impl* ci; hipStream_t main; bool active = false;
+  gdmix_ctx_impl* ci; hipStream_t main; unsigned used = 0;   // bit k: side stream k has work of this call
+  // side stream k joins in: it waits for the fork event (recorded on the caller's stream by the function that owns this object)
+  hipError_t use(int k) {
+    if (used & (1u << k)) return hipSuccess;
+    const hipError_t rc = hipStreamWaitEvent(ci->side[k], ci->side_fork, 0);
+    if (rc == hipSuccess) used |= 1u << k;
+    return rc;
+  }
   void join() {
-    if (!active) return;
-    active = false;
-    for (int k = 0; k < ci->n_side; ++k)
+    for (int k = 0; k < ci->n_side; ++k) {
+      if (!(used & (1u << k))) continue;
       if (hipEventRecord(ci->side_join[k], ci->side[k]) != hipSuccess || hipStreamWaitEvent(main, ci->side_join[k], 0) != hipSuccess)
         (void)hipStreamSynchronize(ci->side[k]);   // last resort: the caller's stream must not run ahead of a side stream
+    }
+    used = 0;
   }
   ~SideJoin() { join(); }
 };

@@ -33,6 +33,7 @@ struct PackStats {      // device-side, read back once per pack
 // each tier appended what it could not hold to the next one's list: three launches and a read-back in a row, ~0.45 ms of a 17 k-entity
 // MovieLens share's 0.83 ms pack). One atomic per wavefront and list (ballot + count); the order inside a list is arbitrary, as before,
 // and matters to nothing: every entity's output lies at offsets of its own.
+constexpr int64_t PACK_FAN_MAX_ENTITIES = 1 << 18;   // batches up to this size run the pack's stages on several streams (pack_impl)
 constexpr int PACK_CAP1 = PACK_LDS_KEYS, PACK_CAP2 = 512, PACK_CAP3 = 1024;   // the tiers' capacities (pack_entity_kernel<CAP, ...>)
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
@@ -553,22 +554,28 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
   }
   DBG_STAGE("pack_entnnz_kernel");
   // Four stages by entity size — wavefront + 256-key LDS staging (rank sort), + 512 keys, + 1 024 keys, and the device-wide sort
-  // for what is larger — on four streams: their entity lists are complete (pack_entnnz_kernel), their outputs disjoint. The later
-  // stages read their counts from device counters (usually zero: the fixed grids exit at once). With fewer than three side
-  // streams (GDMIX_RE_SIDE_STREAM) the stages run one after another on the caller's stream.
-  const bool fan = ctx->n_side >= 3;
+  // for what is larger. Their entity lists are complete (pack_entnnz_kernel) and their outputs disjoint, so they run next to each
+  // other: the first on the caller's stream; the counts of the others are read back on side stream 0 meanwhile (their number and
+  // size are only known on the device), and each stage that has entities gets a stream — side 1, side 2, and side 0 for the
+  // device-wide sort. A batch of small entities only (C2) touches the caller's stream and side 0, like its solve: a context that
+  // woke all its streams for every partition cost three concurrent contexts a third of their throughput (hand-over leg 77 -> 50 M
+  // entities/s: more active streams than the device has hardware queues). With fewer side streams (GDMIX_RE_SIDE_STREAM) the
+  // stages share what there is; with none they run one after another on the caller's stream, all launched blind as before round 4.
   SideJoin side_join{ctx, s};
-  hipStream_t s2 = s, s3 = s, sb = s;
-  if (fan) {
-    HIP_TRY(hipEventRecord(ctx->side_fork, s));
-    for (int k = 0; k < 3; ++k) HIP_TRY(hipStreamWaitEvent(ctx->side[k], ctx->side_fork, 0));
-    side_join.active = true;
-    sb = ctx->side[0]; s2 = ctx->side[1]; s3 = ctx->side[2];
-  }
-  // the device-wide sort's entities (usually none): their number and size are only known on the device, hence the read-back — on
-  // its own stream, while the wavefront stages below run
   PackStats* hs = reinterpret_cast<PackStats*>(ctx->host_pinned);
-  HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(PackStats), hipMemcpyDeviceToHost, sb));
+  // ... and only for a batch small enough for the fixed costs to matter (a MovieLens share: 0.83 -> 0.62 ms): in a large one the
+  // stages fill the device one after another anyway, and a pack that forks and joins streams costs contexts working side by side
+  // (three of them on 1 M-entity partitions: 77 -> 52 M entities/s even with one side stream — cross-stream waits block hardware
+  // queues the contexts share).
+  const int ns = E <= PACK_FAN_MAX_ENTITIES ? ctx->n_side : 0;
+  hipStream_t const sb = ns >= 1 ? ctx->side[0] : s;
+  hipStream_t const s2 = ns >= 2 ? ctx->side[1] : (ns == 1 ? ctx->side[0] : s);
+  hipStream_t const s3 = ns >= 3 ? ctx->side[2] : s2;
+  if (ns >= 1) {
+    HIP_TRY(hipEventRecord(ctx->side_fork, s));
+    HIP_TRY(side_join.use(0));
+    HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(PackStats), hipMemcpyDeviceToHost, sb));
+  }
   int eblocks = (int)((E + PACK_WAVES - 1) / PACK_WAVES);
   if (eblocks > ctx->num_cus * 16) eblocks = ctx->num_cus * 16;
   hipLaunchKernelGGL((pack_entity_kernel<PACK_LDS_KEYS, PACK_WAVES>), dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s,
@@ -576,20 +583,30 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
                      raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
                      out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
   DBG_STAGE("pack_entity_kernel<256>");
+  if (ns >= 1) HIP_TRY(hipStreamSynchronize(sb));   // the counts (the first stage is running)
   // (a C5-shaped entity has 256 +- 50 non-zeros: half of them overflow the first tier; the 512-key tier runs four workgroups of
   // four wavefronts per CU where the 1024-key one runs four of two, and sorts half as many keys)
-  hipLaunchKernelGGL((pack_entity_kernel<PACK_CAP2, 4>), dim3(ctx->num_cus * 4), dim3(WAVE * 4), 0, s2,
-                     (const int32_t*)mid_list, (const int*)&stats->n_mid, raw->ent_row_ptr,
-                     raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
-                     out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
+  if (ns == 0 || hs->n_mid > 0) {
+    if (ns >= 2) HIP_TRY(side_join.use(1));
+    hipLaunchKernelGGL((pack_entity_kernel<PACK_CAP2, 4>), dim3(ctx->num_cus * 4), dim3(WAVE * 4), 0, s2,
+                       (const int32_t*)mid_list, (const int*)&stats->n_mid, raw->ent_row_ptr,
+                       raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
+                       out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
+  }
   DBG_STAGE("pack_entity_kernel<512>");
-  hipLaunchKernelGGL((pack_entity_kernel<PACK_CAP3, 2>), dim3(ctx->num_cus * 4), dim3(WAVE * 2), 0, s3,
-                     (const int32_t*)mid2_list, (const int*)&stats->n_mid2, raw->ent_row_ptr,
-                     raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
-                     out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
+  if (ns == 0 || hs->n_mid2 > 0) {
+    if (ns >= 2) HIP_TRY(side_join.use(ns >= 3 ? 2 : 1));
+    hipLaunchKernelGGL((pack_entity_kernel<PACK_CAP3, 2>), dim3(ctx->num_cus * 4), dim3(WAVE * 2), 0, s3,
+                       (const int32_t*)mid2_list, (const int*)&stats->n_mid2, raw->ent_row_ptr,
+                       raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
+                       out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
+  }
   DBG_STAGE("pack_entity_kernel<1024>");
   {
-    HIP_TRY(hipStreamSynchronize(sb));
+    if (ns == 0) {
+      HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(PackStats), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+    }
     if (hs->n_big > 0) {
       BigPackArgs A{raw->ent_row_ptr, out->ent_nnz_ptr, raw->row_nnz_ptr, raw->col_global, raw->val, ic, out->row_ptr, out->csr_col,
                     out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, big_list, hs->n_big,
