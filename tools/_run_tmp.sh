@@ -1,8 +1,7 @@
 cd /root/repo
-mkdir -p gpurun_out/r04c
-SIDES="3 1 3" bash tools/r04_handover.sh
-for n in 3 2 1 0; do
-GDMIX_RE_SIDE_STREAM=$n timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "pack or tall or routing or fixture_l2 or ragged" > gpurun_out/r04c/tests_$n.log 2>&1
-echo "side=$n tests rc=$?"; tail -1 gpurun_out/r04c/tests_$n.log | cut -c1-200
+for flags in "--no-fe --no-cli --no-other-workloads --no-strong" "--no-cpu-baseline --no-fe --no-cli --no-other-workloads --no-strong" "--no-cli --no-other-workloads --no-strong" "--no-other-workloads --no-strong"; do
+python bench.py $flags 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); h=d['detail']['host_handover']
+print('$flags: handover %.1f M ent/s (%.2f ms/partition)  with index %.1f M   step %.2f ms' % (h['entities_per_s']/1e6, h['ms_per_partition'], h['with_feature_index']['entities_per_s']/1e6, d['ms_per_step']))"
 done
-SKIP_TESTS=1 ADAPT_LIST="192" bash tools/r04_adapt.sh
