@@ -43,6 +43,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SPREAD_DEFAULT = int(os.environ.get("GDMIX_RE_SPREAD", "4"))   # queues the large size classes are dealt over (gdmix_re_set_spread)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -530,7 +531,18 @@ def other_workloads_leg(a, rank, world, solver, opts, coll_dev):
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
-        kernel_ms = np.array(solver.last_solve_ms())
+        kernel_ms_timed = np.array(solver.last_solve_ms())
+        # launch durations for the roofline: one more step with the classes one after another (in the timed steps the large classes
+        # run side by side and stretch each other: gdmix_re_set_spread)
+        solver.set_spread(0)
+        try:
+            packed = res = None
+            packed = solver.pack(wl.raw_dev)
+            res = solver.solve(packed, opts)
+            torch.cuda.synchronize()
+            kernel_ms = np.array(solver.last_solve_ms())
+        finally:
+            solver.set_spread(SPREAD_DEFAULT)
         st = res.status
         conv = int(((st >= 0) & (st <= 2)).sum().item())
         if world > 1:
@@ -559,7 +571,9 @@ def other_workloads_leg(a, rank, world, solver, opts, coll_dev):
                     "alg_bytes_per_launch": b_alg, "achieved_GBps": b_alg / (dms * 1e-3) / 1e9, "frac_of_hbm_peak": b_alg / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "restreamed_bytes_per_launch": b_str, "restreamed_GBps": b_str / (dms * 1e-3) / 1e9,
                     "restreamed_frac_of_hbm_peak": b_str / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, "mean_nfev": float(nfev_e[sel].mean()),
-                    "note": "B(e) of SURVEY 8(d) over the launch's entities / its HIP-event duration (last timed step); restreamed = nfev x (8 nnz + 16 n) + 8 p + 32"}
+                    "avg_launch_ms_in_the_timed_steps": float(kernel_ms_timed[dom_c]),
+                    "note": "B(e) of SURVEY 8(d) over the launch's entities / its HIP-event duration in one more step with the size classes one after another "
+                            "(gdmix_re_set_spread 0; side by side, as in the timed steps, launches stretch each other); restreamed = nfev x (8 nnz + 16 n) + 8 p + 32"}
             out[w] = {"what": wl.what, "entities_per_gpu": wl.E, "N": wl.N, "Z": wl.Z, "entities_per_s": conv * steps / dt,
                       "ms_per_step": dt / steps * 1e3, "converged_per_step": conv, "host_generate_s": t_gen,
                       "parity_classes": {"W": int(((wl.ones > 0) & (wl.ones < n)).sum()), "D": int(wl.E - ((wl.ones > 0) & (wl.ones < n)).sum())},
@@ -729,6 +743,24 @@ def main():
     else:
         converged_all = converged
     value = converged_all * a.steps / dt
+    # ---- the same step with the size classes one after another (gdmix_re_set_spread 0), NOT part of `value`: in the timed region the
+    # large classes run side by side on four queues (their tails overlap: the step is shorter) and every launch lasts longer than it
+    # would alone — a kernel's own roofline figure needs its duration alone
+    saved = (kernel_ms.copy(), pack_ms, solve_ms, list(step_wall))
+    kernel_ms = np.zeros(NUM_CLASSES)
+    solve_ms = 0.0
+    solver.set_spread(0)
+    try:
+        measured_step()
+        kernel_ms = np.zeros(NUM_CLASSES)
+        solve_ms = 0.0
+        for _ in range(3):
+            res = measured_step()
+        torch.cuda.synchronize()
+    finally:
+        solver.set_spread(SPREAD_DEFAULT)
+    alone_cls_ms, alone_solve_ms = kernel_ms / 3.0, solve_ms / 3.0
+    kernel_ms, pack_ms, solve_ms, step_wall = saved[0], saved[1], saved[2], saved[3]
     # ---- the single-GPU legs next to the headline, BEFORE the large workloads: measured after them (BENCH_r03) the hand-over ran at
     # 58 M entities/s instead of 77 M — the 125 GB of the C5 share churn the allocator's blocks and the page-locked staging
     # (profiles/r04_host_path.txt: the same leg alone, with and without round 3's side stream)
@@ -814,7 +846,9 @@ def main():
         dom_bytes = float(b_e[cls == dom].sum())
         dom_ms = float(cls_ms[dom])
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        all_ms = float(cls_ms.sum())
+        dom_alone_ms = float(alone_cls_ms[dom])
+        achieved_alone = dom_bytes / (dom_alone_ms * 1e-3) / 1e9 if dom_alone_ms > 0 else 0.0
+        all_ms = solve_ms / a.steps      # the solve call's device time (the classes overlap: their launch durations do not add up)
         nfev = res.nfev.double().mean().item()
         nit = res.nit.double().mean().item()
         nfev_e = res.nfev.cpu().numpy().astype(np.float64)
@@ -854,15 +888,20 @@ def main():
                     insts = float(traffic_detail["valu_insts"])
                     peak = 256 * 4 * 2.4e9 / 4.0
                     valu = {"insts_per_launch": insts, "insts_per_entity": insts / max(1, int(classes[dom][1])),
-                            "issue_rate_Ginst_s": insts / (dom_ms * 1e-3) / 1e9 if dom_ms else None,
-                            "issue_frac": insts / (dom_ms * 1e-3) / peak if dom_ms else None,
+                            "issue_rate_Ginst_s": insts / (dom_alone_ms * 1e-3) / 1e9 if dom_alone_ms else None,
+                            "issue_frac": insts / (dom_alone_ms * 1e-3) / peak if dom_alone_ms else None,
                             "peak_Ginst_s": peak / 1e9,
-                            "source": "SQ_INSTS_VALU (rocprofv3 --pmc, separate pass) / live launch duration; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles"}
+                            "source": "SQ_INSTS_VALU (rocprofv3 --pmc, separate pass) / live launch duration of the kernel alone (roofline.alone); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles"}
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "traffic_detail": traffic_detail,
                     "valu": valu,
                     "kernel": classes[dom][0], "entities_in_launch": int(classes[dom][1]),
                     "avg_launch_ms": dom_ms, "alg_bytes_per_launch": dom_bytes,
+                    "schedule": f"timed region: the large size classes run side by side on {SPREAD_DEFAULT} queues (gdmix_re_set_spread), so this launch shares the "
+                                "device with the other classes' and lasts longer than alone; `alone` = the same launch with the classes one after another",
+                    "alone": {"avg_launch_ms": dom_alone_ms, "achieved": round(achieved_alone, 3), "frac": achieved_alone / HBM_PEAK_GBS,
+                              "solve_ms_per_step": alone_solve_ms, "class_ms": [round(float(x), 3) for x in alone_cls_ms],
+                              "what": "3 untimed steps after the timed region with gdmix_re_set_spread(ctx, 0)"},
                     "alg_bytes_per_entity": alg_bytes / wl.E,
                     "restreamed_bytes_per_launch": float(b_s[cls == dom].sum()),
                     "all_solve_kernels": {"ms_per_step": all_ms, "alg_GBps": alg_bytes / (all_ms * 1e-3) / 1e9 if all_ms else 0.0},

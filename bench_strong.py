@@ -87,21 +87,32 @@ def _timed_steps(solver, share, opts, steps, warmup, sync, barrier):
         res = solver.solve(packed, opts)
     sync()
     barrier()
+    import gc
     import torch
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     pack_ms = 0.0
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        packed = res = None
-        ev[0].record()
-        packed = solver.pack(share.raw_dev)
-        ev[1].record()
-        res = solver.solve(packed, opts)
-        ev[2].record()
-        ev[2].synchronize()
-        pack_ms += ev[0].elapsed_time(ev[1])
-    sync()
-    own = time.perf_counter() - t0
+    # a share's step is 2 ms: one full collection of the interpreter's garbage (it came at the same call count of a run, whatever the
+    # share: + 6 - 10 ms on ONE share of eight, tools/r04_tallteam2.sh) would be the slowest "rank" of the job — collected before, not during
+    gc.collect()
+    gc.disable()
+    share.step_ms = []
+    try:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            packed = res = None
+            ev[0].record()
+            packed = solver.pack(share.raw_dev)
+            ev[1].record()
+            res = solver.solve(packed, opts)
+            ev[2].record()
+            ev[2].synchronize()
+            pack_ms += ev[0].elapsed_time(ev[1])
+            share.step_ms.append(round((time.perf_counter() - t1) * 1e3, 3))
+        sync()
+        own = time.perf_counter() - t0
+    finally:
+        gc.enable()
     barrier()
     share.pack_ms = pack_ms / steps
     return packed, res, own, time.perf_counter() - t0, np.array(solver.last_solve_ms())
@@ -346,7 +357,7 @@ def projection_leg(name, ranks, solver, opts, c5_entities, steps=2, warmup=1, ml
         top = sorted(((float(class_ms[c]), names[c], int(cnts[c])) for c in range(NUM_CLASSES) if class_ms[c] > 0), reverse=True)[:5]
         per.append({"rank": r, "largest_launches": [{"kernel": k, "entities": e, "ms": round(ms, 3)} for ms, k, e in top], "entities": share.E, "samples": share.N, "nnz": share.Z, "ms_per_step": own_s / steps * 1e3,
                     "pack_ms": share.pack_ms, "solve_kernel_ms": float(class_ms.sum()), "converged": _converged(res),
-                    "largest_nnz": int(share.z.max()) if share.E else 0,
+                    "largest_nnz": int(share.z.max()) if share.E else 0, "step_wall_ms": list(share.step_ms),
                     "generate_s": round(share.gen_s, 2)})
         total_entities, partitions = share.total_entities, share.partitions
         if name == "c5" and rounds > 0:

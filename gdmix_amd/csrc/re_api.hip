@@ -51,6 +51,7 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_G256_4, 1, "re_solve_grp_kernel<256,4> n<=256 nnz<=2048", 256, 2048}, {KIND_G256_4, 1, "re_solve_grp_kernel<256,4> n<=2048 nnz<=4096", 2048, 4096},
     {KIND_G512_4, 1, "re_solve_grp_kernel<512,4> n<=512 nnz<=4096", 512, 4096},
     {KIND_WLDS, 24576, "re_solve_wave_kernel lds<=24K"},     {KIND_WLDS, 65536, "re_solve_wave_kernel lds<=64K"},
+    {KIND_TALL_T, 0, "re_solve_tall_team_kernel<8> x4 p<=64"},
     {KIND_TALL_L, 0, "re_solve_tall_kernel<1> lean p<=64"},
     {KIND_TALL_S, 0, "re_solve_tall_kernel<1> p<=64"},
     {KIND_TALL, 0, "re_solve_tall_kernel<8> p<=64"},
@@ -60,7 +61,7 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_GRID, 0, "re_solve_team_kernel 8 teams"},
     {KIND_GRID, 0, "re_solve_team_kernel device-wide"}};
 
-__global__ void class_base_kernel(int32_t* cc, int tall_adapt_limit) {
+__global__ void class_base_kernel(int32_t* cc, int tall_adapt_limit, int tall_team_n, int tall_team_limit) {
   // cc[0..NC) counts -> cc[NC..2NC) exclusive bases, cc[2NC..3NC) cursors = 0
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     // The split between the one-wavefront and the eight-wavefront tall kernels (4 096 samples by default: right for a batch with
@@ -69,6 +70,22 @@ __global__ void class_base_kernel(int32_t* cc, int tall_adapt_limit) {
     // the step lasts as long as ONE wavefront needs for a 4 000-sample entity (tools/share_timeline.py). The lowest of 512 / 1 024 /
     // 2 048 that keeps the class within `tall_adapt_limit` workgroups (one per CU) wins; re_order_kernel moves the entities.
     int32_t* const ge = cc + 3 * GDMIX_RE_NUM_CLASSES;
+    // The team class (four workgroups per entity) takes the tallest entities of the batch: those above the lowest of
+    // tall_team_n x {1, 2, 4} samples that keeps it within one round of teams — a batch with more than that above the highest
+    // threshold has no team class (throughput binds it, not one entity's chain). No limit: everything from tall_team_n on.
+    int team_from = 0;
+    if (tall_team_n > 0) {
+      if (tall_team_limit <= 0) { if (ge[TALL_TEAM_GE] > 0) team_from = tall_team_n; }
+      else
+        for (int k = 0; k < TALL_TEAM_STEPS && team_from == 0; ++k)
+          if (ge[TALL_TEAM_GE + k] > 0 && ge[TALL_TEAM_GE + k] <= tall_team_limit) team_from = tall_team_n << k;
+      if (team_from > 0) {
+        const int moved = ge[TALL_TEAM_GE + (team_from == tall_team_n ? 0 : (team_from == 2 * tall_team_n ? 1 : 2))];
+        cc[TALL_T_CLASS] += moved;
+        cc[TALL_CLASS] -= moved;
+      }
+    }
+    ge[TALL_TEAM_SLOT] = team_from;
     int split = 0;
     if (tall_adapt_limit > 0) {
       for (int k = 0; k < TALL_ADAPT_STEPS && split == 0; ++k)
@@ -103,9 +120,21 @@ extern "C" {
 // A class whose launch cannot fill the device: fewer wavefronts than three quarters of what the CUs hold at two per SIMD (the eight-wavefront
 // tall workgroups: fewer entities than CUs). Such a class runs on one of the context's side streams, next to the large ones and to
 // the other small ones.
+// Large classes are dealt over the caller's stream and the side streams, in launch order (round 4): side by side their tails overlap
+// — a class launch ends with the workgroups whose entities need the most iterations while the rest of the device idles — and
+// wavefronts of different classes share a SIMD. C2: 9.35 -> 8.93 ms of solve, step 10.70 -> 10.30 ms; MovieLens-20M per-movie 6.04 -> 5.70 ms
+// (tools/r04_spread.sh: 2 / 3 / 4 queues 10.44 / 10.31 / 10.30 ms; most-entities-first changes nothing). gdmix_re_set_spread(ctx, 0)
+// (GDMIX_RE_SPREAD=0 for a whole process): one after another on the caller's stream, as before (A/B, and the per-kernel durations of a
+// profile: overlapped kernels stretch each other).
+static int spread_default() {
+  const char* e = getenv("GDMIX_RE_SPREAD");
+  const int n = e ? atoi(e) : 4;
+  return n > 1 ? n : 0;
+}
 static bool class_is_small(int kind, int count, int num_cus) {
   const int gl = group_lanes(kind);
   long waves = count;                                   // wavefront kernels, one-wavefront tall variants
+  if (kind == KIND_TALL_T) return true;                // at most one round of teams
   if (kind == KIND_TALL) waves = (long)count * 4 * TALL_NW / 8;   // one workgroup per CU: count < num_cus
   else if (gl > 0) waves = gl >= WAVE ? (long)count * (gl / WAVE) : ((long)count * gl + WAVE - 1) / WAVE;
   return waves < (long)num_cus * 6;
@@ -156,6 +185,13 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   c->impl.team_nnz = 16384;
   c->impl.tall_min_n = GDMIX_RE_TALL_MIN_N_DEFAULT;
   c->impl.tall_split_n = GDMIX_RE_TALL_SPLIT_N_DEFAULT;
+  c->impl.tall_team_n = GDMIX_RE_TALL_TEAM_N_DEFAULT;
+  // an eighth of the CUs' worth of entities: the teams take four CUs each for as long as their entity lasts, and the one-wavefront
+  // tall class next to them needs its CUs too (tools/r04_tallteam.sh: 64 entities = every CU held a share's other classes up)
+  c->impl.tall_team_limit = c->impl.num_cus / 8 < TALL_TEAM_MAX ? c->impl.num_cus / 8 : TALL_TEAM_MAX;
+  if (const char* e = getenv("GDMIX_RE_TALL_TEAM")) { if (atoi(e) == 0) c->impl.tall_team_n = 0; }   // A/B switch
+  if (const char* e = getenv("GDMIX_RE_TALL_TEAM_LIMIT")) { if (atoi(e) > 0 && atoi(e) <= TALL_TEAM_MAX) c->impl.tall_team_limit = atoi(e); }   // exploration knob
+  c->impl.spread = spread_default();
   c->impl.grid_sync = nullptr;
   c->impl.big_tmp = nullptr;
   c->impl.big_tmp_bytes = 0;
@@ -186,7 +222,7 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
       }
     }
   }
-  rc = hipMalloc(&c->impl.grid_sync, TEAM_MAX_TEAMS * sizeof(TeamSync) + 3 * TALL_TAIL_BYTES);
+  rc = hipMalloc(&c->impl.grid_sync, TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANTS * TALL_TAIL_BYTES + TALL_TEAM_BYTES);
   if (rc != hipSuccess) {
     set_error("hipMalloc failed: %s", hipGetErrorString(rc));
     (void)hipHostFree(c->impl.host_pinned);
@@ -300,6 +336,18 @@ GDMIX_API int gdmix_re_set_tall_min_n(gdmix_re_ctx* ctx, int min_n) {
   return GDMIX_RE_OK;
 }
 
+GDMIX_API int gdmix_re_set_spread(gdmix_re_ctx* ctx, int queues) {
+  if (!ctx || queues < 0) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
+  ctx->impl.spread = queues > 1 ? queues : 0;
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_re_set_tall_team_n(gdmix_re_ctx* ctx, int team_n) {
+  if (!ctx) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
+  ctx->impl.tall_team_n = team_n;
+  return GDMIX_RE_OK;
+}
+
 GDMIX_API int gdmix_re_set_tall_split_n(gdmix_re_ctx* ctx, int split_n) {
   if (!ctx || split_n < 1) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
   ctx->impl.tall_split_n = split_n;
@@ -404,6 +452,12 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   tab.tall_min_n = ctx->impl.tall_min_n;
   tab.tall_split_n = ctx->impl.tall_split_n;
   tab.tall_adapt_limit = (ctx->impl.tall_split_n == GDMIX_RE_TALL_SPLIT_N_DEFAULT) ? ctx->impl.tall_adapt_limit : 0;   // an explicit split is kept
+  {   // > 0: adaptive from team_n on; < 0: everything from -team_n on (tests); never below TALL_TEAM_MIN_N samples
+    const int tn = ctx->impl.tall_team_n;
+    tab.tall_team_n = tn > 0 ? tn : -tn;
+    if (tab.tall_team_n > 0 && tab.tall_team_n < TALL_TEAM_MIN_N) tab.tall_team_n = TALL_TEAM_MIN_N;
+    tab.tall_team_limit = tn > 0 ? ctx->impl.tall_team_limit : 0;
+  }
   if (opts->sum_loss || opts->linear) {
     // the fixed-effect objective lives in the team kernels only: every entity goes device-wide, one after another
     if (opts->m > TEAM_MCAP) { set_error("sum_loss / linear need m <= %d", TEAM_MCAP); return GDMIX_RE_EINVAL; }
@@ -414,7 +468,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   int32_t* cc = b->class_count;
   HIP_TRY(hipMemsetAsync(cc, 0, 6 * GDMIX_RE_NUM_CLASSES * sizeof(int32_t), s));
   HIP_TRY(launch_classify(b, ic, opts->m, tab, b->cls_tmp, cc, s));
-  hipLaunchKernelGGL(class_base_kernel, dim3(1), dim3(1), 0, s, cc, tab.tall_adapt_limit);
+  hipLaunchKernelGGL(class_base_kernel, dim3(1), dim3(1), 0, s, cc, tab.tall_adapt_limit, tab.tall_team_n, tab.tall_team_limit);
   HIP_TRY(hipGetLastError());
   HIP_TRY(launch_order(b, b->cls_tmp, cc + GDMIX_RE_NUM_CLASSES, cc + 2 * GDMIX_RE_NUM_CLASSES, s));
   int32_t* hc = ctx->impl.host_pinned + 256;
@@ -477,12 +531,13 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
       if (c == TALL_S_CLASS) cnt += lean_merged;
       forked = cnt > 0 && class_is_small(kClasses[c].kind, cnt, ctx->impl.num_cus);
     }
+    if (ctx->impl.spread > 1) forked = true;
     if (forked) HIP_TRY(hipEventRecord(ctx->impl.side_fork, s_main));
   }
   // Launch plan. The tall classes go first: their kernels are the longest chains of a small batch (one workgroup, or one wavefront,
   // per entity, for as long as that entity's solve lasts) and each is preceded by three small launches (fill, sort, tail) that must
   // not queue behind the group kernels' workgroups. Stream of a class:
-  //   large class                      -> the caller's stream, in launch order;
+  //   large class                      -> dealt over the caller's stream and the side streams in launch order (gdmix_re_set_spread);
   //   small tall class (<8>, <1>, lean) -> a side stream of its own (side 1, 2, 0: the device has four hardware queues by default,
   //                                        a fourth side stream would share one — measured: both tall classes of a MovieLens share on
   //                                        one queue, 1.1 + 2.1 ms one after the other);
@@ -490,7 +545,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   //                                        the shortest of the three).
   // Only the streams that get work are woken (SideJoin::use): a C2 partition touches the caller's stream and side 0.
   // Disjoint entities and outputs; the tall variants have a tail slot each: a schedule changes the time, never a bit of the result.
-  struct Launch { int c, b0, cnt; bool small; };
+  struct Launch { int c, b0, cnt; bool small; int spread; };
   Launch plan[GDMIX_RE_NUM_CLASSES];
   int n_plan = 0;
   bool any_large = false;
@@ -503,27 +558,33 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
       if (c == TALL_L_CLASS && lean_merged) cnts[c] = 0;
       if (c == TALL_S_CLASS && lean_merged) { b0s[c] -= lean_merged; cnts[c] += lean_merged; }
     }
-    const int first[3] = {TALL_CLASS, TALL_S_CLASS, TALL_L_CLASS};
-    for (int k = 0; k < 3 + BLOCK_CLASS; ++k) {
-      const int c = k < 3 ? first[k] : k - 3;
-      if (k >= 3 && (c == TALL_CLASS || c == TALL_S_CLASS || c == TALL_L_CLASS)) continue;
+    const int first[4] = {TALL_T_CLASS, TALL_CLASS, TALL_S_CLASS, TALL_L_CLASS};
+    for (int k = 0; k < 4 + BLOCK_CLASS; ++k) {
+      const int c = k < 4 ? first[k] : k - 4;
+      if (k >= 4 && (c == TALL_T_CLASS || c == TALL_CLASS || c == TALL_S_CLASS || c == TALL_L_CLASS)) continue;
       if (cnts[c] <= 0) continue;
       const bool small = forked && class_is_small(kClasses[c].kind, cnts[c], ctx->impl.num_cus);
       any_large = any_large || !small;
-      plan[n_plan++] = Launch{c, b0s[c], cnts[c], small};
+      plan[n_plan++] = Launch{c, b0s[c], cnts[c], small, -1};
     }
   }
   int begin = 0;
+  int spread_rr = 0;
   for (int c = 0; c < BLOCK_CLASS; ++c) begin += hc[c];
   for (int k = 0; k < n_plan; ++k) {
     const int c = plan[k].c, b0 = plan[k].b0, cnt = plan[k].cnt;
     hipStream_t s = s_main;
+    if (!plan[k].small && forked && ctx->impl.spread > 1) {   // large classes side by side
+      const int nq = ctx->impl.spread < ctx->impl.n_side + 1 ? ctx->impl.spread : ctx->impl.n_side + 1;
+      const int q = spread_rr++ % nq;
+      if (q > 0) { HIP_TRY(side_join.use(q - 1)); s = ctx->impl.side[q - 1]; }
+    }
     if (plan[k].small) {
       const int ns = ctx->impl.n_side;
       int k_side = -1;
       if (c == TALL_CLASS) k_side = 1 % ns;
       else if (c == TALL_S_CLASS) k_side = 2 % ns;
-      else if (c == TALL_L_CLASS || any_large) k_side = 0;
+      else if (c == TALL_T_CLASS || c == TALL_L_CLASS || any_large) k_side = 0;
       if (k_side >= 0) { HIP_TRY(side_join.use(k_side)); s = ctx->impl.side[k_side]; }
     }
     if (timing) { HIP_TRY(hipEventRecord(ctx->impl.ev0[c], s)); }
@@ -533,6 +594,12 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
         HIP_TRY(launch_solve_quad(group_lanes(kClasses[c].kind), group_epl(kClasses[c].kind), B, O, P, theta0, b0, cnt,
                                   kClasses[c].ncap, kClasses[c].zcap, s));
         break;
+      case KIND_TALL_T: {
+        const char* xe = getenv("GDMIX_RE_XCD_BARRIER");   // 0: every signal with the full release (A/B and tests)
+        HIP_TRY(launch_solve_tall_team(B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_TEAM * TALL_TAIL_BYTES,
+                                       static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANTS * TALL_TAIL_BYTES, (xe && atoi(xe) == 0) ? 0 : 1, s));
+        break;
+      }
       case KIND_TALL_L: HIP_TRY(launch_solve_tall(TALL_VARIANT_LEAN, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_LEAN * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_LEAN, 0, s)); break;
       case KIND_TALL_S: HIP_TRY(launch_solve_tall(TALL_VARIANT_SMALL, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_SMALL * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_SMALL, lean_merged, s)); break;
       case KIND_TALL: HIP_TRY(launch_solve_tall(TALL_VARIANT_LARGE, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_LARGE * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_LARGE, 0, s)); break;

@@ -25,7 +25,7 @@ namespace gdmix {
 // Each wavefront kind is split into LDS-footprint buckets so that small entities keep high occupancy.
 enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4, KIND_QUAD2 = 5, KIND_QUAD4 = 6, KIND_PAIR4 = 7, KIND_QUAD3 = 8, KIND_PAIR3 = 9, KIND_WREG8 = 10,
        KIND_G64_3 = 11, KIND_G64_4 = 12, KIND_G128_4 = 13, KIND_G256_4 = 14, KIND_G512_4 = 15, KIND_GRID = 16, KIND_G128_3 = 17, KIND_G256_3 = 18,
-       KIND_TALL = 20, KIND_TALL_S = 21, KIND_TALL_L = 22 };   // (19: the register team kernels of round 2, removed in round 3)
+       KIND_TALL = 20, KIND_TALL_S = 21, KIND_TALL_L = 22, KIND_TALL_T = 23 };   // (19: the register team kernels of round 2, removed in round 3)
 
 // group kernels (several entities per wavefront): lanes per entity, coefficient slots per lane; 0 if not a group kind
 __host__ __device__ inline int group_lanes(int kind) {
@@ -43,6 +43,11 @@ constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 5;
 constexpr int TALL_CLASS = BLOCK_CLASS - 1;      // tall entities of at least tall_split_n samples: one workgroup of TALL_NW wavefronts per CU
 constexpr int TALL_S_CLASS = BLOCK_CLASS - 2;    // smaller ones: workgroups of TALL_NW_SMALL wavefronts, several per CU
 constexpr int TALL_L_CLASS = BLOCK_CLASS - 3;    // ... and those that fit a twelfth of a CU's LDS: the lean variant, three wavefronts per SIMD
+constexpr int TALL_T_CLASS = BLOCK_CLASS - 4;    // the tallest of a batch: TALL_TEAM_C workgroups (CUs of one XCD) share one entity's samples
+constexpr int TALL_TEAM_C = 4;                   // workgroups per entity of that class (fixed: an entity's sums depend on the split)
+constexpr int TALL_TEAM_MAX = 64;                // teams per launch
+constexpr int TALL_TEAM_BYTES = 192 * 1024;      // device buffer of the context: the teams' exchange structures (re_solve_tall.hip)
+constexpr int TALL_TEAM_MIN_N = 64;              // no team for fewer samples than this, whatever the caller asks for (every member gets samples)
 #ifndef GDMIX_TALL_NW_SMALL
 #define GDMIX_TALL_NW_SMALL 1
 #endif
@@ -61,7 +66,7 @@ constexpr int TALL_LEAN_ARENA = (tall_lds_bytes(TALL_LEAN_WGS) - 1408) & ~15;   
 __host__ __device__ inline size_t tall_resident_bytes(int nw, int S, int d, int n, int nnz, bool has_w) {
   return (size_t)nw * (d + 1) * (S + 1) * 8 + (size_t)8 * (nnz + 8) + (size_t)4 * (n + 2) + (size_t)(has_w ? 12 : 8) * n + 16;
 }
-enum { TALL_VARIANT_LARGE = 0, TALL_VARIANT_SMALL = 1, TALL_VARIANT_LEAN = 2 };
+enum { TALL_VARIANT_LARGE = 0, TALL_VARIANT_SMALL = 1, TALL_VARIANT_LEAN = 2, TALL_VARIANT_TEAM = 3, TALL_VARIANTS = 4 };
 constexpr int BLOCK_NW = 4;   // wavefronts per workgroup of the block kernel
 #ifndef GDMIX_TEAM_BLOCK_NW
 #define GDMIX_TEAM_BLOCK_NW 8
@@ -80,12 +85,20 @@ struct ClassTable {
   int tall_split_n;    // ... those with at least this many samples one workgroup per CU, the others several
   int tall_adapt_limit;   // > 0: a batch whose eight-wavefront tall class would stay this small with a lower split (2 048, 1 024 or 512 samples)
                           // gets that split (class_base_kernel decides on the device, re_order_kernel moves the entities); 0 = the split is fixed
+  int tall_team_n;        // > 0: tall entities of at least this many samples may get a team of workgroups (TALL_T_CLASS); 0 = never
+  int tall_team_limit;    // > 0: the class takes the entities above the lowest of tall_team_n x {1, 2, 4} that keeps it within this many
+                          // entities (class_base_kernel decides, re_order_kernel moves them); 0 = everything from tall_team_n on
 };
 // counts[3 * NUM_CLASSES + k], k = 0..2: one-wavefront tall entities (TALL_S_CLASS) with at least TALL_ADAPT_N[k] samples;
 // counts[3 * NUM_CLASSES + TALL_ADAPT_SLOT]: the split class_base_kernel chose (0: none). (The row's team-tier columns hold the tiers' largest entity.)
 constexpr int TALL_ADAPT_STEPS = 3;
 __host__ __device__ constexpr int tall_adapt_n(int k) { return k == 0 ? 512 : (k == 1 ? 1024 : 2048); }
 constexpr int TALL_ADAPT_SLOT = 3;
+// counts[3 * NUM_CLASSES + TALL_TEAM_GE + k], k = 0..2: eight-wavefront tall entities with at least tall_team_n << k samples;
+// counts[3 * NUM_CLASSES + TALL_TEAM_SLOT]: the threshold class_base_kernel chose (0: no team class in this batch)
+constexpr int TALL_TEAM_STEPS = 3;
+constexpr int TALL_TEAM_GE = 4;
+constexpr int TALL_TEAM_SLOT = 7;
 
 // Device pointers of a packed batch, passed by value to kernels.
 struct BatchDev {
@@ -129,8 +142,11 @@ struct gdmix_ctx_impl {
   int tall_min_n;         // tall kernel for p <= 64 and n >= this (0 = never)
   int tall_split_n;       // tall entities with n >= this: one large workgroup per CU
   int tall_adapt_limit;   // ClassTable::tall_adapt_limit of this device (half its CUs; GDMIX_RE_TALL_ADAPT overrides, 0 = off)
+  int tall_team_n;        // ClassTable::tall_team_n (gdmix_re_set_tall_team_n; GDMIX_RE_TALL_TEAM=0 switches the class off)
+  int tall_team_limit;    // ClassTable::tall_team_limit: one round of teams on this device
+  int spread;             // > 1: large classes are dealt over this many queues (the caller's stream + side streams); 0: one after another
   void* grid_sync;        // device: TeamSync of the team kernels (the first three also: ticket counters of the tall variants), followed
-                          // by TALL_TAIL_BYTES for each tall variant
+                          // by TALL_TAIL_BYTES for each tall variant (four: the team variant last) and TALL_TEAM_BYTES
   void* big_tmp;          // device: grow-only temporary of the big-entity pack path
   size_t big_tmp_bytes;
   // classes too small to fill the device run on side streams, next to the large ones on the caller's stream and next to each other
@@ -204,6 +220,8 @@ hipError_t launch_solve_grid(const BatchDev& B, const OutDev& O, const SolvePara
 constexpr int TALL_TAIL_BYTES = 256;   // device buffer of the context: padded copy of the end of the batch's row-major arrays
 hipError_t launch_solve_tall(int variant, const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0, int begin, int count,
                              int num_cus, int64_t Z, void* tail_buf, void* sync_buf, int front_small, hipStream_t s);
+hipError_t launch_solve_tall_team(const BatchDev& B, const OutDev& O, const SolveParams& o, const double* theta0, int begin, int count,
+                                  int num_cus, int64_t Z, void* tail_buf, void* team_buf, int xcd_fast, hipStream_t s);
 void launch_sort_class(int32_t* list, int count, const int64_t* ent_nnz_ptr, hipStream_t s);
 hipError_t launch_variance_full(const BatchDev& B, int64_t E, const SolveParams& o, const double* theta, double* variance,
                                 double* scratch, size_t slot_doubles, int slots, int64_t max_p, hipStream_t s);

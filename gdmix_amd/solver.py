@@ -18,7 +18,7 @@ from .batch import RawBatch, WireRawBatch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgdmix_re.so")
 
-NUM_CLASSES = 38
+NUM_CLASSES = 39
 STATUS_NAMES = ("PGTOL", "FACTR", "MAXITER", "MAXFUN", "ABNORMAL")
 VAR_NONE, VAR_SIMPLE, VAR_FULL = 0, 1, 2
 VARIANCE_MODES = {None: VAR_NONE, "simple": VAR_SIMPLE, "SIMPLE": VAR_SIMPLE, "full": VAR_FULL, "FULL": VAR_FULL,
@@ -70,7 +70,7 @@ EXPORTED_SYMBOLS = (
     "gdmix_re_abi_version", "gdmix_re_last_error", "gdmix_re_default_opts", "gdmix_re_create",
     "gdmix_re_destroy", "gdmix_re_pack_workspace_bytes", "gdmix_re_pack", "gdmix_re_solve",
     "gdmix_re_solve_scratch_bytes", "gdmix_re_set_scratch", "gdmix_re_variance_full", "gdmix_re_set_wave_lds_limit", "gdmix_re_score",
-    "gdmix_re_widen_workspace_bytes", "gdmix_re_widen", "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz", "gdmix_re_set_tall_min_n", "gdmix_re_set_tall_split_n",
+    "gdmix_re_widen_workspace_bytes", "gdmix_re_widen", "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz", "gdmix_re_set_tall_min_n", "gdmix_re_set_tall_split_n", "gdmix_re_set_tall_team_n", "gdmix_re_set_spread",
     "gdmix_fe_create", "gdmix_fe_destroy", "gdmix_fe_eval", "gdmix_fe_reduce_buffer", "gdmix_fe_step", "gdmix_fe_result",
     "gdmix_fe_last_eval_ms", "gdmix_fe_score", "gdmix_fe_hessian_diag", "gdmix_fe_hessian_dense_scratch_bytes", "gdmix_fe_hessian_dense",
     "gdmix_fe_variance_of_hessian",
@@ -138,6 +138,8 @@ def load_library():
     lib.gdmix_re_set_team_nnz.argtypes = [C.c_void_p, C.c_int64]
     lib.gdmix_re_set_tall_min_n.argtypes = [C.c_void_p, C.c_int]
     lib.gdmix_re_set_tall_split_n.argtypes = [C.c_void_p, C.c_int]
+    lib.gdmix_re_set_tall_team_n.argtypes = [C.c_void_p, C.c_int]
+    lib.gdmix_re_set_spread.argtypes = [C.c_void_p, C.c_int]
     lib.gdmix_re_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.gdmix_re_last_solve_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.gdmix_re_score.argtypes = [C.c_void_p, C.POINTER(_Packed), C.c_int, C.c_void_p, C.c_void_p,
@@ -149,7 +151,7 @@ def load_library():
     lib.gdmix_java_partition_id.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     lib.gdmix_java_partition_id.restype = C.c_int32
     lib.gdmix_java_partition_ids_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
-    if lib.gdmix_re_abi_version() != 8:
+    if lib.gdmix_re_abi_version() != 9:
         raise GdmixReError("libgdmix_re.so ABI version mismatch")
     _lib = lib
     return lib
@@ -363,6 +365,19 @@ class REDeviceSolver:
     def set_tall_split_n(self, split_n: int):
         """Tall entities of at least split_n samples get a CU each; smaller ones share a CU (eight single-wavefront workgroups)."""
         _check(self.lib.gdmix_re_set_tall_split_n(self._h, int(split_n)), "set_tall_split_n")
+
+    TALL_TEAM_N_DEFAULT = 8192
+
+    def set_tall_team_n(self, team_n: int):
+        """The tallest entities of a batch get a team of four workgroups (four CUs of one XCD share the pass over one entity's samples).
+        team_n > 0: eight-wavefront tall entities from team_n, 2 team_n or 4 team_n samples on — the lowest that keeps the class
+        within one round of teams on the device; team_n < 0: every one of at least -team_n samples (tests); 0: never."""
+        _check(self.lib.gdmix_re_set_tall_team_n(self._h, int(team_n)), "set_tall_team_n")
+
+    def set_spread(self, queues: int):
+        """Large size classes are dealt over `queues` streams (the caller's + the context's side streams; default 4) so that their tails
+        overlap; 0: one after another on the caller's stream (per-class durations then do not stretch each other)."""
+        _check(self.lib.gdmix_re_set_spread(self._h, int(queues)), "set_spread")
 
     def set_timing(self, enabled: bool):
         _check(self.lib.gdmix_re_set_timing(self._h, int(bool(enabled))), "set_timing")

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GDMIX_RE_ABI_VERSION 8
+#define GDMIX_RE_ABI_VERSION 9
 
 #if defined(__GNUC__)
 #define GDMIX_API __attribute__((visibility("default")))
@@ -140,7 +140,7 @@ typedef struct {
   int32_t        max_p, max_n, max_nnz;  /* per-entity maxima over the batch (host, after pack)     */
 } gdmix_re_packed;
 
-#define GDMIX_RE_NUM_CLASSES 38
+#define GDMIX_RE_NUM_CLASSES 39
 
 /* ---- solver options (defaults = REParams/LRParams defaults + scipy defaults) ----------------------
  * base_lr_params.py:22-27, binary_logistic_regression.py:223-231 (pgtol/maxfun/maxls are scipy's). */
@@ -263,6 +263,25 @@ GDMIX_API int gdmix_re_set_tall_min_n(gdmix_re_ctx* ctx, int min_n);
  * wavefront) runs while the others' passes over their samples do. */
 #define GDMIX_RE_TALL_SPLIT_N_DEFAULT 4096
 GDMIX_API int gdmix_re_set_tall_split_n(gdmix_re_ctx* ctx, int split_n);
+/* The tallest entities of a batch get a TEAM of four workgroups (four CUs of one XCD) that share the pass over one entity's
+ * samples: a share of a strongly scaled MovieLens job lasts as long as ONE workgroup needs for its most rated title
+ * (ABI 9, GDMIX_RE_NUM_CLASSES 39). `team_n` > 0: eight-wavefront tall entities of at least team_n, 2 team_n or 4 team_n samples
+ * - the lowest of the three that keeps the class within one round of teams on the device (a quarter of its CUs); a batch with
+ * more entities than that above 4 team_n has no team class (it is bound by throughput, not by one entity's chain).
+ * `team_n` < 0: every tall entity of at least -team_n samples (at least 64), no limit (tests). 0 = never. The split of an
+ * entity's samples over the four workgroups depends on its size alone: results do not depend on the batch, and agree with the
+ * one-workgroup kernel's to rounding (another summation order). */
+#define GDMIX_RE_TALL_TEAM_N_DEFAULT 8192
+GDMIX_API int gdmix_re_set_tall_team_n(gdmix_re_ctx* ctx, int team_n);
+
+/* Launch schedule of a solve. Size classes too small to fill the device always run next to the others on the context's side streams
+ * (three, created with the context). `queues` > 1 (default 4 = the caller's stream + the three side streams; GDMIX_RE_SPREAD in the
+ * environment sets the default of new contexts): the LARGE classes are dealt over that many streams in launch order as well, so that the
+ * tail of one class launch (the entities with the most iterations) overlaps with the next class instead of idling the device; every
+ * side stream is joined back into the caller's stream before gdmix_re_solve returns. 0 or 1: large classes one after another on the
+ * caller's stream. A schedule changes the time, never a bit of the result; per-class durations (gdmix_re_last_solve_ms) of overlapped
+ * launches stretch each other. */
+GDMIX_API int gdmix_re_set_spread(gdmix_re_ctx* ctx, int queues);
 
 /* Optional kernel timing: when enabled, gdmix_re_solve brackets each size class's kernel launch with
  * HIP events on the caller's stream; gdmix_re_last_solve_ms waits for them and returns the elapsed

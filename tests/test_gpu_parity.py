@@ -56,7 +56,8 @@ def _check_pack(packed, pk, val):
     assert np.array_equal(packed.csc_val().cpu().numpy(), csc_val)
 
 
-def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, giant_nnz=16777216, team_nnz=16384, tall_min_n=0):
+def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, giant_nnz=16777216, team_nnz=16384, tall_min_n=0,
+                       tall_split_n=None, tall_team_n=None):
     """tall_min_n: 0 keeps the tall kernel out of the way of the routing under test; None = the library's default."""
     b, opts, exp, _ = load_fixture(name)
     kw = opts_kwargs(opts)
@@ -69,9 +70,15 @@ def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, gian
     device_solver.set_giant_nnz(giant_nnz)
     device_solver.set_team_nnz(team_nnz)
     device_solver.set_tall_min_n(device_solver.TALL_MIN_N_DEFAULT if tall_min_n is None else tall_min_n)
+    if tall_split_n is not None:
+        device_solver.set_tall_split_n(tall_split_n)
+    if tall_team_n is not None:
+        device_solver.set_tall_team_n(tall_team_n)
     try:
         res = device_solver.solve(packed, SolverOptions(**kw), theta0=th0).to_host()
     finally:
+        device_solver.set_tall_split_n(4096)
+        device_solver.set_tall_team_n(device_solver.TALL_TEAM_N_DEFAULT)
         device_solver.set_wave_lds_limit(65536)
         device_solver.set_kernel_mask(7)
         device_solver.set_giant_nnz(16777216)
@@ -125,8 +132,26 @@ def test_tall_kernel_matches_reference_fixture(device_solver, name):
     below 4 096 samples, eight wavefronts above; entities of more coefficients keep their default routing."""
     counts, p, kw = _solve_and_compare(device_solver, name, tall_min_n=1)
     want = int((p <= 64).sum()) if kw["m"] <= 10 else 0
-    got = counts["re_solve_tall_kernel<8> p<=64"] + counts["re_solve_tall_kernel<1> p<=64"] + counts["re_solve_tall_kernel<1> lean p<=64"]
+    got = (counts["re_solve_tall_kernel<8> p<=64"] + counts["re_solve_tall_kernel<1> p<=64"] + counts["re_solve_tall_kernel<1> lean p<=64"]
+           + counts["re_solve_tall_team_kernel<8> x4 p<=64"])     # (the one title above 8 192 samples of ml20m_per_movie_tall gets a team: round 4)
     assert got == want, (got, want)
+
+
+@pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "ref_dataset1", "c2_shipped_cfg", "c2_weights", "c2_no_intercept", "c2_maxiter1", "c2_m3",
+                                  "ragged", "ragged_variance_simple", "ml_per_user", "ml_per_movie", "warm_stage2", "tiny_entities_regbias",
+                                  "exit_factr_1e-7", "exit_hard_02", "exit_extreme_00", "exit_extreme_02", "ml20m_per_movie_tall", "ml20m_per_user_tall"])
+def test_tall_team_kernel_matches_reference_fixture(device_solver, name):
+    """Round 4: FOUR workgroups on one entity (csrc/re_solve_tall.hip, re_solve_tall_team_kernel). Every entity with at most 64
+    coefficients and at least 64 samples through it (split 1: all of them are eight-wavefront entities; team threshold -64: no limit on
+    the class), the smaller ones through the one-workgroup kernel: same fixtures, same tolerances, same iteration counts."""
+    b = load_fixture(name)[0]
+    counts, p, kw = _solve_and_compare(device_solver, name, tall_min_n=1, tall_split_n=1, tall_team_n=-64)
+    n = b.ent_n()
+    want = int(((p <= 64) & (n >= 64)).sum()) if kw["m"] <= 10 else 0
+    assert counts["re_solve_tall_team_kernel<8> x4 p<=64"] == want, (counts, want)
+    assert counts["re_solve_tall_kernel<8> p<=64"] == (int(((p <= 64) & (n < 64)).sum()) if kw["m"] <= 10 else 0)
+    if name.startswith("ml20m"):
+        assert want > 0
 
 
 VARIANT_FIXTURES = ["ref_fixture_l2_0.1", "ref_dataset1", "ref_dataset2", "c2_shipped_cfg", "c2_defaults", "c2_l2_1e-3",
@@ -157,8 +182,9 @@ def test_default_routing_reaches_only_these_classes(device_solver):
             res = device_solver.solve(packed, SolverOptions(l2=1.0, regularize_bias=False, m=m, max_iter=5))
             assert int((res.status < 0).sum().item()) == 0
             used[m] |= {name.split("<")[0].split(" ")[0] for name, c in device_solver.class_counts(packed) if c > 0}
-    assert len(device_solver.class_counts(packed)) == NUM_CLASSES == 38
-    assert used[10] == {"re_solve_grp_kernel", "re_solve_tall_kernel", "re_solve_team_kernel"}, used[10]
+    assert len(device_solver.class_counts(packed)) == NUM_CLASSES == 39
+    # (the 900 MovieLens-20M movies include titles above 8 192 samples: they get a team of workgroups since round 4)
+    assert used[10] == {"re_solve_grp_kernel", "re_solve_tall_kernel", "re_solve_tall_team_kernel", "re_solve_team_kernel"}, used[10]
     assert used[12] == {"re_solve_wave_kernel", "re_solve_team_kernel"}, used[12]      # m > 10: the LDS wavefront kernel and the two-loop block kernel
 
 
@@ -695,3 +721,57 @@ def test_a_small_batch_lowers_the_tall_split_and_only_the_rounding_changes(devic
         worst = max(worst, float(np.max(np.abs(a - f)) / max(np.max(np.abs(f)), 1e-300)))
     assert worst <= 1e-7, worst
     np.testing.assert_allclose(adaptive["fval"], fixed["fval"], rtol=1e-9, atol=1e-12)
+
+
+def test_the_tallest_entities_of_a_batch_get_a_team_of_workgroups(device_solver, monkeypatch):
+    """Round 4: the team class (four workgroups, four CUs of one XCD, on one entity) takes the eight-wavefront tall entities above
+    the lowest of 8 192 / 16 384 / 32 768 samples that keeps it within one round of teams (64 on an MI355X) — chosen on the device
+    (class_base_kernel), the entities moved by re_order_kernel. 3 300 MovieLens-20M movies (a share of eight): the counts add up, exactly
+    the entities above the chosen threshold moved, and the solution agrees with the one-workgroup kernel's to rounding; switched off
+    (team_n 0) nobody moves; the same bits run after run, and with the full release instead of the same-XCD signals."""
+    b = synthetic.make_movielens_20m("per_movie", seed=84, entities=3300)
+    n = b.ent_n()
+    kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
+    team, tall8 = "re_solve_tall_team_kernel<8> x4 p<=64", "re_solve_tall_kernel<8> p<=64"
+    packed = device_solver.pack(b)
+    try:
+        device_solver.set_tall_split_n(4097)     # an explicit split: the per-batch choice between the <1> and <8> kernels stays out of the comparison
+        with_team = device_solver.solve(packed, SolverOptions(**kw, variance_mode=1)).to_host()
+        ct = dict(device_solver.class_counts(packed))
+        idx = {name: i for i, (name, _) in enumerate(device_solver.class_counts(packed))}
+        cls_t = packed._view(packed.c.cls_tmp, packed.E, device_solver.torch.int32).cpu().numpy().copy()
+        again = device_solver.solve(packed, SolverOptions(**kw, variance_mode=1)).to_host()
+        monkeypatch.setenv("GDMIX_RE_XCD_BARRIER", "0")
+        full_release = device_solver.solve(packed, SolverOptions(**kw, variance_mode=1)).to_host()
+        monkeypatch.delenv("GDMIX_RE_XCD_BARRIER")
+        device_solver.set_tall_team_n(0)
+        without = device_solver.solve(packed, SolverOptions(**kw, variance_mode=1)).to_host()
+        cw = dict(device_solver.class_counts(packed))
+    finally:
+        device_solver.set_tall_team_n(device_solver.TALL_TEAM_N_DEFAULT)
+        device_solver.set_tall_split_n(4096)
+    assert cw[team] == 0 and sum(cw.values()) == sum(ct.values()) == b.E
+    assert 0 < ct[team] <= 64 and ct[team] + ct[tall8] == cw[tall8], (ct[team], ct[tall8], cw[tall8])
+    went = cls_t == idx[team]
+    assert [t for t in (8192, 16384, 32768) if np.array_equal(went, n >= t)], (int(n[went].min()), int(went.sum()))
+    # the lowest threshold that fits: the next lower one would not have
+    t = int(n[went].min())
+    lower = [x for x in (8192, 16384) if x * 2 <= t]
+    assert all(int((n >= x).sum()) > 64 for x in lower)
+    for k in ("theta", "variance", "fval", "gnorm", "nit", "nfev", "status"):
+        assert np.array_equal(with_team[k], again[k]), k
+        assert np.array_equal(with_team[k], full_release[k]), k
+    assert np.all(with_team["status"] <= 2) and np.array_equal(with_team["status"], without["status"])
+    same_nit = with_team["nit"] == without["nit"]
+    assert same_nit[went].mean() >= 0.9 and np.all(same_nit[~went])
+    cp = packed.coef_ptr_host()
+    worst = 0.0
+    for e in np.flatnonzero(same_nit):
+        a, f = with_team["theta"][cp[e]:cp[e + 1]], without["theta"][cp[e]:cp[e + 1]]
+        worst = max(worst, float(np.max(np.abs(a - f)) / max(np.max(np.abs(f)), 1e-300)))
+    assert worst <= 1e-7, worst
+    np.testing.assert_allclose(with_team["fval"], without["fval"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(with_team["variance"][np.repeat(same_nit, np.diff(cp))], without["variance"][np.repeat(same_nit, np.diff(cp))], rtol=1e-6)
+    # everybody outside the class: bit for bit what the run without the class gave
+    keep = np.repeat(~went, np.diff(cp))
+    assert np.array_equal(with_team["theta"][keep], without["theta"][keep])
