@@ -42,6 +42,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import gdmix_amd  # noqa: E402,F401  (before the first device call: the package sets the process's hardware-queue default)
 
 SPREAD_DEFAULT = int(os.environ.get("GDMIX_RE_SPREAD", "4"))   # queues the large size classes are dealt over (gdmix_re_set_spread)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md

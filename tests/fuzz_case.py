@@ -73,10 +73,18 @@ def run_case(solver, seed, verbose=False):
     # so that the seeds of the earlier sweeps still draw the same batches and options)
     solver.set_giant_nnz(routing["giant"]); solver.set_team_nnz(routing["team"]); solver.set_kernel_mask(2 if routing["mask"] == 1 else routing["mask"])
     solver.set_tall_min_n(routing["tall"])
+    # round 4: the team class of the tall kernels (four workgroups per entity). Drawn from a generator of its own, so that the seeds of
+    # the earlier sweeps still draw the same batches, options and routings: the library's default (adaptive from 8 192 samples), every
+    # tall entity of at least 64 samples (with the eight-wavefront split at 64), or off
+    routing["tall_team"] = int(np.random.default_rng(seed ^ 0x7A11).choice([8192, 8192, -64, 0]))
+    solver.set_tall_team_n(routing["tall_team"])
+    if routing["tall_team"] < 0:
+        solver.set_tall_split_n(64)
     try:
         res = solver.solve(packed, SolverOptions(**kw), theta0=th0).to_host()
     finally:
         solver.set_giant_nnz(16777216); solver.set_team_nnz(16384); solver.set_kernel_mask(7); solver.set_tall_min_n(solver.TALL_MIN_N_DEFAULT)
+        solver.set_tall_team_n(solver.TALL_TEAM_N_DEFAULT); solver.set_tall_split_n(4096)
     o = oracle.make_opts(**kw)
     ref = oracle.solve(pk, b.val, b.y, b.offset, b.weight, o, theta0=th0)
     coef_ptr = packed.coef_ptr_host()
