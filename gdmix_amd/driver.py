@@ -18,7 +18,9 @@ logger = logging.getLogger(__name__)
 logger.setLevel(logging.INFO)
 
 
-PREFETCH_PARTITIONS = 2   # decoded ahead of the one being solved (the reader pool of the model has two workers)
+# partitions decoded ahead of the one being solved (3 with 12 threads per native call against 2 x 32: warm-started run 0.51 -> 0.44 s per
+# million entities, cold 0.27 -> 0.24; tools/r04_e2e_knobs.sh)
+PREFETCH_PARTITIONS = int(os.environ.get("GDMIX_PREFETCH_PARTITIONS", "3"))
 
 
 def is_empty_directory(input_dir):

@@ -469,7 +469,12 @@ class RandomEffectLRLBFGSModel:
             from concurrent.futures import ThreadPoolExecutor
             # readers and writers apart: a partition's two files take longer to write than the partition takes to solve, and a
             # read queued behind them would stall the device
-            self._io_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="gdmix-read")   # two partitions ahead + their prior models
+            # Inside the pipeline three or four decodes and four to six Avro writers run at once: 32 threads per native call (the
+            # library's default, the optimum of ONE call alone) put ~200 runnable threads on the box and every phase of every call
+            # waited for the others (profiles/r04_host_path.txt: a decode of 11 ms alone took 45 - 75 ms). 12 per call, measured
+            # 2 .. 64 (tools/r04_e2e_knobs.sh); the caller's GDMIX_IO_THREADS wins.
+            os.environ.setdefault("GDMIX_IO_THREADS", "12")
+            self._io_pool = ThreadPoolExecutor(max_workers=6, thread_name_prefix="gdmix-read")   # three partitions ahead + their prior models
             self._write_pool = ThreadPoolExecutor(max_workers=WRITE_BEHIND_THREADS, thread_name_prefix="gdmix-write")
 
     def _read_key(self, input_path, num_features):

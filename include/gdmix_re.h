@@ -236,7 +236,7 @@ GDMIX_API int gdmix_re_set_wave_lds_limit(gdmix_re_ctx* ctx, int bytes);
  * group kernels (several entities per wavefront); the tall kernel and the team kernels are always available. Default 7. Bit 0 was
  * round 1's register-resident one-entity-per-wavefront kernel: unreachable under default routing once the group kernels covered
  * p <= 2048 (tests/test_gpu_parity.py::test_default_routing_reaches_only_these_classes), removed in round 4 with its thirteen size
- * classes (ABI 8, GDMIX_RE_NUM_CLASSES 38); the bit is accepted and ignored. (Round 2's bit 3, team kernels with the history in
+ * classes (ABI 8, GDMIX_RE_NUM_CLASSES 38; 39 since the tall team class of ABI 9); the bit is accepted and ignored. (Round 2's bit 3, team kernels with the history in
  * registers, went in round 3 - profiles/r03_zipf_register_team_kernels.txt.) */
 GDMIX_API int gdmix_re_set_kernel_mask(gdmix_re_ctx* ctx, int mask);
 

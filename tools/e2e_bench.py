@@ -30,9 +30,11 @@ md = {"features": [{"name": "bag", "dtype": "float", "shape": [DIM], "isSparse":
       "labels": [{"name": "response", "dtype": "int", "shape": [], "isSparse": False}]}
 
 phases = {}
+events = []     # E2E_TIMELINE=1: (label, thread, start, end) of every wrapped call — who waits for whom
 
 
 def timed(cls, name, label):
+    import threading
     fn = getattr(cls, name)
 
     def wrapper(*a, **k):
@@ -40,13 +42,18 @@ def timed(cls, name, label):
         try:
             return fn(*a, **k)
         finally:
-            phases[label] = phases.get(label, 0.0) + time.perf_counter() - t
+            t1 = time.perf_counter()
+            phases[label] = phases.get(label, 0.0) + t1 - t
+            events.append((label.strip(" ."), threading.current_thread().name, t, t1))
     setattr(cls, name, wrapper)
 
 
 M = model_mod.RandomEffectLRLBFGSModel
 timed(M, "_read", "read TFRecord (train + scoring passes)")
 timed(M, "_solve_batch", "pack + solve + D2H")
+timed(M, "_read_ahead", "  . decode ahead (+ upload)")
+timed(M, "_train", "  . _train")
+timed(M, "end_pipeline", "  . end_pipeline")
 timed(M, "_save_model", "model Avro")
 timed(M, "_predict", "scoring pass total (read + score + score Avro)")
 timed(model_mod, "_write_scores", "score Avro")
@@ -106,6 +113,7 @@ with tempfile.TemporaryDirectory() as d:
         if rep == 1:
             shutil.rmtree(os.path.join(d, "models"))
         phases.clear()
+        events.clear()
         prof = None
         if os.environ.get("E2E_PROFILE") and rep >= 1:    # cProfile of the main thread (the pipeline's other threads are not seen)
             import cProfile
@@ -125,3 +133,6 @@ with tempfile.TemporaryDirectory() as d:
         print(f"{label}: {dt:.2f} s  {E / dt:,.0f} entities/s end to end ({out / 1e6:.0f} MB of Avro written)")
         for k, v in phases.items():
             print(f"    {k:52s} {v:7.2f} s")
+        if os.environ.get("E2E_TIMELINE") and rep >= 1:
+            for lab, th, a0, a1 in sorted(events, key=lambda e: e[2]):
+                print(f"      {(a0 - t) * 1e3:8.1f} -> {(a1 - t) * 1e3:8.1f} ms ({(a1 - a0) * 1e3:7.1f})  {th:24s} {lab}")
