@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="entities per pass of the CPU baseline (0 = 200k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive hand-over measurement")
+    ap.add_argument("--no-alone", action="store_true",
+                    help="skip roofline.alone (four more steps with the size classes one after another): for a run under rocprofv3, whose "
+                         "per-kernel averages should hold the timed schedule only")
     ap.add_argument("--no-fe", action="store_true", help="skip the fixed-effect evaluation leg (detail.fixed_effect_eval)")
     ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end leg through the CLI (detail.cli_end_to_end)")
     ap.add_argument("--cli-entities", type=int, default=1_000_000, help="entities of the end-to-end leg (partitions of 125 k)")
@@ -748,19 +751,21 @@ def main():
     # large classes run side by side on four queues (their tails overlap: the step is shorter) and every launch lasts longer than it
     # would alone — a kernel's own roofline figure needs its duration alone
     saved = (kernel_ms.copy(), pack_ms, solve_ms, list(step_wall))
-    kernel_ms = np.zeros(NUM_CLASSES)
-    solve_ms = 0.0
-    solver.set_spread(0)
-    try:
-        measured_step()
+    alone_cls_ms, alone_solve_ms = kernel_ms / max(1, a.steps), solve_ms / max(1, a.steps)    # (--no-alone, or spread off: the timed steps themselves)
+    if not a.no_alone and SPREAD_DEFAULT > 1:
         kernel_ms = np.zeros(NUM_CLASSES)
         solve_ms = 0.0
-        for _ in range(3):
-            res = measured_step()
-        torch.cuda.synchronize()
-    finally:
-        solver.set_spread(SPREAD_DEFAULT)
-    alone_cls_ms, alone_solve_ms = kernel_ms / 3.0, solve_ms / 3.0
+        solver.set_spread(0)
+        try:
+            measured_step()
+            kernel_ms = np.zeros(NUM_CLASSES)
+            solve_ms = 0.0
+            for _ in range(3):
+                res = measured_step()
+            torch.cuda.synchronize()
+        finally:
+            solver.set_spread(SPREAD_DEFAULT)
+        alone_cls_ms, alone_solve_ms = kernel_ms / 3.0, solve_ms / 3.0
     kernel_ms, pack_ms, solve_ms, step_wall = saved[0], saved[1], saved[2], saved[3]
     # ---- the single-GPU legs next to the headline, BEFORE the large workloads: measured after them (BENCH_r03) the hand-over ran at
     # 58 M entities/s instead of 77 M — the 125 GB of the C5 share churn the allocator's blocks and the page-locked staging
@@ -902,7 +907,8 @@ def main():
                                 "device with the other classes' and lasts longer than alone; `alone` = the same launch with the classes one after another",
                     "alone": {"avg_launch_ms": dom_alone_ms, "achieved": round(achieved_alone, 3), "frac": achieved_alone / HBM_PEAK_GBS,
                               "solve_ms_per_step": alone_solve_ms, "class_ms": [round(float(x), 3) for x in alone_cls_ms],
-                              "what": "3 untimed steps after the timed region with gdmix_re_set_spread(ctx, 0)"},
+                              "what": "the timed steps themselves (--no-alone, or GDMIX_RE_SPREAD <= 1)" if (a.no_alone or SPREAD_DEFAULT <= 1)
+                                      else "3 untimed steps after the timed region with gdmix_re_set_spread(ctx, 0)"},
                     "alg_bytes_per_entity": alg_bytes / wl.E,
                     "restreamed_bytes_per_launch": float(b_s[cls == dom].sum()),
                     "all_solve_kernels": {"ms_per_step": all_ms, "alg_GBps": alg_bytes / (all_ms * 1e-3) / 1e9 if all_ms else 0.0},

@@ -3,7 +3,7 @@
 # default bench line as the driver runs it
 mkdir -p gpurun_out/r04z
 bash tools/profile_round.sh > gpurun_out/r04z/profile_round.txt 2>&1
-cp gpurun_out/prof_final/summary.txt gpurun_out/r04z/summary.txt; cp gpurun_out/prof_final/latest_traffic.json gpurun_out/r04z/latest_traffic.json
+cp gpurun_out/prof_final/summary.txt gpurun_out/r04z/summary.txt; cp gpurun_out/prof_final/summary_alone.txt gpurun_out/r04z/summary_alone.txt; cp gpurun_out/prof_final/latest_traffic.json gpurun_out/r04z/latest_traffic.json
 tail -3 gpurun_out/prof_final/stats.log | cut -c1-300
 timeout 1200 python bench.py --steps 20 --warmup 5 > gpurun_out/r04z/bench.json 2> gpurun_out/r04z/bench.err
 echo "bench rc=$?"
