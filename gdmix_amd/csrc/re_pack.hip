@@ -258,6 +258,131 @@ __device__ __forceinline__ int count_entity(const unsigned long long* keys, unsi
   return d;
 }
 
+// An entity of at most PACK_RANK_MAX non-zeros all of whose columns are below PACK_BITMAP_COLS (C2's bag: 1 024 features; the
+// MovieLens bags) needs no sort either: the set of its columns is a 2 048-bit map, one 32-bit word per lane; a column's local id is
+// the number of set bits below it (a prefix over the words' popcounts + a masked popcount), col_ptr is a scan over the per-id counts,
+// and an entry's CSC slot is its column's start plus its rank among the entries of the same column in position order — 0 for all
+// but the few columns that occur twice (ballot ranking inside a 64-entry tile, as count_entity does, for those columns only).
+// Same outputs as wave_rank_sort + emit_entity, bit for bit (tests/test_gpu_parity.py::_check_pack on every fixture), without the
+// rank sort's nnz broadcast-compare trips: ~470 -> ~250 wavefront instructions for a 64-entry entity (pack_entity_kernel<256> on C2:
+// 1.01 ms, three quarters of it VALU issue — profiles/r04_final_c2_1m.txt). w: 5 x 64 words of LDS.
+// Inclusive prefix sum over the 64 lanes by DPP: four shifts inside the rows of 16, then the last lane of row 0 / 2 into rows 1 / 3 and the
+// last lane of the lower half into the upper half (row_bcast:15, row_bcast:31) — six VALU instructions where six __shfl_up steps are
+// six LDS permutes with their address arithmetic.
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+constexpr int PACK_BITMAP_COLS = 2048;
+constexpr int PACK_BITMAP_WORDS = 5 * WAVE;
+template <class ValPtr>
+__device__ __forceinline__ int bitmap_entity(const unsigned long long* keys, unsigned* w, ValPtr vals, const int32_t* __restrict__ rp, int n,
+                                             int nnz, int lane, int32_t* __restrict__ csr_col, int32_t* __restrict__ col_ptr,
+                                             int32_t* __restrict__ csc_row, float* __restrict__ csc_val,
+                                             int32_t* __restrict__ uniq_sparse) {
+  unsigned* const bm = w;               // [64] the columns present
+  unsigned* const pre = w + WAVE;       // [64] set bits in the words below
+  unsigned* const cnt = w + 2 * WAVE;   // [128] entries per local id
+  unsigned* const start = w + 4 * WAVE; // [64] CSC start of ids 0 .. 63 (ids 64 .. 127: in the bitmap's words once it is done with)
+  bm[lane] = 0u;
+  cnt[lane] = 0u;
+  cnt[lane + WAVE] = 0u;
+  wave_lds_fence();
+  const bool v0 = lane < nnz, v1 = lane + WAVE < nnz;
+  const unsigned c0 = v0 ? (unsigned)(keys[lane] >> 32) : 0u, c1 = v1 ? (unsigned)(keys[lane + WAVE] >> 32) : 0u;
+  if (v0) atomicOr(&bm[c0 >> 5], 1u << (c0 & 31u));
+  if (v1) atomicOr(&bm[c1 >> 5], 1u << (c1 & 31u));
+  wave_lds_fence();
+  const unsigned word = bm[lane];
+  const unsigned pc = (unsigned)__popc(word);
+  const unsigned incl = wave_incl_scan_u32(pc);
+  const int d = __builtin_amdgcn_readlane((int)incl, WAVE - 1);
+  pre[lane] = incl - pc;
+  wave_lds_fence();
+  unsigned l0 = 0, l1 = 0;
+  if (v0) {
+    l0 = pre[c0 >> 5] + (unsigned)__popc(bm[c0 >> 5] & ((1u << (c0 & 31u)) - 1u));
+    csr_col[lane] = (int32_t)l0;
+    atomicAdd(&cnt[l0], 1u);
+  }
+  if (v1) {
+    l1 = pre[c1 >> 5] + (unsigned)__popc(bm[c1 >> 5] & ((1u << (c1 & 31u)) - 1u));
+    csr_col[lane + WAVE] = (int32_t)l1;
+    atomicAdd(&cnt[l1], 1u);
+  }
+  // the columns of this lane's word, ascending
+  {
+    unsigned rest = word;
+    int out = (int)(incl - pc);
+    while (__any(rest != 0u)) {
+      if (rest) {
+        const int b = __ffs((int)rest) - 1;
+        uniq_sparse[out++] = lane * 32 + b;
+        rest &= rest - 1u;
+      }
+    }
+  }
+  wave_lds_fence();
+  // col_ptr: exclusive scan of the counts of ids 0 .. d - 1 (two per lane)
+  const unsigned x0 = cnt[lane];
+  const unsigned s0 = wave_incl_scan_u32(x0);
+  const unsigned b0 = s0 - x0;
+  start[lane] = b0;
+  if (lane < d) col_ptr[lane] = (int32_t)b0;
+  if (lane == 0) col_ptr[d] = nnz;
+  unsigned* const start_hi = bm;   // the bitmap is done with: its 64 words hold the starts of ids 64 .. 127
+  if (d > WAVE) {                  // (uniform) ids of the second half exist
+    const unsigned x1 = cnt[lane + WAVE];
+    const unsigned b1 = (unsigned)__builtin_amdgcn_readlane((int)s0, WAVE - 1) + wave_incl_scan_u32(x1) - x1;
+    if (lane + WAVE < d) col_ptr[lane + WAVE] = (int32_t)b1;
+    wave_lds_fence();
+    start_hi[lane] = b1;
+  }
+  wave_lds_fence();
+  const int tiles = nnz > WAVE ? 2 : 1;
+  for (int t = 0; t < tiles; ++t) {
+    const int k = t * WAVE + lane;
+    const bool valid = t ? v1 : v0;
+    const unsigned lid = t ? l1 : l0;
+    const bool dup = valid && cnt[lid] > 1u;
+    unsigned rank = 0, tilecnt = 1;
+    unsigned long long todo = __ballot(dup);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const unsigned ll = (unsigned)__shfl((int)lid, leader);
+      const unsigned long long m = __ballot(valid && lid == ll);
+      if (valid && lid == ll) {
+        rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        tilecnt = (unsigned)__popcll(m);
+      }
+      todo &= ~m;
+    }
+    unsigned* const st = lid < (unsigned)WAVE ? &start[lid] : &start_hi[lid - WAVE];
+    if (valid) {
+      const unsigned kpos = *st + rank;
+      csc_val[kpos] = vals[k];
+      int lo = 0, hi = n - 1;   // sample of non-zero k: last i with rp[i] <= k
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rp[mid] <= k) lo = mid; else hi = mid - 1;
+      }
+      csc_row[kpos] = lo;
+    }
+    if (t + 1 < tiles) {   // a second tile follows: the columns that occur more than once move their start on
+      wave_lds_fence();
+      if (dup && rank == 0) *st += tilecnt;
+      wave_lds_fence();
+    }
+  }
+  return d;
+}
+
 // CAP = LDS staging capacity (non-zeros and samples) of a wavefront, NWAVES = wavefronts per workgroup.
 // in_list == nullptr: all E entities, those above CAP skipped (pack_entnnz_kernel put them on a later stage's list);
 // otherwise the *in_count entities of in_list, which fit by construction.
@@ -269,9 +394,10 @@ __global__ __launch_bounds__(WAVE* NWAVES) void pack_entity_kernel(
     int64_t E, int ic, int32_t* __restrict__ row_ptr, unsigned long long* __restrict__ sort_key,
     int32_t* __restrict__ csr_col, int32_t* __restrict__ col_ptr, int32_t* __restrict__ csc_row,
     float* __restrict__ csc_val, int32_t* __restrict__ uniq_sparse, int32_t* __restrict__ d_cnt,
-    PackStats* __restrict__ stats) {
+    PackStats* __restrict__ stats, int pack_bitmap_on) {
   __shared__ unsigned long long lds_keys[NWAVES][CAP];
   __shared__ unsigned long long lds_sorted[NWAVES][PACK_RANK_MAX];
+  __shared__ unsigned lds_bm[NWAVES][PACK_BITMAP_WORDS];
   __shared__ float lds_val[NWAVES][CAP];
   __shared__ int32_t lds_rp[NWAVES][CAP + 1];
   __shared__ int blk_max[3];
@@ -308,15 +434,20 @@ __global__ __launch_bounds__(WAVE* NWAVES) void pack_entity_kernel(
       // explicit LDS instantiation (ds_* accesses; a generic pointer selecting between LDS and HBM compiles
       // to flat_* accesses whose base+offset folding faults at the LDS aperture edge)
       bool wide = false;   // a column of PACK_COUNT_COLS or above (or out of range)
+      bool wide2 = false;  // ... of PACK_BITMAP_COLS or above
       for (int k = lane; k < nnz; k += WAVE) {
         const int64_t c = col_global[z0 + k];
         bad |= (c < 0 || c > 0x7fffffffll);
         wide |= (uint64_t)c >= (uint64_t)PACK_COUNT_COLS;
+        wide2 |= (uint64_t)c >= (uint64_t)PACK_BITMAP_COLS;
         lds_keys[wv][k] = ((unsigned long long)(uint32_t)c << 32) | (unsigned)k;
         lds_val[wv][k] = val[z0 + k];
       }
       wave_lds_fence();
-      if (nnz <= PACK_RANK_MAX) {
+      if (nnz <= PACK_RANK_MAX && pack_bitmap_on && __ballot(wide2) == 0ull) {
+        d = bitmap_entity(lds_keys[wv], lds_bm[wv], lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0, col_ptr + z0 + e,
+                          csc_row + z0, csc_val + z0, uniq_sparse + z0);
+      } else if (nnz <= PACK_RANK_MAX) {
         wave_rank_sort(lds_keys[wv], lds_sorted[wv], nnz, lane);
         d = emit_entity(lds_sorted[wv], lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0, col_ptr + z0 + e,
                         csc_row + z0, csc_val + z0, uniq_sparse + z0);
@@ -504,6 +635,12 @@ static bool debug_sync() {
     }                                                                          \
   } while (0)
 
+// GDMIX_PACK_BITMAP=0: entities of at most 128 non-zeros through the rank sort as before (A/B, and the tests that compare the paths)
+static int pack_bitmap_on() {
+  const char* e = getenv("GDMIX_PACK_BITMAP");
+  return (e && atoi(e) == 0) ? 0 : 1;
+}
+
 int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_intercept, void* ws, size_t ws_bytes,
               gdmix_re_packed* out, hipStream_t s) {
   const int64_t E = raw->E, N = raw->N, Z = raw->Z;
@@ -581,7 +718,7 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
   hipLaunchKernelGGL((pack_entity_kernel<PACK_LDS_KEYS, PACK_WAVES>), dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s,
                      (const int32_t*)nullptr, (const int*)nullptr, raw->ent_row_ptr,
                      raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
-                     out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
+                     out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats, pack_bitmap_on());
   DBG_STAGE("pack_entity_kernel<256>");
   if (ns >= 1) HIP_TRY(hipStreamSynchronize(sb));   // the counts (the first stage is running)
   // (a C5-shaped entity has 256 +- 50 non-zeros: half of them overflow the first tier; the 512-key tier runs four workgroups of
@@ -591,7 +728,7 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
     hipLaunchKernelGGL((pack_entity_kernel<PACK_CAP2, 4>), dim3(ctx->num_cus * 4), dim3(WAVE * 4), 0, s2,
                        (const int32_t*)mid_list, (const int*)&stats->n_mid, raw->ent_row_ptr,
                        raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
-                       out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
+                       out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats, pack_bitmap_on());
   }
   DBG_STAGE("pack_entity_kernel<512>");
   if (ns == 0 || hs->n_mid2 > 0) {
@@ -599,7 +736,7 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
     hipLaunchKernelGGL((pack_entity_kernel<PACK_CAP3, 2>), dim3(ctx->num_cus * 4), dim3(WAVE * 2), 0, s3,
                        (const int32_t*)mid2_list, (const int*)&stats->n_mid2, raw->ent_row_ptr,
                        raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
-                       out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats);
+                       out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats, pack_bitmap_on());
   }
   DBG_STAGE("pack_entity_kernel<1024>");
   {

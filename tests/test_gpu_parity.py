@@ -255,6 +255,55 @@ def test_pack_of_large_entities_counting_and_sort_paths(device_solver, monkeypat
         assert packed.max_n == int(ent_n.max()) and packed.max_nnz == int(np.diff(rp[np.concatenate([[0], np.cumsum(ent_n)])]).max())
 
 
+@pytest.mark.parametrize("dim", [3, 64, 1024, 2047, 2048, 2049, 70000])
+@pytest.mark.parametrize("bitmap", [True, False])
+def test_pack_of_small_entities_bitmap_and_rank_sort_paths(device_solver, monkeypatch, dim, bitmap):
+    """csrc/re_pack.hip: entities of at most 128 non-zeros. All columns below 2 048: the bitmap path (local id = set bits below the
+    column, CSC slot = the column's start + the rank among its own entries) — C2's and MovieLens' bags; a wider feature space, or
+    GDMIX_PACK_BITMAP=0: the rank sort. Every array of the packed batch equals the oracle's, whichever path ran: one tile and two
+    (more than 64 non-zeros), more than 64 distinct columns, a handful of columns each occurring many times (the ranking among equal
+    columns, carried over the tile border), empty samples, entities without any non-zero, a single entry, exactly 128."""
+    if bitmap:
+        monkeypatch.delenv("GDMIX_PACK_BITMAP", raising=False)
+    else:
+        monkeypatch.setenv("GDMIX_PACK_BITMAP", "0")
+    from gdmix_amd.batch import RawBatch
+    rng = np.random.default_rng(1000 + dim)
+    E = 600
+    ent_n = rng.integers(1, 33, E).astype(np.int64)
+    ent_n[:6] = [1, 128, 1, 40, 64, 16]
+    row_nnz = []
+    for e in range(E):
+        budget, hi = 128, int(rng.integers(1, 9))
+        k = np.minimum(rng.integers(0, hi + 1, ent_n[e]), 8)
+        while k.sum() > budget:
+            k[rng.integers(0, k.size)] = 0
+        row_nnz.append(k)
+    row_nnz[0] = np.array([1]); row_nnz[1] = np.ones(128, np.int64); row_nnz[2] = np.array([0]); row_nnz[3] = np.full(40, 3); row_nnz[4] = np.full(64, 2)
+    row_nnz[5] = np.full(16, 8)
+    row_nnz = np.concatenate(row_nnz).astype(np.int64)
+    rp = np.concatenate([[0], np.cumsum(row_nnz)]).astype(np.int64)
+    Z, N = int(rp[-1]), int(ent_n.sum())
+    # a third of the entities draw from a handful of columns (many equal columns), the rest Zipf-like over the whole space
+    ent_of_row = np.repeat(np.arange(E), ent_n)
+    ent_of_nz = np.repeat(ent_of_row, row_nnz)
+    few = (ent_of_nz % 3) == 0
+    cols = np.minimum((float(dim) ** rng.random(Z)).astype(np.int64) - 1, dim - 1)
+    cols[few] = rng.integers(0, min(dim, 5), int(few.sum()))
+    cols[rng.integers(0, Z)] = dim - 1
+    b = RawBatch(ent_row_ptr=np.concatenate([[0], np.cumsum(ent_n)]), row_nnz_ptr=rp, col_global=cols,
+                 val=rng.standard_normal(Z).astype(np.float32), y=(rng.random(N) < 0.5).astype(np.float32),
+                 offset=np.zeros(N, np.float32))
+    nnz_e = np.diff(rp[b.ent_row_ptr])
+    assert nnz_e.max() == 128 and (nnz_e > 64).sum() > 20 and (nnz_e == 0).any()
+    pk = oracle.pack(b.ent_row_ptr, b.row_nnz_ptr, b.col_global)
+    if dim >= 1024:
+        assert np.diff(pk["ent_feat_ptr"]).max() > 64       # ids of the second half exist
+    packed = device_solver.pack(b)
+    _check_pack(packed, pk, b.val)
+    assert packed.max_p == int(np.diff(pk["ent_feat_ptr"]).max()) + 1
+
+
 def test_side_stream_does_not_change_results(device_solver, monkeypatch):
     """gdmix_re_solve launches the classes that cannot fill the device on a second stream of the context, beside the large ones
     (csrc/re_api.hip: class_is_small). A batch with a dozen classes, most of them small: a context without the side stream
