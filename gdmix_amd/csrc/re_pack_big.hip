@@ -33,7 +33,9 @@ namespace gdmix {
     }                                                                                   \
   } while (0)
 
-constexpr int BIG_CH = 4096;               // entries per chunk: the unit of work of every per-entry pass here
+constexpr int BIG_CH = 1024;               // entries per chunk: the unit of work of every per-entry pass here (4 096 until the end of round 4: a share of a
+                                           // strongly scaled job has ~1 200 chunks of that size, one wavefront each for 120 us of big_scatter_kernel; 1 024: per-user share
+                                           // pack 0.58 -> 0.51 ms, whole populations unchanged; 512 is worse again: tools/r04_bigch.sh)
 constexpr unsigned BIG_COUNT_CBITS = 11;   // counting path for column indices below 2^11 (its tables are C counters per chunk)
 
 // sizes[b] = non-zeros of big entity b, nch[b] = its chunks (at least one, so that an entity without non-zeros still gets its

@@ -227,7 +227,7 @@ def test_team_tiers_match_reference_fixture(device_solver, name):
 def test_pack_of_large_entities_counting_and_sort_paths(device_solver, monkeypatch, dim, count_path):
     """csrc/re_pack_big.hip: entities above 1 024 non-zeros. Column indices below 2^11 take the counting path (chunk histograms, no
     sort), larger feature spaces the device-wide radix sort; GDMIX_PACK_BIG_COUNT=0 forces the sort path on a small feature space.
-    Every array of the packed batch equals the oracle's, whichever path ran: entities of one chunk and of many (chunks of 4 096
+    Every array of the packed batch equals the oracle's, whichever path ran: entities of one chunk and of many (chunks of 1 024
     entries), a column that occurs once, empty samples, an entity with samples and no non-zero at all, small entities in between."""
     if count_path:
         monkeypatch.delenv("GDMIX_PACK_BIG_COUNT", raising=False)
