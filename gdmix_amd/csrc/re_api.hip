@@ -172,8 +172,11 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   if (!c) { set_error("out of host memory"); return GDMIX_RE_ENOMEM; }
   c->impl.device = hip_device;
   c->impl.num_cus = prop.multiProcessorCount;
-  c->impl.tall_adapt_limit = c->impl.num_cus * 3 / 4;   // (tools/r04_adapt.sh: 64 / 128 / 192 / 256 / 384 / 512 / 1024 workgroups on a 17 k-user share:
-                                                        // 2.51 / 2.39 / 2.22 / 2.51* / 2.24 / 2.43 / 2.83 ms; * one share of eight, the others 2.2)
+  // (tools/r04_adapt.sh. Before the team class took a batch's tallest entities, 64 / 128 / 192 / 256 / 384 / 512 / 1024 workgroups on a 17 k-user
+  // share: 2.51 / 2.39 / 2.22 / 2.51 / 2.24 / 2.43 / 2.83 ms, and 192 it was. With the heads on teams the eight-wavefront class is a class of
+  // mid-size entities that finish early and hand their CU on: slowest per-user / per-movie share at 128 / 192 / 256 / 320 / 384 / 448 / 512 / 768 / 1024:
+  // 2.32/2.36, 2.13/2.30, 2.03/2.07, 2.07/2.06, (2.0)/2.05, 2.02/2.00, 2.06/2.05, 2.46/1.97, 2.52/1.95 ms -> one and a half workgroups per CU.)
+  c->impl.tall_adapt_limit = c->impl.num_cus * 3 / 2;
   if (const char* e = getenv("GDMIX_RE_TALL_ADAPT")) c->impl.tall_adapt_limit = atoi(e) > 0 ? atoi(e) : 0;
   c->impl.scratch = nullptr;
   c->impl.scratch_bytes = 0;
