@@ -92,7 +92,7 @@ def parse():
     ap.add_argument("--no-rebalance", action="store_true", help="strong-scaling legs: skip the run through the re-balancer")
     ap.add_argument("--rebalance-tolerance", type=float, default=0.02,
                     help="strong-scaling legs: ranks within (1 + tolerance) x the mean cost neither send nor receive (the product's default is 0.05)")
-    ap.add_argument("--strong-steps", type=int, default=2, help="timed steps of each strong-scaling / projection leg")
+    ap.add_argument("--strong-steps", type=int, default=4, help="timed steps of each strong-scaling / projection leg (after two warm-up steps)")
     ap.add_argument("--project-ranks", type=int, default=8,
                     help="--gpus 1, default workload: also solve the shares of an N-rank job one after another on this GPU "
                          "(detail.strong_projection; 0 = skip)")
@@ -817,11 +817,11 @@ def main():
         res = None
         torch.cuda.empty_cache()
         if world > 1 and not a.no_strong:
-            strong = [bench_strong.strong_leg(w, rank, world, solver, opts, coll_dev, a.c5_entities, steps=a.strong_steps, warmup=1,
+            strong = [bench_strong.strong_leg(w, rank, world, solver, opts, coll_dev, a.c5_entities, steps=a.strong_steps, warmup=2,
                                               rebalance=not a.no_rebalance, ml_entities=a.ml_entities or None, tolerance=a.rebalance_tolerance)
                       for w in bench_strong.STRONG_WORKLOADS if _fits(w, a, world, coll_dev)]
         elif world == 1 and a.project_ranks > 1:
-            projection = [bench_strong.projection_leg(w, a.project_ranks, solver, opts, a.c5_entities, steps=a.strong_steps, warmup=1,
+            projection = [bench_strong.projection_leg(w, a.project_ranks, solver, opts, a.c5_entities, steps=a.strong_steps, warmup=2,
                                                       ml_entities=a.ml_entities or None, tolerance=a.rebalance_tolerance)
                           for w in bench_strong.STRONG_WORKLOADS if _fits(w, a, world, coll_dev)]
         solver.set_timing(True)

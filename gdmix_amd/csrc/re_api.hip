@@ -61,7 +61,7 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_GRID, 0, "re_solve_team_kernel 8 teams"},
     {KIND_GRID, 0, "re_solve_team_kernel device-wide"}};
 
-__global__ void class_base_kernel(int32_t* cc, int tall_adapt_limit, int tall_team_n, int tall_team_limit) {
+__global__ void class_base_kernel(int32_t* cc, int tall_adapt_limit, int tall_adapt_small, int tall_team_n, int tall_team_limit) {
   // cc[0..NC) counts -> cc[NC..2NC) exclusive bases, cc[2NC..3NC) cursors = 0
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     // The split between the one-wavefront and the eight-wavefront tall kernels (4 096 samples by default: right for a batch with
@@ -86,8 +86,11 @@ __global__ void class_base_kernel(int32_t* cc, int tall_adapt_limit, int tall_te
       }
     }
     ge[TALL_TEAM_SLOT] = team_from;
+    // ... and only for a batch whose one-wavefront class is small itself (at most `tall_adapt_small` entities: two rounds of its launch):
+    // a whole population is bound by throughput, where the one-wavefront kernel is the better use of a CU (MovieLens-20M per user on one
+    // GPU, 14 k such entities: 8.9 ms with the split at 4 096, 9.4 ms when 224 more entities took a CU each)
     int split = 0;
-    if (tall_adapt_limit > 0) {
+    if (tall_adapt_limit > 0 && cc[TALL_S_CLASS] <= tall_adapt_small) {
       for (int k = 0; k < TALL_ADAPT_STEPS && split == 0; ++k)
         if (ge[k] > 0 && cc[TALL_CLASS] + ge[k] <= tall_adapt_limit) {
           split = tall_adapt_n(k);
@@ -471,7 +474,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   int32_t* cc = b->class_count;
   HIP_TRY(hipMemsetAsync(cc, 0, 6 * GDMIX_RE_NUM_CLASSES * sizeof(int32_t), s));
   HIP_TRY(launch_classify(b, ic, opts->m, tab, b->cls_tmp, cc, s));
-  hipLaunchKernelGGL(class_base_kernel, dim3(1), dim3(1), 0, s, cc, tab.tall_adapt_limit, tab.tall_team_n, tab.tall_team_limit);
+  hipLaunchKernelGGL(class_base_kernel, dim3(1), dim3(1), 0, s, cc, tab.tall_adapt_limit, 16 * ctx->impl.num_cus, tab.tall_team_n, tab.tall_team_limit);
   HIP_TRY(hipGetLastError());
   HIP_TRY(launch_order(b, b->cls_tmp, cc + GDMIX_RE_NUM_CLASSES, cc + 2 * GDMIX_RE_NUM_CLASSES, s));
   int32_t* hc = ctx->impl.host_pinned + 256;
