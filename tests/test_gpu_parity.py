@@ -326,6 +326,35 @@ def test_side_stream_does_not_change_results(device_solver, monkeypatch):
         assert np.array_equal(a[k], r[k]), k
 
 
+def test_large_classes_side_by_side_do_not_change_results(device_solver):
+    """Round 4: the size classes that fill the device are dealt over the caller's stream and the context's side streams
+    (gdmix_re_set_spread, default 4) instead of running one after another. 120 k C2 entities (three large group classes) with
+    MovieLens-20M users (large tall classes) and a few small classes: two, three and four queues give the bits of the one-queue
+    schedule, SIMPLE variances included, and the per-class times come back for every class that ran."""
+    from gdmix_amd.batch import concat
+    b = concat([synthetic.make_survey_batch(120_000, 16, 4, 1024, seed=65), synthetic.make_movielens_20m("per_user", seed=66, entities=9000),
+                synthetic.make_batch(150, 24, 8, 4096, seed=67, size_dist="zipf")])
+    kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12, variance_mode=1)
+    packed = device_solver.pack(b)
+    device_solver.set_timing(True)
+    try:
+        device_solver.set_spread(0)
+        one = device_solver.solve(packed, SolverOptions(**kw)).to_host()
+        ms_one = np.array(device_solver.last_solve_ms())
+        counts = np.array([c for _, c in device_solver.class_counts(packed)])
+        for q in (2, 3, 4):
+            device_solver.set_spread(q)
+            r = device_solver.solve(packed, SolverOptions(**kw)).to_host()
+            ms = np.array(device_solver.last_solve_ms())
+            for k in ("theta", "variance", "fval", "gnorm", "nit", "nfev", "status"):
+                assert np.array_equal(one[k], r[k]), (q, k)
+            assert np.array_equal(ms > 0, ms_one > 0)
+    finally:
+        device_solver.set_spread(4)
+        device_solver.set_timing(False)
+    assert (ms_one > 0).sum() >= 6 and counts[ms_one > 0].min() > 0
+
+
 def test_team_lds_vectors_do_not_change_results(device_solver, monkeypatch):
     """The one-workgroup team kernel keeps x, g, d (and x_old, g_old where they fit) and the residuals of an entity in the LDS
     its workgroup leaves free (csrc/re_solve.hip: team_vec_level) instead of the global scratch slot. Same arithmetic in the
