@@ -192,9 +192,11 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   c->impl.tall_min_n = GDMIX_RE_TALL_MIN_N_DEFAULT;
   c->impl.tall_split_n = GDMIX_RE_TALL_SPLIT_N_DEFAULT;
   c->impl.tall_team_n = GDMIX_RE_TALL_TEAM_N_DEFAULT;
-  // an eighth of the CUs' worth of entities: the teams take four CUs each for as long as their entity lasts, and the one-wavefront
-  // tall class next to them needs its CUs too (tools/r04_tallteam.sh: 64 entities = every CU held a share's other classes up)
-  c->impl.tall_team_limit = c->impl.num_cus / 8 < TALL_TEAM_MAX ? c->impl.num_cus / 8 : TALL_TEAM_MAX;
+  // How many entities the class may take: a quarter of the CUs' worth (one round of teams). Measured twice, because the answer depends on
+  // the class behind it (tools/r04_tallteam2.sh, slowest per-movie share of eight): while the eight-wavefront class was capped at 3/4 of the
+  // CUs, 64 teams held every CU for the length of their entity and the one-wavefront class waited (2.9 ms; 32: 2.25, 16: 2.29); since that
+  // class may take 1.5 workgroups per CU and absorbs what the teams leave, 16 / 32 / 48 / 64: 2.38 / 1.98 / 1.98 / 1.85 - 1.90 ms.
+  c->impl.tall_team_limit = c->impl.num_cus / 4 < TALL_TEAM_MAX ? c->impl.num_cus / 4 : TALL_TEAM_MAX;
   if (const char* e = getenv("GDMIX_RE_TALL_TEAM")) { if (atoi(e) == 0) c->impl.tall_team_n = 0; }   // A/B switch
   if (const char* e = getenv("GDMIX_RE_TALL_TEAM_LIMIT")) { if (atoi(e) > 0 && atoi(e) <= TALL_TEAM_MAX) c->impl.tall_team_limit = atoi(e); }   // exploration knob
   c->impl.spread = spread_default();

@@ -266,7 +266,7 @@ GDMIX_API int gdmix_re_set_tall_split_n(gdmix_re_ctx* ctx, int split_n);
 /* The tallest entities of a batch get a TEAM of four workgroups (four CUs of one XCD) that share the pass over one entity's
  * samples: a share of a strongly scaled MovieLens job lasts as long as ONE workgroup needs for its most rated title
  * (ABI 9, GDMIX_RE_NUM_CLASSES 39). `team_n` > 0: eight-wavefront tall entities of at least team_n, 2 team_n or 4 team_n samples
- * - the lowest of the three that keeps the class within one round of teams on the device (a quarter of its CUs); a batch with
+ * - the lowest of the three that keeps the class within one round of teams on the device (a quarter of its CUs' worth of entities); a batch with
  * more entities than that above 4 team_n has no team class (it is bound by throughput, not by one entity's chain).
  * `team_n` < 0: every tall entity of at least -team_n samples (at least 64), no limit (tests). 0 = never. The split of an
  * entity's samples over the four workgroups depends on its size alone: results do not depend on the batch, and agree with the

@@ -2,13 +2,14 @@
 # round 4: how many entities the team class should take (GDMIX_RE_TALL_TEAM_LIMIT) — 8-share projection of the MovieLens populations
 mkdir -p gpurun_out/tt
 cd /root/repo
-for lim in 0 16 32; do
+for lim in ${LIMITS:-0 16 32}; do
   GDMIX_RE_TALL_TEAM=$([ $lim = 0 ] && echo 0 || echo 1) GDMIX_RE_TALL_TEAM_LIMIT=$lim timeout 900 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-e2e --no-fe --no-cli --c5-entities 100000 --strong-steps 5 > gpurun_out/tt/proj_l$lim.json 2> gpurun_out/tt/proj_l$lim.err
   echo "limit=$lim rc=$?"
 done
 python - <<'PY'
 import json
-for lim in (0, 16, 32):
+import os
+for lim in [int(x) for x in os.environ.get('LIMITS', '0 16 32').split()]:
     try:
         d = json.loads([l for l in open(f'gpurun_out/tt/proj_l{lim}.json') if l.startswith('{')][0])
     except Exception as e:
