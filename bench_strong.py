@@ -355,7 +355,7 @@ def projection_leg(name, ranks, solver, opts, c5_entities, steps=2, warmup=1, ml
         names = [n for n, _ in solver.class_counts(packed)]
         cnts = np.bincount(cls, minlength=NUM_CLASSES)
         top = sorted(((float(class_ms[c]), names[c], int(cnts[c])) for c in range(NUM_CLASSES) if class_ms[c] > 0), reverse=True)[:5]
-        per.append({"rank": r, "largest_launches": [{"kernel": k, "entities": e, "ms": round(ms, 3)} for ms, k, e in top], "entities": share.E, "samples": share.N, "nnz": share.Z, "ms_per_step": own_s / steps * 1e3,
+        per.append({"rank": r, "largest_launches": [{"kernel": k, "entities": e, "ms": round(ms, 3)} for ms, k, e in top], "entities": share.E, "samples": share.N, "nnz": share.Z, "ms_per_step": float(np.median(share.step_ms)), "ms_per_step_mean": own_s / steps * 1e3,
                     "pack_ms": share.pack_ms, "solve_kernel_ms": float(class_ms.sum()), "converged": _converged(res),
                     "largest_nnz": int(share.z.max()) if share.E else 0, "step_wall_ms": list(share.step_ms),
                     "generate_s": round(share.gen_s, 2)})
@@ -367,7 +367,9 @@ def projection_leg(name, ranks, solver, opts, c5_entities, steps=2, warmup=1, ml
     ms = np.array([p["ms_per_step"] for p in per])
     conv = sum(p["converged"] for p in per)
     out = {"workload": name, "what": STRONG_WORKLOADS[name][0], "ranks": ranks, "partitions": partitions,
-           "projection": f"the {ranks} shares were solved one after another on ONE MI355X (no collective on the data path): ms = the slowest share",
+           "projection": f"the {ranks} shares were solved one after another on ONE MI355X (no collective on the data path): ms = the slowest share; a "
+                         "share's ms_per_step = the MEDIAN of its timed steps (step_wall_ms lists them, ms_per_step_mean is their mean: one host hiccup - "
+                         "19.6 ms in a 2 ms step, once in a run - would otherwise be the slowest rank of the job)",
            "total_entities": sum(p["entities"] for p in per), "total_nnz": sum(p["nnz"] for p in per),
            "ms": float(ms.max()), "entities_per_s": conv / (float(ms.max()) * 1e-3), "imbalance": float(ms.max() / ms.mean()),
            "sum_of_shares_ms": float(ms.sum()), "per_rank": per}
