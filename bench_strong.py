@@ -94,6 +94,7 @@ def _timed_steps(solver, share, opts, steps, warmup, sync, barrier):
     # a share's step is 2 ms: one full collection of the interpreter's garbage (it came at the same call count of a run, whatever the
     # share: + 6 - 10 ms on ONE share of eight, tools/r04_tallteam2.sh) would be the slowest "rank" of the job — collected before, not during
     gc.collect()
+    gc_was_on = gc.isenabled()
     gc.disable()
     share.step_ms = []
     try:
@@ -112,7 +113,8 @@ def _timed_steps(solver, share, opts, steps, warmup, sync, barrier):
         sync()
         own = time.perf_counter() - t0
     finally:
-        gc.enable()
+        if gc_was_on:
+            gc.enable()
     barrier()
     share.pack_ms = pack_ms / steps
     return packed, res, own, time.perf_counter() - t0, np.array(solver.last_solve_ms())
