@@ -42,7 +42,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import gdmix_amd  # noqa: E402,F401  (before the first device call: the package sets the process's hardware-queue default)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # a process setting, made by the entry point before the first device call (gdmix_amd/gdmix.py: process_defaults)
 
 SPREAD_DEFAULT = int(os.environ.get("GDMIX_RE_SPREAD", "4"))   # queues the large size classes are dealt over (gdmix_re_set_spread)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -96,6 +96,8 @@ def parse():
     ap.add_argument("--project-ranks", type=int, default=8,
                     help="--gpus 1, default workload: also solve the shares of an N-rank job one after another on this GPU "
                          "(detail.strong_projection; 0 = skip)")
+    ap.add_argument("--detail-file", default="", help="where the full result goes (default gpurun_out/bench_detail.json); the stdout line is the short form")
+    ap.add_argument("--print-detail", action="store_true", help="also print the full result as one JSON line on stderr")
     ap.add_argument("--ml-entities", type=int, default=0, help="strong legs: keep this many MovieLens entities (tests at reduced size; 0 = all)")
     return ap.parse_args()
 
@@ -343,14 +345,15 @@ def cli_end_to_end_leg(entities):
                 shutil.rmtree(os.path.join(d, "models"))
                 shutil.rmtree(os.path.join(d, "ts"), ignore_errors=True)
             t = time.perf_counter()
-            rc = subprocess.call([sys.executable, "-m", "gdmix_amd.gdmix"] + argv[1:], cwd=ROOT,
-                                 env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")))
+            # (the child logs at INFO as the reference does; its stderr is kept out of this run's and shown only if it fails)
+            cp = subprocess.run([sys.executable, "-m", "gdmix_amd.gdmix"] + argv[1:], cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")))
             sub[label + "_s"] = time.perf_counter() - t
-            if rc != 0:
-                raise RuntimeError(f"python -m gdmix_amd.gdmix exited with {rc}")
+            if cp.returncode != 0:
+                raise RuntimeError(f"python -m gdmix_amd.gdmix exited with {cp.returncode}: " + cp.stderr.decode(errors="replace")[-2000:])
             sub[label + "_entities_per_s"] = entities / sub[label + "_s"]
         t = time.perf_counter()
-        subprocess.check_call([sys.executable, "-c", "import gdmix_amd.gdmix"], cwd=ROOT)
+        subprocess.check_call([sys.executable, "-c", "import gdmix_amd.gdmix"], cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         sub["import_only_s"] = time.perf_counter() - t
         sub["what"] = ("wall time of a real child process `python -m gdmix_amd.gdmix --stage=random_effect --action=train ...` on the same "
                        "files (cold = no prior model; warm_start = from the cold run's model files); import_only_s = a child that only imports the CLI module")
@@ -624,11 +627,136 @@ def strong_main(a, rank, world, solver, opts, coll_dev, backend):
                 "roofline": None, "cpu_baseline": None,
                 "note": "strong-scaling mode: roofline and cpu_baseline belong to the default (weak, C2) line",
                 "strong_scaling": [r]}
-        print(json.dumps(line))
+        emit(line, a)
+
+
+DETAIL_DEFAULT = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+COMPACT_LIMIT = 4096   # the driver keeps the tail of stdout: the result line has to be short (BENCH_r04: a 38.5 KB line was cut, parsed = null)
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or d.get(k) is None:
+            return None
+        d = d[k]
+    return d
+
+
+def _r(x, digits=4):
+    """Numbers of the short line: `digits` significant digits."""
+    if isinstance(x, bool) or x is None or isinstance(x, (str, int)):
+        return x
+    try:
+        return float(f"{float(x):.{digits}g}")
+    except (TypeError, ValueError):
+        return x
+
+
+def compact_line(full, detail_file):
+    """The ONE stdout line of a run: the bench contract's keys, `roofline` and `cpu_baseline` as flat objects, one number per
+    side leg under `summary`, and the path of the file that holds everything else (`full`, what earlier rounds printed as one
+    line). Always shorter than COMPACT_LIMIT bytes: optional parts are dropped, last first, until it is."""
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype", "data")}
+    line["ms_per_step"] = _r(line["ms_per_step"], 6)
+    cfg = full.get("config") or {}
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:330]}
+    for k in ("workload_key", "entities_per_gpu", "total_entities", "step", "parallelism", "collective_backend"):
+        if cfg.get(k) is not None:
+            line["config"][k] = cfg[k]
+    if cfg.get("ranks"):
+        line["config"]["rank_ms_per_step"] = [_r(r["ms_per_step"]) for r in cfg["ranks"]]
+    roof = full.get("roofline")
+    if roof:
+        line["roofline"] = {"bound": roof["bound"], "achieved": _r(roof["achieved"], 6), "peak": roof["peak"], "unit": roof["unit"],
+                            "frac": _r(roof["frac"]), "traffic": roof.get("traffic"), "kernel": roof.get("kernel"),
+                            "avg_launch_ms": _r(roof.get("avg_launch_ms")), "alg_bytes_per_launch": roof.get("alg_bytes_per_launch"),
+                            "entities_in_launch": roof.get("entities_in_launch"),
+                            "alone_frac": _r(_get(roof, "alone", "frac")), "alone_launch_ms": _r(_get(roof, "alone", "avg_launch_ms")),
+                            "valu_issue_frac": _r(_get(roof, "valu", "issue_frac")),
+                            "traffic_over_alg": _r(roof["traffic"] / roof["alg_bytes_per_launch"]) if roof.get("traffic") and roof.get("alg_bytes_per_launch") else None}
+        if roof.get("traffic") is None and roof.get("traffic_note"):
+            line["roofline"]["traffic_note"] = str(roof["traffic_note"])[:160]
+    else:
+        line["roofline"] = None
+    cpu = full.get("cpu_baseline")
+    line["cpu_baseline"] = ({"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"], "sample": str(cpu["sample"])[:220]}
+                            if cpu else None)
+    d = full.get("detail") or {}
+    s = {}
+
+    def put(key, value, digits=4):
+        if value is not None:
+            s[key] = _r(value, digits)
+    put("pack_ms", d.get("pack_ms_per_step"))
+    put("solve_ms", d.get("solve_ms_per_step"))
+    put("converged_per_step", d.get("converged_per_step"), 12)
+    put("mean_nfev", d.get("mean_nfev"))
+    put("handover_eps", _get(d, "host_handover", "entities_per_s"))
+    put("score_frac", _get(d, "score_pass", "frac_of_hbm_peak"))
+    put("fe_frac", _get(d, "fixed_effect_eval", "frac_of_hbm_peak"))
+    put("fe_ms_per_eval", _get(d, "fixed_effect_eval", "ms_per_evaluation"))
+    put("fe_zipf_frac", _get(d, "fixed_effect_eval", "zipf", "frac_of_hbm_peak"))
+    for w in ("ml20m_user", "ml20m_movie", "c5share"):
+        put(w + "_ms", _get(d, "workloads", w, "ms_per_step"))
+        put(w + "_eps", _get(d, "workloads", w, "entities_per_s"))
+    put("c5share_dom_restreamed_frac", _get(d, "workloads", "c5share", "roofline", "restreamed_frac_of_hbm_peak"))
+    put("cli_cold_eps", _get(d, "cli_end_to_end", "cold_entities_per_s"))
+    put("cli_warm_eps", _get(d, "cli_end_to_end", "warm_start_entities_per_s"))
+    put("cli_child_s", _get(d, "cli_subprocess", "cold_s"))
+    put("cli_c5_eps", _get(d, "cli_end_to_end_c5", "entities_per_s"))
+    put("cli_ml20m_movie_eps", _get(d, "cli_end_to_end_ml20m_movie", "entities_per_s"))
+    for p in d.get("strong_projection") or []:
+        s.setdefault("proj8", {})[p["workload"] + "_ms"] = _r(p.get("ms"))
+        if p.get("ms_mean") is not None:
+            s["proj8"][p["workload"] + "_ms_mean"] = _r(p["ms_mean"])
+    full_share = d.get("c5_full_share")
+    if full_share:
+        s["c5_full_share"] = {k: _r(full_share.get(k)) for k in ("entities", "s", "entities_per_s", "round_ms_p50", "round_ms_p99", "round_ms_max")
+                              if full_share.get(k) is not None}
+    chain = d.get("chain")
+    if chain:
+        s["chain"] = {k: _r(v) for k, v in chain.items() if isinstance(v, (int, float))}
+    line["summary"] = s
+    st = full.get("strong_scaling")
+    if st:
+        line["strong"] = {x["workload"]: {"ms": _r(x.get("ms")), "entities_per_s": _r(x.get("entities_per_s")), "imbalance": _r(x.get("imbalance")),
+                                          "rebalanced_ms": _r(_get(x, "rebalanced", "ms"))} for x in st}
+    if full.get("note"):
+        line["note"] = str(full["note"])[:160]
+    line["detail_file"] = detail_file
+    # never longer than the limit: drop the optional parts, least important first
+    for drop in (("note",), ("cpu_baseline", "sample"), ("summary", "proj8"), ("strong",), ("summary",), ("config", "rank_ms_per_step")):
+        if len(json.dumps(line)) < COMPACT_LIMIT:
+            break
+        tgt = line
+        for k in drop[:-1]:
+            tgt = tgt.get(k) or {}
+        tgt.pop(drop[-1], None)
+    line["config"]["workload"] = line["config"]["workload"][:max(40, 330 - max(0, len(json.dumps(line)) - COMPACT_LIMIT + 1))]
+    return line
+
+
+def emit(full, a):
+    """Write everything to the detail file and print the short line LAST on stdout (the only stdout line of the run)."""
+    path = a.detail_file or DETAIL_DEFAULT
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            json.dump(full, fh)
+    except OSError as e:      # a read-only checkout: the short line still goes out
+        print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+        path = None
+    if a.print_detail:
+        print(json.dumps(full), file=sys.stderr)
+    sys.stderr.flush()
+    print(json.dumps(compact_line(full, path and os.path.relpath(path, ROOT))), flush=True)
 
 
 def main():
     a = parse()
+    import logging
+    logging.disable(logging.INFO)      # the model logs every partition at INFO, as the reference does: not into the bench's output
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(a)      # does not return
     rank = int(os.environ.get("RANK", "0"))
@@ -946,7 +1074,7 @@ def main():
                        "restreamed_bytes_per_step": b_stream,
                        "restreamed_GBps": b_stream / (float(kernel_ms.sum()) / a.steps * 1e-3) / 1e9 if kernel_ms.sum() else None},
         }
-        print(json.dumps(line))
+        emit(line, a)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

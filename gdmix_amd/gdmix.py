@@ -10,7 +10,21 @@ shared by Params, SchemaParams and REParams, unknown flags are ignored, any fail
 import logging
 import sys
 
-from . import constants
+
+def process_defaults():
+    """Settings of the PROCESS, made by its entry points (this CLI, bench.py) before the first device call — never by importing the
+    package, which an embedding host may do with a runtime it configured itself. GPU_MAX_HW_QUEUES: a context deals its size classes
+    over four streams (gdmix_re_set_spread) and the host pipeline keeps three contexts busy; twelve streams on the four hardware
+    queues a process gets by default alias onto each other (hand-over 72 -> 79 M entities/s with eight, tools/ab.sh hwq). Read by
+    the HIP runtime when it initialises; a value set by the caller wins."""
+    import os
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+if __name__ == "__main__":      # (before the imports below can load the HIP runtime)
+    process_defaults()
+
+from . import constants  # noqa: E402
 from .driver import FixedEffectDriver, RandomEffectDriver
 from .model import RandomEffectLRLBFGSModel
 from .params import Params, SchemaParams

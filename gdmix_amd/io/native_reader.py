@@ -4,6 +4,7 @@ statement of those rules in Python); tests/test_native_io.py compares the two ar
 import ctypes as C
 from collections.abc import Sequence
 import os
+import threading
 
 import numpy as np
 
@@ -53,6 +54,32 @@ class _Models(C.Structure):
 
 
 _lib = None
+
+# Threads per native call while a host pipeline is open (model.begin_pipeline): several decodes and writers run at once there, and
+# the library's default — the optimum of ONE call alone — oversubscribes the box. A module variable with a lock, scoped by
+# pipeline_threads_begin / _end: not the process environment (an embedding host's other calls keep their defaults, and nothing
+# calls setenv next to native threads that are inside getenv).
+_pipeline_threads = []
+_pipeline_lock = threading.Lock()
+
+
+def pipeline_threads_begin(count: int) -> None:
+    with _pipeline_lock:
+        _pipeline_threads.append(max(1, int(count)))
+
+
+def pipeline_threads_end() -> None:
+    with _pipeline_lock:
+        if _pipeline_threads:
+            _pipeline_threads.pop()
+
+
+def _threads(threads) -> int:
+    """An explicit count wins; then an open pipeline's; 0 = the library's own default (GDMIX_IO_THREADS or its built-in)."""
+    t = int(threads)
+    if t > 0 or not _pipeline_threads or os.environ.get("GDMIX_IO_THREADS"):
+        return t
+    return _pipeline_threads[-1]
 
 
 def available() -> bool:
@@ -187,7 +214,7 @@ class EntityIds(Sequence):
         """For every id of self its position in table_ids (whose ids are all different), or -1."""
         out = np.empty(len(self), np.int64)
         rc = load_library().gdmix_io_match_ids(table_ids.raw, table_ids.ptr.ctypes.data, len(table_ids), self.raw, self.ptr.ctypes.data,
-                                               len(self), out.ctypes.data, int(threads))
+                                               len(self), out.ctypes.data, _threads(threads))
         if rc != 0:
             raise GdmixIoError("gdmix_io_match_ids: " + load_library().gdmix_io_last_error().decode("utf-8", "replace"))
         return out
@@ -240,7 +267,7 @@ def read_grouped_files(files, entity_name, feature_bag, offset_column_name, uid_
     lib = load_library()
     sc = _Schema(_enc(entity_name), _enc(feature_bag), _enc(offset_column_name), _enc(uid_column_name),
                  _enc(label_column_name), _enc(weight_column_name),
-                 -1 if num_features is None or feature_bag is None else int(num_features), int(bool(check_crc)), int(threads))
+                 -1 if num_features is None or feature_bag is None else int(num_features), int(bool(check_crc)), _threads(threads))
     arr = (C.c_char_p * len(files))(*[f.encode("utf-8") for f in files])
     out = C.POINTER(_Batch)()
     rc = lib.gdmix_io_read_grouped(arr, len(files), C.byref(sc), C.byref(out))
@@ -260,7 +287,7 @@ def read_grouped_files(files, entity_name, feature_bag, offset_column_name, uid_
     if bool(b.has_label) and not int(b.labels_binary):
         raise AssertionError("labels must be 0 or 1")   # fit() asserts it (binary_logistic_regression.py:208)
     if wire:
-        rc = lib.gdmix_io_narrow(out, int(threads))
+        rc = lib.gdmix_io_narrow(out, _threads(threads))
         if rc != 0:
             raise (ValueError if rc == -6 else GdmixIoError)(f"gdmix_io_narrow: {lib.gdmix_io_last_error().decode('utf-8', 'replace')}")
         kdt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[int(b.row_nnz_width)]
@@ -357,7 +384,7 @@ def write_models_avro(path, header: bytes, sync: bytes, ids, coef_beg, coef_cnt,
                     icpt_enc, len(icpt_enc), class_enc, len(class_enc), loss_enc, len(loss_enc), int(bool(has_intercept)),
                     float(threshold))
     rc = lib.gdmix_io_avro_write_models(path.encode("utf-8"), header, len(header), sync, C.byref(t), int(block_records),
-                                        int(bool(deflate)), int(threads))
+                                        int(bool(deflate)), _threads(threads))
     if rc != 0:
         raise GdmixIoError("gdmix_io_avro_write_models: " + lib.gdmix_io_last_error().decode("utf-8", "replace"))
     return len(ids)
@@ -374,7 +401,7 @@ def write_scores_avro(path, header: bytes, sync: bytes, uid, score, label, weigh
     score, label, weight, per_coord = f32(score), f32(label), f32(weight), f32(per_coord)
     rc = lib.gdmix_io_avro_write_scores(path.encode("utf-8"), header, len(header), sync, len(uid), _ptr(uid), _ptr(score),
                                         _ptr(label), _ptr(weight), _ptr(per_coord), int(block_records), int(bool(deflate)),
-                                        int(threads))
+                                        _threads(threads))
     if rc != 0:
         raise GdmixIoError("gdmix_io_avro_write_scores: " + lib.gdmix_io_last_error().decode("utf-8", "replace"))
     return len(uid)
@@ -411,7 +438,7 @@ def read_example_files(files, feature_bag, num_features, uid_name, label_name=No
     """Per-record (tf.train.Example) files -> dict of flat sample arrays (the fixed-effect stage's input)."""
     lib = load_library()
     sc = _Schema(None, _enc(feature_bag), _enc(offset_name), _enc(uid_name), _enc(label_name), _enc(weight_name),
-                 -1 if num_features is None or feature_bag is None else int(num_features), int(bool(check_crc)), int(threads))
+                 -1 if num_features is None or feature_bag is None else int(num_features), int(bool(check_crc)), _threads(threads))
     arr = (C.c_char_p * len(files))(*[f.encode("utf-8") for f in files])
     out = C.POINTER(_Batch)()
     rc = lib.gdmix_io_read_examples(arr, len(files), C.byref(sc), C.byref(out))
@@ -436,7 +463,7 @@ def read_models_avro(path, data_offset: int, sync: bytes, deflate: bool, prefix,
     pre_ptr, pre_bytes = prefix.ptr, prefix.bytes
     out = C.POINTER(_Models)()
     rc = lib.gdmix_io_avro_read_models(path.encode("utf-8"), int(data_offset), sync, int(bool(deflate)), _ptr(pre_ptr), pre_bytes,
-                                       len(prefix), icpt_enc, len(icpt_enc), int(bool(has_intercept)), int(threads), C.byref(out))
+                                       len(prefix), icpt_enc, len(icpt_enc), int(bool(has_intercept)), _threads(threads), C.byref(out))
     if rc != 0:
         msg = lib.gdmix_io_last_error().decode("utf-8", "replace")
         if rc == -4:
@@ -463,6 +490,6 @@ def map_coefficients(theta, cur_ptr, cur_idx, src_row, prior_coef_ptr, prior_fea
     pth = np.ascontiguousarray(prior_theta, np.float64)
     assert theta.dtype == np.float64 and theta.flags.c_contiguous
     rc = lib.gdmix_io_map_coefficients(len(src_row), _ptr(cur_ptr), _ptr(cur_idx), _ptr(src_row), _ptr(pcp), _ptr(pfp), _ptr(pth),
-                                       _ptr(pidx), int(bool(has_intercept)), _ptr(theta), int(bool(zero_first)), int(threads))
+                                       _ptr(pidx), int(bool(has_intercept)), _ptr(theta), int(bool(zero_first)), _threads(threads))
     if rc != 0:
         raise GdmixIoError("gdmix_io_map_coefficients: " + lib.gdmix_io_last_error().decode("utf-8", "replace"))

@@ -472,8 +472,9 @@ class RandomEffectLRLBFGSModel:
             # Inside the pipeline three or four decodes and four to six Avro writers run at once: 32 threads per native call (the
             # library's default, the optimum of ONE call alone) put ~200 runnable threads on the box and every phase of every call
             # waited for the others (profiles/r04_host_path.txt: a decode of 11 ms alone took 45 - 75 ms). 12 per call, measured
-            # 2 .. 64 (tools/r04_e2e_knobs.sh); the caller's GDMIX_IO_THREADS wins.
-            os.environ.setdefault("GDMIX_IO_THREADS", "12")
+            # 2 .. 64 (tools/r04_e2e_knobs.sh); the caller's GDMIX_IO_THREADS wins, and a box with fewer cores gets fewer. Held in
+            # the reader module for the life of the pipeline (end_pipeline gives it back): the process environment is not touched.
+            native_reader.pipeline_threads_begin(min(12, os.cpu_count() or 1))
             self._io_pool = ThreadPoolExecutor(max_workers=6, thread_name_prefix="gdmix-read")   # three partitions ahead + their prior models
             self._write_pool = ThreadPoolExecutor(max_workers=WRITE_BEHIND_THREADS, thread_name_prefix="gdmix-write")
 
@@ -527,6 +528,7 @@ class RandomEffectLRLBFGSModel:
                 self._io_pool.shutdown(wait=True)
                 self._write_pool.shutdown(wait=True)
                 self._io_pool = self._write_pool = None
+                native_reader.pipeline_threads_end()
             self._read_cache = None
             # the pooled host blocks (up to GDMIX_IO_POOL_MB + 1 GB of writer buffers) go back to the allocator — behind the caller's
             # back: unmapping 5 GB of touched pages takes 36 - 105 ms (profiles/r04_host_path.txt), a fifth of a warm-started

@@ -12,19 +12,63 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--entities", "20000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-fe", "--no-cli", "--no-other-workloads"]
 
 
-def _run(args, timeout=900):
+def _run(args, timeout=900, detail=None):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TF_CONFIG"):
         env.pop(k, None)
+    if detail is not None:
+        args = list(args) + ["--detail-file", detail]
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, capture_output=True, text=True,
                           timeout=timeout)
 
 
-def _line(r):
+def _line(args, tmp_path, timeout=900):
+    """Run bench.py; check the output contract — stdout is ONE short JSON line (the driver keeps only the tail of stdout) that names
+    the file holding the full result — and return the full result with the short line under "_short"."""
+    detail = str(tmp_path / "bench_detail.json")
+    r = _run(args, timeout=timeout, detail=detail)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    out = r.stdout.splitlines()
+    assert len(out) == 1 and out[0].startswith("{"), r.stdout[-2000:]
+    assert len(out[0]) < 4096
+    short = json.loads(out[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "detail_file"):
+        assert k in short, k
+    assert "INFO:" not in r.stderr      # the model's per-partition log lines stay out of the bench's output
+    with open(detail) as fh:
+        full = json.load(fh)
+    assert full["value"] == short["value"] and full["n_gpus"] == short["n_gpus"]
+    full["_short"] = short
+    return full
+
+
+def test_short_line_of_a_full_default_run_fits_the_driver():
+    """The full result of round 4's default run was a 38.5 KB line and the driver recorded `parsed: null`. The short form of that
+    very result: under 4 KB, the contract's keys, roofline and cpu_baseline flat, one number per side leg."""
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r04_final_bench_line.json")) as fh:
+        full = json.load(fh)
+    assert len(json.dumps(full)) > 30000
+    short = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    text = json.dumps(short)
+    assert len(text) < bench.COMPACT_LIMIT == 4096 and json.loads(text) == short
+    assert short["value"] == full["value"] and short["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+    assert short["config"]["workload"].startswith("C2") and "model" not in short["config"]
+    rf = short["roofline"]
+    assert rf["bound"] == "hbm" and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3) and rf["traffic"] > rf["alg_bytes_per_launch"]
+    assert rf["kernel"].startswith("re_solve_grp_kernel") and rf["alone_frac"] > rf["frac"] and 0 < rf["valu_issue_frac"] < 1
+    assert short["cpu_baseline"]["kind"] == "port" and short["cpu_baseline"]["cores"] >= 1
+    sm = short["summary"]
+    assert sm["fe_frac"] == pytest.approx(full["detail"]["fixed_effect_eval"]["frac_of_hbm_peak"], rel=1e-3)
+    assert set(sm["proj8"]) >= {"ml20m_user_ms", "ml20m_movie_ms", "c5_ms"} and sm["c5share_ms"] > 0 and sm["cli_cold_eps"] > 0
+    # ... and whatever a run adds, the line stays short: optional parts go first
+    full["config"]["workload"] = "x" * 5000
+    full["cpu_baseline"]["sample"] = "y" * 5000
+    full["config"]["ranks"] = [{"ms_per_step": 1.2345678 + i} for i in range(512)]
+    fat = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    assert len(json.dumps(fat)) < 4096 and fat["value"] == full["value"] and fat["roofline"]["frac"] == rf["frac"]
 
 
 def test_gpus_flag_without_enough_devices_fails_loudly():
@@ -45,12 +89,12 @@ def test_world_size_must_match_gpus_flag():
 
 
 @pytest.mark.gpu
-def test_gpus_flag_starts_that_many_ranks():
+def test_gpus_flag_starts_that_many_ranks(tmp_path):
     """--gpus 2 without a launcher: two ranks. On the 1-GPU box they share cuda:0 over gloo (harness test, numbers meaningless);
     with two devices visible they are two RCCL ranks on two GPUs."""
     import torch
     share = [] if torch.cuda.device_count() >= 2 else ["--ranks-share-device"]
-    line = _line(_run(["--gpus", "2"] + share + SMALL))
+    line = _line(["--gpus", "2"] + share + SMALL, tmp_path)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
     ranks = line["config"]["ranks"]
     assert [r["rank"] for r in ranks] == [0, 1]
@@ -64,8 +108,8 @@ def test_gpus_flag_starts_that_many_ranks():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload", ["ml20m_movie"])
-def test_other_workloads_produce_a_line(workload):
-    line = _line(_run(["--workload", workload, "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-e2e"]))
+def test_other_workloads_produce_a_line(workload, tmp_path):
+    line = _line(["--workload", workload, "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-e2e"], tmp_path)
     assert line["n_gpus"] == 1 and line["config"]["workload_key"] == workload
     assert line["detail"]["converged_per_step"] == line["config"]["entities_per_gpu"] == 26744
     pc = line["detail"]["per_class"]
@@ -73,13 +117,13 @@ def test_other_workloads_produce_a_line(workload):
 
 
 @pytest.mark.gpu
-def test_default_legs_of_a_two_rank_run():
+def test_default_legs_of_a_two_rank_run(tmp_path):
     """The driver's scaling run is the default command with --gpus N: every rank also measures the MovieLens-20M workloads and
     C5's per-GPU share after C2 (detail.workloads, collectives inside). Two ranks here; on the 1-GPU box they share the device and
     the C5 leg must be skipped by both ranks together (a rank that ran out of memory alone would leave the other in a barrier)."""
     import torch
     share = [] if torch.cuda.device_count() >= 2 else ["--ranks-share-device"]
-    line = _line(_run(["--gpus", "2"] + share + ["--entities", "20000", "--steps", "2", "--warmup", "1"], timeout=1500))
+    line = _line(["--gpus", "2"] + share + ["--entities", "20000", "--steps", "2", "--warmup", "1"], tmp_path, timeout=1500)
     assert line["n_gpus"] == 2 and line["detail"]["converged_per_step"] == 40000
     w = line["detail"]["workloads"]
     assert set(w) == {"ml20m_user", "ml20m_movie", "c5share"}
@@ -100,13 +144,13 @@ def test_default_legs_of_a_two_rank_run():
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload,extra,total", [("ml20m_user", ["--ml-entities", "6000"], 6000), ("ml20m_movie", ["--ml-entities", "3000"], 3000),
                                                   ("c5", ["--c5-entities", "30000"], 60000)])
-def test_strong_scaling_splits_one_population_and_rebalancing_returns_the_same_models(workload, extra, total):
+def test_strong_scaling_splits_one_population_and_rebalancing_returns_the_same_models(workload, extra, total, tmp_path):
     """--scaling strong: ONE population, entity -> partition by the Java hash, partition -> rank by partitions[rank::2]; the same
     share then through the re-balancer (exchange -> widen -> pack -> solve -> give back), whose coefficients must be the plain
     run's. Two ranks: on the 1-GPU box they share cuda:0 and the collectives are staged over gloo; with two devices it is RCCL."""
     import torch
     share = [] if torch.cuda.device_count() >= 2 else ["--ranks-share-device"]
-    line = _line(_run(["--gpus", "2"] + share + ["--scaling", "strong", "--workload", workload, "--steps", "2", "--warmup", "1"] + extra))
+    line = _line(["--gpus", "2"] + share + ["--scaling", "strong", "--workload", workload, "--steps", "2", "--warmup", "1"] + extra, tmp_path)
     assert line["scaling"] == "strong" and line["n_gpus"] == 2 and line["config"]["workload_key"] == workload
     s = line["strong_scaling"][0]
     assert s["total_entities"] == total == sum(r["entities"] for r in s["per_rank"]) == s["converged_per_step"]
@@ -124,10 +168,10 @@ def test_strong_scaling_splits_one_population_and_rebalancing_returns_the_same_m
 
 
 @pytest.mark.gpu
-def test_projection_of_an_eight_rank_job_on_one_device():
+def test_projection_of_an_eight_rank_job_on_one_device(tmp_path):
     """--gpus 1: the shares of an 8-rank job solved one after another (detail.strong_projection), with the re-balancing plan."""
-    line = _line(_run(["--entities", "20000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-fe", "--no-cli",
-                       "--ml-entities", "8000", "--c5-entities", "20000", "--project-ranks", "8"], timeout=1500))
+    line = _line(["--entities", "20000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-fe", "--no-cli",
+                  "--ml-entities", "8000", "--c5-entities", "20000", "--project-ranks", "8"], tmp_path, timeout=1500)
     proj = {p["workload"]: p for p in line["detail"]["strong_projection"]}
     assert set(proj) == {"ml20m_user", "ml20m_movie", "c5"} and line["strong_scaling"] is None
     assert proj["ml20m_user"]["total_entities"] == 8000 and proj["c5"]["total_entities"] == 160000
