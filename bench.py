@@ -750,6 +750,9 @@ def emit(full, a):
     if a.print_detail:
         print(json.dumps(full), file=sys.stderr)
     sys.stderr.flush()
+    if os.environ.get("GDMIX_BENCH_LINE") == "full":      # tools/ scripts that pipe the full result (never the driver's command)
+        print(json.dumps(full), flush=True)
+        return
     print(json.dumps(compact_line(full, path and os.path.relpath(path, ROOT))), flush=True)
 
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GDMIX_BENCH_LINE=full   # these scripts read the full result from stdout (bench.py prints the short line otherwise)
 # round-3 evidence session (GPU box): profiles of every bench workload, the Zipf tail's traffic, the host path, the fixed effect
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r03ev

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GDMIX_BENCH_LINE=full   # these scripts read the full result from stdout (bench.py prints the short line otherwise)
 # rocprofv3 evidence for the bench command (run on the GPU box): kernel-trace stats, then PMC passes on their own
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-fe --no-cli --no-other-workloads --no-alone"

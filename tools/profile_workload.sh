@@ -1,4 +1,5 @@
 #!/bin/bash
+export GDMIX_BENCH_LINE=full   # these scripts read the full result from stdout (bench.py prints the short line otherwise)
 # rocprofv3 evidence for one bench workload (run on the GPU box):  tools/profile_workload.sh <workload> <out-name> [pmc]
 # kernel-trace stats always; with "pmc" also the FETCH_SIZE / WRITE_SIZE / SQ passes, each in its own run.
 W=${1:-c2}; NAME=${2:-$W}; PMC=$3

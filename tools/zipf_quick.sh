@@ -1,4 +1,5 @@
 #!/bin/bash
+export GDMIX_BENCH_LINE=full   # these scripts read the full result from stdout (bench.py prints the short line otherwise)
 # Zipf-shaped partition: pack + solve per class (exploration workload of bench.py)
 python bench.py --steps 3 --warmup 1 --workload zipf --no-cpu-baseline --no-e2e --no-fe --no-cli "$@" 2>/dev/null | python -c "
 import json,sys
