@@ -631,6 +631,7 @@ def strong_main(a, rank, world, solver, opts, coll_dev, backend):
 
 
 DETAIL_DEFAULT = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+RESULT_FD = None        # the process's original stdout once main() has pointed fd 1 at stderr
 COMPACT_LIMIT = 4096   # the driver keeps the tail of stdout: the result line has to be short (BENCH_r04: a 38.5 KB line was cut, parsed = null)
 
 
@@ -751,9 +752,15 @@ def emit(full, a):
         print(json.dumps(full), file=sys.stderr)
     sys.stderr.flush()
     if os.environ.get("GDMIX_BENCH_LINE") == "full":      # tools/ scripts that pipe the full result (never the driver's command)
-        print(json.dumps(full), flush=True)
-        return
-    print(json.dumps(compact_line(full, path and os.path.relpath(path, ROOT))), flush=True)
+        text = json.dumps(full)
+    else:
+        shown = path and (os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT + os.sep) else os.path.abspath(path))
+        text = json.dumps(compact_line(full, shown))
+    sys.stdout.flush()
+    if RESULT_FD is None:
+        print(text, flush=True)
+    else:
+        os.write(RESULT_FD, (text + "\n").encode())
 
 
 def main():
@@ -762,6 +769,13 @@ def main():
     logging.disable(logging.INFO)      # the model logs every partition at INFO, as the reference does: not into the bench's output
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(a)      # does not return
+    # stdout carries the result line and nothing else: whatever a library prints there (gloo's "[Gloo] Rank 0 is connected ...",
+    # a child process) goes to stderr from here on; emit() writes to the saved descriptor
+    global RESULT_FD
+    if RESULT_FD is None:
+        sys.stdout.flush()
+        RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -33,15 +33,38 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build_library(force=False, verbose=False):
-    if not force and not needs_build():
+def build_library(force=False, verbose=False, out=None):
+    """hipcc, one object per source in parallel (build/ next to the sources keeps them: a change to one kernel file recompiles
+    that file), then one link. Objects are keyed by source, headers and flags; `out` names another library file (A/B builds
+    with GDMIX_EXTRA_FLAGS)."""
+    out = out or LIB
+    if not force and out == LIB and not needs_build():
         return LIB
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
     extra = os.environ.get("GDMIX_EXTRA_FLAGS", "").split()   # tuning experiments only
-    cmd = [HIPCC] + FLAGS + extra + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+    flags = [f for f in FLAGS if f != "-shared"] + extra
+    tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
+    objdir = os.path.join(HERE, "build", tag)
+    os.makedirs(objdir, exist_ok=True)
+    newest_header = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+
+    def compile_one(f):
+        src, obj = os.path.join(CSRC, f), os.path.join(objdir, f + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+            return obj
+        cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        return obj
+    with ThreadPoolExecutor(len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 def build_io_library(force=False, verbose=False):
@@ -58,6 +81,9 @@ def build_io_library(force=False, verbose=False):
 
 if __name__ == "__main__":
     force = "--force" in sys.argv
+    out = None
+    if "--out" in sys.argv:          # python -m gdmix_amd.build --out gdmix_amd/lib_x.so   (with GDMIX_EXTRA_FLAGS: an A/B build)
+        out = os.path.abspath(sys.argv[sys.argv.index("--out") + 1])
     if "--io-only" not in sys.argv:
-        print(build_library(force=force, verbose=True))
+        print(build_library(force=force, verbose=True, out=out))
     print(build_io_library(force=force, verbose=True))

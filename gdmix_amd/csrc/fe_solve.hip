@@ -82,6 +82,7 @@ struct FeHot {
   const int32_t* col;        // [n] local column of frequent column h
 };
 
+struct FeSync;
 struct FeDev {
   int n, d, ic, P, m;
   int64_t z, D;
@@ -98,6 +99,8 @@ struct FeDev {
   double* acc_part;         // [FE_DOT_BLOCKS][TEAM_K]
   double* fin_part;         // [FE_FIN_BLOCKS][2]
   unsigned* fin_count;      // workgroups of fe_finish_kernel that have delivered their range sums
+  int32_t* inv;             // [P] global coefficient -> local column of this shard, -1: absent (intercept: -1)
+  struct FeSync* sync;      // ticket + generation stamp of fe_tail_kernel
   CompactState* state;
   CompactPlan* plan;
   CompactMats* mats;
@@ -138,11 +141,15 @@ __device__ __forceinline__ void lds_add(double* acc, int loc, double term) {
 
 template <bool ROWS, bool HESS, bool PACKED>
 __global__ __launch_bounds__(WAVE) void fe_scatter_kernel(FeDev F, SolveParams o) {
-  __shared__ double acc[FE_B + 2];   // + a spare one for the lanes beyond the end of the last trip
+  // exactly 16 KiB: ten wavefronts per CU (160 KiB of LDS). Round 5: a spare accumulator for the lanes beyond the end of the last
+  // trip made it 16 400 B = nine; those lanes now add 0.0 to accumulator 0 (x + 0.0 == x bit for bit; an accumulator that is still
+  // -0.0 cannot occur: they start at +0.0)
+  __shared__ double acc[FE_B];
   const int lane = threadIdx.x;
   const FeCopy& C = ROWS ? F.rc : F.cc;
   const int u = C.order[blockIdx.x];
   if (u < 0) return;
+  if (!HESS && F.state->status >= 0) return;   // the driver has stopped: evaluations enqueued ahead of the status are no-ops
   const int k0 = C.ustart[u], k1 = C.ustart[u + 1], b = C.ublock[u];
   const int kb = PACKED ? C.kbase[u] : 0;
   const bool whole = ROWS && (C.ufirst[b + 1] - C.ufirst[b] == 1);
@@ -155,7 +162,10 @@ __global__ __launch_bounds__(WAVE) void fe_scatter_kernel(FeDev F, SolveParams o
 #pragma unroll
   for (int i = 0; i < FE_B / WAVE; i += 2) *reinterpret_cast<double2*>(acc + (i * WAVE + 2 * lane)) = make_double2(0.0, 0.0);
   // full trips without a guard in sight (a load under a branch is waited for inside the branch); the last, partial trip
-  // reads clamped addresses and sends what is beyond the end to a spare accumulator
+  // reads clamped addresses and sends what is beyond the end to a spare accumulator.
+  // (Round 5, measured and removed: the entry stream two trips ahead of the gathers — prefetch issued BEHIND the gathers so that
+  // the in-order return of loads does not make the gathers wait for it, two register sets, clean ISA: row pass 0.232 -> 0.262 ms,
+  // column pass 0.247 -> 0.255. More bytes in flight per wavefront make this stream slower, not faster: docs/rounds/r05.md.)
   int base = k0;
   for (; base + WAVE * FE_U <= k1; base += WAVE * FE_U) {
     int kq[FE_U], lq[FE_U];
@@ -190,6 +200,7 @@ __global__ __launch_bounds__(WAVE) void fe_scatter_kernel(FeDev F, SolveParams o
     int kq[FE_U], lq[FE_U];
     float vq[FE_U];
     double xq[FE_U];
+    unsigned live = 0u;
 #pragma unroll
     for (int q = 0; q < FE_U; ++q) {
       const int k = base + q * WAVE + lane;
@@ -205,14 +216,16 @@ __global__ __launch_bounds__(WAVE) void fe_scatter_kernel(FeDev F, SolveParams o
         vq[q] = val[kc];
         l = (int)loc[kc];
       }
-      lq[q] = k < k1 ? l : FE_B;
+      lq[q] = k < k1 ? l : 0;
+      live |= (k < k1 ? 1u : 0u) << q;
     }
 #pragma unroll
     for (int q = 0; q < FE_U; ++q) xq[q] = vec[kq[q]];
 #pragma unroll
     for (int q = 0; q < FE_U; ++q) {
       const double v = (double)vq[q];
-      lds_add(acc, lq[q], (HESS && !ROWS) ? v * v * xq[q] : v * xq[q]);
+      const double term = (HESS && !ROWS) ? v * v * xq[q] : v * xq[q];
+      lds_add(acc, lq[q], ((live >> q) & 1u) ? term : 0.0);
     }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the adds have landed
@@ -267,6 +280,7 @@ constexpr int FE_FIX_PER_BLOCK = FE_B / FE_RED_OUT;   // workgroups of fe_rows_f
 template <bool HESS = false>
 __global__ __launch_bounds__(FE_THREADS) void fe_rows_fix_kernel(FeDev F, SolveParams o) {
   __shared__ double lds[FE_STRANDS][FE_RED_OUT];
+  if (!HESS && F.state->status >= 0) return;
   const int tid = threadIdx.x, out = tid % FE_RED_OUT, strand = tid / FE_RED_OUT;
   const int b = F.multi[blockIdx.x / FE_FIX_PER_BLOCK];
   const int i = (blockIdx.x % FE_FIX_PER_BLOCK) * FE_RED_OUT + out;
@@ -287,9 +301,11 @@ __global__ __launch_bounds__(FE_THREADS) void fe_rows_fix_kernel(FeDev F, SolveP
 
 // local gradient (the column blocks' partial sums) into the global coefficient space; the first FE_FIN_BLOCKS workgroups also add
 // up a contiguous range of the per-unit value / residual sums each
+template <bool HESS = false>
 __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
   __shared__ double lds[FE_STRANDS][FE_RED_OUT];
   __shared__ double red[2][FE_WAVES];
+  if (!HESS && F.state->status >= 0) return;
   const int tid = threadIdx.x, out = tid % FE_RED_OUT, strand = tid / FE_RED_OUT;
   const int j0 = blockIdx.x * FE_RED_OUT;
   if (j0 < F.d) {   // workgroup-uniform
@@ -340,10 +356,12 @@ __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
 // ---- frequent columns: FE_HOT_REP accumulators each (FeHot above) -------------------------------------------------------------
 // after fe_finish_kernel (which left 0 for a frequent column: the copy holds no entry under its own number). One workgroup per
 // frequent column: replica r's sum over the virtual block's units by 8 strands, strands in order, then the replicas in order.
+template <bool HESS = false>
 __global__ __launch_bounds__(FE_THREADS) void fe_hot_finish_kernel(FeDev F) {
   constexpr int STR = FE_THREADS / FE_HOT_REP;
   __shared__ double lds[STR][FE_HOT_REP];
   __shared__ double rep[FE_HOT_REP];
+  if (!HESS && F.state->status >= 0) return;
   const FeHot& H = F.hot;
   const int h = blockIdx.x, tid = threadIdx.x, r = tid % FE_HOT_REP, strand = tid / FE_HOT_REP;
   const int b = H.vbase / FE_B, i = h * FE_HOT_REP + r;
@@ -392,15 +410,17 @@ __global__ void fe_hot_remap_kernel(const int32_t* __restrict__ ptr, int n, cons
   }
 }
 
-// g = reduced data gradient + regulariser, and every product the driver needs (re_lbfgs_compact.hpp acc[] layout)
-__global__ __launch_bounds__(FE_THREADS) void fe_dots_kernel(FeDev F, SolveParams o) {
-  __shared__ double red[FE_WAVES][TEAM_K];
+// g = reduced data gradient + regulariser, and every product the driver needs (re_lbfgs_compact.hpp acc[] layout): the share of
+// "virtual block" vb of nvb — coefficients (vb * 256 + tid) + k * nvb * 256 — into acc_part[vb]. The partition is a function of P
+// alone (nvb = min(ceil(P / 256), FE_DOT_BLOCKS)), not of the launch: fe_dots_kernel runs one workgroup per virtual block,
+// fe_tail_kernel deals them over fewer resident workgroups, and both give the same bits.
+__device__ __forceinline__ void fe_dots_block(const FeDev& F, const SolveParams& o, int vb, int nvb, double (*red)[TEAM_K]) {
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
   const int col = F.state->col, head = F.state->head, m = o.m, P = F.P;
   double acc[TEAM_K];
 #pragma unroll
   for (int k = 0; k < TEAM_K; ++k) acc[k] = 0.0;
-  for (int j = blockIdx.x * blockDim.x + tid; j < P; j += gridDim.x * blockDim.x) {
+  for (int j = vb * FE_THREADS + tid; j < P; j += nvb * FE_THREADS) {
     const bool reg = (j < F.D) || o.regularize_bias;   // the intercept is coefficient D
     const double xj = F.W.x[j];
     const double gj = F.fg[j] + (reg ? o.l2 * xj : 0.0);
@@ -441,18 +461,22 @@ __global__ __launch_bounds__(FE_THREADS) void fe_dots_kernel(FeDev F, SolveParam
     double s = red[0][tid];
 #pragma unroll
     for (int w = 1; w < FE_WAVES; ++w) s = (tid == TEAM_K - 1) ? fmax(s, red[w][tid]) : s + red[w][tid];
-    F.acc_part[(size_t)blockIdx.x * TEAM_K + tid] = s;
+    F.acc_part[(size_t)vb * TEAM_K + tid] = s;
   }
 }
 
-// one workgroup: totals of the products, then the driver's decision
-__global__ __launch_bounds__(FE_THREADS) void fe_step_kernel(FeDev F, SolveParams o, int dot_blocks, int32_t* status_out) {
-  __shared__ double tot[TEAM_K];
-  __shared__ CompactMats mats;
+__global__ __launch_bounds__(FE_THREADS) void fe_dots_kernel(FeDev F, SolveParams o) {
+  __shared__ double red[FE_WAVES][TEAM_K];
+  if (F.state->status >= 0) return;     // a step enqueued behind the stop (gdmix_fe_step_async) is a no-op
+  fe_dots_block(F, o, blockIdx.x, gridDim.x, red);
+}
+
+// one workgroup: totals of the products (the virtual blocks' shares, in a fixed order), then the driver's decision
+__device__ __forceinline__ void fe_step_body(const FeDev& F, const SolveParams& o, int dot_blocks, int32_t* status_out, double* tot /* LDS [TEAM_K] */,
+                                             CompactMats& mats /* LDS */, double (*part8)[32] /* LDS [8][32] */) {
   const int tid = threadIdx.x;
   {
     // value v of block b by thread (b % 8) * 32 + v, eight partial totals per value, combined in order
-    __shared__ double part8[8][32];
     const int v = tid & 31, g = tid >> 5;
     if (v < TEAM_K) {
       double s = 0.0;
@@ -505,13 +529,87 @@ __global__ __launch_bounds__(FE_THREADS) void fe_step_kernel(FeDev F, SolveParam
   }
 }
 
+__global__ __launch_bounds__(FE_THREADS) void fe_step_kernel(FeDev F, SolveParams o, int dot_blocks, int32_t* status_out) {
+  __shared__ double tot[TEAM_K];
+  __shared__ CompactMats mats;
+  __shared__ double part8[8][32];
+  if (F.state->status >= 0) return;     // (status_out keeps the status of the stop; fe_update_kernel repeats the stop's plan: idempotent)
+  fe_step_body(F, o, dot_blocks, status_out, tot, mats, part8);
+}
+
+// the elementwise part of a step for coefficient j; the shard's copy of x in local order follows it (the row pass gathers from xl)
+__device__ __forceinline__ void fe_update_one(const FeDev& F, const CompactPlan& plan, const CompactMats& mats, int m, int j) {
+  if (plan.action == CA_STOP_RESTORE) F.W.x[j] = F.W.t[j];
+  else compact_update(plan, mats, F.W, F.P, m, j);
+  const int jl = F.inv[j];
+  if (jl >= 0) F.xl[jl] = F.W.x[j];
+}
+
+// ---- the whole step in ONE launch (round 5) ----------------------------------------------------------------------------------------
+// dots -> decision -> update were three launches (9.4 + 8.4 + 5.9 us and two boundaries) plus fe_prepare_kernel ahead of the next
+// evaluation. Here: at most one workgroup per CU (all resident: the wait below cannot starve anyone), each takes its virtual blocks'
+// share of the products; the workgroup that arrives last adds the shares up in the fixed order and takes the driver's decision;
+// the others wait for its generation stamp, then every workgroup updates the coefficients of its own virtual blocks — the ones
+// whose gradient it wrote itself, so the only data crossing workgroups are the shares (to the last arriver) and state / plan / the
+// m x m matrices (back). Hand-off per MI355X_MICROARCH.md: plain stores, one lane's agent-scope release + drained store queue,
+// relaxed agent atomics for ticket and stamp, one lane's agent-scope acquire, workgroup barrier, plain loads.
+// A stopped problem (status >= 0 from an earlier launch) makes this and every pass kernel return at once: the host may enqueue
+// evaluations ahead of the status it has read (gdmix_fe_step_async).
+struct FeSync { unsigned arrive, gen; };
+
+__global__ __launch_bounds__(FE_THREADS) void fe_tail_kernel(FeDev F, SolveParams o, int dot_blocks, int32_t* status_out, unsigned seq) {
+  __shared__ double red[FE_WAVES][TEAM_K];
+  __shared__ double tot[TEAM_K];
+  __shared__ CompactMats mats;
+  __shared__ double part8[8][32];
+  __shared__ CompactPlan plan_s;
+  __shared__ int last;
+  if (F.state->status >= 0) return;     // written by an earlier launch: uniform over the grid
+  const int tid = threadIdx.x;
+  for (int vb = blockIdx.x; vb < dot_blocks; vb += gridDim.x) {
+    fe_dots_block(F, o, vb, dot_blocks, red);
+    __syncthreads();                     // red is reused
+  }
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = __hip_atomic_fetch_add(&F.sync->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (last) {
+    fe_step_body(F, o, dot_blocks, status_out, tot, mats, part8);
+    __syncthreads();
+    if (tid == 0) {
+      plan_s = *F.plan;   // (this thread wrote it)
+      __hip_atomic_store(&F.sync->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&F.sync->gen, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  } else {
+    if (tid == 0) {
+      while (__hip_atomic_load(&F.sync->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (tid == 0) plan_s = *F.plan;
+    const double* src = reinterpret_cast<const double*>(F.mats);
+    double* dst = reinterpret_cast<double*>(&mats);
+    for (int k = tid; k < (int)(sizeof(CompactMats) / sizeof(double)); k += FE_THREADS) dst[k] = src[k];
+    __syncthreads();
+  }
+  const CompactPlan plan = plan_s;
+  if (plan.action == CA_STOP) return;
+  for (int vb = blockIdx.x; vb < dot_blocks; vb += gridDim.x)
+    for (int j = vb * FE_THREADS + tid; j < F.P; j += dot_blocks * FE_THREADS) fe_update_one(F, plan, mats, o.m, j);
+}
+
 __global__ void fe_update_kernel(FeDev F, int m) {
   const CompactPlan plan = *F.plan;
   if (plan.action == CA_STOP) return;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < F.P; j += gridDim.x * blockDim.x) {
-    if (plan.action == CA_STOP_RESTORE) F.W.x[j] = F.W.t[j];
-    else compact_update(plan, *F.mats, F.W, F.P, m, j);
-  }
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < F.P; j += gridDim.x * blockDim.x) fe_update_one(F, plan, *F.mats, m, j);
 }
 
 __global__ void fe_init_kernel(FeDev F, const double* __restrict__ theta0) {
@@ -521,6 +619,12 @@ __global__ void fe_init_kernel(FeDev F, const double* __restrict__ theta0) {
     F.W.r[j] = 0.0;
     F.W.g[j] = 0.0;
     F.W.t[j] = 0.0;
+  }
+  // the shard's local copy of the start point (afterwards the update keeps it current: fe_update_one)
+  for (int jl = blockIdx.x * blockDim.x + threadIdx.x; jl < F.d; jl += gridDim.x * blockDim.x) {
+    const int64_t j = F.umap[jl];
+    F.xl[jl] = theta0 ? theta0[j] : 0.0;
+    F.inv[j] = jl;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     CompactState S;
@@ -678,8 +782,15 @@ struct gdmix_fe_problem {
   hipEvent_t ev[3];
   bool timed;
   bool dirty;            // the reduce buffer holds a result no step has consumed (and cleared) yet
+  bool fused_tail;       // the step is one launch (fe_tail_kernel); GDMIX_FE_FUSED_TAIL=0: dots / step / update as three (A/B)
+  unsigned gen;          // launches of fe_tail_kernel so far (its generation stamp)
+  int64_t evals;         // gdmix_fe_eval calls so far
+  int64_t seq;           // steps enqueued so far; step k's status lands in status_ring[k % FE_RING] behind ring_ev[k % FE_RING]
+  int32_t* status_ring;  // page-locked
+  hipEvent_t ring_ev[8];
   std::vector<int32_t> uf_c;
 };
+constexpr int FE_RING = 8;
 
 #define HIP_TRY(expr)                                                                   \
   do {                                                                                  \
@@ -845,6 +956,8 @@ static int fe_build_copy(hipStream_t s, int num_cus, const int32_t* ptr, int nse
 
 static void fe_free(gdmix_fe_problem* p) {
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : p->ring_ev) if (e) (void)hipEventDestroy(e);
+  if (p->status_ring) (void)hipHostFree(p->status_ring);
   if (p->pool) (void)hipFree(p->pool);
   for (auto& c : p->copies) if (c) (void)hipFree(c);
   if (p->hot_mem) (void)hipFree(p->hot_mem);
@@ -916,7 +1029,9 @@ static int fe_passes(gdmix_fe_problem* p, const FeDev& F, hipStream_t s, bool ti
   int gd = (F.d + 255) / 256;
   if (gd > 2048) gd = 2048;
   if (gd < 1) gd = 1;
-  hipLaunchKernelGGL(fe_prepare_kernel, dim3(gd), dim3(256), 0, s, F);
+  // xl (x in the shard's local order) is kept current by the step's update (fe_update_one); the Hessian passes may run at
+  // another point: they gather it themselves and put the solver's back afterwards
+  if (HESS) hipLaunchKernelGGL(fe_prepare_kernel, dim3(gd), dim3(256), 0, s, F);
   if (timed) HIP_TRY(hipEventRecord(p->ev[0], s));
   if (F.rc.ent) hipLaunchKernelGGL((fe_scatter_kernel<true, HESS, true>), dim3(F.rc.nlaunch), dim3(WAVE), 0, s, F, p->o);
   else hipLaunchKernelGGL((fe_scatter_kernel<true, HESS, false>), dim3(F.rc.nlaunch), dim3(WAVE), 0, s, F, p->o);
@@ -926,8 +1041,9 @@ static int fe_passes(gdmix_fe_problem* p, const FeDev& F, hipStream_t s, bool ti
   else hipLaunchKernelGGL((fe_scatter_kernel<false, HESS, false>), dim3(F.cc.nlaunch), dim3(WAVE), 0, s, F, p->o);
   if (timed) HIP_TRY(hipEventRecord(p->ev[2], s));
   int gf = (F.d + FE_RED_OUT - 1) / FE_RED_OUT;
-  hipLaunchKernelGGL(fe_finish_kernel, dim3(gf < FE_FIN_BLOCKS ? FE_FIN_BLOCKS : gf), dim3(FE_THREADS), 0, s, F);
-  if (F.hot.n > 0) hipLaunchKernelGGL(fe_hot_finish_kernel, dim3(F.hot.n), dim3(FE_THREADS), 0, s, F);
+  hipLaunchKernelGGL(fe_finish_kernel<HESS>, dim3(gf < FE_FIN_BLOCKS ? FE_FIN_BLOCKS : gf), dim3(FE_THREADS), 0, s, F);
+  if (F.hot.n > 0) hipLaunchKernelGGL(fe_hot_finish_kernel<HESS>, dim3(F.hot.n), dim3(FE_THREADS), 0, s, F);
+  if (HESS) hipLaunchKernelGGL(fe_prepare_kernel, dim3(gd), dim3(256), 0, s, p->F);
   HIP_TRY(hipGetLastError());
   return GDMIX_RE_OK;
 }
@@ -956,6 +1072,15 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   p->timed = false;
   p->dirty = false;      // the pool is zeroed at creation
   for (auto& e : p->ev) e = nullptr;
+  for (auto& e : p->ring_ev) e = nullptr;
+  p->status_ring = nullptr;
+  p->gen = 0u;
+  p->seq = 0;
+  p->evals = 0;
+  {
+    const char* e = getenv("GDMIX_FE_FUSED_TAIL");
+    p->fused_tail = !(e && e[0] == '0');
+  }
   FeDev& F = p->F;
   const int ic = opts->has_intercept ? 1 : 0;
   F.n = (int)b->N; F.z = b->Z; F.d = (int)b->D; F.ic = ic; F.D = num_features; F.P = (int)num_features + ic; F.m = opts->m;
@@ -983,10 +1108,14 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   const size_t o_acc = take((size_t)FE_DOT_BLOCKS * TEAM_K * 8), o_fin = take((size_t)FE_FIN_BLOCKS * 2 * 8 + 64);
   const size_t o_state = take(sizeof(CompactState)), o_plan = take(sizeof(CompactPlan)), o_mats = take(sizeof(CompactMats));
   const size_t o_vec = take(((size_t)5 * P + compact_hist_doubles((int64_t)P, opts->m)) * 8 + 16), o_status = take(64);
+  const size_t o_inv = take(P * 4), o_sync = take(sizeof(FeSync));
   hipError_t rc = hipMalloc(&p->pool, off);
   if (rc != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(rc)); fe_free(p); return GDMIX_RE_ENOMEM; }
   char* base = static_cast<char*>(p->pool);
   rc = hipMemsetAsync(base, 0, off, s);
+  if (rc == hipSuccess) rc = hipMemsetAsync(base + o_inv, 0xff, P * 4, s);   // -1: the coefficient is not a column of this shard
+  if (rc == hipSuccess) rc = hipHostMalloc(reinterpret_cast<void**>(&p->status_ring), FE_RING * sizeof(int32_t), hipHostMallocDefault);
+  for (auto& e : p->ring_ev) if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
   if (rc == hipSuccess && !multi.empty()) {
     rc = hipMemcpyAsync(base + o_multi, multi.data(), multi.size() * 4, hipMemcpyHostToDevice, s);
     if (rc == hipSuccess) rc = hipStreamSynchronize(s);   // `multi` goes out of scope
@@ -1009,6 +1138,8 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   F.W.wy = F.W.ws + (size_t)opts->m * P;
   F.W.rs = F.rs; F.W.alpha = nullptr; F.W.rho = nullptr; F.W.part = nullptr;
   p->status_dev = reinterpret_cast<int32_t*>(base + o_status);
+  F.inv = reinterpret_cast<int32_t*>(base + o_inv);
+  F.sync = reinterpret_cast<FeSync*>(base + o_sync);
   int gp = (int)((P + 255) / 256);
   if (gp > 1024) gp = 1024;
   hipLaunchKernelGGL(fe_init_kernel, dim3(gp), dim3(256), 0, s, F, theta0);
@@ -1031,8 +1162,11 @@ GDMIX_API double* gdmix_fe_reduce_buffer(gdmix_fe_problem* p, int64_t* count) {
 GDMIX_API int gdmix_fe_eval(gdmix_fe_problem* p, void* stream) {
   if (!p) { set_error("problem is NULL"); return GDMIX_RE_EINVAL; }
   if (!p->ev[0]) for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
-  const int rc = fe_passes<false>(p, p->F, static_cast<hipStream_t>(stream), true);
-  if (rc == GDMIX_RE_OK) p->timed = true;
+  // the first two evaluations of a problem are timed (gdmix_fe_last_eval_ms reports the second): with the status read a few steps
+  // late the LAST evaluations of a solve are no-ops
+  const bool timed = p->evals < 2;
+  const int rc = fe_passes<false>(p, p->F, static_cast<hipStream_t>(stream), timed);
+  if (rc == GDMIX_RE_OK) { if (timed) p->timed = true; ++p->evals; }
   return rc;
 }
 
@@ -1040,6 +1174,7 @@ GDMIX_API int gdmix_fe_hessian_diag(gdmix_fe_problem* p, const double* theta, vo
   if (!p) { set_error("problem is NULL"); return GDMIX_RE_EINVAL; }
   FeDev F = p->F;
   if (theta) F.W.x = const_cast<double*>(theta);   // the passes only read x
+  p->dirty = true;   // (a step enqueued behind the stop leaves the buffer as it was)
   return fe_passes<true>(p, F, static_cast<hipStream_t>(stream), false);
 }
 
@@ -1073,22 +1208,81 @@ GDMIX_API int gdmix_fe_variance_of_hessian(gdmix_re_ctx* ctx, double* H, int64_t
   return GDMIX_RE_OK;
 }
 
-GDMIX_API int gdmix_fe_step(gdmix_fe_problem* p, void* stream, int32_t* status) {
-  if (!p || !status) { set_error("NULL argument"); return GDMIX_RE_EINVAL; }
-  hipStream_t s = static_cast<hipStream_t>(stream);
+static int fe_enqueue_step(gdmix_fe_problem* p, hipStream_t s) {
   const FeDev& F = p->F;
   int gp = (F.P + 255) / 256;
-  int dot_blocks = gp < FE_DOT_BLOCKS ? gp : FE_DOT_BLOCKS;
-  hipLaunchKernelGGL(fe_dots_kernel, dim3(dot_blocks), dim3(FE_THREADS), 0, s, F, p->o);
+  const int dot_blocks = gp < FE_DOT_BLOCKS ? gp : FE_DOT_BLOCKS;
+  if (p->fused_tail) {
+    int g = p->ctx->impl.num_cus;          // at most one workgroup per CU: all resident, the wait inside cannot starve one
+    if (g > dot_blocks) g = dot_blocks;
+    if (g < 1) g = 1;
+    ++p->gen;
+    if (p->gen == 0u) ++p->gen;
+    hipLaunchKernelGGL(fe_tail_kernel, dim3(g), dim3(FE_THREADS), 0, s, F, p->o, dot_blocks, p->status_dev, p->gen);
+  } else {
+    hipLaunchKernelGGL(fe_dots_kernel, dim3(dot_blocks), dim3(FE_THREADS), 0, s, F, p->o);
+    hipLaunchKernelGGL(fe_step_kernel, dim3(1), dim3(FE_THREADS), 0, s, F, p->o, dot_blocks, p->status_dev);
+    if (gp > 1024) gp = 1024;
+    hipLaunchKernelGGL(fe_update_kernel, dim3(gp), dim3(256), 0, s, F, p->o.m);
+  }
   p->dirty = false;
-  hipLaunchKernelGGL(fe_step_kernel, dim3(1), dim3(FE_THREADS), 0, s, F, p->o, dot_blocks, p->status_dev);
-  if (gp > 1024) gp = 1024;
-  hipLaunchKernelGGL(fe_update_kernel, dim3(gp), dim3(256), 0, s, F, p->o.m);
   HIP_TRY(hipGetLastError());
-  int32_t* hp = p->ctx->impl.host_pinned + 960;
-  HIP_TRY(hipMemcpyAsync(hp, p->status_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  *status = *hp;
+  const int slot = (int)(p->seq % FE_RING);
+  HIP_TRY(hipMemcpyAsync(p->status_ring + slot, p->status_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipEventRecord(p->ring_ev[slot], s));
+  ++p->seq;
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_fe_step(gdmix_fe_problem* p, void* stream, int32_t* status) {
+  if (!p || !status) { set_error("NULL argument"); return GDMIX_RE_EINVAL; }
+  const int rc = fe_enqueue_step(p, static_cast<hipStream_t>(stream));
+  if (rc != GDMIX_RE_OK) return rc;
+  return gdmix_fe_step_status(p, p->seq - 1, status);
+}
+
+GDMIX_API int gdmix_fe_step_async(gdmix_fe_problem* p, void* stream, int64_t* seq) {
+  if (!p) { set_error("problem is NULL"); return GDMIX_RE_EINVAL; }
+  const int rc = fe_enqueue_step(p, static_cast<hipStream_t>(stream));
+  if (rc == GDMIX_RE_OK && seq) *seq = p->seq - 1;
+  return rc;
+}
+
+GDMIX_API int gdmix_fe_step_status(gdmix_fe_problem* p, int64_t seq, int32_t* status) {
+  if (!p || !status) { set_error("NULL argument"); return GDMIX_RE_EINVAL; }
+  if (seq < 0 || seq >= p->seq || seq + FE_RING <= p->seq) {
+    set_error("step %lld: only the last %d of the %lld enqueued steps can be asked for", (long long)seq, FE_RING, (long long)p->seq);
+    return GDMIX_RE_EINVAL;
+  }
+  const int slot = (int)(seq % FE_RING);
+  HIP_TRY(hipEventSynchronize(p->ring_ev[slot]));
+  *status = p->status_ring[slot];
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_fe_solve(gdmix_fe_problem* p, void* stream, int32_t lookahead, int64_t max_evals, int32_t* status, int64_t* evals) {
+  if (!p || !status) { set_error("NULL argument"); return GDMIX_RE_EINVAL; }
+  if (lookahead < 0 || lookahead >= FE_RING) { set_error("0 <= lookahead < %d", FE_RING); return GDMIX_RE_EINVAL; }
+  int32_t st = -1;
+  int64_t k = 0;
+  for (; k < max_evals + lookahead; ++k) {
+    int rc = gdmix_fe_eval(p, stream);
+    if (rc == GDMIX_RE_OK) rc = fe_enqueue_step(p, static_cast<hipStream_t>(stream));
+    if (rc != GDMIX_RE_OK) return rc;
+    if (k >= lookahead) {
+      rc = gdmix_fe_step_status(p, p->seq - 1 - lookahead, &st);
+      if (rc != GDMIX_RE_OK) return rc;
+      if (st >= 0) break;
+    }
+  }
+  // the steps behind the one that stopped were no-ops and report the same status; wait for them so that nothing of this solve is
+  // still in flight when the caller reads the result
+  if (st >= 0) {
+    const int rc = gdmix_fe_step_status(p, p->seq - 1, &st);
+    if (rc != GDMIX_RE_OK) return rc;
+  }
+  *status = st;
+  if (evals) *evals = k + 1;
   return GDMIX_RE_OK;
 }
 

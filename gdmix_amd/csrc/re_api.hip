@@ -191,12 +191,17 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   c->impl.team_nnz = 16384;
   c->impl.tall_min_n = GDMIX_RE_TALL_MIN_N_DEFAULT;
   c->impl.tall_split_n = GDMIX_RE_TALL_SPLIT_N_DEFAULT;
+  c->impl.tall_split_set = 0;
   c->impl.tall_team_n = GDMIX_RE_TALL_TEAM_N_DEFAULT;
   // How many entities the class may take: a quarter of the CUs' worth (one round of teams). Measured twice, because the answer depends on
   // the class behind it (tools/r04_tallteam2.sh, slowest per-movie share of eight): while the eight-wavefront class was capped at 3/4 of the
   // CUs, 64 teams held every CU for the length of their entity and the one-wavefront class waited (2.9 ms; 32: 2.25, 16: 2.29); since that
   // class may take 1.5 workgroups per CU and absorbs what the teams leave, 16 / 32 / 48 / 64: 2.38 / 1.98 / 1.98 / 1.85 - 1.90 ms.
   c->impl.tall_team_limit = c->impl.num_cus / 4 < TALL_TEAM_MAX ? c->impl.num_cus / 4 : TALL_TEAM_MAX;
+  // a team needs its TALL_TEAM_C workgroups resident at once, each with a whole CU's LDS, and a launch has eight teams at least
+  // (one per XCD): a device (partition) with fewer CUs than that gets no team class at all — its members could never all be
+  // placed and every run would end in the barrier's watchdog
+  if (c->impl.num_cus < 8 * TALL_TEAM_C) c->impl.tall_team_n = 0;
   if (const char* e = getenv("GDMIX_RE_TALL_TEAM")) { if (atoi(e) == 0) c->impl.tall_team_n = 0; }   // A/B switch
   if (const char* e = getenv("GDMIX_RE_TALL_TEAM_LIMIT")) { if (atoi(e) > 0 && atoi(e) <= TALL_TEAM_MAX) c->impl.tall_team_limit = atoi(e); }   // exploration knob
   c->impl.spread = spread_default();
@@ -352,13 +357,14 @@ GDMIX_API int gdmix_re_set_spread(gdmix_re_ctx* ctx, int queues) {
 
 GDMIX_API int gdmix_re_set_tall_team_n(gdmix_re_ctx* ctx, int team_n) {
   if (!ctx) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
-  ctx->impl.tall_team_n = team_n;
+  ctx->impl.tall_team_n = ctx->impl.num_cus < 8 * TALL_TEAM_C ? 0 : team_n;   // (a device too small for a round of teams never gets the class)
   return GDMIX_RE_OK;
 }
 
 GDMIX_API int gdmix_re_set_tall_split_n(gdmix_re_ctx* ctx, int split_n) {
-  if (!ctx || split_n < 1) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
-  ctx->impl.tall_split_n = split_n;
+  if (!ctx || split_n < 0) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
+  ctx->impl.tall_split_n = split_n > 0 ? split_n : GDMIX_RE_TALL_SPLIT_N_DEFAULT;
+  ctx->impl.tall_split_set = split_n > 0 ? 1 : 0;     // 0: back to the default with its per-batch adaptation
   return GDMIX_RE_OK;
 }
 
@@ -459,7 +465,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   tab.team_nnz = opts->m <= TEAM_MCAP ? ctx->impl.team_nnz : 0;
   tab.tall_min_n = ctx->impl.tall_min_n;
   tab.tall_split_n = ctx->impl.tall_split_n;
-  tab.tall_adapt_limit = (ctx->impl.tall_split_n == GDMIX_RE_TALL_SPLIT_N_DEFAULT) ? ctx->impl.tall_adapt_limit : 0;   // an explicit split is kept
+  tab.tall_adapt_limit = ctx->impl.tall_split_set ? 0 : ctx->impl.tall_adapt_limit;   // an explicit split is kept, whatever its value
   {   // > 0: adaptive from team_n on; < 0: everything from -team_n on (tests); never below TALL_TEAM_MIN_N samples
     const int tn = ctx->impl.tall_team_n;
     tab.tall_team_n = tn > 0 ? tn : -tn;

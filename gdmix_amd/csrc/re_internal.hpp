@@ -142,6 +142,7 @@ struct gdmix_ctx_impl {
   int tall_min_n;         // tall kernel for p <= 64 and n >= this (0 = never)
   int tall_split_n;       // tall entities with n >= this: one large workgroup per CU
   int tall_adapt_limit;   // ClassTable::tall_adapt_limit of this device (1.5 x its CUs; GDMIX_RE_TALL_ADAPT overrides, 0 = off)
+  int tall_split_set;     // gdmix_re_set_tall_split_n was called: the caller's split is kept, no per-batch adaptation (also when it is the default value)
   int tall_team_n;        // ClassTable::tall_team_n (gdmix_re_set_tall_team_n; GDMIX_RE_TALL_TEAM=0 switches the class off)
   int tall_team_limit;    // ClassTable::tall_team_limit: one round of teams on this device
   int spread;             // > 1: large classes are dealt over this many queues (the caller's stream + side streams); 0: one after another

@@ -23,6 +23,7 @@ Two device paths, same arithmetic rules:
                     its shard and runs the replicated step on the reduced buffer, like the reference's workers run scipy.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -156,6 +157,9 @@ def device_score(solver, row_nnz_ptr, col_global, val, offset, theta, num_featur
     return score.cpu().numpy(), per.cpu().numpy()
 
 
+LOOKAHEAD = int(os.environ.get("GDMIX_FE_LOOKAHEAD", "2"))   # evaluations enqueued ahead of the status the host has read
+
+
 class _SteppingProblem:
     """gdmix_fe_problem handle; the packed shard and theta0 are kept alive with it."""
 
@@ -191,6 +195,24 @@ class _SteppingProblem:
         st = C.c_int32(-1)
         self._check(self.lib.gdmix_fe_step(self._h, self.solver._stream(), C.byref(st)), "gdmix_fe_step")
         return int(st.value)
+
+    def step_async(self):
+        """Enqueue the step; returns its number (gdmix_fe_step_async)."""
+        seq = C.c_int64(-1)
+        self._check(self.lib.gdmix_fe_step_async(self._h, self.solver._stream(), C.byref(seq)), "gdmix_fe_step_async")
+        return int(seq.value)
+
+    def step_status(self, seq):
+        st = C.c_int32(-1)
+        self._check(self.lib.gdmix_fe_step_status(self._h, int(seq), C.byref(st)), "gdmix_fe_step_status")
+        return int(st.value)
+
+    def solve(self, lookahead=LOOKAHEAD, max_evals=100000):
+        """The whole single-worker loop inside the library (gdmix_fe_solve): the status is read `lookahead` steps late."""
+        st, n = C.c_int32(-1), C.c_int64(0)
+        self._check(self.lib.gdmix_fe_solve(self._h, self.solver._stream(), int(lookahead), int(max_evals), C.byref(st), C.byref(n)),
+                    "gdmix_fe_solve")
+        return int(st.value), int(n.value)
 
     def result(self):
         t = self.solver.torch
@@ -232,18 +254,28 @@ def _device_view(torch, ptr, count, device):
     return torch.as_tensor(h, device=device)
 
 
-def run_stepping_loop(problem, all_reduce=None, max_evals=100000):
-    """do { eval; all_reduce; } while (step() < 0)  — the loop gdmix_fe.h describes. all_reduce(tensor) sums in place
-    across workers (None: single worker)."""
-    buf = problem.reduce_tensor() if all_reduce is not None else None
-    status = -1
-    for _ in range(max_evals):
-        problem.eval()
-        if all_reduce is not None:
-            all_reduce(buf)
-        status = problem.step()
+def run_stepping_loop(problem, all_reduce=None, max_evals=100000, lookahead=None):
+    """do { eval; all_reduce; } while (step() < 0)  — the loop gdmix_fe.h describes, with the status read `lookahead` steps late
+    so that the device never waits for the host between evaluations (the kernels of a stopped problem return at once; every
+    worker takes the same decisions, so all of them enqueue the same number of all-reduces). all_reduce(tensor) sums in place
+    across workers (None: single worker, the loop runs inside the library). A collective that goes through the host (gloo) is
+    synchronous anyway: lookahead 0 unless all_reduce.device_ordered is set (RCCL on the device buffer)."""
+    if lookahead is None:
+        lookahead = LOOKAHEAD if (all_reduce is None or getattr(all_reduce, "device_ordered", False)) else 0
+    if all_reduce is None:
+        status, _ = problem.solve(lookahead, max_evals)
         if status >= 0:
             return status
+        raise RuntimeError(f"the fixed-effect L-BFGS loop did not stop within {max_evals} evaluations")
+    buf = problem.reduce_tensor()
+    for k in range(max_evals + lookahead):
+        problem.eval()
+        all_reduce(buf)
+        seq = problem.step_async()
+        if k >= lookahead:
+            status = problem.step_status(seq - lookahead)
+            if status >= 0:
+                return problem.step_status(seq)      # (the steps behind the stop are no-ops with the same status: nothing left in flight)
     raise RuntimeError(f"the fixed-effect L-BFGS loop did not stop within {max_evals} evaluations")
 
 
@@ -284,8 +316,10 @@ def _fit_stepping(self, row_nnz_ptr, col_global, val, y, num_features, offset=No
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            if dist.get_backend(group) == "nccl":          # RCCL, in place on the device buffer
-                all_reduce = lambda t: dist.all_reduce(t, group=group)
+            if dist.get_backend(group) == "nccl":          # RCCL, in place on the device buffer, ordered on the stream
+                def all_reduce(t):
+                    dist.all_reduce(t, group=group)
+                all_reduce.device_ordered = True
             else:                                          # e.g. gloo: staged through the host
                 def all_reduce(t):
                     h = t.cpu()

@@ -412,6 +412,10 @@ class RandomEffectLRLBFGSModel:
                     import torch
                     dev %= max(1, torch.cuda.device_count())
             self._solver = REDeviceSolver(dev)   # raises if no MI355X / no library: there is no CPU fallback
+            if getattr(self.model_params, "rebalance_entities", False) and hasattr(self._solver, "pin_routing"):
+                # an entity may be solved in another batch than the one its partition would have given it: its kernel must not
+                # depend on the batch, or the same entity would come out with other last bits (REDeviceSolver.pin_routing)
+                self._solver.pin_routing()
         return self._solver
 
     def _solver_options(self):
@@ -677,6 +681,21 @@ class RandomEffectLRLBFGSModel:
             theta0 = self._start_point(model_weights, batch.entity_ids, uniq, feat_ptr, batch.E, num_features)
             solved = solver.solve(packed, opts, theta0=theta0)
             res = solved.to_host(("theta_thr", "variance") + self._STAT_KEYS)
+            if (res["status"] == self.ST_ABORTED).any() and getattr(solver, "tall_team_n", 0) != 0:
+                # a team of workgroups gave up waiting for a member (a device too busy, or too small, to keep four whole CUs per
+                # team resident: csrc/re_solve_tall.hip). Not a reason to lose the job: the partition again with every tall
+                # entity on ONE workgroup (same arithmetic up to the order of its sums), once.
+                logger.warning(f"{int((res['status'] == self.ST_ABORTED).sum())} entities timed out at a team barrier: "
+                               "solving the partition again without the tall team class")
+                keep = solver.tall_team_n
+                solver.set_tall_team_n(0)
+                try:
+                    solved = packed = None
+                    packed = self._pack(solver, batch)
+                    solved = solver.solve(packed, opts, theta0=theta0)
+                    res = solved.to_host(("theta_thr", "variance") + self._STAT_KEYS)
+                finally:
+                    solver.set_tall_team_n(keep)
             theta_thr, variance = res["theta_thr"], res.get("variance")
             self._check_statuses(res["status"], batch.E)
             theta_dev = getattr(solved, "theta_thr", None)    # still in HBM: what the scoring pass of this partition reads
@@ -697,6 +716,8 @@ class RandomEffectLRLBFGSModel:
         if stage is not None:
             theta0 = stage[:int(feat_ptr[-1]) + E * ic]
         return theta0
+
+    ST_ABORTED = 9      # GDMIX_RE_ST_ABORTED (include/gdmix_re.h)
 
     @staticmethod
     def _check_statuses(status, E):

@@ -24,7 +24,12 @@ With a warm start the prior models of the travelling entities go with them (coef
 indices, coefficients); they start on the host (the model table) and are mapped to the solve's local order on the
 host of the solving rank, so this small side channel is staged through page-locked memory.
 
-Nothing here touches the arithmetic: results are bit-identical to the unbalanced run (tests/test_rebalance.py).
+Nothing here touches the arithmetic, but an entity is solved in ANOTHER BATCH than its partition alone would have formed, and
+two of the device's routing thresholds are chosen per batch by default (where the one-CU tall variant and the four-workgroup
+teams start; those variants add an entity's sums in different orders). A model with rebalance_entities therefore pins the
+routing to the entity's own size (REDeviceSolver.pin_routing: fixed split, a team for every entity of at least 8 192 samples):
+results are then bit-identical to an unbalanced run with the same pinned routing, whatever the plan moved
+(tests/test_rebalance.py), and equal to a default-routed run's to rounding (<= 1e-7, on the tall entities only).
 In the CPU tests the same code runs on CPU tensors over gloo.
 """
 import numpy as np

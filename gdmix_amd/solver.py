@@ -71,7 +71,7 @@ EXPORTED_SYMBOLS = (
     "gdmix_re_destroy", "gdmix_re_pack_workspace_bytes", "gdmix_re_pack", "gdmix_re_solve",
     "gdmix_re_solve_scratch_bytes", "gdmix_re_set_scratch", "gdmix_re_variance_full", "gdmix_re_set_wave_lds_limit", "gdmix_re_score",
     "gdmix_re_widen_workspace_bytes", "gdmix_re_widen", "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz", "gdmix_re_set_tall_min_n", "gdmix_re_set_tall_split_n", "gdmix_re_set_tall_team_n", "gdmix_re_set_spread",
-    "gdmix_fe_create", "gdmix_fe_destroy", "gdmix_fe_eval", "gdmix_fe_reduce_buffer", "gdmix_fe_step", "gdmix_fe_result",
+    "gdmix_fe_create", "gdmix_fe_destroy", "gdmix_fe_eval", "gdmix_fe_reduce_buffer", "gdmix_fe_step", "gdmix_fe_step_async", "gdmix_fe_step_status", "gdmix_fe_solve", "gdmix_fe_result",
     "gdmix_fe_last_eval_ms", "gdmix_fe_score", "gdmix_fe_hessian_diag", "gdmix_fe_hessian_dense_scratch_bytes", "gdmix_fe_hessian_dense",
     "gdmix_fe_variance_of_hessian",
     "gdmix_re_class_kernel_name", "gdmix_java_string_hash", "gdmix_java_partition_id",
@@ -125,6 +125,9 @@ def load_library():
     lib.gdmix_fe_reduce_buffer.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     lib.gdmix_fe_reduce_buffer.restype = C.c_void_p
     lib.gdmix_fe_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    lib.gdmix_fe_step_async.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.gdmix_fe_step_status.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]
+    lib.gdmix_fe_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     lib.gdmix_fe_hessian_diag.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gdmix_fe_result.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]
@@ -319,6 +322,7 @@ class REDeviceSolver:
                                "(there is no CPU fallback)")
         self.torch = torch
         self.lib = load_library()
+        self.tall_team_n = self.TALL_TEAM_N_DEFAULT     # (what gdmix_re_create sets; GDMIX_RE_TALL_TEAM=0 in the environment switches the class off)
         self.device_index = int(device)
         self.device = torch.device("cuda", self.device_index)
         torch.cuda.set_device(self.device)
@@ -367,12 +371,24 @@ class REDeviceSolver:
         _check(self.lib.gdmix_re_set_tall_split_n(self._h, int(split_n)), "set_tall_split_n")
 
     TALL_TEAM_N_DEFAULT = 8192
+    TALL_SPLIT_N_DEFAULT = 4096
+
+    def pin_routing(self):
+        """Make an entity's kernel a function of the entity alone. By default two thresholds are chosen per BATCH (where the
+        one-CU-per-entity tall variant starts: 4096 / 2048 / 1024 / 512 samples; where the four-workgroup teams start: team_n x
+        {1, 2, 4}), and those variants add an entity's sums in different orders — the same entity can come out with other last
+        bits in another batch. Pinned: the split at its default whatever the batch holds, a team for every entity of at least
+        TALL_TEAM_N_DEFAULT samples. For runs whose output must not depend on how entities are grouped into batches
+        (entity re-balancing, comparisons across partitionings); it costs the per-batch tuning of latency-bound shares."""
+        self.set_tall_split_n(self.TALL_SPLIT_N_DEFAULT)
+        self.set_tall_team_n(-self.TALL_TEAM_N_DEFAULT)
 
     def set_tall_team_n(self, team_n: int):
         """The tallest entities of a batch get a team of four workgroups (four CUs of one XCD share the pass over one entity's samples).
         team_n > 0: eight-wavefront tall entities from team_n, 2 team_n or 4 team_n samples on — the lowest that keeps the class
         within one round of teams on the device; team_n < 0: every one of at least -team_n samples (tests); 0: never."""
         _check(self.lib.gdmix_re_set_tall_team_n(self._h, int(team_n)), "set_tall_team_n")
+        self.tall_team_n = int(team_n)
 
     def set_spread(self, queues: int):
         """Large size classes are dealt over `queues` streams (the caller's + the context's side streams; default 4) so that their tails

@@ -79,6 +79,19 @@ GDMIX_API int gdmix_fe_variance_of_hessian(gdmix_re_ctx* ctx, double* H, int64_t
 /* Consumes the (all-reduced) buffer. *status: -1 = evaluate again, else GDMIX_RE_ST_*. Synchronises the stream. */
 GDMIX_API int gdmix_fe_step(gdmix_fe_problem* p, void* stream, int32_t* status);
 
+/* The same, stream-ordered (round 5): the step is enqueued, nothing is waited for; *seq (may be NULL) = the number of this step,
+ * counted from 0 over the life of the problem. gdmix_fe_step_status(p, seq, &status) waits for THAT step only and returns its
+ * status (the last 8 enqueued steps can be asked for). Once the driver has stopped, every later gdmix_fe_eval / step on the
+ * problem is a no-op on the device (the kernels return on the stop flag) and reports the status of the stop, so a host loop may
+ * run `lookahead` evaluations ahead of the status it has read and the device never idles between evaluations:
+ *     for k = 0, 1, ...: eval; all_reduce; step_async -> k; if (k >= lookahead and step_status(k - lookahead) >= 0) break;
+ * With several workers every worker takes the same decisions from the same reduced buffer, so all of them enqueue the same
+ * number of all-reduces. gdmix_fe_solve is that loop for ONE worker (no all-reduce), inside the library: *status = the status
+ * of the stop (-1: max_evals evaluations without one), *evals (may be NULL) = evaluations enqueued, no-ops included. */
+GDMIX_API int gdmix_fe_step_async(gdmix_fe_problem* p, void* stream, int64_t* seq);
+GDMIX_API int gdmix_fe_step_status(gdmix_fe_problem* p, int64_t seq, int32_t* status);
+GDMIX_API int gdmix_fe_solve(gdmix_fe_problem* p, void* stream, int32_t lookahead, int64_t max_evals, int32_t* status, int64_t* evals);
+
 /* Result after status >= 0: theta [D + has_intercept] (device pointer, may be NULL) and scalars (host, may be NULL). */
 GDMIX_API int gdmix_fe_result(gdmix_fe_problem* p, double* theta, double* fval, double* gnorm, int32_t* nit,
                               int32_t* nfev, void* stream);
@@ -93,7 +106,9 @@ GDMIX_API int gdmix_fe_score(gdmix_re_ctx* ctx, int64_t n, const int64_t* row_nn
                              const float* offset, const double* theta, int64_t num_features, int has_intercept, float* score,
                              float* per_coord, void* stream);
 
-/* Optional timing of the last gdmix_fe_eval (HIP events on the launch stream): ms of the row pass (X theta), the column pass (X'r). */
+/* Optional timing (HIP events on the launch stream): ms of the row pass (X theta) and the column pass (X'r) of the problem's SECOND
+ * gdmix_fe_eval (its first, if there was only one) — not the last: with the status read a few steps late the last evaluations of a
+ * solve are no-ops. */
 GDMIX_API int gdmix_fe_last_eval_ms(gdmix_fe_problem* p, float* rows_ms, float* cols_ms);
 
 #ifdef __cplusplus

@@ -260,7 +260,9 @@ GDMIX_API int gdmix_re_set_team_nnz(gdmix_re_ctx* ctx, int64_t team_nnz);
 GDMIX_API int gdmix_re_set_tall_min_n(gdmix_re_ctx* ctx, int min_n);
 /* Tall entities of at least `split_n` samples get a CU each (a workgroup of eight wavefronts); smaller ones share a CU,
  * eight single-wavefront workgroups at a time, so that one entity's L-BFGS driver (a latency-bound chain in one
- * wavefront) runs while the others' passes over their samples do. */
+ * wavefront) runs while the others' passes over their samples do. Until this is called the split is the default, lowered per
+ * batch to 2 048 / 1 024 / 512 when the eight-wavefront class stays small that way; a split set by the caller is kept as it is,
+ * also when it equals the default (the way to switch the per-batch choice off); split_n = 0 returns to the adaptive default. */
 #define GDMIX_RE_TALL_SPLIT_N_DEFAULT 4096
 GDMIX_API int gdmix_re_set_tall_split_n(gdmix_re_ctx* ctx, int split_n);
 /* The tallest entities of a batch get a TEAM of four workgroups (four CUs of one XCD) that share the pass over one entity's
@@ -268,9 +270,13 @@ GDMIX_API int gdmix_re_set_tall_split_n(gdmix_re_ctx* ctx, int split_n);
  * (ABI 9, GDMIX_RE_NUM_CLASSES 39). `team_n` > 0: eight-wavefront tall entities of at least team_n, 2 team_n or 4 team_n samples
  * - the lowest of the three that keeps the class within one round of teams on the device (a quarter of its CUs' worth of entities); a batch with
  * more entities than that above 4 team_n has no team class (it is bound by throughput, not by one entity's chain).
- * `team_n` < 0: every tall entity of at least -team_n samples (at least 64), no limit (tests). 0 = never. The split of an
- * entity's samples over the four workgroups depends on its size alone: results do not depend on the batch, and agree with the
- * one-workgroup kernel's to rounding (another summation order). */
+ * `team_n` < 0: every tall entity of at least -team_n samples (at least 64), no limit. 0 = never. The split of an entity's samples
+ * over the four workgroups depends on its size alone, and a team's result agrees with the one-workgroup kernel's to rounding
+ * (another summation order) — but WHICH of the two kernels an entity gets depends on the batch when team_n > 0 (and likewise
+ * for the per-batch split below gdmix_re_set_tall_split_n's default): the same entity can come out with other last bits in
+ * another batch. A caller that needs results independent of the batching (entity re-balancing, comparisons across partitionings)
+ * pins both: gdmix_re_set_tall_split_n(ctx, GDMIX_RE_TALL_SPLIT_N_DEFAULT) and gdmix_re_set_tall_team_n(ctx,
+ * -GDMIX_RE_TALL_TEAM_N_DEFAULT) (gdmix_amd/solver.py: pin_routing). A device with fewer than 32 CUs never gets the class. */
 #define GDMIX_RE_TALL_TEAM_N_DEFAULT 8192
 GDMIX_API int gdmix_re_set_tall_team_n(gdmix_re_ctx* ctx, int team_n);
 

@@ -64,13 +64,16 @@ def main():
     batch, _ = fe.shard_as_batch(rp, cols, vals, y, None, None, True)
     opts = SolverOptions(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=25, threshold=0.0, sum_loss=True)
     thetas = []
-    for reduce in (None, lambda t: dist.all_reduce(t)):
+    def ordered(t):      # RCCL on the device buffer is ordered on the stream: the loop may run ahead of the status it has read
+        dist.all_reduce(t)
+    ordered.device_ordered = True
+    for reduce, ahead in ((None, None), (lambda t: dist.all_reduce(t), 0), (ordered, None), (ordered, 3)):
         prob = fe._SteppingProblem(solver, solver.pack(batch, has_intercept=True), D, opts, None)
         assert prob.reduce_tensor().is_cuda
-        fe.run_stepping_loop(prob, reduce)
+        fe.run_stepping_loop(prob, reduce, lookahead=ahead)
         thetas.append(prob.result()[0])
         prob.close()
-    assert np.array_equal(thetas[0], thetas[1]) and np.abs(thetas[0]).max() > 0
+    assert all(np.array_equal(thetas[0], t) for t in thetas[1:]) and np.abs(thetas[0]).max() > 0
     dist.barrier()
     dist.destroy_process_group()
     print("nccl single-rank exchange ok")

@@ -84,7 +84,7 @@ def run_case(solver, seed, verbose=False):
         res = solver.solve(packed, SolverOptions(**kw), theta0=th0).to_host()
     finally:
         solver.set_giant_nnz(16777216); solver.set_team_nnz(16384); solver.set_kernel_mask(7); solver.set_tall_min_n(solver.TALL_MIN_N_DEFAULT)
-        solver.set_tall_team_n(solver.TALL_TEAM_N_DEFAULT); solver.set_tall_split_n(4096)
+        solver.set_tall_team_n(solver.TALL_TEAM_N_DEFAULT); solver.set_tall_split_n(0)
     o = oracle.make_opts(**kw)
     ref = oracle.solve(pk, b.val, b.y, b.offset, b.weight, o, theta0=th0)
     coef_ptr = packed.coef_ptr_host()

@@ -143,6 +143,44 @@ def test_stepping_kernels_on_ragged_rows_long_columns_and_weights(device_solver)
 
 
 @pytest.mark.gpu
+def test_one_launch_step_and_look_ahead_give_the_bits_of_the_plain_loop(device_solver, monkeypatch):
+    """Round 5: the step is ONE launch (fe_tail_kernel: the products of every virtual block, the last-arriving workgroup's decision,
+    the update and the shard's local copy of x) instead of three plus fe_prepare_kernel, and the host reads the status a few steps
+    late (gdmix_fe_solve / run_stepping_loop; the kernels of a stopped problem return at once). Same partition of the sums, same
+    order: coefficients, value, nit, nfev are bitwise those of the three-launch loop with the status read after every step — cold
+    and warm-started (the local copy of the start point is written at creation), with several row / column blocks and a frequent
+    column, on a shard with fewer coefficients than one workgroup has threads and on one with more virtual blocks than CUs."""
+    for n, D, seed in ((3000, 150, 1), (9000, 7000, 2), (40_000, 140_000, 3)):
+        rng = np.random.default_rng(seed)
+        k = rng.integers(0, 24, n)
+        k[rng.integers(0, n, 3)] = 2000
+        rp = np.concatenate([[0], np.cumsum(k)]).astype(np.int64)
+        cols = np.minimum((float(D + 1) ** rng.random(rp[-1])).astype(np.int64) - 1, D - 1)
+        vals = (rng.standard_normal(rp[-1]) * 0.3).astype(np.float32)
+        y = (rng.random(n) < 0.3).astype(np.float32)
+        off = (0.2 * rng.standard_normal(n)).astype(np.float32)
+        s = fe.FixedEffectDeviceSolver(solver=device_solver)
+        kw = dict(offset=off, l2=1.5, regularize_bias=False, max_iter=30)
+        runs = {}
+        for fused, ahead in (("0", 0), ("1", 0), ("1", 2), ("1", 5), ("0", 3)):
+            monkeypatch.setenv("GDMIX_FE_FUSED_TAIL", fused)
+            monkeypatch.setattr(fe, "LOOKAHEAD", ahead)
+            monkeypatch.setenv("GDMIX_FE_HOT_MIN", "300")
+            th, info = s.fit_stepping(rp, cols, vals, y, D, **kw)
+            th_w, info_w = s.fit_stepping(rp, cols, vals, y, D, theta0=th * 0.5, **dict(kw, max_iter=7))
+            runs[(fused, ahead)] = (th, info, th_w, info_w)
+        ref = runs[("0", 0)]
+        assert ref[1]["nit"] > 5 and ref[3]["nit"] >= 1 and np.abs(ref[0]).max() > 0
+        for key, (th, info, th_w, info_w) in runs.items():
+            assert np.array_equal(th, ref[0]) and info == ref[1], key
+            assert np.array_equal(th_w, ref[2]) and info_w == ref[3], key
+        # ... and the Hessian passes, which run after the stop at a point of their own, leave the solver's local copy alone
+        monkeypatch.setenv("GDMIX_FE_FUSED_TAIL", "1")
+        th_v, info_v = s.fit_stepping(rp, cols, vals, y, D, variance_mode="simple", threshold=0.0, **kw)
+        assert np.array_equal(th_v, ref[0]) and np.all(info_v["variances"] > 0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("chunk,pack,hot,window", [(None, "1", None, None), ("8192", "1", None, None), ("257", "1", None, None),
                                                    ("257", "0", None, None), (None, "0", None, None), (None, "1", "300", None),
                                                    ("257", "1", "2000", None), ("257", "0", "40", None), (None, "1", None, "10"),

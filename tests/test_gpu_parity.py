@@ -77,7 +77,7 @@ def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, gian
     try:
         res = device_solver.solve(packed, SolverOptions(**kw), theta0=th0).to_host()
     finally:
-        device_solver.set_tall_split_n(4096)
+        device_solver.set_tall_split_n(0)
         device_solver.set_tall_team_n(device_solver.TALL_TEAM_N_DEFAULT)
         device_solver.set_wave_lds_limit(65536)
         device_solver.set_kernel_mask(7)
@@ -757,6 +757,40 @@ def test_wire_form_widens_to_the_raw_batch(device_solver, shape):
         assert np.array_equal(rd2[k].cpu().numpy(), getattr(b, k)), k
 
 
+def test_pinned_routing_makes_an_entity_independent_of_its_batch(device_solver):
+    """by default the split between the tall kernels and the team threshold are chosen per batch, so the same entity can
+    get another kernel — other last bits — in another batch. REDeviceSolver.pin_routing (what a model with rebalance_entities
+    does) ties the kernel to the entity's own size: every fifth MovieLens-20M user solved in a batch of 300 and in the batch of
+    1 500 comes out bit for bit the same, the per-batch choice being demonstrably different for the two batches by default."""
+    b = synthetic.make_movielens_20m("per_user", seed=83, entities=1500)
+    ents = np.arange(0, b.E, 5)
+    sub = b.select(ents)
+    opts = SolverOptions(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
+
+    def both():
+        out = []
+        for batch in (b, sub):
+            packed = device_solver.pack(batch)
+            r = device_solver.solve(packed, opts).to_host()
+            cp = packed.coef_ptr_host()
+            cls = packed._view(packed.c.cls_tmp, packed.E, device_solver.torch.int32).cpu().numpy().copy()
+            out.append((r, cp, cls))
+        return out
+    (rb, cpb, clsb), (rs, cps, clss) = both()
+    differently_routed = int((clsb[ents] != clss).sum())
+    try:
+        device_solver.pin_routing()
+        (rb, cpb, clsb), (rs, cps, clss) = both()
+    finally:
+        device_solver.set_tall_split_n(0)
+        device_solver.set_tall_team_n(device_solver.TALL_TEAM_N_DEFAULT)
+    assert differently_routed > 0            # (otherwise this shape no longer exercises the per-batch choice: pick another)
+    assert np.array_equal(clsb[ents], clss)
+    for i, e in enumerate(ents):
+        assert np.array_equal(rb["theta"][cpb[e]:cpb[e + 1]], rs["theta"][cps[i]:cps[i + 1]]), e
+    assert np.array_equal(rb["nit"][ents], rs["nit"]) and np.array_equal(rb["status"][ents], rs["status"])
+
+
 def test_a_small_batch_lowers_the_tall_split_and_only_the_rounding_changes(device_solver):
     """Round 4: a batch whose eight-wavefront tall class stays small anyway (a share of a strongly scaled MovieLens job) gets a lower
     split between the one-wavefront and the eight-wavefront tall kernels — chosen on the device (class_base_kernel), the entities moved
@@ -778,7 +812,7 @@ def test_a_small_batch_lowers_the_tall_split_and_only_the_rounding_changes(devic
         cf = dict(device_solver.class_counts(packed))
         cls_f = packed._view(packed.c.cls_tmp, packed.E, device_solver.torch.int32).cpu().numpy().copy()
     finally:
-        device_solver.set_tall_split_n(4096)
+        device_solver.set_tall_split_n(0)
     assert cf[names[0]] == int((n >= 4097).sum()) and cf[names[0]] < 20
     moved = ca[names[0]] - cf[names[0]]
     assert moved > 20 and ca[names[0]] <= 384, (ca[names[0]], cf[names[0]])
@@ -827,7 +861,7 @@ def test_the_tallest_entities_of_a_batch_get_a_team_of_workgroups(device_solver,
         cw = dict(device_solver.class_counts(packed))
     finally:
         device_solver.set_tall_team_n(device_solver.TALL_TEAM_N_DEFAULT)
-        device_solver.set_tall_split_n(4096)
+        device_solver.set_tall_split_n(0)
     assert cw[team] == 0 and sum(cw.values()) == sum(ct.values()) == b.E
     limit = 64
     assert 0 < ct[team] <= limit and ct[team] + ct[tall8] == cw[tall8], (ct[team], ct[tall8], cw[tall8])
