@@ -96,6 +96,10 @@ def parse():
     ap.add_argument("--project-ranks", type=int, default=8,
                     help="--gpus 1, default workload: also solve the shares of an N-rank job one after another on this GPU "
                          "(detail.strong_projection; 0 = skip)")
+    ap.add_argument("--c5-full-entities", type=int, default=100_000_000,
+                    help="--gpus 1, default workload: BASELINE configs[4] at its real per-GPU share — worker 0's 128 partitions of ONE population of this "
+                         "many Zipf-sized entities in 1 024 partitions, one partition per round (detail.c5_full_share; 0 = skip)")
+    ap.add_argument("--c5-full-rounds", type=int, default=16, help="rounds of the whole 8-worker job projected on this device, plain and with the re-balancing plan applied")
     ap.add_argument("--detail-file", default="", help="where the full result goes (default gpurun_out/bench_detail.json); the stdout line is the short form")
     ap.add_argument("--print-detail", action="store_true", help="also print the full result as one JSON line on stderr")
     ap.add_argument("--ml-entities", type=int, default=0, help="strong legs: keep this many MovieLens entities (tests at reduced size; 0 = all)")
@@ -712,9 +716,13 @@ def compact_line(full, detail_file):
         if p.get("ms_mean") is not None:
             s["proj8"][p["workload"] + "_ms_mean"] = _r(p["ms_mean"])
     full_share = d.get("c5_full_share")
-    if full_share:
-        s["c5_full_share"] = {k: _r(full_share.get(k)) for k in ("entities", "s", "entities_per_s", "round_ms_p50", "round_ms_p99", "round_ms_max")
-                              if full_share.get(k) is not None}
+    if full_share and "skipped" not in full_share:
+        s["c5_full_share"] = {k: _r(full_share.get(k)) for k in ("entities", "s", "entities_per_s", "serial_s", "round_ms_p50", "round_ms_p99", "round_ms_max",
+                                                                 "imbalance_vs_8_rank_mean_round") if full_share.get(k) is not None}
+        pr = full_share.get("projected_rounds")
+        if pr:
+            s["c5_full_share"].update(rounds=len(pr["rounds"]), plain_ms_total=_r(pr["plain_ms_total"]), rebalanced_ms_total=_r(pr["rebalanced_ms_total"]),
+                                      imbalance=_r(pr["mean_imbalance"]), imbalance_after=_r(pr["mean_imbalance_after"]))
     chain = d.get("chain")
     if chain:
         s["chain"] = {k: _r(v) for k, v in chain.items() if isinstance(v, (int, float))}
@@ -971,6 +979,19 @@ def main():
                           for w in bench_strong.STRONG_WORKLOADS if _fits(w, a, world, coll_dev)]
         solver.set_timing(True)
         res = solver.solve(packed, opts, out=out)
+    c5_full = None
+    if a.workload == "c2" and world == 1 and not a.no_other_workloads and a.c5_full_entities > 0:
+        import bench_strong
+        res = None
+        torch.cuda.empty_cache()
+        need = 70e9 * a.c5_full_entities / 100_000_000 + 8e9
+        if torch.cuda.mem_get_info()[0] >= need:
+            c5_full = bench_strong.c5_full_share_leg(solver, opts, local_rank, a.c5_full_entities, ranks=8, partitions=1024,
+                                                     projected_rounds=a.c5_full_rounds, tolerance=a.rebalance_tolerance)
+        else:
+            c5_full = {"skipped": "not enough free device memory (%.0f GB free, %.0f GB needed)" % (torch.cuda.mem_get_info()[0] / 1e9, need / 1e9)}
+        solver.set_timing(True)
+        res = solver.solve(packed, opts, out=out)
 
     if rank == 0:
         # ---- roofline of the dominant kernel = the size-class launch with the largest share of a step ----
@@ -1087,7 +1108,7 @@ def main():
                        "mean_nit": nit, "mean_nfev": nfev,
                        "converged_per_step": converged_all, "parity_classes": {"W": well_posed, "D": int(wl.E - well_posed)}, "N": wl.N, "Z": wl.Z, "P": packed.P,
                        "host_generate_s": t_gen, "host_handover": e2e, "score_pass": score, "fixed_effect_eval": fe_eval, "cli_end_to_end": cli_e2e,
-                       "cli_subprocess": cli_sub, "cli_end_to_end_c5": cli_c5, "cli_end_to_end_ml20m_movie": cli_movie, "workloads": others,
+                       "cli_subprocess": cli_sub, "cli_end_to_end_c5": cli_c5, "cli_end_to_end_ml20m_movie": cli_movie, "workloads": others, "c5_full_share": c5_full,
                        "restreamed_bytes_per_step": b_stream,
                        "restreamed_GBps": b_stream / (float(kernel_ms.sum()) / a.steps * 1e-3) / 1e9 if kernel_ms.sum() else None},
         }

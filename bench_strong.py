@@ -415,3 +415,165 @@ def projection_leg(name, ranks, solver, opts, c5_entities, steps=2, warmup=1, ml
                              "note": "plan only (rebalance.plan_transfers / choose_entities on rebalance.CostModel costs measured here); executed by "
                                      "strong_leg when the job has ranks"}
     return out
+
+
+def c5_full_share_leg(solver, opts, device_index, total_entities=100_000_000, ranks=8, partitions=1024, projected_rounds=16, tolerance=0.05,
+                      contexts=3):
+    """BASELINE configs[4] at its real per-GPU share and at the product path's granularity: ONE population of
+    `total_entities` Zipf-sized entities hashed into `partitions` partitions; worker 0 of `ranks` owns
+    partitions[0::ranks] = 128 of 1 024 = 12.5 M entities and trains them ONE PARTITION PER ROUND
+    (drivers/random_effect_driver.py:60-68). Every partition of the share is generated in HBM (its own Philox stream), then
+      serial     : the 128 rounds one after another on one context — pack + solve per round, a round's ms
+      pipelined  : the same 128 partitions over `contexts` contexts / streams round robin (how model.py's host pipeline and
+                   bench.py's hand-over leg keep the device busy across the rounds' tails) — the share's wall time
+    and, for the first `projected_rounds` rounds, ALL `ranks` workers' partitions of the round solved one after another on this
+    device (a projection: the data path has no collective) plain and with the re-balancer's plan applied — rebalance.plan_transfers /
+    choose_entities on rebalance.SizeCostModel costs measured by the rounds before (the first round: non-zeros), the travelling
+    entities really moved between the rounds' batches in HBM (synthetic.subset_raw / concat_raw) and the new batches timed; the
+    exchange itself (wire bytes over xGMI) cannot run on one GPU and is reported as bytes."""
+    import threading
+    import torch
+    from gdmix_amd import synthetic
+    from gdmix_amd.rebalance import SizeCostModel, choose_entities, plan_transfers
+    from gdmix_amd.solver import NUM_CLASSES, REDeviceSolver
+    sync = torch.cuda.synchronize
+    dev_pids = lambda ids, parts: solver.partition_ids(np.ascontiguousarray(ids, np.int64), parts).cpu().numpy()
+    t0 = time.perf_counter()
+    pop = synthetic.C5Population(total_entities, partitions, partition_ids_fn=dev_pids)
+    t_pop = time.perf_counter() - t0
+    mine = synthetic.rank_partitions(partitions, ranks, 0)
+    t0 = time.perf_counter()
+    share = [pop.partition(K, solver.device) for K in mine]
+    sync()
+    t_gen = time.perf_counter() - t0
+    E = sum(r["E"] for r, _, _ in share)
+    Z = sum(r["Z"] for r, _, _ in share)
+    solver.set_timing(True)
+
+    def step(s, raw):
+        pk = s.pack(raw)
+        rs = s.solve(pk, opts)
+        return pk, rs
+
+    def converged(rs):
+        st = rs.status
+        return int(((st >= 0) & (st <= 2)).sum().item())
+    for raw, _, _ in share[:2]:
+        step(solver, raw)
+    sync()
+    # ---- serial: one round after another
+    round_ms, conv = [], 0
+    t_serial = time.perf_counter()
+    for raw, _, _ in share:
+        t = time.perf_counter()
+        pk, rs = step(solver, raw)
+        sync()
+        round_ms.append((time.perf_counter() - t) * 1e3)
+        conv += converged(rs)
+        del pk, rs
+    t_serial = time.perf_counter() - t_serial
+    # ---- pipelined over `contexts` contexts
+    ws = [REDeviceSolver(device_index) for _ in range(contexts)]
+    streams = [torch.cuda.Stream(device=solver.device) for _ in range(contexts)]
+    for i, s in enumerate(ws):
+        with torch.cuda.stream(streams[i]):
+            step(s, share[i][0])
+            streams[i].synchronize()
+    conv_p = [0] * contexts
+    start = threading.Barrier(contexts + 1)
+
+    def run(i):
+        start.wait()
+        with torch.cuda.stream(streams[i]):
+            for k in range(i, len(share), contexts):
+                pk, rs = step(ws[i], share[k][0])
+                conv_p[i] += converged(rs)      # (the read-back of the statuses also ends the round on this stream)
+                del pk, rs
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(contexts)]
+    for th in threads:
+        th.start()
+    sync()
+    start.wait()
+    t_pipe = time.perf_counter()
+    for th in threads:
+        th.join()
+    sync()
+    t_pipe = time.perf_counter() - t_pipe
+    for s in ws:
+        s.close()
+    rm = np.array(round_ms)
+    out = {"what": f"worker 0 of {ranks}: its {len(mine)} partitions of ONE population of {total_entities} Zipf-sized entities in {partitions} Java-hashed partitions "
+                   "(SURVEY 8(d)), one partition per round, resident in HBM; s = the share's wall time over three contexts, serial_s = one context",
+           "entities": int(E), "nnz": int(Z), "partitions": len(mine), "converged": int(conv), "converged_pipelined": int(sum(conv_p)),
+           "s": t_pipe, "entities_per_s": E / t_pipe, "serial_s": t_serial, "serial_entities_per_s": E / t_serial, "contexts": contexts,
+           "round_ms_p50": float(np.percentile(rm, 50)), "round_ms_p99": float(np.percentile(rm, 99)), "round_ms_max": float(rm.max()),
+           "round_ms_mean": float(rm.mean()), "round_ms": [round(float(x), 2) for x in rm],
+           "largest_entity_nnz": int(max(int(n.max()) for _, n, _ in share) * pop.k),
+           "population_s": round(t_pop, 1), "generate_s": round(t_gen, 1)}
+    # ---- the first rounds of the whole job: every worker's partition of the round, plain and with the plan applied
+    model, totals = SizeCostModel(), np.zeros((2, SizeCostModel.BUCKETS))
+    rounds = []
+
+    def timed(raw):
+        best, keep = None, None
+        for _ in range(2):       # best of two (the first touches the batch's pages)
+            sync()
+            t = time.perf_counter()
+            pk, rs = step(solver, raw)
+            sync()
+            dt = (time.perf_counter() - t) * 1e3
+            if best is None or dt < best:
+                best = dt
+            keep = (pk, rs)
+        return best, keep
+    for k in range(min(projected_rounds, len(mine))):
+        batches = [share[k] if r == 0 else pop.partition(synthetic.rank_partitions(partitions, ranks, r)[k], solver.device) for r in range(ranks)]
+        plain, cls_ms = [], []
+        for raw, n, _ in batches:
+            ms, (pk, rs) = timed(raw)
+            plain.append(ms)
+            cls_ms.append((_entity_classes(pk, torch), np.array(solver.last_solve_ms())))
+            del pk, rs
+        z = [n * pop.k for _, n, _ in batches]
+        costs = [model.cost(zz) for zz in z]
+        loads = np.array([c.sum() for c in costs])
+        T = plan_transfers(loads, tolerance)
+        sent = [choose_entities(costs[i], T[i], model.order(z[i])) if T[i].sum() > 0 else [np.zeros(0, np.int64)] * ranks for i in range(ranks)]
+        moved = sum(int(ix.size) for s_ in sent for ix in s_)
+        bytes_moved = sum(float(z[i][ix].sum()) * 8.0 + float(batches[i][1][ix].sum()) * 12.0 + ix.size * 4.0 for i in range(ranks) for ix in sent[i])
+        after = list(plain)
+        if moved:
+            after = []
+            for j in range(ranks):
+                gone = np.concatenate(sent[j]) if T[j].sum() > 0 else np.zeros(0, np.int64)
+                keep_ix = np.setdiff1d(np.arange(batches[j][0]["E"]), gone)
+                parts_j = [synthetic.subset_raw(batches[j][0], batches[j][1], keep_ix)[0] if gone.size else batches[j][0]]
+                for i in range(ranks):
+                    if i != j and sent[i][j].size:
+                        parts_j.append(synthetic.subset_raw(batches[i][0], batches[i][1], sent[i][j])[0])
+                ms, (pk, rs) = timed(synthetic.concat_raw(parts_j))
+                after.append(ms)
+                del pk, rs, parts_j
+        for (cls, cms), zz in zip(cls_ms, z):       # what this round measured prices the next one
+            totals += SizeCostModel.totals(cls, zz, cms, NUM_CLASSES)
+        model = SizeCostModel.from_totals(totals)
+        pl, af = np.array(plain), np.array(after)
+        rounds.append({"round": k, "plain_ms": [round(float(x), 2) for x in pl], "plain_round_ms": float(pl.max()), "imbalance": float(pl.max() / pl.mean()),
+                       "rebalanced_ms": [round(float(x), 2) for x in af], "rebalanced_round_ms": float(af.max()),
+                       "imbalance_after": float(af.max() / af.mean()), "entities_moved": int(moved), "wire_bytes_moved": float(bytes_moved),
+                       "priced_by": "non-zeros" if k == 0 else f"measured costs of rounds 0..{k - 1}"})
+        del batches
+        torch.cuda.empty_cache()
+    if rounds:
+        pr = np.array([r["plain_round_ms"] for r in rounds])
+        rr = np.array([r["rebalanced_round_ms"] for r in rounds])
+        mean_round = np.array([np.mean(r["plain_ms"]) for r in rounds])
+        out["imbalance_vs_8_rank_mean_round"] = float(np.mean([r["plain_ms"][0] for r in rounds]) / mean_round.mean())
+        out["projected_rounds"] = {
+            "what": f"rounds 0..{len(rounds) - 1} of the whole {ranks}-worker job, every worker's partition of the round solved one after another on this device "
+                    "(projection), plain and with the re-balancer's plan applied to the batches in HBM (exchange itself not timed: bytes reported)",
+            "rounds": rounds, "plain_ms_total": float(pr.sum()), "rebalanced_ms_total": float(rr.sum()),
+            "mean_imbalance": float(np.mean([r["imbalance"] for r in rounds])), "mean_imbalance_after": float(np.mean([r["imbalance_after"] for r in rounds])),
+            "exchange_ms_estimate_per_round": float(np.mean([r["wire_bytes_moved"] for r in rounds]) / 153e9 * 1e3),
+            "exchange_estimate_note": "mean wire bytes of a round / one xGMI link (153 GB/s); a direct all-to-all uses up to 7 links per GPU"}
+    return out

@@ -155,6 +155,21 @@ class WireRawBatch(RawBatch):
     def ent_n(self):
         return self._ent_n.astype(np.int64)
 
+    def ent_nnz(self):
+        """Non-zeros per entity straight from the narrow per-sample counts (no 64-bit row pointer array is built: ADVICE r4)."""
+        if self._row_nnz_ptr is not None:
+            return RawBatch.ent_nnz(self)
+        E = self.E
+        if E == 0 or self._row_nnz.size == 0:
+            return np.zeros(E, np.int64)
+        starts = np.asarray(self.ent_row_ptr[:-1], np.int64)
+        live = starts < self._row_nnz.size          # (entities without samples at the end of the batch)
+        out = np.zeros(E, np.int64)
+        s = np.add.reduceat(self._row_nnz, starts[live], dtype=np.int64)
+        s[np.diff(np.append(starts[live], self._row_nnz.size)) == 0] = 0     # reduceat returns the element itself for an empty range
+        out[live] = s
+        return out
+
     def to_wire(self):
         binary = self._y8 is not None
         return dict(E=self.E, N=self.N, Z=self.Z, ent_n=self._ent_n, row_nnz=self._row_nnz, row_nnz_width=self._row_nnz.dtype.itemsize,

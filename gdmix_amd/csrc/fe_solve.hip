@@ -143,7 +143,8 @@ template <bool ROWS, bool HESS, bool PACKED>
 __global__ __launch_bounds__(WAVE) void fe_scatter_kernel(FeDev F, SolveParams o) {
   // exactly 16 KiB: ten wavefronts per CU (160 KiB of LDS). Round 5: a spare accumulator for the lanes beyond the end of the last
   // trip made it 16 400 B = nine; those lanes now add 0.0 to accumulator 0 (x + 0.0 == x bit for bit; an accumulator that is still
-  // -0.0 cannot occur: they start at +0.0)
+  // -0.0 cannot occur: they start at +0.0). Measured: nine or ten makes no difference (0.556 ms either way, three runs each):
+  // the passes are bound by the CU's vector-memory path, not by occupancy (docs/rounds/r05.md)
   __shared__ double acc[FE_B];
   const int lane = threadIdx.x;
   const FeCopy& C = ROWS ? F.rc : F.cc;

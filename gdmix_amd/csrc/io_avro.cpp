@@ -9,6 +9,7 @@
 // Byte for byte what gdmix_amd/io/avro.py + model.py's Python encoders write (tests/test_native_io.py).
 #include "../../include/gdmix_io.h"
 
+#include <errno.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -97,19 +98,28 @@ size_t buffers_trim() {   // gdmix_io_pool_trim: release the idle byte buffers
 }  // namespace gdmix_io_detail
 namespace {
 
-// Encode blocks [0, n_blocks) with `encode(first record, last record, payload)` on `threads` threads and append them to the
-// file in order. The workers take block numbers from a counter and encode into a ring of buffers; the calling thread writes
-// a block as soon as it and all blocks before it are ready, so encoding and the write() of earlier blocks overlap and a
-// bounded number of blocks is in memory. (A first version worked in rounds: start the threads, encode threads x 4 blocks, join,
-// write them, again — a score file of 2 M records is 1 953 small blocks = 15 rounds of thread starts with everybody idle
-// during the writes.)
+// Encode blocks [0, n_blocks) with `encode(first record, last record, payload)` on `threads` threads into the file, in order.
+// The workers take groups of consecutive blocks from a counter and encode each into a buffer of their own; a group's place in
+// the file is known as soon as the groups before it have been ENCODED (their sizes add up), not written — so every worker
+// pwrite()s its own group, and the copy into the page cache, which is most of a file's time (a model file of a Zipf-sized
+// partition is 100 MB: 18 of its 24 ms were the one thread's fwrite), runs on all of them. Round 5; before, the calling thread
+// wrote the groups one after another from a ring of buffers. (A first version worked in rounds: start the threads, encode
+// threads x 4 blocks, join, write them, again — a score file of 2 M records is 1 953 small blocks = 15 rounds of thread starts.)
 template <class Enc>
 int write_blocks(const char* path, const uint8_t* header, int64_t header_len, const uint8_t* sync, int64_t total,
                  int32_t block_records, int32_t deflate_codec, int32_t threads, Enc&& encode) {
   if (!path || !header || !sync || header_len <= 0 || block_records <= 0) return set_error(GDMIX_IO_EINVAL, "bad argument");
-  FILE* f = fopen(path, "wb");
-  if (!f) return set_error(GDMIX_IO_EIO, "%s: cannot open for writing", path);
-  bool ok = fwrite(header, 1, (size_t)header_len, f) == (size_t)header_len;
+  const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) return set_error(GDMIX_IO_EIO, "%s: cannot open for writing", path);
+  auto put_at = [&](const char* data, size_t len, int64_t off) {
+    while (len > 0) {
+      const ssize_t w = pwrite(fd, data, len, (off_t)off);
+      if (w < 0) { if (errno == EINTR) continue; return false; }
+      data += w; len -= (size_t)w; off += w;
+    }
+    return true;
+  };
+  bool ok = put_at((const char*)header, (size_t)header_len, 0);
   const int64_t n_blocks = (total + block_records - 1) / block_records;
   if (threads <= 0) threads = gdmix_io_detail::default_threads();
   // one block, encoded, framed and appended to `o`
@@ -129,83 +139,64 @@ int write_blocks(const char* path, const uint8_t* header, int64_t header_len, co
     o.append((const char*)sync, 16);
     return true;
   };
-  // The unit of work and of hand-over is a group of consecutive blocks of about a megabyte (a score block is 20 KB: a lock and
-  // a wake-up per block cost four times what the block takes to encode). The first block is encoded here to learn the size.
-  std::string first = g_buffers.take();
+  // The unit of work is a group of consecutive blocks of about a megabyte (a score block is 20 KB: a lock and a wake-up per
+  // block cost four times what the block takes to encode). The first block is encoded here to learn the size.
+  int64_t base = header_len;
+  int64_t group = 1;
   {
-    std::string payload = g_buffers.take(), packed;
-    if (n_blocks > 0 && !emit(0, payload, packed, first)) ok = false;
+    std::string first = g_buffers.take(), payload = g_buffers.take(), packed;
+    if (ok && n_blocks > 0 && !emit(0, payload, packed, first)) ok = false;
+    if (ok && n_blocks > 0) ok = put_at(first.data(), first.size(), base);
+    base += (int64_t)first.size();
+    group = first.size() > 0 ? (int64_t)((1 << 20) / first.size()) : 1;
     g_buffers.give(std::move(payload));
+    g_buffers.give(std::move(first));
   }
-  if (ok && n_blocks > 0) ok = fwrite(first.data(), 1, first.size(), f) == first.size();
-  int64_t group = first.size() > 0 ? (int64_t)((1 << 20) / first.size()) : 1;
   if (group < 1) group = 1;
   if (group > 256) group = 256;
-  g_buffers.give(std::move(first));
   const int64_t n_groups = n_blocks > 1 ? (n_blocks - 1 + group - 1) / group : 0;   // blocks 1 .. n_blocks-1
   if ((int64_t)threads > n_groups) threads = (int)n_groups;
-  const int64_t ring = (int64_t)threads * 4 < n_groups ? (int64_t)threads * 4 : (n_groups > 0 ? n_groups : 1);
-  std::vector<std::string> out((size_t)ring);
-  for (auto& o : out) o = g_buffers.take();
-  std::vector<int64_t> ready((size_t)ring, -1);   // group whose bytes the slot holds
+  std::vector<int64_t> size_of((size_t)n_groups, -1), offset_of((size_t)n_groups + 1, -1);
+  if (n_groups >= 0) offset_of[0] = base;
   std::mutex mu;
-  std::condition_variable cv_ready, cv_free;
-  int64_t written = 0;                            // groups [0, written) are in the file: slot g % ring is free for g < written + ring
+  std::condition_variable cv;
+  int64_t frontier = 0;          // offsets of groups [0, frontier] are known
   std::atomic<int64_t> next{0};
-  std::atomic<int> failed{0};
-  bool stop = !ok;
+  std::atomic<int> failed{ok ? 0 : 1};
   auto work = [&]() {
-    std::string payload = g_buffers.take(), packed;
+    std::string payload = g_buffers.take(), packed, o = g_buffers.take();
     for (;;) {
       const int64_t g = next.fetch_add(1);
       if (g >= n_groups) break;
+      o.clear();
+      bool good = !failed.load();
+      const int64_t b0 = 1 + g * group, b1 = (b0 + group < n_blocks) ? b0 + group : n_blocks;
+      for (int64_t blk = b0; blk < b1 && good; ++blk) good = emit(blk, payload, packed, o);
+      int64_t off;
       {
         std::unique_lock<std::mutex> lk(mu);
-        cv_free.wait(lk, [&] { return stop || g < written + ring; });
-        if (stop) break;
+        size_of[(size_t)g] = good ? (int64_t)o.size() : 0;     // (a failed group still lets the ones behind it learn their place and finish)
+        bool moved = false;
+        while (frontier < n_groups && size_of[(size_t)frontier] >= 0) {
+          offset_of[(size_t)frontier + 1] = offset_of[(size_t)frontier] + size_of[(size_t)frontier];
+          ++frontier;
+          moved = true;
+        }
+        if (moved) cv.notify_all();
+        cv.wait(lk, [&] { return frontier >= g; });
+        off = offset_of[(size_t)g];
       }
-      std::string& o = out[(size_t)(g % ring)];
-      o.clear();
-      const int64_t b0 = 1 + g * group, b1 = (b0 + group < n_blocks) ? b0 + group : n_blocks;
-      for (int64_t blk = b0; blk < b1; ++blk)
-        if (!emit(blk, payload, packed, o)) { failed.store(1); break; }
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        ready[(size_t)(g % ring)] = g;
-      }
-      cv_ready.notify_one();
+      if (!good || !put_at(o.data(), o.size(), off)) failed.store(1);
     }
     g_buffers.give(std::move(payload));
+    g_buffers.give(std::move(o));
   };
   std::vector<std::thread> pool;
-  for (int t = 0; t < threads && ok; ++t) pool.emplace_back(work);
-  for (int64_t g = 0; g < n_groups && ok; ++g) {
-    {
-      std::unique_lock<std::mutex> lk(mu);
-      cv_ready.wait(lk, [&] { return ready[(size_t)(g % ring)] == g; });
-    }
-    const std::string& o = out[(size_t)(g % ring)];
-    if (!failed.load()) ok = fwrite(o.data(), 1, o.size(), f) == o.size();
-    bool wake;
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      written = g + 1;
-      if (!ok || failed.load()) stop = true;
-      wake = stop || next.load() >= written + ring - 1;   // somebody may be waiting for this slot
-    }
-    if (wake) cv_free.notify_all();
-    if (!ok || failed.load()) break;
-  }
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    stop = stop || !ok || failed.load() != 0;
-    if (stop) written = n_groups;   // nobody waits for a slot any more
-  }
-  cv_free.notify_all();
+  for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+  if (n_groups > 0) work();        // the calling thread is one of the workers
   for (auto& th : pool) th.join();
-  for (auto& o : out) g_buffers.give(std::move(o));
   if (failed.load()) ok = false;
-  if (fclose(f) != 0) ok = false;
+  if (close(fd) != 0) ok = false;
   if (!ok) return set_error(GDMIX_IO_EIO, "%s: write failed", path);
   return GDMIX_IO_OK;
 }

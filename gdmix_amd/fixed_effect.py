@@ -453,18 +453,21 @@ def _full_variances_several_workers(solver, packed, theta, D, has_intercept, l2,
     P = D + ic
     uniq_dev = packed.unique_global()
     uniq = uniq_dev.cpu().numpy()
-    local = to_local(theta, uniq, D, has_intercept, dummy)
-    Hl = solver.hessian_dense(packed, local, has_intercept)            # [ld_l, ld_l], local order: intercept first
     p_l = uniq.size + ic
     ld = (P + 63) // 64 * 64
-    idx = torch.cat([torch.full((ic,), D, dtype=torch.int64, device=solver.device), uniq_dev.to(torch.int64)])   # local -> global coefficient
-    if dummy:     # a worker without data trains on one weight-0 sample: its curvature is exactly zero
-        Hl = torch.zeros_like(Hl)
-    rows = torch.zeros((ld, p_l), dtype=torch.float64, device=solver.device)
-    rows.index_copy_(0, idx, Hl[:p_l, :p_l].contiguous())
+    # the summed matrix and the factorisation's work area are ld x ld doubles each, the local matrix another one at most: refuse with a
+    # clear message rather than die in an allocation after the whole training
+    need = 3 * ld * ld * 8 + (1 << 28)
+    if solver.device.type == "cuda" and torch.cuda.mem_get_info(solver.device)[0] < need:
+        raise MemoryError(f"fixed_effect_variance_mode=FULL with {P} coefficients needs {need / 1e9:.1f} GB of free device memory "
+                          f"({torch.cuda.mem_get_info(solver.device)[0] / 1e9:.1f} GB free)")
     Hg = torch.zeros((ld, ld), dtype=torch.float64, device=solver.device)
-    Hg.index_copy_(1, idx, rows)
-    del rows, Hl
+    if not dummy and p_l > 0:     # (a worker without data trains on one weight-0 sample: its curvature is exactly zero — nothing to build or scatter)
+        local = to_local(theta, uniq, D, has_intercept, dummy)
+        Hl = solver.hessian_dense(packed, local, has_intercept)            # [ld_l, ld_l], local order: intercept first
+        idx = torch.cat([torch.full((ic,), D, dtype=torch.int64, device=solver.device), uniq_dev.to(torch.int64)])   # local -> global coefficient
+        Hg.index_put_((idx[:, None], idx[None, :]), Hl[:p_l, :p_l])       # one 2-D scatter into the common index space
+        del Hl
     if dist.get_backend(group) == "nccl":
         dist.all_reduce(Hg, group=group)
     else:      # (gloo: the two-worker tests on one device)

@@ -403,6 +403,91 @@ def make_c5_population_share(device, E_total, world, rank, num_partitions=1024, 
     return raw, n, own, pid
 
 
+class C5Population:
+    """ONE C5 population (BASELINE.json configs[4]), partition by partition: the same entities, sizes, partitions
+    and per-partition Philox streams as make_c5_population_share, but a partition is generated on its own — what a worker of the
+    product path holds at a time (drivers/random_effect_driver.py:60-68: one partition per round). 100 M entities: the sizes are
+    one seeded host draw (800 MB), the partition of every id the Java hash of its decimal form (partition_ids_fn: the device
+    routine gdmix_java_partition_ids_i64; default the host routine of partitioner.py)."""
+
+    def __init__(self, E_total, num_partitions=1024, seed=C5_SEED, mean_nnz=256, k=8, D=65536, max_nnz=1 << 20, partition_ids_fn=None):
+        self.E_total, self.P, self.seed, self.k, self.D = int(E_total), int(num_partitions), int(seed), int(k), int(D)
+        self.n_all = c5_entity_samples(np.random.default_rng(seed), self.E_total, mean_nnz, k, max_nnz)
+        ids = np.arange(self.E_total, dtype=np.int64)
+        if partition_ids_fn is None:
+            from .partitioner import java_partition_ids_int64
+            pid = java_partition_ids_int64(ids, self.P)
+        else:
+            pid = np.asarray(partition_ids_fn(ids, self.P))
+        self.pid_all = pid.astype(np.int32)
+        self.order = np.argsort(self.pid_all, kind="stable").astype(np.int64)        # ids by partition, in id order inside one
+        self.part_ptr = np.concatenate([[0], np.cumsum(np.bincount(self.pid_all, minlength=self.P))]).astype(np.int64)
+        self._w_star = {}
+
+    def ids_of(self, K):
+        return self.order[self.part_ptr[K]:self.part_ptr[K + 1]]
+
+    def partition(self, K, device):
+        """-> (raw, n, ids): partition K's raw batch in HBM (the dict REDeviceSolver.pack takes), samples and global id per entity."""
+        import torch
+        dev = torch.device(device)
+        ids = self.ids_of(K)
+        n = self.n_all[ids]
+        N, k = int(n.sum()), self.k
+        g = torch.Generator(device=dev)
+        if dev not in self._w_star:
+            g.manual_seed(self.seed)
+            self._w_star[dev] = 0.5 * torch.randn(self.D, generator=g, device=dev, dtype=torch.float64)
+        cols = torch.empty((N, k), dtype=torch.int64, device=dev)
+        vals = torch.empty((N, k), dtype=torch.float32, device=dev)
+        offset = torch.empty(N, dtype=torch.float32, device=dev)
+        y = torch.empty(N, dtype=torch.float32, device=dev)
+        if N:
+            g.manual_seed(self.seed * 1_000_003 + 1 + int(K))
+            _c5_rows(g, dev, N, k, self.D, self._w_star[dev], cols, vals, offset, y, 0)
+        raw = dict(E=int(ids.size), N=N, Z=N * k, ent_row_ptr=torch.from_numpy(np.concatenate([[0], np.cumsum(n)])).to(dev),
+                   row_nnz_ptr=torch.arange(N + 1, dtype=torch.int64, device=dev) * k, col_global=cols.reshape(-1), val=vals.reshape(-1),
+                   y=y, offset=offset, weight=None)
+        return raw, n, ids
+
+
+def subset_raw(raw, n, ents):
+    """Entities `ents` (any order) of a device raw batch with a constant number of non-zeros per sample, as a raw batch of their own
+    in HBM — what the re-balancer's exchange makes of a partition, without the ranks (bench_strong's projection of a plan)."""
+    import torch
+    ents = np.asarray(ents, np.int64)
+    ptr = np.concatenate([[0], np.cumsum(n)])
+    k = raw["Z"] // max(1, raw["N"])
+    ne = n[ents]
+    out_start = np.cumsum(ne) - ne
+    N = int(ne.sum())
+    dev = raw["y"].device
+    rows = torch.from_numpy(np.arange(N, dtype=np.int64) - np.repeat(out_start, ne) + np.repeat(ptr[ents], ne)).to(dev)
+    return dict(E=int(ents.size), N=N, Z=N * k, ent_row_ptr=torch.from_numpy(np.concatenate([[0], np.cumsum(ne)])).to(dev),
+                row_nnz_ptr=torch.arange(N + 1, dtype=torch.int64, device=dev) * k,
+                col_global=raw["col_global"].reshape(-1, k)[rows].reshape(-1), val=raw["val"].reshape(-1, k)[rows].reshape(-1),
+                y=raw["y"][rows], offset=raw["offset"][rows], weight=None), ne
+
+
+def concat_raw(parts):
+    """Raw batches (constant non-zeros per sample, no weights) one after another as one raw batch in HBM."""
+    import torch
+    parts = [p for p in parts if p["E"] > 0]
+    if len(parts) == 1:
+        return parts[0]
+    k = parts[0]["Z"] // max(1, parts[0]["N"])
+    N = sum(p["N"] for p in parts)
+    dev = parts[0]["y"].device
+    ptrs, base = [torch.zeros(1, dtype=torch.int64, device=dev)], 0
+    for p in parts:
+        ptrs.append(p["ent_row_ptr"][1:] + base)
+        base += p["N"]
+    return dict(E=sum(p["E"] for p in parts), N=N, Z=N * k, ent_row_ptr=torch.cat(ptrs),
+                row_nnz_ptr=torch.arange(N + 1, dtype=torch.int64, device=dev) * k, col_global=torch.cat([p["col_global"] for p in parts]),
+                val=torch.cat([p["val"] for p in parts]), y=torch.cat([p["y"] for p in parts]), offset=torch.cat([p["offset"] for p in parts]),
+                weight=None)
+
+
 def device_entities_to_host(raw, n, ents):
     """The entities `ents` of a device raw batch with a constant number of non-zeros per sample (make_c5_share_device) as a
     host RawBatch (for comparing a sample with the CPU checker)."""

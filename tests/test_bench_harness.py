@@ -171,7 +171,8 @@ def test_strong_scaling_splits_one_population_and_rebalancing_returns_the_same_m
 def test_projection_of_an_eight_rank_job_on_one_device(tmp_path):
     """--gpus 1: the shares of an 8-rank job solved one after another (detail.strong_projection), with the re-balancing plan."""
     line = _line(["--entities", "20000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-fe", "--no-cli",
-                  "--ml-entities", "8000", "--c5-entities", "20000", "--project-ranks", "8"], tmp_path, timeout=1500)
+                  "--ml-entities", "8000", "--c5-entities", "20000", "--project-ranks", "8", "--c5-full-entities", "400000", "--c5-full-rounds", "3"],
+                 tmp_path, timeout=1500)
     proj = {p["workload"]: p for p in line["detail"]["strong_projection"]}
     assert set(proj) == {"ml20m_user", "ml20m_movie", "c5"} and line["strong_scaling"] is None
     assert proj["ml20m_user"]["total_entities"] == 8000 and proj["c5"]["total_entities"] == 160000
@@ -181,3 +182,13 @@ def test_projection_of_an_eight_rank_job_on_one_device(tmp_path):
         assert abs(p["ms"] - max(r["ms_per_step"] for r in p["per_rank"])) < 1e-9
         plan = p["rebalance_plan"]
         assert plan["after_imbalance"] <= plan["predicted_imbalance"] + 1e-9
+    # C5 at the product path's granularity: worker 0's 128 partitions of ONE population (here 400 k entities), one partition per round,
+    # serial and over three contexts; the first rounds of the whole 8-worker job plain and with the re-balancing plan applied
+    fs = line["detail"]["c5_full_share"]
+    assert fs["partitions"] == 128 and fs["converged"] == fs["converged_pipelined"] == fs["entities"] and 40_000 < fs["entities"] < 60_000
+    assert len(fs["round_ms"]) == 128 and fs["round_ms_p50"] <= fs["round_ms_p99"] <= fs["round_ms_max"] and fs["s"] > 0 and fs["serial_s"] > 0
+    pr = fs["projected_rounds"]
+    assert len(pr["rounds"]) == 3 and pr["rounds"][0]["priced_by"] == "non-zeros" and pr["rounds"][1]["priced_by"].startswith("measured")
+    assert all(len(r["plain_ms"]) == 8 and len(r["rebalanced_ms"]) == 8 and r["imbalance"] >= 1.0 for r in pr["rounds"])
+    short = line["_short"]["summary"]["c5_full_share"]
+    assert short["entities"] == fs["entities"] and short["rounds"] == 3

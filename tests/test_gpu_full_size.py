@@ -159,3 +159,71 @@ def test_c5_share_properties(device_solver):
     # the entities at the 2^20 cap sit in the 32-team tier (the 8-team and device-wide tiers start at 2^21 and 2^24 non-zeros:
     # tests/test_gpu_parity.py::test_large_and_giant_entities_pack_and_solve drives those)
     assert any("32 teams" in s for s in present) and any("128 teams" in s for s in present) and any("workgroup" in s for s in present), present
+
+
+def test_c5_full_share_streams_all_its_partitions(device_solver):
+    """BASELINE configs[4] at its REAL per-GPU share and at the product path's granularity: ONE population of
+    100 M Zipf-sized entities hashed into 1 024 partitions by the Java hash of the decimal id; worker 0 of 8 trains
+    partitions[0::8] — 128 partitions, 12.5 M entities, 3.2 G non-zeros — one partition per round
+    (drivers/random_effect_driver.py:60-68). Every partition is generated in HBM, packed and solved; every entity must end with one
+    of fmin_l_bfgs_b's outcomes; and from every partition a sample STRATIFIED BY KERNEL CLASS (the giants included; at most
+    ~1.5 M non-zeros per class and partition) goes to the oracle: same stop, same iteration count, coefficients to 1e-7, for the
+    entities the checker itself reproduces under rounding-sized noise (the rule of _full_size_properties), 1e-5 / the objective for
+    the rest."""
+    import torch
+    o = SolverOptions(**KW)
+    dev_pids = lambda ids, parts: device_solver.partition_ids(np.ascontiguousarray(ids, np.int64), parts).cpu().numpy()
+    pop = synthetic.C5Population(100_000_000, 1024, partition_ids_fn=dev_pids)
+    mine = synthetic.rank_partitions(1024, 8, 0)
+    assert len(mine) == 128 and pop.part_ptr[-1] == 100_000_000
+    total = sum(int(pop.part_ptr[K + 1] - pop.part_ptr[K]) for K in mine)
+    assert 12_300_000 < total < 12_700_000
+    rng = np.random.default_rng(4)
+    status_hist = np.zeros(5, np.int64)
+    classes_seen, checked, strict_n, same_n, worst = {}, 0, 0, 0, 0.0
+    biggest = 0
+    for K in mine:
+        raw, n, ids = pop.partition(K, device_solver.device)
+        z = n * pop.k
+        biggest = max(biggest, int(z.max()))
+        packed = device_solver.pack(raw)
+        res = device_solver.solve(packed, o).to_host()
+        assert np.isin(res["status"], (0, 1, 2)).all(), (K, np.bincount(res["status"] + 1))
+        status_hist += np.bincount(res["status"], minlength=5)[:5]
+        assert res["gnorm"][res["status"] == 0].max() <= 1e-5
+        cls = packed._view(packed.c.cls_tmp, packed.E, torch.int32).cpu().numpy()
+        names = _class_names(device_solver, packed)
+        sample, taken = stratified_sample(cls, z, rng, total=16, nnz_budget_per_class=1_500_000)
+        for c, t in taken.items():
+            classes_seen[names[c]] = classes_seen.get(names[c], 0) + t
+        hb = synthetic.device_entities_to_host(raw, n, sample)
+        pk, ref = oracle_solve_parallel(hb, KW)
+        coef_ptr = packed.coef_ptr_host()
+        sub_ptr = np.concatenate([[0], np.cumsum(np.diff(coef_ptr)[sample])])
+        assert np.array_equal(np.diff(sub_ptr), np.diff(pk["ent_feat_ptr"]) + 1)
+        sub_theta = res["theta"][_ranges(coef_ptr[sample], np.diff(coef_ptr)[sample])]
+        err = per_entity_rel_err(sub_theta, ref["theta"], sub_ptr)
+        ones = np.add.reduceat(hb.y.astype(np.float64), hb.ent_row_ptr[:-1])
+        sw = (ones > 0) & (ones < hb.ent_n())
+        _, ref2 = oracle_solve_parallel(hb, KW, theta0=1e-14 * rng.standard_normal(int(sub_ptr[-1])))
+        wobble = per_entity_rel_err(ref2["theta"], ref["theta"], sub_ptr)
+        strict = sw & (wobble <= 1e-9) & (ref2["nit"] == ref["nit"]) & (ref2["status"] == ref["status"])
+        same = strict & (res["nit"][sample] == ref["nit"]) & (res["status"][sample] == ref["status"])
+        if same.any():
+            assert err[same].max() <= REL_TOL_DEVICE, (K, err[same].max())
+            worst = max(worst, float(err[same].max()))
+        differ = strict & ~same
+        if differ.any():
+            assert err[differ].max() <= REL_TOL_NORTH_STAR, (K, err[differ].max())
+        loose = sw & ~strict
+        if loose.any():
+            np.testing.assert_allclose(res["fval"][sample][loose], ref["fval"][loose], rtol=1e-6)
+        checked += int(sw.sum()); strict_n += int(strict.sum()); same_n += int(same.sum())
+        del raw, packed, res
+    print(f"\nC5 full share: {total} entities in 128 partitions, status {status_hist.tolist()}, largest entity {biggest} non-zeros; oracle sample "
+          f"{checked} well-posed entities, {strict_n} strictly comparable, {same_n} with the same iteration count, worst theta rel err {worst:.2e}")
+    for nm, t in sorted(classes_seen.items()):
+        print(f"   sampled {t:5d} of class {nm}")
+    assert status_hist.sum() == total and status_hist[0] >= 0.9 * total
+    assert biggest >= 1 << 20 and any("teams" in nm for nm in classes_seen) and any("workgroup" in nm for nm in classes_seen)
+    assert strict_n >= 0.95 * checked and same_n >= 0.97 * strict_n

@@ -1,10 +1,10 @@
 #!/bin/bash
+# A/B of builds on the fixed-effect bench (uniform + zipf), then the tests of the touched paths: gpurun -- bash tools/fe_session2.sh <out> <build> ...
 O=gpurun_out/$1; shift; mkdir -p $O
 BUILDS="$*"
 cd $GRAFT_REPO_ROOT
 cp gdmix_amd/libgdmix_re.so /tmp/lib_keep.so
-for rep in 1 2; do for v in $BUILDS; do DISTS=uniform bash tools/fe_ab.sh $v 2>&1; done; done | tee $O/ab.txt
+for rep in 1 2 3; do for v in $BUILDS; do bash tools/fe_ab.sh $v 2>&1; done; done | tee $O/ab.txt
 cp /tmp/lib_keep.so gdmix_amd/libgdmix_re.so
-timeout 1500 python -m pytest tests/test_fixed_effect.py tests/test_gpu_chain.py -m gpu -x -q > $O/tests.log 2>&1
-echo "tests rc=$?"; tail -15 $O/tests.log | cut -c1-400
-PYTHONPATH=. timeout 600 python tools/chain_demo.py 2>&1 | grep -v "^INFO" | tail -12
+timeout 2400 python -m pytest tests/test_fixed_effect.py tests/test_fe_model.py tests/test_gpu_chain.py tests/test_gpu_parity.py tests/test_rebalance.py tests/test_bench_harness.py -m gpu -x -q > $O/tests.log 2>&1
+echo "tests rc=$?"; tail -5 $O/tests.log | cut -c1-400
