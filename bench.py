@@ -1047,7 +1047,12 @@ def main():
         else:
             with open(tpath) as fh:
                 tj = json.load(fh)
-            if tj.get("_workload") != workload_id:
+            from gdmix_amd import build as _b
+            lib_abi = int(solver.lib.gdmix_re_abi_version())
+            if tj.get("_re_abi") != lib_abi or tj.get("_re_kernel_sources_sha16") != _b.kernel_source_hash():
+                traffic_note = (f"profiles/latest_traffic.json is stale: collected on ABI {tj.get('_re_abi')} / kernel sources {tj.get('_re_kernel_sources_sha16')}, "
+                                f"this library is ABI {lib_abi} / {_b.kernel_source_hash()} (tools/profile_round.sh collects it again)")
+            elif tj.get("_workload") != workload_id:
                 traffic_note = f"PMC passes were collected on workload {tj.get('_workload')!r}, this run is {workload_id!r}"
             elif classes[dom][0] not in tj:
                 traffic_note = f"no PMC pass holds the dominant class {classes[dom][0]!r}"

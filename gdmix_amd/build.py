@@ -26,6 +26,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvi
          "-Wall", "-Wno-unused-function", "-mllvm", "-disable-machine-licm"]
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the sources of the random-effect kernels (csrc/re_*): what PMC evidence collected on one
+    build of the library is stamped with (profiles/latest_traffic.json), so that bench.py can tell a stale file from a current one."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, "re_*"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

@@ -154,7 +154,7 @@ def load_library():
     lib.gdmix_java_partition_id.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     lib.gdmix_java_partition_id.restype = C.c_int32
     lib.gdmix_java_partition_ids_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
-    if lib.gdmix_re_abi_version() != 9:
+    if lib.gdmix_re_abi_version() != 10:
         raise GdmixReError("libgdmix_re.so ABI version mismatch")
     _lib = lib
     return lib

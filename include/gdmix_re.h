@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GDMIX_RE_ABI_VERSION 9
+#define GDMIX_RE_ABI_VERSION 10
 
 #if defined(__GNUC__)
 #define GDMIX_API __attribute__((visibility("default")))

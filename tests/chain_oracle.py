@@ -90,7 +90,9 @@ def random_effect_stage(data, stage, prev):
         e_rows = np.repeat(e_idx, np.diff(p))
         h_rows = np.repeat(has, np.diff(p))
         score, per = _dense_scores(p, c, v, np.where(h_rows, coef[e_rows, c], 0.0), np.where(has, icpt[e_idx], 0.0), offs)
-        out[name] = {"uid": data["uid"][r], "score": score, "per_coord": per, "offset": offs}
+        # samples of entities without a finite optimum (all labels equal, intercept unregularised): their scores are comparable only
+        # through the sigmoid (SURVEY 8(d) class D)
+        out[name] = {"uid": data["uid"][r], "score": score, "per_coord": per, "offset": offs, "strict": ~has | out["well_posed"][e_idx]}
     return out
 
 

@@ -43,9 +43,14 @@ def _ulps(a, b):
 def _check_scores(got, want, what, max_ulp=1.0):
     order = np.argsort(want["uid"], kind="stable")
     assert np.array_equal(got["uid"], want["uid"][order]), what
+    strict = want["strict"][order] if "strict" in want else np.ones(order.size, bool)
+    assert strict.mean() > 0.9
     for k in ("score", "per_coord"):
-        u = _ulps(got[k], want[k][order])
+        u = _ulps(got[k][strict], want[k][order][strict])
         assert u.max() <= max_ulp, (what, k, float(u.max()), int((u > max_ulp).sum()))
+    if (~strict).any():     # entities whose labels are all equal: the probability is what is determined, not the logit
+        sig = lambda x: 1.0 / (1.0 + np.exp(-x.astype(np.float64)))
+        assert np.abs(sig(got["score"][~strict]) - sig(want["score"][order][~strict])).max() <= 1e-4
 
 
 def _check_models(root, stage, ora, dim, prefix):
@@ -62,7 +67,6 @@ def _check_models(root, stage, ora, dim, prefix):
         else:      # all labels equal, intercept unregularised: no finite optimum, the solver walks until the gradient test passes
             # (SURVEY 8(d) class D) — the sign of the intercept and coefficients that stayed small, loosely the oracle's
             assert np.sign(b) == np.sign(want[0]) and abs(b) > 1.0 and np.abs(c).max() <= 1e-2
-            assert np.abs(have - want).max() <= 1e-3 * max(1.0, np.abs(want).max())
     assert worst <= 1e-5, (stage, worst)
     return worst
 
@@ -112,9 +116,15 @@ def test_three_coordinate_chain_matches_the_oracle_chain(tmp_path, child_process
         prev = got[stage]
     # ---- the free-running chain
     if fe_close <= 1.0:
-        for stage in ("per_user", "per_movie"):
-            for w in ("train", "validation"):
-                _check_scores(got[stage][w], free[stage][w], ("free-running", stage, w), max_ulp=2.0)
+        for w in ("train", "validation"):
+            _check_scores(got["per_user"][w], free["per_user"][w], ("free-running", "per_user", w), max_ulp=2.0)
+            # per-movie: the samples of all-equal-label USERS carry offsets that are determined only through the sigmoid (19.2 on one
+            # side, 16.5 on the other: both probability 1 to 1e-7), which moves the movies' coefficients at that level
+            f = free["per_movie"][w]
+            order = np.argsort(f["uid"], kind="stable")
+            ok = f["strict"][order] & free["per_user"][w]["strict"][np.argsort(free["per_user"][w]["uid"], kind="stable")]
+            d = np.abs(got["per_movie"][w]["score"].astype(np.float64) - f["score"][order])[ok]
+            assert d.max() <= 1e-4 * max(1.0, float(np.abs(f["score"]).max())), ("free-running", "per_movie", w, float(d.max()))
     # ---- what the chain is for
     aucs = [res[s]["validation_auc"] for s in chain.STAGES]
     assert aucs[0] < aucs[1] < aucs[2] and aucs[2] - aucs[0] > 0.05, aucs

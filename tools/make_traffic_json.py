@@ -59,5 +59,12 @@ for k, (n, s) in f.items():
     res[cn].update(extra.get(k, {}))
 if workload:
     res["_workload"] = workload
+# what the counters were collected on: bench.py nulls roofline.traffic when the library it runs is another one
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gdmix_amd import build as _build          # noqa: E402
+from gdmix_amd import solver as _solver        # noqa: E402
+res["_re_abi"] = int(_solver.load_library().gdmix_re_abi_version())
+res["_re_kernel_sources_sha16"] = _build.kernel_source_hash()
 json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
