@@ -442,6 +442,18 @@ def cli_shape_leg(kind, entities):
                     "shape: TFRecord decode, upload, pack, solve, scoring of the training data, model + score Avro"}
 
 
+def lbfgs_state_bytes(p, nit, nfev, opts_m=10):
+    """What the compact-form L-BFGS itself moves per entity when its state does not fit on chip (re_solve_team.hpp): every
+    evaluation reads the stored pairs once for the 2m products fused into the gradient's epilogue, every iteration reads them
+    once more for the direction and writes the new pair (16 B per pair and coefficient), and the five p-vectors x, g, d, t, r are
+    read and written once per evaluation (80 B per coefficient). pairs at iteration k = min(k, m)."""
+    p, nit, nfev = np.asarray(p, np.float64), np.asarray(nit, np.float64), np.asarray(nfev, np.float64)
+    full = np.maximum(nit - opts_m, 0.0)
+    pairs_sum = np.minimum(nit, opts_m) * (np.minimum(nit, opts_m) + 1.0) / 2.0 + full * opts_m      # sum over iterations of the pairs stored
+    mean_pairs = np.where(nit > 0, pairs_sum / np.maximum(nit, 1.0), 0.0)
+    return float((p * (16.0 * pairs_sum + 16.0 * mean_pairs * nfev + 16.0 * nit + 80.0 * nfev)).sum())
+
+
 class Workload:
     """What a step runs on: a raw batch in HBM (`raw_dev`, the dict REDeviceSolver.pack takes) plus the per-entity host arrays
     the accounting needs (samples, non-zeros, label sums) and a way to get some entities as a host RawBatch (CPU leg)."""
@@ -577,11 +589,17 @@ def other_workloads_leg(a, rank, world, solver, opts, coll_dev):
             nfev_e = res.nfev.cpu().numpy().astype(np.float64)
             b_alg = float((8.0 * wl.z[sel] + 16.0 * n[sel] + 8.0 * p_e[sel] + 32.0).sum())
             b_str = float((nfev_e[sel] * (8.0 * wl.z[sel] + 16.0 * n[sel]) + 8.0 * p_e[sel] + 32.0).sum())
+            b_state = lbfgs_state_bytes(p_e[sel], res.nit.cpu().numpy()[sel], nfev_e[sel], opts_m=10)
             dms = float(kernel_ms[dom_c])
             roof = {"kernel": classes[dom_c][0], "entities_in_launch": int(sel.sum()), "avg_launch_ms": dms,
                     "alg_bytes_per_launch": b_alg, "achieved_GBps": b_alg / (dms * 1e-3) / 1e9, "frac_of_hbm_peak": b_alg / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "restreamed_bytes_per_launch": b_str, "restreamed_GBps": b_str / (dms * 1e-3) / 1e9,
                     "restreamed_frac_of_hbm_peak": b_str / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, "mean_nfev": float(nfev_e[sel].mean()),
+                    "lbfgs_state_bytes_per_launch": b_state, "restreamed_plus_state_GBps": (b_str + b_state) / (dms * 1e-3) / 1e9,
+                    "restreamed_plus_state_frac_of_hbm_peak": (b_str + b_state) / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "state_note": "for entities that do not stay on chip (team kernels) the L-BFGS state is streamed as well: per evaluation the m-pair history "
+                                  "once for the products fused into the gradient and per iteration once more for the direction (16 B x pairs x p each) plus the five "
+                                  "p-vectors — lbfgs_state_bytes() below; for the resident classes (group kernels) it never leaves the CU and the figure does not apply",
                     "avg_launch_ms_in_the_timed_steps": float(kernel_ms_timed[dom_c]),
                     "note": "B(e) of SURVEY 8(d) over the launch's entities / its HIP-event duration in one more step with the size classes one after another "
                             "(gdmix_re_set_spread 0; side by side, as in the timed steps, launches stretch each other); restreamed = nfev x (8 nnz + 16 n) + 8 p + 32"}
@@ -706,6 +724,7 @@ def compact_line(full, detail_file):
         put(w + "_ms", _get(d, "workloads", w, "ms_per_step"))
         put(w + "_eps", _get(d, "workloads", w, "entities_per_s"))
     put("c5share_dom_restreamed_frac", _get(d, "workloads", "c5share", "roofline", "restreamed_frac_of_hbm_peak"))
+    put("c5share_dom_stream_plus_state_frac", _get(d, "workloads", "c5share", "roofline", "restreamed_plus_state_frac_of_hbm_peak"))
     put("cli_cold_eps", _get(d, "cli_end_to_end", "cold_entities_per_s"))
     put("cli_warm_eps", _get(d, "cli_end_to_end", "warm_start_entities_per_s"))
     put("cli_child_s", _get(d, "cli_subprocess", "cold_s"))
