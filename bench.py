@@ -1043,6 +1043,7 @@ def main():
         nfev = res.nfev.double().mean().item()
         nit = res.nit.double().mean().item()
         nfev_e = res.nfev.cpu().numpy().astype(np.float64)
+        nit_e = res.nit.cpu().numpy().astype(np.float64)
         # the re-streamed figure of SURVEY.md §8(d), B_stream(e) = nfev (8 nnz + 16 n) + 8 p + 32: what a design that does not keep
         # the entity resident moves — and for the classes whose entities do not fit on chip (team kernels) the algorithmic figure
         b_s = nfev_e * (8.0 * z + 16.0 * n) + 8.0 * p + 32.0
@@ -1053,6 +1054,7 @@ def main():
             per_class.append({"kernel": classes[c][0], "entities": int(sel.sum()), "ms": round(float(cls_ms[c]), 3),
                               "alg_GBps": round(float(b_e[sel].sum()) / (cls_ms[c] * 1e-3) / 1e9, 2),
                               "restreamed_GBps": round(float(b_s[sel].sum()) / (cls_ms[c] * 1e-3) / 1e9, 2),
+                              "lbfgs_state_GB": round(lbfgs_state_bytes(p[sel], nit_e[sel], nfev_e[sel], a.lbfgs_m) / 1e9, 3) if "team" in classes[c][0] else None,
                               "mean_n": round(float(n[sel].mean()), 1), "mean_p": round(float(p[sel].mean()), 1),
                               "max_nnz": int(z[sel].max()), "mean_nfev": round(float(nfev_e[sel].mean()), 2)})
         traffic = traffic_detail = valu = None

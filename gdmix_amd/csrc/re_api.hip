@@ -6,6 +6,8 @@
 
 #include <new>
 
+#include <mutex>
+
 #include "re_internal.hpp"
 #include "re_solve_team.hpp"
 
@@ -117,6 +119,26 @@ static BatchDev make_batch_dev(const gdmix_re_packed* b) {
 
 using namespace gdmix;
 
+
+namespace gdmix {
+namespace {
+constexpr int GATE_DEVICES = 64;
+std::mutex g_gate_mu[GATE_DEVICES];
+hipEvent_t g_gate_ev[GATE_DEVICES] = {};
+bool g_gate_armed[GATE_DEVICES] = {};
+}  // namespace
+
+ScopedGridGate::ScopedGridGate(int device, hipStream_t s) : device_(device >= 0 && device < GATE_DEVICES ? device : 0), s_(s), err_(hipSuccess) {
+  g_gate_mu[device_].lock();
+  if (!g_gate_ev[device_]) err_ = hipEventCreateWithFlags(&g_gate_ev[device_], hipEventDisableTiming);
+  if (err_ == hipSuccess && g_gate_armed[device_]) err_ = hipStreamWaitEvent(s_, g_gate_ev[device_], 0);
+}
+
+ScopedGridGate::~ScopedGridGate() {
+  if (g_gate_ev[device_] && hipEventRecord(g_gate_ev[device_], s_) == hipSuccess) g_gate_armed[device_] = true;
+  g_gate_mu[device_].unlock();
+}
+}  // namespace gdmix
 
 extern "C" {
 

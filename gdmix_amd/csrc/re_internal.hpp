@@ -275,6 +275,24 @@ void set_error(const char* fmt, ...);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: one flag per call site would leave the
 // second device of a process at the 64 KB default. One of these per call site (static), a bit per device.
+// Persistent grids (the multi-workgroup team tiers, the device-wide kernel, the tall teams) need ALL their workgroups resident at
+// once — they meet at barriers — and one such grid takes a whole CU per workgroup (512 threads at two wavefronts per SIMD, or a
+// whole CU's LDS). Two of them started at the same time from two contexts of a process (a host pipeline over several contexts:
+// model.py, bench.py's hand-over and full-share legs) can each get half the device and wait for the other half until the
+// barrier's watchdog gives up (round 5: 2 of 12.5 M entities ABORTED, 5 s lost, with three contexts on Zipf-sized partitions).
+// The gate chains them per device: a grid's launch waits (on the device, stream-ordered: the host does not block) for the
+// previous grid of ANY context of this process to finish. ScopedGridGate: construct before the launch, destroy after it.
+class ScopedGridGate {
+ public:
+  ScopedGridGate(int device, hipStream_t s);
+  ~ScopedGridGate();
+  hipError_t status() const { return err_; }
+ private:
+  int device_;
+  hipStream_t s_;
+  hipError_t err_;
+};
+
 struct DynLdsOnce {
   unsigned long long done = 0;   // (set twice by racing threads at worst: the call is idempotent)
   hipError_t set(const void* fn, int bytes = 160 * 1024) {

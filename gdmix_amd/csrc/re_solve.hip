@@ -704,6 +704,10 @@ hipError_t launch_solve_grid(const BatchDev& B, const OutDev& O, const SolvePara
   // GDMIX_RE_XCD_BARRIER=0: every barrier with the full release (A/B and tests); default: measured per team (Team::team_placement)
   const char* xe = getenv("GDMIX_RE_XCD_BARRIER");
   const int xcd_barrier = (xe && atoi(xe) == 0) ? 0 : 1;
+  int device = 0;
+  (void)hipGetDevice(&device);
+  ScopedGridGate gate(device, s);      // one persistent grid at a time per device, whatever context it comes from (re_internal.hpp)
+  if (gate.status() != hipSuccess) return gate.status();
   hipLaunchKernelGGL((re_solve_team_kernel<TEAM_GRID_NW, true>), dim3(blocks), dim3(WAVE * TEAM_GRID_NW), 0, s, B, O, o,
                      theta0, begin, count, scratch, slot_doubles, max_p, static_cast<TeamSync*>(sync_buf), teams, 0, xcd_barrier);
   return hipGetLastError();

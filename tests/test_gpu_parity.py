@@ -487,6 +487,58 @@ def test_team_tiers_give_the_same_bits_run_after_run_under_load(device_solver):
             assert np.array_equal(first[k], r[k]), k
 
 
+def test_contexts_with_persistent_grids_at_the_same_time(device_solver):
+    """Round 5: three contexts of one process that all launch multi-workgroup team tiers (persistent grids that meet at barriers,
+    one CU per workgroup) used to be able to split the device between two grids, each waiting for workgroups the other one's
+    held — until the barrier's watchdog gave up and marked entities ABORTED (2 of 12.5 M on the full C5 share, with 5 s lost).
+    The grids of a device are now chained whatever context they come from (ScopedGridGate): three threads, each with its own context
+    and stream, solve a batch routed through the 128- and 32-team tiers ten times at once; every run ends with fmin_l_bfgs_b's own
+    outcomes and the bits of the run done alone."""
+    import threading
+    import torch
+    from gdmix_amd.solver import REDeviceSolver
+    kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
+    results, errors = {}, []
+
+    def worker(i):
+        try:
+            s2 = REDeviceSolver(0)
+            s2.set_team_nnz(64)
+            st = torch.cuda.Stream()
+            b = synthetic.make_batch(600, 32, 8, 65536, seed=191 + i, size_dist="zipf")
+            with torch.cuda.stream(st):
+                pk = s2.pack(b)
+                alone.wait()              # (every context packed; the first solves below start together)
+                out = []
+                for _ in range(10):
+                    out.append(s2.solve(pk, SolverOptions(**kw)).to_host())
+                    st.synchronize()
+            results[i] = (b, out, dict(s2.class_counts(pk)))
+            s2.close()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+            alone.abort()
+    alone = threading.Barrier(3)
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    try:
+        device_solver.set_team_nnz(64)
+        for i in range(3):
+            b, outs, counts = results[i]
+            assert counts["re_solve_team_kernel 128 teams"] > 20 and counts["re_solve_team_kernel 32 teams"] > 2, counts
+            ref = device_solver.solve(device_solver.pack(b), SolverOptions(**kw)).to_host()
+            assert np.all(ref["status"] <= 2)
+            for r in outs:
+                for k in ("theta", "fval", "nit", "nfev", "status"):
+                    assert np.array_equal(ref[k], r[k]), (i, k)
+    finally:
+        device_solver.set_team_nnz(16384)
+
+
 def test_results_are_bitwise_reproducible(device_solver):
     b = synthetic.make_batch(2000, 16, 4, 1024, seed=5)
     packed = device_solver.pack(b)
