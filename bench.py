@@ -442,16 +442,25 @@ def cli_shape_leg(kind, entities):
                     "shape: TFRecord decode, upload, pack, solve, scoring of the training data, model + score Avro"}
 
 
-def lbfgs_state_bytes(p, nit, nfev, opts_m=10):
-    """What the compact-form L-BFGS itself moves per entity when its state does not fit on chip (re_solve_team.hpp): every
-    evaluation reads the stored pairs once for the 2m products fused into the gradient's epilogue, every iteration reads them
-    once more for the direction and writes the new pair (16 B per pair and coefficient), and the five p-vectors x, g, d, t, r are
-    read and written once per evaluation (80 B per coefficient). pairs at iteration k = min(k, m)."""
+def lbfgs_state_bytes(p, nit, nfev, opts_m=10, n=None, one_workgroup=False):
+    """What the compact-form L-BFGS itself moves per entity when its state does not fit on chip (re_solve_team.hpp), an ESTIMATE
+    from the iteration counts: every evaluation reads the stored pairs once for the 2m products fused into the gradient's
+    epilogue, every iteration reads them once more for the direction and writes the new pair (16 B per pair and coefficient), and
+    the five p-vectors x, g, d, t, r are read and written once per evaluation (16 B per vector and coefficient) — unless they sit
+    in the LDS a one-workgroup entity's workgroup leaves free (csrc/re_solve.hip: team_vec_level — five vectors and the residuals
+    if they fit into 15 290 doubles, else three, else x alone). pairs at iteration k = min(k, m). Calibration on Zipf-1M
+    (profiles/r05_zipf_1m.txt): 8 + 213 GB estimated for the one-workgroup class against 82.6 GB FETCH_SIZE (x 2 for its 16-byte
+    loads, MI355X_MICROARCH.md) + 25.1 GB WRITE_SIZE = 190 GB counted."""
     p, nit, nfev = np.asarray(p, np.float64), np.asarray(nit, np.float64), np.asarray(nfev, np.float64)
     full = np.maximum(nit - opts_m, 0.0)
     pairs_sum = np.minimum(nit, opts_m) * (np.minimum(nit, opts_m) + 1.0) / 2.0 + full * opts_m      # sum over iterations of the pairs stored
     mean_pairs = np.where(nit > 0, pairs_sum / np.maximum(nit, 1.0), 0.0)
-    return float((p * (16.0 * pairs_sum + 16.0 * mean_pairs * nfev + 16.0 * nit + 80.0 * nfev)).sum())
+    vectors = np.full(p.shape, 5.0)
+    if one_workgroup and n is not None:
+        n = np.asarray(n, np.float64)
+        arena = 15290.0
+        vectors = np.where(5 * p + n <= arena, 0.0, np.where(3 * p + n <= arena, 2.0, np.where(p + n <= arena, 4.0, 5.0)))
+    return float((p * (16.0 * pairs_sum + 16.0 * mean_pairs * nfev + 16.0 * nit + 16.0 * vectors * nfev)).sum())
 
 
 class Workload:
@@ -589,7 +598,7 @@ def other_workloads_leg(a, rank, world, solver, opts, coll_dev):
             nfev_e = res.nfev.cpu().numpy().astype(np.float64)
             b_alg = float((8.0 * wl.z[sel] + 16.0 * n[sel] + 8.0 * p_e[sel] + 32.0).sum())
             b_str = float((nfev_e[sel] * (8.0 * wl.z[sel] + 16.0 * n[sel]) + 8.0 * p_e[sel] + 32.0).sum())
-            b_state = lbfgs_state_bytes(p_e[sel], res.nit.cpu().numpy()[sel], nfev_e[sel], opts_m=10)
+            b_state = lbfgs_state_bytes(p_e[sel], res.nit.cpu().numpy()[sel], nfev_e[sel], opts_m=10, n=n[sel], one_workgroup=classes[dom_c][0].endswith("workgroup"))
             dms = float(kernel_ms[dom_c])
             roof = {"kernel": classes[dom_c][0], "entities_in_launch": int(sel.sum()), "avg_launch_ms": dms,
                     "alg_bytes_per_launch": b_alg, "achieved_GBps": b_alg / (dms * 1e-3) / 1e9, "frac_of_hbm_peak": b_alg / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -1054,7 +1063,8 @@ def main():
             per_class.append({"kernel": classes[c][0], "entities": int(sel.sum()), "ms": round(float(cls_ms[c]), 3),
                               "alg_GBps": round(float(b_e[sel].sum()) / (cls_ms[c] * 1e-3) / 1e9, 2),
                               "restreamed_GBps": round(float(b_s[sel].sum()) / (cls_ms[c] * 1e-3) / 1e9, 2),
-                              "lbfgs_state_GB": round(lbfgs_state_bytes(p[sel], nit_e[sel], nfev_e[sel], a.lbfgs_m) / 1e9, 3) if "team" in classes[c][0] else None,
+                              "lbfgs_state_GB": round(lbfgs_state_bytes(p[sel], nit_e[sel], nfev_e[sel], a.lbfgs_m, n=n[sel], one_workgroup=classes[c][0].endswith("workgroup")) / 1e9, 3)
+                              if "team" in classes[c][0] else None,
                               "mean_n": round(float(n[sel].mean()), 1), "mean_p": round(float(p[sel].mean()), 1),
                               "max_nnz": int(z[sel].max()), "mean_nfev": round(float(nfev_e[sel].mean()), 2)})
         traffic = traffic_detail = valu = None

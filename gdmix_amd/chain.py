@@ -162,7 +162,7 @@ def read_scores(score_dir):
             np.array([np.nan if x is None else x for x in lab], np.float32))
 
 
-def partition_stage(root, data, stage, prev_train_scores, prev_valid_scores, num_partitions=4):
+def partition_stage(root, data, stage, prev_train_scores, prev_valid_scores, num_partitions=4, upper_bound=None):
     """The Spark partition job ahead of a random-effect stage (DataPartitioner.scala:203-380), host side: offsets from the previous
     stage's score files (update_offsets: inner join on uid, FLOAT), grouping by entity, Java-hash partition ids, active/ layout."""
     ent_col = data["entity"][stage]
@@ -175,8 +175,10 @@ def partition_stage(root, data, stage, prev_train_scores, prev_valid_scores, num
         keep, off = partitioner.update_offsets(data["uid"][rows_all], s_uid, s_score)
         rows = rows_all[keep]
         ptr, cols, vals, dim = bag_rows(data, stage, rows)
+        # training data: an entity with more than upper_bound samples keeps group 0 (uid mod (count / upper_bound + 1)) as ACTIVE data,
+        # trained on; its other groups are PASSIVE data, only scored (DataPartitioner.scala:322-380)
         batches = partitioner.build_batches(ent[rows], data["uid"][rows], data["response"][rows].astype(np.float32), off, None, ptr, cols, vals,
-                                            num_partitions, split=split)
+                                            num_partitions, upper_bound=upper_bound if split else None, split=split)
         partitioner.write_partitions(os.path.join(out, name), batches, ent_col, stage, int_entity_ids=True, weight_column_name=None)
         if split:
             parts |= {p for (_, p) in batches}
@@ -249,8 +251,9 @@ def auc(label, score):
     return float((ranks[pos].sum() - n1 * (n1 + 1) / 2.0) / (n1 * n0)) if n1 and n0 else float("nan")
 
 
-def run_chain(root, data, num_partitions=4, child_process=False, log=None):
-    """global -> per_user -> per_movie under `root`; -> {stage: {"s", "partition_s", "train_auc", "validation_auc"}, "total_s"}."""
+def run_chain(root, data, num_partitions=4, child_process=False, log=None, upper_bounds=None):
+    """global -> per_user -> per_movie under `root`; -> {stage: {"s", "partition_s", "train_auc", "validation_auc"}, "total_s"}.
+    upper_bounds: {stage: active-data bound per entity} (the rest of a larger entity's samples is passive data)."""
     os.makedirs(root, exist_ok=True)
     write_global_inputs(root, data)
     out = {}
@@ -260,7 +263,8 @@ def run_chain(root, data, num_partitions=4, child_process=False, log=None):
         t_part = 0.0
         if stage != "global":
             t = time.perf_counter()
-            partition_stage(root, data, stage, os.path.join(root, prev, "trainingScores"), os.path.join(root, prev, "validationScores"), num_partitions)
+            partition_stage(root, data, stage, os.path.join(root, prev, "trainingScores"), os.path.join(root, prev, "validationScores"), num_partitions,
+                            upper_bound=(upper_bounds or {}).get(stage))
             t_part = time.perf_counter() - t
         t = time.perf_counter()
         run_stage(stage_argv(root, stage), child_process)

@@ -47,7 +47,7 @@ def global_stage(data):
     return out
 
 
-def random_effect_stage(data, stage, prev):
+def random_effect_stage(data, stage, prev, upper_bound=None):
     """prev: the previous stage's {"train": {uid, score}, "validation": {...}}. -> per-entity thresholded coefficients in the
     global index space (dict entity -> (intercept, dense [dim])), W-class flags, and the stage's scores."""
     ent_all = data["user"] if stage == "per_user" else data["movie"]
@@ -56,9 +56,17 @@ def random_effect_stage(data, stage, prev):
     order = np.argsort(prev["train"]["uid"], kind="stable")
     pos = np.searchsorted(prev["train"]["uid"][order], data["uid"][tr])
     off_tr = prev["train"]["score"][order][pos].astype(np.float32)
+    # active data: with an upper bound an entity of `count` training samples is cut into count / upper_bound + 1 groups by
+    # uid mod groups and trained on group 0 only (DataPartitioner.scala:358-376); everything is scored
+    active = np.ones(tr.size, bool)
+    if upper_bound is not None:
+        _, inv, cnt = np.unique(ent_all[tr], return_inverse=True, return_counts=True)
+        groups = (cnt[inv] / float(upper_bound) + 1.0).astype(np.int64)
+        active = np.mod(data["uid"][tr], groups) == 0
     # entity-major, samples in input order
-    grp = np.argsort(ent_all[tr], kind="stable")
-    rows = tr[grp]
+    grp = np.argsort(ent_all[tr][active], kind="stable")
+    rows = tr[active][grp]
+    off_tr = off_tr[active]
     ents, first, counts = np.unique(ent_all[rows], return_index=True, return_counts=True)
     ent_row_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     ptr, cols, vals, _ = chain.bag_rows(data, stage, rows)
@@ -76,7 +84,7 @@ def random_effect_stage(data, stage, prev):
         icpt[e] = res["theta_thr"][base]
         coef[e, pk["unique_global"][fp[e]:fp[e + 1]]] = res["theta_thr"][base + 1:base + 1 + fp[e + 1] - fp[e]]
     ones = np.add.reduceat(y.astype(np.float64), ent_row_ptr[:-1])
-    out = {"entities": ents, "intercept": icpt, "coef": coef, "well_posed": (ones > 0) & (ones < counts),
+    out = {"entities": ents, "intercept": icpt, "coef": coef, "well_posed": (ones > 0) & (ones < counts), "active_samples": int(active.sum()),
            "status": res["status"], "nit": res["nit"], "raw_theta": res["theta"], "feat_ptr": fp, "unique_global": pk["unique_global"]}
     for name, mask, prev_s in (("train", data["train"], prev["train"]), ("validation", ~data["train"], prev["validation"])):
         r = np.flatnonzero(mask)
@@ -96,8 +104,9 @@ def random_effect_stage(data, stage, prev):
     return out
 
 
-def run(data):
+def run(data, upper_bounds=None):
+    ub = upper_bounds or {}
     g = global_stage(data)
-    u = random_effect_stage(data, "per_user", g)
-    m = random_effect_stage(data, "per_movie", u)
+    u = random_effect_stage(data, "per_user", g, ub.get("per_user"))
+    m = random_effect_stage(data, "per_movie", u, ub.get("per_movie"))
     return {"global": g, "per_user": u, "per_movie": m}

@@ -84,8 +84,11 @@ def test_three_coordinate_chain_matches_the_oracle_chain(tmp_path, child_process
     users, movies, ratings = (943, 1682, 100_000) if not child_process else (300, 500, 20_000)
     data = chain.make_dataset(users, movies, ratings)
     root = str(tmp_path / "chain")
-    res = chain.run_chain(root, data, num_partitions=4, child_process=child_process)
-    free = chain_oracle.run(data)
+    # per-user with DataPartitioner's upper bound: a user keeps at most ~48 training samples as active data (trained on), the rest is
+    # passive data — scored only, and the per-movie stage needs those scores as offsets just the same
+    bounds = {"per_user": 48}
+    res = chain.run_chain(root, data, num_partitions=4, child_process=child_process, upper_bounds=bounds)
+    free = chain_oracle.run(data, bounds)
     # ---- fixed effect
     g = free["global"]
     rec = list(avro.read_file(os.path.join(root, "global", "models", "part-00000.avro")))
@@ -108,7 +111,11 @@ def test_three_coordinate_chain_matches_the_oracle_chain(tmp_path, child_process
     label_of[data["uid"] - uid0] = data["response"]
     prev = got["global"]
     for stage, dim, prefix in (("per_user", chain.D_MOVIE_FEATS, "m"), ("per_movie", chain.D_USER_FEATS, "u")):
-        ora = chain_oracle.random_effect_stage(data, stage, prev)
+        ora = chain_oracle.random_effect_stage(data, stage, prev, bounds.get(stage))
+        if stage == "per_user":      # the bound bites: a good part of the training data is passive, and both kinds of score files exist
+            assert 0.3 * data["train"].sum() < ora["active_samples"] < 0.9 * data["train"].sum()
+            kinds = {f.rsplit("-", 1)[-1] for _, _, fs in os.walk(os.path.join(root, stage, "trainingScores")) for f in fs}
+            assert kinds == {"active.avro", "passive.avro"}, kinds
         _check_models(root, stage, ora, dim, prefix)
         for w in ("train", "validation"):
             _check_scores(got[stage][w], ora[w], (stage, w))

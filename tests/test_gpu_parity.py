@@ -812,10 +812,10 @@ def test_wire_form_widens_to_the_raw_batch(device_solver, shape):
 def test_pinned_routing_makes_an_entity_independent_of_its_batch(device_solver):
     """by default the split between the tall kernels and the team threshold are chosen per batch, so the same entity can
     get another kernel — other last bits — in another batch. REDeviceSolver.pin_routing (what a model with rebalance_entities
-    does) ties the kernel to the entity's own size: every fifth MovieLens-20M user solved in a batch of 300 and in the batch of
-    1 500 comes out bit for bit the same, the per-batch choice being demonstrably different for the two batches by default."""
-    b = synthetic.make_movielens_20m("per_user", seed=83, entities=1500)
-    ents = np.arange(0, b.E, 5)
+    does) ties the kernel to the entity's own size: every fortieth of 24 000 MovieLens-20M users solved in a batch of 600 and in the batch of
+    24 000 comes out bit for bit the same, the per-batch choice being demonstrably different for the two batches by default."""
+    b = synthetic.make_movielens_20m("per_user", seed=83, entities=24000)     # too many users above 512 samples for a lowered split ...
+    ents = np.arange(0, b.E, 40)                                               # ... 600 of them: a small batch, which gets one
     sub = b.select(ents)
     opts = SolverOptions(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
 
