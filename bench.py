@@ -277,6 +277,7 @@ def fixed_effect_leg(solver, rows, nnz_per_row=32, features=100_000, iters=20):
         dt = time.perf_counter() - t0
         _, info = prob.result()
         rows_ms, cols_ms = prob.last_eval_ms()
+        rows_b, cols_b = prob.stream_bytes()
         prob.close()
         nfev = int(info["nfev"])
         Z, P, m = n * k, D + 1, 10
@@ -284,6 +285,10 @@ def fixed_effect_leg(solver, rows, nnz_per_row=32, features=100_000, iters=20):
         ms = dt * 1e3 / nfev
         out = {"ms_per_evaluation": ms, "rows_pass_ms": rows_ms, "cols_pass_ms": cols_ms, "evaluations": nfev, "alg_bytes_per_evaluation": alg,
                "GBps": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "entry_bytes_streamed": {"rows_pass": rows_b, "cols_pass": cols_b, "per_nnz": (rows_b + cols_b) / float(Z),
+                                        "note": "what the passes' own copies hold: 8 B per entry, units of the column pass in the 6-byte form of round 5 "
+                                                "(fp32 value + 16-bit {key delta, accumulator}); the roofline figure stays on the algorithmic 16 B per non-zero"},
+               "streamed_GBps": (rows_b + cols_b + 32.0 * n + (4 + 2 * m) * 8.0 * P) / (ms * 1e-3) / 1e9,
                "shard": f"{n} samples x {k} uniform columns of {D} features, logistic, m=10",
                "what": "gdmix_fe_eval + gdmix_fe_step per L-BFGS evaluation; bytes = 16 B/nnz (value + index, both passes) + 32 B/sample "
                        "+ (4 + 2m) x 8 B/coefficient"}
@@ -461,6 +466,26 @@ def lbfgs_state_bytes(p, nit, nfev, opts_m=10, n=None, one_workgroup=False):
         arena = 15290.0
         vectors = np.where(5 * p + n <= arena, 0.0, np.where(3 * p + n <= arena, 2.0, np.where(p + n <= arena, 4.0, 5.0)))
     return float((p * (16.0 * pairs_sum + 16.0 * mean_pairs * nfev + 16.0 * nit + 16.0 * vectors * nfev)).sum())
+
+
+def chain_leg():
+    """SURVEY.md 8(f) N2 next to the headline: one pass of the coordinate chain through the drop-in CLI (gdmix_amd/chain.py) —
+    global fixed effect -> per-user -> per-movie random effect on MovieLens-100K-shaped data with planted effects, the partition
+    job's offset update (previous stage's float scores joined on uid) and DataPartitioner's active / passive bounding in between.
+    In this process, second pass (context and libraries up); tests/test_gpu_chain.py holds the same chain to the CPU oracle's."""
+    import tempfile
+    from gdmix_amd import chain
+    data = chain.make_dataset()
+    out = None
+    for _ in range(2):
+        with tempfile.TemporaryDirectory() as d:
+            out = chain.run_chain(d, data, num_partitions=4, upper_bounds={"per_user": 48})
+    return {"fe_s": out["global"]["s"], "per_user_s": out["per_user"]["s"], "per_movie_s": out["per_movie"]["s"],
+            "partition_s": out["per_user"]["partition_s"] + out["per_movie"]["partition_s"], "total_s": out["total_s"],
+            "validation_auc": [out[s]["validation_auc"] for s in chain.STAGES], "train_auc": [out[s]["train_auc"] for s in chain.STAGES],
+            "samples": out["global"]["train_samples"] + out["global"]["validation_samples"],
+            "what": "python -m gdmix_amd.gdmix x 3 (fixed_effect, random_effect per user with an active-data bound of 48, random_effect per movie) + the "
+                    "partition step between stages, 100 k ratings of 943 users x 1 682 movies, in process, second pass; AUC per stage on the validation split"}
 
 
 class Workload:
@@ -754,6 +779,7 @@ def compact_line(full, detail_file):
     chain = d.get("chain")
     if chain:
         s["chain"] = {k: _r(v) for k, v in chain.items() if isinstance(v, (int, float))}
+        s["chain"]["validation_auc"] = [_r(x) for x in chain.get("validation_auc", [])]
     line["summary"] = s
     st = full.get("strong_scaling")
     if st:
@@ -978,9 +1004,10 @@ def main():
     fe_eval = None
     if c2_legs and not a.no_fe:
         fe_eval = fixed_effect_leg(solver, a.fe_rows)
-    cli_e2e = cli_sub = cli_c5 = cli_movie = None
+    cli_e2e = cli_sub = cli_c5 = cli_movie = chain_res = None
     if c2_legs and not a.no_cli:
         cli_e2e, cli_sub = cli_end_to_end_leg(a.cli_entities)
+        chain_res = chain_leg()
         if not a.no_other_workloads:
             cli_c5 = cli_shape_leg("c5", a.cli_c5_entities)
             cli_movie = cli_shape_leg("ml20m_movie", None)
@@ -1144,7 +1171,7 @@ def main():
                        "mean_nit": nit, "mean_nfev": nfev,
                        "converged_per_step": converged_all, "parity_classes": {"W": well_posed, "D": int(wl.E - well_posed)}, "N": wl.N, "Z": wl.Z, "P": packed.P,
                        "host_generate_s": t_gen, "host_handover": e2e, "score_pass": score, "fixed_effect_eval": fe_eval, "cli_end_to_end": cli_e2e,
-                       "cli_subprocess": cli_sub, "cli_end_to_end_c5": cli_c5, "cli_end_to_end_ml20m_movie": cli_movie, "workloads": others, "c5_full_share": c5_full,
+                       "cli_subprocess": cli_sub, "cli_end_to_end_c5": cli_c5, "cli_end_to_end_ml20m_movie": cli_movie, "workloads": others, "c5_full_share": c5_full, "chain": chain_res,
                        "restreamed_bytes_per_step": b_stream,
                        "restreamed_GBps": b_stream / (float(kernel_ms.sum()) / a.steps * 1e-3) / 1e9 if kernel_ms.sum() else None},
         }

@@ -63,6 +63,12 @@ struct FeCopy {
   const int32_t* order;    // [nlaunch] workgroup -> unit or -1: units that gather the same stretch of the vector on one XCD (fe_build_copy)
   double* part;            // [nunit][FE_B] partial sums of the blocks that have several units (column pass: of all)
   int nunit, nblock, nlaunch;
+  // the 6-byte form (round 5; fe_cpack_kernel): a unit's entries in trips of 512, per trip 2 KB of values + 1 KB of 16-bit words
+  // {5-bit key delta to the entry before, 11-bit accumulator}, keys rebuilt by a wavefront scan
+  const unsigned char* cdata;
+  const int64_t* cbase;    // [nunit] byte offset of the unit in cdata; -1: the unit is read in the 8-byte / three-array form (or NULL)
+  const int32_t* ctrip;    // [nunit] trips
+  int64_t stream_bytes;    // (host bookkeeping) bytes of entries one pass reads: 6-byte-form units incl. fillers and padding + 8 / 10 B per entry of the others
 };
 
 // Frequent features (real feature frequencies are Zipf-like: one feature can hold a tenth of the non-zeros): in the column pass
@@ -139,6 +145,64 @@ __device__ __forceinline__ void lds_add(double* acc, int loc, double term) {
   __hip_atomic_fetch_add(acc + loc, term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// inclusive prefix sums over the 64 lanes of two 16-bit counters packed in one word (no carry between the halves: sums < 65 536)
+__device__ __forceinline__ unsigned wave_iscan_pair(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1 (lanes without a source keep 0)
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8: prefix within each row of 16
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+  return v;
+}
+
+#ifndef GDMIX_FE_COMPRESS_DEFAULT
+#define GDMIX_FE_COMPRESS_DEFAULT 2     // the column pass: 0.268 -> 0.235 ms; the row pass gets slower in this form (0.246 -> 0.257): measured, docs/rounds/r05.md
+#endif
+constexpr int FE_COMPRESS_DEFAULT = GDMIX_FE_COMPRESS_DEFAULT;
+constexpr int FE_CTRIP = WAVE * 8;            // entries per trip of the 6-byte form
+constexpr int FE_CTRIP_BYTES = FE_CTRIP * 6;  // [2][64] x 16 B of values, then [64] x 16 B of index words
+constexpr int FE_CDELTA_MAX = 31;
+static_assert(FE_LOC_BITS == 11, "index word = delta << 11 | accumulator");
+
+// One unit in the 6-byte form. Trip t: lane l holds entries q * 64 + l, q = 0..7 — every gather instruction covers 64 consecutive
+// entries (~100 consecutive elements of the gathered vector), and the adds of one accumulator happen in exact key order.
+template <bool ROWS, bool HESS>
+__device__ __forceinline__ void fe_scatter_compressed(double* acc, const unsigned char* __restrict__ base, int trips, const double* __restrict__ vec, int lane) {
+  int key0 = 0;     // key of the entry before this trip's first, relative to the unit's first (uniform)
+  for (int t = 0; t < trips; ++t) {
+    const unsigned char* tp = base + (size_t)t * FE_CTRIP_BYTES;
+    uint4 v0, v1, ix;
+    __builtin_memcpy(&v0, tp + lane * 16, 16);
+    __builtin_memcpy(&v1, tp + 1024 + lane * 16, 16);
+    __builtin_memcpy(&ix, tp + 2048 + lane * 16, 16);
+    const unsigned w[4] = {ix.x, ix.y, ix.z, ix.w};
+    const float vq[8] = {__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z), __uint_as_float(v0.w),
+                         __uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z), __uint_as_float(v1.w)};
+    int kq[8], lq[8];
+    double xq[8];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const unsigned pre = wave_iscan_pair((w[h] >> FE_LOC_BITS) & 0x001f001fu);      // rows 2h (low half) and 2h + 1 (high half)
+      const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)pre, 63);
+      kq[2 * h] = key0 + (int)(pre & 0xffffu);
+      key0 += (int)(tot & 0xffffu);
+      kq[2 * h + 1] = key0 + (int)(pre >> 16);
+      key0 += (int)(tot >> 16);
+      lq[2 * h] = (int)(w[h] & ((1u << FE_LOC_BITS) - 1));
+      lq[2 * h + 1] = (int)((w[h] >> 16) & ((1u << FE_LOC_BITS) - 1));
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xq[q] = vec[kq[q]];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double v = (double)vq[q];
+      // a filler (value 0: it only carries a key delta too large for five bits) must not turn a non-finite x into a NaN sum
+      lds_add(acc, lq[q], vq[q] == 0.0f ? 0.0 : ((HESS && !ROWS) ? v * v * xq[q] : v * xq[q]));
+    }
+  }
+}
+
 template <bool ROWS, bool HESS, bool PACKED>
 __global__ __launch_bounds__(WAVE) void fe_scatter_kernel(FeDev F, SolveParams o) {
   // exactly 16 KiB: ten wavefronts per CU (160 KiB of LDS). Round 5: a spare accumulator for the lanes beyond the end of the last
@@ -162,6 +226,10 @@ __global__ __launch_bounds__(WAVE) void fe_scatter_kernel(FeDev F, SolveParams o
   const double* __restrict__ vec = (ROWS ? F.xl : F.rs) + kb;
 #pragma unroll
   for (int i = 0; i < FE_B / WAVE; i += 2) *reinterpret_cast<double2*>(acc + (i * WAVE + 2 * lane)) = make_double2(0.0, 0.0);
+  const int64_t cb = C.cbase ? C.cbase[u] : -1;      // uniform
+  if (cb >= 0) {
+    fe_scatter_compressed<ROWS, HESS>(acc, C.cdata + cb, C.ctrip[u], (ROWS ? F.xl : F.rs) + C.kbase[u], lane);   // (keys are relative to the unit's first in this form, always)
+  } else {
   // full trips without a guard in sight (a load under a branch is waited for inside the branch); the last, partial trip
   // reads clamped addresses and sends what is beyond the end to a spare accumulator.
   // (Round 5, measured and removed: the entry stream two trips ahead of the gathers — prefetch issued BEHIND the gathers so that
@@ -229,6 +297,7 @@ __global__ __launch_bounds__(WAVE) void fe_scatter_kernel(FeDev F, SolveParams o
       lds_add(acc, lq[q], ((live >> q) & 1u) ? term : 0.0);
     }
   }
+  }   // (the 8-byte / three-array forms)
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the adds have landed
   __builtin_amdgcn_wave_barrier();
   if (whole) {
@@ -692,6 +761,74 @@ __global__ __launch_bounds__(256) void fe_pack_kernel(const FeEnt* __restrict__ 
   }
 }
 
+// ---- the 6-byte form of a unit's entries --------------------------------------------------------------------------------------
+// fillers an entry needs in front of it so that every key delta fits FE_CDELTA_MAX: a gap g > 31 takes (g - 1) / 31 fillers of
+// delta 31 (value 0, accumulator 0) and leaves a delta in [1, 31] for the entry itself
+__device__ __forceinline__ int fe_fillers(int gap) { return gap > FE_CDELTA_MAX ? (gap - 1) / FE_CDELTA_MAX : 0; }
+
+// entries of unit u in the 6-byte form, fillers included (one workgroup per unit)
+__global__ __launch_bounds__(256) void fe_ccount_kernel(const FeEnt* __restrict__ ent, const int32_t* __restrict__ ustart, const int32_t* __restrict__ kbase,
+                                                        int32_t* __restrict__ cnt) {
+  __shared__ int red[256 / WAVE];
+  const int u = blockIdx.x, k0 = ustart[u], k1 = ustart[u + 1], kb = kbase[u];
+  int f = 0;
+  for (int k = k0 + threadIdx.x; k < k1; k += 256) f += fe_fillers(ent[k].seg - (k > k0 ? ent[k - 1].seg : kb));
+  for (int sh = 32; sh > 0; sh >>= 1) f += __shfl_down(f, sh);
+  if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x >> 6] = f;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[u] = (k1 - k0) + red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ void fe_cput(unsigned char* base, int pos, float val, unsigned word) {
+  const int t = pos / FE_CTRIP, w = pos % FE_CTRIP, q = w / WAVE, l = w % WAVE;
+  unsigned char* tp = base + (size_t)t * FE_CTRIP_BYTES;
+  *reinterpret_cast<float*>(tp + (q >> 2) * 1024 + l * 16 + (q & 3) * 4) = val;
+  *reinterpret_cast<uint16_t*>(tp + 2048 + l * 16 + q * 2) = (uint16_t)word;
+}
+
+// the units that take the form (cbase[u] >= 0), written into a zeroed buffer: what stays zero is padding (delta 0, value 0)
+__global__ __launch_bounds__(256) void fe_cpack_kernel(const FeEnt* __restrict__ ent, const int32_t* __restrict__ ustart, const int32_t* __restrict__ kbase,
+                                                       const int64_t* __restrict__ cbase, unsigned char* __restrict__ cdata) {
+  __shared__ int wsum[256 / WAVE];
+  __shared__ int carry;
+  const int u = blockIdx.x;
+  if (cbase[u] < 0) return;
+  const int k0 = ustart[u], k1 = ustart[u + 1], kb = kbase[u];
+  unsigned char* base = cdata + cbase[u];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int c0 = k0; c0 < k1; c0 += 256) {
+    const int k = c0 + tid;
+    int gap = 0, f = 0;
+    FeEnt e{0, 0, 0.0f};
+    if (k < k1) {
+      e = ent[k];
+      gap = e.seg - (k > k0 ? ent[k - 1].seg : kb);
+      f = fe_fillers(gap);
+    }
+    // exclusive prefix of f over the 256 entries of this chunk
+    int incl = f;
+    for (int sh = 1; sh < WAVE; sh <<= 1) {
+      const int up = __shfl_up(incl, sh);
+      if (lane >= sh) incl += up;
+    }
+    if (lane == WAVE - 1) wsum[wv] = incl;
+    __syncthreads();
+    int before = carry;
+    for (int w2 = 0; w2 < wv; ++w2) before += wsum[w2];
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (k < k1) {
+      const int first = (k - k0) + before + (incl - f);      // position of this entry's first filler (or of the entry)
+      for (int j = 0; j < f; ++j) fe_cput(base, first + j, 0.0f, (unsigned)FE_CDELTA_MAX << FE_LOC_BITS);
+      fe_cput(base, first + f, e.val, ((unsigned)(gap - FE_CDELTA_MAX * f) << FE_LOC_BITS) | (unsigned)(e.idx % FE_B));
+    }
+    __syncthreads();
+    if (tid == 0) carry += total;
+    __syncthreads();
+  }
+}
+
 // bp[b] = first sorted entry of a block >= b
 __global__ void fe_block_kernel(const uint32_t* __restrict__ sorted, int64_t z, int nblock, int32_t* __restrict__ bp) {
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b <= nblock; b += gridDim.x * blockDim.x) {
@@ -778,6 +915,8 @@ struct gdmix_fe_problem {
   SolveParams o;
   void* pool;            // one device allocation carved into the vectors and partial sums
   void* copies[2];       // the row pass's and the column pass's copy of the non-zeros, with their unit tables
+  void* ccopies[2];      // ... and their units in the 6-byte form
+  int compress;          // bit 0: row pass, bit 1: column pass may use the 6-byte form (GDMIX_FE_COMPRESS; default: FE_COMPRESS_DEFAULT)
   void* hot_mem;         // the frequent columns' tables
   int32_t* status_dev;
   hipEvent_t ev[3];
@@ -822,8 +961,9 @@ static int fe_chunk_len(int64_t z, int nblock, int num_cus) {
 // Build one pass's copy from segment-major source arrays (ptr [nseg+1], idx / val [z]); `len` = extent of idx (outputs of the
 // pass). Device memory of the result in *owned; the block -> unit table is also returned on the host (ufirst).
 static int fe_build_copy(hipStream_t s, int num_cus, const int32_t* ptr, int nseg, const int32_t* idx, const float* val, int64_t z,
-                         int len, bool cut_sparse, FeCopy* out, void** owned, std::vector<int32_t>* ufirst_host) {
+                         int len, bool cut_sparse, bool compress, FeCopy* out, void** owned, void** owned_c, std::vector<int32_t>* ufirst_host) {
   *owned = nullptr;
+  *owned_c = nullptr;
   const int nblock = len > 0 ? (len + FE_B - 1) / FE_B : 1;
   const int chunk = fe_chunk_len(z, nblock, num_cus);
   const size_t zz = (size_t)(z > 0 ? z : 1);
@@ -942,8 +1082,60 @@ static int fe_build_copy(hipStream_t s, int num_cus, const int32_t* ptr, int nse
     rc = hipStreamSynchronize(s);
   }
   if (rc == hipSuccess) rc = hipGetLastError();
+  out->stream_bytes = (int64_t)z * (packed ? 8 : 10);
+  // ---- the 6-byte form for the units it shortens (round 5) ----
+  void* cmem = nullptr;
+  out->cdata = nullptr; out->cbase = nullptr; out->ctrip = nullptr;
+  if (rc == hipSuccess && compress && nunit > 0 && z > 0) {
+    int32_t* cnt_dev = nullptr;
+    void* cnt_mem = nullptr;
+    rc = hipMalloc(&cnt_mem, (size_t)nunit * 4);
+    std::vector<int32_t> cnt((size_t)nunit), us((size_t)nunit + 1);
+    if (rc == hipSuccess) {
+      cnt_dev = static_cast<int32_t*>(cnt_mem);
+      hipLaunchKernelGGL(fe_ccount_kernel, dim3(nunit), dim3(256), 0, s, ent2, ustart, kbase, cnt_dev);
+      rc = hipMemcpyAsync(cnt.data(), cnt_dev, (size_t)nunit * 4, hipMemcpyDeviceToHost, s);
+      if (rc == hipSuccess) rc = hipMemcpyAsync(us.data(), ustart, ((size_t)nunit + 1) * 4, hipMemcpyDeviceToHost, s);
+      if (rc == hipSuccess) rc = hipStreamSynchronize(s);
+    }
+    if (cnt_mem) (void)hipFree(cnt_mem);
+    std::vector<int64_t> cb((size_t)nunit, -1);
+    std::vector<int32_t> ct((size_t)nunit, 0);
+    size_t total = 0;
+    int taken = 0;
+    for (int u = 0; rc == hipSuccess && u < nunit; ++u) {
+      const int64_t nu = (int64_t)us[(size_t)u + 1] - us[(size_t)u];
+      const int64_t trips = ((int64_t)cnt[(size_t)u] + FE_CTRIP - 1) / FE_CTRIP;
+      // the form pays when it is shorter than 8 bytes per entry with room to spare (fillers of sparse blocks, padding of short units)
+      if (nu > 0 && trips * FE_CTRIP_BYTES * 10 <= nu * 8 * 9) { cb[(size_t)u] = (int64_t)total; ct[(size_t)u] = (int32_t)trips; total += (size_t)trips * FE_CTRIP_BYTES; ++taken; }
+    }
+    if (rc == hipSuccess && taken > 0) {
+      const size_t o_cb = 0, o_ct = up256((size_t)nunit * 8), o_data = o_ct + up256((size_t)nunit * 4);
+      rc = hipMalloc(&cmem, o_data + total + 256);
+      if (rc == hipSuccess) {
+        char* cm = static_cast<char*>(cmem);
+        rc = hipMemsetAsync(cm + o_data, 0, total, s);
+        if (rc == hipSuccess) rc = hipMemcpyAsync(cm + o_cb, cb.data(), (size_t)nunit * 8, hipMemcpyHostToDevice, s);
+        if (rc == hipSuccess) rc = hipMemcpyAsync(cm + o_ct, ct.data(), (size_t)nunit * 4, hipMemcpyHostToDevice, s);
+        if (rc == hipSuccess) {
+          hipLaunchKernelGGL(fe_cpack_kernel, dim3(nunit), dim3(256), 0, s, ent2, ustart, kbase, reinterpret_cast<const int64_t*>(cm + o_cb),
+                             reinterpret_cast<unsigned char*>(cm + o_data));
+          rc = hipStreamSynchronize(s);      // (cb / ct go out of scope; tmp is freed below)
+        }
+        if (rc == hipSuccess) {
+          int64_t plain = 0;
+          for (int u = 0; u < nunit; ++u) if (cb[(size_t)u] < 0) plain += (int64_t)us[(size_t)u + 1] - us[(size_t)u];
+          out->stream_bytes = (int64_t)total + plain * (packed ? 8 : 10);
+          out->cdata = reinterpret_cast<const unsigned char*>(cm + o_data);
+          out->cbase = reinterpret_cast<const int64_t*>(cm + o_cb);
+          out->ctrip = reinterpret_cast<const int32_t*>(cm + o_ct);
+        }
+      }
+    }
+  }
+  *owned_c = cmem;
   (void)hipFree(tmp);
-  if (rc != hipSuccess) { set_error("building a pass's copy failed: %s", hipGetErrorString(rc)); (void)hipFree(mem); return GDMIX_RE_EHIP; }
+  if (rc != hipSuccess) { set_error("building a pass's copy failed: %s", hipGetErrorString(rc)); (void)hipFree(mem); if (cmem) (void)hipFree(cmem); *owned_c = nullptr; return GDMIX_RE_EHIP; }
   out->ent = packed ? pent : nullptr;
   out->key = ckey; out->val = cval; out->loc = cloc; out->kbase = kbase; out->ustart = ustart; out->ublock = ublock; out->ufirst = ufirst;
   out->part = nullptr;
@@ -961,6 +1153,7 @@ static void fe_free(gdmix_fe_problem* p) {
   if (p->status_ring) (void)hipHostFree(p->status_ring);
   if (p->pool) (void)hipFree(p->pool);
   for (auto& c : p->copies) if (c) (void)hipFree(c);
+  for (auto& c : p->ccopies) if (c) (void)hipFree(c);
   if (p->hot_mem) (void)hipFree(p->hot_mem);
   delete p;
 }
@@ -986,7 +1179,8 @@ static int fe_split_hot(gdmix_fe_problem* p, const gdmix_re_packed* b, hipStream
     std::sort(hot_cols.begin(), hot_cols.end());
   }
   if (hot_cols.empty())
-    return fe_build_copy(s, ci->num_cus, b->row_ptr, F.n, b->csr_col, b->csr_val, F.z, F.d, true, &F.cc, &p->copies[1], &p->uf_c);
+    return fe_build_copy(s, ci->num_cus, b->row_ptr, F.n, b->csr_col, b->csr_val, F.z, F.d, true, (p->compress & 2) != 0, &F.cc, &p->copies[1],
+                         &p->ccopies[1], &p->uf_c);
   const int nh = (int)hot_cols.size();
   const int vbase = (F.d + FE_B - 1) / FE_B * FE_B;
   std::vector<int32_t> hotmap((size_t)F.d, -1);
@@ -1013,7 +1207,8 @@ static int fe_split_hot(gdmix_fe_problem* p, const gdmix_re_packed* b, hipStream
     rc = hipStreamSynchronize(s);                      // (also: the host vectors above are done with)
   }
   if (rc != hipSuccess) { (void)hipFree(mem); set_error("frequent-column tables: %s", hipGetErrorString(rc)); return GDMIX_RE_EHIP; }
-  const int rc2 = fe_build_copy(s, ci->num_cus, b->row_ptr, F.n, col2, b->csr_val, F.z, vbase + nh * FE_HOT_REP, true, &F.cc, &p->copies[1], &p->uf_c);
+  const int rc2 = fe_build_copy(s, ci->num_cus, b->row_ptr, F.n, col2, b->csr_val, F.z, vbase + nh * FE_HOT_REP, true, (p->compress & 2) != 0, &F.cc,
+                                &p->copies[1], &p->ccopies[1], &p->uf_c);
   (void)hipFree(mem);
   if (rc2 != GDMIX_RE_OK) return rc2;
   F.hot.n = nh;
@@ -1069,6 +1264,9 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   p->ctx = ctx;
   p->pool = nullptr;
   p->copies[0] = p->copies[1] = nullptr;
+  p->ccopies[0] = p->ccopies[1] = nullptr;
+  p->compress = FE_COMPRESS_DEFAULT;
+  if (const char* e = getenv("GDMIX_FE_COMPRESS")) p->compress = atoi(e) & 3;
   p->hot_mem = nullptr;
   p->timed = false;
   p->dirty = false;      // the pool is zeroed at creation
@@ -1092,7 +1290,8 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   o.variance_mode = 0; o.sum_loss = 1; o.linear = opts->linear ? 1 : 0;
   // row pass: outputs = rows, gathered = x by local column: from the column-major arrays. Column pass: the other way round.
   std::vector<int32_t> uf_r, uf_c;
-  int rc2 = fe_build_copy(s, ci->num_cus, b->col_ptr, F.d, b->csc_row, b->csc_val, F.z, F.n, false, &F.rc, &p->copies[0], &uf_r);
+  int rc2 = fe_build_copy(s, ci->num_cus, b->col_ptr, F.d, b->csc_row, b->csc_val, F.z, F.n, false, (p->compress & 1) != 0, &F.rc, &p->copies[0],
+                          &p->ccopies[0], &uf_r);
   if (rc2 == GDMIX_RE_OK) rc2 = fe_split_hot(p, b, s);    // the frequent columns, and the column pass's copy of the others
   if (rc2 != GDMIX_RE_OK) { fe_free(p); return rc2; }
   uf_c = p->uf_c;
@@ -1314,6 +1513,13 @@ GDMIX_API int gdmix_fe_score(gdmix_re_ctx* ctx, int64_t n, const int64_t* row_nn
   hipLaunchKernelGGL(fe_score_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), n, row_nnz_ptr,
                      col_global, val, offset, theta, num_features, has_intercept ? 1 : 0, score, per_coord);
   HIP_TRY(hipGetLastError());
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_fe_stream_bytes(gdmix_fe_problem* p, int64_t* rows_pass, int64_t* cols_pass) {
+  if (!p) { set_error("problem is NULL"); return GDMIX_RE_EINVAL; }
+  if (rows_pass) *rows_pass = p->F.rc.stream_bytes;
+  if (cols_pass) *cols_pass = p->F.cc.stream_bytes;
   return GDMIX_RE_OK;
 }
 

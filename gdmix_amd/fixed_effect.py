@@ -228,6 +228,12 @@ class _SteppingProblem:
         self._check(self.lib.gdmix_fe_hessian_diag(self._h, None if theta_dev is None else theta_dev.data_ptr(), self.solver._stream()),
                     "gdmix_fe_hessian_diag")
 
+    def stream_bytes(self):
+        """(bytes of entries the row pass reads, the column pass reads) — gdmix_fe_stream_bytes."""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self.lib.gdmix_fe_stream_bytes(self._h, C.byref(a), C.byref(b)), "gdmix_fe_stream_bytes")
+        return int(a.value), int(b.value)
+
     def last_eval_ms(self):
         a, b = C.c_float(), C.c_float()
         self._check(self.lib.gdmix_fe_last_eval_ms(self._h, C.byref(a), C.byref(b)), "gdmix_fe_last_eval_ms")

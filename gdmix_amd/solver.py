@@ -72,7 +72,7 @@ EXPORTED_SYMBOLS = (
     "gdmix_re_solve_scratch_bytes", "gdmix_re_set_scratch", "gdmix_re_variance_full", "gdmix_re_set_wave_lds_limit", "gdmix_re_score",
     "gdmix_re_widen_workspace_bytes", "gdmix_re_widen", "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz", "gdmix_re_set_tall_min_n", "gdmix_re_set_tall_split_n", "gdmix_re_set_tall_team_n", "gdmix_re_set_spread",
     "gdmix_fe_create", "gdmix_fe_destroy", "gdmix_fe_eval", "gdmix_fe_reduce_buffer", "gdmix_fe_step", "gdmix_fe_step_async", "gdmix_fe_step_status", "gdmix_fe_solve", "gdmix_fe_result",
-    "gdmix_fe_last_eval_ms", "gdmix_fe_score", "gdmix_fe_hessian_diag", "gdmix_fe_hessian_dense_scratch_bytes", "gdmix_fe_hessian_dense",
+    "gdmix_fe_last_eval_ms", "gdmix_fe_stream_bytes", "gdmix_fe_score", "gdmix_fe_hessian_diag", "gdmix_fe_hessian_dense_scratch_bytes", "gdmix_fe_hessian_dense",
     "gdmix_fe_variance_of_hessian",
     "gdmix_re_class_kernel_name", "gdmix_java_string_hash", "gdmix_java_partition_id",
     "gdmix_java_partition_ids_i64")
@@ -129,6 +129,7 @@ def load_library():
     lib.gdmix_fe_step_status.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]
     lib.gdmix_fe_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     lib.gdmix_fe_hessian_diag.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gdmix_fe_stream_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.gdmix_fe_result.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]
     lib.gdmix_fe_score.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,

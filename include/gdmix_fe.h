@@ -43,7 +43,8 @@ typedef struct gdmix_fe_problem gdmix_fe_problem;
  * The problem builds its own two copies of the non-zeros (8 B per non-zero each, 10 B when a unit of a pass spans more than 2^21
  * elements; temporary: 40 B per non-zero) and keeps reading the shard's y / offset / weight / unique_global, which must outlive it.
  * Synchronises the stream. Test hooks (environment): GDMIX_FE_CHUNK = entries per unit of a pass, GDMIX_FE_PACK=0 = the
- * three-array form of the entries. */
+ * three-array form of the entries, GDMIX_FE_COMPRESS = which passes may read units in the 6-byte form (bit 0 rows, bit 1 columns;
+ * default 2). */
 GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* shard, int64_t num_features,
                               const gdmix_re_opts* opts, const double* theta0, gdmix_fe_problem** out, void* stream);
 GDMIX_API void gdmix_fe_destroy(gdmix_fe_problem* p);
@@ -105,6 +106,11 @@ GDMIX_API int gdmix_fe_result(gdmix_fe_problem* p, double* theta, double* fval, 
 GDMIX_API int gdmix_fe_score(gdmix_re_ctx* ctx, int64_t n, const int64_t* row_nnz_ptr, const int64_t* col_global, const float* val,
                              const float* offset, const double* theta, int64_t num_features, int has_intercept, float* score,
                              float* per_coord, void* stream);
+
+/* Bytes of non-zero entries one row pass / one column pass of this problem reads (its own copies of the shard: 8 B per entry, 10 in the
+ * three-array form; units in the 6-byte form of round 5 — values + 16-bit {key delta, accumulator} words — with their fillers and
+ * padding). What the passes stream, next to the algorithmic 8 B per entry and pass the bench's roofline figure is quoted on. */
+GDMIX_API int gdmix_fe_stream_bytes(gdmix_fe_problem* p, int64_t* rows_pass, int64_t* cols_pass);
 
 /* Optional timing (HIP events on the launch stream): ms of the row pass (X theta) and the column pass (X'r) of the problem's SECOND
  * gdmix_fe_eval (its first, if there was only one) — not the last: with the status read a few steps late the last evaluations of a

@@ -181,11 +181,12 @@ def test_one_launch_step_and_look_ahead_give_the_bits_of_the_plain_loop(device_s
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("compress", ["3", "0"])
 @pytest.mark.parametrize("chunk,pack,hot,window", [(None, "1", None, None), ("8192", "1", None, None), ("257", "1", None, None),
                                                    ("257", "0", None, None), (None, "0", None, None), (None, "1", "300", None),
                                                    ("257", "1", "2000", None), ("257", "0", "40", None), (None, "1", None, "10"),
                                                    ("257", "1", "300", "11"), ("8192", "0", None, "12")])
-def test_passes_cut_into_units_are_deterministic_and_agree(device_solver, monkeypatch, chunk, pack, hot, window):
+def test_passes_cut_into_units_are_deterministic_and_agree(device_solver, monkeypatch, chunk, pack, hot, window, compress):
     """csrc/fe_solve.hip: several row blocks and column blocks, blocks cut into several units (GDMIX_FE_CHUNK forces that on a
     small shard; 257 is no multiple of anything), both forms of the entries (GDMIX_FE_PACK=0: the three arrays a unit spanning more
     than 2^21 gathered elements needs), a frequent feature, empty rows and features that never occur. Two fits are
@@ -207,6 +208,10 @@ def test_passes_cut_into_units_are_deterministic_and_agree(device_solver, monkey
     else:
         monkeypatch.setenv("GDMIX_FE_CHUNK", chunk)
     monkeypatch.setenv("GDMIX_FE_PACK", pack)
+    # compress: GDMIX_FE_COMPRESS, bit 0 the row pass, bit 1 the column pass — units whose key deltas fit five bits with few fillers are
+    # read in the 6-byte form (values + 16-bit {delta, accumulator} words, keys rebuilt by a wavefront scan); the sparse blocks of
+    # this Zipf-distributed shard keep the 8-byte form, units of 257 entries are mostly padding and keep it too: both forms in one launch
+    monkeypatch.setenv("GDMIX_FE_COMPRESS", compress)
     rng = np.random.default_rng(11)
     n, D = 9000, 7000
     k = rng.integers(0, 24, n)
