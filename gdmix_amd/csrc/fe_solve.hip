@@ -484,6 +484,7 @@ __global__ void fe_hot_remap_kernel(const int32_t* __restrict__ ptr, int n, cons
 // "virtual block" vb of nvb — coefficients (vb * 256 + tid) + k * nvb * 256 — into acc_part[vb]. The partition is a function of P
 // alone (nvb = min(ceil(P / 256), FE_DOT_BLOCKS)), not of the launch: fe_dots_kernel runs one workgroup per virtual block,
 // fe_tail_kernel deals them over fewer resident workgroups, and both give the same bits.
+template <bool SC1 = false>
 __device__ __forceinline__ void fe_dots_block(const FeDev& F, const SolveParams& o, int vb, int nvb, double (*red)[TEAM_K]) {
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
   const int col = F.state->col, head = F.state->head, m = o.m, P = F.P;
@@ -531,7 +532,7 @@ __device__ __forceinline__ void fe_dots_block(const FeDev& F, const SolveParams&
     double s = red[0][tid];
 #pragma unroll
     for (int w = 1; w < FE_WAVES; ++w) s = (tid == TEAM_K - 1) ? fmax(s, red[w][tid]) : s + red[w][tid];
-    F.acc_part[(size_t)vb * TEAM_K + tid] = s;
+    st_x<SC1>(F.acc_part + (size_t)vb * TEAM_K + tid, s);   // SC1 (fe_tail_kernel): written through, read by another workgroup of the same launch
   }
 }
 
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(FE_THREADS) void fe_dots_kernel(FeDev F, SolveParam
 }
 
 // one workgroup: totals of the products (the virtual blocks' shares, in a fixed order), then the driver's decision
+template <bool SC1 = false>
 __device__ __forceinline__ void fe_step_body(const FeDev& F, const SolveParams& o, int dot_blocks, int32_t* status_out, double* tot /* LDS [TEAM_K] */,
                                              CompactMats& mats /* LDS */, double (*part8)[32] /* LDS [8][32] */) {
   const int tid = threadIdx.x;
@@ -554,12 +556,12 @@ __device__ __forceinline__ void fe_step_body(const FeDev& F, const SolveParams& 
       for (; b + 56 < dot_blocks; b += 64) {   // eight loads in flight
         double t[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t[q] = F.acc_part[(size_t)(b + 8 * q) * TEAM_K + v];
+        for (int q = 0; q < 8; ++q) t[q] = ld_x<SC1>(F.acc_part + (size_t)(b + 8 * q) * TEAM_K + v);
 #pragma unroll
         for (int q = 0; q < 8; ++q) s = (v == TEAM_K - 1) ? fmax(s, t[q]) : s + t[q];
       }
       for (; b < dot_blocks; b += 8) {
-        const double t = F.acc_part[(size_t)b * TEAM_K + v];
+        const double t = ld_x<SC1>(F.acc_part + (size_t)b * TEAM_K + v);
         s = (v == TEAM_K - 1) ? fmax(s, t) : s + t;
       }
       part8[g][v] = s;
@@ -590,11 +592,18 @@ __device__ __forceinline__ void fe_step_body(const FeDev& F, const SolveParams& 
   {
     double* dst = reinterpret_cast<double*>(F.mats);
     const double* src = reinterpret_cast<const double*>(&mats);
-    for (int k = tid; k < (int)(sizeof(CompactMats) / sizeof(double)); k += FE_THREADS) dst[k] = src[k];
+    for (int k = tid; k < (int)(sizeof(CompactMats) / sizeof(double)); k += FE_THREADS) st_x<SC1>(dst + k, src[k]);
   }
   if (tid == 0) {
-    *F.state = S;
-    *F.plan = plan;
+    *F.state = S;        // (read by later launches only)
+    if (SC1) {           // the plan is read by the other workgroups of this launch: word by word, written through
+      static_assert(sizeof(CompactPlan) % 4 == 0, "plan copied as 32-bit words");
+      const unsigned* src = reinterpret_cast<const unsigned*>(&plan);
+      unsigned* dst = reinterpret_cast<unsigned*>(F.plan);
+      for (int k = 0; k < (int)(sizeof(CompactPlan) / 4); ++k) __hip_atomic_store(dst + k, src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      *F.plan = plan;
+    }
     *status_out = (plan.action == CA_STOP || plan.action == CA_STOP_RESTORE) ? S.status : -1;
   }
 }
@@ -637,37 +646,39 @@ __global__ __launch_bounds__(FE_THREADS) void fe_tail_kernel(FeDev F, SolveParam
   if (F.state->status >= 0) return;     // written by an earlier launch: uniform over the grid
   const int tid = threadIdx.x;
   for (int vb = blockIdx.x; vb < dot_blocks; vb += gridDim.x) {
-    fe_dots_block(F, o, vb, dot_blocks, red);
+    fe_dots_block<true>(F, o, vb, dot_blocks, red);
     __syncthreads();                     // red is reused
   }
+  // What crosses workgroups inside this launch — the shares, then plan and matrices — is written with write-through (sc1) stores
+  // and read with sc1 loads, so the hand-off needs a drained store queue and the counters only: no L2 write-back, no L1 invalidate
+  // (MI355X_MICROARCH.md, "valid forms": sc1 stores and loads on both sides). The first version used plain accesses with an
+  // agent-scope release / acquire pair on either side of both hand-offs: the kernel took 36 - 45 us for 24 us of work
+  // (profiles/r05_fe_counters.txt).
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     last = __hip_atomic_fetch_add(&F.sync->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-  __syncthreads();
+  __syncthreads();                       // (the shares are stored by threads of wavefront 0, whose queue thread 0 has just drained)
   if (last) {
-    fe_step_body(F, o, dot_blocks, status_out, tot, mats, part8);
+    fe_step_body<true>(F, o, dot_blocks, status_out, tot, mats, part8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wavefront: its part of the matrices is at the memory side
     __syncthreads();
     if (tid == 0) {
-      plan_s = *F.plan;   // (this thread wrote it)
       __hip_atomic_store(&F.sync->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_store(&F.sync->gen, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-  } else {
-    if (tid == 0) {
-      while (__hip_atomic_load(&F.sync->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) __builtin_amdgcn_s_sleep(2);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (tid == 0) plan_s = *F.plan;
+  }
+  if (tid == 0) {
+    if (!last) while (__hip_atomic_load(&F.sync->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) __builtin_amdgcn_s_sleep(2);
+    const unsigned* src = reinterpret_cast<const unsigned*>(F.plan);
+    unsigned* dst = reinterpret_cast<unsigned*>(&plan_s);
+    for (int k = 0; k < (int)(sizeof(CompactPlan) / 4); ++k) dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!last) {
     const double* src = reinterpret_cast<const double*>(F.mats);
     double* dst = reinterpret_cast<double*>(&mats);
-    for (int k = tid; k < (int)(sizeof(CompactMats) / sizeof(double)); k += FE_THREADS) dst[k] = src[k];
+    for (int k = tid; k < (int)(sizeof(CompactMats) / sizeof(double)); k += FE_THREADS) dst[k] = ld_x<true>(src + k);
     __syncthreads();
   }
   const CompactPlan plan = plan_s;
