@@ -772,6 +772,9 @@ def compact_line(full, detail_file):
     if full_share and "skipped" not in full_share:
         s["c5_full_share"] = {k: _r(full_share.get(k)) for k in ("entities", "s", "entities_per_s", "serial_s", "round_ms_p50", "round_ms_p99", "round_ms_max",
                                                                  "imbalance_vs_8_rank_mean_round") if full_share.get(k) is not None}
+        pb = full_share.get("partitions_per_batch") or {}
+        if "8" in pb:
+            s["c5_full_share"]["eps_8_partitions_per_batch"] = _r(pb["8"]["entities_per_s"])
         pr = full_share.get("projected_rounds")
         if pr:
             s["c5_full_share"].update(rounds=len(pr["rounds"]), plain_ms_total=_r(pr["plain_ms_total"]), rebalanced_ms_total=_r(pr["rebalanced_ms_total"]),

@@ -374,6 +374,8 @@ def projection_leg(name, ranks, solver, opts, c5_entities, steps=2, warmup=1, ml
                          "19.6 ms in a 2 ms step, once in a run - would otherwise be the slowest rank of the job)",
            "total_entities": sum(p["entities"] for p in per), "total_nnz": sum(p["nnz"] for p in per),
            "ms": float(ms.max()), "entities_per_s": conv / (float(ms.max()) * 1e-3), "imbalance": float(ms.max() / ms.mean()),
+           "ms_mean": float(max(p["ms_per_step_mean"] for p in per)),      # the slowest share by the MEAN of its timed steps (hiccups included)
+           "entities_per_s_by_mean": conv / (float(max(p["ms_per_step_mean"] for p in per)) * 1e-3),
            "sum_of_shares_ms": float(ms.sum()), "per_rank": per}
     assert out["total_entities"] == total_entities
     if all("rounds" in p for p in per):
@@ -501,6 +503,22 @@ def c5_full_share_leg(solver, opts, device_index, total_entities=100_000_000, ra
     t_pipe = time.perf_counter() - t_pipe
     for s in ws:
         s.close()
+    # ---- what several partitions per device batch would buy (NOT what the product path does: it trains one partition per round, as the
+    # reference's driver does): K consecutive partitions of the share concatenated in HBM (untimed), then pack + solve of the batch
+    batched = {}
+    for K in (2, 4, 8):
+        t_k, conv_k = 0.0, 0
+        for g0 in range(0, len(share), K):
+            raw = synthetic.concat_raw([r for r, _, _ in share[g0:g0 + K]])
+            sync()
+            t = time.perf_counter()
+            pk, rs = step(solver, raw)
+            sync()
+            t_k += time.perf_counter() - t
+            conv_k += converged(rs)
+            del pk, rs, raw
+        batched[str(K)] = {"s": t_k, "entities_per_s": E / t_k, "converged": conv_k}
+        torch.cuda.empty_cache()
     rm = np.array(round_ms)
     out = {"what": f"worker 0 of {ranks}: its {len(mine)} partitions of ONE population of {total_entities} Zipf-sized entities in {partitions} Java-hashed partitions "
                    "(SURVEY 8(d)), one partition per round, resident in HBM; s = the share's wall time over three contexts, serial_s = one context",
@@ -509,7 +527,9 @@ def c5_full_share_leg(solver, opts, device_index, total_entities=100_000_000, ra
            "round_ms_p50": float(np.percentile(rm, 50)), "round_ms_p99": float(np.percentile(rm, 99)), "round_ms_max": float(rm.max()),
            "round_ms_mean": float(rm.mean()), "round_ms": [round(float(x), 2) for x in rm],
            "largest_entity_nnz": int(max(int(n.max()) for _, n, _ in share) * pop.k),
-           "population_s": round(t_pop, 1), "generate_s": round(t_gen, 1)}
+           "population_s": round(t_pop, 1), "generate_s": round(t_gen, 1),
+           "partitions_per_batch": {"what": "the same share with K consecutive partitions concatenated into one device batch (one context): what a driver "
+                                            "that trains several partitions per launch would get; the product path trains one per round", **batched}}
     # ---- the first rounds of the whole job: every worker's partition of the round, plain and with the plan applied
     model, totals = SizeCostModel(), np.zeros((2, SizeCostModel.BUCKETS))
     rounds = []

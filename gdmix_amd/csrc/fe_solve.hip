@@ -642,8 +642,9 @@ __global__ __launch_bounds__(FE_THREADS) void fe_tail_kernel(FeDev F, SolveParam
   __shared__ CompactMats mats;
   __shared__ double part8[8][32];
   __shared__ CompactPlan plan_s;
-  __shared__ int last;
+  __shared__ int last, timed_out;
   if (F.state->status >= 0) return;     // written by an earlier launch: uniform over the grid
+  if (threadIdx.x == 0) timed_out = 0;
   const int tid = threadIdx.x;
   for (int vb = blockIdx.x; vb < dot_blocks; vb += gridDim.x) {
     fe_dots_block<true>(F, o, vb, dot_blocks, red);
@@ -669,12 +670,31 @@ __global__ __launch_bounds__(FE_THREADS) void fe_tail_kernel(FeDev F, SolveParam
     }
   }
   if (tid == 0) {
-    if (!last) while (__hip_atomic_load(&F.sync->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) __builtin_amdgcn_s_sleep(2);
+    if (!last) {
+      // bounded: a workgroup of this launch that never arrives (it cannot happen while at most one workgroup per CU is launched on an
+      // otherwise progressing device) must not hang the GPU — after ~4 s the problem is marked ABORTED, which also stops every later launch
+      unsigned spins = 0;
+      uint64_t t0 = 0;
+      while (__hip_atomic_load(&F.sync->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 1023u) == 0) {
+          const uint64_t now = wall_clock64();
+          if (t0 == 0) t0 = now;
+          else if (now - t0 > 400000000ull) {   // 4 s at 100 MHz
+            __hip_atomic_store(reinterpret_cast<int*>(&F.state->status), GDMIX_RE_ST_ABORTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(status_out, (int32_t)GDMIX_RE_ST_ABORTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            timed_out = 1;
+            break;
+          }
+        }
+      }
+    }
     const unsigned* src = reinterpret_cast<const unsigned*>(F.plan);
     unsigned* dst = reinterpret_cast<unsigned*>(&plan_s);
     for (int k = 0; k < (int)(sizeof(CompactPlan) / 4); ++k) dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
+  if (timed_out) return;
   if (!last) {
     const double* src = reinterpret_cast<const double*>(F.mats);
     double* dst = reinterpret_cast<double*>(&mats);

@@ -157,6 +157,7 @@ def device_score(solver, row_nnz_ptr, col_global, val, offset, theta, num_featur
     return score.cpu().numpy(), per.cpu().numpy()
 
 
+ST_ABORTED = 9      # GDMIX_RE_ST_ABORTED
 LOOKAHEAD = int(os.environ.get("GDMIX_FE_LOOKAHEAD", "2"))   # evaluations enqueued ahead of the status the host has read
 
 
@@ -270,6 +271,8 @@ def run_stepping_loop(problem, all_reduce=None, max_evals=100000, lookahead=None
         lookahead = LOOKAHEAD if (all_reduce is None or getattr(all_reduce, "device_ordered", False)) else 0
     if all_reduce is None:
         status, _ = problem.solve(lookahead, max_evals)
+        if status == ST_ABORTED:
+            raise RuntimeError("the fixed-effect step gave up waiting for a workgroup of its own launch (status 9): the result is invalid")
         if status >= 0:
             return status
         raise RuntimeError(f"the fixed-effect L-BFGS loop did not stop within {max_evals} evaluations")
@@ -280,6 +283,8 @@ def run_stepping_loop(problem, all_reduce=None, max_evals=100000, lookahead=None
         seq = problem.step_async()
         if k >= lookahead:
             status = problem.step_status(seq - lookahead)
+            if status == ST_ABORTED:
+                raise RuntimeError("the fixed-effect step gave up waiting for a workgroup of its own launch (status 9): the result is invalid")
             if status >= 0:
                 return problem.step_status(seq)      # (the steps behind the stop are no-ops with the same status: nothing left in flight)
     raise RuntimeError(f"the fixed-effect L-BFGS loop did not stop within {max_evals} evaluations")

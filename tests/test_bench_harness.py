@@ -187,6 +187,7 @@ def test_projection_of_an_eight_rank_job_on_one_device(tmp_path):
     fs = line["detail"]["c5_full_share"]
     assert fs["partitions"] == 128 and fs["converged"] == fs["converged_pipelined"] == fs["entities"] and 40_000 < fs["entities"] < 60_000
     assert len(fs["round_ms"]) == 128 and fs["round_ms_p50"] <= fs["round_ms_p99"] <= fs["round_ms_max"] and fs["s"] > 0 and fs["serial_s"] > 0
+    assert all(fs["partitions_per_batch"][k]["converged"] == fs["entities"] for k in ("2", "4", "8"))
     pr = fs["projected_rounds"]
     assert len(pr["rounds"]) == 3 and pr["rounds"][0]["priced_by"] == "non-zeros" and pr["rounds"][1]["priced_by"].startswith("measured")
     assert all(len(r["plain_ms"]) == 8 and len(r["rebalanced_ms"]) == 8 and r["imbalance"] >= 1.0 for r in pr["rounds"])
