@@ -130,7 +130,7 @@ class RandomEffectDriver:
                         break
                     next_dir = self._anchor_directory(self.model.training_data_dir, partition_index_list[k + ahead])
                     if not is_empty_directory(next_dir):   # a partition that will be skipped is not decoded (nor kept) at all
-                        self.model.prefetch(next_dir, self.model.metadata_file, schema_params, train_partition=partition_index_list[k + ahead])
+                        self.model.prefetch(next_dir, self.model.metadata_file, schema_params)
                         if ahead == 1:
                             self.model.prefetch_prior_model(partition_index_list[k + 1])
             checkpoint_path = self._anchor_directory(self.model.checkpoint_path, partition_index)

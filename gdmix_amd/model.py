@@ -34,7 +34,6 @@ TrainingResult = namedtuple("TrainingResult", ("theta", "variance", "unique_glob
 
 _ROW_BITS = 40
 _ROW_MASK = (1 << _ROW_BITS) - 1
-SOLVE_AHEAD = os.environ.get("GDMIX_SOLVE_AHEAD", "1") != "0"     # cold-start partitions packed + solved by the read-ahead thread (A/B switch)
 WRITE_BEHIND_THREADS = int(os.environ.get("GDMIX_WRITE_THREADS", "8"))   # files being written at a time behind the device work
 
 
@@ -378,9 +377,6 @@ class RandomEffectLRLBFGSModel:
         self._solver = None
         self._read_cache = None     # (key, batch) of the partition _train decoded last
         self._io_pool = None        # begin_pipeline(): files are read ahead and written behind the device work
-        self._solver_ahead = None   # second context: cold-start partitions are solved by the read-ahead thread (_solve_ahead)
-        import threading
-        self._ahead_lock = threading.Lock()
         self._write_pool = None
         self._prefetched = {}       # read key -> Future[RawBatch]
         self._prefetched_models = {}   # model file -> Future[ModelTable]
@@ -489,20 +485,15 @@ class RandomEffectLRLBFGSModel:
     def _read_key(self, input_path, num_features):
         return (os.path.abspath(input_path), self.model_params.partition_entity, self.feature_bag_name, num_features)
 
-    def prefetch(self, input_path, metadata_file, schema_params, train_partition=None):
-        """Start decoding the partition a later train() / predict() call will ask for. train_partition: the partition index when this
-        is the ACTIVE training data of a partition about to be trained — with no prior model for it (a cold start) the background
-        thread also packs and solves it on a context of its own and reads the result back (_solve_ahead), so that the main thread
-        finds the partition solved: its per-partition device latency (16 ms for 25 k Zipf-sized entities) leaves the critical path."""
+    def prefetch(self, input_path, metadata_file, schema_params):
+        """Start decoding the partition a later train() / predict() call will ask for."""
         if self._io_pool is None or not os.path.isdir(input_path):
             return
         tensor_metadata = DatasetMetadata(read_json_file(metadata_file))
         num_features = 1 if self.feature_bag_name is None else tensor_metadata.get_feature_shape(self.feature_bag_name)[0]
         key = self._read_key(input_path, num_features)
         if key not in self._prefetched:
-            cold = train_partition is not None and SOLVE_AHEAD and not os.path.exists(
-                os.path.join(self.model_params.output_model_dir, f"part-{int(train_partition):05d}.avro"))
-            self._prefetched[key] = self._io_pool.submit(self._read_ahead, input_path, tensor_metadata, schema_params, num_features, cold)
+            self._prefetched[key] = self._io_pool.submit(self._read_ahead, input_path, tensor_metadata, schema_params, num_features)
 
     def prefetch_prior_model(self, partition_index):
         """Start loading the model file train() will warm-start partition `partition_index` from, if there is one."""
@@ -580,7 +571,7 @@ class RandomEffectLRLBFGSModel:
         s = self._solver      # None: not created yet — it will be the device solver (there is no other in the product path)
         return s is None or isinstance(s, REDeviceSolver)
 
-    def _read_ahead(self, input_path, tensor_metadata, schema_params, num_features, solve=False):
+    def _read_ahead(self, input_path, tensor_metadata, schema_params, num_features):
         """prefetch(): decode the partition and — once the device solver exists — copy its arrays to HBM on a stream of this
         thread's own, so that the main thread finds the partition resident (the copy of a 125 k-entity C2 partition from
         pageable memory is 6 of the ~22 ms the main thread spends per partition: profiles/r04_host_path.txt). The first
@@ -598,36 +589,9 @@ class RandomEffectLRLBFGSModel:
                     ev = torch.cuda.Event()
                     ev.record(st)
                 batch._device = (raw, ev)
-                if solve and batch.has_label and self.model_params.random_effect_variance_mode is None:
-                    self._solve_ahead(batch, st)
             except Exception as e:    # the main thread uploads it then; a real device problem shows up there
                 logger.debug(f"upload ahead of {input_path} failed: {e}")
         return batch
-
-    def _solve_ahead(self, batch, stream):
-        """Cold-start partition, background thread: pack + solve on a second context (calls on one context are serialised; the main
-        thread's is busy with the partition before this one) and on this thread's stream, results read back; _solve_batch adopts
-        them. Persistent grids of the two contexts are chained on the device by the library (ScopedGridGate). Anything unusual —
-        a status outside fmin_l_bfgs_b's own — leaves the partition to the main thread's ordinary path."""
-        import torch
-        with self._ahead_lock:
-            if self._solver_ahead is None:
-                self._solver_ahead = REDeviceSolver(self._solver.device_index)
-            s2 = self._solver_ahead
-            opts = self._solver_options()
-            with torch.cuda.stream(stream):
-                raw, ev = batch.__dict__["_device"]
-                packed = s2.pack(s2.widen(raw) if "ent_n" in raw else raw, has_intercept=self.has_intercept)
-                feat_ptr = host_array(packed.ent_feat_ptr())
-                uniq = host_array(packed.unique_global())
-                solved = s2.solve(packed, opts, theta0=None)
-                res = solved.to_host(("theta_thr", "variance") + self._STAT_KEYS)
-                stream.synchronize()
-            st = res["status"]
-            if ((st < 0) | (st > 4)).any():
-                return
-            batch.__dict__.pop("_device", None)
-            batch._solved = (packed, solved, res, feat_ptr, uniq, raw)
 
     def _pack(self, solver, batch):
         """gdmix_re_pack of a partition; of its copy in HBM when _read_ahead made one."""
@@ -710,20 +674,7 @@ class RandomEffectLRLBFGSModel:
             theta_thr, variance, uniq = np.zeros(0), None, np.zeros(0, np.int64)
             feat_ptr = np.zeros(1, np.int64)
             stats = {k: np.zeros(0) for k in self._STAT_KEYS}
-        elif not model_weights and batch.__dict__.get("_solved") is not None:
-            # solved ahead by the read-ahead thread (cold start): its stream is idle; the tensors it allocated are used (scoring) and
-            # freed on this one from here on
-            import torch
-            packed, solved, res, feat_ptr, uniq, raw = batch.__dict__.pop("_solved")
-            cur = torch.cuda.current_stream(solver.device)
-            for t in list(packed._tensors.values()) + list(solved._t.values()) + list(raw.values()):
-                if isinstance(t, torch.Tensor) and t.is_cuda:
-                    t.record_stream(cur)
-            theta_thr, variance = res["theta_thr"], res.get("variance")
-            theta_dev = getattr(solved, "theta_thr", None)
-            stats = {k: res[k] for k in self._STAT_KEYS}
         else:
-            batch.__dict__.pop("_solved", None)
             packed = self._pack(solver, batch)
             feat_ptr = host_array(packed.ent_feat_ptr())
             uniq = host_array(packed.unique_global())

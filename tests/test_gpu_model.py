@@ -174,48 +174,6 @@ def test_cli_process_on_zipf_and_movielens_shaped_partition_directories(tmp_path
     assert compared >= 100 and worst <= 1e-5, (compared, worst)      # north_star: coefficients within 1e-5 rel-err of the reference L-BFGS
 
 
-def test_partitions_solved_ahead_by_the_read_ahead_thread_give_the_same_files(tmp_path, monkeypatch):
-    """Round 5: a cold-start partition is packed and solved by the thread that decoded and uploaded it, on a second context, while
-    the main thread finishes the partition before it (model.py: _solve_ahead) — the per-partition device latency of Zipf-sized
-    partitions (team tiers: persistent grids, chained across the two contexts by the library) leaves the critical path. Same files,
-    byte for byte, as with the switch off; a warm start (prior models on disk) takes the ordinary path and still agrees with itself."""
-    import filecmp
-    from gdmix_amd import gdmix as cli
-    from gdmix_amd import model as model_mod
-    from gdmix_amd import synthetic
-    from gdmix_amd.batch import concat
-    from gdmix_amd.partition_dirs import write_partition_dir
-    b = concat([synthetic.make_survey_batch(12000, 32, 8, 65536, seed=51, size_dist="c5zipf", with_uid=True),
-                synthetic.make_survey_batch(2, 9000, 8, 65536, seed=52, size_dist="const", entity_id_base=900_000, with_uid=True)])
-    b.uid = np.arange(b.N, dtype=np.int64)
-    used = []
-    real = model_mod.RandomEffectLRLBFGSModel._solve_ahead
-
-    def spy(self, batch, stream):
-        real(self, batch, stream)
-        used.append(batch.__dict__.get("_solved") is not None)
-    monkeypatch.setattr(model_mod.RandomEffectLRLBFGSModel, "_solve_ahead", spy)
-    outs = {}
-    for name, ahead in (("ahead", True), ("plain", False)):
-        d = tmp_path / name
-        argv, members, _ = write_partition_dir(str(d), b, 8, 65536)
-        monkeypatch.setattr(model_mod, "SOLVE_AHEAD", ahead)
-        os.environ.pop("TF_CONFIG", None)
-        cli.run(argv)
-        outs[name] = (d, members, argv)
-    assert sum(used) >= 4, used          # (the first partitions of a run are decoded before the device solver exists)
-    da, db = outs["ahead"][0], outs["plain"][0]
-    for k in outs["ahead"][1]:
-        assert filecmp.cmp(str(da / "models" / f"part-{k:05d}.avro"), str(db / "models" / f"part-{k:05d}.avro"), shallow=False), k
-        assert filecmp.cmp(str(da / "ts" / f"partitionId={k}" / "part-00000-active.avro"),
-                           str(db / "ts" / f"partitionId={k}" / "part-00000-active.avro"), shallow=False), k
-    # warm start from the models just written: nothing is solved ahead, and the run reproduces
-    n_before = len(used)
-    monkeypatch.setattr(model_mod, "SOLVE_AHEAD", True)
-    cli.run(outs["ahead"][2])
-    assert len(used) == n_before
-
-
 @pytest.mark.parametrize("dim,k", [(1024, 16), (1 << 17, 512)])
 def test_a_partition_the_reader_narrowed_packs_to_the_same_arrays(tmp_path, dim, k):
     """native reader with wire=True (gdmix_io_narrow) -> upload of the 32-bit form -> gdmix_re_widen -> pack: the packed batch and the
