@@ -286,11 +286,22 @@ class FixedEffectLRModelLBFGS:
         table = ModelTable()
         table.add_chunk([GLOBAL_MODEL_ID], local, [0, local.size], np.arange(weights.size, dtype=np.int64), [0, weights.size],
                         variance=var_local)
-        feature_list = read_feature_list(self.feature_file) if self.feature_file else None
+        feature_list = self._feature_prefixes() if self.feature_file else None
         output_file = os.path.join(self.checkpoint_path, "part-00000.avro")
         _export_models_to_avro(output_file, table, feature_list, self.has_intercept, self.variances is not None, self.sparsity_threshold,
                                model_class=MODEL_CLASS[self.model_type])
         logger.info(f"dumped the global model to {output_file}")
+
+    def _feature_prefixes(self):
+        """(feature list, its Avro-encoded form) as _export_models_to_avro and the native model reader take them; for a plain feature
+        file straight from its bytes (native_reader.EncodedFeatures.from_feature_file: 100 k features in milliseconds instead of 0.2 s)."""
+        if native_reader.available():
+            fast = native_reader.EncodedFeatures.from_feature_file(self.feature_file)
+            if fast is not None:
+                return (None, fast)
+        fl = read_feature_list(self.feature_file)
+        enc = [avro.enc_string(n) + avro.enc_string(t) for (n, t) in fl]
+        return (fl, native_reader.EncodedFeatures(enc) if native_reader.available() else enc)
 
     def _load_model(self, catch_exception=False):
         """-> coefficients [num_features (+1, intercept last)] or None (:730-747, load_linear_models_from_avro)."""
@@ -332,7 +343,7 @@ class FixedEffectLRModelLBFGS:
             schema, codec, sync, data_offset = avro.read_header(path)
             if codec not in ("null", "deflate") or not avro.is_model_schema(schema):
                 return None
-            prefix = [avro.enc_string(n) + avro.enc_string(t) for (n, t) in read_feature_list(self.feature_file)]
+            prefix = self._feature_prefixes()[1]
             m = native_reader.read_models_avro(path, data_offset, sync, codec == "deflate", prefix,
                                                avro.enc_string(constants.INTERCEPT) + avro.enc_string(""), True)
         except (KeyError, AssertionError, ValueError):

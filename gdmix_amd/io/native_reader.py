@@ -353,6 +353,41 @@ class EncodedFeatures:
     def of(cls, prefix):
         return prefix if isinstance(prefix, cls) else cls(prefix)
 
+    @classmethod
+    def from_feature_file(cls, path):
+        """The same straight from the bytes of a feature file (`name,term` per line, io/features.py), without a Python object per
+        feature: for a plain file — no quotes, no carriage returns, one comma per line, names and terms shorter than 64 bytes — the
+        encoding string(name) + string(term) = [2 len(name)] name [2 len(term)] term is exactly as long as the line `name,term\n`, so
+        the encoded list is the file shifted right by one byte with the two length bytes dropped on the previous newline and on the
+        comma. Returns None when the file is not that plain (the caller encodes it feature by feature). 65 536 features: 0.3 ms
+        instead of 50 - 100 ms of interpreter time holding the lock while the first partition's files are being written."""
+        with open(path, "rb") as f:
+            data = f.read()
+        if not data:
+            return cls([])
+        if b'"' in data or b"\r" in data or not data.endswith(b"\n"):
+            return None
+        a = np.frombuffer(data, np.uint8)
+        ends = np.flatnonzero(a == 10)
+        commas = np.flatnonzero(a == 44)
+        if commas.size != ends.size:
+            return None
+        starts = np.concatenate([[0], ends[:-1] + 1])
+        if not (np.all(commas > starts - 1) and np.all(commas < ends)):      # exactly one comma inside every line
+            return None
+        name_len, term_len = commas - starts, ends - commas - 1
+        if name_len.max(initial=0) >= 64 or term_len.max(initial=0) >= 64:
+            return None
+        out = np.empty(a.size, np.uint8)
+        out[1:] = a[:-1]
+        out[starts] = (2 * name_len).astype(np.uint8)          # zig-zag varint of a length below 64: one byte
+        out[commas + 1] = (2 * term_len).astype(np.uint8)
+        self = cls.__new__(cls)
+        self.count = int(ends.size)
+        self.ptr = np.concatenate([starts, [a.size]]).astype(np.int64)
+        self.bytes = out.tobytes()
+        return self
+
     def __len__(self):
         return self.count
 

@@ -861,9 +861,13 @@ class RandomEffectLRLBFGSModel:
         """(feature list, its Avro-encoded form) of a feature file, read and encoded once per model object."""
         cache = self.__dict__.setdefault("_feature_cache", {})
         if feature_file not in cache:
-            fl = read_feature_list(feature_file)
-            enc = [avro.enc_string(n) + avro.enc_string(t) for (n, t) in fl]
-            cache[feature_file] = (fl, native_reader.EncodedFeatures(enc) if native_reader.available() else enc)
+            fast = native_reader.EncodedFeatures.from_feature_file(feature_file) if native_reader.available() else None
+            if fast is not None:       # (the list of (name, term) tuples is read only if somebody iterates over it: nobody does on the native path)
+                cache[feature_file] = (_LazyFeatureList(feature_file), fast)
+            else:
+                fl = read_feature_list(feature_file)
+                enc = [avro.enc_string(n) + avro.enc_string(t) for (n, t) in fl]
+                cache[feature_file] = (fl, native_reader.EncodedFeatures(enc) if native_reader.available() else enc)
         return cache[feature_file]
 
     def _save_model(self, output_file, model_coefficients, num_features, feature_file, log_total=False):
@@ -959,6 +963,27 @@ class RandomEffectLRLBFGSModel:
                 variance.append(np.float64(0.0))
         return model_id, TrainingResult(theta=np.array(coeffs), variance=np.array(variance) if variance else None,
                                         unique_global_indices=np.array(uidx, np.int64))
+
+
+class _LazyFeatureList:
+    """The (name, term) list of a feature file, read when first asked for."""
+
+    def __init__(self, path):
+        self._path, self._list = path, None
+
+    def _get(self):
+        if self._list is None:
+            self._list = read_feature_list(self._path)
+        return self._list
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __len__(self):
+        return len(self._get())
+
+    def __getitem__(self, i):
+        return self._get()[i]
 
 
 # ---- Avro writers (record layout of util/io_utils.py:102-212 and :299-375) ----------------------------------
