@@ -119,9 +119,11 @@ __device__ __forceinline__ void wave_rank_sort(KeyPtr keys, KeyPtr sorted, int n
   wave_lds_fence();
 }
 
-// All comparators ascending, so keys at index >= n act as +inf padding and are simply skipped.
+// All comparators ascending, so keys at index >= n act as +inf padding and are simply skipped. Keys in LDS (the passes are fenced
+// for LDS only: a fence that also drained the wavefront's global accesses waited, 55 times per 1 024 keys, for the stores of the
+// entity before and the loads of the one after).
 template <class KeyPtr>
-__device__ __forceinline__ void wave_bitonic_sort(KeyPtr a, int n, int lane) {
+__device__ __forceinline__ void wave_bitonic_sort_lds(KeyPtr a, int n, int lane) {
   if (n < 2) return;
   int np2 = 1;
   while (np2 < n) np2 <<= 1;
@@ -144,7 +146,7 @@ __device__ __forceinline__ void wave_bitonic_sort(KeyPtr a, int n, int lane) {
           if (x > y) { a[i] = y; a[partner] = x; }
         }
       }
-      wave_mem_fence();
+      wave_lds_fence();
     }
   }
 }
@@ -279,10 +281,22 @@ __device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
   return v;
 }
 
+// Inclusive prefix maximum over the 64 lanes, same DPP ladder.
+__device__ __forceinline__ unsigned wave_incl_max_u32(unsigned v) {
+  unsigned w;
+  w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = w > v ? w : v;   // row_shr:1
+  w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = w > v ? w : v;   // row_shr:2
+  w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); v = w > v ? w : v;   // row_shr:4
+  w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); v = w > v ? w : v;   // row_shr:8
+  w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = w > v ? w : v;   // row_bcast:15 -> rows 1, 3
+  w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = w > v ? w : v;   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 constexpr int PACK_BITMAP_COLS = 2048;
 constexpr int PACK_BITMAP_WORDS = 5 * WAVE;
 template <class ValPtr>
-__device__ __forceinline__ int bitmap_entity(const unsigned long long* keys, unsigned* w, ValPtr vals, const int32_t* __restrict__ rp, int n,
+__device__ __forceinline__ int bitmap_entity(const unsigned long long* keys, unsigned* w, unsigned* rowid, ValPtr vals, const int32_t* __restrict__ rp, int n,
                                              int nnz, int lane, int32_t* __restrict__ csr_col, int32_t* __restrict__ col_ptr,
                                              int32_t* __restrict__ csc_row, float* __restrict__ csc_val,
                                              int32_t* __restrict__ uniq_sparse) {
@@ -293,7 +307,16 @@ __device__ __forceinline__ int bitmap_entity(const unsigned long long* keys, uns
   bm[lane] = 0u;
   cnt[lane] = 0u;
   cnt[lane + WAVE] = 0u;
+  rowid[lane] = 0u;
+  rowid[lane + WAVE] = 0u;
   wave_lds_fence();
+  // the sample of every non-zero = the last row that starts at or before it: row i > 0 marks its first position with i (the largest
+  // wins where empty rows share a start), a prefix maximum over the positions carries the marks forward (round 5; a binary search
+  // per non-zero over the row pointers was ~120 of this path's ~275 vector instructions per entity)
+  for (int i = lane; i < n; i += WAVE) {
+    const int s = rp[i];
+    if (i > 0 && s < nnz) atomicMax(&rowid[s], (unsigned)i);
+  }
   const bool v0 = lane < nnz, v1 = lane + WAVE < nnz;
   const unsigned c0 = v0 ? (unsigned)(keys[lane] >> 32) : 0u, c1 = v1 ? (unsigned)(keys[lane + WAVE] >> 32) : 0u;
   if (v0) atomicOr(&bm[c0 >> 5], 1u << (c0 & 31u));
@@ -346,6 +369,12 @@ __device__ __forceinline__ int bitmap_entity(const unsigned long long* keys, uns
   }
   wave_lds_fence();
   const int tiles = nnz > WAVE ? 2 : 1;
+  const unsigned row0 = wave_incl_max_u32(rowid[lane]);
+  unsigned row1 = 0;
+  if (tiles > 1) {
+    const unsigned m = wave_incl_max_u32(rowid[lane + WAVE]), top = (unsigned)__builtin_amdgcn_readlane((int)row0, WAVE - 1);
+    row1 = m > top ? m : top;
+  }
   for (int t = 0; t < tiles; ++t) {
     const int k = t * WAVE + lane;
     const bool valid = t ? v1 : v0;
@@ -367,12 +396,7 @@ __device__ __forceinline__ int bitmap_entity(const unsigned long long* keys, uns
     if (valid) {
       const unsigned kpos = *st + rank;
       csc_val[kpos] = vals[k];
-      int lo = 0, hi = n - 1;   // sample of non-zero k: last i with rp[i] <= k
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (rp[mid] <= k) lo = mid; else hi = mid - 1;
-      }
-      csc_row[kpos] = lo;
+      csc_row[kpos] = (int32_t)(t ? row1 : row0);
     }
     if (t + 1 < tiles) {   // a second tile follows: the columns that occur more than once move their start on
       wave_lds_fence();
@@ -386,6 +410,40 @@ __device__ __forceinline__ int bitmap_entity(const unsigned long long* keys, uns
 // CAP = LDS staging capacity (non-zeros and samples) of a wavefront, NWAVES = wavefronts per workgroup.
 // in_list == nullptr: all E entities, those above CAP skipped (pack_entnnz_kernel put them on a later stage's list);
 // otherwise the *in_count entities of in_list, which fit by construction.
+//
+// The walk is software-pipelined (round 5; before, a wavefront's trip was three memory latencies in a row — the entity's four pointers, its
+// columns / values / row pointers, and a wait for its own stores before the LDS staging was reused — and the kernel spent 71 % of its
+// wavefront-cycles in s_waitcnt at 2.2 TB/s, profiles/r05_final_c2_1m.txt):
+//   * the pointers of a wavefront's next 64 trips are loaded at once, one trip per lane, and handed out with readlane (scalars);
+//   * the first PACK_PF tiles of the NEXT trip's columns and values and its first 64 row pointers are requested right after the
+//     current trip's are staged into LDS — into the registers just consumed, so nothing is copied and nothing waits — and arrive
+//     while the current entity is ranked and written;
+//   * the end of a trip fences LDS only (the staging buffers); stores are never waited for.
+constexpr int PACK_PF = 4;       // 64-entry tiles of an entity requested one trip ahead (256 non-zeros: all of the first tier)
+struct PackAhead {
+  int64_t c[PACK_PF];
+  float v[PACK_PF];
+  int32_t rp;      // low word of the row pointer (the difference to the entity's first fits 31 bits; a register pair half of which
+                   // is dead gets reused while the load is in flight, and the wavefront then waits for it)
+};
+__device__ __forceinline__ int64_t readlane_i64(int64_t x, int src) {
+  const int lo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)x, src);
+  const int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)x >> 32), src);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+}
+__device__ __forceinline__ void pack_request(PackAhead& A, const int64_t* __restrict__ row_nnz_ptr, const int64_t* __restrict__ col_global,
+                                             const float* __restrict__ val, int64_t r0, int64_t z0, int n, int nnz, int lane) {
+#pragma unroll
+  for (int q = 0; q < PACK_PF; ++q) {
+    const int k = q * WAVE + lane;
+    if (k < nnz) {
+      A.c[q] = col_global[z0 + k];
+      A.v[q] = val[z0 + k];
+    }
+  }
+  if (lane <= n) A.rp = reinterpret_cast<const int32_t*>(row_nnz_ptr + r0)[2 * lane];
+}
+
 template <int CAP, int NWAVES>
 __global__ __launch_bounds__(WAVE* NWAVES) void pack_entity_kernel(
     const int32_t* __restrict__ in_list, const int* __restrict__ in_count,
@@ -409,77 +467,132 @@ __global__ __launch_bounds__(WAVE* NWAVES) void pack_entity_kernel(
   // grid-stride over entities: per-entity same-address atomics would serialise in L2 (~10 ns each), so maxima
   // are carried in registers and published once per workgroup.
   const int64_t total = in_list ? (int64_t)*in_count : E;
-  for (int64_t it = (int64_t)blockIdx.x * NWAVES + wv; it < total; it += (int64_t)gridDim.x * NWAVES) {
-    const int64_t e = in_list ? (int64_t)in_list[it] : it;
-    const int64_t r0 = ent_row_ptr[e], r1 = ent_row_ptr[e + 1];
-    const int64_t z0 = ent_nnz_ptr[e], z1 = ent_nnz_ptr[e + 1];
-    const int64_t n64 = r1 - r0, nnz64 = z1 - z0;
-    if (n64 > 0x7ffffff0ll || nnz64 > 0x7ffffff0ll) {
-      if (lane == 0) { atomicExch(&stats->err, GDMIX_RE_ERANGE); d_cnt[e] = 0; }
-      continue;
-    }
-    const int n = (int)n64, nnz = (int)nnz64;
-    const bool small = nnz <= CAP && n <= CAP;
-    if (!small) continue;   // a later stage's (which also writes its row pointers: one wavefront walking the rows of a 4 M-sample
-                            // entity here cost 27 ms; the last stage does it one thread per row)
-    int32_t* const rp_out = row_ptr + r0 + e;
-    for (int i = lane; i <= n; i += WAVE) {
-      const int32_t v = (int32_t)(row_nnz_ptr[r0 + i] - z0);
-      rp_out[i] = v;
-      lds_rp[wv][i] = v;
-    }
-    bool bad = false;
-    int d;
-    {
-      // explicit LDS instantiation (ds_* accesses; a generic pointer selecting between LDS and HBM compiles
-      // to flat_* accesses whose base+offset folding faults at the LDS aperture edge)
-      bool wide = false;   // a column of PACK_COUNT_COLS or above (or out of range)
-      bool wide2 = false;  // ... of PACK_BITMAP_COLS or above
-      for (int k = lane; k < nnz; k += WAVE) {
-        const int64_t c = col_global[z0 + k];
-        bad |= (c < 0 || c > 0x7fffffffll);
-        wide |= (uint64_t)c >= (uint64_t)PACK_COUNT_COLS;
-        wide2 |= (uint64_t)c >= (uint64_t)PACK_BITMAP_COLS;
-        lds_keys[wv][k] = ((unsigned long long)(uint32_t)c << 32) | (unsigned)k;
-        lds_val[wv][k] = val[z0 + k];
-      }
-      wave_lds_fence();
-      if (nnz <= PACK_RANK_MAX && pack_bitmap_on && __ballot(wide2) == 0ull) {
-        d = bitmap_entity(lds_keys[wv], lds_bm[wv], lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0, col_ptr + z0 + e,
-                          csc_row + z0, csc_val + z0, uniq_sparse + z0);
-      } else if (nnz <= PACK_RANK_MAX) {
-        wave_rank_sort(lds_keys[wv], lds_sorted[wv], nnz, lane);
-        d = emit_entity(lds_sorted[wv], lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0, col_ptr + z0 + e,
-                        csc_row + z0, csc_val + z0, uniq_sparse + z0);
-      } else if (__ballot(wide) == 0ull) {
-        d = count_entity(lds_keys[wv], reinterpret_cast<unsigned*>(lds_sorted[wv]), lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0,
-                         col_ptr + z0 + e, csc_row + z0, csc_val + z0, uniq_sparse + z0);
+  const int64_t stride = (int64_t)gridDim.x * NWAVES;
+  enum { SKIP = 0, SMALL = 1, RANGE = 2 };
+  for (int64_t it0 = (int64_t)blockIdx.x * NWAVES + wv; it0 < total; it0 += stride * WAVE) {
+    // this lane's trip of the next 64
+    const int64_t my_it = it0 + (int64_t)lane * stride;
+    int64_t my_e = 0, my_r0 = 0, my_z0 = 0;
+    int my_n = 0, my_nnz = 0, my_state = SKIP;
+    if (my_it < total) {
+      my_e = in_list ? (int64_t)in_list[my_it] : my_it;
+      my_r0 = ent_row_ptr[my_e];
+      my_z0 = ent_nnz_ptr[my_e];
+      const int64_t n64 = ent_row_ptr[my_e + 1] - my_r0, nnz64 = ent_nnz_ptr[my_e + 1] - my_z0;
+      if (n64 > 0x7ffffff0ll || nnz64 > 0x7ffffff0ll) {
+        my_state = RANGE;
       } else {
-        wave_bitonic_sort(lds_keys[wv], nnz, lane);
-        d = emit_entity(lds_keys[wv], lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0, col_ptr + z0 + e,
-                        csc_row + z0, csc_val + z0, uniq_sparse + z0);
+        my_n = (int)n64; my_nnz = (int)nnz64;
+        // not small: a later stage's (which also writes its row pointers: one wavefront walking the rows of a 4 M-sample entity here
+        // cost 27 ms; the last stage does it one thread per row)
+        my_state = (my_nnz <= CAP && my_n <= CAP) ? SMALL : SKIP;
       }
     }
-    if (__ballot(bad) && lane == 0) atomicExch(&stats->err, GDMIX_RE_ERANGE);
-    if (lane == 0) d_cnt[e] = d;
-    mx_p = max(mx_p, d + ic); mx_n = max(mx_n, n); mx_z = max(mx_z, nnz);
-    wave_mem_fence();   // the LDS staging buffers are reused by the next entity of this wave
+    const int64_t left = (total - it0 + stride - 1) / stride;
+    const int cnt = __builtin_amdgcn_readfirstlane((int)(left < WAVE ? left : WAVE));
+    PackAhead A;
+    if (__builtin_amdgcn_readlane(my_state, 0) == SMALL)
+      pack_request(A, row_nnz_ptr, col_global, val, readlane_i64(my_r0, 0), readlane_i64(my_z0, 0), __builtin_amdgcn_readlane(my_n, 0),
+                   __builtin_amdgcn_readlane(my_nnz, 0), lane);
+    for (int t = 0; t < cnt; ++t) {
+      const int state = __builtin_amdgcn_readlane(my_state, t);
+      const int64_t e = readlane_i64(my_e, t), r0 = readlane_i64(my_r0, t), z0 = readlane_i64(my_z0, t);
+      const int n = __builtin_amdgcn_readlane(my_n, t), nnz = __builtin_amdgcn_readlane(my_nnz, t);
+      // all the columns OR-ed: the three questions asked of them are thresholds at powers of two (any column outside [0, 2^31)?
+      // any of PACK_COUNT_COLS or above? any of PACK_BITMAP_COLS or above?), which the OR answers for every one of them at once
+      uint64_t orc = 0;
+      bool bad = false;
+      int32_t* const rp_out = row_ptr + r0 + e;
+      if (state == SMALL) {   // stage what was requested a trip ago
+#pragma unroll
+        for (int q = 0; q < PACK_PF; ++q) {
+          const int k = q * WAVE + lane;
+          if (k < nnz) {
+            const int64_t c = A.c[q];
+            orc |= (uint64_t)c;
+            lds_keys[wv][k] = ((unsigned long long)(uint32_t)c << 32) | (unsigned)k;
+            lds_val[wv][k] = A.v[q];
+          }
+        }
+        if (lane <= n) {
+          const int32_t v = (int32_t)((uint32_t)A.rp - (uint32_t)(uint64_t)z0);
+          rp_out[lane] = v;
+          lds_rp[wv][lane] = v;
+        }
+      }
+      if (t + 1 < cnt && __builtin_amdgcn_readlane(my_state, t + 1) == SMALL)
+        pack_request(A, row_nnz_ptr, col_global, val, readlane_i64(my_r0, t + 1), readlane_i64(my_z0, t + 1),
+                     __builtin_amdgcn_readlane(my_n, t + 1), __builtin_amdgcn_readlane(my_nnz, t + 1), lane);
+      if (state != SMALL) {
+        if (state == RANGE && lane == 0) { atomicExch(&stats->err, GDMIX_RE_ERANGE); d_cnt[e] = 0; }
+        continue;
+      }
+      if (CAP > PACK_PF * WAVE) {   // the rest of a larger tier's entity, not requested ahead
+        for (int k = PACK_PF * WAVE + lane; k < nnz; k += WAVE) {
+          const int64_t c = col_global[z0 + k];
+          orc |= (uint64_t)c;
+          lds_keys[wv][k] = ((unsigned long long)(uint32_t)c << 32) | (unsigned)k;
+          lds_val[wv][k] = val[z0 + k];
+        }
+      }
+      for (int i = WAVE + lane; i <= n; i += WAVE) {
+        const int32_t v = (int32_t)(row_nnz_ptr[r0 + i] - z0);
+        rp_out[i] = v;
+        lds_rp[wv][i] = v;
+      }
+      int d;
+      {
+        // explicit LDS instantiation (ds_* accesses; a generic pointer selecting between LDS and HBM compiles
+        // to flat_* accesses whose base+offset folding faults at the LDS aperture edge)
+        wave_lds_fence();
+        static_assert((PACK_COUNT_COLS & (PACK_COUNT_COLS - 1)) == 0 && (PACK_BITMAP_COLS & (PACK_BITMAP_COLS - 1)) == 0, "thresholds of the OR");
+        const bool wide = orc >= (uint64_t)PACK_COUNT_COLS, wide2 = orc >= (uint64_t)PACK_BITMAP_COLS;
+        bad = orc > 0x7fffffffull;
+        if (nnz <= PACK_RANK_MAX && pack_bitmap_on && __ballot(wide2) == 0ull) {
+          d = bitmap_entity(lds_keys[wv], lds_bm[wv], reinterpret_cast<unsigned*>(lds_sorted[wv]), lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0, col_ptr + z0 + e,
+                            csc_row + z0, csc_val + z0, uniq_sparse + z0);
+        } else if (nnz <= PACK_RANK_MAX) {
+          wave_rank_sort(lds_keys[wv], lds_sorted[wv], nnz, lane);
+          d = emit_entity(lds_sorted[wv], lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0, col_ptr + z0 + e,
+                          csc_row + z0, csc_val + z0, uniq_sparse + z0);
+        } else if (__ballot(wide) == 0ull) {
+          d = count_entity(lds_keys[wv], reinterpret_cast<unsigned*>(lds_sorted[wv]), lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0,
+                           col_ptr + z0 + e, csc_row + z0, csc_val + z0, uniq_sparse + z0);
+        } else {
+          wave_bitonic_sort_lds(lds_keys[wv], nnz, lane);
+          d = emit_entity(lds_keys[wv], lds_val[wv], lds_rp[wv], n, nnz, lane, csr_col + z0, col_ptr + z0 + e,
+                          csc_row + z0, csc_val + z0, uniq_sparse + z0);
+        }
+      }
+      if (__ballot(bad) && lane == 0) atomicExch(&stats->err, GDMIX_RE_ERANGE);
+      if (lane == 0) d_cnt[e] = d;
+      mx_p = max(mx_p, d + ic); mx_n = max(mx_n, n); mx_z = max(mx_z, nnz);
+      wave_lds_fence();   // the LDS staging buffers are reused by the next entity of this wave (its stores are not waited for)
+    }
   }
   if (lane == 0) {
     atomicMax(&blk_max[0], mx_p); atomicMax(&blk_max[1], mx_n); atomicMax(&blk_max[2], mx_z);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    atomicMax(&stats->max_p, blk_max[0]);
-    atomicMax(&stats->max_n, blk_max[1]);
-    atomicMax(&stats->max_nnz, blk_max[2]);
+  // same-address atomics of thousands of workgroups ending together serialise in L2 (an empty later tier's 1 024 workgroups: 37 us of
+  // nothing else); the maxima only grow, so a workgroup whose own are not above what is there already has nothing to publish
+  if (threadIdx.x < 3) {
+    int* const dst = threadIdx.x == 0 ? &stats->max_p : (threadIdx.x == 1 ? &stats->max_n : &stats->max_nnz);
+    const int mine = blk_max[threadIdx.x];
+    if (mine > __atomic_load_n(dst, __ATOMIC_RELAXED)) atomicMax(dst, mine);
   }
 }
 
 // unique_global[ent_feat_ptr[e] + l] = uniq_sparse[ent_nnz_ptr[e] + l]: the compact local -> global map.
 // A wavefront takes 64 consecutive entities: their pointers in one coalesced load (one entity per lane), then entity by entity
-// with the pointers broadcast from the lane that holds them, four entities' loads in flight before the first store (one entity
-// per trip with its pointers loaded inside the trip was three dependent memory latencies per entity: 0.31 ms on C2).
+// with the pointers broadcast from the lane that holds them, COMPACT_DEPTH entities' loads in flight before the first store (one
+// entity per trip with its pointers loaded inside the trip was three dependent memory latencies per entity: 0.31 ms on C2; four in
+// flight 0.21 ms: C2's entities have ~60 columns, 0.24 GB read + 0.48 GB written = 3.4 TB/s, what a copy of that shape reaches;
+// eight in flight 0.31 ms, one entity per lane no better: profiles/r05_pack_ab.txt).
+#ifndef GDMIX_COMPACT_DEPTH
+#define GDMIX_COMPACT_DEPTH 4
+#endif
+constexpr int COMPACT_DEPTH = GDMIX_COMPACT_DEPTH;
 __global__ __launch_bounds__(256) void pack_compact_unique_kernel(const int64_t* __restrict__ ent_nnz_ptr,
                                                                    const int64_t* __restrict__ ent_feat_ptr, int64_t E,
                                                                    const int32_t* __restrict__ uniq_sparse,
@@ -491,11 +604,11 @@ __global__ __launch_bounds__(256) void pack_compact_unique_kernel(const int64_t*
     const int64_t my_z0 = ent_nnz_ptr[e], my_f0 = ent_feat_ptr[e];
     const int my_d = e0 + lane < E ? (int)(ent_feat_ptr[e + 1] - my_f0) : 0;
     const int cnt = (int)(E - e0 < WAVE ? E - e0 : WAVE);
-    for (int k = 0; k < cnt; k += 4) {
-      int64_t z0[4], f0[4];
-      int d[4], v[4];
+    for (int k = 0; k < cnt; k += COMPACT_DEPTH) {
+      int64_t z0[COMPACT_DEPTH], f0[COMPACT_DEPTH];
+      int d[COMPACT_DEPTH], v[COMPACT_DEPTH];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < COMPACT_DEPTH; ++q) {
         const int src = k + q < WAVE ? k + q : WAVE - 1;
         z0[q] = __shfl(my_z0, src);
         f0[q] = __shfl(my_f0, src);
@@ -503,7 +616,7 @@ __global__ __launch_bounds__(256) void pack_compact_unique_kernel(const int64_t*
         v[q] = lane < d[q] ? uniq_sparse[z0[q] + lane] : 0;
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < COMPACT_DEPTH; ++q) {
         if (lane < d[q]) unique_global[f0[q] + lane] = (int64_t)v[q];
         for (int l = lane + WAVE; l < d[q]; l += WAVE) unique_global[f0[q] + l] = (int64_t)uniq_sparse[z0[q] + l];   // p > 64: rare here
       }
@@ -713,8 +826,16 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
     HIP_TRY(side_join.use(0));
     HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(PackStats), hipMemcpyDeviceToHost, sb));
   }
+  // one round of workgroups, all resident (every workgroup walks the same number of entities: 16 per CU were 2.7 rounds of the 6 that
+  // fit, the last one two-thirds full)
+  static int pack_occupancy = 0;
+  if (pack_occupancy == 0) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pack_entity_kernel<PACK_LDS_KEYS, PACK_WAVES>, WAVE * PACK_WAVES, 0) != hipSuccess || occ < 1) occ = 4;
+    pack_occupancy = occ;
+  }
   int eblocks = (int)((E + PACK_WAVES - 1) / PACK_WAVES);
-  if (eblocks > ctx->num_cus * 16) eblocks = ctx->num_cus * 16;
+  if (eblocks > ctx->num_cus * pack_occupancy) eblocks = ctx->num_cus * pack_occupancy;
   hipLaunchKernelGGL((pack_entity_kernel<PACK_LDS_KEYS, PACK_WAVES>), dim3(eblocks), dim3(WAVE * PACK_WAVES), 0, s,
                      (const int32_t*)nullptr, (const int*)nullptr, raw->ent_row_ptr,
                      raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
