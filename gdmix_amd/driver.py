@@ -118,12 +118,42 @@ class RandomEffectDriver:
             if pipelined:
                 self.model.end_pipeline()
 
+    def _plan_group(self, k, partition_index_list, schema_params):
+        """From round k on: the consecutive partitions without a prior model, up to the model's limits (count, bytes of input), are handed
+        to the model as one group — it solves them in one device batch and still writes every partition's own files (model.plan_group).
+        -> the number of rounds the plan covers (1: partition k on its own)."""
+        limit = getattr(self.model, "group_limits", None)
+        if limit is None:
+            return 1
+        max_count, max_bytes = limit()
+        out_dir = self.model.model_params.output_model_dir
+        dirs, covered, total = [], 0, 0
+        for p in partition_index_list[k:]:
+            d = self._anchor_directory(self.model.training_data_dir, p)
+            if is_empty_directory(d):        # skipped by the loop below, whatever group it falls into
+                covered += 1
+                continue
+            if os.path.exists(os.path.join(out_dir, f"part-{p:05d}.avro")):    # warm start: on its own
+                break
+            size = sum(os.path.getsize(f) for f in glob.glob(os.path.join(d, "*")) if os.path.isfile(f))
+            if dirs and (len(dirs) >= max_count or total + size > max_bytes):
+                break
+            dirs.append(d)
+            total += size
+            covered += 1
+        if len(dirs) < 2 or self.model.plan_group(dirs, self.model.metadata_file, schema_params) != len(dirs):
+            return 1
+        return covered
+
     def _train_rounds(self, rounds, partition_index_list, lockstep, schema_params, export_model, output_model_dir, pipelined):
+        planned_until = 0
         for k in range(rounds):
             if k >= len(partition_index_list):
                 self.model.idle_round()
                 continue
             partition_index = partition_index_list[k]
+            if pipelined and not lockstep and k >= planned_until:
+                planned_until = k + self._plan_group(k, partition_index_list, schema_params)
             if pipelined:   # decode the next partitions while this one is solved (prefetch() ignores what is already on its way)
                 for ahead in range(1, PREFETCH_PARTITIONS + 1):
                     if k + ahead >= len(partition_index_list):

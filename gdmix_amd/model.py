@@ -35,6 +35,15 @@ TrainingResult = namedtuple("TrainingResult", ("theta", "variance", "unique_glob
 _ROW_BITS = 40
 _ROW_MASK = (1 << _ROW_BITS) - 1
 WRITE_BEHIND_THREADS = int(os.environ.get("GDMIX_WRITE_THREADS", "8"))   # files being written at a time behind the device work
+# Partitions of a cold start solved in ONE device batch (plan_group; 1 = every partition on its own, as the reference trains them, and the
+# default). A partition of a hashed population is a small batch for an MI355X — one rank's share of BASELINE config 5, one partition per
+# launch, 3.8 M entities/s on the device; eight per launch 5.3 M (profiles/r05_c5_full_share.txt): what a partition waits for is the latency
+# of its few largest entities, which a larger batch shares. Opt-in because a run through the CLI is not bound by that today: with the
+# files decoded and written around it the C5-shaped run is 0.89 - 0.92 M entities/s one partition per launch and 0.84 - 0.88 M with eight
+# (the group waits for all its partitions to be decoded and writes all their files at once: profiles/r05_group_ab.txt). The files that
+# come out are per partition either way.
+GROUP_MAX = max(1, int(os.environ.get("GDMIX_PARTITIONS_PER_BATCH", "1")))
+GROUP_MAX_BYTES = int(float(os.environ.get("GDMIX_GROUP_MB", "512")) * (1 << 20))    # ... of at most this much input (files on disk)
 
 
 class ModelTable:
@@ -381,6 +390,8 @@ class RandomEffectLRLBFGSModel:
         self._prefetched = {}       # read key -> Future[RawBatch]
         self._prefetched_models = {}   # model file -> Future[ModelTable]
         self._pending_writes = []
+        self._group = None          # plan_group(): partitions that are solved in one device batch
+        self._decoded = {}          # read key -> RawBatch decoded for a group, until _read hands it out
         self.last_training_stats = None
 
     # ---- Model API (models/api.py) ---------------------------------------------------------------------
@@ -492,7 +503,7 @@ class RandomEffectLRLBFGSModel:
         tensor_metadata = DatasetMetadata(read_json_file(metadata_file))
         num_features = 1 if self.feature_bag_name is None else tensor_metadata.get_feature_shape(self.feature_bag_name)[0]
         key = self._read_key(input_path, num_features)
-        if key not in self._prefetched:
+        if key not in self._prefetched and key not in self._decoded:
             self._prefetched[key] = self._io_pool.submit(self._read_ahead, input_path, tensor_metadata, schema_params, num_features)
 
     def prefetch_prior_model(self, partition_index):
@@ -528,6 +539,7 @@ class RandomEffectLRLBFGSModel:
             for f in list(self._prefetched.values()) + list(self._prefetched_models.values()):
                 f.cancel()
             self._prefetched, self._prefetched_models = {}, {}
+            self._group, self._decoded = None, {}
             if self._io_pool is not None:
                 self._io_pool.shutdown(wait=True)
                 self._write_pool.shutdown(wait=True)
@@ -548,10 +560,12 @@ class RandomEffectLRLBFGSModel:
             batch = self._read_cache[1]
             self._read_cache = None
             return batch
+        batch = self._decoded.pop(key, None)
         ahead = self._prefetched.pop(key, None)
-        batch = ahead.result() if ahead is not None else self._read_files(input_path, tensor_metadata, schema_params, num_features)
+        if batch is None:
+            batch = ahead.result() if ahead is not None else self._read_files(input_path, tensor_metadata, schema_params, num_features)
         if need_label:
-            self._read_cache = [key, batch, None, None]   # _train adds the packed batch and the coefficients it found
+            self._read_cache = [key, batch, None, None, None]   # _train adds the packed batch and the coefficients it found (or its group)
         return batch
 
     def _read_files(self, input_path, tensor_metadata, schema_params, num_features):
@@ -610,17 +624,28 @@ class RandomEffectLRLBFGSModel:
     def _train(self, input_path, tensor_metadata, model_weights, num_features, schema_params, output_model_file):
         logger.info(f"Start training with {f'loaded {len(model_weights)} previous models' if model_weights else 'zeros'} "
                     f"as the model initial value.")
+        key = self._read_key(input_path, num_features)
+        member = None
+        if self._group is not None and key in self._group["keys"] and not model_weights:
+            member = self._group_member(self._group, key, num_features)      # solved with the partitions around it, or None
         batch = self._read(input_path, tensor_metadata, schema_params, num_features, need_label=True)
         if not batch.has_label:
             raise KeyError(f"label column {schema_params.label_column_name!r} is missing from the training data")
-        theta_thr, variance, uniq, feat_ptr, stats, resident = self._solve_batch(batch, model_weights, num_features)
+        if member is not None and member["batch"] is batch:
+            theta_thr, variance, uniq, feat_ptr, stats = member["solve"]
+            resident = None
+        else:
+            theta_thr, variance, uniq, feat_ptr, stats, resident = self._solve_batch(batch, model_weights, num_features)
         ic = 1 if self.has_intercept else 0
         coef_ptr = feat_ptr + np.arange(batch.E + 1, dtype=np.int64) * ic
         self.last_training_stats = dict(entities=batch.E, samples=batch.N, nnz=batch.Z, **stats)
         results = ModelTable()
         results.add_chunk(batch.entity_ids, theta_thr, coef_ptr, uniq, feat_ptr, variance)
-        if self._read_cache is not None and self._read_cache[1] is batch and resident is not None and len(results) == batch.E:
-            self._read_cache[2:] = list(resident)     # (an entity id listed twice is scored with its later model: no shortcut)
+        if self._read_cache is not None and self._read_cache[1] is batch and len(results) == batch.E:   # (an entity id listed twice is scored with its later model: no shortcut)
+            if resident is not None:
+                self._read_cache[2:4] = list(resident)
+            elif member is not None and member["batch"] is batch:
+                self._read_cache[4] = (self._group, member["rows"])     # scored from the group's device batch (_predict)
         # The trained model is updated over the prior model: prior entities that are not in the current data
         # are carried over (random_effect_lr_lbfgs_model.py:155-162).
         model_weights.update(results)
@@ -629,6 +654,151 @@ class RandomEffectLRLBFGSModel:
         self._write_behind(output_model_file, self._save_model, output_model_file, model_coefficients=model_weights, num_features=num_features,
                            feature_file=self.feature_file, log_total=True)
         return model_weights
+
+    # ---- several partitions in one device batch (cold start) -----------------------------------------------------
+    def plan_group(self, input_paths, metadata_file, schema_params):
+        """The driver is about to train these partitions one after another, none of them with a prior model: decode them all ahead;
+        the first train() call among them then solves all of them in ONE device batch (their wire forms concatenated in HBM) and
+        every call takes its own entities' slice of the result — models, statistics and scores per partition as if each had been solved
+        alone (an entity's kernel is chosen per batch, so its last bits may differ from a run partition by partition, as they may
+        between any two batch compositions: include/gdmix_re.h). -> the number of partitions taken (0: not grouping)."""
+        self._group = None      # (what an unused group decoded stays in _decoded / _prefetched for _read)
+        if GROUP_MAX < 2 or len(input_paths) < 2 or self._io_pool is None or self.model_params.rebalance_entities \
+                or not self._wants_wire():
+            return 0
+        if self._solver is None:
+            try:
+                self._get_solver()      # before the decodes are queued: they upload what they decode once the solver exists
+            except Exception:           # no device: the first solve says so, where it always did
+                return 0
+            if not isinstance(self._solver, REDeviceSolver):
+                return 0
+        tensor_metadata = DatasetMetadata(read_json_file(metadata_file))
+        num_features = 1 if self.feature_bag_name is None else tensor_metadata.get_feature_shape(self.feature_bag_name)[0]
+        paths = list(input_paths)[:GROUP_MAX]
+        for p in paths:
+            self.prefetch(p, metadata_file, schema_params)
+        self._group = dict(keys=[self._read_key(p, num_features) for p in paths], paths=paths, state="planned", members={},
+                           resident=None, scores=None, meta=(tensor_metadata, schema_params))
+        return len(paths)
+
+    @staticmethod
+    def group_limits():
+        """(partitions, bytes of input files) a group may have: what the driver plans with."""
+        return GROUP_MAX, GROUP_MAX_BYTES
+
+    def _group_member(self, g, key, num_features):
+        if g["state"] == "planned":
+            g["state"] = "failed"       # unless the solve below completes
+            self._group_solve(g, num_features)
+        return g["members"].get(key) if g["state"] == "solved" else None
+
+    def _device_wire(self, solver, batch):
+        """The wire form of a decoded partition in HBM: what _read_ahead uploaded, or uploaded now."""
+        ahead = batch.__dict__.pop("_device", None)
+        if ahead is not None:
+            import torch
+            raw, ev = ahead
+            cur = torch.cuda.current_stream(solver.device)
+            cur.wait_event(ev)
+            for v in raw.values():       # allocated on the upload stream, used (and later freed) on this one
+                if isinstance(v, torch.Tensor):
+                    v.record_stream(cur)
+            if "ent_n" in raw:
+                return raw
+        return solver.upload_wire(batch.to_wire())
+
+    @staticmethod
+    def _cat_wire(t, wires):
+        """Wire forms of several partitions (device tensors) -> one. Count and index arrays of different widths are widened to the
+        widest first. None if the partitions do not go together (weights in some of them only)."""
+        out = {k: sum(w[k] for w in wires) for k in ("E", "N", "Z")}
+        for k in ("row_nnz_width", "col_width", "y_width"):
+            out[k] = max(w[k] for w in wires)
+        for k in REDeviceSolver.WIRE_ARRAYS:
+            parts = [w[k] for w in wires]
+            if all(x is None for x in parts):
+                out[k] = None
+                continue
+            if any(x is None for x in parts):
+                return None
+            widest = max((x.dtype for x in parts), key=lambda d: t.empty(0, dtype=d).element_size())
+            parts = [x if x.dtype == widest else x.to(widest) for x in parts]
+            out[k] = t.cat([x.reshape(-1).view(t.uint8) for x in parts]).view(widest)     # (byte views: every width concatenates)
+        return out
+
+    def _group_solve(self, g, num_features):
+        """Pack + solve of all partitions of the group in one batch; g["members"][key] = that partition's slice."""
+        tensor_metadata, schema_params = g["meta"]
+        batches = []
+        for key, path in zip(g["keys"], g["paths"]):
+            b = self._decoded.get(key)
+            if b is None:
+                ahead = self._prefetched.pop(key, None)
+                b = ahead.result() if ahead is not None else self._read_files(path, tensor_metadata, schema_params, num_features)
+                self._decoded[key] = b       # _read finds it there when its turn comes
+            batches.append(b)
+        live = [(k, b) for k, b in zip(g["keys"], batches) if b.E > 0]
+        if len(live) < 2 or not all(isinstance(b, WireRawBatch) and b.has_label for _, b in live):
+            return
+        solver, opts = self._get_solver(), self._solver_options()
+        cat = self._cat_wire(solver.torch, [self._device_wire(solver, b) for _, b in live])
+        if cat is None:
+            return
+        pack = lambda: solver.pack(solver.widen(cat), has_intercept=self.has_intercept)
+        packed, solved, res = self._pack_and_solve(solver, pack, opts, None)
+        E = cat["E"]
+        self._check_statuses(res["status"], E)
+        ic = 1 if self.has_intercept else 0
+        feat_ptr = host_array(packed.ent_feat_ptr())
+        uniq = host_array(packed.unique_global())
+        coef_ptr = feat_ptr + np.arange(E + 1, dtype=np.int64) * ic
+        theta_thr, variance = res["theta_thr"], res.get("variance")
+        e0 = n0 = 0
+        for key, b in live:
+            e1, n1 = e0 + b.E, n0 + b.N
+            c0, c1 = int(coef_ptr[e0]), int(coef_ptr[e1])
+            g["members"][key] = dict(batch=b, rows=(n0, n1), solve=(
+                theta_thr[c0:c1], None if variance is None else variance[c0:c1], uniq[int(feat_ptr[e0]):int(feat_ptr[e1])],
+                feat_ptr[e0:e1 + 1] - feat_ptr[e0], {k: res[k][e0:e1] for k in self._STAT_KEYS}))
+            e0, n0 = e1, n1
+        theta_dev = getattr(solved, "theta_thr", None)
+        g["resident"] = (packed, theta_dev if theta_dev is not None else theta_thr)
+        g["state"] = "solved"
+        logger.info(f"{len(live)} partitions solved in one device batch: {E} entities, {cat['N']} samples")
+
+    def _group_scores(self, g, rows):
+        """Scores of the training samples rows[0]:rows[1] of the group's batch with the models just trained: one scoring pass for the
+        whole group, at the first partition that asks."""
+        if g["scores"] is None:
+            packed, theta = g["resident"]
+            logit, per_coord = self._get_solver().score(packed, theta, None)
+            g["scores"] = (host_array(logit), host_array(per_coord))
+            g["resident"] = None        # the packed batch and the coefficients leave HBM
+        logit, per_coord = g["scores"]
+        return logit[rows[0]:rows[1]], per_coord[rows[0]:rows[1]]
+
+    def _pack_and_solve(self, solver, pack, opts, theta0):
+        """pack() -> solve -> results on the host; once more without the tall team class if a team barrier timed out."""
+        packed = pack()
+        solved = solver.solve(packed, opts, theta0=theta0)
+        res = solved.to_host(("theta_thr", "variance") + self._STAT_KEYS)
+        if (res["status"] == self.ST_ABORTED).any() and getattr(solver, "tall_team_n", 0) != 0:
+            # a team of workgroups gave up waiting for a member (a device too busy, or too small, to keep four whole CUs per
+            # team resident: csrc/re_solve_tall.hip). Not a reason to lose the job: the partition again with every tall
+            # entity on ONE workgroup (same arithmetic up to the order of its sums), once.
+            logger.warning(f"{int((res['status'] == self.ST_ABORTED).sum())} entities timed out at a team barrier: "
+                           "solving the partition again without the tall team class")
+            keep = solver.tall_team_n
+            solver.set_tall_team_n(0)
+            try:
+                solved = packed = None
+                packed = pack()
+                solved = solver.solve(packed, opts, theta0=theta0)
+                res = solved.to_host(("theta_thr", "variance") + self._STAT_KEYS)
+            finally:
+                solver.set_tall_team_n(keep)
+        return packed, solved, res
 
     _STAT_KEYS = ("nit", "nfev", "status", "fval", "gnorm")
 
@@ -679,23 +849,9 @@ class RandomEffectLRLBFGSModel:
             feat_ptr = host_array(packed.ent_feat_ptr())
             uniq = host_array(packed.unique_global())
             theta0 = self._start_point(model_weights, batch.entity_ids, uniq, feat_ptr, batch.E, num_features)
-            solved = solver.solve(packed, opts, theta0=theta0)
-            res = solved.to_host(("theta_thr", "variance") + self._STAT_KEYS)
-            if (res["status"] == self.ST_ABORTED).any() and getattr(solver, "tall_team_n", 0) != 0:
-                # a team of workgroups gave up waiting for a member (a device too busy, or too small, to keep four whole CUs per
-                # team resident: csrc/re_solve_tall.hip). Not a reason to lose the job: the partition again with every tall
-                # entity on ONE workgroup (same arithmetic up to the order of its sums), once.
-                logger.warning(f"{int((res['status'] == self.ST_ABORTED).sum())} entities timed out at a team barrier: "
-                               "solving the partition again without the tall team class")
-                keep = solver.tall_team_n
-                solver.set_tall_team_n(0)
-                try:
-                    solved = packed = None
-                    packed = self._pack(solver, batch)
-                    solved = solver.solve(packed, opts, theta0=theta0)
-                    res = solved.to_host(("theta_thr", "variance") + self._STAT_KEYS)
-                finally:
-                    solver.set_tall_team_n(keep)
+            first = [packed]
+            packed = None
+            packed, solved, res = self._pack_and_solve(solver, lambda: first.pop() if first else self._pack(solver, batch), opts, theta0)
             theta_thr, variance = res["theta_thr"], res.get("variance")
             self._check_statuses(res["status"], batch.E)
             theta_dev = getattr(solved, "theta_thr", None)    # still in HBM: what the scoring pass of this partition reads
@@ -829,12 +985,13 @@ class RandomEffectLRLBFGSModel:
 
     def _predict(self, input_path, tensor_metadata, output_file, schema_params, num_features, model_weights):
         logger.info(f"Start inference for {input_path}.")
-        packed = theta = has_model = None
+        packed = theta = has_model = group = None
         cache = self._read_cache
-        if cache is not None and cache[0] == self._read_key(input_path, num_features) and cache[2] is not None:
-            # The partition that was just trained on: still packed on the device, and every entity's model is the one the
-            # solve returned (thresholded, as saved) - what the table lookup below would reproduce coefficient by coefficient.
-            _, batch, packed, theta = cache
+        if cache is not None and cache[0] == self._read_key(input_path, num_features) and (cache[2] is not None or cache[4] is not None):
+            # The partition that was just trained on: still packed on the device (alone, or inside the batch of its group), and every
+            # entity's model is the one the solve returned (thresholded, as saved) - what the table lookup below would reproduce
+            # coefficient by coefficient.
+            _, batch, packed, theta, group = cache
             self._read_cache = None
         else:
             batch = self._read(input_path, tensor_metadata, schema_params, num_features, need_label=False)
@@ -844,14 +1001,17 @@ class RandomEffectLRLBFGSModel:
             avro.write_file(output_file, schema, [])
             return
         solver = self._get_solver()
-        if packed is None:
-            packed = self._pack(solver, batch)
-            feat_ptr = host_array(packed.ent_feat_ptr())
-            uniq = host_array(packed.unique_global())
-            theta, has_model = _model_coefficients_for_batch(model_weights, batch.entity_ids, uniq, feat_ptr,
-                                                             self.has_intercept, num_features)
-        logit, per_coord = solver.score(packed, theta, has_model)
-        logit, per_coord = host_array(logit), host_array(per_coord)
+        if group is not None:
+            logit, per_coord = self._group_scores(*group)
+        else:
+            if packed is None:
+                packed = self._pack(solver, batch)
+                feat_ptr = host_array(packed.ent_feat_ptr())
+                uniq = host_array(packed.unique_global())
+                theta, has_model = _model_coefficients_for_batch(model_weights, batch.entity_ids, uniq, feat_ptr,
+                                                                 self.has_intercept, num_features)
+            logit, per_coord = solver.score(packed, theta, has_model)
+            logit, per_coord = host_array(logit), host_array(per_coord)
         weights = batch.weight if batch.weight is not None else np.ones(batch.N, np.float32)
         self._write_behind(output_file, _write_scores, output_file, schema, schema_params, batch.uid, logit, batch.y if batch.has_label else None,
                            weights if has_weight else None, per_coord)

@@ -204,3 +204,63 @@ def test_a_partition_the_reader_narrowed_packs_to_the_same_arrays(tmp_path, dim,
     for key in ("theta", "nit", "nfev", "status", "fval"):
         assert np.array_equal(ra[key], rb[key]), key
     s.close()
+
+
+def test_partitions_solved_in_one_device_batch_give_the_files_of_partition_by_partition(tmp_path, monkeypatch, caplog):
+    """model.plan_group: the consecutive cold partitions of a run are solved in ONE device batch (their wire forms concatenated in HBM)
+    and every partition still gets its own model and score files. Six partitions of Zipf-sized entities — one directory empty, one with
+    a prior model (it trains on its own, warm) — once partition by partition (GROUP_MAX = 1), once grouped: the same entities in the
+    same files, coefficients to 1e-7 of their scale (an entity's kernel is chosen per batch: its sums may be ordered differently, not
+    more), scores to 4e-6; the warm-started partition identical (it is not in a group either way)."""
+    import logging
+    from gdmix_amd import model as model_mod, synthetic
+    from gdmix_amd.partition_dirs import write_partition_dir
+    b = synthetic.make_survey_batch(3000, 24, 6, 4096, seed=77, size_dist="c5zipf", with_uid=True)
+    b.uid = np.arange(b.N, dtype=np.int64)
+    runs = {}
+    for name, limit in (("single", 1), ("grouped", 8)):
+        root = tmp_path / name
+        os.makedirs(root)
+        argv, members, _ = write_partition_dir(str(root), b, 6, 4096)
+        assert sorted(members) == [0, 1, 2, 3, 4, 5]
+        # partition 2: an empty directory in the middle of the list; partition 4: a prior model (trained here, alone, first)
+        empty = root / "train" / "active" / "partitionId=2"
+        shutil.rmtree(empty)
+        os.makedirs(empty)
+        monkeypatch.setattr(model_mod, "GROUP_MAX", 1)
+        os.environ.pop("TF_CONFIG", None)
+        open(root / "plist.txt", "w").write("4")
+        cli.run(argv)
+        prior = list(avro.read_file(str(root / "models" / "part-00004.avro")))
+        open(root / "plist.txt", "w").write("0,1,2,3,4,5")
+        monkeypatch.setattr(model_mod, "GROUP_MAX", limit)
+        caplog.clear()
+        with caplog.at_level(logging.INFO, logger="gdmix_amd.model"):
+            cli.run(argv)
+        said = [r.getMessage() for r in caplog.records if "solved in one device batch" in r.getMessage()]
+        assert (said == []) if limit == 1 else (len(said) == 1 and said[0].startswith("3 partitions")), said
+        models = {k: list(avro.read_file(str(root / "models" / f"part-{k:05d}.avro"))) for k in members if k != 2}
+        scores = {k: list(avro.read_file(str(root / "ts" / f"partitionId={k}" / "part-00000-active.avro"))) for k in members if k != 2}
+        assert not os.path.exists(root / "models" / "part-00002.avro")
+        assert len(models[4]) == len(prior)
+        runs[name] = (models, scores)
+    (m1, s1), (m2, s2) = runs["single"], runs["grouped"]
+    assert m1[4] == m2[4] and s1[4] == s2[4]
+    worst = 0.0
+    for k in m1:
+        assert [r["modelId"] for r in m1[k]] == [b.entity_ids[e] for e in members[k]] == [r["modelId"] for r in m2[k]]
+        for r1, r2 in zip(m1[k], m2[k]):
+            a, c = _means_by_feature(r1), _means_by_feature(r2)
+            scale = max(max(abs(v) for v in a.values()), 1e-300)
+            if abs(a[-1]) > 12:         # class D (all labels equal): the unregularised intercept runs off, chaotically; nothing else is kept
+                assert set(a) == set(c) == {-1} and np.sign(a[-1]) == np.sign(c[-1])
+                continue
+            # a coefficient within rounding of the export threshold may be kept in one run and dropped in the other
+            assert all(abs(abs((a.get(f) or c.get(f))) - 1e-4) < 1e-9 for f in set(a) ^ set(c)), (k, r1["modelId"])
+            worst = max(worst, max(abs(a[f] - c[f]) for f in set(a) & set(c)) / scale)
+        assert [r["uid"] for r in s1[k]] == [r["uid"] for r in s2[k]]
+        p1 = np.array([r["predictionScore"] for r in s1[k]], np.float32)
+        p2 = np.array([r["predictionScore"] for r in s2[k]], np.float32)
+        sane = np.abs(p1) < 12
+        assert np.all(np.abs(p1[sane] - p2[sane]) <= 4e-6)
+    assert worst <= 1e-7, worst
