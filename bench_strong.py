@@ -528,8 +528,8 @@ def c5_full_share_leg(solver, opts, device_index, total_entities=100_000_000, ra
            "round_ms_mean": float(rm.mean()), "round_ms": [round(float(x), 2) for x in rm],
            "largest_entity_nnz": int(max(int(n.max()) for _, n, _ in share) * pop.k),
            "population_s": round(t_pop, 1), "generate_s": round(t_gen, 1),
-           "partitions_per_batch": {"what": "the same share with K consecutive partitions concatenated into one device batch (one context): what a driver "
-                                            "that trains several partitions per launch would get; the product path trains one per round", **batched}}
+           "partitions_per_batch": {"what": "the same share with K consecutive partitions concatenated into one device batch (one context): what the driver "
+                                            "gets on the device with GDMIX_PARTITIONS_PER_BATCH = K (model.plan_group; default 1: one partition per round)", **batched}}
     # ---- the first rounds of the whole job: every worker's partition of the round, plain and with the plan applied
     model, totals = SizeCostModel(), np.zeros((2, SizeCostModel.BUCKETS))
     rounds = []
