@@ -9,7 +9,9 @@ What is compared, and how a disagreement is judged (the rule rounds 2-3 applied 
     stop test that passes by the last digit in one summation order fails in another. A disagreement on such an entity, or on a strict
     one, is ADJUDICATED (tolerated, and reported) when all of this holds: both runs end with one of fmin_l_bfgs_b's normal
     outcomes; the device's returned gradient norm passes the test its status claims (PGTOL: |g|_inf <= pgtol); the objective values
-    agree to max(1e-5, 200 ftol) max(|f|, 1) — the same minimum, reached by another path; and the entity is demonstrably decided at
+    agree to max(1e-5, 200 ftol) max(|f|, 1) — the same minimum, reached by another path — or the device's is the LOWER of the two
+    and not below the minimum itself (the oracle again with m = 10 and ftol = 1e-15: after a FACTR stop at a loose ftol neither run is
+    at the minimum, and the one that went on for longer is further down the same valley: round 5, case 702007); and the entity is demonstrably decided at
     rounding level: the oracle under a wider set of ten noise draws changes its own status / nit / nfev, or its stop margin is within
     5 % of the threshold, or the device's coefficients are within 1000 x the oracle's own spread.
   * anything else is UNEXPLAINED and fails the test."""
@@ -117,6 +119,14 @@ def run_case(solver, seed, verbose=False):
     flagged |= wp & (err > tol)
     flagged |= wp_all & ~stable & (err > 1e-6) & (err > 1000.0 * np.maximum(sens, 1e-12))
     adjudicated = []
+    tight = []
+
+    def minimum():
+        """Objective values at the minimum: the oracle with ten pairs and no FACTR stop to speak of, once per case and only if asked."""
+        if not tight:
+            kt = dict(kw, m=10, max_iter=5000, ftol=1e-15, variance_mode=0)
+            tight.append(oracle.solve(pk, b.val, b.y, b.offset, b.weight, oracle.make_opts(**kt), theta0=th0)["fval"])
+        return tight[0]
     if flagged.any():
         # the wider noise set, once per case
         wide = [jiggled(10 + j, mag) for j, mag in enumerate((1e-15, 3e-15, 1e-14, 3e-14, 1e-13, 3e-13, 1e-15, 1e-14, 1e-13, 1e-12))]
@@ -125,6 +135,8 @@ def run_case(solver, seed, verbose=False):
             ok_grad = res["status"][e] != 0 or res["gnorm"][e] <= kw.get("pgtol", 1e-5)
             scale = max(abs(ref["fval"][e]), 1.0)
             ok_f = abs(res["fval"][e] - ref["fval"][e]) <= max(1e-5, 200.0 * kw["ftol"]) * scale
+            if not ok_f and res["fval"][e] < ref["fval"][e]:
+                ok_f = res["fval"][e] >= minimum()[e] - 1e-6 * scale
             moved = any((w["status"][e] != ref["status"][e]) or (w["nit"][e] != ref["nit"][e]) or (w["nfev"][e] != ref["nfev"][e]) for w in wide)
             spread = max([sens[e]] + [float(per_entity_rel_err(w["theta"], ref["theta"], coef_ptr)[e]) for w in wide])
             margin = min(abs(ref["gnorm"][e] - 1e-5) / 1e-5, abs(res["gnorm"][e] - 1e-5) / 1e-5) if 0 in (res["status"][e], ref["status"][e]) else 1.0
