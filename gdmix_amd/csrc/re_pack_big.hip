@@ -38,6 +38,12 @@ constexpr int BIG_CH = 1024;               // entries per chunk: the unit of wor
                                            // pack 0.58 -> 0.51 ms, whole populations unchanged; 512 is worse again: tools/r04_bigch.sh)
 constexpr unsigned BIG_COUNT_CBITS = 11;   // counting path for column indices below 2^11 (its tables are C counters per chunk)
 
+// max statistics of a batch: thousands of entities report to one address, and the maximum only grows — read it first, and only the
+// few that raise it pay for an atomic (same-address atomics serialise in L2, ~10 ns each)
+__device__ __forceinline__ void raise_max(int* addr, int v) {
+  if (v > __atomic_load_n(addr, __ATOMIC_RELAXED)) atomicMax(addr, v);
+}
+
 // sizes[b] = non-zeros of big entity b, nch[b] = its chunks (at least one, so that an entity without non-zeros still gets its
 // pointers written); nch[n_big] = 0 closes the scan
 __global__ void big_sizes_kernel(const int64_t* __restrict__ ent_nnz_ptr, const int32_t* __restrict__ big_list, int n_big,
@@ -98,7 +104,9 @@ __global__ __launch_bounds__(256) void big_maxcol_kernel(const int64_t* __restri
   __syncthreads();
   atomicMax(&smx, mx);
   __syncthreads();
-  if (threadIdx.x == 0 && smx) atomicMax(max_col, smx);
+  // (one same-address atomic per workgroup was most of this kernel: 16 384 of them, 0.21 ms on a MovieLens population whose largest
+  // column is 19; the maximum only grows, so a workgroup that cannot raise it has nothing to say)
+  if (threadIdx.x == 0 && smx > __atomic_load_n(max_col, __ATOMIC_RELAXED)) atomicMax(max_col, smx);
   if (bad) atomicExch(err, GDMIX_RE_ERANGE);
 }
 
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256) void big_cols_kernel(BigPackArgs a, const int6
     if (tid == 0) {
       cp[d] = nnz;
       a.d_cnt[e] = d;
-      atomicMax(a.max_p, d + a.ic);
+      raise_max(a.max_p, d + a.ic);
     }
     __syncthreads();
   }
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(256) void big_cols_small_kernel(BigPackArgs a, cons
     if (lane == 0) {
       cp[d] = nnz;
       a.d_cnt[e] = d;
-      atomicMax(a.max_p, d + a.ic);
+      raise_max(a.max_p, d + a.ic);
     }
   }
 }
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256) void big_rows_kernel(BigPackArgs a, const int6
     if (i == 0 && a.ent_nnz_ptr[e + 1] == z0) {   // samples but not a single non-zero: no entry reaches the passes that write these
       a.col_ptr[z0 + e] = 0;
       a.d_cnt[e] = 0;
-      atomicMax(a.max_p, a.ic);
+      raise_max(a.max_p, a.ic);
     }
     if (i < n) {
       const int64_t k1 = a.row_nnz_ptr[r0 + i + 1] - z0;
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(256) void big_emit_kernel(BigPackArgs a, const int6
       const int d = lid + 1;
       cp[d] = nnz;
       a.d_cnt[e] = d;
-      atomicMax(a.max_p, d + a.ic);
+      raise_max(a.max_p, d + a.ic);
     }
   }
 }
