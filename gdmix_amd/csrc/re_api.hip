@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <new>
 
@@ -113,6 +114,60 @@ static BatchDev make_batch_dev(const gdmix_re_packed* b) {
   B.col_ptr = b->col_ptr; B.csc_row = b->csc_row; B.csc_val = b->csc_val;
   B.y = b->y; B.offset = b->offset; B.weight = b->weight; B.order = b->order;
   return B;
+}
+
+__global__ __launch_bounds__(WAVE) void publish_kernel(const uint32_t* __restrict__ src, int words, uint32_t* box_data, uint32_t* box_flag, uint32_t seq) {
+  // Write-through stores (system scope, relaxed) to the page-locked box, a wait until they are acknowledged, then the flag the same
+  // way. NOT a system-scope release: that writes back this XCD's whole L2 first, behind whatever kernels are filling it at the
+  // moment — 104 us for these 48 bytes next to a running pack tier (and the runtime's own copy kernel ends in one: that was the
+  // 0.1 ms of the read-back it replaces). One wavefront, so the one wait covers every lane's stores.
+  for (int i = threadIdx.x; i < words; i += WAVE) __hip_atomic_store(box_data + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) __hip_atomic_store(box_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static inline void cpu_relax() {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("pause" ::: "memory");
+#endif
+}
+
+static int mailbox_on() {
+  static const int on = [] { const char* e = getenv("GDMIX_RE_MAILBOX"); return (e && atoi(e) == 0) ? 0 : 1; }();
+  return on;
+}
+
+hipError_t post_small(gdmix_ctx_impl* ctx, int box, const void* dev_src, size_t bytes, void* host_dst, hipStream_t s, SmallFetch* f) {
+  f->box = -1; f->seq = 0; f->bytes = bytes; f->host_dst = host_dst; f->s = s;
+  if (!mailbox_on() || bytes % 4 || bytes > MAILBOX_BYTES - MAILBOX_DATA || box < 0 || box >= 4)
+    return hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, s);       // wait_small synchronises
+  char* const base = reinterpret_cast<char*>(ctx->host_pinned) + MAILBOX_OFFSET + (size_t)box * MAILBOX_BYTES;
+  uint32_t seq = ++ctx->mail_seq[box];
+  if (seq == 0) seq = ++ctx->mail_seq[box];     // (0 is the empty box)
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(WAVE), 0, s, static_cast<const uint32_t*>(dev_src), (int)(bytes / 4),
+                     reinterpret_cast<uint32_t*>(base + MAILBOX_DATA), reinterpret_cast<uint32_t*>(base), seq);
+  f->box = box; f->seq = seq;
+  return hipGetLastError();
+}
+
+hipError_t wait_small(gdmix_ctx_impl* ctx, const SmallFetch& f) {
+  if (f.box < 0) return hipStreamSynchronize(f.s);
+  char* const base = reinterpret_cast<char*>(ctx->host_pinned) + MAILBOX_OFFSET + (size_t)f.box * MAILBOX_BYTES;
+  uint32_t* const flag = reinterpret_cast<uint32_t*>(base);
+  timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != f.seq) {
+    for (int k = 0; k < 16; ++k) cpu_relax();
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if ((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000L > FETCH_SPIN_US) {
+      hipError_t rc = hipStreamSynchronize(f.s);        // a long wait: sleep in the runtime; then the box is full, or the stream failed
+      if (rc != hipSuccess) return rc;
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != f.seq) return hipErrorUnknown;
+      break;
+    }
+  }
+  memcpy(f.host_dst, base + MAILBOX_DATA, f.bytes);
+  return hipSuccess;
 }
 
 }  // namespace gdmix
@@ -231,9 +286,12 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   c->impl.big_tmp = nullptr;
   c->impl.big_tmp_bytes = 0;
   c->impl.n_side = 0; c->impl.side_fork = nullptr;
+  c->impl.aux_ev[0] = c->impl.aux_ev[1] = nullptr;
   for (int k = 0; k < gdmix_ctx_impl::MAX_SIDE; ++k) { c->impl.side[k] = nullptr; c->impl.side_join[k] = nullptr; }
   for (int k = 0; k < GDMIX_RE_NUM_CLASSES; ++k) { c->impl.ev0[k] = nullptr; c->impl.ev1[k] = nullptr; c->impl.ev_used[k] = false; }
-  hipError_t rc = hipHostMalloc(reinterpret_cast<void**>(&c->impl.host_pinned), 4096, hipHostMallocDefault);
+  for (uint32_t& q : c->impl.mail_seq) q = 0;
+  hipError_t rc = hipHostMalloc(reinterpret_cast<void**>(&c->impl.host_pinned), HOST_PINNED_BYTES, hipHostMallocMapped | hipHostMallocCoherent);
+  if (rc == hipSuccess) memset(c->impl.host_pinned, 0, HOST_PINNED_BYTES);
   if (rc != hipSuccess) {
     set_error("hipHostMalloc failed: %s", hipGetErrorString(rc));
     delete c;
@@ -245,6 +303,7 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
     if (want > gdmix_ctx_impl::MAX_SIDE) want = gdmix_ctx_impl::MAX_SIDE;
     if (want > 0) {
       rc = hipEventCreateWithFlags(&c->impl.side_fork, hipEventDisableTiming);
+      for (int k = 0; k < 2 && rc == hipSuccess; ++k) rc = hipEventCreateWithFlags(&c->impl.aux_ev[k], hipEventDisableTiming);
       for (int k = 0; k < want && rc == hipSuccess; ++k) {
         rc = hipStreamCreateWithFlags(&c->impl.side[k], hipStreamNonBlocking);
         if (rc == hipSuccess) rc = hipEventCreateWithFlags(&c->impl.side_join[k], hipEventDisableTiming);
@@ -274,6 +333,7 @@ GDMIX_API void gdmix_re_destroy(gdmix_re_ctx* ctx) {
   if (ctx->impl.big_tmp) (void)hipFree(ctx->impl.big_tmp);
   if (ctx->impl.host_pinned) (void)hipHostFree(ctx->impl.host_pinned);
   if (ctx->impl.side_fork) (void)hipEventDestroy(ctx->impl.side_fork);
+  for (int k = 0; k < 2; ++k) if (ctx->impl.aux_ev[k]) (void)hipEventDestroy(ctx->impl.aux_ev[k]);
   for (int k = 0; k < gdmix_ctx_impl::MAX_SIDE; ++k) {
     if (ctx->impl.side_join[k]) (void)hipEventDestroy(ctx->impl.side_join[k]);
     if (ctx->impl.side[k]) (void)hipStreamDestroy(ctx->impl.side[k]);
@@ -508,8 +568,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   HIP_TRY(hipGetLastError());
   HIP_TRY(launch_order(b, b->cls_tmp, cc + GDMIX_RE_NUM_CLASSES, cc + 2 * GDMIX_RE_NUM_CLASSES, s));
   int32_t* hc = ctx->impl.host_pinned + 256;
-  HIP_TRY(hipMemcpyAsync(hc, cc, 6 * GDMIX_RE_NUM_CLASSES * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(fetch_small(&ctx->impl, 0, cc, 6 * GDMIX_RE_NUM_CLASSES * sizeof(int32_t), hc, s));
 
   SolveParams P;
   P.l2 = opts->l2; P.ftol = opts->ftol; P.pgtol = opts->pgtol; P.threshold = opts->threshold;

@@ -133,7 +133,8 @@ struct gdmix_ctx_impl {
   int num_cus;
   void* scratch;
   size_t scratch_bytes;
-  int32_t* host_pinned;   // small pinned buffer for count read-backs
+  int32_t* host_pinned;   // small pinned buffer for count read-backs (HOST_PINNED_BYTES: the read-back areas, then the mailboxes)
+  uint32_t mail_seq[4];   // fetch_small: the last sequence number sent to each mailbox
   int wave_lds_limit;     // entities above this LDS footprint use the block kernel
   int kernel_mask;        // bit1 LDS wave kernel, bit2 group kernels (bit0: the removed register wave kernel, ignored)
   int timing;             // bracket class launches with events
@@ -156,9 +157,30 @@ struct gdmix_ctx_impl {
   hipStream_t side[MAX_SIDE];
   int n_side;
   hipEvent_t side_fork, side_join[MAX_SIDE];
+  hipEvent_t aux_ev[2];   // pack_big_entities: the row table is built on a second stream, next to the column passes
   hipEvent_t ev0[GDMIX_RE_NUM_CLASSES], ev1[GDMIX_RE_NUM_CLASSES];
   bool ev_used[GDMIX_RE_NUM_CLASSES];
 };
+
+// A few bytes from the device to the host WITHOUT a stream synchronise (round 5). The counts a pack or a solve decides its next
+// launches on used to come back by hipMemcpyAsync + hipStreamSynchronize: 40 - 140 us each between the producing kernel's end and
+// the next launch (the kernel timeline of a MovieLens step, tools/timeline_session.sh: the tiers of a pack started 136 us after the
+// 17 us kernel that counts their entities) — a sixth of a strongly scaled share's 1.8 ms step in four such round trips. Now a
+// one-wavefront kernel on the same stream copies them into a mailbox in page-locked host memory and sets its flag with a
+// system-scope release; the host spins on the flag (FETCH_SPIN_US, then falls back to hipStreamSynchronize: a wait behind 70 ms
+// of kernels is not spun through). Stream order makes the flag mean what the synchronise meant for the caller: everything
+// queued on `s` before the call is done. GDMIX_RE_MAILBOX=0: the copy + synchronise as before (A/B).
+constexpr size_t HOST_PINNED_BYTES = 8192;
+constexpr size_t MAILBOX_OFFSET = 4096, MAILBOX_BYTES = 1024, MAILBOX_DATA = 64;   // per box: flag word at 0, data from byte 64
+constexpr int FETCH_SPIN_US = 400;
+struct SmallFetch { int box; uint32_t seq; size_t bytes; void* host_dst; hipStream_t s; };
+hipError_t post_small(gdmix_ctx_impl* ctx, int box, const void* dev_src, size_t bytes, void* host_dst, hipStream_t s, SmallFetch* f);   // queue the hand-over
+hipError_t wait_small(gdmix_ctx_impl* ctx, const SmallFetch& f);                                                                    // ... and take it
+inline hipError_t fetch_small(gdmix_ctx_impl* ctx, int box, const void* dev_src, size_t bytes, void* host_dst, hipStream_t s) {
+  SmallFetch f;
+  hipError_t rc = post_small(ctx, box, dev_src, bytes, host_dst, s, &f);
+  return rc != hipSuccess ? rc : wait_small(ctx, f);
+}
 
 }  // namespace gdmix
 
@@ -266,7 +288,7 @@ struct BigPackArgs {
   int* max_p;   // device
   int* err;     // device
 };
-int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s);
+int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s, hipStream_t aux);
 
 hipError_t launch_partition_ids(const int64_t* ids, int64_t count, int32_t num_partitions, int32_t* out,
                                 hipStream_t s);

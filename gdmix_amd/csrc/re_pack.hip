@@ -848,10 +848,14 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
   hipStream_t const sb = ns >= 1 ? ctx->side[0] : s;
   hipStream_t const s2 = ns >= 2 ? ctx->side[1] : (ns == 1 ? ctx->side[0] : s);
   hipStream_t const s3 = ns >= 3 ? ctx->side[2] : s2;
+  SmallFetch counts;
   if (ns >= 1) {
+    // the counts go to the host from the caller's stream, BEFORE the first tier is launched on it: queued on a side stream next to
+    // that tier they arrived 100 us later (a one-wavefront kernel — and the runtime's copy kernel before it — sat for that long
+    // behind the tier's 1 536 workgroups: tools/timeline_session.sh), and the other tiers and the large entities wait for them
+    HIP_TRY(post_small(ctx, 3, stats, sizeof(PackStats), hs, s, &counts));
     HIP_TRY(hipEventRecord(ctx->side_fork, s));
     HIP_TRY(side_join.use(0));
-    HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(PackStats), hipMemcpyDeviceToHost, sb));
   }
   // one round of workgroups, all resident (every workgroup walks the same number of entities: 16 per CU were 2.7 rounds of the 6 that
   // fit, the last one two-thirds full)
@@ -868,7 +872,7 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
                      raw->row_nnz_ptr, out->ent_nnz_ptr, raw->col_global, raw->val, E, ic, out->row_ptr, sort_key,
                      out->csr_col, out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, stats, pack_bitmap_on());
   DBG_STAGE("pack_entity_kernel<256>");
-  if (ns >= 1) HIP_TRY(hipStreamSynchronize(sb));   // the counts (the first stage is running)
+  if (ns >= 1) HIP_TRY(wait_small(ctx, counts));   // the counts (the first stage is running)
   // (a C5-shaped entity has 256 +- 50 non-zeros: half of them overflow the first tier; the 512-key tier runs four workgroups of
   // four wavefronts per CU where the 1024-key one runs four of two, and sorts half as many keys)
   if (ns == 0 || hs->n_mid > 0) {
@@ -888,15 +892,13 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
   }
   DBG_STAGE("pack_entity_kernel<1024>");
   {
-    if (ns == 0) {
-      HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(PackStats), hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-    }
+    if (ns == 0) HIP_TRY(fetch_small(ctx, 1, stats, sizeof(PackStats), hs, s));
     if (hs->n_big > 0) {
       BigPackArgs A{raw->ent_row_ptr, out->ent_nnz_ptr, raw->row_nnz_ptr, raw->col_global, raw->val, ic, out->row_ptr, out->csr_col,
                     out->col_ptr, out->csc_row, out->csc_val, uniq_sparse, d_cnt, big_list, hs->n_big,
                     (int64_t)hs->big_nnz, &stats->max_p, &stats->err};
-      const int rc = pack_big_entities(ctx, A, sb);
+      // (its row table on the caller's stream, behind the first tier, next to its column passes on sb)
+      const int rc = pack_big_entities(ctx, A, sb, ns >= 1 ? s : sb);
       if (rc != GDMIX_RE_OK) return rc;
     }
   }
@@ -915,8 +917,7 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
   }
   DBG_STAGE("pack_compact_unique_kernel");
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(PackStats), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(fetch_small(ctx, 1, stats, sizeof(PackStats), hs, s));
   if (hs->err) {
     set_error("pack: an entity exceeds a per-entity int32 limit or a feature index is outside [0, 2^31)");
     return hs->err;

@@ -70,10 +70,13 @@ __device__ __forceinline__ int big_find(const int64_t* __restrict__ offs, int n_
 // Chunk q of the big entities' non-zeros: entity b (one bisection per workgroup instead of one per entry, which is what the
 // per-entry passes used to spend their time on), first position inside the entity, length. chunk0 [n_big + 1] = exclusive scan of nch.
 struct BigChunk { int b; int64_t e, z0, start; int len; };
-__device__ __forceinline__ BigChunk big_chunk(const int64_t* __restrict__ chunk0, const int64_t* __restrict__ ent_nnz_ptr,
+// chunk_ent[q] = the big entity chunk q belongs to (big_chunk_ent_kernel, once per pack): every per-chunk pass used to find it by a
+// bisection of chunk0 — 13 dependent loads in front of the chunk's first useful one, 8 of the ~11 us a workgroup spent per chunk
+// (big_maxcol_kernel 144 us for 32 k chunks of a MovieLens population, tools/timeline_session.sh)
+__device__ __forceinline__ BigChunk big_chunk(const int64_t* __restrict__ chunk0, const int32_t* __restrict__ chunk_ent, const int64_t* __restrict__ ent_nnz_ptr,
                                               const int32_t* __restrict__ big_list, int n_big, int64_t q) {
   BigChunk c;
-  c.b = big_find(chunk0, n_big, q);
+  c.b = chunk_ent[q];
   c.e = big_list[c.b];
   c.z0 = ent_nnz_ptr[c.e];
   const int64_t z = ent_nnz_ptr[c.e + 1] - c.z0;
@@ -83,15 +86,25 @@ __device__ __forceinline__ BigChunk big_chunk(const int64_t* __restrict__ chunk0
   return c;
 }
 
+// chunk_ent: one wavefront per big entity writes its index over its chunks
+__global__ __launch_bounds__(256) void big_chunk_ent_kernel(const int64_t* __restrict__ chunk0, int n_big, int32_t* __restrict__ chunk_ent) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < n_big; b += nw) {
+    const int64_t q1 = chunk0[b + 1];
+    for (int64_t q = chunk0[b] + lane; q < q1; q += WAVE) chunk_ent[q] = (int32_t)b;
+  }
+}
+
 // largest global column index among the big entities (and the range check of all of them)
 __global__ __launch_bounds__(256) void big_maxcol_kernel(const int64_t* __restrict__ ent_nnz_ptr, const int64_t* __restrict__ col_global,
-                                                         const int32_t* __restrict__ big_list, const int64_t* __restrict__ chunk0, int n_big,
+                                                         const int32_t* __restrict__ big_list, const int64_t* __restrict__ chunk0, const int32_t* __restrict__ chunk_ent, int n_big,
                                                          unsigned* __restrict__ max_col, int* __restrict__ err) {
   bool bad = false;
   unsigned mx = 0;
   const int64_t nq = chunk0[n_big];
   for (int64_t q = blockIdx.x; q < nq; q += gridDim.x) {
-    const BigChunk k = big_chunk(chunk0, ent_nnz_ptr, big_list, n_big, q);
+    const BigChunk k = big_chunk(chunk0, chunk_ent, ent_nnz_ptr, big_list, n_big, q);
     const int64_t* __restrict__ col = col_global + k.z0 + k.start;
     for (int i = threadIdx.x; i < k.len; i += 256) {
       const int64_t c = col[i];
@@ -112,12 +125,12 @@ __global__ __launch_bounds__(256) void big_maxcol_kernel(const int64_t* __restri
 
 __global__ __launch_bounds__(256) void big_fill_kernel(const int64_t* __restrict__ ent_nnz_ptr,
                                                        const int64_t* __restrict__ col_global,
-                                                       const int32_t* __restrict__ big_list, const int64_t* __restrict__ chunk0,
+                                                       const int32_t* __restrict__ big_list, const int64_t* __restrict__ chunk0, const int32_t* __restrict__ chunk_ent,
                                                        const int64_t* __restrict__ offs, int n_big, unsigned cbits,
                                                        unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
   const int64_t nq = chunk0[n_big];
   for (int64_t q = blockIdx.x; q < nq; q += gridDim.x) {
-    const BigChunk k = big_chunk(chunk0, ent_nnz_ptr, big_list, n_big, q);
+    const BigChunk k = big_chunk(chunk0, chunk_ent, ent_nnz_ptr, big_list, n_big, q);
     const int64_t* __restrict__ col = col_global + k.z0 + k.start;
     const int64_t o = offs[k.b] + k.start;
     for (int i = threadIdx.x; i < k.len; i += 256) {
@@ -130,12 +143,12 @@ __global__ __launch_bounds__(256) void big_fill_kernel(const int64_t* __restrict
 // ---- counting path ------------------------------------------------------------------------------------------------------
 // hist[q][c] = entries of column c in chunk q (C = 2^cbits counters per chunk)
 __global__ __launch_bounds__(256) void big_hist_kernel(const int64_t* __restrict__ ent_nnz_ptr, const int64_t* __restrict__ col_global,
-                                                       const int32_t* __restrict__ big_list, const int64_t* __restrict__ chunk0, int n_big,
+                                                       const int32_t* __restrict__ big_list, const int64_t* __restrict__ chunk0, const int32_t* __restrict__ chunk_ent, int n_big,
                                                        int C, uint32_t* __restrict__ hist) {
   __shared__ unsigned h[1 << BIG_COUNT_CBITS];
   const int64_t nq = chunk0[n_big];
   for (int64_t q = blockIdx.x; q < nq; q += gridDim.x) {
-    const BigChunk k = big_chunk(chunk0, ent_nnz_ptr, big_list, n_big, q);
+    const BigChunk k = big_chunk(chunk0, chunk_ent, ent_nnz_ptr, big_list, n_big, q);
     for (int c = threadIdx.x; c < C; c += 256) h[c] = 0u;
     __syncthreads();
     const int64_t* __restrict__ col = col_global + k.z0 + k.start;
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(256) void big_cols_small_kernel(BigPackArgs a, cons
 // One wavefront per chunk: its entries, 64 at a time in position order, go to the CSC position base[column] + (entries of the
 // same column before it in the tile); the first lane of every column of a tile then advances the base. In-order LDS, one
 // wavefront: no atomics, and the CSC copy is in row-major order within a column, as the stable sort leaves it.
-__global__ __launch_bounds__(WAVE) void big_scatter_kernel(BigPackArgs a, const int64_t* __restrict__ chunk0, const int64_t* __restrict__ offs,
+__global__ __launch_bounds__(WAVE) void big_scatter_kernel(BigPackArgs a, const int64_t* __restrict__ chunk0, const int32_t* __restrict__ chunk_ent, const int64_t* __restrict__ offs,
                                                            int C, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ bits,
                                                            const uint32_t* __restrict__ lidbase, const uint32_t* __restrict__ row_of) {
   constexpr int CMAX = 1 << BIG_COUNT_CBITS;
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(WAVE) void big_scatter_kernel(BigPackArgs a, const 
   const int W = C >= 32 ? C / 32 : 1;
   const int64_t nq = chunk0[a.n_big];
   for (int64_t q = blockIdx.x; q < nq; q += gridDim.x) {
-    const BigChunk k = big_chunk(chunk0, a.ent_nnz_ptr, a.big_list, a.n_big, q);
+    const BigChunk k = big_chunk(chunk0, chunk_ent, a.ent_nnz_ptr, a.big_list, a.n_big, q);
     for (int c = lane; c < C; c += WAVE) base[c] = hist[q * C + c];
     for (int w = lane; w < W; w += WAVE) { bm[w] = bits[(size_t)k.b * W + w]; lb[w] = lidbase[(size_t)k.b * W + w]; }
     wave_lds_fence();
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(256) void big_emit_kernel(BigPackArgs a, const int6
 
 static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s) {
+int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s, hipStream_t aux) {
   const int64_t T = a.big_nnz;
   const int nb = a.n_big;
   if (nb <= 0) return GDMIX_RE_OK;
@@ -421,6 +434,8 @@ int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s) 
   const size_t o_rows = take((size_t)(nb + 2) * 8), o_row_offs = take((size_t)(nb + 2) * 8);
   const size_t o_nch = take((size_t)(nb + 2) * 8), o_chunk0 = take((size_t)(nb + 2) * 8);
   const size_t o_lib = take(lib_tmp);
+  const size_t o_chunk_ent = take((size_t)(max_chunks + 1) * 4);
+  const size_t o_row_of = take(TT * 4);        // the row of every raw position: built before the path is known, on another stream
   if (ctx->big_tmp_bytes < off) {
     HIP_TRY(hipStreamSynchronize(s));
     if (ctx->big_tmp) { HIP_TRY(hipFree(ctx->big_tmp)); ctx->big_tmp = nullptr; ctx->big_tmp_bytes = 0; }
@@ -448,21 +463,39 @@ int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s) 
   HIP_TRY((rocprim::exclusive_scan(lib, tmp, sizes, offs, (int64_t)0, (size_t)nb, rocprim::plus<int64_t>(), s)));
   tmp = lib_tmp;
   HIP_TRY((rocprim::exclusive_scan(lib, tmp, nch, chunk0, (int64_t)0, (size_t)nb + 1, rocprim::plus<int64_t>(), s)));
+  int32_t* const chunk_ent = reinterpret_cast<int32_t*>(base + o_chunk_ent);
+  {
+    const int g = (nb + 3) / 4 < ctx->num_cus * 8 ? (nb + 3) / 4 : ctx->num_cus * 8;
+    hipLaunchKernelGGL(big_chunk_ent_kernel, dim3(g), dim3(256), 0, s, chunk0, nb, chunk_ent);
+  }
+  // row pointers of these entities and the row of every raw position (both paths). Nothing here depends on the columns: the table is
+  // built on `aux` while this stream finds the largest column, waits for the host's decision and counts the columns (round 5: it was
+  // 0.2 ms in the middle of the 0.8 ms chain a MovieLens pack waits for, tools/timeline_session.sh)
+  hipLaunchKernelGGL(big_rowcount_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, a.ent_row_ptr, a.big_list, nb, rows);
+  tmp = lib_tmp;
+  HIP_TRY((rocprim::exclusive_scan(lib, tmp, rows, row_offs, (int64_t)0, (size_t)nb, rocprim::plus<int64_t>(), s)));
+  const bool two_streams = aux != s && ctx->aux_ev[0] && ctx->aux_ev[1];
+  // (the table lives behind everything either path carves out of the work area: its place does not depend on the path)
+  uint32_t* const row_of = reinterpret_cast<uint32_t*>(base + o_row_of);
+  if (two_streams) {
+    HIP_TRY(hipEventRecord(ctx->aux_ev[0], s));
+    HIP_TRY(hipStreamWaitEvent(aux, ctx->aux_ev[0], 0));
+  }
+  hipLaunchKernelGGL(big_rows_kernel, dim3(ctx->num_cus * 32), dim3(256), 0, two_streams ? aux : s, a, offs, row_offs, rows, row_of);
+  if (two_streams) HIP_TRY(hipEventRecord(ctx->aux_ev[1], aux));
+  // (`aux` is the caller's own stream when there are two: a way out of this function in between leaves nothing running that the caller's
+  // stream does not order; `s` waits for the table right in front of the pass that reads it)
+  auto rows_done = [&]() -> hipError_t { return two_streams ? hipStreamWaitEvent(s, ctx->aux_ev[1], 0) : hipSuccess; };
   // workgroups of the per-entry passes: one per chunk up to a few per CU's worth, strided beyond
   const int cgrid = (int)(max_chunks > (int64_t)ctx->num_cus * 64 ? (int64_t)ctx->num_cus * 64 : (max_chunks > 0 ? max_chunks : 1));
   // the bits of the column field: of the largest column index among these entities (one small read-back)
   unsigned* max_col_dev = reinterpret_cast<unsigned*>(sizes + nb + 1);   // the spare entry of `sizes`
   HIP_TRY(hipMemsetAsync(max_col_dev, 0, 4, s));
-  hipLaunchKernelGGL(big_maxcol_kernel, dim3(cgrid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, chunk0, nb, max_col_dev, a.err);
+  hipLaunchKernelGGL(big_maxcol_kernel, dim3(cgrid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, chunk0, chunk_ent, nb, max_col_dev, a.err);
   unsigned max_col = 0;
-  HIP_TRY(hipMemcpyAsync(&max_col, max_col_dev, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(fetch_small(ctx, 2, max_col_dev, 4, &max_col, s));
   unsigned cbits = 1;
   while (cbits < 32 && (max_col >> cbits) != 0u) ++cbits;
-  // row pointers of these entities and the row of every raw position (both paths)
-  hipLaunchKernelGGL(big_rowcount_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, a.ent_row_ptr, a.big_list, nb, rows);
-  tmp = lib_tmp;
-  HIP_TRY((rocprim::exclusive_scan(lib, tmp, rows, row_offs, (int64_t)0, (size_t)nb, rocprim::plus<int64_t>(), s)));
   bool counting = cbits <= BIG_COUNT_CBITS;
   if (const char* e = getenv("GDMIX_PACK_BIG_COUNT")) counting = counting && atoi(e) != 0;   // test hook: 0 = always the sort path
   if (counting) {
@@ -472,17 +505,16 @@ int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s) 
     uint32_t* hist = reinterpret_cast<uint32_t*>(base + o); o += up256((size_t)max_chunks * (size_t)C * 4);
     uint32_t* bits = reinterpret_cast<uint32_t*>(base + o); o += up256((size_t)nb * W * 4);
     uint32_t* lidbase = reinterpret_cast<uint32_t*>(base + o); o += up256((size_t)nb * W * 4);
-    uint32_t* row_of = reinterpret_cast<uint32_t*>(base + o);
-    hipLaunchKernelGGL(big_rows_kernel, dim3(ctx->num_cus * 32), dim3(256), 0, s, a, offs, row_offs, rows, row_of);
-    hipLaunchKernelGGL(big_hist_kernel, dim3(cgrid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, chunk0, nb, C, hist);
+    hipLaunchKernelGGL(big_hist_kernel, dim3(cgrid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, chunk0, chunk_ent, nb, C, hist);
     if (C <= WAVE) hipLaunchKernelGGL(big_cols_small_kernel, dim3((nb + 3) / 4 < ctx->num_cus * 32 ? (nb + 3) / 4 : ctx->num_cus * 32), dim3(256), 0, s, a, chunk0, C, hist, bits, lidbase);
     else hipLaunchKernelGGL(big_cols_kernel, dim3(nb < ctx->num_cus * 16 ? nb : ctx->num_cus * 16), dim3(256), 0, s, a, chunk0, C, hist, bits, lidbase);
     const int sgrid = (int)(max_chunks > (int64_t)ctx->num_cus * 256 ? (int64_t)ctx->num_cus * 256 : (max_chunks > 0 ? max_chunks : 1));
-    hipLaunchKernelGGL(big_scatter_kernel, dim3(sgrid), dim3(WAVE), 0, s, a, chunk0, offs, C, hist, bits, lidbase, row_of);
+    HIP_TRY(rows_done());
+    hipLaunchKernelGGL(big_scatter_kernel, dim3(sgrid), dim3(WAVE), 0, s, a, chunk0, chunk_ent, offs, C, hist, bits, lidbase, row_of);
     HIP_TRY(hipGetLastError());
     return GDMIX_RE_OK;
   }
-  if (T <= 0) return GDMIX_RE_OK;
+  if (T <= 0) { HIP_TRY(rows_done()); return GDMIX_RE_OK; }
   size_t o = o_work;
   unsigned long long* keys_a = reinterpret_cast<unsigned long long*>(base + o); o += up256(TT * 8);
   unsigned long long* keys_b = reinterpret_cast<unsigned long long*>(base + o); o += up256(TT * 8);
@@ -493,16 +525,14 @@ int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s) 
   int64_t g64 = (T + 255) / 256;
   grid = (int)(g64 > ctx->num_cus * 32 ? ctx->num_cus * 32 : g64);
   const unsigned end_bit = cbits + ebits;
-  hipLaunchKernelGGL(big_fill_kernel, dim3(cgrid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, chunk0, offs, nb, cbits,
+  hipLaunchKernelGGL(big_fill_kernel, dim3(cgrid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, chunk0, chunk_ent, offs, nb, cbits,
                      keys_a, vals_a);
   tmp = lib_tmp;
   HIP_TRY((rocprim::radix_sort_pairs(lib, tmp, keys_a, keys_b, vals_a, vals_b, (size_t)T, 0u, end_bit, s)));
   hipLaunchKernelGGL(big_heads_kernel, dim3(grid), dim3(256), 0, s, keys_b, T, head);
   tmp = lib_tmp;
   HIP_TRY((rocprim::exclusive_scan(lib, tmp, head, scan, (int64_t)0, (size_t)T, rocprim::plus<int64_t>(), s)));
-  // the row of every raw position; the sort's input values are free again
-  uint32_t* row_of = vals_a;
-  hipLaunchKernelGGL(big_rows_kernel, dim3(ctx->num_cus * 32), dim3(256), 0, s, a, offs, row_offs, rows, row_of);
+  HIP_TRY(rows_done());
   hipLaunchKernelGGL(big_emit_kernel, dim3(grid), dim3(256), 0, s, a, offs, T, cbits, keys_b, vals_b, head, scan, row_of);
   HIP_TRY(hipGetLastError());
   return GDMIX_RE_OK;
