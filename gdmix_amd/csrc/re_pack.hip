@@ -219,82 +219,6 @@ __device__ __forceinline__ int emit_entity(KeyPtr sk, ValPtr vals, const int32_t
   return carry;
 }
 
-// An entity of more than PACK_RANK_MAX non-zeros all of whose columns are below 64 (MovieLens bags: 20 and 24 features) needs no
-// sort: lane c counts column c, a scan over the lanes gives every column's first CSC position and local id, and the entries are
-// placed 64 at a time in position order (lanes of equal column rank themselves with a ballot per distinct column of the tile;
-// in-order LDS, one wavefront, no atomics in the placement). keys: the staged (column << 32 | position) keys, unsorted; base: 64
-// words of LDS. Same outputs as the sort + emit_entity, without the 55 passes of the bitonic network over 1 024 keys.
-constexpr int PACK_COUNT_COLS = 64;
-template <class ValPtr>
-__device__ __forceinline__ int count_entity(const unsigned long long* keys, unsigned* base, ValPtr vals, const int32_t* __restrict__ rp, int n,
-                                            int nnz, int lane, int32_t* __restrict__ csr_col, int32_t* __restrict__ col_ptr,
-                                            int32_t* __restrict__ csc_row, float* __restrict__ csc_val,
-                                            int32_t* __restrict__ uniq_sparse) {
-  base[lane] = 0u;
-  wave_lds_fence();
-  for (int k = lane; k < nnz; k += WAVE) atomicAdd(&base[(unsigned)(keys[k] >> 32)], 1u);   // integer counts: any order
-  wave_lds_fence();
-  const unsigned tot = base[lane];
-  unsigned xn = tot;
-#pragma unroll
-  for (int d = 1; d < WAVE; d <<= 1) {
-    const unsigned yn = __shfl_up(xn, d);
-    if (lane >= d) xn += yn;
-  }
-  const unsigned start = xn - tot;
-  const unsigned long long present = __ballot(tot != 0u);
-  const int d = __popcll(present);
-  if (tot) {
-    const int lid = __popcll(present & ((1ull << lane) - 1ull));
-    uniq_sparse[lid] = lane;
-    col_ptr[lid] = (int32_t)start;
-  }
-  if (lane == 0) col_ptr[d] = nnz;
-  wave_lds_fence();
-  base[lane] = start;
-  wave_lds_fence();
-  for (int t = 0; t < nnz; t += WAVE) {
-    const int k = t + lane;
-    const bool valid = k < nnz;
-    const unsigned c = valid ? (unsigned)(keys[k] >> 32) : 0u;
-    unsigned rank = 0, cnt = 0;
-    unsigned long long todo = __ballot(valid);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const unsigned cl = (unsigned)__shfl((int)c, leader);
-      const unsigned long long m = __ballot(valid && c == cl);
-      if (valid && c == cl) {
-        rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-        cnt = (unsigned)__popcll(m);
-      }
-      todo &= ~m;
-    }
-    if (valid) {
-      const unsigned kpos = base[c] + rank;
-      csr_col[k] = __popcll(present & ((1ull << c) - 1ull));
-      csc_val[kpos] = vals[k];
-      int lo = 0, hi = n - 1;   // sample of non-zero k: last i with rp[i] <= k
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (rp[mid] <= k) lo = mid; else hi = mid - 1;
-      }
-      csc_row[kpos] = lo;
-    }
-    wave_lds_fence();
-    if (valid && rank == 0) base[c] += cnt;
-    wave_lds_fence();
-  }
-  return d;
-}
-
-// An entity of at most PACK_RANK_MAX non-zeros all of whose columns are below PACK_BITMAP_COLS (C2's bag: 1 024 features; the
-// MovieLens bags) needs no sort either: the set of its columns is a 2 048-bit map, one 32-bit word per lane; a column's local id is
-// the number of set bits below it (a prefix over the words' popcounts + a masked popcount), col_ptr is a scan over the per-id counts,
-// and an entry's CSC slot is its column's start plus its rank among the entries of the same column in position order — 0 for all
-// but the few columns that occur twice (ballot ranking inside a 64-entry tile, as count_entity does, for those columns only).
-// Same outputs as wave_rank_sort + emit_entity, bit for bit (tests/test_gpu_parity.py::_check_pack on every fixture), without the
-// rank sort's nnz broadcast-compare trips: ~470 -> ~250 wavefront instructions for a 64-entry entity (pack_entity_kernel<256> on C2:
-// 1.01 ms, three quarters of it VALU issue — profiles/r04_final_c2_1m.txt). w: 5 x 64 words of LDS.
 // Inclusive prefix sum over the 64 lanes by DPP: four shifts inside the rows of 16, then the last lane of row 0 / 2 into rows 1 / 3 and the
 // last lane of the lower half into the upper half (row_bcast:15, row_bcast:31) — six VALU instructions where six __shfl_up steps are
 // six LDS permutes with their address arithmetic.
@@ -320,6 +244,90 @@ __device__ __forceinline__ unsigned wave_incl_max_u32(unsigned v) {
   return v;
 }
 
+// An entity of more than PACK_RANK_MAX non-zeros all of whose columns are below 64 (MovieLens bags: 20 and 24 features) needs no
+// sort: lane c counts column c, a scan over the lanes gives every column's first CSC position and local id, and the entries are
+// placed 64 at a time in position order (lanes of equal column rank themselves with a ballot per distinct column of the tile;
+// in-order LDS, one wavefront, no atomics in the placement). keys: the staged (column << 32 | position) keys, unsorted; base: 64
+// words of LDS. Same outputs as the sort + emit_entity, without the 55 passes of the bitonic network over 1 024 keys.
+constexpr int PACK_COUNT_COLS = 64;
+template <class ValPtr>
+__device__ __forceinline__ int count_entity(unsigned long long* keys, unsigned* base, ValPtr vals, const int32_t* __restrict__ rp, int n,
+                                            int nnz, int lane, int32_t* __restrict__ csr_col, int32_t* __restrict__ col_ptr,
+                                            int32_t* __restrict__ csc_row, float* __restrict__ csc_val,
+                                            int32_t* __restrict__ uniq_sparse) {
+  // The low word of a key (the position, which is the key's index here) makes room for the row marks: row i > 0 marks its first position
+  // with i, a prefix maximum per tile + a carry gives every position its sample (as bitmap_entity does; a bisection of the row pointers per
+  // non-zero was a quarter of this path's instructions — MovieLens entities have hundreds of samples: ten steps each).
+  unsigned* const kw = reinterpret_cast<unsigned*>(keys);
+  base[lane] = 0u;
+  for (int k = lane; k < nnz; k += WAVE) kw[2 * k] = 0u;
+  wave_lds_fence();
+  for (int k = lane; k < nnz; k += WAVE) atomicAdd(&base[kw[2 * k + 1]], 1u);   // integer counts: any order
+  for (int i = lane; i < n; i += WAVE) {
+    const int s = rp[i];
+    if (i > 0 && s < nnz) atomicMax(&kw[2 * s], (unsigned)i);
+  }
+  wave_lds_fence();
+  const unsigned tot = base[lane];
+  unsigned xn = tot;
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const unsigned yn = __shfl_up(xn, d);
+    if (lane >= d) xn += yn;
+  }
+  const unsigned start = xn - tot;
+  const unsigned long long present = __ballot(tot != 0u);
+  const int d = __popcll(present);
+  if (tot) {
+    const int lid = __popcll(present & ((1ull << lane) - 1ull));
+    uniq_sparse[lid] = lane;
+    col_ptr[lid] = (int32_t)start;
+  }
+  if (lane == 0) col_ptr[d] = nnz;
+  wave_lds_fence();
+  base[lane] = start;
+  wave_lds_fence();
+  unsigned row_carry = 0;
+  for (int t = 0; t < nnz; t += WAVE) {
+    const int k = t + lane;
+    const bool valid = k < nnz;
+    const unsigned c = valid ? kw[2 * k + 1] : 0u;
+    unsigned row = wave_incl_max_u32(valid ? kw[2 * k] : 0u);
+    row = row > row_carry ? row : row_carry;
+    row_carry = (unsigned)__builtin_amdgcn_readlane((int)row, WAVE - 1);
+    unsigned rank = 0, cnt = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const unsigned cl = (unsigned)__shfl((int)c, leader);
+      const unsigned long long m = __ballot(valid && c == cl);
+      if (valid && c == cl) {
+        rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        cnt = (unsigned)__popcll(m);
+      }
+      todo &= ~m;
+    }
+    if (valid) {
+      const unsigned kpos = base[c] + rank;
+      csr_col[k] = __popcll(present & ((1ull << c) - 1ull));
+      csc_val[kpos] = vals[k];
+      csc_row[kpos] = (int32_t)row;
+    }
+    wave_lds_fence();
+    if (valid && rank == 0) base[c] += cnt;
+    wave_lds_fence();
+  }
+  return d;
+}
+
+// An entity of at most PACK_RANK_MAX non-zeros all of whose columns are below PACK_BITMAP_COLS (C2's bag: 1 024 features; the
+// MovieLens bags) needs no sort either: the set of its columns is a 2 048-bit map, one 32-bit word per lane; a column's local id is
+// the number of set bits below it (a prefix over the words' popcounts + a masked popcount), col_ptr is a scan over the per-id counts,
+// and an entry's CSC slot is its column's start plus its rank among the entries of the same column in position order — 0 for all
+// but the few columns that occur twice (ballot ranking inside a 64-entry tile, as count_entity does, for those columns only).
+// Same outputs as wave_rank_sort + emit_entity, bit for bit (tests/test_gpu_parity.py::_check_pack on every fixture), without the
+// rank sort's nnz broadcast-compare trips: ~470 -> ~250 wavefront instructions for a 64-entry entity (pack_entity_kernel<256> on C2:
+// 1.01 ms, three quarters of it VALU issue — profiles/r04_final_c2_1m.txt). w: 5 x 64 words of LDS.
 constexpr int PACK_BITMAP_COLS = 2048;
 constexpr int PACK_BITMAP_WORDS = 5 * WAVE;
 template <class ValPtr>
