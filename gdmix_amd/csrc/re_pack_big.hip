@@ -57,6 +57,64 @@ __global__ void big_sizes_kernel(const int64_t* __restrict__ ent_nnz_ptr, const 
   }
 }
 
+// The head of the device-wide pack in ONE launch, for up to BIG_HEAD_MAX big entities (round 5): their sizes, chunk counts and row counts
+// and the three exclusive scans over them (offs, chunk0 with its closing total, row_offs), and the zero the column maximum starts
+// from. It was seven launches of a few microseconds each (two per-entity kernels, three library scans of two launches, a memset):
+// 0.1 ms of launch latency in front of a share's 0.45 ms pack (tools/timeline_session.sh). One workgroup, tiles of 1 024 entities.
+constexpr int BIG_HEAD_MAX = 1 << 16;
+__global__ __launch_bounds__(1024) void big_head_kernel(const int64_t* __restrict__ ent_nnz_ptr, const int64_t* __restrict__ ent_row_ptr,
+                                                        const int32_t* __restrict__ big_list, int n_big, int64_t* __restrict__ sizes,
+                                                        int64_t* __restrict__ offs, int64_t* __restrict__ nch, int64_t* __restrict__ chunk0,
+                                                        int64_t* __restrict__ rows, int64_t* __restrict__ row_offs, unsigned* __restrict__ max_col) {
+  __shared__ long long wsum[3][16];
+  __shared__ long long carry[3];
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) { carry[0] = carry[1] = carry[2] = 0; *max_col = 0u; }
+  __syncthreads();
+  for (int b0 = 0; b0 <= n_big; b0 += 1024) {
+    const int b = b0 + (int)threadIdx.x;
+    long long v[3] = {0, 0, 0};
+    if (b < n_big) {
+      const int64_t e = big_list[b];
+      const int64_t z = ent_nnz_ptr[e + 1] - ent_nnz_ptr[e];
+      v[0] = z;
+      v[1] = z > 0 ? (z + BIG_CH - 1) / BIG_CH : 1;
+      v[2] = ent_row_ptr[e + 1] - ent_row_ptr[e] + 1;
+      sizes[b] = v[0]; nch[b] = v[1]; rows[b] = v[2];
+    } else if (b == n_big) {
+      nch[b] = 0;
+    }
+    long long inc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      long long x = v[k];
+#pragma unroll
+      for (int d = 1; d < WAVE; d <<= 1) {
+        const long long y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+      }
+      inc[k] = x;
+      if (lane == WAVE - 1) wsum[k][wv] = x;
+    }
+    __syncthreads();
+    long long excl[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      long long base = carry[k];
+      for (int w = 0; w < wv; ++w) base += wsum[k][w];
+      excl[k] = base + inc[k] - v[k];
+    }
+    if (b < n_big) { offs[b] = excl[0]; chunk0[b] = excl[1]; row_offs[b] = excl[2]; }
+    else if (b == n_big) chunk0[b] = excl[1];
+    __syncthreads();
+    if (threadIdx.x == 1023) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) carry[k] = excl[k] + v[k];
+    }
+    __syncthreads();
+  }
+}
+
 // largest b with offs[b] <= i
 __device__ __forceinline__ int big_find(const int64_t* __restrict__ offs, int n_big, int64_t i) {
   int lo = 0, hi = n_big - 1;
@@ -457,12 +515,23 @@ int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s, 
   int64_t* chunk0 = reinterpret_cast<int64_t*>(base + o_chunk0);
   void* lib = base + o_lib;
 
+  unsigned* max_col_dev = reinterpret_cast<unsigned*>(sizes + nb + 1);   // the spare entry of `sizes`
   int grid = (nb + 1 + 255) / 256;
-  hipLaunchKernelGGL(big_sizes_kernel, dim3(grid), dim3(256), 0, s, a.ent_nnz_ptr, a.big_list, nb, sizes, nch);
   size_t tmp = lib_tmp;
-  HIP_TRY((rocprim::exclusive_scan(lib, tmp, sizes, offs, (int64_t)0, (size_t)nb, rocprim::plus<int64_t>(), s)));
-  tmp = lib_tmp;
-  HIP_TRY((rocprim::exclusive_scan(lib, tmp, nch, chunk0, (int64_t)0, (size_t)nb + 1, rocprim::plus<int64_t>(), s)));
+  const bool one_launch_head = nb <= BIG_HEAD_MAX;
+  if (one_launch_head) {
+    hipLaunchKernelGGL(big_head_kernel, dim3(1), dim3(1024), 0, s, a.ent_nnz_ptr, a.ent_row_ptr, a.big_list, nb, sizes, offs, nch, chunk0, rows, row_offs,
+                       max_col_dev);
+  } else {
+    hipLaunchKernelGGL(big_sizes_kernel, dim3(grid), dim3(256), 0, s, a.ent_nnz_ptr, a.big_list, nb, sizes, nch);
+    HIP_TRY((rocprim::exclusive_scan(lib, tmp, sizes, offs, (int64_t)0, (size_t)nb, rocprim::plus<int64_t>(), s)));
+    tmp = lib_tmp;
+    HIP_TRY((rocprim::exclusive_scan(lib, tmp, nch, chunk0, (int64_t)0, (size_t)nb + 1, rocprim::plus<int64_t>(), s)));
+    hipLaunchKernelGGL(big_rowcount_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, a.ent_row_ptr, a.big_list, nb, rows);
+    tmp = lib_tmp;
+    HIP_TRY((rocprim::exclusive_scan(lib, tmp, rows, row_offs, (int64_t)0, (size_t)nb, rocprim::plus<int64_t>(), s)));
+    HIP_TRY(hipMemsetAsync(max_col_dev, 0, 4, s));
+  }
   int32_t* const chunk_ent = reinterpret_cast<int32_t*>(base + o_chunk_ent);
   {
     const int g = (nb + 3) / 4 < ctx->num_cus * 8 ? (nb + 3) / 4 : ctx->num_cus * 8;
@@ -471,9 +540,6 @@ int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s, 
   // row pointers of these entities and the row of every raw position (both paths). Nothing here depends on the columns: the table is
   // built on `aux` while this stream finds the largest column, waits for the host's decision and counts the columns (round 5: it was
   // 0.2 ms in the middle of the 0.8 ms chain a MovieLens pack waits for, tools/timeline_session.sh)
-  hipLaunchKernelGGL(big_rowcount_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, a.ent_row_ptr, a.big_list, nb, rows);
-  tmp = lib_tmp;
-  HIP_TRY((rocprim::exclusive_scan(lib, tmp, rows, row_offs, (int64_t)0, (size_t)nb, rocprim::plus<int64_t>(), s)));
   const bool two_streams = aux != s && ctx->aux_ev[0] && ctx->aux_ev[1];
   // (the table lives behind everything either path carves out of the work area: its place does not depend on the path)
   uint32_t* const row_of = reinterpret_cast<uint32_t*>(base + o_row_of);
@@ -489,8 +555,6 @@ int pack_big_entities(gdmix_ctx_impl* ctx, const BigPackArgs& a, hipStream_t s, 
   // workgroups of the per-entry passes: one per chunk up to a few per CU's worth, strided beyond
   const int cgrid = (int)(max_chunks > (int64_t)ctx->num_cus * 64 ? (int64_t)ctx->num_cus * 64 : (max_chunks > 0 ? max_chunks : 1));
   // the bits of the column field: of the largest column index among these entities (one small read-back)
-  unsigned* max_col_dev = reinterpret_cast<unsigned*>(sizes + nb + 1);   // the spare entry of `sizes`
-  HIP_TRY(hipMemsetAsync(max_col_dev, 0, 4, s));
   hipLaunchKernelGGL(big_maxcol_kernel, dim3(cgrid), dim3(256), 0, s, a.ent_nnz_ptr, a.col_global, a.big_list, chunk0, chunk_ent, nb, max_col_dev, a.err);
   unsigned max_col = 0;
   HIP_TRY(fetch_small(ctx, 2, max_col_dev, 4, &max_col, s));

@@ -35,15 +35,17 @@ TrainingResult = namedtuple("TrainingResult", ("theta", "variance", "unique_glob
 _ROW_BITS = 40
 _ROW_MASK = (1 << _ROW_BITS) - 1
 WRITE_BEHIND_THREADS = int(os.environ.get("GDMIX_WRITE_THREADS", "8"))   # files being written at a time behind the device work
-# Partitions of a cold start solved in ONE device batch (plan_group; 1 = every partition on its own, as the reference trains them, and the
-# default). A partition of a hashed population is a small batch for an MI355X — one rank's share of BASELINE config 5, one partition per
-# launch, 3.8 M entities/s on the device; eight per launch 5.3 M (profiles/r05_c5_full_share.txt): what a partition waits for is the latency
-# of its few largest entities, which a larger batch shares. Opt-in because a run through the CLI is not bound by that today: with the
-# files decoded and written around it the C5-shaped run is 0.89 - 0.92 M entities/s one partition per launch and 0.84 - 0.88 M with eight
-# (the group waits for all its partitions to be decoded and writes all their files at once: profiles/r05_group_ab.txt). The files that
-# come out are per partition either way.
-GROUP_MAX = max(1, int(os.environ.get("GDMIX_PARTITIONS_PER_BATCH", "1")))
-GROUP_MAX_BYTES = int(float(os.environ.get("GDMIX_GROUP_MB", "512")) * (1 << 20))    # ... of at most this much input (files on disk)
+# Consecutive cold-start partitions solved in ONE device batch (plan_group): up to GROUP_MAX of them and GROUP_MAX_BYTES of input files
+# (GDMIX_PARTITIONS_PER_BATCH=1: every partition on its own, as the reference trains them). A partition of a hashed population is a small
+# batch for an MI355X — one rank's share of BASELINE config 5, one partition per launch, 3.8 M entities/s on the device; two / four / eight
+# per launch 4.6 / 5.1 / 5.3 M (profiles/r05_c5_full_share.txt): what a partition waits for is the latency of its few largest entities,
+# which a larger batch shares. Through the CLI the group also has to wait for all its partitions to be decoded and hands all their files
+# to the writers at once, so small groups win: a C5-shaped run of 8 partitions of 63 MB, 0.91 - 0.96 M entities/s one by one, 1.07 - 1.09 M
+# in pairs, 0.94 - 0.96 in threes, 1.01 - 1.03 in fours, 0.84 - 0.88 all eight at once; C2's 150 MB partitions lose a tenth when paired
+# (their device time is already amortised, their files are what the run waits for). Hence the byte bound: partitions of that size stay
+# alone, smaller ones pair up (profiles/r05_group_ab.txt). The files that come out are per partition either way.
+GROUP_MAX = max(1, int(os.environ.get("GDMIX_PARTITIONS_PER_BATCH", "4")))
+GROUP_MAX_BYTES = int(float(os.environ.get("GDMIX_GROUP_MB", "160")) * (1 << 20))
 
 
 class ModelTable:
