@@ -1169,6 +1169,8 @@ def main():
             "detail": {"strong_projection": projection, "step_wall_ms": [round((b[0] - c) * 1e3, 3) for b, c in zip(step_wall, [t0] + [x[0] for x in step_wall[:-1]])],
                        "step_device_ms": [[round(x[1], 3), round(x[2], 3)] for x in step_wall],
                        "pack_ms_per_step": pack_ms / a.steps, "solve_ms_per_step": solve_ms / a.steps,
+                       "unique_compaction": ("next to the solve (gdmix_re_set_defer_unique): inside solve_ms, not pack_ms"
+                                             if os.environ.get("GDMIX_RE_DEFER_UNIQUE", "1") != "0" else "inside the pack"),
                        "solve_kernel_ms_per_step": float(kernel_ms.sum()) / a.steps,
                        "classes": classes, "class_ms": [round(float(x) / a.steps, 3) for x in kernel_ms], "per_class": per_class,
                        "mean_nit": nit, "mean_nfev": nfev,

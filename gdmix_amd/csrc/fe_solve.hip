@@ -1290,6 +1290,7 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   hipStream_t s = static_cast<hipStream_t>(stream);
   gdmix_ctx_impl* ci = &ctx->impl;
   HIP_TRY(hipSetDevice(ci->device));
+  HIP_TRY(join_unique(ci, s));   // the shard's unique_global is read here
   gdmix_fe_problem* p = new (std::nothrow) gdmix_fe_problem();
   if (!p) { set_error("out of host memory"); return GDMIX_RE_ENOMEM; }
   p->ctx = ctx;

@@ -287,6 +287,7 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   c->impl.big_tmp_bytes = 0;
   c->impl.n_side = 0; c->impl.side_fork = nullptr;
   c->impl.aux_ev[0] = c->impl.aux_ev[1] = nullptr;
+  c->impl.defer_unique = 0; c->impl.unique_pending = false; c->impl.unique_ev = nullptr;
   for (int k = 0; k < gdmix_ctx_impl::MAX_SIDE; ++k) { c->impl.side[k] = nullptr; c->impl.side_join[k] = nullptr; }
   for (int k = 0; k < GDMIX_RE_NUM_CLASSES; ++k) { c->impl.ev0[k] = nullptr; c->impl.ev1[k] = nullptr; c->impl.ev_used[k] = false; }
   for (uint32_t& q : c->impl.mail_seq) q = 0;
@@ -304,6 +305,7 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
     if (want > 0) {
       rc = hipEventCreateWithFlags(&c->impl.side_fork, hipEventDisableTiming);
       for (int k = 0; k < 2 && rc == hipSuccess; ++k) rc = hipEventCreateWithFlags(&c->impl.aux_ev[k], hipEventDisableTiming);
+      if (rc == hipSuccess) rc = hipEventCreateWithFlags(&c->impl.unique_ev, hipEventDisableTiming);
       for (int k = 0; k < want && rc == hipSuccess; ++k) {
         rc = hipStreamCreateWithFlags(&c->impl.side[k], hipStreamNonBlocking);
         if (rc == hipSuccess) rc = hipEventCreateWithFlags(&c->impl.side_join[k], hipEventDisableTiming);
@@ -329,6 +331,8 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
 
 GDMIX_API void gdmix_re_destroy(gdmix_re_ctx* ctx) {
   if (!ctx) return;
+  if (ctx->impl.unique_pending && ctx->impl.unique_ev) (void)hipEventSynchronize(ctx->impl.unique_ev);   // a deferred kernel nobody waited for
+  if (ctx->impl.unique_ev) (void)hipEventDestroy(ctx->impl.unique_ev);
   if (ctx->impl.grid_sync) (void)hipFree(ctx->impl.grid_sync);
   if (ctx->impl.big_tmp) (void)hipFree(ctx->impl.big_tmp);
   if (ctx->impl.host_pinned) (void)hipHostFree(ctx->impl.host_pinned);
@@ -359,7 +363,21 @@ GDMIX_API int gdmix_re_pack(gdmix_re_ctx* ctx, const gdmix_re_raw_batch* raw_dev
   }
   if (raw_dev->Z > 0 && (!raw_dev->col_global || !raw_dev->val)) { set_error("raw batch has NULL arrays"); return GDMIX_RE_EINVAL; }
   HIP_TRY(hipSetDevice(ctx->impl.device));
+  HIP_TRY(join_unique(&ctx->impl, static_cast<hipStream_t>(stream)));   // (the workspace of the pack before may be this one)
   return pack_impl(&ctx->impl, raw_dev, has_intercept, workspace, workspace_bytes, out, static_cast<hipStream_t>(stream));
+}
+
+GDMIX_API int gdmix_re_set_defer_unique(gdmix_re_ctx* ctx, int enabled) {
+  if (!ctx) { set_error("ctx is NULL"); return GDMIX_RE_EINVAL; }
+  ctx->impl.defer_unique = (enabled && ctx->impl.n_side > 0) ? 1 : 0;
+  return GDMIX_RE_OK;
+}
+
+GDMIX_API int gdmix_re_pack_join(gdmix_re_ctx* ctx, void* stream) {
+  if (!ctx) { set_error("ctx is NULL"); return GDMIX_RE_EINVAL; }
+  HIP_TRY(hipSetDevice(ctx->impl.device));
+  HIP_TRY(join_unique(&ctx->impl, static_cast<hipStream_t>(stream)));
+  return GDMIX_RE_OK;
 }
 
 static int slots_for(const gdmix_re_packed* b, const gdmix_re_opts* o, size_t* slot_doubles) {
@@ -756,6 +774,8 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     const int rc = run_variance_full(ctx, b, B, P, out->theta, out->variance, s);
     if (rc != GDMIX_RE_OK) return rc;
   }
+  // a pack's deferred compaction ran next to this solve: from here on the caller's stream is behind it, as it is behind the solve
+  HIP_TRY(join_unique(&ctx->impl, s_main));
   return GDMIX_RE_OK;
 }
 
@@ -768,6 +788,7 @@ GDMIX_API int gdmix_re_variance_full(gdmix_re_ctx* ctx, const gdmix_re_packed* b
   }
   if (b->E == 0) return GDMIX_RE_OK;
   HIP_TRY(hipSetDevice(ctx->impl.device));
+  HIP_TRY(join_unique(&ctx->impl, static_cast<hipStream_t>(stream)));
   SolveParams P;
   P.l2 = opts->l2; P.ftol = opts->ftol; P.pgtol = opts->pgtol; P.threshold = opts->threshold;
   P.regularize_bias = opts->regularize_bias; P.has_intercept = opts->has_intercept ? 1 : 0; P.m = opts->m; P.max_iter = opts->max_iter;
@@ -781,6 +802,7 @@ GDMIX_API int gdmix_re_score(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int ha
   if (!ctx || !b || !logit || !logit_per_coord) { set_error("NULL argument"); return GDMIX_RE_EINVAL; }
   if (!theta && !has_model) { set_error("theta is NULL"); return GDMIX_RE_EINVAL; }
   HIP_TRY(hipSetDevice(ctx->impl.device));
+  HIP_TRY(join_unique(&ctx->impl, static_cast<hipStream_t>(stream)));
   BatchDev B = make_batch_dev(b);
   HIP_TRY(launch_score(B, b->E, b->N, has_intercept ? 1 : 0, theta, has_model, logit, logit_per_coord,
                        static_cast<hipStream_t>(stream)));

@@ -158,6 +158,11 @@ struct gdmix_ctx_impl {
   int n_side;
   hipEvent_t side_fork, side_join[MAX_SIDE];
   hipEvent_t aux_ev[2];   // pack_big_entities: the row table is built on a second stream, next to the column passes
+  // gdmix_re_set_defer_unique: the last kernel of a pack (the compaction of the unique feature ids, which no solve kernel reads) runs on
+  // the last side stream, next to the solve that follows; `unique_ev` marks its end, `unique_pending` that nobody has waited for it yet
+  int defer_unique;
+  bool unique_pending;
+  hipEvent_t unique_ev;
   hipEvent_t ev0[GDMIX_RE_NUM_CLASSES], ev1[GDMIX_RE_NUM_CLASSES];
   bool ev_used[GDMIX_RE_NUM_CLASSES];
 };
@@ -262,6 +267,15 @@ hipError_t launch_variance_of_hessian(gdmix_ctx_impl* ci, double* H, double* M, 
 inline size_t var_full_slot_doubles(int64_t max_p) { return (size_t)2 * max_p * max_p + max_p + 8; }
 hipError_t launch_score(const BatchDev& B, int64_t E, int64_t N, int ic, const double* theta, const uint8_t* has_model,
                         float* logit, float* per_coord, hipStream_t s);
+
+// the caller's stream waits for a deferred compaction that is still outstanding (every entry point that reads unique_global, or that
+// reuses the workspace it is written from, calls this first; gdmix_re_solve calls it last)
+inline hipError_t join_unique(gdmix_ctx_impl* ci, hipStream_t s) {
+  if (!ci->unique_pending) return hipSuccess;
+  const hipError_t rc = hipStreamWaitEvent(s, ci->unique_ev, 0);
+  if (rc == hipSuccess) ci->unique_pending = false;
+  return rc;
+}
 
 // pack (re_pack.hip)
 size_t pack_workspace_bytes(int64_t E, int64_t N, int64_t Z);

@@ -917,15 +917,39 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
   hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb, stats);
   hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, s, d_cnt, E, block_sums, out->ent_feat_ptr);
   DBG_STAGE("scan kernels");
+  // The compaction is the one kernel of a pack that no solve kernel reads the output of (unique_global is for the model table and the
+  // fixed-effect shard): with gdmix_re_set_defer_unique it runs on the last side stream, behind the scan, NEXT to the solve the caller
+  // queues after this function returns — a copy-shaped kernel beside kernels bound by their arithmetic — and the statistics come back
+  // without waiting for it. Whoever reads unique_global waits for `unique_ev` (join_unique).
+  const bool defer = ctx->defer_unique && ctx->n_side > 0;
+  hipStream_t const sc = defer ? ctx->side[ctx->n_side - 1] : s;
+  SmallFetch tail_fetch;
+  if (defer) {
+    HIP_TRY(post_small(ctx, 1, stats, sizeof(PackStats), hs, s, &tail_fetch));
+    HIP_TRY(hipEventRecord(ctx->side_fork, s));   // (this call's side streams have been joined above)
+    HIP_TRY(hipStreamWaitEvent(sc, ctx->side_fork, 0));
+  }
   {
+    // deferred: a grid that is resident at once with room to spare — workgroups of a grid that is still being placed hold up the
+    // placement of every other queue's kernels (the solve's first launches would wait for this kernel's last round instead of running
+    // next to it: measured, the step did not move with the 16-per-CU grid)
+    static int defer_wgs = 0;
+    if (defer_wgs == 0) { const char* e = getenv("GDMIX_RE_DEFER_WGS"); defer_wgs = (e && atoi(e) > 0) ? atoi(e) : 4; }
+    const int per_cu = defer ? defer_wgs : 16;
     int grid = (int)((E + 3) / 4);
-    if (grid > ctx->num_cus * 16) grid = ctx->num_cus * 16;
-    hipLaunchKernelGGL(pack_compact_unique_kernel, dim3(grid), dim3(256), 0, s, out->ent_nnz_ptr, out->ent_feat_ptr, E,
+    if (grid > ctx->num_cus * per_cu) grid = ctx->num_cus * per_cu;
+    hipLaunchKernelGGL(pack_compact_unique_kernel, dim3(grid), dim3(256), 0, sc, out->ent_nnz_ptr, out->ent_feat_ptr, E,
                        uniq_sparse, out->unique_global);
   }
   DBG_STAGE("pack_compact_unique_kernel");
   HIP_TRY(hipGetLastError());
-  HIP_TRY(fetch_small(ctx, 1, stats, sizeof(PackStats), hs, s));
+  if (defer) {
+    HIP_TRY(hipEventRecord(ctx->unique_ev, sc));
+    ctx->unique_pending = true;
+    HIP_TRY(wait_small(ctx, tail_fetch));
+  } else {
+    HIP_TRY(fetch_small(ctx, 1, stats, sizeof(PackStats), hs, s));
+  }
   if (hs->err) {
     set_error("pack: an entity exceeds a per-entity int32 limit or a feature index is outside [0, 2^31)");
     return hs->err;

@@ -7,6 +7,7 @@ There is NO CPU fallback: if the library is missing or no gfx950 device is visib
 raises. (The CPU restatement under oracle/ is test infrastructure and is never imported here.)
 """
 import ctypes as C
+import functools
 import os
 from dataclasses import dataclass
 from typing import Optional
@@ -68,7 +69,7 @@ class _Result(C.Structure):
 
 EXPORTED_SYMBOLS = (
     "gdmix_re_abi_version", "gdmix_re_last_error", "gdmix_re_default_opts", "gdmix_re_create",
-    "gdmix_re_destroy", "gdmix_re_pack_workspace_bytes", "gdmix_re_pack", "gdmix_re_solve",
+    "gdmix_re_destroy", "gdmix_re_pack_workspace_bytes", "gdmix_re_pack", "gdmix_re_set_defer_unique", "gdmix_re_pack_join", "gdmix_re_solve",
     "gdmix_re_solve_scratch_bytes", "gdmix_re_set_scratch", "gdmix_re_variance_full", "gdmix_re_set_wave_lds_limit", "gdmix_re_score",
     "gdmix_re_widen_workspace_bytes", "gdmix_re_widen", "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz", "gdmix_re_set_tall_min_n", "gdmix_re_set_tall_split_n", "gdmix_re_set_tall_team_n", "gdmix_re_set_spread",
     "gdmix_fe_create", "gdmix_fe_destroy", "gdmix_fe_eval", "gdmix_fe_reduce_buffer", "gdmix_fe_step", "gdmix_fe_step_async", "gdmix_fe_step_status", "gdmix_fe_solve", "gdmix_fe_result",
@@ -105,6 +106,8 @@ def load_library():
     lib.gdmix_re_pack_workspace_bytes.restype = C.c_size_t
     lib.gdmix_re_pack.argtypes = [C.c_void_p, C.POINTER(_RawBatch), C.c_int, C.c_void_p, C.c_size_t,
                                   C.POINTER(_Packed), C.c_void_p]
+    lib.gdmix_re_set_defer_unique.argtypes = [C.c_void_p, C.c_int]
+    lib.gdmix_re_pack_join.argtypes = [C.c_void_p, C.c_void_p]
     lib.gdmix_re_widen_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64]
     lib.gdmix_re_widen_workspace_bytes.restype = C.c_size_t
     lib.gdmix_re_widen.argtypes = [C.c_void_p, C.POINTER(_WireBatch), C.c_void_p, C.c_size_t, C.POINTER(_RawBatch), C.c_void_p]
@@ -155,7 +158,7 @@ def load_library():
     lib.gdmix_java_partition_id.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     lib.gdmix_java_partition_id.restype = C.c_int32
     lib.gdmix_java_partition_ids_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
-    if lib.gdmix_re_abi_version() != 10:
+    if lib.gdmix_re_abi_version() != 11:
         raise GdmixReError("libgdmix_re.so ABI version mismatch")
     _lib = lib
     return lib
@@ -207,8 +210,9 @@ def java_partition_id(s: str, num_partitions: int) -> int:
 class PackedBatch:
     """A packed ragged CSR/CSC batch resident in HBM. Keeps the torch tensors that back it alive."""
 
-    def __init__(self, c_struct, tensors, raw_dev, has_intercept):
+    def __init__(self, c_struct, tensors, raw_dev, has_intercept, join=None):
         self.c = c_struct
+        self._join = join       # REDeviceSolver.pack_join of the context that packed it (gdmix_re_set_defer_unique), or None
         self._tensors = tensors
         self._raw_dev = raw_dev
         self.has_intercept = bool(has_intercept)
@@ -234,7 +238,18 @@ class PackedBatch:
 
     def unique_global(self):
         import torch
+        if self._join is not None:
+            self._join()        # the compaction that writes it may still be running next to the solve (a no-op once waited for)
         return self._view(self.c.unique_global, self.D, torch.int64)
+
+    def __del__(self):  # pragma: no cover
+        # the workspace goes back to torch's allocator in the order of the current stream: that stream must be behind a deferred
+        # compaction nobody has waited for (a batch packed and dropped without a solve)
+        try:
+            if self._join is not None:
+                self._join()
+        except Exception:
+            pass
 
     def csr_col(self):
         import torch
@@ -332,6 +347,24 @@ class REDeviceSolver:
         _check(self.lib.gdmix_re_create(self.device_index, C.byref(h)), "gdmix_re_create")
         self._h = h
         self._scratch = None
+        # the compaction of the unique feature ids next to the solve (gdmix_re_set_defer_unique; GDMIX_RE_DEFER_UNIQUE=0: inside the pack)
+        self._pack_gen = 0      # packs of this context so far: only the latest one's compaction can be outstanding
+        self.set_defer_unique(os.environ.get("GDMIX_RE_DEFER_UNIQUE", "1") != "0")
+
+    def set_defer_unique(self, enabled: bool):
+        _check(self.lib.gdmix_re_set_defer_unique(self._h, int(bool(enabled))), "gdmix_re_set_defer_unique")
+
+    def pack_join(self):
+        """The current stream waits for a pack's deferred compaction (PackedBatch.unique_global calls it; every library call that reads
+        the array does so itself)."""
+        if getattr(self, "_h", None):
+            _check(self.lib.gdmix_re_pack_join(self._h, self._stream()), "gdmix_re_pack_join")
+
+    def _pack_join_of(self, gen):
+        # a batch older than the context's latest pack has been waited for already (gdmix_re_pack waits first): its accessor or its
+        # destructor must not make the stream wait for the NEWER batch's compaction, which is meant to run next to that batch's solve
+        if gen == self._pack_gen:
+            self.pack_join()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -500,7 +533,8 @@ class REDeviceSolver:
         c_packed = _Packed()
         _check(self.lib.gdmix_re_pack(self._h, C.byref(c_raw), int(bool(has_intercept)), ws.data_ptr(), nbytes,
                                       C.byref(c_packed), self._stream()), "gdmix_re_pack")
-        return PackedBatch(c_packed, {"workspace": ws}, rd, has_intercept)
+        self._pack_gen += 1
+        return PackedBatch(c_packed, {"workspace": ws}, rd, has_intercept, join=functools.partial(self._pack_join_of, self._pack_gen))
 
     # ---- solve -----------------------------------------------------------------------------------
     def alloc_result(self, packed: PackedBatch, variance=False):

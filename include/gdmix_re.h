@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GDMIX_RE_ABI_VERSION 10
+#define GDMIX_RE_ABI_VERSION 11
 
 #if defined(__GNUC__)
 #define GDMIX_API __attribute__((visibility("default")))
@@ -194,6 +194,19 @@ GDMIX_API size_t gdmix_re_pack_workspace_bytes(int64_t E, int64_t N, int64_t Z);
  * global-indexing form yields identical coefficients on the entity's support). */
 GDMIX_API int gdmix_re_pack(gdmix_re_ctx* ctx, const gdmix_re_raw_batch* raw_dev, int has_intercept,
                   void* workspace, size_t workspace_bytes, gdmix_re_packed* out, void* stream);
+
+/* (ABI 11) The last kernel of a pack compacts every entity's unique feature ids into `unique_global` — the one output no solve
+ * kernel reads (it names the coefficients for the model table, job_consumers.py:243, and maps a fixed-effect shard's columns). With
+ * `enabled` != 0 gdmix_re_pack queues that kernel on a side stream of the context and returns without waiting for it, so it runs
+ * NEXT to the gdmix_re_solve the caller queues behind the pack: a copy-shaped kernel beside kernels bound by their arithmetic.
+ * Every other member of gdmix_re_packed is ordered on `stream` as before. `unique_global` is ordered on the stream of the next of
+ * these calls on the same context: gdmix_re_solve (on return the stream is behind the compaction as it is behind the solve),
+ * gdmix_re_score, gdmix_re_variance_full, gdmix_fe_create, gdmix_re_pack (the next batch), gdmix_re_pack_join. A caller that reads
+ * unique_global itself, or frees / reuses the workspace, without one of them in between calls gdmix_re_pack_join(ctx, stream)
+ * first. Default off (everything stream-ordered when gdmix_re_pack returns); gdmix_amd/solver.py switches it on. Results are the
+ * same bits either way. A context without side streams ignores the request. */
+GDMIX_API int gdmix_re_set_defer_unique(gdmix_re_ctx* ctx, int enabled);
+GDMIX_API int gdmix_re_pack_join(gdmix_re_ctx* ctx, void* stream);
 
 /* Wire form -> raw form on the device (two prefix sums and two widening copies, ~0.3 ms for C2), enqueued on
  * `stream`; fills *out (a host struct of device pointers into `workspace` and into the wire arrays). The result

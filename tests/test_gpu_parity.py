@@ -326,6 +326,50 @@ def test_side_stream_does_not_change_results(device_solver, monkeypatch):
         assert np.array_equal(a[k], r[k]), k
 
 
+def test_unique_ids_compacted_next_to_the_solve_are_the_same(device_solver):
+    """ABI 11, gdmix_re_set_defer_unique (csrc/re_pack.hip: the end of pack_impl): the compaction of the per-entity unique feature ids
+    (job_consumers.py:243, np.unique) runs on a side stream next to the solve that follows the pack. The array is bit-exact against the
+    oracle whether it is read right after the pack (the accessor waits), after the solve, or from a context that keeps the kernel inside
+    the pack; batches packed and dropped without a solve, workspace reused at once, leave nothing behind; solves are the same bits."""
+    import torch
+    from gdmix_amd.solver import REDeviceSolver
+    b = synthetic.make_batch(200_000, 16, 4, 1024, seed=71)
+    pk = oracle.pack(b.ent_row_ptr, b.row_nnz_ptr, b.col_global)
+    kw = dict(l2=1.0, regularize_bias=False, has_intercept=True, m=10, max_iter=100, ftol=1e-12)
+    rd = device_solver.upload(b)
+    # (a) read right after the pack
+    packed = device_solver.pack(rd)
+    assert np.array_equal(packed.unique_global().cpu().numpy(), pk["unique_global"])
+    # (b) read after the solve only, the pack -> solve pair as the product path issues it, a few times over with churn in between:
+    # batches packed and dropped unsolved, their workspace handed straight to the next allocation
+    want = None
+    for rep in range(4):
+        for _ in range(3):
+            junk = device_solver.pack(rd)
+            del junk
+            torch.full((b.Z + 1,), -1, dtype=torch.int64, device="cuda")   # lands where a dropped workspace was
+        packed = device_solver.pack(rd)
+        res = device_solver.solve(packed, SolverOptions(**kw))
+        got_u = packed.unique_global().cpu().numpy()
+        assert np.array_equal(got_u, pk["unique_global"]), rep
+        got = res.to_host()
+        if want is None:
+            want = got
+        for k in ("theta", "fval", "nit", "nfev", "status"):
+            assert np.array_equal(got[k], want[k]), (rep, k)
+    # (c) a context that keeps the compaction inside the pack
+    plain = REDeviceSolver(0)
+    try:
+        plain.set_defer_unique(False)
+        pp = plain.pack(rd)
+        r = plain.solve(pp, SolverOptions(**kw)).to_host()
+        assert np.array_equal(pp.unique_global().cpu().numpy(), pk["unique_global"])
+    finally:
+        plain.close()
+    for k in ("theta", "fval", "nit", "nfev", "status"):
+        assert np.array_equal(want[k], r[k]), k
+
+
 def test_large_classes_side_by_side_do_not_change_results(device_solver):
     """Round 4: the size classes that fill the device are dealt over the caller's stream and the context's side streams
     (gdmix_re_set_spread, default 4) instead of running one after another. 120 k C2 entities (three large group classes) with
