@@ -59,6 +59,17 @@ __device__ __forceinline__ double wave_max_nonneg(double v) {
   return readlane63(v);
 }
 
+// Max over the wave of non-negative ints, as a uniform value (all lanes must be active).
+__device__ __forceinline__ int wave_max_nonneg_i32(int v) {
+  v = max(v, __builtin_amdgcn_mov_dpp(v, 0x111, 0xf, 0xf, true));
+  v = max(v, __builtin_amdgcn_mov_dpp(v, 0x112, 0xf, 0xf, true));
+  v = max(v, __builtin_amdgcn_mov_dpp(v, 0x114, 0xf, 0xf, true));
+  v = max(v, __builtin_amdgcn_mov_dpp(v, 0x118, 0xf, 0xf, true));
+  v = max(v, __builtin_amdgcn_mov_dpp(v, 0x142, 0xf, 0xf, true));
+  v = max(v, __builtin_amdgcn_mov_dpp(v, 0x143, 0xf, 0xf, true));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 // Compiler-level ordering point between LDS accesses of different lanes of ONE wave. The LDS queue
 // of a wave is processed in order, so no hardware wait is needed; the fences only stop the compiler
 // from moving memory operations across this point.

@@ -559,47 +559,58 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
 #pragma unroll
         for (int s = 0; s < EPL; ++s) V.d[s] = -V.g[s];
       }
-      // two-loop recursion over each row's last cnt pairs (indices M_REG-cnt .. M_REG-1, newest last)
-#pragma unroll
-      for (int a = M_REG - 1; a >= 0; --a) {
-        const bool use = need_dir && (a >= M_REG - cnt);
-        if (__any(use)) {
-          if (use) {
-            double sa[EPL], ya[EPL];
-#pragma unroll
-            for (int s = 0; s < EPL; ++s) { sa[s] = S[a][s]; ya[s] = Y[a][s]; }
-            double t = 0.0;
-#pragma unroll
-            for (int s = 0; s < EPL; ++s) t += sa[s] * V.d[s];
-            const double al = rho[a] * grp_sum<G>(t, X);
-            alpha[a] = al;
-#pragma unroll
-            for (int s = 0; s < EPL; ++s) V.d[s] -= al * ya[s];
-          }
-        }
+      // two-loop recursion over each row's last cnt pairs (indices M_REG-cnt .. M_REG-1, newest last). The pairs any row of the wave
+      // uses are M_REG-cmax .. M_REG-1 with cmax uniform: the first loop leaves at its lower end, the second enters at it (a switch
+      // that falls through) — until round 5 every one of the 2 M_REG steps was skipped on its own (`if (__any(use))`: a compare, an
+      // exec save and a taken branch each, ~11 of 20 skipped at C2's mean history of 4.5 pairs).
+      const int cmax = wave_max_nonneg_i32(need_dir ? cnt : 0);
+      const int a0 = M_REG - cmax;
+#define QUAD_FIRST_LOOP_STEP(a)                                                   \
+      {                                                                           \
+        if ((a) < a0) goto first_loop_done;                                       \
+        const bool use = need_dir && ((a) >= M_REG - cnt);                        \
+        if (use) {                                                                \
+          double t = 0.0;                                                         \
+          _Pragma("unroll") for (int s = 0; s < EPL; ++s) t += S[a][s] * V.d[s];  \
+          const double al = rho[a] * grp_sum<G>(t, X);                            \
+          alpha[a] = al;                                                          \
+          _Pragma("unroll") for (int s = 0; s < EPL; ++s) V.d[s] -= al * Y[a][s]; \
+        }                                                                         \
       }
+      static_assert(M_REG == 10, "the steps below are written out for ten pairs");
+      QUAD_FIRST_LOOP_STEP(9) QUAD_FIRST_LOOP_STEP(8) QUAD_FIRST_LOOP_STEP(7) QUAD_FIRST_LOOP_STEP(6) QUAD_FIRST_LOOP_STEP(5)
+      QUAD_FIRST_LOOP_STEP(4) QUAD_FIRST_LOOP_STEP(3) QUAD_FIRST_LOOP_STEP(2) QUAD_FIRST_LOOP_STEP(1) QUAD_FIRST_LOOP_STEP(0)
+#undef QUAD_FIRST_LOOP_STEP
+    first_loop_done:
       if (need_dir && cnt > 0) {
         const double h0 = 1.0 / scal[SC_THETA];
 #pragma unroll
         for (int s = 0; s < EPL; ++s) V.d[s] *= h0;
       }
-#pragma unroll
-      for (int a = 0; a < M_REG; ++a) {
-        const bool use = need_dir && (a >= M_REG - cnt);
-        if (__any(use)) {
-          if (use) {
-            double sa[EPL], ya[EPL];
-#pragma unroll
-            for (int s = 0; s < EPL; ++s) { sa[s] = S[a][s]; ya[s] = Y[a][s]; }
-            double t = 0.0;
-#pragma unroll
-            for (int s = 0; s < EPL; ++s) t += ya[s] * V.d[s];
-            const double c = alpha[a] - rho[a] * grp_sum<G>(t, X);
-#pragma unroll
-            for (int s = 0; s < EPL; ++s) V.d[s] += c * sa[s];
-          }
-        }
+#define QUAD_SECOND_LOOP_STEP(a)                                                  \
+      {                                                                           \
+        const bool use = need_dir && ((a) >= M_REG - cnt);                        \
+        if (use) {                                                                \
+          double t = 0.0;                                                         \
+          _Pragma("unroll") for (int s = 0; s < EPL; ++s) t += Y[a][s] * V.d[s];  \
+          const double c = alpha[a] - rho[a] * grp_sum<G>(t, X);                  \
+          _Pragma("unroll") for (int s = 0; s < EPL; ++s) V.d[s] += c * S[a][s];  \
+        }                                                                         \
       }
+      switch (a0) {
+        case 0: QUAD_SECOND_LOOP_STEP(0) [[fallthrough]];
+        case 1: QUAD_SECOND_LOOP_STEP(1) [[fallthrough]];
+        case 2: QUAD_SECOND_LOOP_STEP(2) [[fallthrough]];
+        case 3: QUAD_SECOND_LOOP_STEP(3) [[fallthrough]];
+        case 4: QUAD_SECOND_LOOP_STEP(4) [[fallthrough]];
+        case 5: QUAD_SECOND_LOOP_STEP(5) [[fallthrough]];
+        case 6: QUAD_SECOND_LOOP_STEP(6) [[fallthrough]];
+        case 7: QUAD_SECOND_LOOP_STEP(7) [[fallthrough]];
+        case 8: QUAD_SECOND_LOOP_STEP(8) [[fallthrough]];
+        case 9: QUAD_SECOND_LOOP_STEP(9) [[fallthrough]];
+        default: break;
+      }
+#undef QUAD_SECOND_LOOP_STEP
       if (need_dir) {
         // z = x + d ; d = z - x (mainlb re-derives d from the subspace point); save x, g
         double dd = 0.0, gdp = 0.0;
