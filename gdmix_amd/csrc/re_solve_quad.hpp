@@ -581,7 +581,7 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
       QUAD_FIRST_LOOP_STEP(9) QUAD_FIRST_LOOP_STEP(8) QUAD_FIRST_LOOP_STEP(7) QUAD_FIRST_LOOP_STEP(6) QUAD_FIRST_LOOP_STEP(5)
       QUAD_FIRST_LOOP_STEP(4) QUAD_FIRST_LOOP_STEP(3) QUAD_FIRST_LOOP_STEP(2) QUAD_FIRST_LOOP_STEP(1) QUAD_FIRST_LOOP_STEP(0)
 #undef QUAD_FIRST_LOOP_STEP
-    first_loop_done:
+    first_loop_done:;
       if (need_dir && cnt > 0) {
         const double h0 = 1.0 / scal[SC_THETA];
 #pragma unroll
