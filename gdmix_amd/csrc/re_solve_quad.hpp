@@ -315,6 +315,9 @@ __device__ __forceinline__ bool grp_any(bool v) {
   return ((m >> sh) & ((1ull << G) - 1ull)) != 0ull;
 }
 
+#ifndef QUAD_FUSED_COLS
+#define QUAD_FUSED_COLS 1
+#endif
 // sum_k val[k] * vec[idx[k]] over `len` packed {idx, float bits} pairs starting at `pairs`, added to acc
 // in index order. Gathers are issued four at a time; the FMA chain keeps the sequential order (masked
 // tail entries multiply by an exact 0).
@@ -345,6 +348,41 @@ __device__ __forceinline__ double gather_dot2(const int2* pairs, int len, const 
     acc += (r > 1 ? (double)__int_as_float(p1.y) : 0.0) * v1;
   }
   return acc;
+}
+
+// The EPL columns of a lane in ONE loop, two entries of each per trip: every trip issues all its pair loads, then all its
+// gathers (2 EPL in flight) — EPL loops one after the other were 2 EPL dependent LDS round trips per trip of each and a loop
+// branch per column, with two wavefronts per SIMD to hide them. A column's products are added in its own order as before;
+// a column that has ended adds exact zeros (gathered from the residual's slot 0, always finite).
+template <int EPL>
+__device__ __forceinline__ void gather_dot2_cols(const int2* csc, const unsigned (&colc)[EPL], const double* vec, double (&acc)[EPL]) {
+  int len[EPL], mx = 0;
+  const int2* pairs[EPL];
+#pragma unroll
+  for (int s = 0; s < EPL; ++s) {
+    len[s] = (int)(colc[s] >> 16);
+    pairs[s] = csc + (colc[s] & 0xffffu);
+    mx = max(mx, len[s]);
+  }
+  for (int c = 0; c < mx; c += 2) {
+    int2 p0[EPL], p1[EPL];
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+      const int r = len[s] - c;
+      p0[s] = pairs[s][r > 0 ? c : 0];
+      p1[s] = pairs[s][r > 1 ? c + 1 : 0];
+      if (r <= 0) p0[s] = make_int2(0, 0);
+      if (r <= 1) p1[s] = make_int2(0, 0);
+    }
+    double v0[EPL], v1[EPL];
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) { v0[s] = vec[p0[s].x]; v1[s] = vec[p1[s].x]; }
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+      acc[s] += (double)__int_as_float(p0[s].y) * v0[s];
+      acc[s] += (double)__int_as_float(p1[s].y) * v1[s];
+    }
+  }
 }
 
 // f and g at xt. rowc: packed (start | len << 16) of the lane's first sample; colc[s]: same for the
@@ -407,6 +445,24 @@ __device__ __forceinline__ double quad_eval(const QuadLds& L, const SolveParams&
   part += 0.5 * o.l2 * sq;
   grp_fence<G>();
   const double inv_n = 1.0 / (double)n;
+  if (EPL <= 3 && QUAD_FUSED_COLS) {
+    double acc[EPL];
+    unsigned cc[EPL];
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+      const int j = gl + G * s;
+      acc[s] = (ic && j == 0) ? rpart : 0.0;
+      cc[s] = (j < p) ? colc[s] : 0u;
+    }
+    gather_dot2_cols<EPL>(L.csc(), cc, rs, acc);
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+      const int j = gl + G * s;
+      const double reg = (j < first_reg) ? 0.0 : o.l2 * xt[s];
+      g[s] = (j < p) ? inv_n * (acc[s] + reg) : 0.0;
+    }
+    return inv_n * part;
+  }
 #pragma unroll
   for (int s = 0; s < EPL; ++s) {
     const int j = gl + G * s;
