@@ -233,7 +233,7 @@ __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL >= 3 
   }
   grp_fence<G>();
   SolveStats st;
-  quad_solve<G, EPL>(L, o, gl, n, p, ic, valid, rowc, colc, V, X, st);
+  quad_solve<G, EPL, (NCAP > G)>(L, o, gl, n, p, ic, valid, rowc, colc, V, X, st);
   if (!valid) return;
 
 #pragma unroll

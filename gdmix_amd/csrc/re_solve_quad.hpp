@@ -318,6 +318,9 @@ __device__ __forceinline__ bool grp_any(bool v) {
 #ifndef QUAD_FUSED_COLS
 #define QUAD_FUSED_COLS 1
 #endif
+#ifndef QUAD_FUSED_COLS4
+#define QUAD_FUSED_COLS4 1
+#endif
 // sum_k val[k] * vec[idx[k]] over `len` packed {idx, float bits} pairs starting at `pairs`, added to acc
 // in index order. Gathers are issued four at a time; the FMA chain keeps the sequential order (masked
 // tail entries multiply by an exact 0).
@@ -385,9 +388,35 @@ __device__ __forceinline__ void gather_dot2_cols(const int2* csc, const unsigned
   }
 }
 
+// The same with ONE entry of each column per trip (EPL = 4: two per trip spill).
+template <int EPL>
+__device__ __forceinline__ void gather_dot1_cols(const int2* csc, const unsigned (&colc)[EPL], const double* vec, double (&acc)[EPL]) {
+  int len[EPL], mx = 0;
+  const int2* pairs[EPL];
+#pragma unroll
+  for (int s = 0; s < EPL; ++s) {
+    len[s] = (int)(colc[s] >> 16);
+    pairs[s] = csc + (colc[s] & 0xffffu);
+    mx = max(mx, len[s]);
+  }
+  for (int c = 0; c < mx; ++c) {
+    int2 p0[EPL];
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+      p0[s] = pairs[s][c < len[s] ? c : 0];
+      if (c >= len[s]) p0[s] = make_int2(0, 0);
+    }
+    double v0[EPL];
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) v0[s] = vec[p0[s].x];
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) acc[s] += (double)__int_as_float(p0[s].y) * v0[s];
+  }
+}
+
 // f and g at xt. rowc: packed (start | len << 16) of the lane's first sample; colc[s]: same for the
 // lane's coefficient slots (len = 0 for the intercept / unused slots).
-template <int G, int EPL>
+template <int G, int EPL, bool LONG_COLS = true>
 __device__ __forceinline__ double quad_eval(const QuadLds& L, const SolveParams& o, int gl, int n, int p, int ic,
                                             unsigned rowc, const unsigned (&colc)[EPL], const double (&xt)[EPL],
                                             double (&g)[EPL], XWave& X, bool first, bool& counted) {
@@ -445,7 +474,7 @@ __device__ __forceinline__ double quad_eval(const QuadLds& L, const SolveParams&
   part += 0.5 * o.l2 * sq;
   grp_fence<G>();
   const double inv_n = 1.0 / (double)n;
-  if (EPL <= 3 && QUAD_FUSED_COLS) {
+  if ((EPL <= 3 && QUAD_FUSED_COLS) || (EPL == 4 && QUAD_FUSED_COLS4 && LONG_COLS)) {
     double acc[EPL];
     unsigned cc[EPL];
 #pragma unroll
@@ -454,7 +483,8 @@ __device__ __forceinline__ double quad_eval(const QuadLds& L, const SolveParams&
       acc[s] = (ic && j == 0) ? rpart : 0.0;
       cc[s] = (j < p) ? colc[s] : 0u;
     }
-    gather_dot2_cols<EPL>(L.csc(), cc, rs, acc);
+    if (EPL <= 3) gather_dot2_cols<EPL>(L.csc(), cc, rs, acc);
+    else gather_dot1_cols<EPL>(L.csc(), cc, rs, acc);
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
       const int j = gl + G * s;
@@ -486,7 +516,10 @@ struct QuadState {
 };
 
 // The solve of the (up to) four entities of a wave. `valid` marks rows that own an entity.
-template <int G, int EPL>
+// LONG_COLS: the class holds entities with more samples than the group has lanes (columns of several entries are the rule): the
+// EPL = 4 kernels then gather their four columns in one loop too, an entry of each per trip (C5-shaped classes - 1 to - 3 %); where
+// columns mostly hold one entry (C2's <16,4>: n <= 16) the four short loops are as fast and spill less (+ 0.5 % with the fused loop)
+template <int G, int EPL, bool LONG_COLS = true>
 __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& o, int gl, int n, int p, int ic,
                                            bool valid, unsigned rowc, const unsigned (&colc)[EPL], QuadState<EPL>& V,
                                            XWave& X, SolveStats& out) {
@@ -523,7 +556,7 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
     if (status < 0) {
       // ---- f, g at the trial point; g'd, y'y and max|g| in one reduction pass ------------------------
       bool counted;
-      f = quad_eval<G, EPL>(L, o, gl, n, p, ic, rowc, colc, V.x, V.g, X, first, counted);
+      f = quad_eval<G, EPL, LONG_COLS>(L, o, gl, n, p, ic, rowc, colc, V.x, V.g, X, first, counted);
       nfev += counted ? 1 : 0;
       {
         double a = 0.0, b = 0.0, c = 0.0;
