@@ -579,7 +579,7 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
       } else {
         LineSearch LS = *L.ls();
         const int task = dcsrch_step(LS, f, gd, stp);
-        *L.ls() = LS;
+        if (task == LS_FG) *L.ls() = LS;   // (an accepted or abandoned search is started afresh by dcsrch_start: nothing reads its state again)
         if (task == LS_FG) {
           ++ifun;
           if (ifun - 1 < o.maxls) {
