@@ -330,6 +330,13 @@ __device__ __forceinline__ StepIO dcstep(StepIO v, double fp, double dp, double 
   return o;
 }
 
+// dcsrch's convergence test (the strong Wolfe conditions), which decides a search whatever its warnings say (it is the last
+// assignment of `task` in dcsrch): callers that hold only these three numbers of the state can ask it first.
+__device__ __forceinline__ bool dcsrch_converged(double finit, double gtest, double ginit, double f, double g, double stp) {
+  const double ftest = finit + stp * gtest;
+  return f <= ftest && fabs(g) <= LS_GTOL * (-ginit);
+}
+
 __device__ __forceinline__ int dcsrch_step(LineSearch& S, double f, double g, double& stp_io) {
   double stp = stp_io;
   int task = LS_FG;
@@ -339,7 +346,7 @@ __device__ __forceinline__ int dcsrch_step(LineSearch& S, double f, double g, do
   if (S.brackt && S.stmax - S.stmin <= LS_XTOL * S.stmax) task = LS_WARN;
   if (stp == LS_STPMAX && f <= ftest && g <= S.gtest) task = LS_WARN;
   if (stp == LS_STPMIN && (f > ftest || g >= S.gtest)) task = LS_WARN;
-  if (f <= ftest && fabs(g) <= LS_GTOL * (-S.ginit)) task = LS_CONV;
+  if (dcsrch_converged(S.finit, S.gtest, S.ginit, f, g, stp)) task = LS_CONV;
   if (task != LS_FG) return task;
   // dcsrch calls dcstep either on the function values or, in stage 1 while f > ftest, on the modified
   // function psi(a) = phi(a) - a*gtest. Both forms are one call here: with gt = 0 the subtractions and
