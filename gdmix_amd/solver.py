@@ -247,7 +247,7 @@ class PackedBatch:
         # compaction nobody has waited for (a batch packed and dropped without a solve)
         try:
             if self._join is not None:
-                self._join()
+                self._join(dropping=True)
         except Exception:
             pass
 
@@ -354,17 +354,19 @@ class REDeviceSolver:
     def set_defer_unique(self, enabled: bool):
         _check(self.lib.gdmix_re_set_defer_unique(self._h, int(bool(enabled))), "gdmix_re_set_defer_unique")
 
-    def pack_join(self):
-        """The current stream waits for a pack's deferred compaction (PackedBatch.unique_global calls it; every library call that reads
-        the array does so itself)."""
+    def pack_join(self, stream=None):
+        """A stream (default: the current one) waits for a pack's deferred compaction (PackedBatch.unique_global calls it; every
+        library call that reads the array does so itself)."""
         if getattr(self, "_h", None):
-            _check(self.lib.gdmix_re_pack_join(self._h, self._stream()), "gdmix_re_pack_join")
+            _check(self.lib.gdmix_re_pack_join(self._h, self._stream() if stream is None else stream), "gdmix_re_pack_join")
 
-    def _pack_join_of(self, gen):
+    def _pack_join_of(self, gen, pack_stream, dropping=False):
         # a batch older than the context's latest pack has been waited for already (gdmix_re_pack waits first): its accessor or its
-        # destructor must not make the stream wait for the NEWER batch's compaction, which is meant to run next to that batch's solve
+        # destructor must not make the stream wait for the NEWER batch's compaction, which is meant to run next to that batch's solve.
+        # A reader waits on its own (the current) stream; a batch that is dropped makes the stream it was packed on wait — the one its
+        # workspace goes back to the allocator on — whatever thread and stream the destructor happens to run under.
         if gen == self._pack_gen:
-            self.pack_join()
+            self.pack_join(pack_stream if dropping else None)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -531,10 +533,11 @@ class REDeviceSolver:
         nbytes = self.lib.gdmix_re_pack_workspace_bytes(E, N, Z)
         ws = t.empty(nbytes, dtype=t.uint8, device=self.device)
         c_packed = _Packed()
+        st = self._stream()
         _check(self.lib.gdmix_re_pack(self._h, C.byref(c_raw), int(bool(has_intercept)), ws.data_ptr(), nbytes,
-                                      C.byref(c_packed), self._stream()), "gdmix_re_pack")
+                                      C.byref(c_packed), st), "gdmix_re_pack")
         self._pack_gen += 1
-        return PackedBatch(c_packed, {"workspace": ws}, rd, has_intercept, join=functools.partial(self._pack_join_of, self._pack_gen))
+        return PackedBatch(c_packed, {"workspace": ws}, rd, has_intercept, join=functools.partial(self._pack_join_of, self._pack_gen, st))
 
     # ---- solve -----------------------------------------------------------------------------------
     def alloc_result(self, packed: PackedBatch, variance=False):
