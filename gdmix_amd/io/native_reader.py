@@ -12,8 +12,8 @@ from ..batch import RawBatch, WireRawBatch
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "libgdmix_io.so")
-ABI_VERSION = 6
-EXPORTED_SYMBOLS = ("gdmix_io_abi_version", "gdmix_io_last_error", "gdmix_io_read_grouped", "gdmix_io_free", "gdmix_io_narrow", "gdmix_io_pool_trim",
+ABI_VERSION = 7
+EXPORTED_SYMBOLS = ("gdmix_io_abi_version", "gdmix_io_build_id", "gdmix_io_last_error", "gdmix_io_read_grouped", "gdmix_io_free", "gdmix_io_narrow", "gdmix_io_pool_trim",
                     "gdmix_io_crc32c", "gdmix_io_masked_crc32c", "gdmix_io_avro_write_models", "gdmix_io_avro_write_scores",
                     "gdmix_io_write_grouped", "gdmix_io_read_examples", "gdmix_io_avro_read_models", "gdmix_io_free_models", "gdmix_io_map_coefficients", "gdmix_io_ids_unique", "gdmix_io_match_ids")
 
@@ -92,12 +92,17 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise GdmixIoError(f"{LIB_PATH} is missing: run `python -m gdmix_amd.build`")
+    from .. import build as _build
+    stale = _build.check_library(LIB_PATH, _build.io_source_id(), "csrc/io_*.cpp")
+    if stale:
+        raise GdmixIoError(stale)
     lib = C.CDLL(LIB_PATH)
     for sym in EXPORTED_SYMBOLS:
         if not hasattr(lib, sym):
             raise GdmixIoError(f"{LIB_PATH} does not export {sym}")
     lib.gdmix_io_abi_version.restype = C.c_int
     lib.gdmix_io_last_error.restype = C.c_char_p
+    lib.gdmix_io_build_id.restype = C.c_char_p
     lib.gdmix_io_read_grouped.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.POINTER(_Schema), C.POINTER(C.POINTER(_Batch))]
     lib.gdmix_io_read_examples.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.POINTER(_Schema), C.POINTER(C.POINTER(_Batch))]
     lib.gdmix_io_free.argtypes = [C.POINTER(_Batch)]

@@ -38,7 +38,7 @@ extern "C" {
 #define GDMIX_IO_ENOMEM   (-5)
 #define GDMIX_IO_ERANGE   (-6)   /* a value does not fit the 32-bit hand-over form (gdmix_io_narrow) */
 
-#define GDMIX_IO_ABI_VERSION 6
+#define GDMIX_IO_ABI_VERSION 7
 
 typedef struct gdmix_io_schema {
   const char* entity;        /* context key of the entity id (int64 or bytes scalar)                       */
@@ -82,6 +82,8 @@ typedef struct gdmix_io_batch {
 } gdmix_io_batch;
 
 GDMIX_IO_API int gdmix_io_abi_version(void);
+/* (ABI 7) hash of the sources this binary was compiled from (gdmix_amd/build.py: io_source_id()); see gdmix_re_build_id. */
+GDMIX_IO_API const char* gdmix_io_build_id(void);
 GDMIX_IO_API const char* gdmix_io_last_error(void);
 
 /* Read every record of `files` (".gz" => gzip, ".deflate" => zlib, anything else raw: input_data_pipeline.py:63-85)

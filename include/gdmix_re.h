@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GDMIX_RE_ABI_VERSION 11
+#define GDMIX_RE_ABI_VERSION 12
 
 #if defined(__GNUC__)
 #define GDMIX_API __attribute__((visibility("default")))
@@ -179,6 +179,10 @@ typedef struct {
 } gdmix_re_result;
 
 GDMIX_API int  gdmix_re_abi_version(void);
+/* (ABI 12) Hash (16 hex digits) of the sources this binary was compiled from — the .hip units, csrc/*.hpp and the two C headers;
+ * gdmix_amd/build.py: source_id(). The library travels prebuilt next to its sources; the Python loader refuses a binary whose id is
+ * not the hash of the sources beside it, and build.needs_build() compares this id, not modification times. */
+GDMIX_API const char* gdmix_re_build_id(void);
 GDMIX_API const char* gdmix_re_last_error(void);
 
 GDMIX_API int  gdmix_re_create(int hip_device, gdmix_re_ctx** out);

@@ -93,6 +93,7 @@ def main():
                 for name, v in combo:
                     if name == "LIB":
                         shutil.copy(os.path.join(ROOT, v), lib_path)
+                        env["GDMIX_ALLOW_STALE_LIB"] = "1"      # a build of other sources under the product's name: the loader refuses those
                     elif v == "unset":
                         env.pop(name, None)
                     else:

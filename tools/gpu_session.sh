@@ -37,15 +37,15 @@ for step in "$@"; do
   echo "== $key: $val"
   case $key in
     tests) timeout 3000 python -m pytest $val -m gpu -x -q > $log 2>&1; echo "tests rc=$?" >> $log; grep -v "^INFO\|^DEBUG" $log | tail -4 | cut -c1-300 ;;
-    lib) cp $val gdmix_amd/libgdmix_re.so ;;
+    lib) cp $val gdmix_amd/libgdmix_re.so; export GDMIX_ALLOW_STALE_LIB=1 ;;   # builds of other sources: the loader refuses those otherwise
     ab) timeout 2400 python tools/ab.py $val --out $out/ab$n > $log 2>&1; grep -v "^--" $log | tail -24 | cut -c1-260 ;;
     project|cli)
       BENCH_EXTRA=$([ $key = project ] && echo "--no-cli" || echo "--project-ranks 0")
       for rep in 1 2; do
-        if [ "${val%%:*}" = lib ]; then for L in $(echo ${val#lib:} | tr , ' '); do cp $L gdmix_amd/libgdmix_re.so; bench_once "$L rep=$rep"; done
+        if [ "${val%%:*}" = lib ]; then export GDMIX_ALLOW_STALE_LIB=1; for L in $(echo ${val#lib:} | tr , ' '); do cp $L gdmix_amd/libgdmix_re.so; bench_once "$L rep=$rep"; done
         else for v in $(echo ${val#*=} | tr , ' '); do bench_once "${val%%=*}=$v rep=$rep" "${val%%=*}=$v"; done; fi
       done 2>&1 | tee $log | cut -c1-400 ;;
-    fe) cp gdmix_amd/libgdmix_re.so /tmp/lib_keep.so
+    fe) cp gdmix_amd/libgdmix_re.so /tmp/lib_keep.so; export GDMIX_ALLOW_STALE_LIB=1
         for rep in 1 2 3; do for b in $val; do
           if [ -n "${FE_ENV:-}" ]; then for v in $(echo ${FE_ENV#*=} | tr , ' '); do env ${FE_ENV%%=*}=$v bash tools/fe_ab.sh $b 2>&1 | sed "s/^/${FE_ENV%%=*}=$v /"; done
           else bash tools/fe_ab.sh $b 2>&1; fi
@@ -56,4 +56,4 @@ for step in "$@"; do
     *) echo "unknown step $key" ;;
   esac
 done
-cp $out/lib_at_start.so gdmix_amd/libgdmix_re.so; rm -f $out/lib_at_start.so
+cp $out/lib_at_start.so gdmix_amd/libgdmix_re.so; rm -f $out/lib_at_start.so; unset GDMIX_ALLOW_STALE_LIB

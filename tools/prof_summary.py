@@ -21,9 +21,9 @@ def stats(db):
     tot = sum(r[2] for r in rows) or 1
     for name, calls, total, avg, mn, mx in rows[:25]:
         print(f"{short(name):72s} {calls:6d} {total / 1e3:12.1f} {avg / 1e3:11.2f} {mn / 1e3:10.2f} {mx / 1e3:10.2f} {100 * total / tot:6.2f}")
-    print("# launch geometry / resources of the gdmix kernels (first dispatch of each)")
+    print("# launch geometry / resources of the gdmix kernels, by total time (first dispatch of each; template kernels are named `void gdmix::...`)")
     for r in cur.execute("select name, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, accum_vgpr_count, sgpr_count "
-                         "from kernels where name like 'gdmix::%' group by name"):
+                         "from kernels where name like '%gdmix::%' group by name order by sum(duration) desc"):
         print(f"{short(r[0]):60s} grid={r[1]} wg={r[2]} lds={r[3]} scratch={r[4]} vgpr={r[5]} agpr={r[6]} sgpr={r[7]}")
 
 
