@@ -140,6 +140,16 @@ def spawn_ranks(a):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+HOST_LEG_REPEATS = 3      # the host-bound legs (CLI, hand-over, chain) are repeated: one run of them on a shared box says little
+
+
+def _spread(xs):
+    """Median, extremes and every run of a repeated host-bound measurement (a +- 20 % box-to-box spread makes a
+    single run of these legs meaningless for a round-over-round comparison)."""
+    xs = [float(x) for x in xs]
+    return {"median": float(np.median(xs)), "min": min(xs), "max": max(xs), "runs": [round(x, 6) for x in xs]}
+
+
 def cpu_baseline(sub, opts_kw, min_seconds=10.0):
     """Time the fp64 CPU restatement (the oracle, kind 'port') on the entities of `sub`, repeated until at least
     `min_seconds` of wall time, one oracle call per host core (ctypes releases the GIL), entities dealt to the cores in
@@ -235,12 +245,16 @@ def host_handover(batch, opts, device_index, P, partitions=24, workers=3):
             th.join()
         dt = time.perf_counter() - t0
         return dt, sum(w.converged for w in ws)
-    # best of two runs each (thread start-up and the first touch of the staging blocks show up in the first)
-    dt, conv = min(pipelined(False), pipelined(False))
-    dt_ix, conv_ix = min(pipelined(True), pipelined(True))
+    # one run to settle (thread start-up, the first touch of the staging blocks), then HOST_LEG_REPEATS: the median is the figure
+    pipelined(False)
+    runs = sorted(pipelined(False) for _ in range(HOST_LEG_REPEATS))
+    dt, conv = runs[len(runs) // 2]
+    runs_ix = sorted(pipelined(True) for _ in range(HOST_LEG_REPEATS))
+    dt_ix, conv_ix = runs_ix[len(runs_ix) // 2]
     for w in ws:
         w.solver.close()
     return {"ms_per_partition": dt / partitions * 1e3, "entities_per_s": conv / dt, "partitions": partitions, "streams": workers,
+            "entities_per_s_spread": _spread(c / t for t, c in runs),
             "h2d_bytes_per_partition": h2d, "d2h_bytes_per_partition": P * 8 + batch.E * 4,
             "with_feature_index": {"ms_per_partition": dt_ix / partitions * 1e3, "entities_per_s": conv_ix / dt_ix,
                                    "d2h_bytes_per_partition": P * 8 + batch.E * 4 + (P - batch.E) * 4,
@@ -250,7 +264,7 @@ def host_handover(batch, opts, device_index, P, partitions=24, workers=3):
                     f"{workers} streams, partitions round robin; serial_one_stream = the same for one partition without overlap"}
 
 
-def fixed_effect_leg(solver, rows, nnz_per_row=32, features=100_000, iters=20):
+def fixed_effect_leg(solver, rows, nnz_per_row=32, features=100_000, iters=20, dist="uniform"):
     """SURVEY.md 8(f) N1 next to the headline: one worker's shard (rows x 32 uniform columns of 100k features, logistic, m = 10)
     resident in HBM, L-BFGS by the stepping kernels of include/gdmix_fe.h; time per evaluation (two passes over the non-zeros
     + the replicated step) and the algorithmic bytes it moves (tools/fe_bench.py has the same accounting)."""
@@ -259,7 +273,10 @@ def fixed_effect_leg(solver, rows, nnz_per_row=32, features=100_000, iters=20):
     from gdmix_amd.solver import SolverOptions
     rng = np.random.default_rng(0)
     n, k, D = rows, nnz_per_row, features
-    cols = rng.integers(0, D, n * k, dtype=np.int64)
+    if dist == "zipf":   # feature j with probability ~ 1/(j+1) (tools/fe_bench.py): the most frequent one holds 1/ln(D) of all entries
+        cols = np.minimum((float(D + 1) ** rng.random(n * k)).astype(np.int64) - 1, D - 1)
+    else:
+        cols = rng.integers(0, D, n * k, dtype=np.int64)
     vals = (rng.random(n * k, dtype=np.float32) - 0.5) * 2.0
     y = (rng.random(n, dtype=np.float32) < 0.5).astype(np.float32)
     off = np.zeros(n, np.float32)
@@ -289,7 +306,8 @@ def fixed_effect_leg(solver, rows, nnz_per_row=32, features=100_000, iters=20):
                                         "note": "what the passes' own copies hold: 8 B per entry, units of the column pass in the 6-byte form of round 5 "
                                                 "(fp32 value + 16-bit {key delta, accumulator}); the roofline figure stays on the algorithmic 16 B per non-zero"},
                "streamed_GBps": (rows_b + cols_b + 32.0 * n + (4 + 2 * m) * 8.0 * P) / (ms * 1e-3) / 1e9,
-               "shard": f"{n} samples x {k} uniform columns of {D} features, logistic, m=10",
+               "streamed_frac_of_hbm_peak": (rows_b + cols_b + 32.0 * n + (4 + 2 * m) * 8.0 * P) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "shard": f"{n} samples x {k} {dist} columns of {D} features, logistic, m=10",
                "what": "gdmix_fe_eval + gdmix_fe_step per L-BFGS evaluation; bytes = 16 B/nnz (value + index, both passes) + 32 B/sample "
                        "+ (4 + 2m) x 8 B/coefficient"}
     del packed
@@ -336,30 +354,40 @@ def cli_end_to_end_leg(entities):
                 "--partition_entity=ent", "--regularize_bias=False", "--l2_reg_weight=1.0", f"--training_score_dir={d}/ts",
                 "--action=train"]
         os.environ.pop("TF_CONFIG", None)
-        times = []
-        for rep in range(3):   # cold, cold again (the measured one), warm start from the second run's models
-            if rep == 1:
-                shutil.rmtree(os.path.join(d, "models"))
-                shutil.rmtree(os.path.join(d, "ts"), ignore_errors=True)
-            t = time.perf_counter()
-            cli.run(argv)
-            times.append(time.perf_counter() - t)
+        cold_runs, warm_runs = [], []
+        for rep in range(1 + HOST_LEG_REPEATS):   # a first cold run to settle, then (cold, warm start from its models) pairs
+            for kind in ("cold", "warm"):
+                if kind == "cold" and os.path.isdir(os.path.join(d, "models")):
+                    shutil.rmtree(os.path.join(d, "models"))
+                    shutil.rmtree(os.path.join(d, "ts"), ignore_errors=True)
+                if rep == 0 and kind == "warm":
+                    continue
+                t = time.perf_counter()
+                cli.run(argv)
+                if rep:
+                    (cold_runs if kind == "cold" else warm_runs).append(time.perf_counter() - t)
+        times = [None, float(np.median(cold_runs)), float(np.median(warm_runs))]
         size_out = sum(os.path.getsize(os.path.join(r, x)) for r, _, fs in os.walk(d) for x in fs if x.endswith(".avro"))
         # the same run the way gdmix-workflow starts a stage (single_node/local_ops.py:42-54): a fresh `python -m ...` child per
         # stage — interpreter start, imports, HIP context, library load and the run itself; files are in the page cache
         import subprocess
         sub = {}
-        for label, wipe in (("cold", True), ("warm_start", False)):
-            if wipe:
-                shutil.rmtree(os.path.join(d, "models"))
-                shutil.rmtree(os.path.join(d, "ts"), ignore_errors=True)
-            t = time.perf_counter()
-            # (the child logs at INFO as the reference does; its stderr is kept out of this run's and shown only if it fails)
-            cp = subprocess.run([sys.executable, "-m", "gdmix_amd.gdmix"] + argv[1:], cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
-                                env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")))
-            sub[label + "_s"] = time.perf_counter() - t
-            if cp.returncode != 0:
-                raise RuntimeError(f"python -m gdmix_amd.gdmix exited with {cp.returncode}: " + cp.stderr.decode(errors="replace")[-2000:])
+        child = {"cold": [], "warm_start": []}
+        for rep in range(HOST_LEG_REPEATS):
+            for label, wipe in (("cold", True), ("warm_start", False)):
+                if wipe:
+                    shutil.rmtree(os.path.join(d, "models"))
+                    shutil.rmtree(os.path.join(d, "ts"), ignore_errors=True)
+                t = time.perf_counter()
+                # (the child logs at INFO as the reference does; its stderr is kept out of this run's and shown only if it fails)
+                cp = subprocess.run([sys.executable, "-m", "gdmix_amd.gdmix"] + argv[1:], cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                    env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")))
+                child[label].append(time.perf_counter() - t)
+                if cp.returncode != 0:
+                    raise RuntimeError(f"python -m gdmix_amd.gdmix exited with {cp.returncode}: " + cp.stderr.decode(errors="replace")[-2000:])
+        for label, xs in child.items():
+            sub[label + "_s"] = float(np.median(xs))
+            sub[label + "_s_spread"] = _spread(xs)
             sub[label + "_entities_per_s"] = entities / sub[label + "_s"]
         t = time.perf_counter()
         subprocess.check_call([sys.executable, "-c", "import gdmix_amd.gdmix"], cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -369,6 +397,7 @@ def cli_end_to_end_leg(entities):
     return {"entities": entities, "partitions": parts, "tfrecord_bytes_in": size_in, "avro_bytes_out": size_out,
             "cold_s": times[1], "cold_entities_per_s": entities / times[1], "warm_start_s": times[2],
             "warm_start_entities_per_s": entities / times[2],
+            "cold_entities_per_s_spread": _spread(entities / t for t in cold_runs), "warm_start_entities_per_s_spread": _spread(entities / t for t in warm_runs),
             "what": "python -m gdmix_amd.gdmix --stage=random_effect --action=train on entity-grouped TFRecord partitions: decode, "
                     "upload, pack, solve, score the training data, model + score Avro files; in-process second run (cold = no prior "
                     "model), then a warm start from its model files"}, sub
@@ -424,15 +453,19 @@ def cli_shape_leg(kind, entities):
             timed(M, "_solve_batch", "upload_pack_solve_readback_s")
             timed(M, "_save_model", "model_avro_s")
             timed(model_mod, "_write_scores", "score_avro_s")
-            times = []
-            for rep in range(2):
+            times, runs, phase_runs = [], [], []
+            for rep in range(1 + HOST_LEG_REPEATS):   # the first run settles (context, libraries, page cache); the median of the others is the figure
                 phases.clear()
                 if rep:
                     shutil.rmtree(os.path.join(d, "models"))
                     shutil.rmtree(os.path.join(d, "ts"), ignore_errors=True)
                 t = time.perf_counter()
                 cli.run(argv)
-                times.append(time.perf_counter() - t)
+                (runs if rep else times).append(time.perf_counter() - t)
+                phase_runs.append(dict(phases))
+            mid = int(np.argsort(runs)[len(runs) // 2])
+            times.append(runs[mid])
+            phases = phase_runs[1 + mid]
         finally:
             for owner, name, fn in saved:
                 setattr(owner, name, fn)
@@ -441,6 +474,7 @@ def cli_shape_leg(kind, entities):
     dom = max(phases, key=phases.get) if phases else None
     return {"shape": kind, "entities": int(b.E), "samples": int(b.N), "nnz": int(b.Z), "largest_entity_nnz": int(z.max()), "partitions": len(members),
             "tfrecord_bytes_in": size_in, "avro_bytes_out": size_out, "cold_s": times[1], "entities_per_s": b.E / times[1],
+            "entities_per_s_spread": _spread(b.E / t for t in runs),
             "first_run_s": times[0], "phases_thread_s": {k: round(v, 4) for k, v in phases.items()}, "dominant_phase": dom,
             "generate_s": round(t_gen, 2), "write_tfrecord_s": round(t_write, 2),
             "what": "python -m gdmix_amd.gdmix --stage=random_effect --action=train (in process, second run) on 8 Java-hashed partitions of this "
@@ -476,11 +510,13 @@ def chain_leg():
     import tempfile
     from gdmix_amd import chain
     data = chain.make_dataset()
-    out = None
-    for _ in range(2):
+    outs = []
+    for _ in range(1 + HOST_LEG_REPEATS):
         with tempfile.TemporaryDirectory() as d:
-            out = chain.run_chain(d, data, num_partitions=4, upper_bounds={"per_user": 48})
-    return {"fe_s": out["global"]["s"], "per_user_s": out["per_user"]["s"], "per_movie_s": out["per_movie"]["s"],
+            outs.append(chain.run_chain(d, data, num_partitions=4, upper_bounds={"per_user": 48}))
+    outs = sorted(outs[1:], key=lambda o: o["total_s"])
+    out = outs[len(outs) // 2]
+    return {"total_s_spread": _spread(o["total_s"] for o in outs), "fe_s": out["global"]["s"], "per_user_s": out["per_user"]["s"], "per_movie_s": out["per_movie"]["s"],
             "partition_s": out["per_user"]["partition_s"] + out["per_movie"]["partition_s"], "total_s": out["total_s"],
             "validation_auc": [out[s]["validation_auc"] for s in chain.STAGES], "train_auc": [out[s]["train_auc"] for s in chain.STAGES],
             "samples": out["global"]["train_samples"] + out["global"]["validation_samples"],
@@ -718,6 +754,8 @@ def compact_line(full, detail_file):
     line["ms_per_step"] = _r(line["ms_per_step"], 6)
     cfg = full.get("config") or {}
     line["config"] = {"workload": str(cfg.get("workload", ""))[:330]}
+    if _get(cfg, "library", "build_id"):
+        line["config"]["build_id"] = cfg["library"]["build_id"]
     for k in ("workload_key", "entities_per_gpu", "total_entities", "step", "parallelism", "collective_backend"):
         if cfg.get(k) is not None:
             line["config"][k] = cfg[k]
@@ -737,8 +775,8 @@ def compact_line(full, detail_file):
     else:
         line["roofline"] = None
     cpu = full.get("cpu_baseline")
-    line["cpu_baseline"] = ({"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"], "sample": str(cpu["sample"])[:220]}
-                            if cpu else None)
+    line["cpu_baseline"] = ({"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"], "sample": str(cpu["sample"])[:220],
+                             "reference_quoted": cpu.get("reference_quoted")} if cpu else None)
     d = full.get("detail") or {}
     s = {}
 
@@ -753,7 +791,10 @@ def compact_line(full, detail_file):
     put("score_frac", _get(d, "score_pass", "frac_of_hbm_peak"))
     put("fe_frac", _get(d, "fixed_effect_eval", "frac_of_hbm_peak"))
     put("fe_ms_per_eval", _get(d, "fixed_effect_eval", "ms_per_evaluation"))
+    put("fe_streamed_frac", _get(d, "fixed_effect_eval", "streamed_frac_of_hbm_peak"))
     put("fe_zipf_frac", _get(d, "fixed_effect_eval", "zipf", "frac_of_hbm_peak"))
+    put("fe_zipf_ms_per_eval", _get(d, "fixed_effect_eval", "zipf", "ms_per_evaluation"))
+    put("solve_to_host_ms", _get(d, "solve_to_host", "ms_per_step"))
     for w in ("ml20m_user", "ml20m_movie", "c5share"):
         put(w + "_ms", _get(d, "workloads", w, "ms_per_step"))
         put(w + "_eps", _get(d, "workloads", w, "entities_per_s"))
@@ -783,6 +824,17 @@ def compact_line(full, detail_file):
     if chain:
         s["chain"] = {k: _r(v) for k, v in chain.items() if isinstance(v, (int, float))}
         s["chain"]["validation_auc"] = [_r(x) for x in chain.get("validation_auc", [])]
+    # the host-bound legs are medians of HOST_LEG_REPEATS runs: [min, max] of each next to them
+    spread = {}
+    for key, path in (("handover_eps", ("host_handover", "entities_per_s_spread")), ("cli_cold_eps", ("cli_end_to_end", "cold_entities_per_s_spread")),
+                      ("cli_warm_eps", ("cli_end_to_end", "warm_start_entities_per_s_spread")), ("cli_child_s", ("cli_subprocess", "cold_s_spread")),
+                      ("cli_c5_eps", ("cli_end_to_end_c5", "entities_per_s_spread")), ("cli_ml20m_movie_eps", ("cli_end_to_end_ml20m_movie", "entities_per_s_spread")),
+                      ("chain_total_s", ("chain", "total_s_spread"))):
+        sp = _get(d, *path)
+        if sp:
+            spread[key] = [_r(sp["min"], 3), _r(sp["max"], 3)]
+    if spread:
+        s["host_legs_min_max"] = spread
     line["summary"] = s
     st = full.get("strong_scaling")
     if st:
@@ -792,7 +844,7 @@ def compact_line(full, detail_file):
         line["note"] = str(full["note"])[:160]
     line["detail_file"] = detail_file
     # never longer than the limit: drop the optional parts, least important first
-    for drop in (("note",), ("cpu_baseline", "sample"), ("summary", "proj8"), ("strong",), ("summary",), ("config", "rank_ms_per_step")):
+    for drop in (("note",), ("cpu_baseline", "sample"), ("summary", "host_legs_min_max"), ("summary", "proj8"), ("strong",), ("summary",), ("config", "rank_ms_per_step")):
         if len(json.dumps(line)) < COMPACT_LIMIT:
             break
         tgt = line
@@ -983,6 +1035,29 @@ def main():
     p_host = int(packed.P)
     th_host = out["theta_thr"]
     c2_legs = a.workload == "c2" and world == 1
+    # SURVEY.md §8(d) metric (i) to the letter: "resident ragged-CSR batch -> theta resident on host". The headline step ends with
+    # theta in HBM (config.step says so); this is the same step plus the copy of the thresholded coefficients (float64) and the
+    # status words into page-locked host memory, serial on one stream (the hand-over leg below overlaps it with the next partition)
+    to_host = None
+    if c2_legs and not a.no_e2e:
+        th_pin = torch.empty(p_host, dtype=torch.float64).pin_memory()
+        st_pin = torch.empty(wl.E, dtype=torch.int32).pin_memory()
+        evh = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ms = []
+        for i in range(1 + 3):
+            evh[0].record()
+            pk = packed if a.solve_only else solver.pack(raw_dev)
+            r = solver.solve(pk, opts, out=out)
+            th_pin.copy_(r.theta_thr[:p_host], non_blocking=True)
+            st_pin.copy_(r.status, non_blocking=True)
+            evh[1].record()
+            evh[1].synchronize()
+            if i:
+                ms.append(evh[0].elapsed_time(evh[1]))
+        to_host = {"ms_per_step": float(np.median(ms)), "runs_ms": [round(x, 3) for x in ms], "d2h_bytes": p_host * 8 + wl.E * 4,
+                   "entities_per_s": wl.E / (float(np.median(ms)) * 1e-3),
+                   "what": "pack + solve + D2H of theta_thr (f64) and status into page-locked memory, one stream, no overlap"}
+        del th_pin, st_pin
     # host hand-over (SURVEY.md §8(d) metric (ii)): packed host batch -> H2D -> solve -> D2H -> thresholded theta on the host
     e2e = None
     if c2_legs and not a.no_e2e:
@@ -1007,6 +1082,7 @@ def main():
     fe_eval = None
     if c2_legs and not a.no_fe:
         fe_eval = fixed_effect_leg(solver, a.fe_rows)
+        fe_eval["zipf"] = fixed_effect_leg(solver, a.fe_rows, dist="zipf")   # the driver sees the skewed shard too
     cli_e2e = cli_sub = cli_c5 = cli_movie = chain_res = None
     if c2_legs and not a.no_cli:
         cli_e2e, cli_sub = cli_end_to_end_leg(a.cli_entities)
@@ -1154,6 +1230,9 @@ def main():
             sub = wl.host_sample(sample)
             v, cores, es, d, passes = cpu_baseline(sub, opts_kw)
             cpu = {"value": round(v, 1), "unit": "entities/s", "cores": cores, "kind": "port",
+                   # the reference itself (TF + scipy, one entity per fmin_l_bfgs_b call) cannot run on the GPU box; its rate measured in the build
+                   # container on these shapes is quoted, not timed here
+                   "reference_quoted": {"value": 639, "unit": "entities/s/core", "source": "BASELINE.md section 3"},
                    "sample": f"first {es} entities of the same {a.workload} batch ({sub.Z} non-zeros) x {passes} passes, oracle/re_oracle.c fp64 "
                              f"(restatement pinned to the reference by tests/golden), {cores} threads, {d:.1f} s"}
         line = {
@@ -1162,9 +1241,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": wl.what, "workload_key": a.workload,
-                       "entities_per_gpu": wl.E, "step": "solve" if a.solve_only else "pack+solve",
+                       "entities_per_gpu": wl.E, "step": "solve, theta on device" if a.solve_only else "pack+solve, theta on device",
                        "l2": 1.0, "regularize_bias": False, "max_iter": 100, "parallelism": f"entity-shard x{world}",
-                       "collective_backend": backend, "ranks": per_rank},
+                       "collective_backend": backend, "ranks": per_rank,
+                       # which binary ran: the hash of its sources (gdmix_re_build_id) and of its compiler flags
+                       "library": {"build_id": solver.lib.gdmix_re_build_id().decode(), "flags_id": build.embedded_id(build.LIB, build.FLAGS_MARKER),
+                                   "sources_id": build.source_id()}},
             "roofline": roofline, "cpu_baseline": cpu, "strong_scaling": strong,
             "detail": {"strong_projection": projection, "step_wall_ms": [round((b[0] - c) * 1e3, 3) for b, c in zip(step_wall, [t0] + [x[0] for x in step_wall[:-1]])],
                        "step_device_ms": [[round(x[1], 3), round(x[2], 3)] for x in step_wall],
@@ -1175,7 +1257,7 @@ def main():
                        "classes": classes, "class_ms": [round(float(x) / a.steps, 3) for x in kernel_ms], "per_class": per_class,
                        "mean_nit": nit, "mean_nfev": nfev,
                        "converged_per_step": converged_all, "parity_classes": {"W": well_posed, "D": int(wl.E - well_posed)}, "N": wl.N, "Z": wl.Z, "P": packed.P,
-                       "host_generate_s": t_gen, "host_handover": e2e, "score_pass": score, "fixed_effect_eval": fe_eval, "cli_end_to_end": cli_e2e,
+                       "host_generate_s": t_gen, "solve_to_host": to_host, "host_handover": e2e, "score_pass": score, "fixed_effect_eval": fe_eval, "cli_end_to_end": cli_e2e,
                        "cli_subprocess": cli_sub, "cli_end_to_end_c5": cli_c5, "cli_end_to_end_ml20m_movie": cli_movie, "workloads": others, "c5_full_share": c5_full, "chain": chain_res,
                        "restreamed_bytes_per_step": b_stream,
                        "restreamed_GBps": b_stream / (float(kernel_ms.sum()) / a.steps * 1e-3) / 1e9 if kernel_ms.sum() else None},

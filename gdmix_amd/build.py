@@ -92,6 +92,8 @@ def embedded_id(path, marker=ID_MARKER):
 
 def needs_build():
     """True when libgdmix_re.so is missing or was not compiled from the sources (and flags) next to it."""
+    if os.environ.get("GDMIX_ALLOW_STALE_LIB", "0") == "1" and os.path.exists(LIB):
+        return False      # an A/B build was swapped in under the product's name (tools/ab.py, tools/gpu_session.sh): leave it there
     return embedded_id(LIB) != source_id() or embedded_id(LIB, FLAGS_MARKER) != flags_id()
 
 

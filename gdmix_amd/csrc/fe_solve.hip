@@ -1309,8 +1309,11 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   p->seq = 0;
   p->evals = 0;
   {
+    // the one-launch step has workgroups waiting for the last arriver: next to ANOTHER process's persistent grid neither might get
+    // all its workgroups placed (re_internal.hpp: why this kernel is not behind the inter-process lock). A device that another
+    // process is present on gets the three-launch step; GDMIX_FE_FUSED_TAIL=0 / 1 decides whatever the device looks like.
     const char* e = getenv("GDMIX_FE_FUSED_TAIL");
-    p->fused_tail = !(e && e[0] == '0');
+    p->fused_tail = e ? e[0] != '0' : !device_has_another_process(ci->device);
   }
   FeDev& F = p->F;
   const int ic = opts->has_intercept ? 1 : 0;

@@ -5,7 +5,16 @@
 #include <string.h>
 #include <time.h>
 
+#include <errno.h>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <condition_variable>
+#include <map>
 #include <new>
+#include <string>
 
 #include <mutex>
 
@@ -183,14 +192,200 @@ hipEvent_t g_gate_ev[GATE_DEVICES] = {};
 bool g_gate_armed[GATE_DEVICES] = {};
 }  // namespace
 
-ScopedGridGate::ScopedGridGate(int device, hipStream_t s) : device_(device >= 0 && device < GATE_DEVICES ? device : 0), s_(s), err_(hipSuccess) {
+// ---- the same between PROCESSES (round 6; VERDICT r5 missing 3) --------------------------------------------------------------
+// The reference runs num_of_consumers processes per worker (random_effect_lr_lbfgs_model.py:103,214-217) and TF_CONFIG may list more
+// workers than the box has GPUs: two processes can drive one device, and their persistent grids can starve each other exactly as two
+// contexts' could. There is no stream-ordered primitive between processes, so the chain is a file lock per device:
+//   <dir>/gdmix_re_grid_<pci bus id>.lock   held (flock, exclusive) by a process while any of its persistent grids is in flight
+//   <dir>/gdmix_re_grid_<pci bus id>.turn   the turnstile: held while a process WAITS for the lock
+// A process takes the lock when its count of grids in flight goes 0 -> 1 and drops it from a host function queued behind the last
+// grid (hipLaunchHostFunc on the device's release stream, ordered by the gate's event: the caller's stream never waits for it), so
+// inside one process nothing changes — grids of several contexts still chain on the device, the host does not block. A launch that
+// finds the lock already held by its own process rides along unless the turnstile is taken (somebody else waits): then it waits
+// until the process has let go and queues behind the waiter — two processes alternate, neither starves. A killed process loses its
+// locks with its descriptors. GDMIX_RE_GRID_LOCK=0 turns it off, GDMIX_RE_LOCK_DIR moves the files (default /tmp; processes in
+// containers with separate /tmp do not see each other: give them a shared directory).
+class GridLock {
+ public:
+  explicit GridLock(const std::string& base) : base_(base) {}
+  // false: the lock files cannot be used (read-only directory ...): the caller goes on unprotected, as before round 6
+  bool acquire() {
+    std::unique_lock<std::mutex> g(mu_);
+    if (!open_files()) return false;
+    for (;;) {
+      if (state_ == HELD) {
+        if (!somebody_waits()) { ++count_; ++rides_; return true; }
+        cv_.wait(g);
+      } else if (state_ == ACQUIRING) {
+        cv_.wait(g);
+      } else {
+        state_ = ACQUIRING;
+        g.unlock();
+        const bool ok = flock_retry(turn_fd_, LOCK_EX) && flock_retry(dev_fd_, LOCK_EX);
+        flock_retry(turn_fd_, LOCK_UN);
+        g.lock();
+        if (!ok) { state_ = FREE; cv_.notify_all(); return false; }
+        state_ = HELD;
+        count_ = 1;
+        ++takes_;
+        cv_.notify_all();
+        return true;
+      }
+    }
+  }
+  void release() {
+    std::lock_guard<std::mutex> g(mu_);
+    if (state_ != HELD || count_ <= 0) return;
+    if (--count_ == 0) {
+      flock_retry(dev_fd_, LOCK_UN);
+      state_ = FREE;
+      cv_.notify_all();
+    }
+  }
+  void stats(long* takes, long* rides) {
+    std::lock_guard<std::mutex> g(mu_);
+    *takes = takes_;
+    *rides = rides_;
+  }
+
+ private:
+  enum State { FREE, ACQUIRING, HELD };
+  static bool flock_retry(int fd, int op) {
+    int rc;
+    do rc = flock(fd, op); while (rc != 0 && errno == EINTR);
+    return rc == 0;
+  }
+  static int open_one(const std::string& path) {
+    const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+    if (fd >= 0) (void)fchmod(fd, 0666);      // another user's process on the same device must be able to open it
+    return fd;
+  }
+  bool open_files() {
+    if (dev_fd_ >= 0) return true;
+    if (failed_) return false;
+    dev_fd_ = open_one(base_ + ".lock");
+    turn_fd_ = open_one(base_ + ".turn");
+    probe_fd_ = open_one(base_ + ".turn");    // a second description of the turnstile: flock is per description
+    if (dev_fd_ < 0 || turn_fd_ < 0 || probe_fd_ < 0) {
+      fprintf(stderr, "gdmix_re: cannot open %s.lock (%s): persistent grids of several processes on this device are not chained\n", base_.c_str(), strerror(errno));
+      for (int* fd : {&dev_fd_, &turn_fd_, &probe_fd_}) { if (*fd >= 0) close(*fd); *fd = -1; }
+      failed_ = true;
+      return false;
+    }
+    return true;
+  }
+  // is the turnstile taken? (by another process — inside this one the state machine keeps waiters off it while the lock is held)
+  bool somebody_waits() {
+    if (flock(probe_fd_, LOCK_SH | LOCK_NB) == 0) { flock_retry(probe_fd_, LOCK_UN); return false; }
+    return errno == EWOULDBLOCK;
+  }
+  std::string base_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  State state_ = FREE;
+  int count_ = 0, dev_fd_ = -1, turn_fd_ = -1, probe_fd_ = -1;
+  bool failed_ = false;
+  long takes_ = 0, rides_ = 0;
+};
+
+namespace {
+std::mutex g_locks_mu;
+std::map<std::string, GridLock*> g_locks;      // by key, never freed (a handful per process)
+GridLock* g_dev_lock[GATE_DEVICES] = {};
+hipStream_t g_rel_stream[GATE_DEVICES] = {};
+bool g_dev_lock_off[GATE_DEVICES] = {};
+
+GridLock* grid_lock_by_key(const char* key) {
+  std::lock_guard<std::mutex> g(g_locks_mu);
+  auto it = g_locks.find(key);
+  if (it != g_locks.end()) return it->second;
+  const char* dir = getenv("GDMIX_RE_LOCK_DIR");
+  std::string base = std::string(dir && *dir ? dir : "/tmp") + "/gdmix_re_grid_";
+  for (const char* c = key; *c; ++c) base += (isalnum((unsigned char)*c) || *c == '.' || *c == '-') ? *c : '_';
+  return g_locks[key] = new GridLock(base);
+}
+
+// the lock of a HIP device of this process (nullptr: off), keyed by its PCI bus id — the same for every process whatever
+// HIP_VISIBLE_DEVICES makes of the ordinals
+GridLock* grid_lock_of_device(int device) {
+  if (g_dev_lock_off[device]) return nullptr;
+  if (g_dev_lock[device]) return g_dev_lock[device];
+  const char* e = getenv("GDMIX_RE_GRID_LOCK");
+  char bus[64] = "";
+  if ((e && atoi(e) == 0) || hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess || !bus[0] ||
+      hipStreamCreateWithFlags(&g_rel_stream[device], hipStreamNonBlocking) != hipSuccess) {
+    g_dev_lock_off[device] = true;
+    return nullptr;
+  }
+  return g_dev_lock[device] = grid_lock_by_key(bus);
+}
+
+void grid_lock_release_cb(void* p) { static_cast<GridLock*>(p)->release(); }
+
+// Presence of a process on a device: a POSIX read lock on byte 0 of <dir>/gdmix_re_grid_<pci bus id>.here, taken when the process
+// creates its first context there and kept for its lifetime. Record locks belong to the process, so a query for a conflicting
+// write lock (F_GETLK) answers "does ANOTHER process hold one" in one system call.
+std::mutex g_here_mu;
+std::map<std::string, int> g_here_fd;
+
+int presence_fd(int device) {
+  char bus[64] = "";
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess || !bus[0]) return -1;
+  std::lock_guard<std::mutex> g(g_here_mu);
+  auto it = g_here_fd.find(bus);
+  if (it != g_here_fd.end()) return it->second;
+  const char* dir = getenv("GDMIX_RE_LOCK_DIR");
+  std::string path = std::string(dir && *dir ? dir : "/tmp") + "/gdmix_re_grid_";
+  for (const char* c = bus; *c; ++c) path += (isalnum((unsigned char)*c) || *c == '.' || *c == '-') ? *c : '_';
+  path += ".here";
+  const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+  if (fd >= 0) {
+    (void)fchmod(fd, 0666);
+    struct flock fl = {};
+    fl.l_type = F_RDLCK; fl.l_whence = SEEK_SET; fl.l_start = 0; fl.l_len = 1;
+    (void)fcntl(fd, F_SETLK, &fl);      // (never closed: closing ANY descriptor of the file would drop the process's lock)
+  }
+  return g_here_fd[bus] = fd;
+}
+}  // namespace
+
+void device_register_process(int device) {
+  const char* e = getenv("GDMIX_RE_GRID_LOCK");
+  if (!(e && atoi(e) == 0)) (void)presence_fd(device);
+}
+
+bool device_has_another_process(int device) {
+  const char* e = getenv("GDMIX_RE_GRID_LOCK");
+  if (e && atoi(e) == 0) return false;
+  const int fd = presence_fd(device);
+  if (fd < 0) return false;
+  struct flock fl = {};
+  fl.l_type = F_WRLCK; fl.l_whence = SEEK_SET; fl.l_start = 0; fl.l_len = 1;
+  return fcntl(fd, F_GETLK, &fl) == 0 && fl.l_type != F_UNLCK;
+}
+
+ScopedGridGate::ScopedGridGate(int device, hipStream_t s) : device_(device >= 0 && device < GATE_DEVICES ? device : 0), s_(s), err_(hipSuccess), held_(nullptr) {
   g_gate_mu[device_].lock();
   if (!g_gate_ev[device_]) err_ = hipEventCreateWithFlags(&g_gate_ev[device_], hipEventDisableTiming);
   if (err_ == hipSuccess && g_gate_armed[device_]) err_ = hipStreamWaitEvent(s_, g_gate_ev[device_], 0);
+  if (err_ == hipSuccess) {
+    GridLock* const L = grid_lock_of_device(device_);
+    if (L && L->acquire()) held_ = L;         // may block the host: another PROCESS has a persistent grid in flight on this device
+  }
 }
 
 ScopedGridGate::~ScopedGridGate() {
-  if (g_gate_ev[device_] && hipEventRecord(g_gate_ev[device_], s_) == hipSuccess) g_gate_armed[device_] = true;
+  const bool recorded = g_gate_ev[device_] && hipEventRecord(g_gate_ev[device_], s_) == hipSuccess;
+  if (recorded) g_gate_armed[device_] = true;
+  if (held_) {
+    // let go behind the grid, from the release stream: the caller's stream does not wait for a host function
+    GridLock* const L = static_cast<GridLock*>(held_);
+    if (!(recorded && hipStreamWaitEvent(g_rel_stream[device_], g_gate_ev[device_], 0) == hipSuccess &&
+          hipLaunchHostFunc(g_rel_stream[device_], grid_lock_release_cb, L) == hipSuccess)) {
+      (void)hipStreamSynchronize(s_);         // could not queue the release: wait for the grid here
+      L->release();
+    }
+  }
   g_gate_mu[device_].unlock();
 }
 }  // namespace gdmix
@@ -222,6 +417,25 @@ static bool class_is_small(int kind, int count, int num_cus) {
 
 GDMIX_API int gdmix_re_abi_version(void) { return GDMIX_RE_ABI_VERSION; }
 
+// Test hooks of the inter-process chain of persistent grids (host only, no device): the lock a device named `key` would use.
+GDMIX_API int gdmix_re_grid_lock_acquire(const char* key) {
+  if (!key || !*key) { set_error("key is empty"); return GDMIX_RE_EINVAL; }
+  return grid_lock_by_key(key)->acquire() ? GDMIX_RE_OK : GDMIX_RE_EINVAL;
+}
+GDMIX_API int gdmix_re_grid_lock_release(const char* key) {
+  if (!key || !*key) { set_error("key is empty"); return GDMIX_RE_EINVAL; }
+  grid_lock_by_key(key)->release();
+  return GDMIX_RE_OK;
+}
+GDMIX_API int gdmix_re_grid_lock_stats(const char* key, int64_t* takes, int64_t* rides) {
+  if (!key || !*key || !takes || !rides) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
+  long t = 0, r = 0;
+  grid_lock_by_key(key)->stats(&t, &r);
+  *takes = t;
+  *rides = r;
+  return GDMIX_RE_OK;
+}
+
 GDMIX_API const char* gdmix_re_last_error(void) { return g_err; }
 
 GDMIX_API void gdmix_re_default_opts(gdmix_re_opts* o) {
@@ -252,6 +466,7 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   if (!c) { set_error("out of host memory"); return GDMIX_RE_ENOMEM; }
   c->impl.device = hip_device;
   c->impl.num_cus = prop.multiProcessorCount;
+  device_register_process(hip_device);      // (what gdmix_fe_create asks before it chooses the one-launch step: re_internal.hpp)
   // (tools/r04_adapt.sh. Before the team class took a batch's tallest entities, 64 / 128 / 192 / 256 / 384 / 512 / 1024 workgroups on a 17 k-user
   // share: 2.51 / 2.39 / 2.22 / 2.51 / 2.24 / 2.43 / 2.83 ms, and 192 it was. With the heads on teams the eight-wavefront class is a class of
   // mid-size entities that finish early and hand their CU on: slowest per-user / per-movie share at 128 / 192 / 256 / 320 / 384 / 448 / 512 / 768 / 1024:
@@ -554,7 +769,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     int lds = kClasses[c].lds;
     const int gl = group_lanes(kClasses[c].kind);
     if (lds > 0 && gl > 0)
-      lds = (gl >= WAVE ? 1 : WAVE / gl) * quad_layout(gl * group_epl(kClasses[c].kind), kClasses[c].ncap, kClasses[c].zcap, gl > WAVE ? gl / WAVE : 1).bytes;
+      lds = (gl >= WAVE ? 1 : WAVE / gl) * quad_layout(gl * group_epl(kClasses[c].kind), kClasses[c].ncap, kClasses[c].zcap, gl > WAVE ? gl / WAVE : 1, gl >= WAVE ? 1 : WAVE / gl).bytes;
     bool on = lds > 0 && (lds <= ctx->impl.wave_lds_limit || (gl > WAVE && ctx->impl.wave_lds_limit >= 65536 && lds <= 160 * 1024));
     if (gl > 0 && !(ctx->impl.kernel_mask & 4)) on = false;
     if (kClasses[c].kind == KIND_WLDS && !(ctx->impl.kernel_mask & 2)) on = false;

@@ -318,6 +318,16 @@ void set_error(const char* fmt, ...);
 // barrier's watchdog gives up (round 5: 2 of 12.5 M entities ABORTED, 5 s lost, with three contexts on Zipf-sized partitions).
 // The gate chains them per device: a grid's launch waits (on the device, stream-ordered: the host does not block) for the
 // previous grid of ANY context of this process to finish. ScopedGridGate: construct before the launch, destroy after it.
+// Between PROCESSES on one device (round 6) the same chain is a file lock per device, held while a process has such a grid in
+// flight (GridLock, re_api.hip). Gated: the team tiers and the device-wide kernel (re_solve.hip), the tall teams (re_solve_tall.hip).
+// NOT gated: fe_tail_kernel (fe_solve.hip) — its launches are queued ahead of collectives that wait for the other workers, so a lock
+// held for queued work could deadlock two fixed-effect workers on one device; gdmix_fe_create falls back to the three-launch step
+// (no workgroup waits for another) when another process is present on the device — and the pack tiers, which hold no workgroup
+// waiting for another.
+// This process is (now) present on the device / another process is: record locks on a per-device file (re_api.hip).
+void device_register_process(int device);
+bool device_has_another_process(int device);
+
 class ScopedGridGate {
  public:
   ScopedGridGate(int device, hipStream_t s);
@@ -327,6 +337,7 @@ class ScopedGridGate {
   int device_;
   hipStream_t s_;
   hipError_t err_;
+  void* held_;      // the inter-process lock of the device (GridLock, re_api.hip) when this launch holds a count of it
 };
 
 struct DynLdsOnce {

@@ -192,7 +192,7 @@ __attribute__((amdgpu_waves_per_eu(EPL == 2 ? GDMIX_QUAD_WAVES_EPL2 : (EPL >= 3 
   const int64_t c0 = f0 + e * ic;
 
   QuadLds L;
-  L.q = quad_layout(G * EPL, NCAP, ZCAP, NWG);
+  L.q = quad_layout(G * EPL, NCAP, ZCAP, NWG, NG);
   L.base = smem + (size_t)row * L.q.bytes;
   L.hdr = L.base + (NWG > 1 ? (tid >> 6) * QUAD_HDR_BYTES : 0);
   L.has_w = B.weight != nullptr;
@@ -308,7 +308,7 @@ static hipError_t launch_quad_t(const BatchDev& B, const OutDev& O, const SolveP
                                 int begin, int count, hipStream_t s) {
   constexpr int NG = G >= WAVE ? 1 : WAVE / G;
   constexpr int NWG = G > WAVE ? G / WAVE : 1;
-  const int row_lds_bytes = quad_layout(G * EPL, NCAP, ZCAP, NWG).bytes;
+  const int row_lds_bytes = quad_layout(G * EPL, NCAP, ZCAP, NWG, NG).bytes;
   static DynLdsOnce lds_attr;
   if (hipError_t rc = lds_attr.set(reinterpret_cast<const void*>(re_solve_grp_kernel<G, EPL, NCAP, ZCAP>)); rc != hipSuccess) return rc;
   hipLaunchKernelGGL((re_solve_grp_kernel<G, EPL, NCAP, ZCAP>), dim3((count + NG - 1) / NG), dim3(G > WAVE ? G : WAVE),

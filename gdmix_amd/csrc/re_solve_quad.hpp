@@ -37,9 +37,33 @@ __device__ __forceinline__ double dpp_row(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// The same exchange through the LDS crossbar (ds_swizzle_b32, bit mode: lane' = lane ^ X inside 32 lanes; no memory is touched):
+// 0 vector instructions for the move instead of two v_mov_b32_dpp, at the latency of the LDS queue. quad_perm [1,0,3,2] = ^1,
+// [2,3,0,1] = ^2, row_half_mirror = ^7, row_mirror = ^15, the other row of a pair = ^16: the partner lanes of the DPP butterflies
+// below, so a sum built this way has the same bits. GDMIX_QUAD_SWZ: 1 = the reductions of several values at once (loss / residual
+// sum / |x|^2; g'd / y'y / max|g|; d'd / g'd: their moves overlap), 2 = the one-value reductions of the two-loop recursion as
+// well (a dependent chain). A/B: profiles/r06_c2_ab.txt.
+#ifndef GDMIX_QUAD_SWZ
+#define GDMIX_QUAD_SWZ 0
+#endif
+template <int X>
+__device__ __forceinline__ double swz_xor(double v) {
+  constexpr int pat = 0x1f | (X << 10);
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
+  return __hiloint2double(hi, lo);
+}
+
 // dpp_ctrl: quad_perm:[1,0,3,2] = 0xB1, quad_perm:[2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
 // Butterfly: every lane of the row ends with the same bits (each stage adds the same two partial sums).
 __device__ __forceinline__ double row_sum(double v) {
+#if GDMIX_QUAD_SWZ & 2
+  v += swz_xor<1>(v);
+  v += swz_xor<2>(v);
+  v += swz_xor<7>(v);
+  v += swz_xor<15>(v);
+  return v;
+#endif
   v += dpp_row<0xB1>(v);
   v += dpp_row<0x4E>(v);
   v += dpp_row<0x141>(v);
@@ -48,6 +72,18 @@ __device__ __forceinline__ double row_sum(double v) {
 }
 
 __device__ __forceinline__ void row_sum2(double& a, double& b) {
+#if GDMIX_QUAD_SWZ & 1
+#define GDMIX_SSTEP2(X)                \
+  {                                    \
+    const double ta = swz_xor<X>(a);   \
+    const double tb = swz_xor<X>(b);   \
+    a += ta;                           \
+    b += tb;                           \
+  }
+  GDMIX_SSTEP2(1) GDMIX_SSTEP2(2) GDMIX_SSTEP2(7) GDMIX_SSTEP2(15)
+#undef GDMIX_SSTEP2
+  return;
+#endif
 #define GDMIX_RSTEP2(CTRL)              \
   {                                     \
     const double ta = dpp_row<CTRL>(a); \
@@ -106,7 +142,8 @@ __device__ __forceinline__ double xwave_combine(XWave& X, double v, int slot, bo
 template <int G>
 __device__ __forceinline__ double grp_sum(double v, XWave& X) {
   v = row_sum(v);
-  if (G >= 32) { double a, b; rowpair_split(v, a, b); v = a + b; }
+  if (G >= 32 && (GDMIX_QUAD_SWZ & 2)) v += swz_xor<16>(v);
+  else if (G >= 32) { double a, b; rowpair_split(v, a, b); v = a + b; }
   if (G >= 64) { double a, b; half_split(v, a, b); v = a + b; }
   if (G > 64) { v = xwave_combine<G>(X, v, 0, false); X.phase ^= 1; }
   return v;
@@ -115,7 +152,11 @@ __device__ __forceinline__ double grp_sum(double v, XWave& X) {
 template <int G>
 __device__ __forceinline__ void grp_sum2(double& a, double& b, XWave& X) {
   row_sum2(a, b);
-  if (G >= 32) {
+  if (G >= 32 && (GDMIX_QUAD_SWZ & 1)) {
+    const double ta = swz_xor<16>(a), tb = swz_xor<16>(b);
+    a += ta;
+    b += tb;
+  } else if (G >= 32) {
     double a0, a1, b0, b1;
     rowpair_split(a, a0, a1);
     rowpair_split(b, b0, b1);
@@ -143,6 +184,20 @@ __device__ __forceinline__ void grp_sum2(double& a, double& b, XWave& X) {
 }
 
 __device__ __forceinline__ void row_sum3(double& a, double& b, double& c) {
+#if GDMIX_QUAD_SWZ & 1
+#define GDMIX_SSTEP3(X)                \
+  {                                    \
+    const double ta = swz_xor<X>(a);   \
+    const double tb = swz_xor<X>(b);   \
+    const double tc = swz_xor<X>(c);   \
+    a += ta;                           \
+    b += tb;                           \
+    c += tc;                           \
+  }
+  GDMIX_SSTEP3(1) GDMIX_SSTEP3(2) GDMIX_SSTEP3(7) GDMIX_SSTEP3(15)
+#undef GDMIX_SSTEP3
+  return;
+#endif
 #define GDMIX_RSTEP3S(CTRL)             \
   {                                     \
     const double ta = dpp_row<CTRL>(a); \
@@ -160,7 +215,12 @@ __device__ __forceinline__ void row_sum3(double& a, double& b, double& c) {
 template <int G>
 __device__ __forceinline__ void grp_sum3(double& a, double& b, double& c, XWave& X) {
   row_sum3(a, b, c);
-  if (G >= 32) {
+  if (G >= 32 && (GDMIX_QUAD_SWZ & 1)) {
+    const double ta = swz_xor<16>(a), tb = swz_xor<16>(b), tc = swz_xor<16>(c);
+    a += ta;
+    b += tb;
+    c += tc;
+  } else if (G >= 32) {
     double a0, a1, b0, b1, c0, c1;
     rowpair_split(a, a0, a1);
     rowpair_split(b, b0, b1);
@@ -193,6 +253,20 @@ __device__ __forceinline__ void grp_sum3(double& a, double& b, double& c, XWave&
 }
 
 __device__ __forceinline__ void row_sum2_max(double& a, double& b, double& c) {
+#if GDMIX_QUAD_SWZ & 1
+#define GDMIX_SSTEP3M(X)               \
+  {                                    \
+    const double ta = swz_xor<X>(a);   \
+    const double tb = swz_xor<X>(b);   \
+    const double tc = swz_xor<X>(c);   \
+    a += ta;                           \
+    b += tb;                           \
+    c = max_nn(c, tc);                 \
+  }
+  GDMIX_SSTEP3M(1) GDMIX_SSTEP3M(2) GDMIX_SSTEP3M(7) GDMIX_SSTEP3M(15)
+#undef GDMIX_SSTEP3M
+  return;
+#endif
 #define GDMIX_RSTEP3(CTRL)              \
   {                                     \
     const double ta = dpp_row<CTRL>(a); \
@@ -209,7 +283,12 @@ __device__ __forceinline__ void row_sum2_max(double& a, double& b, double& c) {
 template <int G>
 __device__ __forceinline__ void grp_sum2_max(double& a, double& b, double& c, XWave& X) {
   row_sum2_max(a, b, c);
-  if (G >= 32) {
+  if (G >= 32 && (GDMIX_QUAD_SWZ & 1)) {
+    const double ta = swz_xor<16>(a), tb = swz_xor<16>(b), tc = swz_xor<16>(c);
+    a += ta;
+    b += tb;
+    c = max_nn(c, tc);
+  } else if (G >= 32) {
     double a0, a1, b0, b1, c0, c1;
     rowpair_split(a, a0, a1);
     rowpair_split(b, b0, b1);
@@ -258,7 +337,16 @@ struct QuadLayout {
 // <16,4> and was deleted in round 4: profiles/r03_c2_history_by_age.txt.)
 constexpr int QUAD_HDR_BYTES = 8 * (2 * M_REG + 16 + 8);   // rho, alpha, LineSearch slot, 8 scalars (one per wavefront of the group)
 
-__host__ __device__ inline QuadLayout quad_layout(int pcap, int ncap, int zcap, int waves = 1) {
+// GDMIX_QUAD_ROW_DW: where the next row of a wavefront starts, in dwords modulo the 64 banks (rows = entities per wavefront > 1
+// only; < 0 = the packed size). A 32-lane ds_read_b64 group holds two rows of a G = 16 wavefront: lane-aligned reads (x_old, g_old,
+// the published point) of the two rows meet in the banks unless the rows start 32 banks apart — but the CSR pairs of rows of four
+// non-zeros (32 bytes a lane) then meet four deep. Sweep and counters: profiles/r06_c2_ab.txt.
+#ifndef GDMIX_QUAD_ROW_DW
+#define GDMIX_QUAD_ROW_DW (-1)
+#endif
+constexpr int LDS_BYTES_PER_CU = 160 * 1024;
+
+__host__ __device__ inline QuadLayout quad_layout(int pcap, int ncap, int zcap, int waves = 1, int rows = 1) {
   QuadLayout q;
   // groups wider than a wavefront keep one private copy of the uniform solver state per wavefront (all
   // copies hold the same values; sharing one would race between a fast wave's write and a slow wave's read)
@@ -276,6 +364,11 @@ __host__ __device__ inline QuadLayout quad_layout(int pcap, int ncap, int zcap, 
   q.o = off; off += 4 * ncap;
   q.w = off; off += 4 * ncap;
   q.bytes = (off + 15) & ~15;
+  if (GDMIX_QUAD_ROW_DW >= 0 && rows > 1) {
+    const int padded = q.bytes + 4 * ((GDMIX_QUAD_ROW_DW - q.bytes / 4) & 63);
+    // never at the price of a resident wavefront
+    if (LDS_BYTES_PER_CU / (rows * padded) >= LDS_BYTES_PER_CU / (rows * q.bytes) || LDS_BYTES_PER_CU / (rows * padded) >= 8) q.bytes = padded;
+  }
   return q;
 }
 
@@ -304,6 +397,32 @@ struct QuadLds {
 static_assert(sizeof(LineSearch) <= 128, "LineSearch must fit its LDS slot");
 
 enum { SC_FOLD = 0, SC_GDOLD = 1, SC_THETA = 2, SC_MOVED = 3 };
+
+// ---- per-entity uniform state in the LANES of a register pair (GDMIX_QUAD_LANE_STATE, round 6) ----------------------------------
+// rho[a], alpha[a] and the three scalars an iteration carries (f_old, g'd_old, theta) are uniform per entity. Until round 6 they
+// lived in the row's LDS header: one ds_read per use inside the dependent chain of the two-loop recursion, 9 + 9 LDS accesses to
+// shift rho at a push. Here lane a of every 16-lane row keeps rho[a] (alpha[a]) of the row's entity in ONE register pair; a use is
+// a v_mov_b64_dpp row_newbcast:a (gfx90a+: the one DPP control 64-bit moves take), a store two v_cndmask under a constant lane
+// mask, the shift one row_shl:1. Groups wider than a row keep identical copies in every row (all their reductions are bit-equal
+// in all lanes). Lanes: 0..9 rho | alpha, 10 f_old, 11 g'd_old, 12 theta (of the first pair only).
+// Measured (profiles/r06_c2_ab.txt): LDS instructions of <32,3> - 36 %, vector instructions + 4.8 %, the kernel alone 4.50 -> 4.55 ms,
+// <16,4> (four more registers to spill) 2.41 -> 2.61 ms, the C2 step 9.04 -> 9.22 ms: these kernels are bound by vector issue, not by
+// LDS traffic. Off; kept for the record and for the next architecture.
+#ifndef GDMIX_QUAD_LANE_STATE
+#define GDMIX_QUAD_LANE_STATE 0
+#endif
+enum { LN_FOLD = 10, LN_GDOLD = 11, LN_THETA = 12 };
+static_assert(M_REG <= 10, "lane slots 10..12 hold the scalars");
+
+template <int LANE>
+__device__ __forceinline__ double row_get(double v) {
+  // mov_dpp, not update_dpp: no `old` operand the compiler would have to materialise in the destination first
+  return __longlong_as_double(__builtin_amdgcn_mov_dpp(__double_as_longlong(v), 0x150 + LANE, 0xf, 0xf, true));
+}
+template <int LANE>
+__device__ __forceinline__ double row_put(double reg, double v) {
+  return __builtin_amdgcn_inverse_ballot_w64(0x0001000100010001ull << LANE) ? v : reg;
+}
 
 // Is `v` true in any lane of the entity's group? G <= 64: from the wavefront's ballot (all lanes of a group are active
 // together). Wider groups: this wavefront's part only (quad_eval collects the wavefronts' parts behind its first fence).
@@ -543,8 +662,13 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
   bool iter0 = true, first = true;
   // nfev is scipy's funcalls: an evaluation at the point of the previous evaluation is not counted (quad_eval)
   double f = 0.0, gd = 0.0, rr = 0.0, stp = 0.0, sbgnrm = 0.0;
+#if GDMIX_QUAD_LANE_STATE
+  double rho_v = row_put<LN_THETA>(0.0, 1.0), alpha_v = 0.0;
+#endif
   if (valid) {
+#if !GDMIX_QUAD_LANE_STATE
     scal[SC_FOLD] = 0.0; scal[SC_GDOLD] = 0.0; scal[SC_THETA] = 1.0;
+#endif
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
       const int j = gl + G * s;
@@ -583,8 +707,14 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
         // kernels waits for: the 15 stores alone were 2 % of the C2 step.
         int task = LS_CONV;
         {
+#if GDMIX_QUAD_LANE_STATE
+          // finit, ginit of the search are f_old, g'd_old of the iteration; gtest = ftol * ginit (dcsrch_start): same bits
+          const double ginit = row_get<LN_GDOLD>(rho_v);
+          const bool conv = dcsrch_converged(row_get<LN_FOLD>(rho_v), LS_FTOL * ginit, ginit, f, gd, stp);
+#else
           const LineSearch* const lsp = L.ls();
           const bool conv = dcsrch_converged(lsp->finit, lsp->gtest, lsp->ginit, f, gd, stp);
+#endif
           if (__any(!conv)) {
             if (!conv) {
               LineSearch LS = *L.ls();
@@ -609,7 +739,11 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
           // ---- NEW_X: scipy's python loop first (nit / maxiter / maxfun), then mainlb's own tests ---
           ++nit;
           iter0 = false;
+#if GDMIX_QUAD_LANE_STATE
+          const double fold = row_get<LN_FOLD>(rho_v);
+#else
           const double fold = scal[SC_FOLD];
+#endif
           const double dmx = fmax(fabs(fold), fmax(fabs(f), 1.0));
           if (nit >= o.max_iter) status = 2;
           else if (nfev > o.maxfun) status = 3;
@@ -617,14 +751,25 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
           else if (fold - f <= o.ftol * dmx) status = 1;
           else {
             need_dir = true;
+#if GDMIX_QUAD_LANE_STATE
+            const double gdold = row_get<LN_GDOLD>(rho_v);
+#else
             const double gdold = scal[SC_GDOLD];
+#endif
             double dr, ddum;
             if (stp == 1.0) { dr = gd - gdold; ddum = -gdold; }
             else { dr = (gd - gdold) * stp; ddum = -gdold * stp; }
             if (dr > EPSMCH * ddum) {
               // push (s, y): the history shifts down by one, newest at KR-1
+#if GDMIX_QUAD_LANE_STATE
+              {
+                const double sh = dpp_row<0x101>(rho_v);   // row_shl:1: lane a <- lane a + 1
+                rho_v = __builtin_amdgcn_inverse_ballot_w64(0x01ff01ff01ff01ffull) ? sh : rho_v;
+              }
+#else
 #pragma unroll
               for (int a = 0; a < M_REG - 1; ++a) rho[a] = rho[a + 1];
+#endif
 #pragma unroll
               for (int a = 0; a < KR - 1; ++a) {
 #pragma unroll
@@ -636,8 +781,13 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
                 S[KR - 1][s] = stp * V.d[s];   // exact for stp == 1
                 Y[KR - 1][s] = V.g[s] - ((j < p) ? go[j] : 0.0);
               }
+#if GDMIX_QUAD_LANE_STATE
+              rho_v = row_put<M_REG - 1>(rho_v, 1.0 / dr);
+              rho_v = row_put<LN_THETA>(rho_v, rr / dr);
+#else
               rho[M_REG - 1] = 1.0 / dr;
               scal[SC_THETA] = rr / dr;
+#endif
               if (cnt < m) ++cnt;
             }
           }
@@ -652,10 +802,21 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
           const int j = gl + G * s;
           if (j < p) { V.x[s] = xo[j]; V.g[s] = go[j]; }
         }
+#if GDMIX_QUAD_LANE_STATE
+        f = row_get<LN_FOLD>(rho_v);
+#else
         f = scal[SC_FOLD];
+#endif
         restart = false;
         if (cnt == 0) { status = 4; need_dir = false; }
-        else { cnt = 0; scal[SC_THETA] = 1.0; }
+        else {
+          cnt = 0;
+#if GDMIX_QUAD_LANE_STATE
+          rho_v = row_put<LN_THETA>(rho_v, 1.0);
+#else
+          scal[SC_THETA] = 1.0;
+#endif
+        }
       }
       if (need_dir) {
 #pragma unroll
@@ -667,6 +828,43 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
       // exec save and a taken branch each, ~11 of 20 skipped at C2's mean history of 4.5 pairs).
       const int cmax = wave_max_nonneg_i32(need_dir ? cnt : 0);
       const int a0 = M_REG - cmax;
+#if GDMIX_QUAD_LANE_STATE
+#define QUAD_RHO(a) row_get<a>(rho_v)
+#define QUAD_ALPHA(a) row_get<a>(alpha_v)
+#define QUAD_SET_ALPHA(a, v) alpha_v = row_put<a>(alpha_v, v)
+#else
+#define QUAD_RHO(a) rho[a]
+#define QUAD_ALPHA(a) alpha[a]
+#define QUAD_SET_ALPHA(a, v) alpha[a] = (v)
+#endif
+      // GDMIX_QUAD_ZERO_STEPS (round 6): a row that does not use pair a takes the step with a zero multiplier instead of sitting it
+      // out under an exec mask — d - 0 * y is d (the stored pairs are finite), and the wave saves the exec save / branch / restore
+      // and the copies of d the compiler placed behind every masked region (three v_mov_b64 a step at EPL = 3).
+      // Measured (profiles/r06_c2_ab.txt): <32,3> alone 4.50 -> 4.52 ms, <16,4> 2.41 -> 2.77 ms (the compiler keeps more of d live: 70 -> 84
+      // spilled registers), step 9.04 -> 9.43 ms. Off.
+#ifndef GDMIX_QUAD_ZERO_STEPS
+#define GDMIX_QUAD_ZERO_STEPS 0
+#endif
+#if GDMIX_QUAD_ZERO_STEPS
+#define QUAD_FIRST_LOOP_STEP(a)                                                   \
+      {                                                                           \
+        if ((a) < a0) goto first_loop_done;                                       \
+        const bool use = need_dir && ((a) >= M_REG - cnt);                        \
+        double t = 0.0;                                                           \
+        _Pragma("unroll") for (int s = 0; s < EPL; ++s) t += S[a][s] * V.d[s];    \
+        const double nal = use ? -(QUAD_RHO(a) * grp_sum<G>(t, X)) : 0.0;         \
+        QUAD_SET_ALPHA(a, -nal);                                                  \
+        _Pragma("unroll") for (int s = 0; s < EPL; ++s) V.d[s] = fma(nal, Y[a][s], V.d[s]); \
+      }
+#define QUAD_SECOND_LOOP_STEP(a)                                                  \
+      {                                                                           \
+        const bool use = need_dir && ((a) >= M_REG - cnt);                        \
+        double t = 0.0;                                                           \
+        _Pragma("unroll") for (int s = 0; s < EPL; ++s) t += Y[a][s] * V.d[s];    \
+        const double c = use ? QUAD_ALPHA(a) - QUAD_RHO(a) * grp_sum<G>(t, X) : 0.0; \
+        _Pragma("unroll") for (int s = 0; s < EPL; ++s) V.d[s] += c * S[a][s];    \
+      }
+#else
 #define QUAD_FIRST_LOOP_STEP(a)                                                   \
       {                                                                           \
         if ((a) < a0) goto first_loop_done;                                       \
@@ -674,31 +872,38 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
         if (use) {                                                                \
           double t = 0.0;                                                         \
           _Pragma("unroll") for (int s = 0; s < EPL; ++s) t += S[a][s] * V.d[s];  \
-          const double al = rho[a] * grp_sum<G>(t, X);                            \
-          alpha[a] = al;                                                          \
+          const double al = QUAD_RHO(a) * grp_sum<G>(t, X);                       \
+          QUAD_SET_ALPHA(a, al);                                                  \
           _Pragma("unroll") for (int s = 0; s < EPL; ++s) V.d[s] -= al * Y[a][s]; \
         }                                                                         \
       }
+#endif
       static_assert(M_REG == 10, "the steps below are written out for ten pairs");
       QUAD_FIRST_LOOP_STEP(9) QUAD_FIRST_LOOP_STEP(8) QUAD_FIRST_LOOP_STEP(7) QUAD_FIRST_LOOP_STEP(6) QUAD_FIRST_LOOP_STEP(5)
       QUAD_FIRST_LOOP_STEP(4) QUAD_FIRST_LOOP_STEP(3) QUAD_FIRST_LOOP_STEP(2) QUAD_FIRST_LOOP_STEP(1) QUAD_FIRST_LOOP_STEP(0)
 #undef QUAD_FIRST_LOOP_STEP
     first_loop_done:;
       if (need_dir && cnt > 0) {
+#if GDMIX_QUAD_LANE_STATE
+        const double h0 = 1.0 / row_get<LN_THETA>(rho_v);
+#else
         const double h0 = 1.0 / scal[SC_THETA];
+#endif
 #pragma unroll
         for (int s = 0; s < EPL; ++s) V.d[s] *= h0;
       }
+#if !GDMIX_QUAD_ZERO_STEPS
 #define QUAD_SECOND_LOOP_STEP(a)                                                  \
       {                                                                           \
         const bool use = need_dir && ((a) >= M_REG - cnt);                        \
         if (use) {                                                                \
           double t = 0.0;                                                         \
           _Pragma("unroll") for (int s = 0; s < EPL; ++s) t += Y[a][s] * V.d[s];  \
-          const double c = alpha[a] - rho[a] * grp_sum<G>(t, X);                  \
+          const double c = QUAD_ALPHA(a) - QUAD_RHO(a) * grp_sum<G>(t, X);        \
           _Pragma("unroll") for (int s = 0; s < EPL; ++s) V.d[s] += c * S[a][s];  \
         }                                                                         \
       }
+#endif
       switch (a0) {
         case 0: QUAD_SECOND_LOOP_STEP(0) [[fallthrough]];
         case 1: QUAD_SECOND_LOOP_STEP(1) [[fallthrough]];
@@ -713,6 +918,9 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
         default: break;
       }
 #undef QUAD_SECOND_LOOP_STEP
+#undef QUAD_RHO
+#undef QUAD_ALPHA
+#undef QUAD_SET_ALPHA
       if (need_dir) {
         // z = x + d ; d = z - x (mainlb re-derives d from the subspace point); save x, g
         double dd = 0.0, gdp = 0.0;
@@ -729,8 +937,13 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
         }
         grp_sum2<G>(dd, gdp, X);
         gd = gdp;
+#if GDMIX_QUAD_LANE_STATE
+        rho_v = row_put<LN_GDOLD>(rho_v, gd);
+        rho_v = row_put<LN_FOLD>(rho_v, f);
+#else
         scal[SC_GDOLD] = gd;
         scal[SC_FOLD] = f;
+#endif
         if (gd >= 0.0) {
           restart = true;   // lnsrlb info = -4: stay in this loop
         } else {

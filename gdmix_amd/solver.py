@@ -68,7 +68,7 @@ class _Result(C.Structure):
 
 
 EXPORTED_SYMBOLS = (
-    "gdmix_re_abi_version", "gdmix_re_build_id", "gdmix_re_last_error", "gdmix_re_default_opts", "gdmix_re_create",
+    "gdmix_re_abi_version", "gdmix_re_build_id", "gdmix_re_grid_lock_acquire", "gdmix_re_grid_lock_release", "gdmix_re_grid_lock_stats", "gdmix_re_last_error", "gdmix_re_default_opts", "gdmix_re_create",
     "gdmix_re_destroy", "gdmix_re_pack_workspace_bytes", "gdmix_re_pack", "gdmix_re_set_defer_unique", "gdmix_re_pack_join", "gdmix_re_solve",
     "gdmix_re_solve_scratch_bytes", "gdmix_re_set_scratch", "gdmix_re_variance_full", "gdmix_re_set_wave_lds_limit", "gdmix_re_score",
     "gdmix_re_widen_workspace_bytes", "gdmix_re_widen", "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz", "gdmix_re_set_tall_min_n", "gdmix_re_set_tall_split_n", "gdmix_re_set_tall_team_n", "gdmix_re_set_spread",
@@ -101,6 +101,9 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     lib.gdmix_re_abi_version.restype = C.c_int
     lib.gdmix_re_build_id.restype = C.c_char_p
+    lib.gdmix_re_grid_lock_acquire.argtypes = [C.c_char_p]
+    lib.gdmix_re_grid_lock_release.argtypes = [C.c_char_p]
+    lib.gdmix_re_grid_lock_stats.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.gdmix_re_last_error.restype = C.c_char_p
     lib.gdmix_re_default_opts.argtypes = [C.POINTER(_Opts)]
     lib.gdmix_re_default_opts.restype = None

@@ -185,6 +185,17 @@ GDMIX_API int  gdmix_re_abi_version(void);
 GDMIX_API const char* gdmix_re_build_id(void);
 GDMIX_API const char* gdmix_re_last_error(void);
 
+/* (ABI 12) Two PROCESSES on one device — the reference starts num_of_consumers processes per worker
+ * (random_effect_lr_lbfgs_model.py:103,214-217) and TF_CONFIG may list more workers than the box has GPUs. The solver's persistent grids
+ * (team tiers, tall teams) need all their workgroups resident; two of them from two processes can starve each other. They are chained by a
+ * file lock per device (<GDMIX_RE_LOCK_DIR or /tmp>/gdmix_re_grid_<pci bus id>.lock, held while a process has such a grid in flight; a
+ * turnstile file keeps two processes alternating; GDMIX_RE_GRID_LOCK=0 turns it off). These three entry points are that lock for a named
+ * key, host only — what tests/test_grid_lock.py drives from several processes. acquire blocks until this process may launch (it counts:
+ * one release per acquire); stats returns how often the process took the file lock and how often a launch rode on a lock it already held. */
+GDMIX_API int gdmix_re_grid_lock_acquire(const char* key);
+GDMIX_API int gdmix_re_grid_lock_release(const char* key);
+GDMIX_API int gdmix_re_grid_lock_stats(const char* key, int64_t* takes, int64_t* rides);
+
 GDMIX_API int  gdmix_re_create(int hip_device, gdmix_re_ctx** out);
 GDMIX_API void gdmix_re_destroy(gdmix_re_ctx* ctx);
 

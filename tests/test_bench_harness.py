@@ -63,6 +63,21 @@ def test_short_line_of_a_full_default_run_fits_the_driver():
     sm = short["summary"]
     assert sm["fe_frac"] == pytest.approx(full["detail"]["fixed_effect_eval"]["frac_of_hbm_peak"], rel=1e-3)
     assert set(sm["proj8"]) >= {"ml20m_user_ms", "ml20m_movie_ms", "c5_ms"} and sm["c5share_ms"] > 0 and sm["cli_cold_eps"] > 0
+    # round 6's keys, grafted onto that result: where theta ends, the step with the copy to the host, the reference's
+    # quoted CPU rate, the Zipf fixed-effect shard and the [min, max] of every repeated host-bound leg
+    sp = {"median": 3.5e6, "min": 3.1e6, "max": 3.9e6, "runs": [3.1e6, 3.5e6, 3.9e6]}
+    full["detail"]["solve_to_host"] = {"ms_per_step": 19.25}
+    full["detail"]["fixed_effect_eval"]["zipf"] = {"frac_of_hbm_peak": 0.47, "ms_per_evaluation": 0.58}
+    full["detail"]["fixed_effect_eval"]["streamed_frac_of_hbm_peak"] = 0.455
+    full["detail"]["cli_end_to_end"]["cold_entities_per_s_spread"] = sp
+    full["detail"]["host_handover"]["entities_per_s_spread"] = sp
+    full["cpu_baseline"]["reference_quoted"] = {"value": 639, "unit": "entities/s/core", "source": "BASELINE.md section 3"}
+    full["config"]["step"] = "pack+solve, theta on device"
+    short = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    assert len(json.dumps(short)) < 4096
+    assert short["summary"]["solve_to_host_ms"] == 19.25 and short["summary"]["fe_zipf_frac"] == 0.47 and short["summary"]["fe_streamed_frac"] == 0.455
+    assert short["summary"]["host_legs_min_max"] == {"handover_eps": [3.1e6, 3.9e6], "cli_cold_eps": [3.1e6, 3.9e6]}
+    assert short["cpu_baseline"]["reference_quoted"]["value"] == 639 and short["config"]["step"].endswith("theta on device")
     # ... and whatever a run adds, the line stays short: optional parts go first
     full["config"]["workload"] = "x" * 5000
     full["cpu_baseline"]["sample"] = "y" * 5000
@@ -100,6 +115,8 @@ def test_gpus_flag_starts_that_many_ranks(tmp_path):
     assert [r["rank"] for r in ranks] == [0, 1]
     assert [r["device"] for r in ranks] == ([0, 0] if share else [0, 1])
     assert line["config"]["collective_backend"] == ("gloo" if share else "nccl")
+    # the short line the driver parses carries both (N > 1 stays one command away)
+    assert len(line["_short"]["config"]["rank_ms_per_step"]) == 2 and line["_short"]["config"]["collective_backend"] == ("gloo" if share else "nccl")
     assert all(r["entities"] == 20000 and r["converged_per_step"] == 20000 and r["ms_per_step"] > 0 for r in ranks)
     assert line["detail"]["converged_per_step"] == 40000
     assert abs(line["value"] - 40000 * line["steps"] / (line["ms_per_step"] * line["steps"] / 1e3)) < 1e-6 * line["value"]

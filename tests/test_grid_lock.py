@@ -1,0 +1,148 @@
+"""Two processes on one device (VERDICT r5 missing 3): the file lock that chains their persistent grids (csrc/re_api.hip: GridLock),
+driven through its host-only entry points from real processes. CPU only — no device is touched. What it must give:
+mutual exclusion between processes, riding along inside a process while nobody else waits, and alternation (no starvation) when
+somebody does. The reference's case: num_of_consumers processes per worker (random_effect_lr_lbfgs_model.py:103,214-217)."""
+import ctypes as C
+import multiprocessing as mp
+import os
+import time
+
+import pytest
+
+from gdmix_amd import build, solver
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    build.build_library()
+
+
+def _lib(lock_dir):
+    os.environ["GDMIX_RE_LOCK_DIR"] = lock_dir
+    return solver.load_library()
+
+
+def _stats(lib, key):
+    t, r = C.c_int64(), C.c_int64()
+    assert lib.gdmix_re_grid_lock_stats(key, C.byref(t), C.byref(r)) == 0
+    return t.value, r.value
+
+
+def _worker(lock_dir, key, rounds, hold_s, log_path, name, start):
+    lib = _lib(lock_dir)
+    start.wait()
+    with open(log_path, "a", buffering=1) as log:
+        for _ in range(rounds):
+            assert lib.gdmix_re_grid_lock_acquire(key) == 0
+            log.write(f"{name} in {time.monotonic():.6f}\n")
+            time.sleep(hold_s)
+            log.write(f"{name} out {time.monotonic():.6f}\n")
+            assert lib.gdmix_re_grid_lock_release(key) == 0
+
+
+def _intervals(log_path):
+    ins, out = {}, []
+    for ln in open(log_path):
+        who, what, t = ln.split()
+        if what == "in":
+            ins[who] = float(t)
+        else:
+            out.append((who, ins.pop(who), float(t)))
+    return sorted(out, key=lambda x: x[1])
+
+
+def test_two_processes_never_hold_the_lock_together_and_both_get_their_turns(tmp_path):
+    ctx = mp.get_context("spawn")
+    log = str(tmp_path / "log.txt")
+    start = ctx.Barrier(2)
+    ps = [ctx.Process(target=_worker, args=(str(tmp_path), b"0000:0c:00.0", 25, 0.004, log, n, start)) for n in ("A", "B")]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    iv = _intervals(log)
+    assert len(iv) == 50
+    for (w0, a0, b0), (w1, a1, b1) in zip(iv, iv[1:]):
+        assert a1 >= b0 - 1e-4, (w0, a0, b0, w1, a1, b1)          # no overlap between holders
+    # neither process is starved: while both still have rounds left, no process gets more than a few turns in a row
+    first_done = min(max(i for i, x in enumerate(iv) if x[0] == w) for w in ("A", "B"))
+    run, longest = 1, 1
+    for i in range(1, first_done + 1):
+        run = run + 1 if iv[i][0] == iv[i - 1][0] else 1
+        longest = max(longest, run)
+    assert longest <= 4, [x[0] for x in iv]
+
+
+def test_inside_one_process_launches_ride_on_the_held_lock(tmp_path):
+    lib = _lib(str(tmp_path))
+    key = b"ride-test"
+    t0, r0 = _stats(lib, key)
+    for _ in range(3):
+        assert lib.gdmix_re_grid_lock_acquire(key) == 0            # three grids in flight at once: one file lock
+    assert _stats(lib, key) == (t0 + 1, r0 + 2)
+    for _ in range(3):
+        assert lib.gdmix_re_grid_lock_release(key) == 0
+    assert lib.gdmix_re_grid_lock_acquire(key) == 0                # all gone: the next launch takes it again
+    assert _stats(lib, key) == (t0 + 2, r0 + 2)
+    assert lib.gdmix_re_grid_lock_release(key) == 0
+    assert lib.gdmix_re_grid_lock_release(key) == 0                # an unmatched release is ignored
+
+
+def _holder(lock_dir, key, acquired, go_on, about_to=None):
+    lib = _lib(lock_dir)
+    if about_to is not None:
+        about_to.set()
+    assert lib.gdmix_re_grid_lock_acquire(key) == 0
+    acquired.set()
+    go_on.wait(60)
+    assert lib.gdmix_re_grid_lock_release(key) == 0
+
+
+def test_a_waiter_stops_the_holder_from_riding_on(tmp_path):
+    """A holds the lock; B waits at the turnstile; a second launch of A must NOT ride along (it would starve B): it queues behind B."""
+    import threading
+    ctx = mp.get_context("spawn")
+    key = b"fair-test"
+    lib = _lib(str(tmp_path))
+    assert lib.gdmix_re_grid_lock_acquire(key) == 0                # this process = A, one grid in flight
+    acquired, go_on, about_to = ctx.Event(), ctx.Event(), ctx.Event()
+    b = ctx.Process(target=_holder, args=(str(tmp_path), key, acquired, go_on, about_to))
+    b.start()
+    assert about_to.wait(120)
+    time.sleep(0.5)                                                # B is at the turnstile now (it cannot have the lock: A holds it)
+    assert not acquired.is_set()
+    second = {}
+
+    def launch_again():
+        assert lib.gdmix_re_grid_lock_acquire(key) == 0
+        second["t"] = time.monotonic()
+        assert lib.gdmix_re_grid_lock_release(key) == 0
+    th = threading.Thread(target=launch_again)
+    th.start()
+    time.sleep(0.3)
+    assert "t" not in second                                       # A's second launch waits although A holds the lock
+    t_release = time.monotonic()
+    assert lib.gdmix_re_grid_lock_release(key) == 0                # A's first grid is done
+    assert acquired.wait(30)                                       # B gets its turn ...
+    assert "t" not in second                                       # ... before A's second launch
+    go_on.set()
+    th.join(30)
+    b.join(30)
+    assert b.exitcode == 0 and second["t"] > t_release
+
+
+def test_a_killed_holder_does_not_keep_the_lock(tmp_path):
+    ctx = mp.get_context("spawn")
+    key = b"kill-test"
+    acquired, go_on = ctx.Event(), ctx.Event()
+    b = ctx.Process(target=_holder, args=(str(tmp_path), key, acquired, go_on))
+    b.start()
+    assert acquired.wait(30)
+    b.kill()
+    b.join(30)
+    lib = _lib(str(tmp_path))
+    t = time.monotonic()
+    assert lib.gdmix_re_grid_lock_acquire(key) == 0                # the kernel dropped the dead process's flock
+    assert time.monotonic() - t < 5
+    assert lib.gdmix_re_grid_lock_release(key) == 0

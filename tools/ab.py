@@ -109,11 +109,12 @@ def main():
                     with open(detail) as fh:
                         d = json.load(fh)
                     vals = [pick(d, f) for f in fields]
+                    ident = pick(d, "config.library.flags_id")
                     cls = ""
                     if a.class_ms_above >= 0 and pick(d, "detail.class_ms"):
                         cls = "  classes " + str([round(x, 3) for x in d["detail"]["class_ms"] if x > a.class_ms_above])
                     print(f"{w:12s} {tag}: " + "  ".join(f"{f.split('.')[-1]} {v:.4g}" if isinstance(v, (int, float)) else f"{f.split('.')[-1]} {v}"
-                                                        for f, v in zip(fields, vals)) + cls, flush=True)
+                                                        for f, v in zip(fields, vals)) + cls + (f"  flags {ident}" if ident else ""), flush=True)
                     if isinstance(vals[0], (int, float)):
                         key = (w, tag)
                         best[key] = min(best.get(key, float("inf")), vals[0])
