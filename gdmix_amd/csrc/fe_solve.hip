@@ -587,7 +587,11 @@ __device__ __forceinline__ void fe_step_body(const FeDev& F, const SolveParams& 
   CompactPlan plan;
   plan.action = CA_STOP; plan.col = S.col; plan.head = S.head; plan.stp = S.stp; plan.gamma = 1.0;
   const double f_new = F.fg[F.P] + 0.5 * o.l2 * acc[0];
-  compact_advance(S, acc, f_new, o, mats, plan);
+  // The data term is a sum of non-negative losses: - infinity is the mark a worker whose step was ABORTED leaves in its value slot
+  // (fe_tail_kernel's watchdog), and the all-reduce has carried it to every worker — all of them stop in the same evaluation, none
+  // is left alone in a collective (fixed_effect.run_stepping_loop raises on every worker).
+  if (F.fg[F.P] == -__builtin_inf()) S.status = GDMIX_RE_ST_ABORTED_PEER;
+  else compact_advance(S, acc, f_new, o, mats, plan);
   __syncthreads();
   {
     double* dst = reinterpret_cast<double*>(F.mats);
@@ -634,7 +638,7 @@ __device__ __forceinline__ void fe_update_one(const FeDev& F, const CompactPlan&
 // relaxed agent atomics for ticket and stamp, one lane's agent-scope acquire, workgroup barrier, plain loads.
 // A stopped problem (status >= 0 from an earlier launch) makes this and every pass kernel return at once: the host may enqueue
 // evaluations ahead of the status it has read (gdmix_fe_step_async).
-struct FeSync { unsigned arrive, gen; };
+struct FeSync { unsigned arrive, gen, aborted; };      // aborted: sticky, set by a waiter whose watchdog fired (never cleared: the problem is dead)
 
 __global__ __launch_bounds__(FE_THREADS) void fe_tail_kernel(FeDev F, SolveParams o, int dot_blocks, int32_t* status_out, unsigned seq) {
   __shared__ double red[FE_WAVES][TEAM_K];
@@ -665,6 +669,12 @@ __global__ __launch_bounds__(FE_THREADS) void fe_tail_kernel(FeDev F, SolveParam
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wavefront: its part of the matrices is at the memory side
     __syncthreads();
     if (tid == 0) {
+      // a waiter of this launch gave up before this workgroup arrived: its ABORTED must survive the state / status this
+      // workgroup has just written — the coefficients of the workgroups that left are not updated, the fit is invalid
+      if (__hip_atomic_load(&F.sync->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __hip_atomic_store(reinterpret_cast<int*>(&F.state->status), GDMIX_RE_ST_ABORTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(status_out, (int32_t)GDMIX_RE_ST_ABORTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       __hip_atomic_store(&F.sync->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&F.sync->gen, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -681,6 +691,8 @@ __global__ __launch_bounds__(FE_THREADS) void fe_tail_kernel(FeDev F, SolveParam
           const uint64_t now = wall_clock64();
           if (t0 == 0) t0 = now;
           else if (now - t0 > 400000000ull) {   // 4 s at 100 MHz
+            __hip_atomic_store(&F.sync->aborted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // first: the last arriver reads it
+            F.fg[F.P] = -__builtin_inf();      // what this worker contributes to the next all-reduce: every worker stops (fe_step_body)
             __hip_atomic_store(reinterpret_cast<int*>(&F.state->status), GDMIX_RE_ST_ABORTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(status_out, (int32_t)GDMIX_RE_ST_ABORTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             timed_out = 1;

@@ -270,11 +270,16 @@ hipError_t launch_score(const BatchDev& B, int64_t E, int64_t N, int ic, const d
 
 // the caller's stream waits for a deferred compaction that is still outstanding (every entry point that reads unique_global, or that
 // reuses the workspace it is written from, calls this first; gdmix_re_solve calls it last)
+// Every stream that asks waits for the event until the compaction has actually FINISHED (the flag used to be cleared by the
+// first caller's wait, so a later reader on another stream was not ordered behind the kernel). A context is single-threaded by
+// contract (include/gdmix_re.h: "calls on one context must be serialised by the caller") — a PackedBatch dropped on another thread
+// is joined by solver.py under the solver's lock.
 inline hipError_t join_unique(gdmix_ctx_impl* ci, hipStream_t s) {
   if (!ci->unique_pending) return hipSuccess;
-  const hipError_t rc = hipStreamWaitEvent(s, ci->unique_ev, 0);
-  if (rc == hipSuccess) ci->unique_pending = false;
-  return rc;
+  const hipError_t q = hipEventQuery(ci->unique_ev);
+  if (q == hipSuccess) { ci->unique_pending = false; return hipSuccess; }
+  if (q != hipErrorNotReady) return q;
+  return hipStreamWaitEvent(s, ci->unique_ev, 0);
 }
 
 // pack (re_pack.hip)

@@ -158,6 +158,7 @@ def device_score(solver, row_nnz_ptr, col_global, val, offset, theta, num_featur
 
 
 ST_ABORTED = 9      # GDMIX_RE_ST_ABORTED
+ST_ABORTED_PEER = 10   # GDMIX_RE_ST_ABORTED_PEER: another worker's step was aborted (its mark came with the all-reduce)
 LOOKAHEAD = int(os.environ.get("GDMIX_FE_LOOKAHEAD", "2"))   # evaluations enqueued ahead of the status the host has read
 
 
@@ -269,10 +270,13 @@ def run_stepping_loop(problem, all_reduce=None, max_evals=100000, lookahead=None
     synchronous anyway: lookahead 0 unless all_reduce.device_ordered is set (RCCL on the device buffer)."""
     if lookahead is None:
         lookahead = LOOKAHEAD if (all_reduce is None or getattr(all_reduce, "device_ordered", False)) else 0
+    if not 0 <= int(lookahead) < FE_RING:      # the status ring of the library (gdmix_fe_step_status would fail mid-run, collectives queued)
+        raise ValueError(f"lookahead must be in 0..{FE_RING - 1}, not {lookahead}")
+    lookahead = int(lookahead)
     if all_reduce is None:
         status, _ = problem.solve(lookahead, max_evals)
-        if status == ST_ABORTED:
-            raise RuntimeError("the fixed-effect step gave up waiting for a workgroup of its own launch (status 9): the result is invalid")
+        if status in (ST_ABORTED, ST_ABORTED_PEER):
+            raise RuntimeError(f"the fixed-effect step gave up waiting for a workgroup of its own launch (status {status}): the result is invalid")
         if status >= 0:
             return status
         raise RuntimeError(f"the fixed-effect L-BFGS loop did not stop within {max_evals} evaluations")
@@ -284,7 +288,16 @@ def run_stepping_loop(problem, all_reduce=None, max_evals=100000, lookahead=None
         if k >= lookahead:
             status = problem.step_status(seq - lookahead)
             if status == ST_ABORTED:
-                raise RuntimeError("the fixed-effect step gave up waiting for a workgroup of its own launch (status 9): the result is invalid")
+                # The abort is a per-device timeout: the other workers have not seen it. This worker's value slot carries the mark
+                # (csrc/fe_solve.hip), the next all-reduce hands it to everybody and their step stops with the same status — one
+                # evaluation later, so this worker joins one more all-reduce before it raises: every worker has then enqueued the
+                # same number of collectives and none hangs in RCCL.
+                problem.eval()
+                all_reduce(buf)
+                raise RuntimeError("the fixed-effect step gave up waiting for a workgroup of its own launch (status 9): the result is invalid "
+                                   "(every worker stops in the same evaluation)")
+            if status == ST_ABORTED_PEER:      # one evaluation behind the worker it happened on: the collectives are even, nothing to add
+                raise RuntimeError("another worker's fixed-effect step was aborted (status 10): the result is invalid")
             if status >= 0:
                 return problem.step_status(seq)      # (the steps behind the stop are no-ops with the same status: nothing left in flight)
     raise RuntimeError(f"the fixed-effect L-BFGS loop did not stop within {max_evals} evaluations")
@@ -469,9 +482,13 @@ def _full_variances_several_workers(solver, packed, theta, D, has_intercept, l2,
     # the summed matrix and the factorisation's work area are ld x ld doubles each, the local matrix another one at most: refuse with a
     # clear message rather than die in an allocation after the whole training
     need = 3 * ld * ld * 8 + (1 << 28)
-    if solver.device.type == "cuda" and torch.cuda.mem_get_info(solver.device)[0] < need:
-        raise MemoryError(f"fixed_effect_variance_mode=FULL with {P} coefficients needs {need / 1e9:.1f} GB of free device memory "
-                          f"({torch.cuda.mem_get_info(solver.device)[0] / 1e9:.1f} GB free)")
+    if solver.device.type == "cuda":
+        # free = what the driver reports + what torch's caching allocator holds without using it (after a whole training run that can
+        # be most of the HBM: ADVICE r5 — the driver's figure alone refused allocations that would have succeeded)
+        free = torch.cuda.mem_get_info(solver.device)[0] + torch.cuda.memory_reserved(solver.device) - torch.cuda.memory_allocated(solver.device)
+        if free < need:
+            raise MemoryError(f"fixed_effect_variance_mode=FULL with {P} coefficients needs {need / 1e9:.1f} GB of free device memory "
+                              f"({free / 1e9:.1f} GB free)")
     Hg = torch.zeros((ld, ld), dtype=torch.float64, device=solver.device)
     if not dummy and p_l > 0:     # (a worker without data trains on one weight-0 sample: its curvature is exactly zero — nothing to build or scatter)
         local = to_local(theta, uniq, D, has_intercept, dummy)

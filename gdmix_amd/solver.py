@@ -336,6 +336,19 @@ class SolveResult:
         return out
 
 
+def _serialised(fn):
+    """Calls on one context must be serialised by the caller (include/gdmix_re.h). The owner thread does that by construction; the one
+    caller that is not the owner is a PackedBatch's destructor, which the garbage collector may run on any thread while the owner is
+    inside gdmix_re_pack with the interpreter lock released: every context call of the solver takes its re-entrant lock."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        with self._ctx_lock:
+            return fn(self, *a, **k)
+    return wrapper
+
+
 class REDeviceSolver:
     """One MI355X: pack, solve and score entity batches through the C ABI."""
 
@@ -352,6 +365,8 @@ class REDeviceSolver:
         torch.cuda.set_device(self.device)
         torch.zeros(1, device=self.device)  # force HIP context creation through torch's runtime
         h = C.c_void_p()
+        import threading
+        self._ctx_lock = threading.RLock()
         _check(self.lib.gdmix_re_create(self.device_index, C.byref(h)), "gdmix_re_create")
         self._h = h
         self._scratch = None
@@ -359,15 +374,18 @@ class REDeviceSolver:
         self._pack_gen = 0      # packs of this context so far: only the latest one's compaction can be outstanding
         self.set_defer_unique(os.environ.get("GDMIX_RE_DEFER_UNIQUE", "1") != "0")
 
+    @_serialised
     def set_defer_unique(self, enabled: bool):
         _check(self.lib.gdmix_re_set_defer_unique(self._h, int(bool(enabled))), "gdmix_re_set_defer_unique")
 
+    @_serialised
     def pack_join(self, stream=None):
         """A stream (default: the current one) waits for a pack's deferred compaction (PackedBatch.unique_global calls it; every
         library call that reads the array does so itself)."""
         if getattr(self, "_h", None):
             _check(self.lib.gdmix_re_pack_join(self._h, self._stream() if stream is None else stream), "gdmix_re_pack_join")
 
+    @_serialised
     def _pack_join_of(self, gen, pack_stream, dropping=False):
         # a batch older than the context's latest pack has been waited for already (gdmix_re_pack waits first): its accessor or its
         # destructor must not make the stream wait for the NEWER batch's compaction, which is meant to run next to that batch's solve.
@@ -376,6 +394,7 @@ class REDeviceSolver:
         if gen == self._pack_gen:
             self.pack_join(pack_stream if dropping else None)
 
+    @_serialised
     def close(self):
         if getattr(self, "_h", None):
             self.lib.gdmix_re_destroy(self._h)
@@ -503,6 +522,7 @@ class REDeviceSolver:
                 st[k] = t.empty(int(a.size * 1.25) + 1024, dtype=tdt, pin_memory=True)
         return st
 
+    @_serialised
     def widen(self, wd):
         """gdmix_re_widen: wire form (device tensors from upload_wire) -> the raw form gdmix_re_pack takes, on the device."""
         t = self.torch
@@ -526,6 +546,7 @@ class REDeviceSolver:
                   _keep=(ws, wd))
         return rd
 
+    @_serialised
     def pack(self, raw, has_intercept=True) -> PackedBatch:
         """raw: RawBatch (host) or the dict returned by upload() / widen() (device). A batch the reader narrowed (WireRawBatch) is uploaded
         in that form and widened on the device."""
@@ -557,6 +578,7 @@ class REDeviceSolver:
                     nit=t.empty(E, dtype=t.int32, device=dev), nfev=t.empty(E, dtype=t.int32, device=dev),
                     status=t.full((E,), -1, dtype=t.int32, device=dev))
 
+    @_serialised
     def solve(self, packed: PackedBatch, opts: Optional[SolverOptions] = None, theta0=None, out=None) -> SolveResult:
         t = self.torch
         opts = opts or SolverOptions()
@@ -583,6 +605,7 @@ class REDeviceSolver:
                                        self._stream()), "gdmix_re_solve")
         return SolveResult(tensors, packed.E, packed.P)
 
+    @_serialised
     def variance_full(self, packed: PackedBatch, opts: SolverOptions, theta):
         """diag of the inverse Hessian of every entity at theta ([P], local index space; numpy or device tensor) -> device tensor [P]."""
         t = self.torch
@@ -603,6 +626,7 @@ class REDeviceSolver:
         return out
 
     # ---- fixed effect, FULL variances with several workers (include/gdmix_fe.h) -----------------------
+    @_serialised
     def hessian_dense(self, packed: PackedBatch, theta_local, has_intercept=True):
         """X~' D X~ of a one-entity batch (a worker's shard) at theta_local (the shard's local order, intercept first) as a dense
         [ld, ld] device tensor, ld = p rounded up to 64; no regulariser."""
@@ -618,6 +642,7 @@ class REDeviceSolver:
                                                scratch.data_ptr(), nbytes, self._stream()), "gdmix_fe_hessian_dense")
         return H
 
+    @_serialised
     def variance_of_hessian(self, H, p, l2, unregularised_index=-1):
         """diag((H + (l2 + 1e-12) I - l2 e_u e_u')^-1)[0, p) of a summed curvature matrix H ([ld, ld] device tensor, overwritten)."""
         t = self.torch
@@ -636,6 +661,7 @@ class REDeviceSolver:
         return list(zip(names, cc[:NUM_CLASSES].tolist()))
 
     # ---- score -----------------------------------------------------------------------------------
+    @_serialised
     def score(self, packed: PackedBatch, theta, has_model=None):
         t = self.torch
         if isinstance(theta, np.ndarray):

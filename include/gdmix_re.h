@@ -60,6 +60,8 @@ extern "C" {
 #define GDMIX_RE_ST_MAXFUN    3   /* STOP: TOTAL NO. of f AND g EVALUATIONS EXCEEDS LIMIT    */
 #define GDMIX_RE_ST_ABNORMAL  4   /* ABNORMAL_TERMINATION_IN_LNSRCH                          */
 #define GDMIX_RE_ST_ABORTED   9   /* device-wide kernel gave up waiting at a barrier (never expected; the result is invalid) */
+#define GDMIX_RE_ST_ABORTED_PEER 10 /* fixed effect with several workers: ANOTHER worker's step was aborted; its mark came with the
+                                     * all-reduce and every worker stops in the same evaluation (the result is invalid) */
 /* "converged" for the entities/sec metric = status in {PGTOL, FACTR, MAXITER}: the reference treats
  * all three as a finished model (job_consumers.py:36-63 never looks at warnflag). */
 

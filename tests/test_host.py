@@ -578,3 +578,81 @@ def test_entity_id_listed_twice_is_scored_with_its_later_model(tmp_path):
     k0, k1 = int(b.row_nnz_ptr[0]), int(b.row_nnz_ptr[1])
     z = mean_a["(INTERCEPT)"] + sum(float(b.val[k]) * mean_a.get(f"f{int(b.col_global[k])}", 0.0) for k in range(k0, k1)) + float(b.offset[0])
     assert abs(cold[0]["predictionScore"] - z) < 1e-5 and n0 > 0
+
+
+# ---- the model's recovery paths (they had no test) -------------------------------------------------------------------
+
+def test_an_aborted_team_barrier_is_solved_again_without_the_tall_team_class_and_the_setting_comes_back():
+    """_pack_and_solve: GDMIX_RE_ST_ABORTED from a tall-team barrier -> the partition once more with every tall entity on one
+    workgroup (set_tall_team_n(0)), then the solver's own threshold again — also when the second solve raises."""
+    import types
+    from gdmix_amd.model import RandomEffectLRLBFGSModel as M
+    calls = []
+
+    class Solved:
+        def __init__(self, status):
+            self.status = status
+
+        def to_host(self, keys):
+            return {"status": np.array(self.status, np.int32), "theta_thr": np.zeros(3)}
+
+    class Solver:
+        tall_team_n = 16384
+
+        def set_tall_team_n(self, n):
+            calls.append(("set", n))
+            self.tall_team_n = n
+
+        def solve(self, packed, opts, theta0=None):
+            calls.append(("solve", self.tall_team_n))
+            return Solved([0, 9, 1] if self.tall_team_n else [0, 0, 1])
+    me = types.SimpleNamespace(ST_ABORTED=M.ST_ABORTED, _STAT_KEYS=M._STAT_KEYS)
+    packs = []
+    s = Solver()
+    packed, solved, res = M._pack_and_solve(me, s, lambda: packs.append(1) or "packed", None, None)
+    assert list(res["status"]) == [0, 0, 1] and len(packs) == 2
+    assert calls == [("solve", 16384), ("set", 0), ("solve", 0), ("set", 16384)] and s.tall_team_n == 16384
+    # a clean solve: one pack, nothing switched
+    calls.clear()
+    s2 = Solver()
+    s2.tall_team_n = 0          # the class is off (GDMIX_RE_TALL_TEAM=0): an ABORTED from a team TIER is not retried, the caller sees it
+    s2.solve = lambda packed, opts, theta0=None: Solved([9, 0, 0])
+    _, _, res = M._pack_and_solve(me, s2, lambda: "packed", None, None)
+    assert list(res["status"]) == [9, 0, 0] and calls == []
+    # the retry itself fails: the threshold is restored all the same
+    s3 = Solver()
+    n = {"solve": 0}
+
+    def flaky(packed, opts, theta0=None):
+        n["solve"] += 1
+        if n["solve"] == 2:
+            raise RuntimeError("device lost")
+        return Solved([9, 0, 0])
+    s3.solve = flaky
+    with pytest.raises(RuntimeError, match="device lost"):
+        M._pack_and_solve(me, s3, lambda: "packed", None, None)
+    assert s3.tall_team_n == 16384
+
+
+def test_partitions_with_and_without_weights_do_not_go_into_one_device_batch():
+    """_cat_wire: a group is one wire batch — partitions where only some carry a weight column cannot be one (the caller then solves
+    each on its own); widths are widened to the widest, counts add up."""
+    import torch
+    from gdmix_amd.model import RandomEffectLRLBFGSModel as M
+    from gdmix_amd.solver import REDeviceSolver
+
+    def wire(E, N, Z, col_dtype, weight):
+        w = {k: None for k in REDeviceSolver.WIRE_ARRAYS}
+        w.update(E=E, N=N, Z=Z, row_nnz_width=1, col_width=torch.empty(0, dtype=col_dtype).element_size(), y_width=1,
+                 ent_n=torch.full((E,), N // E, dtype=torch.int32), row_nnz=torch.ones(N, dtype=torch.uint8),
+                 col_global=torch.arange(Z, dtype=col_dtype), val=torch.ones(Z), y=torch.zeros(N, dtype=torch.uint8),
+                 offset=torch.zeros(N), weight=torch.ones(N) if weight else None)
+        return w
+    a, b = wire(2, 4, 4, torch.int16, True), wire(1, 3, 3, torch.int32, True)
+    cat = M._cat_wire(torch, [a, b])
+    assert (cat["E"], cat["N"], cat["Z"], cat["col_width"]) == (3, 7, 7, 4)
+    assert cat["col_global"].dtype == torch.int32 and cat["col_global"].tolist() == [0, 1, 2, 3, 0, 1, 2]
+    assert cat["weight"].numel() == 7
+    assert M._cat_wire(torch, [a, wire(1, 3, 3, torch.int32, False)]) is None
+    none = M._cat_wire(torch, [wire(2, 4, 4, torch.int16, False), wire(1, 3, 3, torch.int16, False)])
+    assert none is not None and none["weight"] is None
