@@ -159,6 +159,7 @@ def device_score(solver, row_nnz_ptr, col_global, val, offset, theta, num_featur
 
 ST_ABORTED = 9      # GDMIX_RE_ST_ABORTED
 ST_ABORTED_PEER = 10   # GDMIX_RE_ST_ABORTED_PEER: another worker's step was aborted (its mark came with the all-reduce)
+FE_RING = 8         # status ring of the library (csrc/fe_solve.hip: FE_RING): a status can be read at most FE_RING - 1 steps late
 LOOKAHEAD = int(os.environ.get("GDMIX_FE_LOOKAHEAD", "2"))   # evaluations enqueued ahead of the status the host has read
 
 
