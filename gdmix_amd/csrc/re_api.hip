@@ -66,6 +66,7 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_TALL_T, 0, "re_solve_tall_team_kernel<8> x4 p<=64"},
     {KIND_TALL_L, 0, "re_solve_tall_kernel<1> lean p<=64"},
     {KIND_TALL_S, 0, "re_solve_tall_kernel<1> p<=64"},
+    {KIND_TALL_M, 0, "re_solve_tall_kernel<4> p<=64"},
     {KIND_TALL, 0, "re_solve_tall_kernel<8> p<=64"},
     {KIND_BLOCK, 0, "re_solve_team_kernel workgroup"},
     {KIND_GRID, 0, "re_solve_team_kernel 128 teams"},
@@ -73,7 +74,7 @@ static const ClassDesc kClasses[GDMIX_RE_NUM_CLASSES] = {
     {KIND_GRID, 0, "re_solve_team_kernel 8 teams"},
     {KIND_GRID, 0, "re_solve_team_kernel device-wide"}};
 
-__global__ void class_base_kernel(int32_t* cc, int tall_adapt_limit, int tall_adapt_small, int tall_team_n, int tall_team_limit) {
+__global__ void class_base_kernel(int32_t* cc, int tall_adapt_limit, int tall_adapt_small, int tall_team_n, int tall_team_limit, int tall_mid_n) {
   // cc[0..NC) counts -> cc[NC..2NC) exclusive bases, cc[2NC..3NC) cursors = 0
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     // The split between the one-wavefront and the eight-wavefront tall kernels (4 096 samples by default: right for a batch with
@@ -111,6 +112,23 @@ __global__ void class_base_kernel(int32_t* cc, int tall_adapt_limit, int tall_ad
         }
     }
     ge[TALL_ADAPT_SLOT] = split;
+    // The mid class (four wavefronts per entity, two workgroups per CU) takes the largest one-wavefront entities BELOW the split: the
+    // lowest threshold of tall_mid_step() that keeps it within one round of its launch (-tall_mid_n workgroups), in a small batch only
+    // (same test as the split: a whole population is bound by throughput). tall_mid_n > 0: everything from that many samples on.
+    int mid_from = 0;
+    // entities of at least `split` samples have left the one-wavefront class (counted with the same rule: ge[k] of the chosen split)
+    const int gone = split > 0 ? ge[split == tall_adapt_n(0) ? 0 : (split == tall_adapt_n(1) ? 1 : 2)] : 0;
+    if (tall_mid_n > 0) {
+      const int cnt = (split > 0 && split <= tall_mid_n) ? 0 : ge[TALL_MID_GE] - gone;
+      if (cnt > 0) { mid_from = tall_mid_n; cc[TALL_M_CLASS] += cnt; cc[TALL_S_CLASS] -= cnt; }
+    } else if (tall_mid_n < 0 && cc[TALL_S_CLASS] <= tall_adapt_small) {
+      for (int k = 0; k < TALL_MID_STEPS && mid_from == 0; ++k) {
+        if (split > 0 && tall_mid_step(k) >= split) break;
+        const int cnt = ge[TALL_MID_GE + k] - gone;
+        if (cnt > 0 && cnt <= -tall_mid_n) { mid_from = tall_mid_step(k); cc[TALL_M_CLASS] += cnt; cc[TALL_S_CLASS] -= cnt; }
+      }
+    }
+    ge[TALL_MID_SLOT] = mid_from;
     int run = 0;
     for (int c = 0; c < GDMIX_RE_NUM_CLASSES; ++c) { cc[GDMIX_RE_NUM_CLASSES + c] = run; run += cc[c]; cc[2 * GDMIX_RE_NUM_CLASSES + c] = 0; }
   }
@@ -411,6 +429,7 @@ static bool class_is_small(int kind, int count, int num_cus) {
   long waves = count;                                   // wavefront kernels, one-wavefront tall variants
   if (kind == KIND_TALL_T) return true;                // at most one round of teams
   if (kind == KIND_TALL) waves = (long)count * 4 * TALL_NW / 8;   // one workgroup per CU: count < num_cus
+  if (kind == KIND_TALL_M) waves = (long)count * 8 / TALL_MID_WGS;   // two workgroups per CU
   else if (gl > 0) waves = gl >= WAVE ? (long)count * (gl / WAVE) : ((long)count * gl + WAVE - 1) / WAVE;
   return waves < (long)num_cus * 6;
 }
@@ -490,6 +509,9 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   // CUs, 64 teams held every CU for the length of their entity and the one-wavefront class waited (2.9 ms; 32: 2.25, 16: 2.29); since that
   // class may take 1.5 workgroups per CU and absorbs what the teams leave, 16 / 32 / 48 / 64: 2.38 / 1.98 / 1.98 / 1.85 - 1.90 ms.
   c->impl.tall_team_limit = c->impl.num_cus / 4 < TALL_TEAM_MAX ? c->impl.num_cus / 4 : TALL_TEAM_MAX;
+  // the mid class: chosen per batch, at most one round of its launch (two four-wavefront workgroups per CU)
+  c->impl.tall_mid_n = -(c->impl.num_cus * TALL_MID_WGS);
+  if (const char* e = getenv("GDMIX_RE_TALL_MID")) { if (atoi(e) == 0) c->impl.tall_mid_n = 0; else if (atoi(e) > 1) c->impl.tall_mid_n = -atoi(e); }   // A/B switch: 0 = off, n > 1 = the class's size limit
   // a team needs its TALL_TEAM_C workgroups resident at once, each with a whole CU's LDS, and a launch has eight teams at least
   // (one per XCD): a device (partition) with fewer CUs than that gets no team class at all — its members could never all be
   // placed and every run would end in the barrier's watchdog
@@ -676,6 +698,12 @@ GDMIX_API int gdmix_re_set_tall_team_n(gdmix_re_ctx* ctx, int team_n) {
   return GDMIX_RE_OK;
 }
 
+GDMIX_API int gdmix_re_set_tall_mid_n(gdmix_re_ctx* ctx, int mid_n) {
+  if (!ctx) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
+  ctx->impl.tall_mid_n = mid_n < 0 ? -(ctx->impl.num_cus * TALL_MID_WGS) : mid_n;
+  return GDMIX_RE_OK;
+}
+
 GDMIX_API int gdmix_re_set_tall_split_n(gdmix_re_ctx* ctx, int split_n) {
   if (!ctx || split_n < 0) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
   ctx->impl.tall_split_n = split_n > 0 ? split_n : GDMIX_RE_TALL_SPLIT_N_DEFAULT;
@@ -787,6 +815,8 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
     if (tab.tall_team_n > 0 && tab.tall_team_n < TALL_TEAM_MIN_N) tab.tall_team_n = TALL_TEAM_MIN_N;
     tab.tall_team_limit = tn > 0 ? ctx->impl.tall_team_limit : 0;
   }
+  // the mid class adapts with the split: a caller who pinned the split (gdmix_re_set_tall_split_n) pinned the routing — no per-batch class
+  tab.tall_mid_n = (ctx->impl.tall_mid_n < 0 && ctx->impl.tall_split_set) ? 0 : ctx->impl.tall_mid_n;
   if (opts->sum_loss || opts->linear) {
     // the fixed-effect objective lives in the team kernels only: every entity goes device-wide, one after another
     if (opts->m > TEAM_MCAP) { set_error("sum_loss / linear need m <= %d", TEAM_MCAP); return GDMIX_RE_EINVAL; }
@@ -797,7 +827,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
   int32_t* cc = b->class_count;
   HIP_TRY(hipMemsetAsync(cc, 0, 6 * GDMIX_RE_NUM_CLASSES * sizeof(int32_t), s));
   HIP_TRY(launch_classify(b, ic, opts->m, tab, b->cls_tmp, cc, s));
-  hipLaunchKernelGGL(class_base_kernel, dim3(1), dim3(1), 0, s, cc, tab.tall_adapt_limit, 16 * ctx->impl.num_cus, tab.tall_team_n, tab.tall_team_limit);
+  hipLaunchKernelGGL(class_base_kernel, dim3(1), dim3(1), 0, s, cc, tab.tall_adapt_limit, 16 * ctx->impl.num_cus, tab.tall_team_n, tab.tall_team_limit, tab.tall_mid_n);
   HIP_TRY(hipGetLastError());
   HIP_TRY(launch_order(b, b->cls_tmp, cc + GDMIX_RE_NUM_CLASSES, cc + 2 * GDMIX_RE_NUM_CLASSES, s));
   int32_t* hc = ctx->impl.host_pinned + 256;
@@ -886,10 +916,10 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
       if (c == TALL_L_CLASS && lean_merged) cnts[c] = 0;
       if (c == TALL_S_CLASS && lean_merged) { b0s[c] -= lean_merged; cnts[c] += lean_merged; }
     }
-    const int first[4] = {TALL_T_CLASS, TALL_CLASS, TALL_S_CLASS, TALL_L_CLASS};
-    for (int k = 0; k < 4 + BLOCK_CLASS; ++k) {
-      const int c = k < 4 ? first[k] : k - 4;
-      if (k >= 4 && (c == TALL_T_CLASS || c == TALL_CLASS || c == TALL_S_CLASS || c == TALL_L_CLASS)) continue;
+    const int first[5] = {TALL_T_CLASS, TALL_CLASS, TALL_M_CLASS, TALL_S_CLASS, TALL_L_CLASS};
+    for (int k = 0; k < 5 + BLOCK_CLASS; ++k) {
+      const int c = k < 5 ? first[k] : k - 5;
+      if (k >= 5 && (c == TALL_T_CLASS || c == TALL_CLASS || c == TALL_M_CLASS || c == TALL_S_CLASS || c == TALL_L_CLASS)) continue;
       if (cnts[c] <= 0) continue;
       const bool small = forked && class_is_small(kClasses[c].kind, cnts[c], ctx->impl.num_cus);
       any_large = any_large || !small;
@@ -912,6 +942,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
       int k_side = -1;
       if (c == TALL_CLASS) k_side = 1 % ns;
       else if (c == TALL_S_CLASS) k_side = 2 % ns;
+      else if (c == TALL_M_CLASS && !any_large) k_side = -1;      // the caller's stream, ahead of the group classes (three side streams: a fourth would share a hardware queue)
       else if (c == TALL_T_CLASS || c == TALL_L_CLASS || any_large) k_side = 0;
       if (k_side >= 0) { HIP_TRY(side_join.use(k_side)); s = ctx->impl.side[k_side]; }
     }
@@ -930,6 +961,7 @@ GDMIX_API int gdmix_re_solve(gdmix_re_ctx* ctx, const gdmix_re_packed* b, const 
       }
       case KIND_TALL_L: HIP_TRY(launch_solve_tall(TALL_VARIANT_LEAN, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_LEAN * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_LEAN, 0, s)); break;
       case KIND_TALL_S: HIP_TRY(launch_solve_tall(TALL_VARIANT_SMALL, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_SMALL * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_SMALL, lean_merged, s)); break;
+      case KIND_TALL_M: HIP_TRY(launch_solve_tall(TALL_VARIANT_MID, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_MID * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_MID, 0, s)); break;
       case KIND_TALL: HIP_TRY(launch_solve_tall(TALL_VARIANT_LARGE, B, O, P, theta0, b0, cnt, ctx->impl.num_cus, b->Z, static_cast<char*>(ctx->impl.grid_sync) + TEAM_MAX_TEAMS * sizeof(TeamSync) + TALL_VARIANT_LARGE * TALL_TAIL_BYTES, static_cast<TeamSync*>(ctx->impl.grid_sync) + TALL_VARIANT_LARGE, 0, s)); break;
       default: HIP_TRY(launch_solve_wave(B, O, P, theta0, b0, cnt, kClasses[c].lds, s)); break;
     }

@@ -25,7 +25,7 @@ namespace gdmix {
 // Each wavefront kind is split into LDS-footprint buckets so that small entities keep high occupancy.
 enum { KIND_WREG1 = 0, KIND_WREG2 = 1, KIND_WREG4 = 2, KIND_WLDS = 3, KIND_BLOCK = 4, KIND_QUAD2 = 5, KIND_QUAD4 = 6, KIND_PAIR4 = 7, KIND_QUAD3 = 8, KIND_PAIR3 = 9, KIND_WREG8 = 10,
        KIND_G64_3 = 11, KIND_G64_4 = 12, KIND_G128_4 = 13, KIND_G256_4 = 14, KIND_G512_4 = 15, KIND_GRID = 16, KIND_G128_3 = 17, KIND_G256_3 = 18,
-       KIND_TALL = 20, KIND_TALL_S = 21, KIND_TALL_L = 22, KIND_TALL_T = 23 };   // (19: the register team kernels of round 2, removed in round 3)
+       KIND_TALL = 20, KIND_TALL_S = 21, KIND_TALL_L = 22, KIND_TALL_T = 23, KIND_TALL_M = 24 };   // (19: the register team kernels of round 2, removed in round 3)
 
 // group kernels (several entities per wavefront): lanes per entity, coefficient slots per lane; 0 if not a group kind
 __host__ __device__ inline int group_lanes(int kind) {
@@ -41,9 +41,10 @@ constexpr int TEAM32_CLASS = GDMIX_RE_NUM_CLASSES - 3;   // 32 teams of 8 CUs
 constexpr int TEAM128_CLASS = GDMIX_RE_NUM_CLASSES - 4;  // 128 teams of 2 CUs
 constexpr int BLOCK_CLASS = GDMIX_RE_NUM_CLASSES - 5;
 constexpr int TALL_CLASS = BLOCK_CLASS - 1;      // tall entities of at least tall_split_n samples: one workgroup of TALL_NW wavefronts per CU
-constexpr int TALL_S_CLASS = BLOCK_CLASS - 2;    // smaller ones: workgroups of TALL_NW_SMALL wavefronts, several per CU
-constexpr int TALL_L_CLASS = BLOCK_CLASS - 3;    // ... and those that fit a twelfth of a CU's LDS: the lean variant, three wavefronts per SIMD
-constexpr int TALL_T_CLASS = BLOCK_CLASS - 4;    // the tallest of a batch: TALL_TEAM_C workgroups (CUs of one XCD) share one entity's samples
+constexpr int TALL_M_CLASS = BLOCK_CLASS - 2;    // (round 6) the largest of the smaller ones in a SMALL batch: workgroups of TALL_NW_MID wavefronts, two per CU
+constexpr int TALL_S_CLASS = BLOCK_CLASS - 3;    // smaller ones: workgroups of TALL_NW_SMALL wavefronts, several per CU
+constexpr int TALL_L_CLASS = BLOCK_CLASS - 4;    // ... and those that fit a twelfth of a CU's LDS: the lean variant, three wavefronts per SIMD
+constexpr int TALL_T_CLASS = BLOCK_CLASS - 5;    // the tallest of a batch: TALL_TEAM_C workgroups (CUs of one XCD) share one entity's samples
 constexpr int TALL_TEAM_C = 4;                   // workgroups per entity of that class (fixed: an entity's sums depend on the split)
 constexpr int TALL_TEAM_MAX = 64;                // teams per launch
 constexpr int TALL_TEAM_BYTES = 192 * 1024;      // device buffer of the context: the teams' exchange structures (re_solve_tall.hip)
@@ -53,6 +54,8 @@ constexpr int TALL_TEAM_MIN_N = 64;              // no team for fewer samples th
 #endif
 constexpr int TALL_NW = 8;
 constexpr int TALL_NW_SMALL = GDMIX_TALL_NW_SMALL;
+constexpr int TALL_NW_MID = 4;           // wavefronts of a mid workgroup,
+constexpr int TALL_MID_WGS = 2;          // of which a CU holds two (half its LDS each: an entity of ~1 800 MovieLens samples stays resident)
 constexpr int TALL_MAX_P = 64;      // coefficients (one per lane of the master wavefront)
 constexpr int TALL_LEAN_WAVES = 3;                    // lean variant: wavefronts per SIMD,
 constexpr int TALL_LEAN_WGS = 4 * TALL_LEAN_WAVES;    // one-wavefront workgroups per CU,
@@ -66,7 +69,7 @@ constexpr int TALL_LEAN_ARENA = (tall_lds_bytes(TALL_LEAN_WGS) - 1408) & ~15;   
 __host__ __device__ inline size_t tall_resident_bytes(int nw, int S, int d, int n, int nnz, bool has_w) {
   return (size_t)nw * (d + 1) * (S + 1) * 8 + (size_t)8 * (nnz + 8) + (size_t)4 * (n + 2) + (size_t)(has_w ? 12 : 8) * n + 16;
 }
-enum { TALL_VARIANT_LARGE = 0, TALL_VARIANT_SMALL = 1, TALL_VARIANT_LEAN = 2, TALL_VARIANT_TEAM = 3, TALL_VARIANTS = 4 };
+enum { TALL_VARIANT_LARGE = 0, TALL_VARIANT_SMALL = 1, TALL_VARIANT_LEAN = 2, TALL_VARIANT_TEAM = 3, TALL_VARIANT_MID = 4, TALL_VARIANTS = 5 };
 constexpr int BLOCK_NW = 4;   // wavefronts per workgroup of the block kernel
 #ifndef GDMIX_TEAM_BLOCK_NW
 #define GDMIX_TEAM_BLOCK_NW 8
@@ -88,6 +91,9 @@ struct ClassTable {
   int tall_team_n;        // > 0: tall entities of at least this many samples may get a team of workgroups (TALL_T_CLASS); 0 = never
   int tall_team_limit;    // > 0: the class takes the entities above the lowest of tall_team_n x {1, 2, 4} that keeps it within this many
                           // entities (class_base_kernel decides, re_order_kernel moves them); 0 = everything from tall_team_n on
+  int tall_mid_n;         // (round 6) > 0: one-wavefront tall entities of at least this many samples go to the mid class whatever the batch
+                          // holds (tests); 0: no mid class; < 0: chosen per batch, -tall_mid_n = the class's size limit (one round of its
+                          // launch): the lowest of tall_mid_step(k) samples that keeps the class within it, in a small batch only
 };
 // counts[3 * NUM_CLASSES + k], k = 0..2: one-wavefront tall entities (TALL_S_CLASS) with at least TALL_ADAPT_N[k] samples;
 // counts[3 * NUM_CLASSES + TALL_ADAPT_SLOT]: the split class_base_kernel chose (0: none). (The row's team-tier columns hold the tiers' largest entity.)
@@ -99,6 +105,17 @@ constexpr int TALL_ADAPT_SLOT = 3;
 constexpr int TALL_TEAM_STEPS = 3;
 constexpr int TALL_TEAM_GE = 4;
 constexpr int TALL_TEAM_SLOT = 7;
+// counts[3 * NUM_CLASSES + TALL_MID_GE + k], k = 0..5: one-wavefront tall entities (TALL_S_CLASS) with at least tall_mid_step(k) samples;
+// counts[3 * NUM_CLASSES + TALL_MID_SLOT]: the threshold class_base_kernel chose (0: no mid class in this batch).
+// Why a mid class (round 6): a share of a strongly scaled MovieLens job is as long as ONE wavefront needs for the
+// largest entity below the per-batch split — a 970-sample user x 49 evaluations, 25 - 40 us each, streamed (it does not fit the eighth
+// of a CU's LDS a one-wavefront workgroup has). On four wavefronts with half a CU's LDS the same entity is resident and an
+// evaluation is a pass of four samples per lane. Whole populations (thousands of such entities) are bound by throughput, where
+// one wavefront per entity is the better use of a CU: the class exists only in a batch small enough for the split to adapt too.
+constexpr int TALL_MID_STEPS = 6;
+__host__ __device__ constexpr int tall_mid_step(int k) { return k == 0 ? 256 : (k == 1 ? 384 : (k == 2 ? 512 : (k == 3 ? 768 : (k == 4 ? 1024 : 1536)))); }
+constexpr int TALL_MID_GE = 8;
+constexpr int TALL_MID_SLOT = 14;
 
 // Device pointers of a packed batch, passed by value to kernels.
 struct BatchDev {
@@ -146,6 +163,7 @@ struct gdmix_ctx_impl {
   int tall_split_set;     // gdmix_re_set_tall_split_n was called: the caller's split is kept, no per-batch adaptation (also when it is the default value)
   int tall_team_n;        // ClassTable::tall_team_n (gdmix_re_set_tall_team_n; GDMIX_RE_TALL_TEAM=0 switches the class off)
   int tall_team_limit;    // ClassTable::tall_team_limit: one round of teams on this device
+  int tall_mid_n;         // ClassTable::tall_mid_n (gdmix_re_set_tall_mid_n; GDMIX_RE_TALL_MID=0 switches the class off)
   int spread;             // > 1: large classes are dealt over this many queues (the caller's stream + side streams); 0: one after another
   void* grid_sync;        // device: TeamSync of the team kernels (the first three also: ticket counters of the tall variants), followed
                           // by TALL_TAIL_BYTES for each tall variant (four: the team variant last) and TALL_TEAM_BYTES

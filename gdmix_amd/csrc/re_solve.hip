@@ -19,10 +19,11 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
                                    const int64_t* __restrict__ ent_feat_ptr, int64_t E, int ic, int m, bool has_w,
                                    ClassTable tab, int32_t* __restrict__ cls_out, int32_t* __restrict__ counts) {
   __shared__ int32_t local[GDMIX_RE_NUM_CLASSES];
-  __shared__ int32_t tall_ge[TALL_ADAPT_STEPS], team_ge[TALL_TEAM_STEPS];
+  __shared__ int32_t tall_ge[TALL_ADAPT_STEPS], team_ge[TALL_TEAM_STEPS], mid_ge[TALL_MID_STEPS];
   if (threadIdx.x < GDMIX_RE_NUM_CLASSES) local[threadIdx.x] = 0;
   if (threadIdx.x < TALL_ADAPT_STEPS) tall_ge[threadIdx.x] = 0;
   if (threadIdx.x < TALL_TEAM_STEPS) team_ge[threadIdx.x] = 0;
+  if (threadIdx.x < TALL_MID_STEPS) mid_ge[threadIdx.x] = 0;
   __syncthreads();
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(ent_row_ptr[e + 1] - ent_row_ptr[e]);
@@ -58,6 +59,12 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
       for (int k = 0; k < TALL_ADAPT_STEPS; ++k)
         if (n >= tall_adapt_n(k)) atomicAdd(&tall_ge[k], 1);
     }
+    if (c == TALL_S_CLASS && tab.tall_mid_n < 0 && n >= tall_mid_step(0)) {      // candidates of the mid class (class_base_kernel decides)
+#pragma unroll
+      for (int k = 0; k < TALL_MID_STEPS; ++k)
+        if (n >= tall_mid_step(k)) atomicAdd(&mid_ge[k], 1);
+    }
+    if (c == TALL_S_CLASS && tab.tall_mid_n > 0 && n >= tab.tall_mid_n) atomicAdd(&mid_ge[0], 1);      // a fixed threshold: slot 0 counts them
     if (c == TALL_CLASS && tab.tall_team_n > 0 && n >= tab.tall_team_n) {   // candidates of the team class (class_base_kernel decides)
 #pragma unroll
       for (int k = 0; k < TALL_TEAM_STEPS; ++k)
@@ -73,6 +80,7 @@ __global__ void re_classify_kernel(const int64_t* __restrict__ ent_row_ptr, cons
   if (threadIdx.x < GDMIX_RE_NUM_CLASSES && local[threadIdx.x]) atomicAdd(&counts[threadIdx.x], local[threadIdx.x]);
   if (threadIdx.x < TALL_ADAPT_STEPS && tall_ge[threadIdx.x]) atomicAdd(&counts[3 * GDMIX_RE_NUM_CLASSES + threadIdx.x], tall_ge[threadIdx.x]);
   if (threadIdx.x < TALL_TEAM_STEPS && team_ge[threadIdx.x]) atomicAdd(&counts[3 * GDMIX_RE_NUM_CLASSES + TALL_TEAM_GE + threadIdx.x], team_ge[threadIdx.x]);
+  if (threadIdx.x < TALL_MID_STEPS && mid_ge[threadIdx.x]) atomicAdd(&counts[3 * GDMIX_RE_NUM_CLASSES + TALL_MID_GE + threadIdx.x], mid_ge[threadIdx.x]);
 }
 
 // order[class_base[c] + k] = e. Position inside a class is by ticket: the launch order inside a class
@@ -88,6 +96,7 @@ __global__ __launch_bounds__(256) void re_order_kernel(int32_t* __restrict__ cls
   __shared__ int32_t cnt[GDMIX_RE_NUM_CLASSES], base[GDMIX_RE_NUM_CLASSES];
   const int split = *split_dev;
   const int team_from = split_dev[TALL_TEAM_SLOT - TALL_ADAPT_SLOT];   // > 0: eight-wavefront tall entities of at least this many samples get a team
+  const int mid_from = split_dev[TALL_MID_SLOT - TALL_ADAPT_SLOT];     // > 0: one-wavefront tall entities of at least this many samples (below the split) go to the mid class
   const int64_t chunk = (int64_t)blockDim.x * 8;
   for (int64_t start = (int64_t)blockIdx.x * chunk; start < E; start += (int64_t)gridDim.x * chunk) {
     if (threadIdx.x < GDMIX_RE_NUM_CLASSES) cnt[threadIdx.x] = 0;
@@ -99,6 +108,7 @@ __global__ __launch_bounds__(256) void re_order_kernel(int32_t* __restrict__ cls
       c[k] = (e < E) ? cls[e] : -1;
       if (split > 0 && c[k] == TALL_S_CLASS && ent_row_ptr[e + 1] - ent_row_ptr[e] >= split) { c[k] = TALL_CLASS; cls[e] = TALL_CLASS; }
       else if (team_from > 0 && c[k] == TALL_CLASS && ent_row_ptr[e + 1] - ent_row_ptr[e] >= team_from) { c[k] = TALL_T_CLASS; cls[e] = TALL_T_CLASS; }
+      else if (mid_from > 0 && c[k] == TALL_S_CLASS && ent_row_ptr[e + 1] - ent_row_ptr[e] >= mid_from) { c[k] = TALL_M_CLASS; cls[e] = TALL_M_CLASS; }
       pos[k] = (c[k] >= 0) ? atomicAdd(&cnt[c[k]], 1) : 0;
     }
     __syncthreads();

@@ -19,7 +19,7 @@ from .batch import RawBatch, WireRawBatch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgdmix_re.so")
 
-NUM_CLASSES = 39
+NUM_CLASSES = 40
 STATUS_NAMES = ("PGTOL", "FACTR", "MAXITER", "MAXFUN", "ABNORMAL")
 VAR_NONE, VAR_SIMPLE, VAR_FULL = 0, 1, 2
 VARIANCE_MODES = {None: VAR_NONE, "simple": VAR_SIMPLE, "SIMPLE": VAR_SIMPLE, "full": VAR_FULL, "FULL": VAR_FULL,
@@ -71,7 +71,7 @@ EXPORTED_SYMBOLS = (
     "gdmix_re_abi_version", "gdmix_re_build_id", "gdmix_re_grid_lock_acquire", "gdmix_re_grid_lock_release", "gdmix_re_grid_lock_stats", "gdmix_re_last_error", "gdmix_re_default_opts", "gdmix_re_create",
     "gdmix_re_destroy", "gdmix_re_pack_workspace_bytes", "gdmix_re_pack", "gdmix_re_set_defer_unique", "gdmix_re_pack_join", "gdmix_re_solve",
     "gdmix_re_solve_scratch_bytes", "gdmix_re_set_scratch", "gdmix_re_variance_full", "gdmix_re_set_wave_lds_limit", "gdmix_re_score",
-    "gdmix_re_widen_workspace_bytes", "gdmix_re_widen", "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz", "gdmix_re_set_tall_min_n", "gdmix_re_set_tall_split_n", "gdmix_re_set_tall_team_n", "gdmix_re_set_spread",
+    "gdmix_re_widen_workspace_bytes", "gdmix_re_widen", "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz", "gdmix_re_set_tall_min_n", "gdmix_re_set_tall_split_n", "gdmix_re_set_tall_team_n", "gdmix_re_set_tall_mid_n", "gdmix_re_set_spread",
     "gdmix_fe_create", "gdmix_fe_destroy", "gdmix_fe_eval", "gdmix_fe_reduce_buffer", "gdmix_fe_step", "gdmix_fe_step_async", "gdmix_fe_step_status", "gdmix_fe_solve", "gdmix_fe_result",
     "gdmix_fe_last_eval_ms", "gdmix_fe_stream_bytes", "gdmix_fe_score", "gdmix_fe_hessian_diag", "gdmix_fe_hessian_dense_scratch_bytes", "gdmix_fe_hessian_dense",
     "gdmix_fe_variance_of_hessian",
@@ -154,6 +154,7 @@ def load_library():
     lib.gdmix_re_set_tall_min_n.argtypes = [C.c_void_p, C.c_int]
     lib.gdmix_re_set_tall_split_n.argtypes = [C.c_void_p, C.c_int]
     lib.gdmix_re_set_tall_team_n.argtypes = [C.c_void_p, C.c_int]
+    lib.gdmix_re_set_tall_mid_n.argtypes = [C.c_void_p, C.c_int]
     lib.gdmix_re_set_spread.argtypes = [C.c_void_p, C.c_int]
     lib.gdmix_re_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.gdmix_re_last_solve_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -452,6 +453,11 @@ class REDeviceSolver:
         within one round of teams on the device; team_n < 0: every one of at least -team_n samples (tests); 0: never."""
         _check(self.lib.gdmix_re_set_tall_team_n(self._h, int(team_n)), "set_tall_team_n")
         self.tall_team_n = int(team_n)
+
+    def set_tall_mid_n(self, mid_n: int):
+        """The mid tall class (four wavefronts per entity, two workgroups per CU): mid_n < 0 per batch (default), > 0 every one-wavefront
+        tall entity of at least mid_n samples (tests), 0 never. gdmix_re_set_tall_mid_n."""
+        _check(self.lib.gdmix_re_set_tall_mid_n(self._h, int(mid_n)), "set_tall_mid_n")
 
     def set_spread(self, queues: int):
         """Large size classes are dealt over `queues` streams (the caller's + the context's side streams; default 4) so that their tails

@@ -499,3 +499,53 @@ def test_device_full_variance_beyond_the_host_limit(device_solver, regularize_bi
     want = np.diag(np.linalg.inv(H))
     np.testing.assert_allclose(info["variances"], want, rtol=1e-8)
     np.testing.assert_allclose(info["variances"][D - 40:D], 1.0 / (l2 + 1e-12), rtol=1e-12)
+
+
+# ---- the stepping loop's failure protocol, on stand-ins: no device ------------------------------------------------------
+
+class _StubProblem:
+    """What run_stepping_loop drives: statuses[k] is the status of step k (-1 = go on)."""
+
+    def __init__(self, statuses):
+        self.statuses, self.evals, self.steps = list(statuses), 0, 0
+
+    def reduce_tensor(self):
+        return "buf"
+
+    def eval(self):
+        self.evals += 1
+
+    def step_async(self):
+        self.steps += 1
+        return self.steps - 1
+
+    def step_status(self, seq):
+        return self.statuses[min(seq, len(self.statuses) - 1)]
+
+
+@pytest.mark.parametrize("lookahead", [0, 2])
+def test_every_worker_of_an_aborted_fit_enqueues_the_same_number_of_all_reduces(lookahead):
+    """Step k of worker A times out (status 9). Its value slot carries the mark, the NEXT all-reduce hands it to worker B, whose step
+    k + 1 stops with status 10. A joins one more all-reduce before it raises; B none: both have enqueued k + lookahead + 2, nobody is
+    left alone in a collective."""
+    from gdmix_amd import fixed_effect as fe
+    k = 3
+    counts = {}
+    for name, statuses in (("A", [-1] * k + [fe.ST_ABORTED]), ("B", [-1] * (k + 1) + [fe.ST_ABORTED_PEER])):
+        n = {"all_reduce": 0}
+
+        def all_reduce(buf):
+            n["all_reduce"] += 1
+        with pytest.raises(RuntimeError, match="aborted|gave up"):
+            fe.run_stepping_loop(_StubProblem(statuses), all_reduce=all_reduce, lookahead=lookahead)
+        counts[name] = n["all_reduce"]
+    assert counts["A"] == counts["B"] == k + lookahead + 2
+
+
+def test_a_lookahead_the_status_ring_cannot_hold_is_refused_before_the_first_collective():
+    from gdmix_amd import fixed_effect as fe
+    n = {"all_reduce": 0}
+    with pytest.raises(ValueError, match="lookahead"):
+        fe.run_stepping_loop(_StubProblem([0]), all_reduce=lambda b: n.__setitem__("all_reduce", n["all_reduce"] + 1), lookahead=fe.FE_RING)
+    assert n["all_reduce"] == 0
+    assert fe.run_stepping_loop(_StubProblem([-1, -1, 1]), all_reduce=lambda b: None, lookahead=fe.FE_RING - 1) == 1

@@ -57,7 +57,7 @@ def _check_pack(packed, pk, val):
 
 
 def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, giant_nnz=16777216, team_nnz=16384, tall_min_n=0,
-                       tall_split_n=None, tall_team_n=None):
+                       tall_split_n=None, tall_team_n=None, tall_mid_n=None):
     """tall_min_n: 0 keeps the tall kernel out of the way of the routing under test; None = the library's default."""
     b, opts, exp, _ = load_fixture(name)
     kw = opts_kwargs(opts)
@@ -74,9 +74,12 @@ def _solve_and_compare(device_solver, name, lds_limit=65536, kernel_mask=7, gian
         device_solver.set_tall_split_n(tall_split_n)
     if tall_team_n is not None:
         device_solver.set_tall_team_n(tall_team_n)
+    if tall_mid_n is not None:
+        device_solver.set_tall_mid_n(tall_mid_n)
     try:
         res = device_solver.solve(packed, SolverOptions(**kw), theta0=th0).to_host()
     finally:
+        device_solver.set_tall_mid_n(-1)
         device_solver.set_tall_split_n(0)
         device_solver.set_tall_team_n(device_solver.TALL_TEAM_N_DEFAULT)
         device_solver.set_wave_lds_limit(65536)
@@ -133,8 +136,27 @@ def test_tall_kernel_matches_reference_fixture(device_solver, name):
     counts, p, kw = _solve_and_compare(device_solver, name, tall_min_n=1)
     want = int((p <= 64).sum()) if kw["m"] <= 10 else 0
     got = (counts["re_solve_tall_kernel<8> p<=64"] + counts["re_solve_tall_kernel<1> p<=64"] + counts["re_solve_tall_kernel<1> lean p<=64"]
-           + counts["re_solve_tall_team_kernel<8> x4 p<=64"])     # (the one title above 8 192 samples of ml20m_per_movie_tall gets a team: round 4)
+           + counts["re_solve_tall_team_kernel<8> x4 p<=64"]      # (the one title above 8 192 samples of ml20m_per_movie_tall gets a team: round 4)
+           + counts["re_solve_tall_kernel<4> p<=64"])             # (round 6: the mid class, chosen per batch)
     assert got == want, (got, want)
+
+
+@pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "ref_dataset1", "c2_shipped_cfg", "c2_weights", "c2_no_intercept", "c2_maxiter1", "c2_m3",
+                                  "ragged", "ragged_variance_simple", "ml_per_user", "ml_per_movie", "warm_stage2", "tiny_entities_regbias",
+                                  "exit_factr_1e-7", "exit_hard_02", "exit_extreme_00", "exit_extreme_02", "ml20m_per_movie_tall", "ml20m_per_user_tall"])
+def test_tall_mid_kernel_matches_reference_fixture(device_solver, name):
+    """Round 6: the MID tall class (re_solve_tall_kernel<4>: four wavefronts per entity, two workgroups per CU, half a CU's LDS each).
+    Every entity with at most 64 coefficients that is not lean and has at least 8 samples through it (threshold 8; the split pinned at
+    its default so that nothing above moves away): same fixtures, same tolerances, same iteration counts."""
+    b = load_fixture(name)[0]
+    counts, p, kw = _solve_and_compare(device_solver, name, tall_min_n=1, tall_split_n=4096, tall_team_n=0, tall_mid_n=8)
+    n = b.ent_n()
+    tall = (p <= 64) if kw["m"] <= 10 else np.zeros_like(p, bool)
+    mid = counts["re_solve_tall_kernel<4> p<=64"]
+    assert mid + counts["re_solve_tall_kernel<1> lean p<=64"] + counts["re_solve_tall_kernel<1> p<=64"] == int((tall & (n < 4096)).sum())
+    assert counts["re_solve_tall_kernel<1> p<=64"] <= int((tall & (n < 8)).sum())      # what is left on one wavefront is below the threshold
+    if name.startswith("ml20m"):
+        assert mid > 0
 
 
 @pytest.mark.parametrize("name", ["ref_fixture_l2_0.1", "ref_dataset1", "c2_shipped_cfg", "c2_weights", "c2_no_intercept", "c2_maxiter1", "c2_m3",
@@ -182,7 +204,7 @@ def test_default_routing_reaches_only_these_classes(device_solver):
             res = device_solver.solve(packed, SolverOptions(l2=1.0, regularize_bias=False, m=m, max_iter=5))
             assert int((res.status < 0).sum().item()) == 0
             used[m] |= {name.split("<")[0].split(" ")[0] for name, c in device_solver.class_counts(packed) if c > 0}
-    assert len(device_solver.class_counts(packed)) == NUM_CLASSES == 39
+    assert len(device_solver.class_counts(packed)) == NUM_CLASSES == 40
     # (the 900 MovieLens-20M movies include titles above 8 192 samples: they get a team of workgroups since round 4)
     assert used[10] == {"re_solve_grp_kernel", "re_solve_tall_kernel", "re_solve_tall_team_kernel", "re_solve_team_kernel"}, used[10]
     assert used[12] == {"re_solve_wave_kernel", "re_solve_team_kernel"}, used[12]      # m > 10: the LDS wavefront kernel and the two-loop block kernel
@@ -912,13 +934,25 @@ def test_a_small_batch_lowers_the_tall_split_and_only_the_rounding_changes(devic
     assert cf[names[0]] == int((n >= 4097).sum()) and cf[names[0]] < 20
     moved = ca[names[0]] - cf[names[0]]
     assert moved > 20 and ca[names[0]] <= 384, (ca[names[0]], cf[names[0]])
-    assert ca[names[1]] == cf[names[1]] - moved and ca[names[2]] == cf[names[2]]
+    # round 6: of what stays below the split, the largest go to the MID class (four wavefronts, two workgroups per CU) — at most one
+    # round of its launch, from the lowest of its thresholds that fits; a pinned split (the fixed run) pins that choice too
+    mid_name = "re_solve_tall_kernel<4> p<=64"
+    assert cf[mid_name] == 0 and 0 < ca[mid_name] <= 512
+    assert ca[names[1]] + ca[mid_name] == cf[names[1]] - moved and ca[names[2]] == cf[names[2]]
     assert sum(ca.values()) == sum(cf.values()) == b.E
     # exactly the one-wavefront entities of at least the chosen split moved, and the split is one of the three candidates
     idx = {name: i for i, (name, _) in enumerate(device_solver.class_counts(packed))}
     went = (cls_a == idx[names[0]]) & (cls_f != idx[names[0]])
     assert int(went.sum()) == moved
-    assert [s for s in (512, 1024, 2048) if np.array_equal(went, (cls_f == idx[names[1]]) & (n >= s))], int(n[went].min())
+    split = [s for s in (512, 1024, 2048) if np.array_equal(went, (cls_f == idx[names[1]]) & (n >= s))]
+    assert split, int(n[went].min())
+    went_mid = cls_a == idx[mid_name]
+    steps = [t for t in (256, 384, 512, 768, 1024, 1536) if t < split[0]]
+    fits = [t for t in steps if np.array_equal(went_mid, (cls_f == idx[names[1]]) & (n >= t) & (n < split[0]))]
+    assert fits, (int(n[went_mid].min()), int(went_mid.sum()), split)
+    # ... the lowest that fits: the next lower threshold would have made the class larger than one round
+    lower = [t for t in steps if t < fits[0]]
+    assert all(int(((cls_f == idx[names[1]]) & (n >= t) & (n < split[0])).sum()) > 512 for t in lower)
     assert np.array_equal(adaptive["status"], fixed["status"])
     same_nit = adaptive["nit"] == fixed["nit"]
     assert same_nit.mean() > 0.97
