@@ -509,9 +509,13 @@ GDMIX_API int gdmix_re_create(int hip_device, gdmix_re_ctx** out) {
   // CUs, 64 teams held every CU for the length of their entity and the one-wavefront class waited (2.9 ms; 32: 2.25, 16: 2.29); since that
   // class may take 1.5 workgroups per CU and absorbs what the teams leave, 16 / 32 / 48 / 64: 2.38 / 1.98 / 1.98 / 1.85 - 1.90 ms.
   c->impl.tall_team_limit = c->impl.num_cus / 4 < TALL_TEAM_MAX ? c->impl.num_cus / 4 : TALL_TEAM_MAX;
-  // the mid class: chosen per batch, at most one round of its launch (two four-wavefront workgroups per CU)
-  c->impl.tall_mid_n = -(c->impl.num_cus * TALL_MID_WGS);
-  if (const char* e = getenv("GDMIX_RE_TALL_MID")) { if (atoi(e) == 0) c->impl.tall_mid_n = 0; else if (atoi(e) > 1) c->impl.tall_mid_n = -atoi(e); }   // A/B switch: 0 = off, n > 1 = the class's size limit
+  // The mid class (round 6) is OFF unless asked for (gdmix_re_set_tall_mid_n(ctx, -1), GDMIX_RE_TALL_MID=1): measured on the shares of a
+  // strongly scaled MovieLens-20M job it loses — per-user share 1.87 - 1.96 -> 2.24 - 2.26 ms, per-movie 1.69 - 1.74 -> 1.83 - 1.88 ms
+  // (profiles/r06_ml20m_mid.txt, with the timelines): the one-wavefront launch does not get shorter when its largest entities leave
+  // (1.25 -> 1.28 ms: it is bound by the throughput of the ~14 k small entities it also carries, eight per CU, not by its longest
+  // chain), and every mid workgroup takes half a CU's LDS away from four of them.
+  c->impl.tall_mid_n = 0;
+  if (const char* e = getenv("GDMIX_RE_TALL_MID")) { if (atoi(e) == 1) c->impl.tall_mid_n = -(c->impl.num_cus * TALL_MID_WGS); else if (atoi(e) > 1) c->impl.tall_mid_n = -atoi(e); }   // 1 = per batch, n > 1 = per batch with this size limit
   // a team needs its TALL_TEAM_C workgroups resident at once, each with a whole CU's LDS, and a launch has eight teams at least
   // (one per XCD): a device (partition) with fewer CUs than that gets no team class at all — its members could never all be
   // placed and every run would end in the barrier's watchdog

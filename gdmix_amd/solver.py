@@ -455,8 +455,8 @@ class REDeviceSolver:
         self.tall_team_n = int(team_n)
 
     def set_tall_mid_n(self, mid_n: int):
-        """The mid tall class (four wavefronts per entity, two workgroups per CU): mid_n < 0 per batch (default), > 0 every one-wavefront
-        tall entity of at least mid_n samples (tests), 0 never. gdmix_re_set_tall_mid_n."""
+        """The mid tall class (four wavefronts per entity, two workgroups per CU): mid_n < 0 per batch, > 0 every one-wavefront
+        tall entity of at least mid_n samples (tests), 0 never (the default: profiles/r06_ml20m_mid.txt). gdmix_re_set_tall_mid_n."""
         _check(self.lib.gdmix_re_set_tall_mid_n(self._h, int(mid_n)), "set_tall_mid_n")
 
     def set_spread(self, queues: int):

@@ -312,11 +312,13 @@ GDMIX_API int gdmix_re_set_tall_team_n(gdmix_re_ctx* ctx, int team_n);
 /* (ABI 12, GDMIX_RE_NUM_CLASSES 40) The MID tall class: in a SMALL batch (a share of a strongly scaled job) the largest one-wavefront tall
  * entities below the split get a workgroup of four wavefronts with half a CU's LDS (they stay resident there; on one wavefront they are
  * streamed, and the share lasts as long as that one wavefront's chain: random_effect_driver.py:60-68 splits the partitions over the
- * workers, BASELINE config 3). mid_n < 0 (default): chosen per batch on the device — the lowest of 256 / 384 / 512 / 768 / 1 024 / 1 536
+ * workers, BASELINE config 3). OFF by default: measured, it makes those shares slower (the one-wavefront launch is bound by the
+ * throughput of its many small entities, not by its longest chain, and a mid workgroup takes LDS away from four of them:
+ * profiles/r06_ml20m_mid.txt); kept, parity-tested, for devices where that balance differs. mid_n < 0: chosen per batch on the device — the lowest of 256 / 384 / 512 / 768 / 1 024 / 1 536
  * samples that keeps the class within one round of its launch (two workgroups per CU), only when the one-wavefront class is small and the
  * split is not pinned; mid_n > 0: every one-wavefront tall entity of at least mid_n samples, whatever the batch (tests); 0: never. Same
  * caveat as the teams: the kernel an entity gets depends on the batch, its sums are added in another order (agreement to rounding);
- * gdmix_re_set_tall_split_n(ctx, default) pins this choice too. GDMIX_RE_TALL_MID=0 in the environment switches the class off. */
+ * gdmix_re_set_tall_split_n(ctx, default) pins this choice too. GDMIX_RE_TALL_MID=1 in the environment switches the per-batch class on. */
 GDMIX_API int gdmix_re_set_tall_mid_n(gdmix_re_ctx* ctx, int mid_n);
 
 /* Launch schedule of a solve. Size classes too small to fill the device always run next to the others on the context's side streams
