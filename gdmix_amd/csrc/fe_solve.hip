@@ -97,7 +97,7 @@ struct FeDev {
   const int32_t* multi;     // [nmulti] row blocks cut into several units
   int nmulti, nred;         // nred = rc.nunit + nmulti * (workgroups of fe_rows_fix_kernel per block) entries of loss_part / rsum_part
   const float *y, *o, *w;   // w may be NULL
-  const int64_t* umap;      // [d] local -> global feature id
+  const int32_t* umap;      // [d] local -> global feature id
   double* xl;               // [d] x of the features present in this shard
   double* rs;               // [n] per-sample residual
   double* fg;               // [P + 1] global data gradient (intercept last), then the data value
@@ -735,7 +735,7 @@ __global__ void fe_init_kernel(FeDev F, const double* __restrict__ theta0) {
   }
   // the shard's local copy of the start point (afterwards the update keeps it current: fe_update_one)
   for (int jl = blockIdx.x * blockDim.x + threadIdx.x; jl < F.d; jl += gridDim.x * blockDim.x) {
-    const int64_t j = F.umap[jl];
+    const int64_t j = F.umap[jl];      // (widened: an index into the global coefficient space)
     F.xl[jl] = theta0 ? theta0[j] : 0.0;
     F.inv[j] = jl;
   }

@@ -622,7 +622,8 @@ __global__ __launch_bounds__(WAVE* NWAVES) void pack_entity_kernel(
 // A wavefront takes 64 consecutive entities: their pointers in one coalesced load (one entity per lane), then entity by entity
 // with the pointers broadcast from the lane that holds them, COMPACT_DEPTH entities' loads in flight before the first store (one
 // entity per trip with its pointers loaded inside the trip was three dependent memory latencies per entity: 0.31 ms on C2; four in
-// flight 0.21 ms: C2's entities have ~60 columns, 0.24 GB read + 0.48 GB written = 3.4 TB/s, what a copy of that shape reaches;
+// flight 0.21 ms: C2's entities have ~60 columns, 0.24 GB read + 0.48 GB written = 3.4 TB/s, what a copy of that shape reaches (round 6:
+// the output is int32 like the input — 0.24 GB written; the array was int64 for the host's convenience only);
 // eight in flight 0.31 ms, one entity per lane no better: profiles/r05_pack_ab.txt).
 #ifndef GDMIX_COMPACT_DEPTH
 #define GDMIX_COMPACT_DEPTH 4
@@ -631,7 +632,7 @@ constexpr int COMPACT_DEPTH = GDMIX_COMPACT_DEPTH;
 __global__ __launch_bounds__(256) void pack_compact_unique_kernel(const int64_t* __restrict__ ent_nnz_ptr,
                                                                    const int64_t* __restrict__ ent_feat_ptr, int64_t E,
                                                                    const int32_t* __restrict__ uniq_sparse,
-                                                                   int64_t* __restrict__ unique_global) {
+                                                                   int32_t* __restrict__ unique_global) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t e0 = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * WAVE; e0 < E; e0 += nwaves * WAVE) {
@@ -652,8 +653,8 @@ __global__ __launch_bounds__(256) void pack_compact_unique_kernel(const int64_t*
       }
 #pragma unroll
       for (int q = 0; q < COMPACT_DEPTH; ++q) {
-        if (lane < d[q]) unique_global[f0[q] + lane] = (int64_t)v[q];
-        for (int l = lane + WAVE; l < d[q]; l += WAVE) unique_global[f0[q] + l] = (int64_t)uniq_sparse[z0[q] + l];   // p > 64: rare here
+        if (lane < d[q]) unique_global[f0[q] + lane] = v[q];
+        for (int l = lane + WAVE; l < d[q]; l += WAVE) unique_global[f0[q] + l] = uniq_sparse[z0[q] + l];   // p > 64: rare here
       }
     }
   }
@@ -742,7 +743,7 @@ static PackLayout pack_layout(int64_t E, int64_t N, int64_t Z) {
   L.col_ptr = take((size_t)(Z + E + 1) * 4);
   L.csc_row = take((size_t)(Z + 1) * 4);
   L.csc_val = take((size_t)(Z + 1) * 4);
-  L.unique_global = take((size_t)(Z + 1) * 8);
+  L.unique_global = take((size_t)(Z + 1) * 4);      // int32 since ABI 12 (global feature indices are below 2^31: INTEGRATION.md)
   L.order = take((size_t)(E + 1) * 4);
   L.cls_tmp = take((size_t)(E + 1) * 4);
   L.d_cnt = take((size_t)(E + 1) * 4);
@@ -811,7 +812,7 @@ int pack_impl(gdmix_ctx_impl* ctx, const gdmix_re_raw_batch* raw, int has_interc
   out->col_ptr = reinterpret_cast<int32_t*>(base + L.col_ptr);
   out->csc_row = reinterpret_cast<int32_t*>(base + L.csc_row);
   out->csc_val = reinterpret_cast<float*>(base + L.csc_val);
-  out->unique_global = reinterpret_cast<int64_t*>(base + L.unique_global);
+  out->unique_global = reinterpret_cast<int32_t*>(base + L.unique_global);
   out->y = raw->y; out->offset = raw->offset; out->weight = raw->weight;
   out->order = reinterpret_cast<int32_t*>(base + L.order);
   out->class_count = reinterpret_cast<int32_t*>(base + L.class_count);

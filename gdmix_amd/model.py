@@ -32,6 +32,14 @@ logger.setLevel(logging.INFO)
 TrainingResult = namedtuple("TrainingResult", ("theta", "variance", "unique_global_indices"))
 
 
+def torch_int64():
+    """torch.int64 without importing torch at module import (the host tests run without a device). The device keeps a batch's local ->
+    global feature map as int32 (ABI 12); the host side of this file — model table, Avro writer, coefficient mapping — works on int64:
+    widened on the device before the copy (a 10 us kernel) rather than by numpy on the host (a few ms per partition)."""
+    import torch
+    return torch.int64
+
+
 _ROW_BITS = 40
 _ROW_MASK = (1 << _ROW_BITS) - 1
 WRITE_BEHIND_THREADS = int(os.environ.get("GDMIX_WRITE_THREADS", "8"))   # files being written at a time behind the device work
@@ -753,7 +761,7 @@ class RandomEffectLRLBFGSModel:
         self._check_statuses(res["status"], E)
         ic = 1 if self.has_intercept else 0
         feat_ptr = host_array(packed.ent_feat_ptr())
-        uniq = host_array(packed.unique_global())
+        uniq = host_array(packed.unique_global().to(torch_int64()))
         coef_ptr = feat_ptr + np.arange(E + 1, dtype=np.int64) * ic
         theta_thr, variance = res["theta_thr"], res.get("variance")
         e0 = n0 = 0
@@ -849,7 +857,7 @@ class RandomEffectLRLBFGSModel:
         else:
             packed = self._pack(solver, batch)
             feat_ptr = host_array(packed.ent_feat_ptr())
-            uniq = host_array(packed.unique_global())
+            uniq = host_array(packed.unique_global().to(torch_int64()))
             theta0 = self._start_point(model_weights, batch.entity_ids, uniq, feat_ptr, batch.E, num_features)
             first = [packed]
             packed = None
@@ -920,7 +928,7 @@ class RandomEffectLRLBFGSModel:
         else:
             if on_device:
                 packed = solver.pack(solver.widen(work), has_intercept=self.has_intercept)
-                fp_dev, uq_dev = packed.ent_feat_ptr(), packed.unique_global()
+                fp_dev, uq_dev = packed.ent_feat_ptr(), packed.unique_global().to(torch.int64)      # (the exchange's index columns are int64 on every rank)
             else:
                 packed = solver.pack(wire_to_raw(work), has_intercept=self.has_intercept)
                 fp_dev, uq_dev = as_t(packed.ent_feat_ptr().cpu().numpy(), torch.int64), as_t(packed.unique_global().cpu().numpy(), torch.int64)
@@ -1009,7 +1017,7 @@ class RandomEffectLRLBFGSModel:
             if packed is None:
                 packed = self._pack(solver, batch)
                 feat_ptr = host_array(packed.ent_feat_ptr())
-                uniq = host_array(packed.unique_global())
+                uniq = host_array(packed.unique_global().to(torch_int64()))
                 theta, has_model = _model_coefficients_for_batch(model_weights, batch.entity_ids, uniq, feat_ptr,
                                                                  self.has_intercept, num_features)
             logit, per_coord = solver.score(packed, theta, has_model)

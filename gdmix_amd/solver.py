@@ -249,7 +249,7 @@ class PackedBatch:
         import torch
         if self._join is not None:
             self._join()        # the compaction that writes it may still be running next to the solve (a no-op once waited for)
-        return self._view(self.c.unique_global, self.D, torch.int64)
+        return self._view(self.c.unique_global, self.D, torch.int32)      # int32 since ABI 12: half the bytes to compact, to copy and to keep
 
     def __del__(self):  # pragma: no cover
         # the workspace goes back to torch's allocator in the order of the current stream: that stream must be behind a deferred

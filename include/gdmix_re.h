@@ -129,7 +129,9 @@ typedef struct {
   int32_t*       col_ptr;       /* [Z+E] sparse: d_e + 1 entries at ent_nnz_ptr[e] + e */
   int32_t*       csc_row;       /* [Z]   entity-relative sample index */
   float*         csc_val;       /* [Z]   */
-  int64_t*       unique_global; /* [D]   (allocated Z) local -> global feature index */
+  int32_t*       unique_global; /* [D]   (allocated Z) local -> global feature index; int32 since ABI 12 (was int64: global feature
+                                 *       indices are below 2^31 on this path, and the array is written, copied to the host and read there
+                                 *       once per partition — half the bytes each time) */
   const float*   y;             /* [N]   */
   const float*   offset;        /* [N]   */
   const float*   weight;        /* [N] or NULL */

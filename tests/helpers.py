@@ -138,6 +138,9 @@ class _Arr:
     def cpu(self):
         return self
 
+    def to(self, dtype):      # (model.py widens the device's int32 feature map before the copy; the oracle's is int64 already)
+        return self
+
     def numpy(self):
         return self.a
 
