@@ -855,6 +855,26 @@ def compact_line(full, detail_file):
     return line
 
 
+def gpu_state():
+    """Clocks, power and temperature of device 0 as rocm-smi reports them at the end of the run (a per-movie step of
+    6.18 ms on the driver's box against 5.30 on the builder's had no explanation on record — the next such gap can be read against
+    the state of the box). Best effort: {} when the tool is missing or its output changes."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        out = subprocess.run([exe, "-d", "0", "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--json"], capture_output=True, text=True, timeout=20)
+        card = next(iter(json.loads(out.stdout).values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(w in kl for w in ("sclk", "mclk", "fclk", "power", "temperature (sensor junction)", "performance level")):
+                keep[k] = v
+        return keep
+    except Exception as e:  # noqa: BLE001
+        return {"unavailable": str(e)[:120]}
+
+
 def emit(full, a):
     """Write everything to the detail file and print the short line LAST on stdout (the only stdout line of the run)."""
     path = a.detail_file or DETAIL_DEFAULT
@@ -1257,6 +1277,7 @@ def main():
                        "classes": classes, "class_ms": [round(float(x) / a.steps, 3) for x in kernel_ms], "per_class": per_class,
                        "mean_nit": nit, "mean_nfev": nfev,
                        "converged_per_step": converged_all, "parity_classes": {"W": well_posed, "D": int(wl.E - well_posed)}, "N": wl.N, "Z": wl.Z, "P": packed.P,
+                       "gpu_state_at_end": gpu_state(),
                        "host_generate_s": t_gen, "solve_to_host": to_host, "host_handover": e2e, "score_pass": score, "fixed_effect_eval": fe_eval, "cli_end_to_end": cli_e2e,
                        "cli_subprocess": cli_sub, "cli_end_to_end_c5": cli_c5, "cli_end_to_end_ml20m_movie": cli_movie, "workloads": others, "c5_full_share": c5_full, "chain": chain_res,
                        "restreamed_bytes_per_step": b_stream,

@@ -82,11 +82,15 @@ def run_case(solver, seed, verbose=False):
     solver.set_tall_team_n(routing["tall_team"])
     if routing["tall_team"] < 0:
         solver.set_tall_split_n(64)
+    # round 6: the mid class of the tall kernels (four wavefronts per entity). A generator of its own again: off (the library's default), or
+    # every one-wavefront tall entity of at least 16 samples
+    routing["tall_mid"] = int(np.random.default_rng(seed ^ 0x3D1D).choice([0, 0, 16]))
+    solver.set_tall_mid_n(routing["tall_mid"])
     try:
         res = solver.solve(packed, SolverOptions(**kw), theta0=th0).to_host()
     finally:
         solver.set_giant_nnz(16777216); solver.set_team_nnz(16384); solver.set_kernel_mask(7); solver.set_tall_min_n(solver.TALL_MIN_N_DEFAULT)
-        solver.set_tall_team_n(solver.TALL_TEAM_N_DEFAULT); solver.set_tall_split_n(0)
+        solver.set_tall_team_n(solver.TALL_TEAM_N_DEFAULT); solver.set_tall_split_n(0); solver.set_tall_mid_n(0)
     o = oracle.make_opts(**kw)
     ref = oracle.solve(pk, b.val, b.y, b.offset, b.weight, o, theta0=th0)
     coef_ptr = packed.coef_ptr_host()
