@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/fe_prof.sh for a given shard shape: bash tools/fe_prof_args.sh <out dir> [fe_bench.py arguments]   e.g.  ... 4000000 32 100000 zipf
+# the fixed effect under rocprofv3 for a given shard shape: bash tools/fe_prof_args.sh <out dir> [fe_bench.py arguments]   e.g.  ... 4000000 32 100000 zipf
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export PYTHONPATH=. FE_BENCH_PATHS=stepping
 O=$1; shift
