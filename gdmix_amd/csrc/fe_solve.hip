@@ -103,7 +103,7 @@ struct FeDev {
   double* fg;               // [P + 1] global data gradient (intercept last), then the data value
   double *loss_part, *rsum_part;   // [nred]
   double* acc_part;         // [FE_DOT_BLOCKS][TEAM_K]
-  double* fin_part;         // [FE_FIN_BLOCKS][2]
+  double* fin_part;         // [FE_FIN_BLOCKS][3]: value hi, residual sum, value lo
   unsigned* fin_count;      // workgroups of fe_finish_kernel that have delivered their range sums
   int32_t* inv;             // [P] global coefficient -> local column of this shard, -1: absent (intercept: -1)
   struct FeSync* sync;      // ticket + generation stamp of fe_tail_kernel
@@ -369,12 +369,39 @@ __global__ __launch_bounds__(FE_THREADS) void fe_rows_fix_kernel(FeDev F, SolveP
   }
 }
 
+// ---- the data term's VALUE, added up error-free (round 6) ----------------------------------------------------------------------------
+// The value of a shard is a sum of millions of losses: f ~ 5e5 has an ulp of 5.8e-11, and a line search near the optimum asks for
+// decreases of that size (tools/fuzz_fe.py case 6100134: five features, 726 k samples, expected decrease of the fifth iteration
+// ~ 1.4 ulp). Added over a tree of fp64 sums the value carries a few ulps of noise, every trial of the search fails the
+// sufficient-decrease test and the fit ends ABNORMAL where scipy on an accurately summed objective (and the oracle, which adds in
+// long double) takes the step and stops on the projected gradient. The per-unit sums (<= 2 048 losses each) stay plain fp64; from
+// there on — the ranges of fe_finish_kernel, its wavefronts, the final 64 — the partial sums are (hi, lo) pairs combined with TwoSum,
+// rounded once at the end. A few dozen instructions in a kernel of 13 us; the gradient is not touched.
+__device__ __forceinline__ void dd_add(double& hi, double& lo, double x) {      // (hi, lo) += x, Knuth's TwoSum: no error term lost
+  const double s = hi + x, bb = s - hi;
+  lo += (hi - (s - bb)) + (x - bb);
+  hi = s;
+}
+__device__ __forceinline__ void dd_add2(double& hi, double& lo, double xh, double xl) { dd_add(hi, lo, xh); lo += xl; }
+// (hi, lo) of all 64 lanes -> lane 63 holds the total pair (the shift pattern of wave_sum; an invalid source reads 0)
+__device__ __forceinline__ void wave_sum_dd(double& hi, double& lo) {
+#define GDMIX_DD_STEP(CTRL, MASK)                                                     \
+  {                                                                                   \
+    const double oh = dpp_get0<CTRL, MASK>(hi), ol = dpp_get0<CTRL, MASK>(lo);        \
+    dd_add2(hi, lo, oh, ol);                                                          \
+  }
+  GDMIX_DD_STEP(0x111, 0xf) GDMIX_DD_STEP(0x112, 0xf) GDMIX_DD_STEP(0x114, 0xf) GDMIX_DD_STEP(0x118, 0xf) GDMIX_DD_STEP(0x142, 0xa) GDMIX_DD_STEP(0x143, 0xc)
+#undef GDMIX_DD_STEP
+  hi = readlane63(hi);
+  lo = readlane63(lo);
+}
+
 // local gradient (the column blocks' partial sums) into the global coefficient space; the first FE_FIN_BLOCKS workgroups also add
 // up a contiguous range of the per-unit value / residual sums each
 template <bool HESS = false>
 __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
   __shared__ double lds[FE_STRANDS][FE_RED_OUT];
-  __shared__ double red[2][FE_WAVES];
+  __shared__ double red[3][FE_WAVES];
   if (!HESS && F.state->status >= 0) return;
   const int tid = threadIdx.x, out = tid % FE_RED_OUT, strand = tid / FE_RED_OUT;
   const int j0 = blockIdx.x * FE_RED_OUT;
@@ -389,22 +416,23 @@ __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
   const int chunk = (F.nred + FE_FIN_BLOCKS - 1) / FE_FIN_BLOCKS;
   const int b0 = blockIdx.x * chunk;
   const int b1 = (b0 + chunk < F.nred) ? b0 + chunk : F.nred;
-  double a = 0.0, r = 0.0;
+  double a = 0.0, al = 0.0, r = 0.0;
   for (int b = b0 + tid; b < b1; b += FE_THREADS) {
-    a += F.loss_part[b];
+    dd_add(a, al, F.loss_part[b]);
     r += F.rsum_part[b];
   }
-  a = wave_sum(a);
+  wave_sum_dd(a, al);
   r = wave_sum(r);
-  if (lane == 0) { red[0][wv] = a; red[1][wv] = r; }
+  if (lane == 0) { red[0][wv] = a; red[1][wv] = r; red[2][wv] = al; }
   __syncthreads();
   __shared__ int last;
   if (tid == 0) {
-    double sa = red[0][0], sr = red[1][0];
+    double sa = red[0][0], sl = red[2][0], sr = red[1][0];
 #pragma unroll
-    for (int w = 1; w < FE_WAVES; ++w) { sa += red[0][w]; sr += red[1][w]; }
-    st_x<true>(F.fin_part + 2 * blockIdx.x, sa);
-    st_x<true>(F.fin_part + 2 * blockIdx.x + 1, sr);
+    for (int w = 1; w < FE_WAVES; ++w) { dd_add2(sa, sl, red[0][w], red[2][w]); sr += red[1][w]; }
+    st_x<true>(F.fin_part + 3 * blockIdx.x, sa);
+    st_x<true>(F.fin_part + 3 * blockIdx.x + 1, sr);
+    st_x<true>(F.fin_part + 3 * blockIdx.x + 2, sl);
     __threadfence();
     last = atomicAdd(F.fin_count, 1u) == FE_FIN_BLOCKS - 1;
   }
@@ -413,11 +441,12 @@ __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
   // intercept gradient (HESS: fg[D] = sum_i d_i, the intercept's entry; fg[P] unused)
   if (last && tid < WAVE) {
     __threadfence();
-    const double a = wave_sum(tid < FE_FIN_BLOCKS ? ld_x<true>(F.fin_part + 2 * tid) : 0.0);
-    const double r = wave_sum(tid < FE_FIN_BLOCKS ? ld_x<true>(F.fin_part + 2 * tid + 1) : 0.0);
+    double a = tid < FE_FIN_BLOCKS ? ld_x<true>(F.fin_part + 3 * tid) : 0.0, al = tid < FE_FIN_BLOCKS ? ld_x<true>(F.fin_part + 3 * tid + 2) : 0.0;
+    wave_sum_dd(a, al);
+    const double r = wave_sum(tid < FE_FIN_BLOCKS ? ld_x<true>(F.fin_part + 3 * tid + 1) : 0.0);
     if (tid == 0) {
       if (F.ic) F.fg[F.D] = r;
-      F.fg[F.P] = a;
+      F.fg[F.P] = a + al;      // rounded once
       *F.fin_count = 0u;
     }
   }
@@ -1352,7 +1381,7 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   const size_t o_xl = take((size_t)(F.d + 1) * 8), o_rs = take((size_t)(F.n + 1) * 8), o_fg = take((P + 1) * 8);
   const size_t o_pr = take((size_t)F.rc.nunit * FE_B * 8), o_pc = take((size_t)F.cc.nunit * FE_B * 8);
   const size_t o_multi = take((multi.size() + 1) * 4), o_red = take((size_t)F.nred * 2 * 8 + 16);
-  const size_t o_acc = take((size_t)FE_DOT_BLOCKS * TEAM_K * 8), o_fin = take((size_t)FE_FIN_BLOCKS * 2 * 8 + 64);
+  const size_t o_acc = take((size_t)FE_DOT_BLOCKS * TEAM_K * 8), o_fin = take((size_t)FE_FIN_BLOCKS * 3 * 8 + 64);
   const size_t o_state = take(sizeof(CompactState)), o_plan = take(sizeof(CompactPlan)), o_mats = take(sizeof(CompactMats));
   const size_t o_vec = take(((size_t)5 * P + compact_hist_doubles((int64_t)P, opts->m)) * 8 + 16), o_status = take(64);
   const size_t o_inv = take(P * 4), o_sync = take(sizeof(FeSync));
@@ -1375,7 +1404,7 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   F.loss_part = reinterpret_cast<double*>(base + o_red); F.rsum_part = F.loss_part + F.nred;
   F.acc_part = reinterpret_cast<double*>(base + o_acc);
   F.fin_part = reinterpret_cast<double*>(base + o_fin);
-  F.fin_count = reinterpret_cast<unsigned*>(base + o_fin + (size_t)FE_FIN_BLOCKS * 2 * 8);
+  F.fin_count = reinterpret_cast<unsigned*>(base + o_fin + (size_t)FE_FIN_BLOCKS * 3 * 8);
   F.state = reinterpret_cast<CompactState*>(base + o_state);
   F.plan = reinterpret_cast<CompactPlan*>(base + o_plan);
   F.mats = reinterpret_cast<CompactMats*>(base + o_mats);
