@@ -702,6 +702,11 @@ GDMIX_API int gdmix_re_set_tall_team_n(gdmix_re_ctx* ctx, int team_n) {
   return GDMIX_RE_OK;
 }
 
+GDMIX_API int gdmix_re_device_shared(gdmix_re_ctx* ctx) {
+  if (!ctx) { set_error("ctx is NULL"); return GDMIX_RE_EINVAL; }
+  return device_has_another_process(ctx->impl.device) ? 1 : 0;
+}
+
 GDMIX_API int gdmix_re_set_tall_mid_n(gdmix_re_ctx* ctx, int mid_n) {
   if (!ctx) { set_error("bad argument"); return GDMIX_RE_EINVAL; }
   ctx->impl.tall_mid_n = mid_n < 0 ? -(ctx->impl.num_cus * TALL_MID_WGS) : mid_n;

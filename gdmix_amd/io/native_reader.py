@@ -93,7 +93,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise GdmixIoError(f"{LIB_PATH} is missing: run `python -m gdmix_amd.build`")
     from .. import build as _build
-    stale = _build.check_library(LIB_PATH, _build.io_source_id(), "csrc/io_*.cpp")
+    stale = _build.check_library(LIB_PATH, _build.io_source_id, "csrc/io_*.cpp")
     if stale:
         raise GdmixIoError(stale)
     lib = C.CDLL(LIB_PATH)

@@ -68,7 +68,7 @@ class _Result(C.Structure):
 
 
 EXPORTED_SYMBOLS = (
-    "gdmix_re_abi_version", "gdmix_re_build_id", "gdmix_re_grid_lock_acquire", "gdmix_re_grid_lock_release", "gdmix_re_grid_lock_stats", "gdmix_re_last_error", "gdmix_re_default_opts", "gdmix_re_create",
+    "gdmix_re_abi_version", "gdmix_re_build_id", "gdmix_re_device_shared", "gdmix_re_grid_lock_acquire", "gdmix_re_grid_lock_release", "gdmix_re_grid_lock_stats", "gdmix_re_last_error", "gdmix_re_default_opts", "gdmix_re_create",
     "gdmix_re_destroy", "gdmix_re_pack_workspace_bytes", "gdmix_re_pack", "gdmix_re_set_defer_unique", "gdmix_re_pack_join", "gdmix_re_solve",
     "gdmix_re_solve_scratch_bytes", "gdmix_re_set_scratch", "gdmix_re_variance_full", "gdmix_re_set_wave_lds_limit", "gdmix_re_score",
     "gdmix_re_widen_workspace_bytes", "gdmix_re_widen", "gdmix_re_set_timing", "gdmix_re_last_solve_ms", "gdmix_re_set_kernel_mask", "gdmix_re_set_giant_nnz", "gdmix_re_set_team_nnz", "gdmix_re_set_tall_min_n", "gdmix_re_set_tall_split_n", "gdmix_re_set_tall_team_n", "gdmix_re_set_tall_mid_n", "gdmix_re_set_spread",
@@ -95,12 +95,13 @@ def load_library():
     except Exception:  # pragma: no cover - torch is always present in this image
         pass
     from . import build as _build
-    stale = _build.check_library(LIB_PATH, _build.source_id(), "csrc/*.hip, *.hpp")
+    stale = _build.check_library(LIB_PATH, _build.source_id, "csrc/*.hip, *.hpp")
     if stale:   # a prebuilt library that is not the build of the sources it travels with: every number it produced would be mislabelled
         raise GdmixReError(stale)
     lib = C.CDLL(LIB_PATH)
     lib.gdmix_re_abi_version.restype = C.c_int
     lib.gdmix_re_build_id.restype = C.c_char_p
+    lib.gdmix_re_device_shared.argtypes = [C.c_void_p]
     lib.gdmix_re_grid_lock_acquire.argtypes = [C.c_char_p]
     lib.gdmix_re_grid_lock_release.argtypes = [C.c_char_p]
     lib.gdmix_re_grid_lock_stats.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -453,6 +454,13 @@ class REDeviceSolver:
         within one round of teams on the device; team_n < 0: every one of at least -team_n samples (tests); 0: never."""
         _check(self.lib.gdmix_re_set_tall_team_n(self._h, int(team_n)), "set_tall_team_n")
         self.tall_team_n = int(team_n)
+
+    def device_shared(self) -> bool:
+        """Is another PROCESS present on this solver's device right now (gdmix_re_device_shared)?"""
+        rc = self.lib.gdmix_re_device_shared(self._h)
+        if rc < 0:
+            _check(rc, "gdmix_re_device_shared")
+        return bool(rc)
 
     def set_tall_mid_n(self, mid_n: int):
         """The mid tall class (four wavefronts per entity, two workgroups per CU): mid_n < 0 per batch, > 0 every one-wavefront

@@ -196,6 +196,10 @@ GDMIX_API const char* gdmix_re_last_error(void);
  * turnstile file keeps two processes alternating; GDMIX_RE_GRID_LOCK=0 turns it off). These three entry points are that lock for a named
  * key, host only — what tests/test_grid_lock.py drives from several processes. acquire blocks until this process may launch (it counts:
  * one release per acquire); stats returns how often the process took the file lock and how often a launch rode on a lock it already held. */
+/* 1 if ANOTHER process has a context on this context's device right now (each process holds a record lock on a per-device file from its
+ * first gdmix_re_create on; same directory and switch as above), 0 if not, < 0 on error. What gdmix_fe_create asks before it chooses the
+ * one-launch step (whose workgroups wait for each other: next to another process's persistent grid it takes the three-launch form). */
+GDMIX_API int gdmix_re_device_shared(gdmix_re_ctx* ctx);
 GDMIX_API int gdmix_re_grid_lock_acquire(const char* key);
 GDMIX_API int gdmix_re_grid_lock_release(const char* key);
 GDMIX_API int gdmix_re_grid_lock_stats(const char* key, int64_t* takes, int64_t* rides);

@@ -76,3 +76,45 @@ def test_two_cli_processes_share_cuda0_and_write_the_single_process_files(tmp_pa
             assert list(avro.read_file(os.path.join(d, f))) == want[f], (tag, f)
     # the lock files of the device exist: the chain was in use (GDMIX_RE_GRID_LOCK=0 would leave the directory empty)
     assert any(f.endswith(".lock") for f in os.listdir(lock_dir)) and any(f.endswith(".here") for f in os.listdir(lock_dir))
+
+
+def _present(dev, ready, go_on):
+    from gdmix_amd.solver import REDeviceSolver
+    s = REDeviceSolver(dev)
+    ready.set()
+    go_on.wait(120)
+    s.close()
+
+
+def test_a_second_process_on_the_device_is_seen_and_the_fixed_effect_takes_the_three_launch_step(tmp_path, monkeypatch):
+    """gdmix_re_device_shared: a child process with a context on cuda:0 is seen while it lives, and not after. While it is there a
+    fixed-effect fit takes the three-launch step (fe_tail_kernel's workgroups wait for each other: not next to another process's
+    persistent grid) — same bits as the one-launch step (the products are added over the same virtual blocks)."""
+    import multiprocessing as mp
+    from gdmix_amd import fixed_effect as fe
+    from gdmix_amd.solver import REDeviceSolver
+    monkeypatch.setenv("GDMIX_RE_LOCK_DIR", str(tmp_path))
+    monkeypatch.delenv("GDMIX_FE_FUSED_TAIL", raising=False)
+    rng = np.random.default_rng(5)
+    n, k, D = 20000, 6, 300
+    cols = rng.integers(0, D, n * k)
+    vals = rng.standard_normal(n * k).astype(np.float32)
+    y = (rng.random(n) < 0.4).astype(np.float32)
+    rp = np.arange(n + 1, dtype=np.int64) * k
+    dev = REDeviceSolver(0)
+    fes = fe.FixedEffectDeviceSolver(solver=dev)
+    assert not dev.device_shared()
+    alone, info_alone = fes.fit_stepping(rp, cols, vals, y, D, l2=1.0, max_iter=40)
+    ctx = mp.get_context("spawn")
+    ready, go_on = ctx.Event(), ctx.Event()
+    child = ctx.Process(target=_present, args=(0, ready, go_on))
+    child.start()
+    try:
+        assert ready.wait(300)
+        assert dev.device_shared()
+        shared, info_shared = fes.fit_stepping(rp, cols, vals, y, D, l2=1.0, max_iter=40)
+    finally:
+        go_on.set()
+        child.join(120)
+    assert child.exitcode == 0 and not dev.device_shared()
+    assert np.array_equal(alone, shared) and int(info_alone["nit"]) == int(info_shared["nit"]) and int(info_alone["status"]) == int(info_shared["status"])
