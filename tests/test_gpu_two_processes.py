@@ -93,7 +93,9 @@ def test_a_second_process_on_the_device_is_seen_and_the_fixed_effect_takes_the_t
     import multiprocessing as mp
     from gdmix_amd import fixed_effect as fe
     from gdmix_amd.solver import REDeviceSolver
-    monkeypatch.setenv("GDMIX_RE_LOCK_DIR", str(tmp_path))
+    # (the default lock directory: this process may have registered on the device under it in an earlier test, and the child must look
+    # in the same place)
+    monkeypatch.delenv("GDMIX_RE_LOCK_DIR", raising=False)
     monkeypatch.delenv("GDMIX_FE_FUSED_TAIL", raising=False)
     rng = np.random.default_rng(5)
     n, k, D = 20000, 6, 300
