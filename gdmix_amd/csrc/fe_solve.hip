@@ -79,7 +79,7 @@ struct FeCopy {
 // FE_HOT_MAX most frequent of them) get FE_HOT_REP accumulators each: in the column pass's copy an entry of frequent column h in
 // row r goes to the virtual column vbase + h * FE_HOT_REP + r % FE_HOT_REP. The virtual columns form one more block at the end
 // (entries by ascending row like every block: one sweep over the residuals for all of them), neighbouring rows land on different
-// accumulators, and fe_hot_finish_kernel adds a column's FE_HOT_REP sums in replica order. No atomics across workgroups, fixed shape.
+// accumulators, and fe_hot_finish_block (the last workgroups of fe_finish_kernel) adds a column's FE_HOT_REP sums in replica order. No atomics across workgroups, fixed shape.
 constexpr int FE_HOT_MAX = 64;
 constexpr int FE_HOT_REP = 32;
 static_assert(FE_HOT_MAX * FE_HOT_REP <= FE_B && FE_B % FE_HOT_REP == 0, "the virtual columns are one block");
@@ -396,6 +396,46 @@ __device__ __forceinline__ void wave_sum_dd(double& hi, double& lo) {
   lo = readlane63(lo);
 }
 
+// ---- frequent columns: FE_HOT_REP accumulators each (FeHot above) -------------------------------------------------------------
+// next to fe_finish_kernel's own workgroups (which find 0 for a frequent column — the copy holds no entry under its own number — and
+// write nothing then: the buffer is clear before an evaluation). One workgroup per
+// frequent column: replica r's sum over the virtual block's units by 8 strands, strands in order, then the replicas in order.
+// (Round 6: the workgroups of this step are the LAST F.hot.n workgroups of fe_finish_kernel's grid, not a launch of their own — one
+// launch boundary (~6 us on this device) and 10 us of a nearly empty device less per evaluation of a shard with frequent columns.)
+__device__ __forceinline__ void fe_hot_finish_block(const FeDev& F, int h) {
+  constexpr int STR = FE_THREADS / FE_HOT_REP;
+  __shared__ double lds[STR][FE_HOT_REP];
+  __shared__ double rep[FE_HOT_REP];
+  const FeHot& H = F.hot;
+  const int tid = threadIdx.x, r = tid % FE_HOT_REP, strand = tid / FE_HOT_REP;
+  const int b = H.vbase / FE_B, i = h * FE_HOT_REP + r;
+  const int u0 = F.cc.ufirst[b], u1 = F.cc.ufirst[b + 1];
+  const double* __restrict__ part = F.cc.part;
+  double t = 0.0;
+  int u = u0 + strand;
+  for (; u + 3 * STR < u1; u += 4 * STR) {
+    const double a0 = part[(size_t)u * FE_B + i], a1 = part[(size_t)(u + STR) * FE_B + i];
+    const double a2 = part[(size_t)(u + 2 * STR) * FE_B + i], a3 = part[(size_t)(u + 3 * STR) * FE_B + i];
+    t += a0; t += a1; t += a2; t += a3;
+  }
+  for (; u < u1; u += STR) t += part[(size_t)u * FE_B + i];
+  lds[strand][r] = t;
+  __syncthreads();
+  if (strand == 0) {
+    double g = lds[0][r];
+#pragma unroll
+    for (int k = 1; k < STR; ++k) g += lds[k][r];
+    rep[r] = g;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double g = rep[0];
+#pragma unroll
+    for (int k = 1; k < FE_HOT_REP; ++k) g += rep[k];
+    F.fg[F.umap[H.col[h]]] = g;
+  }
+}
+
 // local gradient (the column blocks' partial sums) into the global coefficient space; the first FE_FIN_BLOCKS workgroups also add
 // up a contiguous range of the per-unit value / residual sums each
 template <bool HESS = false>
@@ -403,13 +443,17 @@ __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
   __shared__ double lds[FE_STRANDS][FE_RED_OUT];
   __shared__ double red[3][FE_WAVES];
   if (!HESS && F.state->status >= 0) return;
+  const int nfin = (int)gridDim.x - F.hot.n;      // the frequent columns' workgroups sit behind the others (fe_passes)
+  if ((int)blockIdx.x >= nfin) { fe_hot_finish_block(F, (int)blockIdx.x - nfin); return; }
   const int tid = threadIdx.x, out = tid % FE_RED_OUT, strand = tid / FE_RED_OUT;
   const int j0 = blockIdx.x * FE_RED_OUT;
   if (j0 < F.d) {   // workgroup-uniform
     const int jj = j0 + out < F.d ? j0 + out : F.d - 1;
     const int b = jj / FE_B, i = jj % FE_B;
     const double g = fe_strand_sum(F.cc.part, F.cc.ufirst[b], F.cc.ufirst[b + 1], i, strand, lds, out);
-    if (strand == 0 && j0 + out < F.d) F.fg[F.umap[jj]] = g;
+    // (an exact 0 is not written: the buffer is clear before an evaluation — gdmix_fe_eval / the step's dots — and a frequent column's
+    // own slot, which holds no entry here, belongs to the workgroup that adds up its replicas in this same launch)
+    if (strand == 0 && j0 + out < F.d && g != 0.0) F.fg[F.umap[jj]] = g;
   }
   if (blockIdx.x >= FE_FIN_BLOCKS) return;
   const int lane = tid & (WAVE - 1), wv = tid >> 6;
@@ -449,45 +493,6 @@ __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
       F.fg[F.P] = a + al;      // rounded once
       *F.fin_count = 0u;
     }
-  }
-}
-
-// ---- frequent columns: FE_HOT_REP accumulators each (FeHot above) -------------------------------------------------------------
-// after fe_finish_kernel (which left 0 for a frequent column: the copy holds no entry under its own number). One workgroup per
-// frequent column: replica r's sum over the virtual block's units by 8 strands, strands in order, then the replicas in order.
-template <bool HESS = false>
-__global__ __launch_bounds__(FE_THREADS) void fe_hot_finish_kernel(FeDev F) {
-  constexpr int STR = FE_THREADS / FE_HOT_REP;
-  __shared__ double lds[STR][FE_HOT_REP];
-  __shared__ double rep[FE_HOT_REP];
-  if (!HESS && F.state->status >= 0) return;
-  const FeHot& H = F.hot;
-  const int h = blockIdx.x, tid = threadIdx.x, r = tid % FE_HOT_REP, strand = tid / FE_HOT_REP;
-  const int b = H.vbase / FE_B, i = h * FE_HOT_REP + r;
-  const int u0 = F.cc.ufirst[b], u1 = F.cc.ufirst[b + 1];
-  const double* __restrict__ part = F.cc.part;
-  double t = 0.0;
-  int u = u0 + strand;
-  for (; u + 3 * STR < u1; u += 4 * STR) {
-    const double a0 = part[(size_t)u * FE_B + i], a1 = part[(size_t)(u + STR) * FE_B + i];
-    const double a2 = part[(size_t)(u + 2 * STR) * FE_B + i], a3 = part[(size_t)(u + 3 * STR) * FE_B + i];
-    t += a0; t += a1; t += a2; t += a3;
-  }
-  for (; u < u1; u += STR) t += part[(size_t)u * FE_B + i];
-  lds[strand][r] = t;
-  __syncthreads();
-  if (strand == 0) {
-    double g = lds[0][r];
-#pragma unroll
-    for (int k = 1; k < STR; ++k) g += lds[k][r];
-    rep[r] = g;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double g = rep[0];
-#pragma unroll
-    for (int k = 1; k < FE_HOT_REP; ++k) g += rep[k];
-    F.fg[F.umap[H.col[h]]] = g;
   }
 }
 
@@ -1309,8 +1314,7 @@ static int fe_passes(gdmix_fe_problem* p, const FeDev& F, hipStream_t s, bool ti
   else hipLaunchKernelGGL((fe_scatter_kernel<false, HESS, false>), dim3(F.cc.nlaunch), dim3(WAVE), 0, s, F, p->o);
   if (timed) HIP_TRY(hipEventRecord(p->ev[2], s));
   int gf = (F.d + FE_RED_OUT - 1) / FE_RED_OUT;
-  hipLaunchKernelGGL(fe_finish_kernel<HESS>, dim3(gf < FE_FIN_BLOCKS ? FE_FIN_BLOCKS : gf), dim3(FE_THREADS), 0, s, F);
-  if (F.hot.n > 0) hipLaunchKernelGGL(fe_hot_finish_kernel<HESS>, dim3(F.hot.n), dim3(FE_THREADS), 0, s, F);
+  hipLaunchKernelGGL(fe_finish_kernel<HESS>, dim3((gf < FE_FIN_BLOCKS ? FE_FIN_BLOCKS : gf) + F.hot.n), dim3(FE_THREADS), 0, s, F);
   if (HESS) hipLaunchKernelGGL(fe_prepare_kernel, dim3(gd), dim3(256), 0, s, p->F);
   HIP_TRY(hipGetLastError());
   return GDMIX_RE_OK;
