@@ -79,7 +79,7 @@ struct FeCopy {
 // FE_HOT_MAX most frequent of them) get FE_HOT_REP accumulators each: in the column pass's copy an entry of frequent column h in
 // row r goes to the virtual column vbase + h * FE_HOT_REP + r % FE_HOT_REP. The virtual columns form one more block at the end
 // (entries by ascending row like every block: one sweep over the residuals for all of them), neighbouring rows land on different
-// accumulators, and fe_hot_finish_block (the last workgroups of fe_finish_kernel) adds a column's FE_HOT_REP sums in replica order. No atomics across workgroups, fixed shape.
+// accumulators, and fe_hot_finish_block (the first workgroups of fe_finish_kernel) adds a column's FE_HOT_REP sums in replica order. No atomics across workgroups, fixed shape.
 constexpr int FE_HOT_MAX = 64;
 constexpr int FE_HOT_REP = 32;
 static_assert(FE_HOT_MAX * FE_HOT_REP <= FE_B && FE_B % FE_HOT_REP == 0, "the virtual columns are one block");
@@ -400,7 +400,7 @@ __device__ __forceinline__ void wave_sum_dd(double& hi, double& lo) {
 // next to fe_finish_kernel's own workgroups (which find 0 for a frequent column — the copy holds no entry under its own number — and
 // write nothing then: the buffer is clear before an evaluation). One workgroup per
 // frequent column: replica r's sum over the virtual block's units by 8 strands, strands in order, then the replicas in order.
-// (Round 6: the workgroups of this step are the LAST F.hot.n workgroups of fe_finish_kernel's grid, not a launch of their own — one
+// (Round 6: the workgroups of this step are the FIRST F.hot.n workgroups of fe_finish_kernel's grid, not a launch of their own — one
 // launch boundary (~6 us on this device) and 10 us of a nearly empty device less per evaluation of a shard with frequent columns.)
 __device__ __forceinline__ void fe_hot_finish_block(const FeDev& F, int h) {
   constexpr int STR = FE_THREADS / FE_HOT_REP;
@@ -443,10 +443,12 @@ __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
   __shared__ double lds[FE_STRANDS][FE_RED_OUT];
   __shared__ double red[3][FE_WAVES];
   if (!HESS && F.state->status >= 0) return;
-  const int nfin = (int)gridDim.x - F.hot.n;      // the frequent columns' workgroups sit behind the others (fe_passes)
-  if ((int)blockIdx.x >= nfin) { fe_hot_finish_block(F, (int)blockIdx.x - nfin); return; }
+  // the frequent columns' workgroups come FIRST in the grid: each is a long chain (a thousand units' sums by eight strands) and must
+  // start with the launch, not behind it
+  if ((int)blockIdx.x < F.hot.n) { fe_hot_finish_block(F, (int)blockIdx.x); return; }
+  const int bid = (int)blockIdx.x - F.hot.n;
   const int tid = threadIdx.x, out = tid % FE_RED_OUT, strand = tid / FE_RED_OUT;
-  const int j0 = blockIdx.x * FE_RED_OUT;
+  const int j0 = bid * FE_RED_OUT;
   if (j0 < F.d) {   // workgroup-uniform
     const int jj = j0 + out < F.d ? j0 + out : F.d - 1;
     const int b = jj / FE_B, i = jj % FE_B;
@@ -455,10 +457,10 @@ __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
     // own slot, which holds no entry here, belongs to the workgroup that adds up its replicas in this same launch)
     if (strand == 0 && j0 + out < F.d && g != 0.0) F.fg[F.umap[jj]] = g;
   }
-  if (blockIdx.x >= FE_FIN_BLOCKS) return;
+  if (bid >= FE_FIN_BLOCKS) return;
   const int lane = tid & (WAVE - 1), wv = tid >> 6;
   const int chunk = (F.nred + FE_FIN_BLOCKS - 1) / FE_FIN_BLOCKS;
-  const int b0 = blockIdx.x * chunk;
+  const int b0 = bid * chunk;
   const int b1 = (b0 + chunk < F.nred) ? b0 + chunk : F.nred;
   double a = 0.0, al = 0.0, r = 0.0;
   for (int b = b0 + tid; b < b1; b += FE_THREADS) {
@@ -474,9 +476,9 @@ __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
     double sa = red[0][0], sl = red[2][0], sr = red[1][0];
 #pragma unroll
     for (int w = 1; w < FE_WAVES; ++w) { dd_add2(sa, sl, red[0][w], red[2][w]); sr += red[1][w]; }
-    st_x<true>(F.fin_part + 3 * blockIdx.x, sa);
-    st_x<true>(F.fin_part + 3 * blockIdx.x + 1, sr);
-    st_x<true>(F.fin_part + 3 * blockIdx.x + 2, sl);
+    st_x<true>(F.fin_part + 3 * bid, sa);
+    st_x<true>(F.fin_part + 3 * bid + 1, sr);
+    st_x<true>(F.fin_part + 3 * bid + 2, sl);
     __threadfence();
     last = atomicAdd(F.fin_count, 1u) == FE_FIN_BLOCKS - 1;
   }
