@@ -101,7 +101,7 @@ struct FeDev {
   double* xl;               // [d] x of the features present in this shard
   double* rs;               // [n] per-sample residual
   double* fg;               // [P + 1] global data gradient (intercept last), then the data value
-  double *loss_part, *rsum_part;   // [nred]
+  double *loss_part, *rsum_part, *loss_lo_part;   // [nred] each: value (hi), residual sum, value (lo)
   double* acc_part;         // [FE_DOT_BLOCKS][TEAM_K]
   double* fin_part;         // [FE_FIN_BLOCKS][3]: value hi, residual sum, value lo
   unsigned* fin_count;      // workgroups of fe_finish_kernel that have delivered their range sums
@@ -117,11 +117,40 @@ __global__ void fe_prepare_kernel(FeDev F) {
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < F.d; j += gridDim.x * blockDim.x) F.xl[j] = F.W.x[F.umap[j]];
 }
 
+// ---- the data term's VALUE, added up error-free (round 6) ----------------------------------------------------------------------------
+// The value of a shard is a sum of millions of losses: f ~ 5e5 has an ulp of 5.8e-11, and a line search near the optimum asks for
+// decreases of that size (tools/fuzz_fe.py case 6100134: five features, 726 k samples, expected decrease of the fifth iteration
+// ~ 1.4 ulp). Added over a tree of fp64 sums the value carries a few ulps of noise, every trial of the search fails the
+// sufficient-decrease test and the fit ends ABNORMAL where scipy on an accurately summed objective (and the oracle, which adds in
+// long double) takes the step and stops on the projected gradient. So the value is added up as (hi, lo) pairs combined with TwoSum
+// at EVERY level — a lane's rows, the unit's wavefront, the ranges of fe_finish_kernel, its wavefronts, the final 64 — and rounded
+// once at the end: f is the correctly rounded sum of the fp64 loss terms (first version: from the per-unit sums up only; case
+// 6500120, 294 k samples, still searched two evaluations longer than the oracle on the per-unit sums' noise). Six more flops per row in
+// passes whose vector units idle 90 % of the time; the gradient is not touched.
+__device__ __forceinline__ void dd_add(double& hi, double& lo, double x) {      // (hi, lo) += x, Knuth's TwoSum: no error term lost
+  const double s = hi + x, bb = s - hi;
+  lo += (hi - (s - bb)) + (x - bb);
+  hi = s;
+}
+__device__ __forceinline__ void dd_add2(double& hi, double& lo, double xh, double xl) { dd_add(hi, lo, xh); lo += xl; }
+// (hi, lo) of all 64 lanes -> lane 63 holds the total pair (the shift pattern of wave_sum; an invalid source reads 0)
+__device__ __forceinline__ void wave_sum_dd(double& hi, double& lo) {
+#define GDMIX_DD_STEP(CTRL, MASK)                                                     \
+  {                                                                                   \
+    const double oh = dpp_get0<CTRL, MASK>(hi), ol = dpp_get0<CTRL, MASK>(lo);        \
+    dd_add2(hi, lo, oh, ol);                                                          \
+  }
+  GDMIX_DD_STEP(0x111, 0xf) GDMIX_DD_STEP(0x112, 0xf) GDMIX_DD_STEP(0x114, 0xf) GDMIX_DD_STEP(0x118, 0xf) GDMIX_DD_STEP(0x142, 0xa) GDMIX_DD_STEP(0x143, 0xc)
+#undef GDMIX_DD_STEP
+  hi = readlane63(hi);
+  lo = readlane63(lo);
+}
+
 // what becomes of a finished row sum
 // HESS: the pass computes the diagonal of X~' D X~ instead of the gradient (fixed_effect_lr_lbfgs_model.py:271-296): the row pass
 // leaves d_i = w_i rho_i (1 - rho_i), rho = sigmoid(logit), the column pass sums val^2 d_i
 template <bool HESS>
-__device__ __forceinline__ void fe_emit_row(const FeDev& F, const SolveParams& o, int s, double sum, double xb, double& loss, double& rsum) {
+__device__ __forceinline__ void fe_emit_row(const FeDev& F, const SolveParams& o, int s, double sum, double xb, double& loss, double& loss_lo, double& rsum) {
   const double zi = sum + xb + (double)F.o[s];
   const double yi = (double)F.y[s];
   const double wi = F.w ? (double)F.w[s] : 1.0;
@@ -131,10 +160,10 @@ __device__ __forceinline__ void fe_emit_row(const FeDev& F, const SolveParams& o
     ri = wi * rho * (1.0 - rho);
   } else if (o.linear) {
     const double e = zi - yi;
-    loss += wi * e * e;
+    dd_add(loss, loss_lo, wi * e * e);
     ri = 2.0 * wi * e;
   } else {
-    loss += logistic_terms(zi, yi, wi, ri);
+    dd_add(loss, loss_lo, logistic_terms(zi, yi, wi, ri));
   }
   F.rs[s] = ri;
   rsum += ri;
@@ -301,19 +330,19 @@ __global__ __launch_bounds__(WAVE) void fe_scatter_kernel(FeDev F, SolveParams o
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the adds have landed
   __builtin_amdgcn_wave_barrier();
   if (whole) {
-    double loss = 0.0, rsum = 0.0;
+    double loss = 0.0, loss_lo = 0.0, rsum = 0.0;
     const int r0 = b * FE_B;
     const int nr = (F.n - r0 < FE_B) ? F.n - r0 : FE_B;
-    for (int i = lane; i < nr; i += WAVE) fe_emit_row<HESS>(F, o, r0 + i, acc[i], xb, loss, rsum);
-    loss = wave_sum(loss);
+    for (int i = lane; i < nr; i += WAVE) fe_emit_row<HESS>(F, o, r0 + i, acc[i], xb, loss, loss_lo, rsum);
+    wave_sum_dd(loss, loss_lo);
     rsum = wave_sum(rsum);
-    if (lane == 0) { F.loss_part[u] = loss; F.rsum_part[u] = rsum; }
+    if (lane == 0) { F.loss_part[u] = loss; F.loss_lo_part[u] = loss_lo; F.rsum_part[u] = rsum; }
   } else {
     double* __restrict__ out = C.part + (size_t)u * FE_B;
 #pragma unroll
     for (int i = 0; i < FE_B / WAVE; i += 2)
       *reinterpret_cast<double2*>(out + (i * WAVE + 2 * lane)) = *reinterpret_cast<const double2*>(acc + (i * WAVE + 2 * lane));
-    if (ROWS && lane == 0) { F.loss_part[u] = 0.0; F.rsum_part[u] = 0.0; }
+    if (ROWS && lane == 0) { F.loss_part[u] = 0.0; F.loss_lo_part[u] = 0.0; F.rsum_part[u] = 0.0; }
   }
 }
 
@@ -357,43 +386,17 @@ __global__ __launch_bounds__(FE_THREADS) void fe_rows_fix_kernel(FeDev F, SolveP
   const int row = b * FE_B + i;
   const double xb = F.ic ? F.W.x[F.D] : 0.0;
   const double t = fe_strand_sum(F.rc.part, F.rc.ufirst[b], F.rc.ufirst[b + 1], i, strand, lds, out);
-  double loss = 0.0, rsum = 0.0;
-  if (strand == 0 && row < F.n) fe_emit_row<HESS>(F, o, row, t, xb, loss, rsum);
+  double loss = 0.0, loss_lo = 0.0, rsum = 0.0;
+  if (strand == 0 && row < F.n) fe_emit_row<HESS>(F, o, row, t, xb, loss, loss_lo, rsum);
   if (tid < WAVE) {   // the outputs' threads are the first FE_RED_OUT lanes of wavefront 0
-    loss = wave_sum(loss);
+    wave_sum_dd(loss, loss_lo);
     rsum = wave_sum(rsum);
     if (tid == 0) {
       F.loss_part[F.rc.nunit + blockIdx.x] = loss;
+      F.loss_lo_part[F.rc.nunit + blockIdx.x] = loss_lo;
       F.rsum_part[F.rc.nunit + blockIdx.x] = rsum;
     }
   }
-}
-
-// ---- the data term's VALUE, added up error-free (round 6) ----------------------------------------------------------------------------
-// The value of a shard is a sum of millions of losses: f ~ 5e5 has an ulp of 5.8e-11, and a line search near the optimum asks for
-// decreases of that size (tools/fuzz_fe.py case 6100134: five features, 726 k samples, expected decrease of the fifth iteration
-// ~ 1.4 ulp). Added over a tree of fp64 sums the value carries a few ulps of noise, every trial of the search fails the
-// sufficient-decrease test and the fit ends ABNORMAL where scipy on an accurately summed objective (and the oracle, which adds in
-// long double) takes the step and stops on the projected gradient. The per-unit sums (<= 2 048 losses each) stay plain fp64; from
-// there on — the ranges of fe_finish_kernel, its wavefronts, the final 64 — the partial sums are (hi, lo) pairs combined with TwoSum,
-// rounded once at the end. A few dozen instructions in a kernel of 13 us; the gradient is not touched.
-__device__ __forceinline__ void dd_add(double& hi, double& lo, double x) {      // (hi, lo) += x, Knuth's TwoSum: no error term lost
-  const double s = hi + x, bb = s - hi;
-  lo += (hi - (s - bb)) + (x - bb);
-  hi = s;
-}
-__device__ __forceinline__ void dd_add2(double& hi, double& lo, double xh, double xl) { dd_add(hi, lo, xh); lo += xl; }
-// (hi, lo) of all 64 lanes -> lane 63 holds the total pair (the shift pattern of wave_sum; an invalid source reads 0)
-__device__ __forceinline__ void wave_sum_dd(double& hi, double& lo) {
-#define GDMIX_DD_STEP(CTRL, MASK)                                                     \
-  {                                                                                   \
-    const double oh = dpp_get0<CTRL, MASK>(hi), ol = dpp_get0<CTRL, MASK>(lo);        \
-    dd_add2(hi, lo, oh, ol);                                                          \
-  }
-  GDMIX_DD_STEP(0x111, 0xf) GDMIX_DD_STEP(0x112, 0xf) GDMIX_DD_STEP(0x114, 0xf) GDMIX_DD_STEP(0x118, 0xf) GDMIX_DD_STEP(0x142, 0xa) GDMIX_DD_STEP(0x143, 0xc)
-#undef GDMIX_DD_STEP
-  hi = readlane63(hi);
-  lo = readlane63(lo);
 }
 
 // ---- frequent columns: FE_HOT_REP accumulators each (FeHot above) -------------------------------------------------------------
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(FE_THREADS) void fe_finish_kernel(FeDev F) {
   const int b1 = (b0 + chunk < F.nred) ? b0 + chunk : F.nred;
   double a = 0.0, al = 0.0, r = 0.0;
   for (int b = b0 + tid; b < b1; b += FE_THREADS) {
-    dd_add(a, al, F.loss_part[b]);
+    dd_add2(a, al, F.loss_part[b], F.loss_lo_part[b]);
     r += F.rsum_part[b];
   }
   wave_sum_dd(a, al);
@@ -1386,7 +1389,7 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   auto take = [&](size_t bytes) { size_t r = off; off = up256(off + bytes); return r; };
   const size_t o_xl = take((size_t)(F.d + 1) * 8), o_rs = take((size_t)(F.n + 1) * 8), o_fg = take((P + 1) * 8);
   const size_t o_pr = take((size_t)F.rc.nunit * FE_B * 8), o_pc = take((size_t)F.cc.nunit * FE_B * 8);
-  const size_t o_multi = take((multi.size() + 1) * 4), o_red = take((size_t)F.nred * 2 * 8 + 16);
+  const size_t o_multi = take((multi.size() + 1) * 4), o_red = take((size_t)F.nred * 3 * 8 + 16);
   const size_t o_acc = take((size_t)FE_DOT_BLOCKS * TEAM_K * 8), o_fin = take((size_t)FE_FIN_BLOCKS * 3 * 8 + 64);
   const size_t o_state = take(sizeof(CompactState)), o_plan = take(sizeof(CompactPlan)), o_mats = take(sizeof(CompactMats));
   const size_t o_vec = take(((size_t)5 * P + compact_hist_doubles((int64_t)P, opts->m)) * 8 + 16), o_status = take(64);
@@ -1407,7 +1410,7 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   F.fg = reinterpret_cast<double*>(base + o_fg);
   F.rc.part = reinterpret_cast<double*>(base + o_pr); F.cc.part = reinterpret_cast<double*>(base + o_pc);
   F.multi = reinterpret_cast<const int32_t*>(base + o_multi);
-  F.loss_part = reinterpret_cast<double*>(base + o_red); F.rsum_part = F.loss_part + F.nred;
+  F.loss_part = reinterpret_cast<double*>(base + o_red); F.rsum_part = F.loss_part + F.nred; F.loss_lo_part = F.rsum_part + F.nred;
   F.acc_part = reinterpret_cast<double*>(base + o_acc);
   F.fin_part = reinterpret_cast<double*>(base + o_fin);
   F.fin_count = reinterpret_cast<unsigned*>(base + o_fin + (size_t)FE_FIN_BLOCKS * 3 * 8);
