@@ -1029,6 +1029,21 @@ def main():
     else:
         converged_all = converged
     value = converged_all * a.steps / dt
+    # clocks and power WHILE the device works (outside the timed region): rocm-smi is asked from a second thread while this one keeps
+    # solving the same batch; the state at the end of the whole run (idle clocks) is recorded too
+    gpu_load_state = None
+    if rank == 0 and world == 1:
+        import threading
+        box = {}
+        th = threading.Thread(target=lambda: box.update(state=gpu_state()))
+        th.start()
+        n_extra = 0
+        while th.is_alive() and n_extra < 400:
+            solver.solve(packed, opts, out=out)
+            n_extra += 1
+        th.join()
+        torch.cuda.synchronize()
+        gpu_load_state = dict(box.get("state") or {}, solves_meanwhile=n_extra)
     # ---- the same step with the size classes one after another (gdmix_re_set_spread 0), NOT part of `value`: in the timed region the
     # large classes run side by side on four queues (their tails overlap: the step is shorter) and every launch lasts longer than it
     # would alone — a kernel's own roofline figure needs its duration alone
@@ -1277,7 +1292,7 @@ def main():
                        "classes": classes, "class_ms": [round(float(x) / a.steps, 3) for x in kernel_ms], "per_class": per_class,
                        "mean_nit": nit, "mean_nfev": nfev,
                        "converged_per_step": converged_all, "parity_classes": {"W": well_posed, "D": int(wl.E - well_posed)}, "N": wl.N, "Z": wl.Z, "P": packed.P,
-                       "gpu_state_at_end": gpu_state(),
+                       "gpu_state_under_load": gpu_load_state, "gpu_state_at_end": gpu_state(),
                        "host_generate_s": t_gen, "solve_to_host": to_host, "host_handover": e2e, "score_pass": score, "fixed_effect_eval": fe_eval, "cli_end_to_end": cli_e2e,
                        "cli_subprocess": cli_sub, "cli_end_to_end_c5": cli_c5, "cli_end_to_end_ml20m_movie": cli_movie, "workloads": others, "c5_full_share": c5_full, "chain": chain_res,
                        "restreamed_bytes_per_step": b_stream,
