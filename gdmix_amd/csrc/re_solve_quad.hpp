@@ -411,6 +411,9 @@ enum { SC_FOLD = 0, SC_GDOLD = 1, SC_THETA = 2, SC_MOVED = 3 };
 #ifndef GDMIX_QUAD_LANE_STATE
 #define GDMIX_QUAD_LANE_STATE 0
 #endif
+#ifndef GDMIX_QUAD_ZERO_STEPS
+#define GDMIX_QUAD_ZERO_STEPS 0      // (described where the steps are: quad_solve)
+#endif
 enum { LN_FOLD = 10, LN_GDOLD = 11, LN_THETA = 12 };
 static_assert(M_REG <= 10, "lane slots 10..12 hold the scalars");
 
@@ -629,6 +632,30 @@ __device__ __forceinline__ double quad_eval(const QuadLds& L, const SolveParams&
   return inv_n * part;
 }
 
+// ---- the history without its shift (GDMIX_QUAD_APPEND, round 6) ------------------------------------------------------------------
+// A push shifts the whole register history down by one (54 v_mov_b64 at EPL = 3, + 9 + 9 LDS accesses for rho): the pair-push item of
+// VERDICT r5. Round 5 tried "pair a in slot a" with the slot chosen per ROW and lost to the ten compare / exec-save / branch skips
+// that needs. Here the slot is chosen per WAVEFRONT: while slots are free, every trip on which any row of the wavefront stores a pair
+// takes the next slot w for all rows (one scalar jump into ten static bodies); a row that stores nothing on that trip simply does not
+// use slot w (its mask `um` lacks the bit: a hole). Slot order is still time order for every row, so both loops of the recursion run
+// over the slots any row uses, in the same static order as before, with a row's `use` read from its mask. Once all ten slots are taken
+// a row frees, when it stores a pair, its oldest slot that holds nothing it uses (a hole, or a pair beyond its last m) — else its
+// oldest pair — by shifting the slots above it down (v_cndmask instead of v_mov: per-row start). Same pairs in the same order: same
+// bits. A/B: profiles/r06_c2_ab.txt.
+#ifndef GDMIX_QUAD_APPEND
+#define GDMIX_QUAD_APPEND 0
+#endif
+static_assert(!(GDMIX_QUAD_APPEND && (GDMIX_QUAD_LANE_STATE || GDMIX_QUAD_ZERO_STEPS)), "the append form of the history keeps rho in LDS and the masked steps");
+
+// OR of a per-entity value over the wavefront's entities (every lane of a group holds the group's value)
+template <int G>
+__device__ __forceinline__ unsigned wave_or_groups(unsigned v) {
+  unsigned r = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+  if (G < 64) r |= (unsigned)__builtin_amdgcn_readlane((int)v, 32);
+  if (G < 32) r |= (unsigned)__builtin_amdgcn_readlane((int)v, 16) | (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return r;
+}
+
 template <int EPL>
 struct QuadState {
   double x[EPL], g[EPL], d[EPL];
@@ -657,6 +684,10 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
   double* const go = L.go();
   const int m = o.m;
   int cnt = 0;
+#if GDMIX_QUAD_APPEND
+  int w = 0;            // slots taken so far, the same for every row of the wavefront (M_REG: full)
+  unsigned um = 0u;     // this row's pairs in use: bit a = slot a
+#endif
   int nit = 0, nfev = 0, ifun = 0;
   int status = valid ? -1 : 0;
   bool iter0 = true, first = true;
@@ -677,6 +708,9 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
   }
   while (__any(status < 0)) {
     bool need_dir = false, restart = false;
+#if GDMIX_QUAD_APPEND
+    bool do_push = false;
+#endif
     if (status < 0) {
       // ---- f, g at the trial point; g'd, y'y and max|g| in one reduction pass ------------------------
       bool counted;
@@ -759,6 +793,9 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
             double dr, ddum;
             if (stp == 1.0) { dr = gd - gdold; ddum = -gdold; }
             else { dr = (gd - gdold) * stp; ddum = -gdold * stp; }
+#if GDMIX_QUAD_APPEND
+            do_push = dr > EPSMCH * ddum;      // stored behind this region, where the slot is uniform (dr is formed again there: no register carries it)
+#else
             if (dr > EPSMCH * ddum) {
               // push (s, y): the history shifts down by one, newest at KR-1
 #if GDMIX_QUAD_LANE_STATE
@@ -790,10 +827,65 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
 #endif
               if (cnt < m) ++cnt;
             }
+#endif
           }
         }
       }
     }
+#if GDMIX_QUAD_APPEND
+    // ---- the pairs of this trip: one slot for the whole wavefront while slots are free, then a shift per row ----------------------
+    if (__any(do_push)) {
+      double p_rho = 0.0;
+      if (do_push) {
+        const double gdold = scal[SC_GDOLD];
+        const double dr = (stp == 1.0) ? gd - gdold : (gd - gdold) * stp;      // as in the region above: same bits
+        p_rho = 1.0 / dr;
+        scal[SC_THETA] = rr / dr;
+      }
+      if (w < M_REG) {
+#define QUAD_APPEND_AT(a)                                                             \
+        case a:                                                                        \
+          if (do_push) {                                                               \
+            _Pragma("unroll") for (int s = 0; s < EPL; ++s) {                          \
+              const int j = gl + G * s;                                                \
+              S[a][s] = stp * V.d[s];                                                  \
+              Y[a][s] = V.g[s] - ((j < p) ? go[j] : 0.0);                              \
+            }                                                                          \
+          }                                                                            \
+          break;
+        switch (w) {
+          QUAD_APPEND_AT(0) QUAD_APPEND_AT(1) QUAD_APPEND_AT(2) QUAD_APPEND_AT(3) QUAD_APPEND_AT(4)
+          QUAD_APPEND_AT(5) QUAD_APPEND_AT(6) QUAD_APPEND_AT(7) QUAD_APPEND_AT(8) QUAD_APPEND_AT(9)
+          default: break;
+        }
+#undef QUAD_APPEND_AT
+        if (do_push) { rho[w] = p_rho; um |= 1u << w; }
+        ++w;
+      } else if (do_push) {
+        const unsigned freeb = ~um & ((1u << M_REG) - 1u);
+        const int k = freeb ? (__ffs((int)freeb) - 1) : 0;      // the slot this row gives up: everything above it moves down by one
+#pragma unroll
+        for (int a = 0; a < KR - 1; ++a) {
+          const bool mv = a >= k;
+#pragma unroll
+          for (int s = 0; s < EPL; ++s) { S[a][s] = mv ? S[a + 1][s] : S[a][s]; Y[a][s] = mv ? Y[a + 1][s] : Y[a][s]; }
+        }
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) {
+          const int j = gl + G * s;
+          S[KR - 1][s] = stp * V.d[s];
+          Y[KR - 1][s] = V.g[s] - ((j < p) ? go[j] : 0.0);
+        }
+        for (int a = k; a < M_REG - 1; ++a) rho[a] = rho[a + 1];
+        rho[M_REG - 1] = p_rho;
+        um = (um & ((1u << k) - 1u)) | ((um >> (k + 1)) << k) | (1u << (M_REG - 1));
+      }
+      if (do_push) {
+        if (__popc(um) > m) um &= um - 1u;      // more than the last m pairs: the oldest is not used any more
+        cnt = __popc(um);
+      }
+    }
+#endif
     // ---- new search direction for the rows that need one (again after a line-search restart) ---------
     while (__any(need_dir)) {
       if (need_dir && restart) {
@@ -811,6 +903,9 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
         if (cnt == 0) { status = 4; need_dir = false; }
         else {
           cnt = 0;
+#if GDMIX_QUAD_APPEND
+          um = 0u;
+#endif
 #if GDMIX_QUAD_LANE_STATE
           rho_v = row_put<LN_THETA>(rho_v, 1.0);
 #else
@@ -826,8 +921,20 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
       // uses are M_REG-cmax .. M_REG-1 with cmax uniform: the first loop leaves at its lower end, the second enters at it (a switch
       // that falls through) — until round 5 every one of the 2 M_REG steps was skipped on its own (`if (__any(use))`: a compare, an
       // exec save and a taken branch each, ~11 of 20 skipped at C2's mean history of 4.5 pairs).
+#if GDMIX_QUAD_APPEND
+      // the slots any row of the wavefront uses in this direction: [lo, hi) (uniform); a row's own from its mask
+      const unsigned um_all = wave_or_groups<G>(need_dir ? um : 0u);
+      const int lo = um_all ? (__ffs((int)um_all) - 1) : M_REG, hi = um_all ? (32 - __clz((int)um_all)) : 0;
+#define QUAD_USE(a) (need_dir && ((um >> (a)) & 1u))
+#define QUAD_FIRST_EXIT(a) if ((a) < lo) goto first_loop_done;
+#define QUAD_SECOND_EXIT(a) if ((a) >= hi) goto second_loop_done;
+#else
       const int cmax = wave_max_nonneg_i32(need_dir ? cnt : 0);
       const int a0 = M_REG - cmax;
+#define QUAD_USE(a) (need_dir && ((a) >= M_REG - cnt))
+#define QUAD_FIRST_EXIT(a) if ((a) < a0) goto first_loop_done;
+#define QUAD_SECOND_EXIT(a)
+#endif
 #if GDMIX_QUAD_LANE_STATE
 #define QUAD_RHO(a) row_get<a>(rho_v)
 #define QUAD_ALPHA(a) row_get<a>(alpha_v)
@@ -867,8 +974,8 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
 #else
 #define QUAD_FIRST_LOOP_STEP(a)                                                   \
       {                                                                           \
-        if ((a) < a0) goto first_loop_done;                                       \
-        const bool use = need_dir && ((a) >= M_REG - cnt);                        \
+        QUAD_FIRST_EXIT(a)                                                        \
+        const bool use = QUAD_USE(a);                                             \
         if (use) {                                                                \
           double t = 0.0;                                                         \
           _Pragma("unroll") for (int s = 0; s < EPL; ++s) t += S[a][s] * V.d[s];  \
@@ -879,8 +986,24 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
       }
 #endif
       static_assert(M_REG == 10, "the steps below are written out for ten pairs");
+#if GDMIX_QUAD_APPEND
+      switch (hi) {      // newest slot in use first
+        case 10: QUAD_FIRST_LOOP_STEP(9) [[fallthrough]];
+        case 9: QUAD_FIRST_LOOP_STEP(8) [[fallthrough]];
+        case 8: QUAD_FIRST_LOOP_STEP(7) [[fallthrough]];
+        case 7: QUAD_FIRST_LOOP_STEP(6) [[fallthrough]];
+        case 6: QUAD_FIRST_LOOP_STEP(5) [[fallthrough]];
+        case 5: QUAD_FIRST_LOOP_STEP(4) [[fallthrough]];
+        case 4: QUAD_FIRST_LOOP_STEP(3) [[fallthrough]];
+        case 3: QUAD_FIRST_LOOP_STEP(2) [[fallthrough]];
+        case 2: QUAD_FIRST_LOOP_STEP(1) [[fallthrough]];
+        case 1: QUAD_FIRST_LOOP_STEP(0) [[fallthrough]];
+        default: break;
+      }
+#else
       QUAD_FIRST_LOOP_STEP(9) QUAD_FIRST_LOOP_STEP(8) QUAD_FIRST_LOOP_STEP(7) QUAD_FIRST_LOOP_STEP(6) QUAD_FIRST_LOOP_STEP(5)
       QUAD_FIRST_LOOP_STEP(4) QUAD_FIRST_LOOP_STEP(3) QUAD_FIRST_LOOP_STEP(2) QUAD_FIRST_LOOP_STEP(1) QUAD_FIRST_LOOP_STEP(0)
+#endif
 #undef QUAD_FIRST_LOOP_STEP
     first_loop_done:;
       if (need_dir && cnt > 0) {
@@ -895,7 +1018,8 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
 #if !GDMIX_QUAD_ZERO_STEPS
 #define QUAD_SECOND_LOOP_STEP(a)                                                  \
       {                                                                           \
-        const bool use = need_dir && ((a) >= M_REG - cnt);                        \
+        QUAD_SECOND_EXIT(a)                                                       \
+        const bool use = QUAD_USE(a);                                             \
         if (use) {                                                                \
           double t = 0.0;                                                         \
           _Pragma("unroll") for (int s = 0; s < EPL; ++s) t += Y[a][s] * V.d[s];  \
@@ -904,7 +1028,11 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
         }                                                                         \
       }
 #endif
+#if GDMIX_QUAD_APPEND
+      switch (lo) {
+#else
       switch (a0) {
+#endif
         case 0: QUAD_SECOND_LOOP_STEP(0) [[fallthrough]];
         case 1: QUAD_SECOND_LOOP_STEP(1) [[fallthrough]];
         case 2: QUAD_SECOND_LOOP_STEP(2) [[fallthrough]];
@@ -917,6 +1045,12 @@ __device__ __forceinline__ void quad_solve(const QuadLds& L, const SolveParams& 
         case 9: QUAD_SECOND_LOOP_STEP(9) [[fallthrough]];
         default: break;
       }
+#if GDMIX_QUAD_APPEND
+    second_loop_done:;
+#endif
+#undef QUAD_USE
+#undef QUAD_FIRST_EXIT
+#undef QUAD_SECOND_EXIT
 #undef QUAD_SECOND_LOOP_STEP
 #undef QUAD_RHO
 #undef QUAD_ALPHA
