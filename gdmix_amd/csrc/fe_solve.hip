@@ -102,7 +102,7 @@ struct FeDev {
   double* rs;               // [n] per-sample residual
   double* fg;               // [P + 1] global data gradient (intercept last), then the data value
   double *loss_part, *rsum_part, *loss_lo_part;   // [nred] each: value (hi), residual sum, value (lo)
-  double* acc_part;         // [FE_DOT_BLOCKS][TEAM_K]
+  double* acc_part;         // [FE_DOT_BLOCKS][COMPACT_KD]
   double* fin_part;         // [FE_FIN_BLOCKS][3]: value hi, residual sum, value lo
   unsigned* fin_count;      // workgroups of fe_finish_kernel that have delivered their range sums
   int32_t* inv;             // [P] global coefficient -> local column of this shard, -1: absent (intercept: -1)
@@ -524,12 +524,12 @@ __global__ void fe_hot_remap_kernel(const int32_t* __restrict__ ptr, int n, cons
 // alone (nvb = min(ceil(P / 256), FE_DOT_BLOCKS)), not of the launch: fe_dots_kernel runs one workgroup per virtual block,
 // fe_tail_kernel deals them over fewer resident workgroups, and both give the same bits.
 template <bool SC1 = false>
-__device__ __forceinline__ void fe_dots_block(const FeDev& F, const SolveParams& o, int vb, int nvb, double (*red)[TEAM_K]) {
+__device__ __forceinline__ void fe_dots_block(const FeDev& F, const SolveParams& o, int vb, int nvb, double (*red)[COMPACT_KD]) {
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
   const int col = F.state->col, head = F.state->head, m = o.m, P = F.P;
-  double acc[TEAM_K];
+  double acc[COMPACT_KD];   // ... and S'g, Y'g taken directly behind the TEAM_K products (re_lbfgs_compact.hpp: why)
 #pragma unroll
-  for (int k = 0; k < TEAM_K; ++k) acc[k] = 0.0;
+  for (int k = 0; k < COMPACT_KD; ++k) acc[k] = 0.0;
   for (int j = vb * FE_THREADS + tid; j < P; j += nvb * FE_THREADS) {
     const bool reg = (j < F.D) || o.regularize_bias;   // the intercept is coefficient D
     const double xj = F.W.x[j];
@@ -555,61 +555,66 @@ __device__ __forceinline__ void fe_dots_block(const FeDev& F, const SolveParams&
     }
 #pragma unroll
     for (int i = 0; i < TEAM_MCAP; ++i) {
-      acc[5 + i] += (i < col ? h[i].x : 0.0) * yj;
-      acc[5 + TEAM_MCAP + i] += (i < col ? h[i].y : 0.0) * yj;
+      const double hx = i < col ? h[i].x : 0.0, hy = i < col ? h[i].y : 0.0;
+      acc[5 + i] += hx * yj;
+      acc[5 + TEAM_MCAP + i] += hy * yj;
+      acc[TEAM_K + i] += hx * gj;
+      acc[TEAM_K + TEAM_MCAP + i] += hy * gj;
     }
   }
+  static_assert(COMPACT_KD <= WAVE, "one lane per value");
   double mine = 0.0;
 #pragma unroll
-  for (int k = 0; k < TEAM_K; ++k) {
+  for (int k = 0; k < COMPACT_KD; ++k) {
     const double t = (k == TEAM_K - 1) ? wave_max_nonneg(acc[k]) : wave_sum(acc[k]);
     if (lane == k) mine = t;
   }
-  if (lane < TEAM_K) red[wv][lane] = mine;
+  if (lane < COMPACT_KD) red[wv][lane] = mine;
   __syncthreads();
-  if (tid < TEAM_K) {
+  if (tid < COMPACT_KD) {
     double s = red[0][tid];
 #pragma unroll
     for (int w = 1; w < FE_WAVES; ++w) s = (tid == TEAM_K - 1) ? fmax(s, red[w][tid]) : s + red[w][tid];
-    st_x<SC1>(F.acc_part + (size_t)vb * TEAM_K + tid, s);   // SC1 (fe_tail_kernel): written through, read by another workgroup of the same launch
+    st_x<SC1>(F.acc_part + (size_t)vb * COMPACT_KD + tid, s);   // SC1 (fe_tail_kernel): written through, read by another workgroup of the same launch
   }
 }
 
 __global__ __launch_bounds__(FE_THREADS) void fe_dots_kernel(FeDev F, SolveParams o) {
-  __shared__ double red[FE_WAVES][TEAM_K];
+  __shared__ double red[FE_WAVES][COMPACT_KD];
   if (F.state->status >= 0) return;     // a step enqueued behind the stop (gdmix_fe_step_async) is a no-op
   fe_dots_block(F, o, blockIdx.x, gridDim.x, red);
 }
 
 // one workgroup: totals of the products (the virtual blocks' shares, in a fixed order), then the driver's decision
 template <bool SC1 = false>
-__device__ __forceinline__ void fe_step_body(const FeDev& F, const SolveParams& o, int dot_blocks, int32_t* status_out, double* tot /* LDS [TEAM_K] */,
-                                             CompactMats& mats /* LDS */, double (*part8)[32] /* LDS [8][32] */) {
+__device__ __forceinline__ void fe_step_body(const FeDev& F, const SolveParams& o, int dot_blocks, int32_t* status_out, double* tot /* LDS [COMPACT_KD] */,
+                                             CompactMats& mats /* LDS */, double (*part4)[WAVE] /* LDS [4][64] */) {
   const int tid = threadIdx.x;
   {
-    // value v of block b by thread (b % 8) * 32 + v, eight partial totals per value, combined in order
-    const int v = tid & 31, g = tid >> 5;
-    if (v < TEAM_K) {
+    // value v of block b by thread (b % 4) * 64 + v, four partial totals per value, combined in order
+    static_assert(FE_THREADS == 4 * WAVE && COMPACT_KD <= WAVE, "four groups of one lane per value");
+    const int v = tid & (WAVE - 1), g = tid >> 6;
+    if (v < COMPACT_KD) {
       double s = 0.0;
       int b = g;
-      for (; b + 56 < dot_blocks; b += 64) {   // eight loads in flight
+      for (; b + 28 < dot_blocks; b += 32) {   // eight loads in flight
         double t[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t[q] = ld_x<SC1>(F.acc_part + (size_t)(b + 8 * q) * TEAM_K + v);
+        for (int q = 0; q < 8; ++q) t[q] = ld_x<SC1>(F.acc_part + (size_t)(b + 4 * q) * COMPACT_KD + v);
 #pragma unroll
         for (int q = 0; q < 8; ++q) s = (v == TEAM_K - 1) ? fmax(s, t[q]) : s + t[q];
       }
-      for (; b < dot_blocks; b += 8) {
-        const double t = ld_x<SC1>(F.acc_part + (size_t)b * TEAM_K + v);
+      for (; b < dot_blocks; b += 4) {
+        const double t = ld_x<SC1>(F.acc_part + (size_t)b * COMPACT_KD + v);
         s = (v == TEAM_K - 1) ? fmax(s, t) : s + t;
       }
-      part8[g][v] = s;
+      part4[g][v] = s;
     }
     __syncthreads();
-    if (tid < TEAM_K) {
-      double s = part8[0][tid];
+    if (tid < COMPACT_KD) {
+      double s = part4[0][tid];
 #pragma unroll
-      for (int k = 1; k < 8; ++k) s = (tid == TEAM_K - 1) ? fmax(s, part8[k][tid]) : s + part8[k][tid];
+      for (int k = 1; k < 4; ++k) s = (tid == TEAM_K - 1) ? fmax(s, part4[k][tid]) : s + part4[k][tid];
       tot[tid] = s;
     }
   }
@@ -619,9 +624,9 @@ __device__ __forceinline__ void fe_step_body(const FeDev& F, const SolveParams& 
     for (int k = tid; k < (int)(sizeof(CompactMats) / sizeof(double)); k += FE_THREADS) dst[k] = src[k];
   }
   __syncthreads();
-  double acc[TEAM_K];
+  double acc[COMPACT_KD];
 #pragma unroll
-  for (int k = 0; k < TEAM_K; ++k) acc[k] = tot[k];
+  for (int k = 0; k < COMPACT_KD; ++k) acc[k] = tot[k];
   CompactState S = *F.state;
   CompactPlan plan;
   plan.action = CA_STOP; plan.col = S.col; plan.head = S.head; plan.stp = S.stp; plan.gamma = 1.0;
@@ -630,7 +635,7 @@ __device__ __forceinline__ void fe_step_body(const FeDev& F, const SolveParams& 
   // (fe_tail_kernel's watchdog), and the all-reduce has carried it to every worker — all of them stop in the same evaluation, none
   // is left alone in a collective (fixed_effect.run_stepping_loop raises on every worker).
   if (F.fg[F.P] == -__builtin_inf()) S.status = GDMIX_RE_ST_ABORTED_PEER;
-  else compact_advance(S, acc, f_new, o, mats, plan);
+  else compact_advance(S, acc, f_new, o, mats, plan, true, acc + TEAM_K);
   __syncthreads();
   {
     double* dst = reinterpret_cast<double*>(F.mats);
@@ -652,11 +657,11 @@ __device__ __forceinline__ void fe_step_body(const FeDev& F, const SolveParams& 
 }
 
 __global__ __launch_bounds__(FE_THREADS) void fe_step_kernel(FeDev F, SolveParams o, int dot_blocks, int32_t* status_out) {
-  __shared__ double tot[TEAM_K];
+  __shared__ double tot[COMPACT_KD];
   __shared__ CompactMats mats;
-  __shared__ double part8[8][32];
+  __shared__ double part4[4][WAVE];
   if (F.state->status >= 0) return;     // (status_out keeps the status of the stop; fe_update_kernel repeats the stop's plan: idempotent)
-  fe_step_body(F, o, dot_blocks, status_out, tot, mats, part8);
+  fe_step_body(F, o, dot_blocks, status_out, tot, mats, part4);
 }
 
 // the elementwise part of a step for coefficient j; the shard's copy of x in local order follows it (the row pass gathers from xl)
@@ -680,10 +685,10 @@ __device__ __forceinline__ void fe_update_one(const FeDev& F, const CompactPlan&
 struct FeSync { unsigned arrive, gen, aborted; };      // aborted: sticky, set by a waiter whose watchdog fired (never cleared: the problem is dead)
 
 __global__ __launch_bounds__(FE_THREADS) void fe_tail_kernel(FeDev F, SolveParams o, int dot_blocks, int32_t* status_out, unsigned seq) {
-  __shared__ double red[FE_WAVES][TEAM_K];
-  __shared__ double tot[TEAM_K];
+  __shared__ double red[FE_WAVES][COMPACT_KD];
+  __shared__ double tot[COMPACT_KD];
   __shared__ CompactMats mats;
-  __shared__ double part8[8][32];
+  __shared__ double part4[4][WAVE];
   __shared__ CompactPlan plan_s;
   __shared__ int last, timed_out;
   if (F.state->status >= 0) return;     // written by an earlier launch: uniform over the grid
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(FE_THREADS) void fe_tail_kernel(FeDev F, SolveParam
   }
   __syncthreads();                       // (the shares are stored by threads of wavefront 0, whose queue thread 0 has just drained)
   if (last) {
-    fe_step_body<true>(F, o, dot_blocks, status_out, tot, mats, part8);
+    fe_step_body<true>(F, o, dot_blocks, status_out, tot, mats, part4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wavefront: its part of the matrices is at the memory side
     __syncthreads();
     if (tid == 0) {
@@ -1390,7 +1395,7 @@ GDMIX_API int gdmix_fe_create(gdmix_re_ctx* ctx, const gdmix_re_packed* b, int64
   const size_t o_xl = take((size_t)(F.d + 1) * 8), o_rs = take((size_t)(F.n + 1) * 8), o_fg = take((P + 1) * 8);
   const size_t o_pr = take((size_t)F.rc.nunit * FE_B * 8), o_pc = take((size_t)F.cc.nunit * FE_B * 8);
   const size_t o_multi = take((multi.size() + 1) * 4), o_red = take((size_t)F.nred * 3 * 8 + 16);
-  const size_t o_acc = take((size_t)FE_DOT_BLOCKS * TEAM_K * 8), o_fin = take((size_t)FE_FIN_BLOCKS * 3 * 8 + 64);
+  const size_t o_acc = take((size_t)FE_DOT_BLOCKS * COMPACT_KD * 8), o_fin = take((size_t)FE_FIN_BLOCKS * 3 * 8 + 64);
   const size_t o_state = take(sizeof(CompactState)), o_plan = take(sizeof(CompactPlan)), o_mats = take(sizeof(CompactMats));
   const size_t o_vec = take(((size_t)5 * P + compact_hist_doubles((int64_t)P, opts->m)) * 8 + 16), o_status = take(64);
   const size_t o_inv = take(P * 4), o_sync = take(sizeof(FeSync));

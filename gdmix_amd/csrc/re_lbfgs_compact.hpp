@@ -12,6 +12,7 @@ namespace gdmix {
 constexpr int TEAM_MCAP = 10;                 // history pairs the compact path keeps accumulators for
 constexpr int TEAM_K = 2 * TEAM_MCAP + 7;     // fused reduction width: sq, gd, gg, yy, yg, S'y, Y'y, r'd, max|g|
 constexpr int TEAM_RD = 2 * TEAM_MCAP + 5;    // acc index of r'd
+constexpr int COMPACT_KD = TEAM_K + 2 * TEAM_MCAP;   // acc[] with the DIRECT products behind it: TEAM_K + i = S_i'g, TEAM_K + MCAP + i = Y_i'g
 // acc[] layout, with y = g - r (r = the gradient at the last accepted iterate): 0 sum x_j^2 over regularised j, 1 g'd,
 // 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (chronological i < col), K-2 r'd, K-1 max|g_j|.
 // nfev is scipy's funcalls: ScalarFunction serves a point equal to the previously evaluated one from its cache without counting
@@ -25,6 +26,12 @@ constexpr int TEAM_RD = 2 * TEAM_MCAP + 5;    // acc index of r'd
 // The products are taken with y, not with g: S'g and Y'g at the new gradient are the stored ones plus these, and the new
 // column of S'Y / Y'Y is these — sums, where products with g would need differences of nearly equal numbers once the
 // gradient changes little between iterates.
+// ... and S'g and Y'g are ALSO taken directly (round 6; compact_advance's `sg`, 2 m more accumulators: COMPACT_KD in all): a stored s_i'g_k that is the sum of s_i'y over the iterations since the pair was made carries
+// the rounding of every term at the size the gradient had THEN — eps |s_i| |y_k| each — which is |g_then| / |g_now| times what the
+// direct product's is. A fit whose gradient falls by 10^3 - 10^4 inside the history window (tools/fuzz_fe.py case 6700230: squared
+// loss, |g| 3 000 -> 0.9 in twelve iterations) left the reference's trajectory by 1e-5 at the first iterate the problem amplifies,
+// where L-BFGS-B itself (direct products: cauchy's p = W'g) and the two-loop oracle stay together to 1e-9 (profiles/r06_fuzz.txt).
+// Without `sg` (GDMIX_TEAM_DIRECT_AB=0 builds of the team kernels) the sums are used, as in rounds 3 - 5.
 
 // History layout of the compact-form kernels: tiles of 64 consecutive coefficients, and inside a tile slot-major:
 //     (s, y) of coefficient j, slot sl  =  ((double2*)W.ws)[((j >> 6) * m + sl) * 64 + (j & 63)]
@@ -70,7 +77,8 @@ struct CompactMats {    // the m x m part (LDS; every workgroup keeps a replica)
 // Called by every thread of a workgroup with identical arguments. Contains one __syncthreads() on the
 // CA_DIRECTION path.
 __device__ __forceinline__ void compact_advance(CompactState& S, const double* acc /* [TEAM_K], registers or LDS */, double f_new,
-                                                const SolveParams& o, CompactMats& L, CompactPlan& plan, bool counted = true) {
+                                                const SolveParams& o, CompactMats& L, CompactPlan& plan, bool counted = true,
+                                                const double* sg = nullptr /* [2 MCAP]: S_i'g, Y_i'g taken directly (chronological), or none */) {
   const int m = o.m;
   counted = counted || S.first;
   S.nfev += counted ? 1 : 0;
@@ -164,19 +172,26 @@ __device__ __forceinline__ void compact_advance(CompactState& S, const double* a
       if (i + 1 < m) { L.ap[i] = pa; L.bp[i] = pb; }
       wave_lds_fence();
     }
-    // s_i'y, y_i'y of row i in chronological order after the shift (y = g - g_k)
-    double sy_i = 0.0, yy_i = 0.0;
+    // s_i'y, y_i'y of row i in chronological order after the shift (y = g - g_k); s_i'g, y_i'g likewise where the caller has them
+    double sy_i = 0.0, yy_i = 0.0, sg_i = 0.0, yg_i = 0.0;
 #pragma unroll
     for (int k = 0; k < TEAM_MCAP; ++k) {
       if (i == k) {
-        if (shift) { if (k + 1 < TEAM_MCAP) { sy_i = acc[5 + (k + 1 < TEAM_MCAP ? k + 1 : k)]; yy_i = acc[5 + TEAM_MCAP + (k + 1 < TEAM_MCAP ? k + 1 : k)]; } }
-        else { sy_i = acc[5 + k]; yy_i = acc[5 + TEAM_MCAP + k]; }
+        if (shift) {
+          if (k + 1 < TEAM_MCAP) {
+            sy_i = acc[5 + (k + 1 < TEAM_MCAP ? k + 1 : k)]; yy_i = acc[5 + TEAM_MCAP + (k + 1 < TEAM_MCAP ? k + 1 : k)];
+            if (sg) { sg_i = sg[k + 1 < TEAM_MCAP ? k + 1 : k]; yg_i = sg[TEAM_MCAP + (k + 1 < TEAM_MCAP ? k + 1 : k)]; }
+          }
+        } else {
+          sy_i = acc[5 + k]; yy_i = acc[5 + TEAM_MCAP + k];
+          if (sg) { sg_i = sg[k]; yg_i = sg[TEAM_MCAP + k]; }
+        }
       }
     }
-    // S'g, Y'g at the new gradient: the stored products at g_k plus the products with y; the new pair in closed form
+    // S'g, Y'g at the new gradient: taken directly, or the stored products at g_k plus the products with y; the new pair in closed form
     const int old_rows = store_pair ? cnew : col;
     double ai = 0.0, bi = 0.0;
-    if (i < old_rows && !restore) { ai = L.ap[i] + sy_i; bi = L.bp[i] + yy_i; }
+    if (i < old_rows && !restore) { ai = sg ? sg_i : L.ap[i] + sy_i; bi = sg ? yg_i : L.bp[i] + yy_i; }
     if (store_pair) {
       if (i < cnew) {
         L.SY[i * TEAM_MCAP + cnew] = sy_i;

@@ -32,7 +32,18 @@ namespace gdmix {
 #define TEAM_PROF(i) do { } while (0)
 #endif
 
-constexpr int TEAM_VEC = 32;                  // doubles per workgroup slot of the device-wide exchange buffer
+// GDMIX_TEAM_DIRECT_AB=1 (round 6, the default): the team kernels take S'g and Y'g directly too (re_lbfgs_compact.hpp: why) — 20 more
+// accumulators in registers and a reduction of 47 values instead of 27. With two tiles per trip at every history length that
+// spilled 152 registers and cost 5 % on a Zipf partition; with one tile per trip from GDMIX_TEAM_DIRECT_ONE_TILE_FROM + 1 pairs on
+// it spills fewer than before (17) and costs 1.7 - 1.9 % (C5 share 700 -> 714 ms, profiles/r06_fuzz.txt). =0: the sums of round 3.
+#ifndef GDMIX_TEAM_DIRECT_AB
+#define GDMIX_TEAM_DIRECT_AB 1
+#endif
+#ifndef GDMIX_TEAM_DIRECT_ONE_TILE_FROM
+#define GDMIX_TEAM_DIRECT_ONE_TILE_FROM 5
+#endif
+constexpr int TEAM_KX = GDMIX_TEAM_DIRECT_AB ? COMPACT_KD : TEAM_K;   // the team's accumulators: [0, TEAM_K - 1) as acc[], then S'g, Y'g (direct only), max|g| LAST
+constexpr int TEAM_VEC = GDMIX_TEAM_DIRECT_AB ? 48 : 32;   // doubles per workgroup slot of the device-wide exchange buffer
 constexpr int TEAM_MAX_BLOCKS = 256;           // workgroups per team
 constexpr int TEAM_MAX_TEAMS = 256;
 constexpr int TEAM_SHORT_COL = 16;            // tiles whose columns are all this short: one lane per column
@@ -423,19 +434,24 @@ __device__ __forceinline__ double team_fg(Team<NW>& tm, const EntityView& P, con
 }
 
 // The products of team_eval over this thread's coefficients, with HC (>= col) history slots requested per coefficient.
-// Two tiles per trip: all 2 x (4 + HC) loads of the trip are in flight before the first product (the passes over the history
-// are bound by how many bytes a CU keeps in flight, not by arithmetic).
+// Two tiles per trip (one for the long histories, below): all 2 x (4 + HC) loads of the trip are in flight before the first product (the
+// passes over the history are bound by how many bytes a CU keeps in flight, not by arithmetic). A wavefront takes its tiles in the
+// same order either way: the sums do not depend on the tiles per trip.
 template <int NW, int HC>
 __device__ __forceinline__ void team_products(const Team<NW>& tm, const Work& W, int p, int m, int col, int head, int first_reg,
-                                              double (&acc)[TEAM_K]) {
+                                              double (&acc)[TEAM_KX]) {
   const double* __restrict__ x = W.x;
-  for (int tile = tm.wid; tile * WAVE < p; tile += 2 * tm.nwaves) {
-    const int jv[2] = {tile * WAVE + tm.lane, (tile + tm.nwaves) * WAVE + tm.lane};
-    const bool ok[2] = {jv[0] < p, jv[1] < p};
-    double xj[2], gj[2], dj[2], rj[2];
-    double2 h[2][HC > 0 ? HC : 1];
+  // (with the direct products the long histories go one tile per trip: their 2 x HC pairs and 4 HC + 7 accumulators do not fit the registers)
+  constexpr int T = (GDMIX_TEAM_DIRECT_AB && HC > GDMIX_TEAM_DIRECT_ONE_TILE_FROM) ? 1 : 2;
+  for (int tile = tm.wid; tile * WAVE < p; tile += T * tm.nwaves) {
+    int jv[T];
+    bool ok[T];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < T; ++u) { jv[u] = (tile + u * tm.nwaves) * WAVE + tm.lane; ok[u] = jv[u] < p; }
+    double xj[T], gj[T], dj[T], rj[T];
+    double2 h[T][HC > 0 ? HC : 1];
+#pragma unroll
+    for (int u = 0; u < T; ++u) {
       const int j = ok[u] ? jv[u] : tm.lane;   // tile 0 always exists: a safe address for the lanes past the end
       xj[u] = x[j]; gj[u] = W.g[j]; dj[u] = W.d[j]; rj[u] = W.r[j];
 #pragma unroll
@@ -447,7 +463,7 @@ __device__ __forceinline__ void team_products(const Team<NW>& tm, const Work& W,
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < T; ++u) {
       if (ok[u]) {
         if (jv[u] >= first_reg) acc[0] += xj[u] * xj[u];
         acc[1] += gj[u] * dj[u];
@@ -456,11 +472,16 @@ __device__ __forceinline__ void team_products(const Team<NW>& tm, const Work& W,
         acc[3] += yj * yj;
         acc[4] += yj * gj[u];
         acc[TEAM_RD] += rj[u] * dj[u];
-        acc[TEAM_K - 1] = fmax(acc[TEAM_K - 1], fabs(gj[u]));
+        acc[TEAM_KX - 1] = fmax(acc[TEAM_KX - 1], fabs(gj[u]));
 #pragma unroll
         for (int i = 0; i < HC; ++i) {
-          acc[5 + i] += (i < col ? h[u][i].x : 0.0) * yj;
-          acc[5 + TEAM_MCAP + i] += (i < col ? h[u][i].y : 0.0) * yj;
+          const double hx = i < col ? h[u][i].x : 0.0, hy = i < col ? h[u][i].y : 0.0;
+          acc[5 + i] += hx * yj;
+          acc[5 + TEAM_MCAP + i] += hy * yj;
+          if (GDMIX_TEAM_DIRECT_AB) {
+            acc[TEAM_K - 1 + i] += hx * gj[u];
+            acc[TEAM_K - 1 + TEAM_MCAP + i] += hy * gj[u];
+          }
         }
       }
     }
@@ -468,10 +489,11 @@ __device__ __forceinline__ void team_products(const Team<NW>& tm, const Work& W,
 }
 
 // f, g and every dot product the driver needs, at W.x, all vectors in HBM. acc[] layout: 0 sum x_j^2 over regularised j,
-// 1 g'd, 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (y = g - r; chronological i < col), K-2 r'd, K-1 max|g_j|.
+// 1 g'd, 2 g'g, 3 y'y, 4 y'g, 5.. S_i'y, 5+MCAP.. Y_i'y (y = g - r; chronological i < col), TEAM_RD r'd, then (direct products)
+// S_i'g, Y_i'g, and max|g_j| last (Team::reduce takes the maximum of its last value).
 template <int NW>
 __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, const SolveParams& o, const Work& W,
-                                            int col, int head, double (&acc)[TEAM_K]
+                                            int col, int head, double (&acc)[TEAM_KX]
 #ifdef GDMIX_TEAM_PROFILE
                                             , unsigned long long (&prof_t)[8], unsigned long long& prof_last
 #endif
@@ -487,7 +509,7 @@ __device__ __forceinline__ double team_eval(Team<NW>& tm, const EntityView& P, c
   // Products with the gradient in a second sweep over the same coefficients (the thread that stored g[j] reads it
   // back: no synchronisation), so that the accumulators and the tile staging above are not live at the same time.
 #pragma unroll
-  for (int k = 0; k < TEAM_K; ++k) acc[k] = 0.0;
+  for (int k = 0; k < TEAM_KX; ++k) acc[k] = 0.0;
   GDMIX_HIST_DISPATCH(col, (team_products<NW, HC>(tm, W, p, m, col, head, first_reg, acc)))
   TEAM_PROF(2);
   tm.reduce(acc);
@@ -532,7 +554,7 @@ __device__ __forceinline__ void team_solve(Team<NW>& tm, const EntityView& P, co
   CompactState S;
   compact_init(S);
   CompactPlan plan;
-  double acc[TEAM_K];
+  double acc[TEAM_KX];
   TEAM_PROF_DECL
   for (int j = tm.tid; j < p; j += tm.NT) { W.d[j] = 0.0; W.r[j] = 0.0; }
   tm.sync();
@@ -547,7 +569,17 @@ __device__ __forceinline__ void team_solve(Team<NW>& tm, const EntityView& P, co
     const double f_new = team_eval(tm, P, o, W, S.col, S.head, acc);
 #endif
     if (tm.aborted()) { ++S.nfev; S.status = GDMIX_RE_ST_ABORTED; break; }
+#if GDMIX_TEAM_DIRECT_AB
+    {
+      double a[TEAM_K];
+#pragma unroll
+      for (int k = 0; k < TEAM_K - 1; ++k) a[k] = acc[k];
+      a[TEAM_K - 1] = acc[TEAM_KX - 1];
+      compact_advance(S, a, f_new, o, L.mats, plan, tm.moved_get(upd), acc + (TEAM_K - 1));
+    }
+#else
     compact_advance(S, acc, f_new, o, L.mats, plan, tm.moved_get(upd));
+#endif
     TEAM_PROF(4);
     if (plan.action == CA_STOP) break;
     if (plan.action == CA_STOP_RESTORE) {

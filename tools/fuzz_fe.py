@@ -12,6 +12,7 @@ import numpy as np
 from gdmix_amd import fixed_effect as fe
 from gdmix_amd.solver import REDeviceSolver
 from oracle import oracle
+import fuzz_fe_case   # tests/fuzz_fe_case.py: the draws
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -27,38 +28,15 @@ bad = 0
 t0 = time.time()
 worst = 0.0
 for case in range(cases):
-    rng = np.random.default_rng(seed0 + case)
-    n = int(rng.choice([50, 3000, 40000, 300000, 700000]))
-    n = int(n * (0.5 + rng.random()))
-    D = int(rng.choice([5, 300, 20000, 150000]))
-    kmax = int(rng.choice([1, 4, 12, 40]))
-    k = rng.integers(0, kmax + 1, n)
-    if rng.random() < 0.3:    # a few very long rows
-        k[rng.integers(0, n, 3)] = rng.integers(3000, 9000, 3)
-    rp = np.concatenate([[0], np.cumsum(k)]).astype(np.int64)
-    Z = int(rp[-1])
-    cols = rng.integers(0, D, Z)
-    if rng.random() < 0.4 and Z:   # dominant columns
-        hot = rng.random(Z) < 0.3
-        cols[hot] = rng.integers(0, min(D, 3), int(hot.sum()))
-    vals = (rng.standard_normal(Z) * float(rng.choice([0.1, 1.0]))).astype(np.float32)
-    linear = bool(rng.random() < 0.35)
-    ic = bool(rng.random() < 0.8)
-    w_true = rng.standard_normal(D) * 0.3
-    z = np.zeros(n)
-    np.add.at(z, np.repeat(np.arange(n), k), vals.astype(np.float64) * w_true[cols])
-    off = (0.2 * rng.standard_normal(n)).astype(np.float32) if rng.random() < 0.7 else None
-    wt = (0.5 + rng.random(n)).astype(np.float32) if rng.random() < 0.5 else None
-    y = (z + 0.1 * rng.standard_normal(n)).astype(np.float32) if linear else (rng.random(n) < 1 / (1 + np.exp(-z))).astype(np.float32)
-    l2 = float(rng.choice([0.1, 1.0, 10.0, 100.0]))
-    regb = bool(rng.random() < 0.5)
-    max_iter = int(rng.choice([3, 30, 200]))
-    m = int(rng.choice([3, 10]))
-    th0 = 0.05 * rng.standard_normal(D + (1 if ic else 0)) if rng.random() < 0.3 else None
-    if th0 is not None:   # the oracle works in the space of the features present in the shard: start the absent ones at 0
-        absent = np.ones(D, bool)
-        absent[cols] = False
-        th0[:D][absent] = 0.0
+    c = fuzz_fe_case.draw(seed0 + case)
+    n, D, Z, rp, cols, vals, y, off, wt = c.n, c.D, c.Z, c.rp, c.cols, c.vals, c.y, c.off, c.wt
+    linear, ic, l2, regb, max_iter, m, th0 = c.linear, c.ic, c.l2, c.regb, c.max_iter, c.m, c.th0
+    for kv in filter(None, os.environ.get("FUZZ_FE_OVERRIDE", "").split(",")):   # one case taken apart: FUZZ_FE_OVERRIDE=m=3,l2=1.0 (after every draw, so the data stay the seed's)
+        key, v = kv.split("=")
+        if key == "m": m = int(v)
+        elif key == "l2": l2 = float(v)
+        elif key == "max_iter": max_iter = int(v)
+        else: raise SystemExit(f"FUZZ_FE_OVERRIDE: unknown key {key}")
     mt = fe.LINEAR_REGRESSION if linear else fe.LOGISTIC_REGRESSION
     kw = dict(offset=off, weight=wt, has_intercept=ic, l2=l2, regularize_bias=regb, model_type=mt, theta0=th0, max_iter=max_iter, m=m)
     th_step, info_step = s.fit_stepping(rp, cols, vals, y, D, **kw)
