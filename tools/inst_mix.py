@@ -33,10 +33,9 @@ for k, v in rows[:16]:
     f32 = sum(w.get(c, 0) for c in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32")) * t / tb
     act = w.get("SQ_ACTIVE_INST_VALU", 0)
     lanes = w.get("SQ_THREAD_CYCLES_VALU", 0) / act if act else float("nan")      # thread-cycles per busy cycle = lanes active, averaged over cycles
-    cyc = w.get("SQ_INST_CYCLES_VALU", 0) / tb if w else float("nan")
     br = w.get("SQ_INSTS_BRANCH", 0) / tb if w else float("nan")
     print(f"{k[-58:]:58s} {na[k]:8d} {t / 1e6:10.1f} {pct(v.get('SQ_INSTS_VALU_FMA_F64', 0)):>6s} {pct(v.get('SQ_INSTS_VALU_ADD_F64', 0)):>6s} "
           f"{pct(v.get('SQ_INSTS_VALU_MUL_F64', 0)):>6s} {pct(v.get('SQ_INSTS_VALU_TRANS_F64', 0)):>7s} {pct(v.get('SQ_INSTS_VALU_INT32', 0)):>6s} "
-          f"{pct(v.get('SQ_INSTS_VALU_INT64', 0)):>6s} {pct(v.get('SQ_INSTS_VALU_CVT', 0)):>5s} {pct(f32):>5s} {pct(t - named - f32):>6s} {lanes:10.2f} {cyc:8.2f} {br:11.3f}")
+          f"{pct(v.get('SQ_INSTS_VALU_INT64', 0)):>6s} {pct(v.get('SQ_INSTS_VALU_CVT', 0)):>5s} {pct(f32):>5s} {pct(t - named - f32):>6s} {lanes:10.2f} {br:11.3f}")
 print("# columns fma64 ... other: percent of the kernel's SQ_INSTS_VALU (wave-level instructions, summed over its launches); 'other' = what no counter names "
       "(v_mov, DPP moves, compares, selects, permlane, readlane ...). lanes/inst = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU.")

@@ -9,8 +9,8 @@ O=gpurun_out/${1:?out}; W=${2:-c2}
 CMD="python bench.py --steps 5 --warmup 2 --workload $W --no-cpu-baseline --no-e2e --no-fe --no-cli --no-other-workloads --no-alone --project-ranks 0"
 rm -rf $O; mkdir -p $O
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT -d $O/a -o a -- $CMD > $O/a.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_BRANCH -d $O/b -o b -- $CMD > $O/b.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_BRANCH -d $O/b -o b -- $CMD > $O/b.log 2>&1
 A=$(ls $O/a/*.db 2>/dev/null | head -1); B=$(ls $O/b/*.db 2>/dev/null | head -1)
 python tools/inst_mix.py $A $B > $O/mix.txt 2> $O/mix.err
-tail -3 $O/a.log $O/b.log | cut -c1-300; cat $O/mix.err | tail -5; cat $O/mix.txt | cut -c1-250
+tail -q -n 2 $O/a.log $O/b.log | cut -c1-300; cat $O/mix.err | tail -5; cat $O/mix.txt | cut -c1-250
 find $O -name "*.db" -delete
