@@ -156,12 +156,32 @@ __device__ __forceinline__ double rcp_nr(double u) {
   return y;
 }
 
+// Horner steps p = fma(p, x, C) with the coefficient in a SCALAR register pair (GDMIX_SGPR_POLY=1; round 6, measured, off). Written plainly,
+// the compiler turns each step into v_fmac_f64 with the coefficient moved into the destination first: two v_mov_b32 per step, 38 vector
+// instructions per sample's logistic terms in kernels whose vector issue is 67 % busy (profiles/r06_inst_mix.txt). With the switch the
+// coefficient goes into vcc by two s_mov_b32 and v_fma_f64 takes it as its one constant-bus operand: same operations on the same numbers, same
+// bits (346 parity tests) — and the same time (C2 8.97 vs 8.95 ms, MovieLens per user 8.42 vs 8.45, same box: profiles/r06_c2_ab.txt, session F).
+// The moves sat in the shadow of the chain's own latency: a Horner step waits for the step before it either way.
+#ifndef GDMIX_SGPR_POLY
+#define GDMIX_SGPR_POLY 0
+#endif
+#define GDMIX_HSTEP(K_) "s_mov_b32 vcc_lo, %[l" #K_ "]\n\ts_mov_b32 vcc_hi, %[h" #K_ "]\n\tv_fma_f64 %[p], %[p], %[x], vcc\n\t"
+#define GDMIX_HCONST(K_, C_) [l##K_] "i"((unsigned)(__builtin_bit_cast(unsigned long long, (double)(C_)) & 0xffffffffull)), \
+                             [h##K_] "i"((unsigned)(__builtin_bit_cast(unsigned long long, (double)(C_)) >> 32))
+
 __device__ __forceinline__ double exp_neg(double a) {   // exp(-a) for a >= 0
   a = fmin(a, 800.0);
   const double kf = __builtin_rint(a * 1.4426950408889634074);
   double r = __builtin_fma(kf, 6.93147180369123816490e-01, -a);
   r = __builtin_fma(kf, 1.90821492927058770002e-10, r);   // r = k ln2 - a, |r| <= ln2/2
   double p = 1.0 / 6227020800.0;
+#if GDMIX_SGPR_POLY
+  asm(GDMIX_HSTEP(0) GDMIX_HSTEP(1) GDMIX_HSTEP(2) GDMIX_HSTEP(3) GDMIX_HSTEP(4) GDMIX_HSTEP(5) GDMIX_HSTEP(6) GDMIX_HSTEP(7) GDMIX_HSTEP(8) GDMIX_HSTEP(9)
+      : [p] "+v"(p)
+      : [x] "v"(r), GDMIX_HCONST(0, 1.0 / 479001600.0), GDMIX_HCONST(1, 1.0 / 39916800.0), GDMIX_HCONST(2, 1.0 / 3628800.0), GDMIX_HCONST(3, 1.0 / 362880.0), GDMIX_HCONST(4, 1.0 / 40320.0), GDMIX_HCONST(5, 1.0 / 5040.0), GDMIX_HCONST(6, 1.0 / 720.0), GDMIX_HCONST(7, 1.0 / 120.0), GDMIX_HCONST(8, 1.0 / 24.0), GDMIX_HCONST(9, 1.0 / 6.0)
+      : "vcc");
+  p = __builtin_fma(p, r, 0.5);
+#else
   p = __builtin_fma(p, r, 1.0 / 479001600.0);
   p = __builtin_fma(p, r, 1.0 / 39916800.0);
   p = __builtin_fma(p, r, 1.0 / 3628800.0);
@@ -173,6 +193,7 @@ __device__ __forceinline__ double exp_neg(double a) {   // exp(-a) for a >= 0
   p = __builtin_fma(p, r, 1.0 / 24.0);
   p = __builtin_fma(p, r, 1.0 / 6.0);
   p = __builtin_fma(p, r, 0.5);
+#endif
   p = __builtin_fma(p, r * r, r) + 1.0;
   return __builtin_amdgcn_ldexp(p, -(int)kf);
 }
@@ -186,6 +207,12 @@ __device__ __forceinline__ double log_1_2(double u) {   // log(u) for u in [1, 2
   const double slo = __builtin_fma(-s, den, num) * y;    // quotient residual, kept as a low part
   const double s2 = s * s;
   double p = 2.0 / 21.0;
+#if GDMIX_SGPR_POLY
+  asm(GDMIX_HSTEP(0) GDMIX_HSTEP(1) GDMIX_HSTEP(2) GDMIX_HSTEP(3) GDMIX_HSTEP(4) GDMIX_HSTEP(5) GDMIX_HSTEP(6) GDMIX_HSTEP(7) GDMIX_HSTEP(8)
+      : [p] "+v"(p)
+      : [x] "v"(s2), GDMIX_HCONST(0, 2.0 / 19.0), GDMIX_HCONST(1, 2.0 / 17.0), GDMIX_HCONST(2, 2.0 / 15.0), GDMIX_HCONST(3, 2.0 / 13.0), GDMIX_HCONST(4, 2.0 / 11.0), GDMIX_HCONST(5, 2.0 / 9.0), GDMIX_HCONST(6, 2.0 / 7.0), GDMIX_HCONST(7, 2.0 / 5.0), GDMIX_HCONST(8, 2.0 / 3.0)
+      : "vcc");
+#else
   p = __builtin_fma(p, s2, 2.0 / 19.0);
   p = __builtin_fma(p, s2, 2.0 / 17.0);
   p = __builtin_fma(p, s2, 2.0 / 15.0);
@@ -195,6 +222,7 @@ __device__ __forceinline__ double log_1_2(double u) {   // log(u) for u in [1, 2
   p = __builtin_fma(p, s2, 2.0 / 7.0);
   p = __builtin_fma(p, s2, 2.0 / 5.0);
   p = __builtin_fma(p, s2, 2.0 / 3.0);
+#endif
   const double lo = __builtin_fma(s * s2, p, (k ? 1.90821492927058770002e-10 : 0.0) + 2.0 * slo);
   const double res = 2.0 * s + lo;
   return k ? res + 6.93147180369123816490e-01 : res;
