@@ -597,7 +597,14 @@ __device__ __forceinline__ void fe_step_body(const FeDev& F, const SolveParams& 
     if (v < COMPACT_KD) {
       double s = 0.0;
       int b = g;
-      for (; b + 28 < dot_blocks; b += 32) {   // eight loads in flight
+      for (; b + 60 < dot_blocks; b += 64) {   // sixteen loads in flight (four groups take the blocks where eight did: the chain is twice as long)
+        double t[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t[q] = ld_x<SC1>(F.acc_part + (size_t)(b + 4 * q) * COMPACT_KD + v);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s = (v == TEAM_K - 1) ? fmax(s, t[q]) : s + t[q];
+      }
+      for (; b + 28 < dot_blocks; b += 32) {   // eight
         double t[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) t[q] = ld_x<SC1>(F.acc_part + (size_t)(b + 4 * q) * COMPACT_KD + v);
