@@ -2,6 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY (see oracle/re_oracle.c header): imported by tests/, by
 __graft_entry__.smoke() and by bench.py's cpu_baseline leg — never by gdmix_amd/.
+Pinned twice: against the fixtures the reference itself produced (tests/test_oracle_golden.py, tests/golden/) and against
+scipy.optimize.fmin_l_bfgs_b run live on seeded problems (tests/test_oracle_scipy.py).
 """
 import ctypes as C
 import os
